@@ -1,0 +1,187 @@
+/*
+ * wfa_hip.h — C ABI of the MI355X-native batched wavefront aligner (libwfa_hip.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of kcleal/pywfa: the calls that
+ * pywfa's Cython host (pywfa/align.pyx) makes into the vendored WFA2-lib, i.e.
+ *
+ *   wavefront_aligner_new(&attributes)                       align.pyx:344,419   wfa.h:125-126
+ *   wavefront_align(aligner, pattern, plen, text, tlen)      align.pyx:439       wfa.h:199-204
+ *   wavefront_align_lambda(...)  (wildcard matching)         align.pyx:441-442   wfa.h:205-210
+ *   wavefront_aligner_delete(aligner)                        align.pyx:881-883   wfa.h:129-130
+ *   reads of aligner->cigar->{score,operations,begin_offset,end_offset}
+ *            aligner->align_status.status                    align.pyx:443,461-467,737-786
+ *   writes to aligner->{alignment_form,alignment_scope,heuristic,penalties,...}
+ *                                                            align.pyx:469-729
+ *
+ * Every entry point below is plain C (pointers + sizes, no torch / HIP types in the
+ * signatures; a stream is passed as an opaque void*).  The reference aligns ONE pair per
+ * call on one CPU thread; the replacement aligns a BATCH of independent pairs per call on
+ * one GPU (one alignment per workgroup), so the batch forms are additive while the config
+ * struct carries exactly the kwargs of WavefrontAligner.__init__ (align.pyx:309-334).
+ *
+ * Error model: the reference calls exit(1) on invalid penalties / ends-free sizes
+ * (wavefront_penalties.c:101-112, wavefront_align.c:95-101).  Here every function returns
+ * WFA_HIP_OK (0) or a negative WFA_HIP_E* code and wfa_hip_last_error() gives the text.
+ * Per-pair results use the reference's own status codes (wfa.h:46-51):
+ *   0 completed, 1 partial (heuristically dropped), -100 max steps reached, -200 OOM.
+ */
+#ifndef WFA_HIP_H_
+#define WFA_HIP_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* distance_metric_t values of the reference (wavefront_penalties.h:42-48) */
+#define WFA_DIST_INDEL     0
+#define WFA_DIST_EDIT      1
+#define WFA_DIST_LINEAR    2
+#define WFA_DIST_AFFINE    3
+#define WFA_DIST_AFFINE2P  4
+
+#define WFA_SCOPE_SCORE    0   /* compute_score      (align.pyx:374-375) */
+#define WFA_SCOPE_FULL     1   /* compute_alignment  (align.pyx:372-373) */
+
+#define WFA_SPAN_END2END   0   /* alignment_end2end  (align.pyx:396-397) */
+#define WFA_SPAN_ENDSFREE  1   /* alignment_endsfree (align.pyx:394-395) */
+
+#define WFA_HEUR_NONE      0   /* wf_heuristic_none        (align.pyx:401-402) */
+#define WFA_HEUR_ADAPTIVE  1   /* wf_heuristic_wfadaptive  (align.pyx:403-407) */
+#define WFA_HEUR_XDROP     2   /* wf_heuristic_xdrop       (align.pyx:408-411) */
+
+#define WFA_MEM_HIGH       0   /* wavefront_memory_high (explicit wavefront history)  */
+#define WFA_MEM_MED        1   /* wavefront_memory_med  (same results as high)        */
+#define WFA_MEM_LOW        2   /* wavefront_memory_low  (same results as high)        */
+#define WFA_MEM_BIWFA      3   /* wavefront_memory_ultralow — not on this path */
+
+/* per-pair status codes, identical to the reference (wfa.h:46-51) */
+#define WFA_STATUS_COMPLETED          0
+#define WFA_STATUS_PARTIAL            1
+#define WFA_STATUS_MAX_STEPS_REACHED  (-100)
+#define WFA_STATUS_OOM                (-200)
+
+/* library return codes */
+#define WFA_HIP_OK            0
+#define WFA_HIP_EINVAL       (-1)   /* invalid configuration / arguments (reference: exit(1)) */
+#define WFA_HIP_ENOTSUP      (-2)   /* configuration outside the accelerated path             */
+#define WFA_HIP_EDEVICE      (-3)   /* HIP runtime error (no GPU, launch failure, OOM)         */
+
+/*
+ * Configuration = kwargs of pywfa.WavefrontAligner.__init__ (align.pyx:309-334), as a POD.
+ * Defaults (wfa_hip_config_default) are pywfa's: affine 0/4/6/2 (24/1), scope full,
+ * span ends-free with all free ends 0, no heuristic, memory high, max_steps unlimited.
+ */
+typedef struct wfa_hip_config {
+  int32_t distance;                /* WFA_DIST_*                                    */
+  int32_t match;                   /* <= 0                                          */
+  int32_t mismatch;                /* > 0                                           */
+  int32_t gap_opening;             /* >= 0                                          */
+  int32_t gap_extension;           /* > 0                                           */
+  int32_t gap_opening2;            /* >= 0 (affine2p)                               */
+  int32_t gap_extension2;          /* > 0  (affine2p)                               */
+  int32_t scope;                   /* WFA_SCOPE_*                                   */
+  int32_t span;                    /* WFA_SPAN_*                                    */
+  int32_t pattern_begin_free;
+  int32_t pattern_end_free;
+  int32_t text_begin_free;
+  int32_t text_end_free;
+  int32_t heuristic;               /* WFA_HEUR_*                                    */
+  int32_t min_wavefront_length;    /* adaptive                                      */
+  int32_t max_distance_threshold;  /* adaptive                                      */
+  int32_t steps_between_cutoffs;   /* adaptive, X-drop                              */
+  int32_t xdrop;                   /* X-drop                                        */
+  int32_t memory_mode;             /* WFA_MEM_*                                     */
+  int32_t max_steps;               /* <= 0: unlimited (align.pyx:415-417)           */
+  int32_t wildcard;                /* -1: none; else the byte that matches anything */
+  int32_t reserved;                /* must be 0                                     */
+} wfa_hip_config_t;
+
+typedef struct wfa_hip_aligner wfa_hip_aligner_t;  /* replaces wavefront_aligner_t*      */
+typedef struct wfa_hip_batch   wfa_hip_batch_t;    /* a batch of pairs resident in HBM   */
+
+/* ---- library / device ------------------------------------------------------------------ */
+
+/* ABI version of this header (bumped on any signature change). */
+int wfa_hip_abi_version(void);
+/* Number of visible HIP devices, or a negative WFA_HIP_E* code. */
+int wfa_hip_device_count(void);
+/* Text for the last error on this thread when no aligner handle exists (create failed). */
+const char* wfa_hip_global_error(void);
+
+/* ---- aligner handle -------------------------------------------------------------------- */
+
+/* Fill *cfg with pywfa's defaults (align.pyx:309-334; wavefront_attributes.c:38-100). */
+int wfa_hip_config_default(wfa_hip_config_t* cfg);
+/* Validate like wavefront_penalties_set_* (wavefront_penalties.c:95-173) but return
+ * WFA_HIP_EINVAL instead of exit(1). err (nullable) receives a message of at most errlen. */
+int wfa_hip_config_validate(const wfa_hip_config_t* cfg, char* err, size_t errlen);
+
+/* Replaces wavefront_aligner_new (wfa.h:125-126). device = HIP device ordinal.
+ * Returns NULL on error (see wfa_hip_global_error). */
+wfa_hip_aligner_t* wfa_hip_create(const wfa_hip_config_t* cfg, int device);
+/* Replaces wavefront_aligner_delete (wfa.h:129-130). */
+void wfa_hip_destroy(wfa_hip_aligner_t* aligner);
+/* Replaces pywfa's property setters that poke C fields after construction
+ * (align.pyx:469-729): swap in a new validated configuration. */
+int wfa_hip_set_config(wfa_hip_aligner_t* aligner, const wfa_hip_config_t* cfg);
+int wfa_hip_get_config(const wfa_hip_aligner_t* aligner, wfa_hip_config_t* cfg);
+const char* wfa_hip_last_error(const wfa_hip_aligner_t* aligner);
+
+/* ---- host-buffer batch alignment (the drop-in for N x wavefront_align) ------------------ */
+
+/*
+ * Align n independent (pattern, text) pairs; synchronous.
+ *   seqs            ASCII bytes, compared raw like the reference (wavefront_sequences.c:250);
+ *                   pair i uses seqs[p_off[i] .. +p_len[i]) and seqs[t_off[i] .. +t_len[i])
+ *   score[i]        what aligner->cigar->score holds after wavefront_align (align.pyx:443)
+ *   status[i]       what aligner->align_status.status holds (align.pyx:461-463)
+ *   cigar_ops       (nullable unless scope=full) caller buffer; pair i owns the region
+ *                   [cigar_off[i], cigar_off[i+1]) which must hold >= p_len[i]+t_len[i] bytes
+ *   cigar_off       n+1 region starts (host-computed prefix sums)
+ *   cigar_begin[i], cigar_len[i]
+ *                   the op string cigar->operations[begin_offset:end_offset) of pair i is
+ *                   cigar_ops[cigar_begin[i] .. +cigar_len[i])  (chars M X I D)
+ * All buffers are borrowed for the call; outputs are caller-owned.
+ */
+int wfa_hip_align_batch(wfa_hip_aligner_t* aligner, int64_t n,
+                        const uint8_t* seqs,
+                        const int64_t* p_off, const int32_t* p_len,
+                        const int64_t* t_off, const int32_t* t_len,
+                        int32_t* score, int32_t* status,
+                        uint8_t* cigar_ops, const int64_t* cigar_off,
+                        int64_t* cigar_begin, int32_t* cigar_len);
+
+/* ---- HBM-resident batches (what bench.py times; inputs resident before the clock starts) -- */
+
+/* Upload n pairs (same input arrays as above) and 2-bit pack them on the device.
+ * The returned batch keeps sequences, per-pair metadata and result arrays in HBM. */
+wfa_hip_batch_t* wfa_hip_batch_create(wfa_hip_aligner_t* aligner, int64_t n,
+                                      const uint8_t* seqs,
+                                      const int64_t* p_off, const int32_t* p_len,
+                                      const int64_t* t_off, const int32_t* t_len);
+void wfa_hip_batch_destroy(wfa_hip_batch_t* batch);
+/* Enqueue the alignment kernels for the whole batch on `stream` (hipStream_t passed as
+ * void*, NULL = the library's own stream) and return without waiting. */
+int wfa_hip_batch_run(wfa_hip_batch_t* batch, void* stream);
+/* Wait for the last run of this batch. */
+int wfa_hip_batch_sync(wfa_hip_batch_t* batch);
+/* Copy results of the last run to host arrays (cigar_* nullable for scope=score). */
+int wfa_hip_batch_results(wfa_hip_batch_t* batch, int32_t* score, int32_t* status,
+                          uint8_t* cigar_ops, const int64_t* cigar_off,
+                          int64_t* cigar_begin, int32_t* cigar_len);
+/* HIP-event time (ms) of the dominant alignment kernel in the last run, and the number of
+ * pairs that kernel processed (for bench.py's roofline line). */
+int wfa_hip_batch_last_kernel_ms(wfa_hip_batch_t* batch, float* ms, int64_t* pairs);
+/* Algorithmic HBM bytes of one run: 2-bit packed sequence bytes + 8 result bytes per pair
+ * (+ CIGAR op bytes for scope=full), SURVEY.md §8(d). */
+int64_t wfa_hip_batch_algorithmic_bytes(const wfa_hip_batch_t* batch);
+/* Pairs the fast (register/LDS) kernel handed to the general kernel in the last run. */
+int64_t wfa_hip_batch_fallback_pairs(const wfa_hip_batch_t* batch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WFA_HIP_H_ */

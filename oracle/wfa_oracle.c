@@ -1,0 +1,678 @@
+/*
+ * oracle/wfa_oracle.c — TEST INFRASTRUCTURE (the parity checker), not product code.
+ *
+ * A plain-C, single-threaded CPU restatement of the algorithm on pywfa's hot path: the
+ * gap-affine / gap-affine-2p wavefront alignment loop of the vendored WFA2-lib v2.3
+ * (R = /root/reference/pywfa/WFA2_lib/wavefront).  It is written from the algorithm's
+ * semantics, with flat arrays and an explicit [lo,hi]+NULL model,
+ * not from WFA2-lib's slab/component structure.  Each function cites the reference
+ * file:line whose behaviour it restates.
+ *
+ * PINNED: oracle/_ref (the real WFA2-lib compiled from /root/reference by oracle/Makefile)
+ * is compared with this file bit-for-bit (status, score, op string) on large random
+ * corpora by tests/test_oracle_vs_ref.py, and both are compared with the committed golden
+ * fixtures in tests/golden/ (the reference's own known answers, tests/test.py) by
+ * tests/test_oracle_golden.py.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call this.
+ * Nothing under pywfa_amd/ links or imports it.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+
+#include "wfa_hip.h"
+
+#define OFFSET_NULL (INT32_MIN / 2) /* R/wavefront_offset.h:44 */
+
+/* internal end reasons (R/wfa.h:52-55) */
+#define END_REACHED 1
+#define END_UNREACHABLE 2
+
+/* one stored wavefront: offsets for k in [base, base+cap), valid range [lo,hi] */
+typedef struct {
+  int exists; /* pointer != NULL in the reference */
+  int lo, hi; /* lo > hi  <=>  ->null flag of the reference */
+  int base;   /* k of element 0 */
+  int64_t idx; /* index of element 0 in the arena */
+} wf_t;
+
+typedef struct {
+  /* penalties after wavefront_penalties_set_* (R/wavefront_penalties.c:95-173) */
+  int match, x, o1, e1, o2, e2;
+  int ncomp; /* 3 affine, 5 affine2p */
+  int scope; /* max_score_scope (R/wavefront_components.c:81-124) */
+  /* history: comp-major tables indexed by score (full) or score % scope (score-only) */
+  wf_t* wf[5]; /* 0=M 1=I1 2=D1 3=I2 4=D2 */
+  int64_t wf_cap;
+  int modular;
+  int32_t* arena;
+  int64_t arena_cap, arena_used;
+  int64_t slot_stride; /* modular: ints per (slot, comp) */
+  /* scratch for heuristics */
+  int32_t* tmp;
+  int64_t tmp_cap;
+} oracle_ws_t;
+
+static void ws_free(oracle_ws_t* ws) {
+  int c;
+  for (c = 0; c < 5; ++c) free(ws->wf[c]);
+  free(ws->arena);
+  free(ws->tmp);
+  memset(ws, 0, sizeof(*ws));
+}
+
+static int ws_reserve_scores(oracle_ws_t* ws, int64_t n) {
+  if (n <= ws->wf_cap) return 0;
+  int64_t cap = ws->wf_cap ? ws->wf_cap : 64;
+  while (cap < n) cap *= 2;
+  int c;
+  for (c = 0; c < 5; ++c) {
+    wf_t* p = (wf_t*)realloc(ws->wf[c], (size_t)cap * sizeof(wf_t));
+    if (!p) return -1;
+    memset(p + ws->wf_cap, 0, (size_t)(cap - ws->wf_cap) * sizeof(wf_t));
+    ws->wf[c] = p;
+  }
+  ws->wf_cap = cap;
+  return 0;
+}
+
+static int ws_reserve_arena(oracle_ws_t* ws, int64_t n) {
+  if (n <= ws->arena_cap) return 0;
+  int64_t cap = ws->arena_cap ? ws->arena_cap : 4096;
+  while (cap < n) cap *= 2;
+  int32_t* p = (int32_t*)realloc(ws->arena, (size_t)cap * sizeof(int32_t));
+  if (!p) return -1;
+  ws->arena = p;
+  ws->arena_cap = cap;
+  return 0;
+}
+
+/* storage for wavefront (comp c, score s) covering k in [lo,hi] */
+static int wf_alloc(oracle_ws_t* ws, int c, int s, int lo, int hi) {
+  const int64_t slot = ws->modular ? (s % ws->scope) : s;
+  wf_t* w = &ws->wf[c][slot];
+  const int64_t n = (int64_t)hi - lo + 1;
+  if (ws->modular) {
+    w->idx = (slot * 5 + c) * ws->slot_stride;
+    if (n > ws->slot_stride) return -1;
+  } else {
+    if (ws_reserve_arena(ws, ws->arena_used + n)) return -1;
+    w->idx = ws->arena_used;
+    ws->arena_used += n;
+  }
+  w->exists = 1;
+  w->lo = lo;
+  w->hi = hi;
+  w->base = lo;
+  return 0;
+}
+
+static inline wf_t* wf_slot(oracle_ws_t* ws, int c, int s) {
+  return &ws->wf[c][ws->modular ? (s % ws->scope) : s];
+}
+
+/* R/wavefront_compute.c:255-297: a wavefront at a negative score, missing, or flagged
+ * null is replaced by the shared null wavefront (lo=1, hi=-1; R/wavefront.c:110-117). */
+typedef struct {
+  int null;
+  int lo, hi;
+  const int32_t* off; /* off[k - base] */
+  int base;
+} wf_in_t;
+
+static wf_in_t wf_fetch(oracle_ws_t* ws, int c, int s) {
+  wf_in_t in;
+  in.null = 1;
+  in.lo = 1;
+  in.hi = -1;
+  in.off = NULL;
+  in.base = 0;
+  if (s < 0) return in;
+  const wf_t* w = wf_slot(ws, c, s);
+  if (!w->exists || w->lo > w->hi) return in;
+  in.null = 0;
+  in.lo = w->lo;
+  in.hi = w->hi;
+  in.off = ws->arena + w->idx;
+  in.base = w->base;
+  return in;
+}
+
+/* Reading outside [lo,hi] yields NULL (lazy padding, R/wavefront_compute.c:490-567). */
+static inline int32_t wf_get(const wf_in_t* in, int k) {
+  return (k >= in->lo && k <= in->hi) ? in->off[k - in->base] : OFFSET_NULL;
+}
+
+#define MAX2(a, b) ((a) > (b) ? (a) : (b))
+#define MIN2(a, b) ((a) < (b) ? (a) : (b))
+
+/* R/wavefront_compute.c:571-605 (wavefront_compute_trim_ends) */
+static void wf_trim(oracle_ws_t* ws, wf_t* w, int plen, int tlen) {
+  const int32_t* off = ws->arena + w->idx;
+  int k;
+  for (k = w->hi; k >= w->lo; --k) {
+    const int32_t o = off[k - w->base];
+    const uint32_t h = (uint32_t)o;
+    const uint32_t v = (uint32_t)(o - k);
+    if (h <= (uint32_t)tlen && v <= (uint32_t)plen) break;
+  }
+  w->hi = k;
+  for (k = w->lo; k <= w->hi; ++k) {
+    const int32_t o = off[k - w->base];
+    const uint32_t h = (uint32_t)o;
+    const uint32_t v = (uint32_t)(o - k);
+    if (h <= (uint32_t)tlen && v <= (uint32_t)plen) break;
+  }
+  w->lo = k;
+}
+
+/*
+ * Compute-next for score s (R/wavefront_compute_affine.c:44-86,229-260;
+ * R/wavefront_compute_affine2p.c:45-106,286-368; limits R/wavefront_compute.c:40-86;
+ * which outputs exist R/wavefront_compute.c:440-485).  Returns 1 for a null step.
+ */
+static int compute_next(oracle_ws_t* ws, int s, int plen, int tlen, int* err) {
+  const int two = (ws->ncomp == 5);
+  wf_in_t mx = wf_fetch(ws, 0, s - ws->x);
+  wf_in_t mo1 = wf_fetch(ws, 0, s - ws->o1 - ws->e1);
+  wf_in_t i1e = wf_fetch(ws, 1, s - ws->e1);
+  wf_in_t d1e = wf_fetch(ws, 2, s - ws->e1);
+  wf_in_t mo2 = wf_fetch(ws, 0, -1), i2e = mo2, d2e = mo2; /* null wavefronts */
+  if (two) {
+    mo2 = wf_fetch(ws, 0, s - ws->o2 - ws->e2);
+    i2e = wf_fetch(ws, 3, s - ws->e2);
+    d2e = wf_fetch(ws, 4, s - ws->e2);
+  }
+  int c;
+  /* the slot is being overwritten (modular) or is fresh (full) */
+  for (c = 0; c < ws->ncomp; ++c) wf_slot(ws, c, s)->exists = 0;
+  if (mx.null && mo1.null && i1e.null && d1e.null && (!two || (mo2.null && i2e.null && d2e.null))) {
+    return 1;
+  }
+  int lo = mx.lo, hi = mx.hi;
+  lo = MIN2(lo, mo1.lo - 1); hi = MAX2(hi, mo1.hi + 1);
+  lo = MIN2(lo, i1e.lo + 1); hi = MAX2(hi, i1e.hi + 1);
+  lo = MIN2(lo, d1e.lo - 1); hi = MAX2(hi, d1e.hi - 1);
+  if (two) {
+    lo = MIN2(lo, mo2.lo - 1); hi = MAX2(hi, mo2.hi + 1);
+    lo = MIN2(lo, i2e.lo + 1); hi = MAX2(hi, i2e.hi + 1);
+    lo = MIN2(lo, d2e.lo - 1); hi = MAX2(hi, d2e.hi - 1);
+  }
+  const int has_i1 = !mo1.null || !i1e.null;
+  const int has_d1 = !mo1.null || !d1e.null;
+  const int has_i2 = two && (!mo2.null || !i2e.null);
+  const int has_d2 = two && (!mo2.null || !d2e.null);
+  /* the reference delegates to the 1-piece kernel when all *2 inputs are null; the values
+   * it would have produced for I2/D2 are then never stored, so the result is identical */
+  if (wf_alloc(ws, 0, s, lo, hi)) { *err = 1; return 0; }
+  if (has_i1 && wf_alloc(ws, 1, s, lo, hi)) { *err = 1; return 0; }
+  if (has_d1 && wf_alloc(ws, 2, s, lo, hi)) { *err = 1; return 0; }
+  if (has_i2 && wf_alloc(ws, 3, s, lo, hi)) { *err = 1; return 0; }
+  if (has_d2 && wf_alloc(ws, 4, s, lo, hi)) { *err = 1; return 0; }
+  /* arena may have moved: re-fetch input pointers */
+  mx = wf_fetch(ws, 0, s - ws->x);
+  mo1 = wf_fetch(ws, 0, s - ws->o1 - ws->e1);
+  i1e = wf_fetch(ws, 1, s - ws->e1);
+  d1e = wf_fetch(ws, 2, s - ws->e1);
+  if (two) {
+    mo2 = wf_fetch(ws, 0, s - ws->o2 - ws->e2);
+    i2e = wf_fetch(ws, 3, s - ws->e2);
+    d2e = wf_fetch(ws, 4, s - ws->e2);
+  }
+  int32_t* om = ws->arena + wf_slot(ws, 0, s)->idx;
+  int32_t* oi1 = has_i1 ? ws->arena + wf_slot(ws, 1, s)->idx : NULL;
+  int32_t* od1 = has_d1 ? ws->arena + wf_slot(ws, 2, s)->idx : NULL;
+  int32_t* oi2 = has_i2 ? ws->arena + wf_slot(ws, 3, s)->idx : NULL;
+  int32_t* od2 = has_d2 ? ws->arena + wf_slot(ws, 4, s)->idx : NULL;
+  int k;
+  for (k = lo; k <= hi; ++k) {
+    const int32_t ins1 = MAX2(wf_get(&mo1, k - 1), wf_get(&i1e, k - 1)) + 1;
+    const int32_t del1 = MAX2(wf_get(&mo1, k + 1), wf_get(&d1e, k + 1));
+    int32_t ins = ins1, del = del1;
+    if (oi1) oi1[k - lo] = ins1;
+    if (od1) od1[k - lo] = del1;
+    if (two) {
+      const int32_t ins2 = MAX2(wf_get(&mo2, k - 1), wf_get(&i2e, k - 1)) + 1;
+      const int32_t del2 = MAX2(wf_get(&mo2, k + 1), wf_get(&d2e, k + 1));
+      if (oi2) oi2[k - lo] = ins2;
+      if (od2) od2[k - lo] = del2;
+      ins = MAX2(ins1, ins2);
+      del = MAX2(del1, del2);
+    }
+    const int32_t misms = wf_get(&mx, k) + 1;
+    int32_t mv = MAX2(del, MAX2(misms, ins));
+    /* only M is clamped (R/wavefront_compute_affine.c:80-84) */
+    const uint32_t h = (uint32_t)mv;
+    const uint32_t v = (uint32_t)(mv - k);
+    if (h > (uint32_t)tlen) mv = OFFSET_NULL;
+    if (v > (uint32_t)plen) mv = OFFSET_NULL;
+    om[k - lo] = mv;
+  }
+  for (c = 0; c < ws->ncomp; ++c) {
+    wf_t* w = wf_slot(ws, c, s);
+    if (w->exists) wf_trim(ws, w, plen, tlen);
+  }
+  return 0;
+}
+
+typedef struct {
+  int steps_wait;
+  int have_max_sw; /* max_sw_score_k != DPMATRIX_DIAGONAL_NULL */
+  int max_sw;
+} heur_t;
+
+/* R/wavefront_heuristic.c:161-172 (wf_heuristic_equate) */
+static void heur_equate(wf_t* dst, const wf_t* src) {
+  if (!dst->exists) return;
+  if (src->lo > dst->lo) dst->lo = src->lo;
+  if (src->hi < dst->hi) dst->hi = src->hi;
+}
+
+/*
+ * Heuristic cut-off after extend (R/wavefront_heuristic.c:509-567), with wf-adaptive
+ * (:176-192,232-293) and X-drop (:297-383).
+ */
+static int heur_cutoff(oracle_ws_t* ws, const wfa_hip_config_t* cfg, heur_t* hs, int s,
+                       int plen, int tlen) {
+  wf_t* m = wf_slot(ws, 0, s);
+  if (!m->exists || m->lo > m->hi) return 0;
+  --hs->steps_wait;
+  const int lo_base = m->lo, hi_base = m->hi;
+  const int32_t* off = ws->arena + m->idx;
+  if (cfg->heuristic == WFA_HEUR_ADAPTIVE) {
+    if (hs->steps_wait <= 0 && (hi_base - lo_base + 1) >= cfg->min_wavefront_length) {
+      const int64_t n = (int64_t)hi_base - lo_base + 1;
+      if (n > ws->tmp_cap) {
+        free(ws->tmp);
+        ws->tmp = (int32_t*)malloc((size_t)n * 2 * sizeof(int32_t));
+        if (!ws->tmp) return -1;
+        ws->tmp_cap = n * 2;
+      }
+      int32_t* dist = ws->tmp;
+      int k, min_d = MAX2(plen, tlen);
+      for (k = lo_base; k <= hi_base; ++k) {
+        const int32_t o = off[k - m->base];
+        const int left_v = plen - (o - k);
+        const int left_h = tlen - o;
+        const int d = (o >= 0) ? MAX2(left_v, left_h) : -OFFSET_NULL;
+        dist[k - lo_base] = d;
+        min_d = MIN2(min_d, d);
+      }
+      const int thr = cfg->max_distance_threshold;
+      const int ak = tlen - plen;
+      const int top_limit = MIN2(ak, m->hi);
+      int lo_red = m->lo;
+      for (k = m->lo; k < top_limit; ++k) {
+        if (dist[k - lo_base] - min_d <= thr) break;
+        ++lo_red;
+      }
+      m->lo = lo_red;
+      const int bottom_limit = MAX2(ak, m->lo);
+      int hi_red = m->hi;
+      for (k = m->hi; k > bottom_limit; --k) {
+        if (dist[k - lo_base] - min_d <= thr) break;
+        --hi_red;
+      }
+      m->hi = hi_red;
+      hs->steps_wait = cfg->steps_between_cutoffs;
+    }
+  } else if (cfg->heuristic == WFA_HEUR_XDROP) {
+    if (hs->steps_wait <= 0) {
+      const int g = (ws->match != 0) ? -ws->match : -1; /* R/wavefront_heuristic.c:306-307 */
+      int k, cmax = INT_MIN;
+      const int64_t n = (int64_t)hi_base - lo_base + 1;
+      if (n > ws->tmp_cap) {
+        free(ws->tmp);
+        ws->tmp = (int32_t*)malloc((size_t)n * 2 * sizeof(int32_t));
+        if (!ws->tmp) return -1;
+        ws->tmp_cap = n * 2;
+      }
+      int32_t* sw = ws->tmp;
+      for (k = lo_base; k <= hi_base; ++k) {
+        const int32_t o = off[k - m->base];
+        if (o < 0) continue;
+        const int v = o - k, h = o;
+        const int sc = (g * (v + h) - s) / 2; /* C truncating division */
+        sw[k - lo_base] = sc;
+        if (cmax < sc) cmax = sc;
+      }
+      if (hs->have_max_sw) {
+        const int max_sw = hs->max_sw;
+        for (k = m->lo; k <= m->hi; ++k) {
+          if (off[k - m->base] < 0) continue;
+          if (max_sw - sw[k - lo_base] < cfg->xdrop) break;
+        }
+        m->lo = k;
+        for (k = m->hi; k >= m->lo; --k) {
+          if (off[k - m->base] < 0) continue;
+          if (max_sw - sw[k - lo_base] < cfg->xdrop) break;
+        }
+        m->hi = k;
+        if (cmax > hs->max_sw) hs->max_sw = cmax;
+      } else {
+        hs->max_sw = cmax;
+        hs->have_max_sw = 1;
+      }
+      hs->steps_wait = cfg->steps_between_cutoffs;
+    }
+  }
+  if (lo_base == m->lo && hi_base == m->hi) return 0;
+  int c;
+  for (c = 1; c < ws->ncomp; ++c) heur_equate(wf_slot(ws, c, s), m);
+  return 0;
+}
+
+/* candidate readers of the backtrace (R/wavefront_backtrace.c:64-219): value only if the
+ * stored wavefront exists and k lies in its stored [lo,hi]; (offset<<4)|type otherwise NULL */
+static inline int64_t bt_cand(oracle_ws_t* ws, int c, int s, int k, int add, int type) {
+  if (s < 0) return OFFSET_NULL;
+  const wf_t* w = wf_slot(ws, c, s);
+  if (!w->exists || k < w->lo || k > w->hi) return OFFSET_NULL;
+  const int32_t o = ws->arena[w->idx + (k - w->base)];
+  return (((int64_t)(o + add)) << 4) | type;
+}
+
+typedef struct {
+  uint8_t* buf; /* written right-to-left */
+  int64_t begin; /* index of the first valid op */
+  int64_t end;
+} ops_t;
+
+static inline void ops_push(ops_t* ops, char c, int n) {
+  while (n-- > 0) ops->buf[--ops->begin] = (uint8_t)c;
+}
+
+/* R/wavefront_backtrace.c:320-529 (wavefront_backtrace_affine), M→M components */
+static void backtrace(oracle_ws_t* ws, int plen, int tlen, int end_s, int end_k, int32_t end_off,
+                      ops_t* ops) {
+  enum { BT_I1_OPEN = 1, BT_I1_EXT, BT_I2_OPEN, BT_I2_EXT, BT_D1_OPEN, BT_D1_EXT, BT_D2_OPEN,
+         BT_D2_EXT, BT_M };
+  const int two = (ws->ncomp == 5);
+  int comp = 0; /* 0=M 1=I1 2=D1 3=I2 4=D2 */
+  int s = end_s, k = end_k;
+  int32_t offset = end_off;
+  int h = offset, v = offset - k;
+  if (v < plen) ops_push(ops, 'D', plen - v);
+  if (h < tlen) ops_push(ops, 'I', tlen - h);
+  while (v > 0 && h > 0 && s > 0) {
+    const int s_x = s - ws->x;
+    const int s_o1 = s - ws->o1 - ws->e1, s_e1 = s - ws->e1;
+    const int s_o2 = s - ws->o2 - ws->e2, s_e2 = s - ws->e2;
+    int64_t best;
+    if (comp == 0) {
+      best = bt_cand(ws, 0, s_x, k, 1, BT_M);
+      best = MAX2(best, bt_cand(ws, 0, s_o1, k - 1, 1, BT_I1_OPEN));
+      best = MAX2(best, bt_cand(ws, 1, s_e1, k - 1, 1, BT_I1_EXT));
+      best = MAX2(best, bt_cand(ws, 0, s_o1, k + 1, 0, BT_D1_OPEN));
+      best = MAX2(best, bt_cand(ws, 2, s_e1, k + 1, 0, BT_D1_EXT));
+      if (two) {
+        best = MAX2(best, bt_cand(ws, 0, s_o2, k - 1, 1, BT_I2_OPEN));
+        best = MAX2(best, bt_cand(ws, 3, s_e2, k - 1, 1, BT_I2_EXT));
+        best = MAX2(best, bt_cand(ws, 0, s_o2, k + 1, 0, BT_D2_OPEN));
+        best = MAX2(best, bt_cand(ws, 4, s_e2, k + 1, 0, BT_D2_EXT));
+      }
+    } else if (comp == 1) {
+      best = MAX2(bt_cand(ws, 0, s_o1, k - 1, 1, BT_I1_OPEN), bt_cand(ws, 1, s_e1, k - 1, 1, BT_I1_EXT));
+    } else if (comp == 3) {
+      best = MAX2(bt_cand(ws, 0, s_o2, k - 1, 1, BT_I2_OPEN), bt_cand(ws, 3, s_e2, k - 1, 1, BT_I2_EXT));
+    } else if (comp == 2) {
+      best = MAX2(bt_cand(ws, 0, s_o1, k + 1, 0, BT_D1_OPEN), bt_cand(ws, 2, s_e1, k + 1, 0, BT_D1_EXT));
+    } else {
+      best = MAX2(bt_cand(ws, 0, s_o2, k + 1, 0, BT_D2_OPEN), bt_cand(ws, 4, s_e2, k + 1, 0, BT_D2_EXT));
+    }
+    if (best < 0) break;
+    if (comp == 0) {
+      const int32_t src = (int32_t)(best >> 4);
+      ops_push(ops, 'M', offset - src);
+      offset = src;
+      v = offset - k;
+      h = offset;
+      if (v <= 0 || h <= 0) break;
+    }
+    const int type = (int)(best & 0xF);
+    switch (type) {
+      case BT_M: s = s_x; comp = 0; break;
+      case BT_I1_OPEN: s = s_o1; comp = 0; break;
+      case BT_I1_EXT: s = s_e1; comp = 1; break;
+      case BT_I2_OPEN: s = s_o2; comp = 0; break;
+      case BT_I2_EXT: s = s_e2; comp = 3; break;
+      case BT_D1_OPEN: s = s_o1; comp = 0; break;
+      case BT_D1_EXT: s = s_e1; comp = 2; break;
+      case BT_D2_OPEN: s = s_o2; comp = 0; break;
+      default: s = s_e2; comp = 4; break;
+    }
+    if (type == BT_M) {
+      ops_push(ops, 'X', 1);
+      --offset;
+    } else if (type <= BT_I2_EXT) {
+      ops_push(ops, 'I', 1);
+      --k;
+      --offset;
+    } else {
+      ops_push(ops, 'D', 1);
+      ++k;
+    }
+    v = offset - k;
+    h = offset;
+  }
+  if (comp == 0) {
+    if (v > 0 && h > 0) {
+      const int n = MIN2(v, h);
+      ops_push(ops, 'M', n);
+      v -= n;
+      h -= n;
+    }
+    ops_push(ops, 'D', v > 0 ? v : 0);
+    ops_push(ops, 'I', h > 0 ? h : 0);
+  }
+}
+
+/* R/wavefront_compute.c:108-120 + R/wavefront_penalties.h:73 */
+static int classic_score(const oracle_ws_t* ws, int v, int h, int s) {
+  if (ws->match == 0) return -s;
+  return ((-ws->match) * (v + h) - s) / 2;
+}
+
+/*
+ * One alignment (R/wavefront_align.c:212-240 → R/wavefront_unialign.c:54-94,241-273,147-237).
+ * ops (nullable) must hold plen+tlen bytes; the op string ends at ops+plen+tlen and starts
+ * at *ops_begin.  Returns 0, or -1 when out of memory.
+ */
+static int align_one(oracle_ws_t* ws, const wfa_hip_config_t* cfg, const uint8_t* P, int plen,
+                     const uint8_t* T, int tlen, int32_t* out_score, int32_t* out_status,
+                     uint8_t* ops_buf, int64_t* ops_begin, int32_t* ops_len) {
+  const int endsfree = (cfg->span == WFA_SPAN_ENDSFREE);
+  const int full = (cfg->scope == WFA_SCOPE_FULL);
+  /* Q13: free begins are only initialised for ends-free spans */
+  const int pbf = (endsfree && ws->match == 0) ? cfg->pattern_begin_free : 0;
+  const int tbf = (endsfree && ws->match == 0) ? cfg->text_begin_free : 0;
+  const int64_t max_steps = (cfg->max_steps <= 0) ? INT_MAX : cfg->max_steps;
+  const int wc = cfg->wildcard;
+  int err = 0;
+  ws->modular = !full;
+  ws->arena_used = 0;
+  if (ws->modular) {
+    ws->slot_stride = (int64_t)plen + tlen + 8;
+    if (ws_reserve_scores(ws, ws->scope)) return -1;
+    if (ws_reserve_arena(ws, ws->slot_stride * 5 * ws->scope)) return -1;
+    int c, i;
+    for (c = 0; c < 5; ++c) for (i = 0; i < ws->scope; ++i) ws->wf[c][i].exists = 0;
+  } else {
+    if (ws_reserve_scores(ws, 64)) return -1;
+  }
+  *ops_len = 0;
+  if (ops_begin) *ops_begin = 0;
+  /* wavefront 0 (R/wavefront_aligner.c:251-310) */
+  if (wf_alloc(ws, 0, 0, -pbf, tbf)) return -1;
+  {
+    int32_t* o = ws->arena + ws->wf[0][0].idx;
+    int k;
+    for (k = -pbf; k <= tbf; ++k) o[k + pbf] = (k > 0) ? k : 0;
+    int c;
+    for (c = 1; c < 5; ++c) ws->wf[c][0].exists = 0;
+  }
+  heur_t hs;
+  hs.steps_wait = cfg->steps_between_cutoffs; /* R/wavefront_heuristic.c:114-121 */
+  hs.have_max_sw = 0;
+  hs.max_sw = 0;
+  int null_steps = 0;
+  int s = 0;
+  int end_reason = 0, end_k = 0;
+  int32_t end_off = OFFSET_NULL;
+  for (;;) {
+    /* ---- extend + termination + cut-off (R/wavefront_extend.c:90-125,263-297) ---- */
+    wf_t* m = wf_slot(ws, 0, s);
+    if (!m->exists) {
+      if (null_steps > ws->scope) { end_reason = END_UNREACHABLE; break; }
+    } else {
+      int32_t* off = ws->arena + m->idx;
+      int k;
+      for (k = m->lo; k <= m->hi; ++k) {
+        int32_t o = off[k - m->base];
+        if (o == OFFSET_NULL) continue;
+        int v = o - k, h = o;
+        /* R/wavefront_extend_kernels.c:64-88: byte-equal run, stopped by the sentinels */
+        if (wc < 0) {
+          while (v < plen && h < tlen && P[v] == T[h]) { ++v; ++h; }
+        } else {
+          while (v < plen && h < tlen && (P[v] == T[h] || P[v] == wc || T[h] == wc)) { ++v; ++h; }
+        }
+        o = h;
+        off[k - m->base] = o;
+        if (endsfree) {
+          /* R/wavefront_termination.c:115-162, tested after each k in ascending order */
+          if ((h >= tlen && plen - v <= cfg->pattern_end_free) ||
+              (v >= plen && tlen - h <= cfg->text_end_free)) {
+            end_reason = END_REACHED; end_k = k; end_off = o;
+            break;
+          }
+        }
+      }
+      if (!endsfree) {
+        /* R/wavefront_termination.c:37-61 */
+        const int ak = tlen - plen;
+        if (m->lo <= ak && ak <= m->hi && off[ak - m->base] >= tlen) {
+          end_reason = END_REACHED; end_k = ak; end_off = tlen;
+        }
+      }
+      if (end_reason) break;
+      if (cfg->heuristic != WFA_HEUR_NONE) {
+        if (heur_cutoff(ws, cfg, &hs, s, plen, tlen)) return -1;
+      }
+    }
+    /* ---- next score (R/wavefront_unialign.c:262-265) ---- */
+    ++s;
+    if (!ws->modular && ws_reserve_scores(ws, (int64_t)s + 1)) return -1;
+    if (compute_next(ws, s, plen, tlen, &err)) ++null_steps; else null_steps = 0;
+    if (err) return -1;
+    if (s >= max_steps) {
+      /* R/wavefront_unialign.c:102-107 */
+      *out_status = WFA_STATUS_MAX_STEPS_REACHED;
+      *out_score = (int32_t)(-max_steps);
+      return 0;
+    }
+  }
+  /* ---- finish (R/wavefront_unialign.c:147-237) ---- */
+  if (!full) {
+    if (end_reason == END_REACHED) {
+      *out_score = classic_score(ws, plen, tlen, s);
+      *out_status = WFA_STATUS_COMPLETED;
+    } else {
+      /* the reference evaluates the score at its (unset) end position; with match==0 that
+       * is -s; with match<0 it is computed from k=INT_MAX, offset=NULL (wrapping) */
+      const int32_t k = INT_MAX;
+      const int32_t ev = (int32_t)((uint32_t)OFFSET_NULL - (uint32_t)k);
+      *out_score = (ws->match == 0) ? -s : (int32_t)(((int64_t)(-ws->match) * ((int64_t)ev + OFFSET_NULL) - s) / 2);
+      *out_status = WFA_STATUS_PARTIAL;
+    }
+    return 0;
+  }
+  if (end_reason == END_REACHED) {
+    ops_t ops;
+    ops.buf = ops_buf;
+    ops.end = (int64_t)plen + tlen;
+    ops.begin = ops.end;
+    backtrace(ws, plen, tlen, s, end_k, end_off, &ops);
+    *ops_begin = ops.begin;
+    *ops_len = (int32_t)(ops.end - ops.begin);
+    *out_score = classic_score(ws, end_off - end_k, end_off, s);
+    *out_status = WFA_STATUS_COMPLETED;
+  } else {
+    /* no backtrace; maxtrim of the empty CIGAR clears it (R/alignment/cigar.c:473-613) */
+    *out_score = INT32_MIN;
+    *out_status = WFA_STATUS_PARTIAL;
+  }
+  return 0;
+}
+
+/* R/wavefront_penalties.c:95-173 */
+static int ws_set_penalties(oracle_ws_t* ws, const wfa_hip_config_t* cfg) {
+  if (cfg->distance != WFA_DIST_AFFINE && cfg->distance != WFA_DIST_AFFINE2P) return -1;
+  const int two = (cfg->distance == WFA_DIST_AFFINE2P);
+  if (cfg->match > 0 || cfg->mismatch <= 0 || cfg->gap_opening < 0 || cfg->gap_extension <= 0) return -1;
+  if (two && (cfg->gap_opening2 < 0 || cfg->gap_extension2 <= 0)) return -1;
+  ws->ncomp = two ? 5 : 3;
+  if (cfg->match < 0) {
+    ws->match = cfg->match;
+    ws->x = 2 * cfg->mismatch - 2 * cfg->match;
+    ws->o1 = 2 * cfg->gap_opening;
+    ws->e1 = 2 * cfg->gap_extension - cfg->match;
+    ws->o2 = 2 * cfg->gap_opening2;
+    ws->e2 = 2 * cfg->gap_extension2 - cfg->match;
+  } else {
+    ws->match = 0;
+    ws->x = cfg->mismatch;
+    ws->o1 = cfg->gap_opening;
+    ws->e1 = cfg->gap_extension;
+    ws->o2 = cfg->gap_opening2;
+    ws->e2 = cfg->gap_extension2;
+  }
+  /* R/wavefront_components.c:81-124 */
+  int scope_indel = ws->o1 + ws->e1;
+  if (two && ws->o2 + ws->e2 > scope_indel) scope_indel = ws->o2 + ws->e2;
+  ws->scope = MAX2(scope_indel, ws->x) + 1;
+  return 0;
+}
+
+/*
+ * Public entry: same argument list as wfa_hip_align_batch minus the handle.
+ * Returns 0; -1 invalid/unsupported configuration; -2 out of memory.
+ */
+int wfa_oracle_align_batch(const wfa_hip_config_t* cfg, int64_t n, const uint8_t* seqs,
+                           const int64_t* p_off, const int32_t* p_len,
+                           const int64_t* t_off, const int32_t* t_len,
+                           int32_t* score, int32_t* status,
+                           uint8_t* cigar_ops, const int64_t* cigar_off,
+                           int64_t* cigar_begin, int32_t* cigar_len) {
+  oracle_ws_t ws;
+  memset(&ws, 0, sizeof(ws));
+  if (ws_set_penalties(&ws, cfg)) return -1;
+  /* match<0 with free begins needs the ends-free re-seeding of R/wavefront_compute.c:124-254
+   * ("next"): not restated here */
+  if (cfg->match < 0 && cfg->span == WFA_SPAN_ENDSFREE &&
+      (cfg->pattern_begin_free > 0 || cfg->text_begin_free > 0)) return -1;
+  if (cfg->memory_mode == WFA_MEM_BIWFA) return -1;
+  const int full = (cfg->scope == WFA_SCOPE_FULL);
+  if (full && (!cigar_ops || !cigar_off || !cigar_begin || !cigar_len)) return -1;
+  int64_t i;
+  int rc = 0;
+  for (i = 0; i < n; ++i) {
+    const int plen = p_len[i], tlen = t_len[i];
+    if (cfg->span == WFA_SPAN_ENDSFREE &&
+        (cfg->pattern_begin_free > plen || cfg->pattern_end_free > plen ||
+         cfg->text_begin_free > tlen || cfg->text_end_free > tlen)) { rc = -1; break; }
+    int64_t ob = 0;
+    int32_t ol = 0;
+    int32_t sc = 0, st = 0;
+    if (align_one(&ws, cfg, seqs + p_off[i], plen, seqs + t_off[i], tlen, &sc, &st,
+                  full ? cigar_ops + cigar_off[i] : NULL, &ob, &ol)) { rc = -2; break; }
+    score[i] = sc;
+    status[i] = st;
+    if (cigar_begin) cigar_begin[i] = (full && cigar_off) ? cigar_off[i] + ob : 0;
+    if (cigar_len) cigar_len[i] = ol;
+  }
+  ws_free(&ws);
+  return rc;
+}
