@@ -1,0 +1,275 @@
+"""ctypes binding of libwfa_hip.so (the C ABI declared in include/wfa_hip.h).
+
+This is the reference-side binding a pywfa maintainer would add instead of ``WFA_wrap.pxd``
+(INTEGRATION.md shows the Cython form).  There is NO CPU fallback: if the library cannot be loaded,
+or no HIP device is present, every alignment entry point raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwfa_hip.so")
+
+ABI_VERSION = 1
+
+OK, EINVAL, ENOTSUP, EDEVICE = 0, -1, -2, -3
+
+DIST = {"indel": 0, "levenshtein": 1, "linear": 2, "affine": 3, "affine2p": 4}
+DIST_NAMES = {v: k for k, v in DIST.items()}
+SCOPE = {"score": 0, "full": 1}
+SPAN = {"end-to-end": 0, "ends-free": 1}
+HEUR = {None: 0, "adaptive": 1, "X-drop": 2}
+HEUR_NAMES = {v: k for k, v in HEUR.items()}
+MEM = {"high": 0, "medium": 1, "low": 2, "biwfa": 3}
+MEM_NAMES = {v: k for k, v in MEM.items()}
+
+
+class Config(ctypes.Structure):
+    """wfa_hip_config_t"""
+
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "distance", "match", "mismatch", "gap_opening", "gap_extension", "gap_opening2",
+        "gap_extension2", "scope", "span", "pattern_begin_free", "pattern_end_free",
+        "text_begin_free", "text_end_free", "heuristic", "min_wavefront_length",
+        "max_distance_threshold", "steps_between_cutoffs", "xdrop", "memory_mode", "max_steps",
+        "wildcard", "reserved")]
+
+    def copy(self):
+        c = Config()
+        ctypes.memmove(ctypes.byref(c), ctypes.byref(self), ctypes.sizeof(Config))
+        return c
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# every symbol include/wfa_hip.h declares (tests/test_abi.py checks the library exports them all)
+SYMBOLS = [
+    "wfa_hip_abi_version", "wfa_hip_device_count", "wfa_hip_global_error", "wfa_hip_config_default",
+    "wfa_hip_config_validate", "wfa_hip_create", "wfa_hip_destroy", "wfa_hip_set_config",
+    "wfa_hip_get_config", "wfa_hip_last_error", "wfa_hip_align_batch", "wfa_hip_batch_create",
+    "wfa_hip_batch_destroy", "wfa_hip_batch_run", "wfa_hip_batch_sync", "wfa_hip_batch_results",
+    "wfa_hip_batch_last_kernel_ms", "wfa_hip_batch_algorithmic_bytes", "wfa_hip_batch_fallback_pairs",
+]
+
+
+def lib():
+    """Load libwfa_hip.so (built in-tree by ``__graft_entry__.build()`` / csrc/build.sh)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(f"{LIB_PATH} is missing: build it with pywfa_amd/csrc/build.sh "
+                          "(there is no CPU fallback)")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    cfgp = ctypes.POINTER(Config)
+    L.wfa_hip_abi_version.restype = ctypes.c_int
+    L.wfa_hip_device_count.restype = ctypes.c_int
+    L.wfa_hip_global_error.restype = ctypes.c_char_p
+    L.wfa_hip_config_default.argtypes = [cfgp]
+    L.wfa_hip_config_validate.argtypes = [cfgp, ctypes.c_char_p, ctypes.c_size_t]
+    L.wfa_hip_create.argtypes = [cfgp, ctypes.c_int]
+    L.wfa_hip_create.restype = vp
+    L.wfa_hip_destroy.argtypes = [vp]
+    L.wfa_hip_destroy.restype = None
+    L.wfa_hip_set_config.argtypes = [vp, cfgp]
+    L.wfa_hip_get_config.argtypes = [vp, cfgp]
+    L.wfa_hip_last_error.argtypes = [vp]
+    L.wfa_hip_last_error.restype = ctypes.c_char_p
+    L.wfa_hip_align_batch.argtypes = [vp, i64] + [vp] * 11
+    L.wfa_hip_batch_create.argtypes = [vp, i64] + [vp] * 5
+    L.wfa_hip_batch_create.restype = vp
+    L.wfa_hip_batch_destroy.argtypes = [vp]
+    L.wfa_hip_batch_destroy.restype = None
+    L.wfa_hip_batch_run.argtypes = [vp, vp]
+    L.wfa_hip_batch_sync.argtypes = [vp]
+    L.wfa_hip_batch_results.argtypes = [vp] * 7
+    L.wfa_hip_batch_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(i64)]
+    L.wfa_hip_batch_algorithmic_bytes.argtypes = [vp]
+    L.wfa_hip_batch_algorithmic_bytes.restype = i64
+    L.wfa_hip_batch_fallback_pairs.argtypes = [vp]
+    L.wfa_hip_batch_fallback_pairs.restype = i64
+    if L.wfa_hip_abi_version() != ABI_VERSION:
+        raise NativeError("libwfa_hip.so ABI version mismatch: rebuild it")
+    _lib = L
+    return L
+
+
+def default_config():
+    c = Config()
+    lib().wfa_hip_config_default(ctypes.byref(c))
+    return c
+
+
+def validate(cfg):
+    """Return (code, message)."""
+    buf = ctypes.create_string_buffer(256)
+    rc = lib().wfa_hip_config_validate(ctypes.byref(cfg), buf, 256)
+    return rc, buf.value.decode()
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _check_batch(batch):
+    seqs = np.ascontiguousarray(batch["seqs"], dtype=np.uint8)
+    p_off = np.ascontiguousarray(batch["p_off"], dtype=np.int64)
+    t_off = np.ascontiguousarray(batch["t_off"], dtype=np.int64)
+    p_len = np.ascontiguousarray(batch["p_len"], dtype=np.int32)
+    t_len = np.ascontiguousarray(batch["t_len"], dtype=np.int32)
+    n = p_len.shape[0]
+    if not (p_off.shape[0] == t_off.shape[0] == t_len.shape[0] == n):
+        raise ValueError("batch arrays differ in length")
+    if n:
+        if int((p_off + p_len).max()) > seqs.size or int((t_off + t_len).max()) > seqs.size:
+            raise ValueError("sequence offsets run past the blob")
+    return seqs, p_off, p_len, t_off, t_len, n
+
+
+class Aligner:
+    """Owns one wfa_hip_aligner_t (replaces the wavefront_aligner_t* of align.pyx:419)."""
+
+    def __init__(self, cfg, device=0):
+        L = lib()
+        self._h = L.wfa_hip_create(ctypes.byref(cfg), device)
+        if not self._h:
+            msg = L.wfa_hip_global_error().decode()
+            rc, vmsg = validate(cfg)
+            if rc == EINVAL:
+                raise ValueError(vmsg)
+            if rc == ENOTSUP:
+                raise NotImplementedError(vmsg)
+            raise NativeError(f"wfa_hip_create failed: {msg}")
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().wfa_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def error(self):
+        return lib().wfa_hip_last_error(self._h).decode()
+
+    def _raise(self, rc, what):
+        msg = self.error()
+        if rc == EINVAL:
+            raise ValueError(f"{what}: {msg}")
+        if rc == ENOTSUP:
+            raise NotImplementedError(f"{what}: {msg}")
+        raise NativeError(f"{what}: {msg}")
+
+    def set_config(self, cfg):
+        rc = lib().wfa_hip_set_config(self._h, ctypes.byref(cfg))
+        if rc != OK:
+            self._raise(rc, "wfa_hip_set_config")
+
+    def get_config(self):
+        c = Config()
+        lib().wfa_hip_get_config(self._h, ctypes.byref(c))
+        return c
+
+    def align_batch(self, batch, want_cigar):
+        """Host-buffer path (wfa_hip_align_batch). Returns score, status, (ops, begin, len) or None."""
+        seqs, p_off, p_len, t_off, t_len, n = _check_batch(batch)
+        score = np.zeros(n, np.int32)
+        status = np.zeros(n, np.int32)
+        if want_cigar:
+            cigar_off = np.zeros(n + 1, np.int64)
+            np.cumsum(p_len.astype(np.int64) + t_len.astype(np.int64), out=cigar_off[1:])
+            ops = np.zeros(max(int(cigar_off[-1]), 1), np.uint8)
+            cbeg = np.zeros(n, np.int64)
+            clen = np.zeros(n, np.int32)
+        else:
+            cigar_off = ops = cbeg = clen = None
+        rc = lib().wfa_hip_align_batch(self._h, n, _ptr(seqs), _ptr(p_off), _ptr(p_len), _ptr(t_off),
+                                       _ptr(t_len), _ptr(score), _ptr(status), _ptr(ops),
+                                       _ptr(cigar_off), _ptr(cbeg), _ptr(clen))
+        if rc != OK:
+            self._raise(rc, "wfa_hip_align_batch")
+        return score, status, ((ops, cbeg, clen) if want_cigar else None)
+
+    def batch(self, batch):
+        return ResidentBatch(self, batch)
+
+
+class ResidentBatch:
+    """A batch kept in HBM (wfa_hip_batch_t): upload + 2-bit pack once, run many times."""
+
+    def __init__(self, aligner, batch):
+        seqs, p_off, p_len, t_off, t_len, n = _check_batch(batch)
+        self.aligner = aligner
+        self.n = n
+        self._p_len, self._t_len = p_len, t_len
+        self._h = lib().wfa_hip_batch_create(aligner._h, n, _ptr(seqs), _ptr(p_off), _ptr(p_len),
+                                             _ptr(t_off), _ptr(t_len))
+        if not self._h:
+            msg = aligner.error()
+            if "failed:" in msg:
+                raise NativeError(f"wfa_hip_batch_create: {msg}")
+            raise ValueError(f"wfa_hip_batch_create: {msg}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().wfa_hip_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, stream=None):
+        rc = lib().wfa_hip_batch_run(self._h, stream)
+        if rc != OK:
+            self.aligner._raise(rc, "wfa_hip_batch_run")
+
+    def sync(self):
+        rc = lib().wfa_hip_batch_sync(self._h)
+        if rc != OK:
+            self.aligner._raise(rc, "wfa_hip_batch_sync")
+
+    def results(self, want_cigar):
+        n = self.n
+        score = np.zeros(n, np.int32)
+        status = np.zeros(n, np.int32)
+        if want_cigar:
+            cigar_off = np.zeros(n + 1, np.int64)
+            np.cumsum(self._p_len.astype(np.int64) + self._t_len.astype(np.int64), out=cigar_off[1:])
+            ops = np.zeros(max(int(cigar_off[-1]), 1), np.uint8)
+            cbeg = np.zeros(n, np.int64)
+            clen = np.zeros(n, np.int32)
+        else:
+            cigar_off = ops = cbeg = clen = None
+        rc = lib().wfa_hip_batch_results(self._h, _ptr(score), _ptr(status), _ptr(ops), _ptr(cigar_off),
+                                         _ptr(cbeg), _ptr(clen))
+        if rc != OK:
+            self.aligner._raise(rc, "wfa_hip_batch_results")
+        return score, status, ((ops, cbeg, clen) if want_cigar else None)
+
+    def last_kernel(self):
+        ms = ctypes.c_float(0)
+        pairs = ctypes.c_int64(0)
+        rc = lib().wfa_hip_batch_last_kernel_ms(self._h, ctypes.byref(ms), ctypes.byref(pairs))
+        if rc != OK:
+            self.aligner._raise(rc, "wfa_hip_batch_last_kernel_ms")
+        return ms.value, pairs.value
+
+    def algorithmic_bytes(self):
+        return int(lib().wfa_hip_batch_algorithmic_bytes(self._h))
+
+    def fallback_pairs(self):
+        return int(lib().wfa_hip_batch_fallback_pairs(self._h))

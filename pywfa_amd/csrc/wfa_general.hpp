@@ -1,0 +1,554 @@
+// wfa_general.hpp — the general wavefront-alignment kernel: ONE alignment per workgroup at a time,
+// lanes over diagonals k, any sequence length, gap-affine and gap-affine-2p, end-to-end and
+// ends-free, none / wf-adaptive / X-drop, score-only (modular ring of max_score_scope wavefronts)
+// or full CIGAR (explicit wavefront history + on-device backtrace).
+//
+// What each phase restates (R = /root/reference/pywfa/WFA2_lib/wavefront):
+//   driver loop            R/wavefront_unialign.c:241-273 (extend -> finished? -> ++score -> compute -> limits)
+//   wavefront 0            R/wavefront_aligner.c:251-310
+//   extend                 R/wavefront_extend_kernels.c:64-163, R/wavefront_extend.c:90-125,263-297
+//   termination            R/wavefront_termination.c:37-61 (end2end), :115-162 (ends-free, lowest k wins)
+//   heuristic cut-off      R/wavefront_heuristic.c:176-293 (wf-adaptive), :297-383 (X-drop), :509-567
+//   compute-next           R/wavefront_compute_affine.c:44-86,229-260, R/wavefront_compute_affine2p.c:45-106,334-368
+//                          with R/wavefront_compute.c:40-86 (limits), :298-344 (inputs by score), :571-605 (trim)
+//   finish / status        R/wavefront_unialign.c:98-107,147-237
+//   backtrace              R/wavefront_backtrace.c:49-101,320-529
+//
+// Storage.  A workgroup owns one slice of the HBM workspace (a.ws + blockIdx.x * a.ws_stride int32):
+//   score-only: a ring of `scope` slots x NCOMP components x (plen+tlen+3) offsets, indexed by k;
+//   full:       an arena; the offsets of score s (NCOMP x width) are appended bottom-up, the
+//               per-score directory record {lo[],hi[],base,width,data,exists} grows top-down.
+// The directory records of the last `scope` scores are mirrored in LDS (the "meta ring"); reading a
+// wavefront outside its [lo,hi] yields NULL exactly like the reference's lazily padded arrays
+// (R/wavefront_compute.c:490-567).  Integer arithmetic only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include "wfa_common.hpp"
+
+namespace wfa {
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m, 64));
+  return v;
+}
+
+// 16 bases starting at base position `pos` of a 2-bit packed sequence (bits beyond the sequence end
+// are garbage; callers clamp by the remaining length).
+__device__ __forceinline__ uint32_t window16(const uint32_t* __restrict__ w, int pos) {
+  const int i = pos >> 4;
+  const uint32_t lo = w[i];
+  const uint32_t hi = w[i + 1];
+  return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(pos & 15) << 1);
+}
+
+// Extend one diagonal (R/wavefront_extend_kernels.c:64-88): length of the common prefix of
+// pattern[v..] and text[h..], which cannot pass either sequence end (the reference's sentinels).
+template <bool PACKED>
+struct SeqView {
+  const uint32_t* pw;
+  const uint32_t* tw;
+  const uint8_t* pb;
+  const uint8_t* tb;
+  int plen, tlen, wildcard;
+
+  __device__ __forceinline__ int extend(int k, int off) const {
+    const int h = off, v = off - k;
+    const int maxrun = min(plen - v, tlen - h);
+    int run = 0;
+    if (PACKED) {
+      while (run < maxrun) {
+        const uint32_t x = window16(pw, v + run) ^ window16(tw, h + run);
+        const int m = x ? (__builtin_ctz(x) >> 1) : 16;
+        run += m;
+        if (m < 16) break;
+      }
+      run = min(run, maxrun);
+    } else {
+      if (wildcard < 0) {
+        while (run < maxrun && pb[v + run] == tb[h + run]) ++run;
+      } else {
+        while (run < maxrun) {
+          const int pc = pb[v + run], tc = tb[h + run];
+          if (!(pc == tc || pc == wildcard || tc == wildcard)) break;
+          ++run;
+        }
+      }
+    }
+    return off + run;
+  }
+};
+
+// one input wavefront as the compute loop sees it: value(k) = (lo<=k<=hi) ? ws[idx0 + k] : NULL
+struct WfIn {
+  int lo, hi, idx0;
+  __device__ __forceinline__ bool null() const { return lo > hi; }
+  __device__ __forceinline__ int get(const int* __restrict__ ws, int k) const {
+    return (k >= lo && k <= hi) ? ws[idx0 + k] : WFA_OFFSET_NULL;
+  }
+};
+
+template <int NCOMP>
+struct Meta {
+  // layout of one directory record / meta-ring entry (ints)
+  static constexpr int LO = 0;          // lo[NCOMP]
+  static constexpr int HI = NCOMP;      // hi[NCOMP]
+  static constexpr int BASE = 2 * NCOMP;
+  static constexpr int WIDTH = 2 * NCOMP + 1;
+  static constexpr int DATA = 2 * NCOMP + 2;
+  static constexpr int EXISTS = 2 * NCOMP + 3;  // M "pointer != NULL" of the reference
+  static constexpr int INTS = 2 * NCOMP + 4;
+};
+
+template <int NCOMP>
+__device__ __forceinline__ WfIn fetch_in(const int* ring, int scope, int s, int c) {
+  typedef Meta<NCOMP> MT;
+  WfIn in;
+  in.lo = 1; in.hi = -1; in.idx0 = 0;
+  if (s >= 0) {
+    const int* m = ring + (s % scope) * MT::INTS;
+    const int lo = m[MT::LO + c], hi = m[MT::HI + c];
+    if (lo <= hi) {
+      in.lo = lo; in.hi = hi;
+      in.idx0 = m[MT::DATA] + c * m[MT::WIDTH] - m[MT::BASE];
+    }
+  }
+  in.lo = __builtin_amdgcn_readfirstlane(in.lo);
+  in.hi = __builtin_amdgcn_readfirstlane(in.hi);
+  in.idx0 = __builtin_amdgcn_readfirstlane(in.idx0);
+  return in;
+}
+
+// candidate of the backtrace (R/wavefront_backtrace.c:64-219), read from the HBM directory
+template <int NCOMP>
+__device__ __forceinline__ long long bt_cand(const int* ws, long long ws_stride, int s, int c, int k,
+                                             int add, int type) {
+  typedef Meta<NCOMP> MT;
+  if (s < 0) return WFA_OFFSET_NULL;
+  const int* m = ws + ws_stride - (long long)(s + 1) * MT::INTS;
+  if (k < m[MT::LO + c] || k > m[MT::HI + c]) return WFA_OFFSET_NULL;
+  const int o = ws[m[MT::DATA] + c * m[MT::WIDTH] + (k - m[MT::BASE])];
+  return (((long long)(o + add)) << 4) | type;
+}
+
+struct OpsWriter {
+  uint8_t* buf;       // region of this pair
+  long long begin;    // index (relative to buf) of the first valid op; ops are written right-to-left
+  __device__ __forceinline__ void push(char c, int n) {
+    while (n-- > 0) buf[--begin] = (uint8_t)c;
+  }
+};
+
+// R/wavefront_backtrace.c:320-529, single lane.
+template <int NCOMP>
+__device__ void backtrace(const int* ws, long long ws_stride, const WfaDevConfig& cfg, int plen, int tlen,
+                          int end_s, int end_k, int end_off, OpsWriter& ops) {
+  enum { BT_I1_OPEN = 1, BT_I1_EXT, BT_I2_OPEN, BT_I2_EXT, BT_D1_OPEN, BT_D1_EXT, BT_D2_OPEN, BT_D2_EXT, BT_M };
+  int comp = 0, s = end_s, k = end_k, offset = end_off;
+  int h = offset, v = offset - k;
+  if (v < plen) ops.push('D', plen - v);
+  if (h < tlen) ops.push('I', tlen - h);
+  while (v > 0 && h > 0 && s > 0) {
+    const int s_x = s - cfg.x, s_o1 = s - cfg.o1 - cfg.e1, s_e1 = s - cfg.e1;
+    const int s_o2 = s - cfg.o2 - cfg.e2, s_e2 = s - cfg.e2;
+    long long best;
+    if (comp == 0) {
+      best = bt_cand<NCOMP>(ws, ws_stride, s_x, 0, k, 1, BT_M);
+      best = max(best, bt_cand<NCOMP>(ws, ws_stride, s_o1, 0, k - 1, 1, BT_I1_OPEN));
+      best = max(best, bt_cand<NCOMP>(ws, ws_stride, s_e1, 1, k - 1, 1, BT_I1_EXT));
+      best = max(best, bt_cand<NCOMP>(ws, ws_stride, s_o1, 0, k + 1, 0, BT_D1_OPEN));
+      best = max(best, bt_cand<NCOMP>(ws, ws_stride, s_e1, 2, k + 1, 0, BT_D1_EXT));
+      if (NCOMP == 5) {
+        best = max(best, bt_cand<NCOMP>(ws, ws_stride, s_o2, 0, k - 1, 1, BT_I2_OPEN));
+        best = max(best, bt_cand<NCOMP>(ws, ws_stride, s_e2, 3, k - 1, 1, BT_I2_EXT));
+        best = max(best, bt_cand<NCOMP>(ws, ws_stride, s_o2, 0, k + 1, 0, BT_D2_OPEN));
+        best = max(best, bt_cand<NCOMP>(ws, ws_stride, s_e2, 4, k + 1, 0, BT_D2_EXT));
+      }
+    } else if (comp == 1) {
+      best = max(bt_cand<NCOMP>(ws, ws_stride, s_o1, 0, k - 1, 1, BT_I1_OPEN),
+                 bt_cand<NCOMP>(ws, ws_stride, s_e1, 1, k - 1, 1, BT_I1_EXT));
+    } else if (comp == 2) {
+      best = max(bt_cand<NCOMP>(ws, ws_stride, s_o1, 0, k + 1, 0, BT_D1_OPEN),
+                 bt_cand<NCOMP>(ws, ws_stride, s_e1, 2, k + 1, 0, BT_D1_EXT));
+    } else if (comp == 3) {
+      best = max(bt_cand<NCOMP>(ws, ws_stride, s_o2, 0, k - 1, 1, BT_I2_OPEN),
+                 bt_cand<NCOMP>(ws, ws_stride, s_e2, NCOMP == 5 ? 3 : 1, k - 1, 1, BT_I2_EXT));
+    } else {
+      best = max(bt_cand<NCOMP>(ws, ws_stride, s_o2, 0, k + 1, 0, BT_D2_OPEN),
+                 bt_cand<NCOMP>(ws, ws_stride, s_e2, NCOMP == 5 ? 4 : 2, k + 1, 0, BT_D2_EXT));
+    }
+    if (best < 0) break;
+    if (comp == 0) {
+      const int src = (int)(best >> 4);
+      ops.push('M', offset - src);
+      offset = src;
+      v = offset - k; h = offset;
+      if (v <= 0 || h <= 0) break;
+    }
+    const int type = (int)(best & 0xF);
+    switch (type) {
+      case BT_M: s = s_x; comp = 0; break;
+      case BT_I1_OPEN: s = s_o1; comp = 0; break;
+      case BT_I1_EXT: s = s_e1; comp = 1; break;
+      case BT_I2_OPEN: s = s_o2; comp = 0; break;
+      case BT_I2_EXT: s = s_e2; comp = 3; break;
+      case BT_D1_OPEN: s = s_o1; comp = 0; break;
+      case BT_D1_EXT: s = s_e1; comp = 2; break;
+      case BT_D2_OPEN: s = s_o2; comp = 0; break;
+      default: s = s_e2; comp = 4; break;
+    }
+    if (type == BT_M) { ops.push('X', 1); --offset; }
+    else if (type <= BT_I2_EXT) { ops.push('I', 1); --k; --offset; }
+    else { ops.push('D', 1); ++k; }
+    v = offset - k; h = offset;
+  }
+  if (comp == 0) {
+    if (v > 0 && h > 0) {
+      const int n = min(v, h);
+      ops.push('M', n);
+      v -= n; h -= n;
+    }
+    ops.push('D', max(v, 0));
+    ops.push('I', max(h, 0));
+  }
+}
+
+// R/wavefront_compute.c:108-120 with WF_SCORE_TO_SW_SCORE (R/wavefront_penalties.h:73)
+__device__ __forceinline__ int classic_score(const WfaDevConfig& cfg, int v, int h, int s) {
+  if (cfg.match == 0) return -s;
+  return ((-cfg.match) * (v + h) - s) / 2;
+}
+
+template <int NCOMP, bool PACKED, bool FULL>
+__global__ void __launch_bounds__(512)
+wfa_general_kernel(const WfaKernelArgs a) {
+  typedef Meta<NCOMP> MT;
+  extern __shared__ int smem[];
+  const WfaDevConfig& cfg = a.cfg;
+  const int scope = cfg.scope;
+  int* const ring = smem;                   // scope * MT::INTS
+  int* const TR = smem + scope * MT::INTS;  // trim scratch: min k in-bounds [NCOMP], max k in-bounds [NCOMP]
+  int* const EK = TR + 2 * NCOMP;           // EK[0] end k; EK[1] heur min; EK[2] lo cand; EK[3] hi cand; EK[4] max
+  const int tid = threadIdx.x, T = blockDim.x;
+  int* const ws = a.ws + (long long)blockIdx.x * a.ws_stride;
+  const long long ws_stride = a.ws_stride;
+  const uint32_t nwork = a.nwork_dev ? *a.nwork_dev : a.nwork;
+
+  for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+    const uint32_t pair = a.worklist ? a.worklist[wi] : wi;
+    const WfaPairMeta pm = a.meta[pair];
+    const int plen = pm.plen, tlen = pm.tlen;
+    SeqView<PACKED> seq;
+    seq.plen = plen; seq.tlen = tlen; seq.wildcard = cfg.wildcard;
+    if (PACKED) {
+      seq.pw = a.words + pm.p_woff; seq.tw = a.words + pm.t_woff; seq.pb = nullptr; seq.tb = nullptr;
+    } else {
+      seq.pb = a.bytes + a.p_boff[pair]; seq.tb = a.bytes + a.t_boff[pair]; seq.pw = nullptr; seq.tw = nullptr;
+    }
+    const int pbf = (cfg.endsfree && cfg.match == 0) ? cfg.pbf : 0;
+    const int tbf = (cfg.endsfree && cfg.match == 0) ? cfg.tbf : 0;
+    const int rstride = plen + tlen + 3;   // ring: offsets of k in [-plen-1, tlen+1]
+    const int rbase = -plen - 1;
+    bool overflow = false;
+    if (!FULL && (long long)scope * NCOMP * rstride > ws_stride) overflow = true;
+    if (FULL && (long long)(tbf + pbf + 1) * NCOMP + 2 * MT::INTS > ws_stride) overflow = true;
+
+    // ---- wavefront 0 ----
+    int used = 0;  // FULL: ints of the arena in use
+    int cur_lo = -pbf, cur_hi = tbf, cur_idx0, cur_exists = 1;
+    {
+      const int base = FULL ? -pbf : rbase;
+      const int width = FULL ? (tbf + pbf + 1) : rstride;
+      const int data = 0;
+      cur_idx0 = data - base;
+      __syncthreads();  // previous pair fully done with ring / scratch
+      if (tid == 0) {
+        int* m = ring;
+        for (int c = 0; c < NCOMP; ++c) { m[MT::LO + c] = 1; m[MT::HI + c] = -1; }
+        m[MT::LO] = -pbf; m[MT::HI] = tbf;
+        m[MT::BASE] = base; m[MT::WIDTH] = width; m[MT::DATA] = data; m[MT::EXISTS] = 1;
+        for (int c = 0; c < 2 * NCOMP; ++c) TR[c] = (c < NCOMP) ? INT_MAX : INT_MIN;
+        EK[0] = INT_MAX; EK[1] = INT_MAX; EK[2] = INT_MAX; EK[3] = INT_MIN; EK[4] = INT_MIN;
+      }
+      if (!overflow) {
+        for (int k = -pbf + tid; k <= tbf; k += T) ws[cur_idx0 + k] = (k > 0) ? k : 0;
+      }
+      if (FULL) used = NCOMP * width;
+    }
+
+    int s = 0, null_steps = 0;
+    int steps_wait = cfg.steps_between, have_max_sw = 0, max_sw = 0;
+    int end_reason = overflow ? 3 : 0;  // 1 reached, 2 unreachable, 3 overflow, 4 max steps
+    int end_k = 0, end_off = WFA_OFFSET_NULL;
+
+    while (!end_reason) {
+      // =============================== extend(s) ===============================
+      __syncthreads();  // offsets of score s (and the meta ring) are visible; TR reads of compute(s) are done
+      if (tid == 0) {
+        for (int c = 0; c < 2 * NCOMP; ++c) TR[c] = (c < NCOMP) ? INT_MAX : INT_MIN;
+      }
+      if (!cur_exists) {
+        if (null_steps > scope) { end_reason = 2; break; }
+      } else {
+        for (int k = cur_lo + tid; k <= cur_hi; k += T) {
+          const int off = ws[cur_idx0 + k];
+          if (off == WFA_OFFSET_NULL) continue;
+          const int ext = seq.extend(k, off);
+          if (ext != off) ws[cur_idx0 + k] = ext;
+          if (cfg.endsfree) {
+            const int h = ext, v = ext - k;
+            if ((h >= tlen && plen - v <= cfg.pef) || (v >= plen && tlen - h <= cfg.tef)) atomicMin(&EK[0], k);
+          }
+        }
+        __syncthreads();
+        if (cfg.endsfree) {
+          const int ek = EK[0];
+          if (ek != INT_MAX) { end_reason = 1; end_k = ek; end_off = ws[cur_idx0 + ek]; }
+        } else {
+          const int ak = tlen - plen;
+          if (cur_lo <= ak && ak <= cur_hi && ws[cur_idx0 + ak] >= tlen) { end_reason = 1; end_k = ak; end_off = tlen; }
+        }
+        if (end_reason) break;
+        // ---------------------------- heuristic cut-off ----------------------------
+        if (cfg.heuristic != 0 && cur_lo <= cur_hi) {
+          --steps_wait;
+          int new_lo = cur_lo, new_hi = cur_hi;
+          if (cfg.heuristic == 1) {
+            if (steps_wait <= 0 && (cur_hi - cur_lo + 1) >= cfg.min_wf_len) {
+              int dmin = max(plen, tlen);
+              for (int k = cur_lo + tid; k <= cur_hi; k += T) {
+                const int off = ws[cur_idx0 + k];
+                const int d = (off >= 0) ? max(plen - (off - k), tlen - off) : -WFA_OFFSET_NULL;
+                dmin = min(dmin, d);
+              }
+              dmin = wave_min(dmin);
+              if ((tid & 63) == 0) atomicMin(&EK[1], dmin);
+              __syncthreads();
+              dmin = EK[1];
+              int lc = INT_MAX, hc = INT_MIN;
+              for (int k = cur_lo + tid; k <= cur_hi; k += T) {
+                const int off = ws[cur_idx0 + k];
+                const int d = (off >= 0) ? max(plen - (off - k), tlen - off) : -WFA_OFFSET_NULL;
+                if (d - dmin <= cfg.max_dist_thr) { lc = min(lc, k); hc = max(hc, k); }
+              }
+              lc = wave_min(lc); hc = wave_max(hc);
+              if ((tid & 63) == 0) { atomicMin(&EK[2], lc); atomicMax(&EK[3], hc); }
+              __syncthreads();
+              lc = EK[2]; hc = EK[3];
+              const int ak = tlen - plen;
+              const int top_limit = min(ak, cur_hi);
+              if (top_limit > cur_lo) new_lo = min(lc, top_limit);
+              const int bottom_limit = max(ak, new_lo);
+              if (bottom_limit < cur_hi) new_hi = max(hc, bottom_limit);
+              steps_wait = cfg.steps_between;
+            }
+          } else if (cfg.heuristic == 2) {
+            if (steps_wait <= 0) {
+              const int g = (cfg.match != 0) ? -cfg.match : -1;  // R/wavefront_heuristic.c:306-307
+              int cmax = INT_MIN, lc = INT_MAX, hc = INT_MIN;
+              for (int k = cur_lo + tid; k <= cur_hi; k += T) {
+                const int off = ws[cur_idx0 + k];
+                if (off < 0) continue;
+                const int sw = (g * ((off - k) + off) - s) / 2;
+                cmax = max(cmax, sw);
+                if (have_max_sw && max_sw - sw < cfg.xdrop) { lc = min(lc, k); hc = max(hc, k); }
+              }
+              cmax = wave_max(cmax); lc = wave_min(lc); hc = wave_max(hc);
+              if ((tid & 63) == 0) { atomicMax(&EK[4], cmax); atomicMin(&EK[2], lc); atomicMax(&EK[3], hc); }
+              __syncthreads();
+              cmax = EK[4]; lc = EK[2]; hc = EK[3];
+              if (have_max_sw) {
+                if (lc == INT_MAX) { new_lo = cur_hi + 1; new_hi = cur_hi; }
+                else { new_lo = lc; new_hi = hc; }
+                if (cmax > max_sw) max_sw = cmax;
+              } else {
+                max_sw = cmax; have_max_sw = 1;
+              }
+              steps_wait = cfg.steps_between;
+            }
+          }
+          if (new_lo != cur_lo || new_hi != cur_hi) {
+            cur_lo = new_lo; cur_hi = new_hi;
+            if (tid == 0) {
+              int* m = ring + (s % scope) * MT::INTS;
+              m[MT::LO] = new_lo; m[MT::HI] = new_hi;
+              for (int c = 1; c < NCOMP; ++c) {  // wf_heuristic_equate (R/wavefront_heuristic.c:161-172)
+                if (m[MT::LO + c] <= m[MT::HI + c]) {
+                  m[MT::LO + c] = max(m[MT::LO + c], new_lo);
+                  m[MT::HI + c] = min(m[MT::HI + c], new_hi);
+                }
+              }
+            }
+          }
+        }
+      }
+      if (FULL && tid == 0) {
+        // final directory record of score s (its lo/hi can no longer change)
+        const int* m = ring + (s % scope) * MT::INTS;
+        int* d = ws + ws_stride - (long long)(s + 1) * MT::INTS;
+        for (int c = 0; c < MT::INTS; ++c) d[c] = m[c];
+      }
+      // =============================== compute(s+1) ===============================
+      ++s;
+      __syncthreads();  // meta ring updates of the cut-off are visible; EK reads are done
+      if (tid == 0) { EK[0] = INT_MAX; EK[1] = INT_MAX; EK[2] = INT_MAX; EK[3] = INT_MIN; EK[4] = INT_MIN; }
+      const WfIn mx = fetch_in<NCOMP>(ring, scope, s - cfg.x, 0);
+      const WfIn mo1 = fetch_in<NCOMP>(ring, scope, s - cfg.o1 - cfg.e1, 0);
+      const WfIn i1e = fetch_in<NCOMP>(ring, scope, s - cfg.e1, 1);
+      const WfIn d1e = fetch_in<NCOMP>(ring, scope, s - cfg.e1, 2);
+      WfIn mo2, i2e, d2e;
+      mo2.lo = i2e.lo = d2e.lo = 1; mo2.hi = i2e.hi = d2e.hi = -1; mo2.idx0 = i2e.idx0 = d2e.idx0 = 0;
+      if (NCOMP == 5) {
+        mo2 = fetch_in<NCOMP>(ring, scope, s - cfg.o2 - cfg.e2, 0);
+        i2e = fetch_in<NCOMP>(ring, scope, s - cfg.e2, 3);
+        d2e = fetch_in<NCOMP>(ring, scope, s - cfg.e2, 4);
+      }
+      const bool all_null = mx.null() && mo1.null() && i1e.null() && d1e.null() &&
+                            (NCOMP == 3 || (mo2.null() && i2e.null() && d2e.null()));
+      int* const mslot = ring + (s % scope) * MT::INTS;
+      if (all_null) {
+        ++null_steps;
+        cur_exists = 0; cur_lo = 1; cur_hi = -1; cur_idx0 = 0;
+        if (FULL && (long long)used + (long long)(s + 2) * MT::INTS > ws_stride) { end_reason = 3; break; }
+        if (tid == 0) {
+          for (int c = 0; c < NCOMP; ++c) { mslot[MT::LO + c] = 1; mslot[MT::HI + c] = -1; }
+          mslot[MT::BASE] = 0; mslot[MT::WIDTH] = 0; mslot[MT::DATA] = 0; mslot[MT::EXISTS] = 0;
+        }
+      } else {
+        null_steps = 0;
+        int lo = mx.lo, hi = mx.hi;
+        lo = min(lo, mo1.lo - 1); hi = max(hi, mo1.hi + 1);
+        lo = min(lo, i1e.lo + 1); hi = max(hi, i1e.hi + 1);
+        lo = min(lo, d1e.lo - 1); hi = max(hi, d1e.hi - 1);
+        if (NCOMP == 5) {
+          lo = min(lo, mo2.lo - 1); hi = max(hi, mo2.hi + 1);
+          lo = min(lo, i2e.lo + 1); hi = max(hi, i2e.hi + 1);
+          lo = min(lo, d2e.lo - 1); hi = max(hi, d2e.hi - 1);
+        }
+        const bool has_i1 = !mo1.null() || !i1e.null();
+        const bool has_d1 = !mo1.null() || !d1e.null();
+        const bool has_i2 = (NCOMP == 5) && (!mo2.null() || !i2e.null());
+        const bool has_d2 = (NCOMP == 5) && (!mo2.null() || !d2e.null());
+        int base, width, data;
+        if (FULL) {
+          base = lo; width = hi - lo + 1; data = used;
+          if ((long long)used + (long long)NCOMP * width + (long long)(s + 2) * MT::INTS > ws_stride) { end_reason = 3; break; }
+          used += NCOMP * width;
+        } else {
+          base = rbase; width = rstride; data = (s % scope) * NCOMP * rstride;
+        }
+        const int o_m = data - base;
+        const int o_i1 = o_m + width, o_d1 = o_m + 2 * width, o_i2 = o_m + 3 * width, o_d2 = o_m + 4 * width;
+        int tmin[NCOMP], tmax[NCOMP];
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) { tmin[c] = INT_MAX; tmax[c] = INT_MIN; }
+        for (int k = lo + tid; k <= hi; k += T) {
+          const int ins1 = max(mo1.get(ws, k - 1), i1e.get(ws, k - 1)) + 1;
+          const int del1 = max(mo1.get(ws, k + 1), d1e.get(ws, k + 1));
+          int ins = ins1, del = del1;
+          if (has_i1) {
+            ws[o_i1 + k] = ins1;
+            if ((uint32_t)ins1 <= (uint32_t)tlen && (uint32_t)(ins1 - k) <= (uint32_t)plen) { tmin[1] = min(tmin[1], k); tmax[1] = max(tmax[1], k); }
+          }
+          if (has_d1) {
+            ws[o_d1 + k] = del1;
+            if ((uint32_t)del1 <= (uint32_t)tlen && (uint32_t)(del1 - k) <= (uint32_t)plen) { tmin[2] = min(tmin[2], k); tmax[2] = max(tmax[2], k); }
+          }
+          if (NCOMP == 5) {
+            const int ins2 = max(mo2.get(ws, k - 1), i2e.get(ws, k - 1)) + 1;
+            const int del2 = max(mo2.get(ws, k + 1), d2e.get(ws, k + 1));
+            if (has_i2) {
+              ws[o_i2 + k] = ins2;
+              if ((uint32_t)ins2 <= (uint32_t)tlen && (uint32_t)(ins2 - k) <= (uint32_t)plen) { tmin[NCOMP - 2] = min(tmin[NCOMP - 2], k); tmax[NCOMP - 2] = max(tmax[NCOMP - 2], k); }
+            }
+            if (has_d2) {
+              ws[o_d2 + k] = del2;
+              if ((uint32_t)del2 <= (uint32_t)tlen && (uint32_t)(del2 - k) <= (uint32_t)plen) { tmin[NCOMP - 1] = min(tmin[NCOMP - 1], k); tmax[NCOMP - 1] = max(tmax[NCOMP - 1], k); }
+            }
+            ins = max(ins1, ins2);
+            del = max(del1, del2);
+          }
+          int mv = max(del, max(mx.get(ws, k) + 1, ins));
+          // only M is clamped (R/wavefront_compute_affine.c:80-84)
+          if ((uint32_t)mv > (uint32_t)tlen || (uint32_t)(mv - k) > (uint32_t)plen) mv = WFA_OFFSET_NULL;
+          else { tmin[0] = min(tmin[0], k); tmax[0] = max(tmax[0], k); }
+          ws[o_m + k] = mv;
+        }
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) {
+          const int mn = wave_min(tmin[c]), mxk = wave_max(tmax[c]);
+          if ((tid & 63) == 0) {
+            if (mn != INT_MAX) atomicMin(&TR[c], mn);
+            if (mxk != INT_MIN) atomicMax(&TR[NCOMP + c], mxk);
+          }
+        }
+        __syncthreads();
+        // trimmed limits (R/wavefront_compute.c:571-605): first/last in-bounds offset; none -> null
+        int tlo[NCOMP], thi[NCOMP];
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) {
+          const int mn = TR[c], mxk = TR[NCOMP + c];
+          const bool has = (c == 0) || (c == 1 && has_i1) || (c == 2 && has_d1) ||
+                           (NCOMP == 5 && c == 3 && has_i2) || (NCOMP == 5 && c == 4 && has_d2);
+          if (has && mn != INT_MAX) { tlo[c] = mn; thi[c] = mxk; } else { tlo[c] = 1; thi[c] = -1; }
+        }
+        cur_exists = 1; cur_lo = tlo[0]; cur_hi = thi[0]; cur_idx0 = o_m;
+        if (tid == 0) {
+#pragma unroll
+          for (int c = 0; c < NCOMP; ++c) { mslot[MT::LO + c] = tlo[c]; mslot[MT::HI + c] = thi[c]; }
+          mslot[MT::BASE] = base; mslot[MT::WIDTH] = width; mslot[MT::DATA] = data; mslot[MT::EXISTS] = 1;
+        }
+      }
+      if (s >= cfg.max_steps) { end_reason = 4; break; }  // R/wavefront_unialign.c:102-107
+    }
+
+    // =============================== finish ===============================
+    if (tid == 0) {
+      int out_score, out_status;
+      long long cbeg = FULL ? a.cigar_off[pair + 1] : 0;
+      int clen = 0;
+      if (end_reason == 3) {
+        if (FULL && a.fb_list) {
+          // arena too small: hand the pair back to the host, which re-runs it with a larger arena
+          out_status = WFA_INTERNAL_OVERFLOW; out_score = 0;
+          a.fb_list[atomicAdd(a.fb_count, 1u)] = pair;
+        } else {
+          out_status = -200; out_score = INT_MIN;  // WF_STATUS_OOM
+        }
+      } else if (end_reason == 4) {
+        out_status = -100; out_score = -cfg.max_steps;
+      } else if (!FULL) {
+        if (end_reason == 1) { out_score = classic_score(cfg, plen, tlen, s); out_status = 0; }
+        else {
+          // the reference evaluates the score at its unset end position (k=INT_MAX, offset=NULL)
+          out_score = (cfg.match == 0) ? -s : (int)(((long long)(-cfg.match) * 1 - s) / 2);
+          out_status = 1;
+        }
+      } else {
+        if (end_reason == 1) {
+          OpsWriter ops;
+          ops.buf = a.cigar_ops + a.cigar_off[pair];
+          ops.begin = (long long)plen + tlen;
+          backtrace<NCOMP>(ws, ws_stride, cfg, plen, tlen, s, end_k, end_off, ops);
+          cbeg = a.cigar_off[pair] + ops.begin;
+          clen = (int)((long long)plen + tlen - ops.begin);
+          out_score = classic_score(cfg, end_off - end_k, end_off, s);
+          out_status = 0;
+        } else {
+          out_score = INT_MIN; out_status = 1;  // empty CIGAR after maxtrim (R/alignment/cigar.c:473-613)
+        }
+      }
+      a.score[pair] = out_score;
+      a.status[pair] = out_status;
+      if (FULL) { a.cigar_begin[pair] = cbeg; a.cigar_len[pair] = clen; }
+    }
+  }
+}
+
+}  // namespace wfa

@@ -1,0 +1,652 @@
+// wfa_hip.hip — host side of libwfa_hip.so: the C ABI declared in include/wfa_hip.h.
+//
+// It replaces, for batches of independent pairs, what pywfa's Cython host does per pair through
+// WFA2-lib's C API (align.pyx:344-443,461-467,737-786): build the aligner from the kwargs, run
+// wavefront_align, read status / score / CIGAR ops.  Plain HIP runtime only (no torch types).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "wfa_hip.h"
+#include "wfa_common.hpp"
+#include "wfa_pack.hpp"
+#include "wfa_general.hpp"
+#include "wfa_fast.hpp"
+
+#define WFA_HIP_ABI_VERSION 1
+
+static thread_local std::string g_error;
+
+struct wfa_hip_aligner {
+  int device = 0;
+  wfa_hip_config_t cfg;
+  WfaDevConfig dcfg;
+  int ncomp = 3;
+  hipStream_t stream = nullptr;
+  int cu_count = 256;
+  size_t total_mem = 0;
+  std::string err;
+  // persistent workspace for the general kernel (grown on demand)
+  int32_t* ws = nullptr;
+  size_t ws_bytes = 0;
+};
+
+struct wfa_hip_batch {
+  wfa_hip_aligner* al = nullptr;
+  int64_t n = 0;
+  // host copies needed later
+  std::vector<int32_t> h_plen, h_tlen;
+  int max_width = 0;       // max(plen+tlen)+3
+  int max_len = 0;         // max(plen, tlen)
+  int64_t packed_bytes = 0;  // sum of ceil(len/4) over all sequences (algorithmic 2-bit bytes)
+  int64_t ops_bytes = 0;     // sum(plen+tlen)
+  // device
+  uint8_t* d_bytes = nullptr;
+  int64_t* d_pboff = nullptr;
+  int64_t* d_tboff = nullptr;
+  WfaPairMeta* d_meta = nullptr;
+  uint32_t* d_words = nullptr;
+  uint8_t* d_flags = nullptr;
+  int32_t* d_score = nullptr;
+  int32_t* d_status = nullptr;
+  uint8_t* d_ops = nullptr;
+  int64_t* d_cigar_off = nullptr;
+  int64_t* d_cigar_begin = nullptr;
+  int32_t* d_cigar_len = nullptr;
+  uint32_t* d_list_packed = nullptr;  // worklists (nullptr = identity over all pairs)
+  uint32_t* d_list_bytes = nullptr;
+  uint32_t n_packed = 0, n_bytes = 0;
+  uint32_t* d_fb_list = nullptr;   // pairs handed from the fast kernel to the general kernel
+  uint32_t* d_ovf_list[2] = {nullptr, nullptr};  // pairs whose arena overflowed
+  uint32_t* d_counters = nullptr;  // [0] fallback count, [1] overflow count A, [2] overflow count B
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool ran = false, synced = true;
+  float last_ms = 0.f;
+  int64_t last_kernel_pairs = 0;
+  int64_t last_fallback = 0;
+  hipStream_t last_stream = nullptr;
+  int64_t arena_ints = 0;  // FULL: arena size used by the last launch
+};
+
+#define HIP_TRY(al, expr)                                                                      \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      char buf_[512];                                                                          \
+      snprintf(buf_, sizeof(buf_), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      if (al) (al)->err = buf_;                                                                \
+      g_error = buf_;                                                                          \
+      return WFA_HIP_EDEVICE;                                                                  \
+    }                                                                                          \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// configuration
+// ------------------------------------------------------------------------------------------------
+extern "C" int wfa_hip_abi_version(void) { return WFA_HIP_ABI_VERSION; }
+
+extern "C" int wfa_hip_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { g_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e); return WFA_HIP_EDEVICE; }
+  return n;
+}
+
+extern "C" const char* wfa_hip_global_error(void) { return g_error.c_str(); }
+
+extern "C" int wfa_hip_config_default(wfa_hip_config_t* c) {
+  if (!c) return WFA_HIP_EINVAL;
+  memset(c, 0, sizeof(*c));
+  c->distance = WFA_DIST_AFFINE;  // align.pyx:311
+  c->match = 0; c->mismatch = 4; c->gap_opening = 6; c->gap_extension = 2;  // align.pyx:313-316
+  c->gap_opening2 = 24; c->gap_extension2 = 1;                               // align.pyx:317-318
+  c->scope = WFA_SCOPE_FULL;      // align.pyx:319
+  c->span = WFA_SPAN_ENDSFREE;    // align.pyx:320
+  c->heuristic = WFA_HEUR_NONE;   // align.pyx:325
+  c->min_wavefront_length = 10; c->max_distance_threshold = 50; c->steps_between_cutoffs = 1;  // :328-330
+  c->xdrop = 20;                  // align.pyx:331
+  c->memory_mode = WFA_MEM_HIGH;  // align.pyx:312
+  c->max_steps = 0;               // align.pyx:333
+  c->wildcard = -1;               // align.pyx:332
+  return WFA_HIP_OK;
+}
+
+static int fail_cfg(char* err, size_t errlen, int code, const char* msg) {
+  if (err && errlen) snprintf(err, errlen, "%s", msg);
+  g_error = msg;
+  return code;
+}
+
+extern "C" int wfa_hip_config_validate(const wfa_hip_config_t* c, char* err, size_t errlen) {
+  if (!c) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "null config");
+  if (c->distance < WFA_DIST_INDEL || c->distance > WFA_DIST_AFFINE2P)
+    return fail_cfg(err, errlen, WFA_HIP_EINVAL, "unknown distance");
+  if (c->distance != WFA_DIST_AFFINE && c->distance != WFA_DIST_AFFINE2P)
+    return fail_cfg(err, errlen, WFA_HIP_ENOTSUP, "distance not on the accelerated path (only affine / affine2p)");
+  // wavefront_penalties.c:95-173 (the reference prints and exit(1)s)
+  if (c->match > 0) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "Match score must be negative or zero");
+  if (c->mismatch <= 0 || c->gap_opening < 0 || c->gap_extension <= 0)
+    return fail_cfg(err, errlen, WFA_HIP_EINVAL, "Penalties must be (X>0,O>=0,E>0)");
+  if (c->distance == WFA_DIST_AFFINE2P && (c->gap_opening2 < 0 || c->gap_extension2 <= 0))
+    return fail_cfg(err, errlen, WFA_HIP_EINVAL, "Penalties must be (X>0,O1>=0,E1>0,O2>=0,E2>0)");
+  if (c->scope != WFA_SCOPE_SCORE && c->scope != WFA_SCOPE_FULL) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "unknown scope");
+  if (c->span != WFA_SPAN_END2END && c->span != WFA_SPAN_ENDSFREE) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "unknown span");
+  if (c->heuristic < WFA_HEUR_NONE || c->heuristic > WFA_HEUR_XDROP) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "unknown heuristic");
+  if (c->memory_mode < WFA_MEM_HIGH || c->memory_mode > WFA_MEM_BIWFA) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "unknown memory_mode");
+  if (c->memory_mode == WFA_MEM_BIWFA) return fail_cfg(err, errlen, WFA_HIP_ENOTSUP, "memory_mode biwfa is not on the accelerated path");
+  if (c->pattern_begin_free < 0 || c->pattern_end_free < 0 || c->text_begin_free < 0 || c->text_end_free < 0)
+    return fail_cfg(err, errlen, WFA_HIP_EINVAL, "ends-free sizes must be >= 0");
+  if (c->match < 0 && c->span == WFA_SPAN_ENDSFREE && (c->pattern_begin_free > 0 || c->text_begin_free > 0))
+    return fail_cfg(err, errlen, WFA_HIP_ENOTSUP, "match<0 with free begins (ends-free re-seeding) is not on the accelerated path");
+  if (c->wildcard < -1 || c->wildcard > 255) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "wildcard must be -1 or a byte");
+  if (c->reserved != 0) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "reserved must be 0");
+  return WFA_HIP_OK;
+}
+
+static void derive_dev_config(const wfa_hip_config_t& c, WfaDevConfig* d, int* ncomp) {
+  const bool two = (c.distance == WFA_DIST_AFFINE2P);
+  *ncomp = two ? 5 : 3;
+  // Eizenga rescaling when match<0 (wavefront_penalties.c:113-122,148-164)
+  if (c.match < 0) {
+    d->match = c.match;
+    d->x = 2 * c.mismatch - 2 * c.match;
+    d->o1 = 2 * c.gap_opening; d->e1 = 2 * c.gap_extension - c.match;
+    d->o2 = 2 * c.gap_opening2; d->e2 = 2 * c.gap_extension2 - c.match;
+  } else {
+    d->match = 0;
+    d->x = c.mismatch;
+    d->o1 = c.gap_opening; d->e1 = c.gap_extension;
+    d->o2 = c.gap_opening2; d->e2 = c.gap_extension2;
+  }
+  if (!two) { d->o2 = d->o1; d->e2 = d->e1; }
+  int scope_indel = d->o1 + d->e1;
+  if (two) scope_indel = std::max(scope_indel, d->o2 + d->e2);
+  d->scope = std::max(scope_indel, d->x) + 1;  // wavefront_components.c:81-124
+  d->endsfree = (c.span == WFA_SPAN_ENDSFREE);
+  d->pbf = c.pattern_begin_free; d->pef = c.pattern_end_free;
+  d->tbf = c.text_begin_free; d->tef = c.text_end_free;
+  d->heuristic = c.heuristic;
+  d->min_wf_len = c.min_wavefront_length; d->max_dist_thr = c.max_distance_threshold;
+  d->steps_between = c.steps_between_cutoffs; d->xdrop = c.xdrop;
+  d->max_steps = (c.max_steps <= 0) ? INT_MAX : c.max_steps;  // align.pyx:415-417
+  d->wildcard = c.wildcard;
+}
+
+extern "C" wfa_hip_aligner_t* wfa_hip_create(const wfa_hip_config_t* cfg, int device) {
+  char msg[256];
+  if (wfa_hip_config_validate(cfg, msg, sizeof(msg)) != WFA_HIP_OK) return nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_error = std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    return nullptr;
+  }
+  if (device < 0 || device >= ndev) { g_error = "device ordinal out of range"; return nullptr; }
+  if ((e = hipSetDevice(device)) != hipSuccess) { g_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return nullptr; }
+  wfa_hip_aligner* al = new wfa_hip_aligner();
+  al->device = device;
+  al->cfg = *cfg;
+  derive_dev_config(al->cfg, &al->dcfg, &al->ncomp);
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { g_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e); delete al; return nullptr; }
+  al->cu_count = prop.multiProcessorCount;
+  al->total_mem = prop.totalGlobalMem;
+  if ((e = hipStreamCreateWithFlags(&al->stream, hipStreamNonBlocking)) != hipSuccess) { g_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete al; return nullptr; }
+  return al;
+}
+
+extern "C" void wfa_hip_destroy(wfa_hip_aligner_t* al) {
+  if (!al) return;
+  (void)hipSetDevice(al->device);
+  if (al->ws) (void)hipFree(al->ws);
+  if (al->stream) (void)hipStreamDestroy(al->stream);
+  delete al;
+}
+
+extern "C" int wfa_hip_set_config(wfa_hip_aligner_t* al, const wfa_hip_config_t* cfg) {
+  if (!al) return WFA_HIP_EINVAL;
+  char msg[256];
+  const int rc = wfa_hip_config_validate(cfg, msg, sizeof(msg));
+  if (rc != WFA_HIP_OK) { al->err = msg; return rc; }
+  al->cfg = *cfg;
+  derive_dev_config(al->cfg, &al->dcfg, &al->ncomp);
+  return WFA_HIP_OK;
+}
+
+extern "C" int wfa_hip_get_config(const wfa_hip_aligner_t* al, wfa_hip_config_t* cfg) {
+  if (!al || !cfg) return WFA_HIP_EINVAL;
+  *cfg = al->cfg;
+  return WFA_HIP_OK;
+}
+
+extern "C" const char* wfa_hip_last_error(const wfa_hip_aligner_t* al) { return al ? al->err.c_str() : g_error.c_str(); }
+
+// ------------------------------------------------------------------------------------------------
+// batches
+// ------------------------------------------------------------------------------------------------
+static void batch_free(wfa_hip_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->al->device);
+  void* ptrs[] = {b->d_bytes, b->d_pboff, b->d_tboff, b->d_meta, b->d_words, b->d_flags, b->d_score, b->d_status,
+                  b->d_ops, b->d_cigar_off, b->d_cigar_begin, b->d_cigar_len, b->d_list_packed, b->d_list_bytes,
+                  b->d_fb_list, b->d_ovf_list[0], b->d_ovf_list[1], b->d_counters};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  delete b;
+}
+
+extern "C" void wfa_hip_batch_destroy(wfa_hip_batch_t* b) { batch_free(b); }
+
+static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const uint8_t* seqs,
+                       const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len) {
+  const wfa_hip_config_t& c = al->cfg;
+  b->al = al;
+  b->n = n;
+  b->h_plen.assign(p_len, p_len + n);
+  b->h_tlen.assign(t_len, t_len + n);
+  std::vector<WfaPairMeta> meta((size_t)n);
+  uint64_t woff = 0;
+  int64_t blob_end = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int pl = p_len[i], tl = t_len[i];
+    if (pl < 0 || tl < 0 || p_off[i] < 0 || t_off[i] < 0) { al->err = "negative length or offset"; return WFA_HIP_EINVAL; }
+    if ((int64_t)pl + tl > (int64_t)INT_MAX / 2 - 8) { al->err = "sequence too long"; return WFA_HIP_EINVAL; }
+    // wavefront_align.c:86-102: the reference exit(1)s here
+    if (c.span == WFA_SPAN_ENDSFREE &&
+        (c.pattern_begin_free > pl || c.pattern_end_free > pl || c.text_begin_free > tl || c.text_end_free > tl)) {
+      al->err = "Ends-free parameters must be not larger than the sequences";
+      return WFA_HIP_EINVAL;
+    }
+    meta[i].p_woff = (uint32_t)woff; woff += (uint64_t)((pl + 15) >> 4);
+    meta[i].t_woff = (uint32_t)woff; woff += (uint64_t)((tl + 15) >> 4);
+    meta[i].plen = pl; meta[i].tlen = tl;
+    if (woff > 0xFFFFFFF0ull) { al->err = "batch too large: more than 2^32 packed words (split the batch)"; return WFA_HIP_EINVAL; }
+    b->max_width = std::max(b->max_width, pl + tl + 3);
+    b->max_len = std::max(b->max_len, std::max(pl, tl));
+    b->packed_bytes += (int64_t)((pl + 3) >> 2) + ((tl + 3) >> 2);
+    b->ops_bytes += (int64_t)pl + tl;
+    blob_end = std::max(blob_end, std::max(p_off[i] + pl, t_off[i] + tl));
+  }
+  const bool full = (c.scope == WFA_SCOPE_FULL);
+  const size_t nn = (size_t)std::max<int64_t>(n, 1);
+  HIP_TRY(al, hipMalloc((void**)&b->d_bytes, (size_t)blob_end + 64));
+  HIP_TRY(al, hipMalloc((void**)&b->d_pboff, nn * sizeof(int64_t)));
+  HIP_TRY(al, hipMalloc((void**)&b->d_tboff, nn * sizeof(int64_t)));
+  HIP_TRY(al, hipMalloc((void**)&b->d_meta, nn * sizeof(WfaPairMeta)));
+  HIP_TRY(al, hipMalloc((void**)&b->d_words, ((size_t)woff + 4) * sizeof(uint32_t)));
+  HIP_TRY(al, hipMalloc((void**)&b->d_flags, nn));
+  HIP_TRY(al, hipMalloc((void**)&b->d_score, nn * sizeof(int32_t)));
+  HIP_TRY(al, hipMalloc((void**)&b->d_status, nn * sizeof(int32_t)));
+  HIP_TRY(al, hipMalloc((void**)&b->d_fb_list, nn * sizeof(uint32_t)));
+  HIP_TRY(al, hipMalloc((void**)&b->d_counters, 16 * sizeof(uint32_t)));
+  HIP_TRY(al, hipMemsetAsync(b->d_counters, 0, 16 * sizeof(uint32_t), al->stream));
+  HIP_TRY(al, hipMemsetAsync(b->d_flags, 0, nn, al->stream));
+  HIP_TRY(al, hipMemsetAsync(b->d_words + woff, 0, 4 * sizeof(uint32_t), al->stream));
+  if (full) {
+    std::vector<int64_t> coff((size_t)n + 1);
+    coff[0] = 0;
+    for (int64_t i = 0; i < n; ++i) coff[i + 1] = coff[i] + p_len[i] + t_len[i];
+    HIP_TRY(al, hipMalloc((void**)&b->d_ops, (size_t)std::max<int64_t>(b->ops_bytes, 1)));
+    HIP_TRY(al, hipMalloc((void**)&b->d_cigar_off, ((size_t)n + 1) * sizeof(int64_t)));
+    HIP_TRY(al, hipMalloc((void**)&b->d_cigar_begin, nn * sizeof(int64_t)));
+    HIP_TRY(al, hipMalloc((void**)&b->d_cigar_len, nn * sizeof(int32_t)));
+    HIP_TRY(al, hipMalloc((void**)&b->d_ovf_list[0], nn * sizeof(uint32_t)));
+    HIP_TRY(al, hipMalloc((void**)&b->d_ovf_list[1], nn * sizeof(uint32_t)));
+    HIP_TRY(al, hipMemcpyAsync(b->d_cigar_off, coff.data(), ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, al->stream));
+    HIP_TRY(al, hipStreamSynchronize(al->stream));  // coff is a local
+  }
+  if (n > 0) {
+    HIP_TRY(al, hipMemcpyAsync(b->d_bytes, seqs, (size_t)blob_end, hipMemcpyHostToDevice, al->stream));
+    HIP_TRY(al, hipMemcpyAsync(b->d_pboff, p_off, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, al->stream));
+    HIP_TRY(al, hipMemcpyAsync(b->d_tboff, t_off, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, al->stream));
+    HIP_TRY(al, hipMemcpyAsync(b->d_meta, meta.data(), (size_t)n * sizeof(WfaPairMeta), hipMemcpyHostToDevice, al->stream));
+    const int threads = 256;
+    const int64_t want = (n + 3) / 4;  // 4 waves (pairs) per workgroup
+    const int grid = (int)std::min<int64_t>(want, (int64_t)al->cu_count * 16);
+    hipLaunchKernelGGL(wfa::wfa_pack_kernel, dim3(grid), dim3(threads), 0, al->stream,
+                       b->d_bytes, b->d_pboff, b->d_tboff, b->d_meta, n, b->d_words, b->d_flags);
+    HIP_TRY(al, hipGetLastError());
+    std::vector<uint8_t> flags((size_t)n);
+    HIP_TRY(al, hipMemcpyAsync(flags.data(), b->d_flags, (size_t)n, hipMemcpyDeviceToHost, al->stream));
+    HIP_TRY(al, hipStreamSynchronize(al->stream));
+    // split into the 2-bit and the 8-bit work lists (wildcard matching needs the bytes)
+    std::vector<uint32_t> lp, lb;
+    if (c.wildcard >= 0) {
+      lb.resize((size_t)n);
+      for (int64_t i = 0; i < n; ++i) lb[i] = (uint32_t)i;
+    } else {
+      int64_t nbad = 0;
+      for (int64_t i = 0; i < n; ++i) nbad += flags[i];
+      if (nbad) {
+        lp.reserve((size_t)(n - nbad)); lb.reserve((size_t)nbad);
+        for (int64_t i = 0; i < n; ++i) (flags[i] ? lb : lp).push_back((uint32_t)i);
+      }
+    }
+    b->n_bytes = (uint32_t)lb.size();
+    b->n_packed = (uint32_t)(lb.empty() ? n : lp.size());
+    if (!lb.empty()) {
+      HIP_TRY(al, hipMalloc((void**)&b->d_list_bytes, lb.size() * sizeof(uint32_t)));
+      HIP_TRY(al, hipMemcpy(b->d_list_bytes, lb.data(), lb.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      if (!lp.empty()) {
+        HIP_TRY(al, hipMalloc((void**)&b->d_list_packed, lp.size() * sizeof(uint32_t)));
+        HIP_TRY(al, hipMemcpy(b->d_list_packed, lp.data(), lp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      }
+    } else {
+      // every pair is pure ACGT: the ASCII blob is no longer needed
+      (void)hipFree(b->d_bytes); b->d_bytes = nullptr;
+    }
+  }
+  HIP_TRY(al, hipEventCreate(&b->ev0));
+  HIP_TRY(al, hipEventCreate(&b->ev1));
+  return WFA_HIP_OK;
+}
+
+extern "C" wfa_hip_batch_t* wfa_hip_batch_create(wfa_hip_aligner_t* al, int64_t n, const uint8_t* seqs,
+                                                 const int64_t* p_off, const int32_t* p_len,
+                                                 const int64_t* t_off, const int32_t* t_len) {
+  if (!al) { g_error = "null aligner"; return nullptr; }
+  if (n < 0 || n > 0x7FFFFFF0ll || (n > 0 && (!seqs || !p_off || !p_len || !t_off || !t_len))) {
+    al->err = "invalid batch arguments"; g_error = al->err; return nullptr;
+  }
+  if (hipSetDevice(al->device) != hipSuccess) { al->err = "hipSetDevice failed"; g_error = al->err; return nullptr; }
+  wfa_hip_batch* b = new wfa_hip_batch();
+  b->al = al;
+  const int rc = batch_build(al, b, n, seqs, p_off, p_len, t_off, t_len);
+  if (rc != WFA_HIP_OK) { g_error = al->err; batch_free(b); return nullptr; }
+  return b;
+}
+
+// ---- launch geometry -------------------------------------------------------------------------------
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+static int ensure_ws(wfa_hip_aligner* al, size_t bytes) {
+  if (bytes <= al->ws_bytes) return WFA_HIP_OK;
+  if (al->ws) { (void)hipFree(al->ws); al->ws = nullptr; al->ws_bytes = 0; }
+  HIP_TRY(al, hipMalloc((void**)&al->ws, bytes));
+  al->ws_bytes = bytes;
+  return WFA_HIP_OK;
+}
+
+template <int NCOMP, bool FULL>
+static int launch_general(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream, bool packed,
+                          const uint32_t* worklist, const uint32_t* nwork_dev, uint32_t nwork_host,
+                          int64_t ws_stride, int grid, int threads, uint32_t* ovf_list, uint32_t* ovf_count) {
+  WfaKernelArgs a;
+  memset(&a, 0, sizeof(a));
+  a.words = b->d_words; a.bytes = b->d_bytes; a.meta = b->d_meta; a.p_boff = b->d_pboff; a.t_boff = b->d_tboff;
+  a.worklist = worklist; a.nwork_dev = nwork_dev; a.nwork = nwork_host;
+  a.score = b->d_score; a.status = b->d_status;
+  a.cigar_ops = b->d_ops; a.cigar_off = b->d_cigar_off; a.cigar_begin = b->d_cigar_begin; a.cigar_len = b->d_cigar_len;
+  a.ws = al->ws; a.ws_stride = ws_stride;
+  a.fb_list = ovf_list; a.fb_count = ovf_count;
+  a.cfg = al->dcfg;
+  const size_t smem = ((size_t)al->dcfg.scope * wfa::Meta<NCOMP>::INTS + 2 * NCOMP + 8) * sizeof(int);
+  if (packed) hipLaunchKernelGGL((wfa::wfa_general_kernel<NCOMP, true, FULL>), dim3(grid), dim3(threads), smem, stream, a);
+  else hipLaunchKernelGGL((wfa::wfa_general_kernel<NCOMP, false, FULL>), dim3(grid), dim3(threads), smem, stream, a);
+  HIP_TRY(al, hipGetLastError());
+  return WFA_HIP_OK;
+}
+
+static int launch_general_dyn(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream, bool packed,
+                              const uint32_t* worklist, const uint32_t* nwork_dev, uint32_t nwork_host,
+                              int64_t ws_stride, int grid, int threads, uint32_t* ovf_list, uint32_t* ovf_count) {
+  const bool full = (al->cfg.scope == WFA_SCOPE_FULL);
+  if (al->ncomp == 3) {
+    return full ? launch_general<3, true>(al, b, stream, packed, worklist, nwork_dev, nwork_host, ws_stride, grid, threads, ovf_list, ovf_count)
+                : launch_general<3, false>(al, b, stream, packed, worklist, nwork_dev, nwork_host, ws_stride, grid, threads, ovf_list, ovf_count);
+  }
+  return full ? launch_general<5, true>(al, b, stream, packed, worklist, nwork_dev, nwork_host, ws_stride, grid, threads, ovf_list, ovf_count)
+              : launch_general<5, false>(al, b, stream, packed, worklist, nwork_dev, nwork_host, ws_stride, grid, threads, ovf_list, ovf_count);
+}
+
+// Geometry of the general kernel: threads per alignment, workgroups in flight, workspace per workgroup.
+struct Geometry { int threads; int grid; int64_t ws_stride; };
+
+static int64_t free_budget(wfa_hip_aligner* al) {
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = al->total_mem / 2;
+  // what we already hold as workspace can be re-used
+  return (int64_t)((double)(fr + al->ws_bytes) * 0.8);
+}
+
+static Geometry plan_general(wfa_hip_aligner* al, const wfa_hip_batch* b, uint32_t nwork, int64_t arena_ints) {
+  Geometry g;
+  const bool full = (al->cfg.scope == WFA_SCOPE_FULL);
+  int threads = 64;
+  if (b->max_len > 2000) threads = (al->cfg.heuristic == WFA_HEUR_ADAPTIVE) ? 128 : 256;
+  threads = env_int("WFA_HIP_THREADS", threads);
+  threads = std::max(64, std::min(512, (threads / 64) * 64));
+  const int waves = threads / 64;
+  int per_cu = std::max(1, env_int("WFA_HIP_WAVES_PER_CU", 16) / waves);
+  int64_t grid = (int64_t)al->cu_count * per_cu;
+  grid = std::min<int64_t>(grid, std::max<uint32_t>(nwork, 1));
+  int64_t stride;
+  if (full) stride = arena_ints;
+  else stride = (int64_t)al->dcfg.scope * al->ncomp * b->max_width;
+  stride = (stride + 63) & ~63ll;
+  const int64_t budget = free_budget(al);
+  while (grid > 1 && grid * stride * 4 > budget) grid = (grid + 1) / 2;
+  g.threads = threads; g.grid = (int)grid; g.ws_stride = stride;
+  return g;
+}
+
+static int64_t initial_arena_ints(const wfa_hip_aligner* al, const wfa_hip_batch* b) {
+  typedef long long ll;
+  const int mi = 2 * al->ncomp + 4;
+  // room for a run whose score is ~ the longer sequence and whose wavefronts are ~128 wide, and never
+  // less than what wavefront 0 and a few hundred scores need; overflowing pairs are re-run larger
+  ll ints = (ll)b->max_len * (al->ncomp * 64 + mi) / 4 + (ll)b->max_width * al->ncomp * 4 + 4096 * mi;
+  ints = std::max<ll>(ints, 1 << 14);
+  const int e = env_int("WFA_HIP_ARENA_KB", 0);
+  if (e > 0) ints = (ll)e * 256;
+  return ints;
+}
+
+extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
+  if (!b) return WFA_HIP_EINVAL;
+  wfa_hip_aligner* al = b->al;
+  HIP_TRY(al, hipSetDevice(al->device));
+  hipStream_t stream = stream_ ? (hipStream_t)stream_ : al->stream;
+  b->last_stream = stream;
+  b->ran = true; b->synced = false;
+  b->last_fallback = 0;
+  b->last_kernel_pairs = 0;
+  if (b->n == 0) { b->synced = true; return WFA_HIP_OK; }
+  const bool full = (al->cfg.scope == WFA_SCOPE_FULL);
+  HIP_TRY(al, hipMemsetAsync(b->d_counters, 0, 16 * sizeof(uint32_t), stream));
+  b->arena_ints = full ? initial_arena_ints(al, b) : 0;
+
+  // 1) the fast register-resident kernel takes the 2-bit pairs it supports; what does not fit its
+  //    diagonal window is appended to d_fb_list and finished by the general kernel below.
+  const bool use_fast = wfa::fast_supported(al->dcfg, al->ncomp, full) && b->n_packed > 0 && env_int("WFA_HIP_NO_FAST", 0) == 0;
+  HIP_TRY(al, hipEventRecord(b->ev0, stream));
+  if (use_fast) {
+    const int rc = wfa::launch_fast(al->dcfg, al->cu_count, stream, b->d_words, b->d_meta, b->d_list_packed, b->n_packed,
+                                    b->d_score, b->d_status, b->d_fb_list, b->d_counters + 0);
+    if (rc != 0) { al->err = "fast kernel launch failed"; return WFA_HIP_EDEVICE; }
+    b->last_kernel_pairs = b->n_packed;
+  }
+  // 2) general kernel over the 2-bit work list (or over the fast kernel's leftovers)
+  if (b->n_packed > 0) {
+    const uint32_t nwork = b->n_packed;
+    Geometry g = plan_general(al, b, use_fast ? std::min<uint32_t>(nwork, (uint32_t)al->cu_count * 16) : nwork, b->arena_ints);
+    int rc = ensure_ws(al, (size_t)g.grid * g.ws_stride * 4);
+    if (rc != WFA_HIP_OK) return rc;
+    if (use_fast) {
+      rc = launch_general_dyn(al, b, stream, true, b->d_fb_list, b->d_counters + 0, 0, g.ws_stride, g.grid, g.threads,
+                              b->d_ovf_list[0], b->d_counters + 1);
+    } else {
+      rc = launch_general_dyn(al, b, stream, true, b->d_list_packed, nullptr, nwork, g.ws_stride, g.grid, g.threads,
+                              b->d_ovf_list[0], b->d_counters + 1);
+      b->last_kernel_pairs = nwork;
+    }
+    if (rc != WFA_HIP_OK) return rc;
+  }
+  HIP_TRY(al, hipEventRecord(b->ev1, stream));
+  // 3) 8-bit pairs (non-ACGT letters, wildcard matching)
+  if (b->n_bytes > 0) {
+    Geometry g = plan_general(al, b, b->n_bytes, b->arena_ints);
+    int rc = ensure_ws(al, (size_t)g.grid * g.ws_stride * 4);
+    if (rc != WFA_HIP_OK) return rc;
+    rc = launch_general_dyn(al, b, stream, false, b->d_list_bytes, nullptr, b->n_bytes, g.ws_stride, g.grid, g.threads,
+                            b->d_ovf_list[0], b->d_counters + 1);
+    if (rc != WFA_HIP_OK) return rc;
+  }
+  return WFA_HIP_OK;
+}
+
+// Re-run the pairs whose arena overflowed with an 8x larger arena (fewer workgroups in flight), until
+// none is left or the arena no longer fits the device: those get WF_STATUS_OOM (-200, wfa.h:50).
+static int retry_overflows(wfa_hip_batch* b) {
+  wfa_hip_aligner* al = b->al;
+  hipStream_t stream = b->last_stream;
+  int cur = 0;
+  for (int round = 0; round < 12; ++round) {
+    uint32_t novf = 0;
+    HIP_TRY(al, hipMemcpy(&novf, b->d_counters + 1 + cur, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (novf == 0) return WFA_HIP_OK;
+    std::vector<uint32_t> ids(novf);
+    HIP_TRY(al, hipMemcpy(ids.data(), b->d_ovf_list[cur], novf * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> flags((size_t)b->n, 0);
+    if (b->n_bytes) HIP_TRY(al, hipMemcpy(flags.data(), b->d_flags, (size_t)b->n, hipMemcpyDeviceToHost));
+    const bool all_bytes = (al->cfg.wildcard >= 0);
+    std::vector<uint32_t> lp, lb;
+    for (uint32_t id : ids) ((all_bytes || flags[id]) ? lb : lp).push_back(id);
+    b->arena_ints *= 8;
+    const int nxt = cur ^ 1;
+    HIP_TRY(al, hipMemset(b->d_counters + 1 + nxt, 0, sizeof(uint32_t)));
+    const int64_t budget = free_budget(al);
+    if (b->arena_ints * 4 > budget) {
+      // cannot grow further: report OOM for these pairs
+      std::vector<int32_t> st(1, WFA_STATUS_OOM), sc(1, INT_MIN);
+      for (uint32_t id : ids) {
+        HIP_TRY(al, hipMemcpy(b->d_status + id, st.data(), 4, hipMemcpyHostToDevice));
+        HIP_TRY(al, hipMemcpy(b->d_score + id, sc.data(), 4, hipMemcpyHostToDevice));
+        if (b->d_cigar_len) HIP_TRY(al, hipMemset(b->d_cigar_len + id, 0, 4));
+      }
+      return WFA_HIP_OK;
+    }
+    for (int kind = 0; kind < 2; ++kind) {
+      std::vector<uint32_t>& l = kind ? lb : lp;
+      if (l.empty()) continue;
+      uint32_t* d_l = b->d_fb_list;  // free to reuse: the first pass is complete
+      HIP_TRY(al, hipMemcpy(d_l, l.data(), l.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      Geometry g = plan_general(al, b, (uint32_t)l.size(), b->arena_ints);
+      int rc = ensure_ws(al, (size_t)g.grid * g.ws_stride * 4);
+      if (rc != WFA_HIP_OK) return rc;
+      rc = launch_general_dyn(al, b, stream, kind == 0, d_l, nullptr, (uint32_t)l.size(), g.ws_stride, g.grid, g.threads,
+                              b->d_ovf_list[nxt], b->d_counters + 1 + nxt);
+      if (rc != WFA_HIP_OK) return rc;
+      HIP_TRY(al, hipStreamSynchronize(stream));
+    }
+    cur = nxt;
+  }
+  al->err = "arena overflow retries exhausted";
+  return WFA_HIP_EDEVICE;
+}
+
+extern "C" int wfa_hip_batch_sync(wfa_hip_batch_t* b) {
+  if (!b) return WFA_HIP_EINVAL;
+  wfa_hip_aligner* al = b->al;
+  if (!b->ran || b->synced) return WFA_HIP_OK;
+  HIP_TRY(al, hipSetDevice(al->device));
+  HIP_TRY(al, hipStreamSynchronize(b->last_stream));
+  if (b->n > 0) {
+    HIP_TRY(al, hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1));
+    uint32_t fb = 0;
+    HIP_TRY(al, hipMemcpy(&fb, b->d_counters, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    b->last_fallback = fb;
+    if (al->cfg.scope == WFA_SCOPE_FULL) {
+      const int rc = retry_overflows(b);
+      if (rc != WFA_HIP_OK) return rc;
+    }
+  }
+  b->synced = true;
+  return WFA_HIP_OK;
+}
+
+extern "C" int wfa_hip_batch_results(wfa_hip_batch_t* b, int32_t* score, int32_t* status, uint8_t* cigar_ops,
+                                     const int64_t* cigar_off, int64_t* cigar_begin, int32_t* cigar_len) {
+  if (!b) return WFA_HIP_EINVAL;
+  wfa_hip_aligner* al = b->al;
+  int rc = wfa_hip_batch_sync(b);
+  if (rc != WFA_HIP_OK) return rc;
+  const int64_t n = b->n;
+  if (n == 0) return WFA_HIP_OK;
+  if (!score || !status) { al->err = "score/status outputs are required"; return WFA_HIP_EINVAL; }
+  HIP_TRY(al, hipMemcpy(score, b->d_score, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(al, hipMemcpy(status, b->d_status, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  const bool full = (al->cfg.scope == WFA_SCOPE_FULL);
+  if (cigar_len) {
+    if (full) HIP_TRY(al, hipMemcpy(cigar_len, b->d_cigar_len, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    else memset(cigar_len, 0, (size_t)n * sizeof(int32_t));
+  }
+  if (cigar_begin) {
+    if (full) HIP_TRY(al, hipMemcpy(cigar_begin, b->d_cigar_begin, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost));
+    else memset(cigar_begin, 0, (size_t)n * sizeof(int64_t));
+  }
+  if (full && cigar_ops) {
+    if (!cigar_off || !cigar_begin || !cigar_len) { al->err = "cigar_off/cigar_begin/cigar_len are required with cigar_ops"; return WFA_HIP_EINVAL; }
+    // the device regions are laid out back to back in pair order (plen+tlen bytes each); the caller's
+    // regions may be spaced differently: copy whole, then re-base per pair when they differ
+    bool same = true;
+    int64_t acc = 0;
+    for (int64_t i = 0; i < n && same; ++i) { same = (cigar_off[i] == acc); acc += b->h_plen[i] + b->h_tlen[i]; }
+    if (same) {
+      if (b->ops_bytes) HIP_TRY(al, hipMemcpy(cigar_ops, b->d_ops, (size_t)b->ops_bytes, hipMemcpyDeviceToHost));
+    } else {
+      std::vector<uint8_t> tmp((size_t)std::max<int64_t>(b->ops_bytes, 1));
+      if (b->ops_bytes) HIP_TRY(al, hipMemcpy(tmp.data(), b->d_ops, (size_t)b->ops_bytes, hipMemcpyDeviceToHost));
+      acc = 0;
+      for (int64_t i = 0; i < n; ++i) {
+        const int64_t cap = (int64_t)b->h_plen[i] + b->h_tlen[i];
+        const int64_t rel = cigar_begin[i] - acc;
+        if (cigar_len[i] > 0) memcpy(cigar_ops + cigar_off[i] + rel, tmp.data() + cigar_begin[i], (size_t)cigar_len[i]);
+        cigar_begin[i] = cigar_off[i] + rel;
+        acc += cap;
+      }
+    }
+  }
+  return WFA_HIP_OK;
+}
+
+extern "C" int wfa_hip_batch_last_kernel_ms(wfa_hip_batch_t* b, float* ms, int64_t* pairs) {
+  if (!b) return WFA_HIP_EINVAL;
+  const int rc = wfa_hip_batch_sync(b);
+  if (rc != WFA_HIP_OK) return rc;
+  if (ms) *ms = b->last_ms;
+  if (pairs) *pairs = b->last_kernel_pairs;
+  return WFA_HIP_OK;
+}
+
+extern "C" int64_t wfa_hip_batch_algorithmic_bytes(const wfa_hip_batch_t* b) {
+  if (!b) return 0;
+  int64_t bytes = b->packed_bytes + 8 * b->n;
+  if (b->al->cfg.scope == WFA_SCOPE_FULL) bytes += b->ops_bytes;
+  return bytes;
+}
+
+extern "C" int64_t wfa_hip_batch_fallback_pairs(const wfa_hip_batch_t* b) { return b ? b->last_fallback : 0; }
+
+extern "C" int wfa_hip_align_batch(wfa_hip_aligner_t* al, int64_t n, const uint8_t* seqs,
+                                   const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len,
+                                   int32_t* score, int32_t* status, uint8_t* cigar_ops, const int64_t* cigar_off,
+                                   int64_t* cigar_begin, int32_t* cigar_len) {
+  if (!al) return WFA_HIP_EINVAL;
+  wfa_hip_batch_t* b = wfa_hip_batch_create(al, n, seqs, p_off, p_len, t_off, t_len);
+  if (!b) return (al->err.find("failed:") != std::string::npos) ? WFA_HIP_EDEVICE : WFA_HIP_EINVAL;
+  int rc = wfa_hip_batch_run(b, nullptr);
+  if (rc == WFA_HIP_OK) rc = wfa_hip_batch_results(b, score, status, cigar_ops, cigar_off, cigar_begin, cigar_len);
+  wfa_hip_batch_destroy(b);
+  return rc;
+}
