@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py — pairwise alignments/s of the batched wavefront-alignment hot path on MI355X.
+
+Workload (BASELINE.json configs[1], "C2"): 10 M x 150 bp synthetic short-read pairs at 2 % error
+(seed 1002), gap-affine 0/4/6/2, end-to-end, scope=score.  One "step" = one pass of the alignment
+kernels over the whole batch, with the 2-bit packed sequences already resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P]
+
+N > 1: launched by torch.distributed.run, one rank per GPU; every rank aligns its own P pairs (weak
+scaling, pairs are independent: no collective on the data path); barrier + device sync on both sides
+of the timed region, MAX over ranks, rank 0 prints ONE JSON line.  Extra keys: "roofline" (HBM, from
+HIP events around the kernels on their stream) and "cpu_baseline" (the real WFA2-lib from oracle/_ref
+when present, else the C restatement, on a bounded sample, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(batch, cfg_kw, budget_s=12.0):
+    """Time the CPU reference on a bounded prefix of the same workload (1 thread)."""
+    from oracle import loader
+    from pywfa_amd import datagen
+    if loader.have_reference():
+        fn, kind = loader.reference(), "reference"
+    else:
+        fn, kind = loader.oracle(), "port"
+    cfg = loader.make_config(**cfg_kw)
+    n_all = len(batch["p_len"])
+    probe = min(n_all, 100000)
+    t0 = time.perf_counter()
+    loader.run(fn, cfg, datagen.subset(batch, np.arange(probe)), want_cigar=False)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    n = int(min(n_all, max(probe, budget_s * probe / dt)))
+    t0 = time.perf_counter()
+    loader.run(fn, cfg, datagen.subset(batch, np.arange(n)), want_cigar=False)
+    dt = time.perf_counter() - t0
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": n / dt, "unit": "alignments/s", "cores": 1, "kind": kind,
+            "sample": f"first {n} pairs of the same batch, 1 thread, {dt:.1f} s; host CPU: {model} ({os.cpu_count()} logical cores)",
+            "library": os.path.basename(loader.reference_path() or "liboracle.so")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=10_000_000, help="pairs per GPU")
+    ap.add_argument("--length", type=int, default=150)
+    ap.add_argument("--error", type=float, default=0.02)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world
+
+    from pywfa_amd import _native, datagen
+
+    cfg_kw = dict(distance="affine", match=0, mismatch=4, gap_opening=6, gap_extension=2,
+                  span="end-to-end", scope="score")
+    cfg = _native.default_config()
+    cfg.span, cfg.scope = _native.SPAN["end-to-end"], _native.SCOPE["score"]
+
+    # each rank owns the pairs [rank*P, (rank+1)*P) of the seed-1002 stream (weak scaling)
+    t0 = time.perf_counter()
+    batch = datagen.generate(args.pairs, args.length, args.error, datagen.SEEDS["C2"], first=rank * args.pairs)
+    t_gen = time.perf_counter() - t0
+
+    al = _native.Aligner(cfg, device=local_rank)
+    t0 = time.perf_counter()
+    rb = al.batch(batch)  # H2D + 2-bit pack: untimed, inputs are resident before the clock starts
+    t_upload = time.perf_counter() - t0
+
+    def barrier():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        rb.run()
+    rb.sync()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rb.run()
+    rb.sync()  # device sync of the stream the kernels run on
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, kernel_pairs = rb.last_kernel()  # mean HIP-event time per step over the timed steps
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    score, status, _ = rb.results(False)
+    alg_bytes = rb.algorithmic_bytes()
+    fallback = rb.fallback_pairs()
+    # PCIe-inclusive rate (host ASCII in -> host results out), reported beside the resident figure
+    t0 = time.perf_counter()
+    s2, st2, _ = al.align_batch(batch, False)
+    t_e2e = time.perf_counter() - t0
+    assert np.array_equal(s2, score)
+    rb.close()
+    al.close()
+
+    if rank == 0:
+        total_pairs = args.pairs * n_gpus * args.steps
+        value = total_pairs / elapsed
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        out = {
+            "metric": "pairwise alignments/sec",
+            "value": value,
+            "unit": "alignments/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {"workload": f"C2: {args.pairs} x {args.length}bp pairs per GPU, {args.error * 100:g}% error (seed 1002), "
+                                   "gap-affine 0/4/6/2, end-to-end, scope=score, 2-bit packed sequences resident in HBM",
+                       "pairs_per_gpu": args.pairs, "read_length": args.length, "parallelism": f"pairs sharded over {n_gpus} GPU(s), no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_pair": alg_bytes / max(args.pairs, 1),
+                         "kernel_ms": kernel_ms, "kernel": "wfa alignment kernels of one step (HIP events on the launch stream)"},
+            "extra": {"mean_score": float(score.mean()), "completed": int((status == 0).sum()),
+                      "fallback_pairs": int(fallback), "datagen_s": t_gen, "upload_pack_s": t_upload,
+                      "pcie_inclusive_alignments_per_s": args.pairs / t_e2e},
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(batch, cfg_kw)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -172,8 +172,9 @@ int wfa_hip_batch_sync(wfa_hip_batch_t* batch);
 int wfa_hip_batch_results(wfa_hip_batch_t* batch, int32_t* score, int32_t* status,
                           uint8_t* cigar_ops, const int64_t* cigar_off,
                           int64_t* cigar_begin, int32_t* cigar_len);
-/* HIP-event time (ms) of the dominant alignment kernel in the last run, and the number of
- * pairs that kernel processed (for bench.py's roofline line). */
+/* Mean HIP-event time (ms) per run of the alignment kernels, over the runs enqueued since the
+ * previous sync (events are recorded on the stream the kernels are launched on), and the number of
+ * pairs one run hands to the dominant kernel (for bench.py's roofline line). */
 int wfa_hip_batch_last_kernel_ms(wfa_hip_batch_t* batch, float* ms, int64_t* pairs);
 /* Algorithmic HBM bytes of one run: 2-bit packed sequence bytes + 8 result bytes per pair
  * (+ CIGAR op bytes for scope=full), SURVEY.md §8(d). */

@@ -161,3 +161,21 @@ def run(fn, cfg, batch, want_cigar=None):
     if want_cigar:
         cigars = [ops[cbeg[i]:cbeg[i] + clen[i]].tobytes() for i in range(n)]
     return {"score": score, "status": status, "cigars": cigars}
+
+
+def check_cigars(cfg, batch, score, ops, cbeg, clen, check_score=True):
+    """Property check of GPU transcripts (see wfa_oracle_check_cigars). Returns (n_bad, first_bad)."""
+    oracle()
+    lib = ctypes.CDLL(os.path.join(HERE, "liboracle.so"))
+    fn = lib.wfa_oracle_check_cigars
+    fn.restype = ctypes.c_int64
+    fn.argtypes = [ctypes.POINTER(Config), ctypes.c_int64] + [ctypes.c_void_p] * 9 + [ctypes.c_int, ctypes.c_void_p]
+    first = ctypes.c_int64(-1)
+    seqs = np.ascontiguousarray(batch["seqs"], dtype=np.uint8)
+    arrs = [np.ascontiguousarray(batch["p_off"], np.int64), np.ascontiguousarray(batch["p_len"], np.int32),
+            np.ascontiguousarray(batch["t_off"], np.int64), np.ascontiguousarray(batch["t_len"], np.int32),
+            np.ascontiguousarray(score, np.int32), np.ascontiguousarray(ops, np.uint8),
+            np.ascontiguousarray(cbeg, np.int64), np.ascontiguousarray(clen, np.int32)]
+    bad = fn(ctypes.byref(cfg), len(arrs[1]), _ptr(seqs), *[_ptr(a) for a in arrs], 1 if check_score else 0,
+             ctypes.byref(first))
+    return int(bad), int(first.value)

@@ -676,3 +676,61 @@ int wfa_oracle_align_batch(const wfa_hip_config_t* cfg, int64_t n, const uint8_t
   ws_free(&ws);
   return rc;
 }
+
+/*
+ * Size-independent property check used by the full-size GPU tests: for every pair the op string
+ * must be a valid transcript (M on equal bytes, X on different bytes, I/D consume text/pattern,
+ * both sequences fully consumed) and, for end-to-end alignments with match == 0, the gap-affine
+ * (or 2-piece) penalty of the transcript must equal -score (cigar_score_gap_affine semantics,
+ * R/alignment/cigar.c).  Returns the number of failing pairs; first_bad receives the first index.
+ */
+int64_t wfa_oracle_check_cigars(const wfa_hip_config_t* cfg, int64_t n, const uint8_t* seqs,
+                                const int64_t* p_off, const int32_t* p_len,
+                                const int64_t* t_off, const int32_t* t_len,
+                                const int32_t* score, const uint8_t* cigar_ops,
+                                const int64_t* cigar_begin, const int32_t* cigar_len,
+                                int check_score, int64_t* first_bad) {
+  const int two = (cfg->distance == WFA_DIST_AFFINE2P);
+  int64_t bad = 0, i;
+  if (first_bad) *first_bad = -1;
+  for (i = 0; i < n; ++i) {
+    const uint8_t* P = seqs + p_off[i];
+    const uint8_t* T = seqs + t_off[i];
+    const uint8_t* ops = cigar_ops + cigar_begin[i];
+    const int len = cigar_len[i];
+    int v = 0, h = 0, ok = 1, j = 0;
+    int64_t pen = 0;
+    while (j < len && ok) {
+      const uint8_t op = ops[j];
+      int run = 1;
+      while (j + run < len && ops[j + run] == op) ++run;
+      int r;
+      switch (op) {
+        case 'M':
+          for (r = 0; r < run; ++r) { if (v >= p_len[i] || h >= t_len[i] || P[v] != T[h]) { ok = 0; break; } ++v; ++h; }
+          break;
+        case 'X':
+          for (r = 0; r < run; ++r) { if (v >= p_len[i] || h >= t_len[i] || P[v] == T[h]) { ok = 0; break; } ++v; ++h; }
+          pen += (int64_t)cfg->mismatch * run;
+          break;
+        case 'I':
+        case 'D': {
+          int64_t g = cfg->gap_opening + (int64_t)cfg->gap_extension * run;
+          if (two) {
+            const int64_t g2 = cfg->gap_opening2 + (int64_t)cfg->gap_extension2 * run;
+            if (g2 < g) g = g2;
+          }
+          pen += g;
+          if (op == 'I') h += run; else v += run;
+          break;
+        }
+        default: ok = 0;
+      }
+      j += run;
+    }
+    if (ok && (v != p_len[i] || h != t_len[i])) ok = 0;
+    if (ok && check_score && pen != -(int64_t)score[i]) ok = 0;
+    if (!ok) { if (!bad && first_bad) *first_bad = i; ++bad; }
+  }
+  return bad;
+}

@@ -1,0 +1,533 @@
+"""Host-side mirror of pywfa's interface for the wavefront-alignment hot path.
+
+``WavefrontAligner`` keeps the constructor kwargs, methods, properties, exceptions and result
+objects of pywfa's Cython class (/root/reference/pywfa/align.pyx:306-883) and adds batch forms
+(``wavefront_align_batch`` / ``align_batch``).  Every alignment — single pair or batch — runs on the
+GPU through the C ABI of ``libwfa_hip.so`` (include/wfa_hip.h); there is no CPU path in this package
+and constructing an aligner fails loudly when the library or a HIP device is missing.
+
+Deliberate deviations from the reference (DESIGN.md §"Deviations"):
+  * invalid penalties / ends-free sizes raise ``ValueError`` where WFA2-lib calls ``exit(1)``
+    (wavefront_penalties.c:101-112, wavefront_align.c:95-101);
+  * ``distance`` indel / levenshtein / linear and ``memory_mode="biwfa"`` raise
+    ``NotImplementedError`` (outside this path);
+  * property setters re-derive the whole native configuration (the reference pokes single C fields
+    and leaves derived state stale).
+"""
+import sys
+
+import numpy as np
+
+from . import _native
+from . import datagen
+
+__all__ = ["WavefrontAligner", "AlignmentResult", "clip_cigartuples", "cigartuples_to_str",
+           "elide_mismatches_from_cigar"]
+
+# CIGAR tuple codes (align.pyx:11-14, README.rst:61-86): M I D N S H P = X B
+_OP_CODE = {ord("M"): 0, ord("I"): 1, ord("D"): 2, ord("N"): 3, ord("S"): 4, ord("H"): 5,
+            ord("P"): 6, ord("="): 7, ord("X"): 8, ord("B"): 9}
+_OP_CHARS = "MIDNSHP=XB"
+_INT_MAX = 2147483647
+
+
+class AlignmentResult:
+    """Result object of ``WavefrontAligner.__call__`` (align.pyx:17-180)."""
+
+    def __init__(self, pl, tl, ps, pe, ts, te, ct, s, p, t, status):
+        self.pattern_length = pl
+        self.text_length = tl
+        self.pattern_start = ps
+        self.pattern_end = pe
+        self.text_start = ts
+        self.text_end = te
+        self.cigartuples = ct
+        self.score = s
+        self.pattern = p
+        self.text = t
+        self.status = status
+
+    def __repr__(self):
+        keys = ("score", "pattern_start", "pattern_end", "text_start", "text_end", "cigartuples",
+                "pattern", "text")
+        return "".join(f"    {k}: {self.__dict__[k]}\n" for k in keys)
+
+    def __str__(self):
+        score = "Score: %d" % self.score
+        if self.pattern and self.cigartuples:
+            t = self.aligned_text
+            p = self.aligned_pattern
+            if len(t) > 30:
+                t = t[:30] + "..."
+                p = p[:30] + "..."
+            c = self.cigarstring[:30]
+            return "\n".join([p, t, c, score, "Length: %d" % len(t)])
+        return score
+
+    def __eq__(self, other):
+        return isinstance(other, AlignmentResult) and self.__dict__ == other.__dict__
+
+    @staticmethod
+    def _aligned(sequence, tuples, begin, end, gap_type):
+        # The reference unpacks (op, length) tuples as (length, mid) and compares mid with "D"/"I"
+        # (align.pyx:168-180): the gap branch never fires and slices are
+        # taken with the op code as length.  Reproduced as is.
+        seq = sequence[begin:end]
+        parts = []
+        index = 0
+        for length, mid in tuples:
+            if mid == gap_type:
+                parts.append("-" * length)
+            else:
+                parts.append(seq[index:index + length])
+                index += length
+        parts.append(seq[index:end - begin])
+        return "".join(parts)
+
+    @property
+    def aligned_pattern(self):
+        if self.pattern:
+            return self._aligned(self.pattern, self.cigartuples, self.pattern_start, self.pattern_end, "D")
+        return None
+
+    @property
+    def aligned_text(self):
+        if self.text:
+            return self._aligned(self.text, self.cigartuples, self.text_start, self.text_end, "I")
+        return None
+
+    @property
+    def cigarstring(self):
+        return cigartuples_to_str(self.cigartuples)
+
+    @property
+    def pretty(self):
+        """Three-row view of the alignment (align.pyx:122-165)."""
+        compact = [i for i in self.cigartuples if i[0] != 0 and i[0] != [8]]
+        out = f"{self.cigarstring}      ALIGNMENT\n"
+        out += f"{cigartuples_to_str(compact)}      ALIGNMENT.COMPACT\n"
+        p, g, t = ["      PATTERN    "], ["                 "], ["      TEXT       "]
+        pat, txt = self.pattern, self.text
+        pi = ti = 0
+        for op, n in self.cigartuples:
+            if op in (1, 4, 5):
+                t.append(txt[ti:ti + n]); ti += n
+                p.append("-" * n); g.append(" " * n)
+            elif op in (0, 7):
+                t.append(txt[ti:ti + n]); ti += n
+                p.append(pat[pi:pi + n]); pi += n
+                g.append("|" * n)
+            elif op == 2:
+                t.append("-" * n)
+                p.append(pat[pi:pi + n]); pi += n
+                g.append(" " * n)
+            elif op == 8:
+                t.append(txt[ti:ti + n]); ti += n
+                p.append(pat[pi:pi + n]); pi += n
+                g.append("*" * n)
+            else:
+                raise ValueError(f"Cigar operation not available for pretty print - {op}")
+        return out + "".join(p) + "\n" + "".join(g) + "\n" + "".join(t) + "\n"
+
+
+def _flank_scan(ct, threshold_left, threshold_right, text_len, pattern_len):
+    """Shared scan of clip_cigartuples / locations: skip ops at both flanks until an M run of at
+    least the threshold (align.pyx:199-234, :797-831).  Returns (i, j, ps, pe, ts, te)."""
+    ts = ps = 0
+    i = 0
+    for i in range(len(ct)):
+        op, n = ct[i]
+        if op == 0:
+            if n >= threshold_left:
+                break
+            ts += n; ps += n
+        elif op == 2:
+            ps += n
+        elif op == 8:
+            ts += n; ps += n
+        elif op == 1:
+            ts += n
+    te, pe = text_len, pattern_len
+    j = len(ct) - 1
+    for j in range(len(ct) - 1, -1, -1):
+        op, n = ct[j]
+        if op == 0:
+            if n >= threshold_right:
+                break
+            te -= n; pe -= n
+        elif op == 2:
+            pe -= n
+        elif op == 8:
+            pe -= n; te -= n
+        elif op == 1:
+            te -= n
+    return i, j, ps, pe, ts, te
+
+
+def clip_cigartuples(align_result, min_aligned_bases_left=5, min_aligned_bases_right=5):
+    """Trim flanking blocks with fewer aligned bases than the thresholds into soft-clips
+    (align.pyx:183-250).  Mutates and returns ``align_result``; the score is not adjusted."""
+    ct = align_result.cigartuples
+    if not ct:
+        return align_result
+    i, j, ps, pe, ts, te = _flank_scan(ct, int(min_aligned_bases_left), int(min_aligned_bases_right),
+                                       align_result.text_length, align_result.pattern_length)
+    modified = []
+    if align_result.text_start + ts > 0:
+        modified.append((4, ts))
+    modified += ct[i:j + 1]
+    if align_result.text_length - te > 0:
+        modified.append((4, align_result.text_length - te))
+    align_result.cigartuples = modified
+    align_result.text_start, align_result.text_end = ts, te
+    align_result.pattern_start, align_result.pattern_end = ps, pe
+    return align_result
+
+
+def elide_mismatches_from_cigar(cigartuples):
+    """Merge adjacent M (0) and X (8) runs into single M runs (align.pyx:253-277)."""
+    if not cigartuples:
+        return []
+    out = []
+    block = 0
+    for op, n in cigartuples:
+        if op == 0 or op == 8:
+            block += n
+        else:
+            if block:
+                out.append((0, block))
+                block = 0
+            out.append((op, n))
+    if block:
+        out.append((0, block))
+    return out
+
+
+def cigartuples_to_str(cigartuples):
+    """``[(op, n), ...]`` -> ``"{n}{op}..."`` (align.pyx:280-295)."""
+    if not cigartuples:
+        return ""
+    return "".join(f"{int(n)}{_OP_CHARS[op]}" for op, n in cigartuples)
+
+
+def _rle(ops):
+    """Run-length encode a uint8 array of op chars -> (chars, lengths)."""
+    if ops.size == 0:
+        return ops, np.zeros(0, np.int64)
+    change = np.flatnonzero(ops[1:] != ops[:-1]) + 1
+    starts = np.concatenate(([0], change))
+    lengths = np.diff(np.concatenate((starts, [ops.size])))
+    return ops[starts], lengths
+
+
+def _ops_to_tuples(ops):
+    ch, ln = _rle(ops)
+    return [(_OP_CODE[int(c)], int(n)) for c, n in zip(ch, ln)]
+
+
+def _ops_to_string(ops):
+    ch, ln = _rle(ops)
+    return "".join(f"{int(n)}{chr(int(c))}" for c, n in zip(ch, ln))
+
+
+class WavefrontAligner:
+    """Drop-in for ``pywfa.WavefrontAligner`` on the GPU. If a pattern is supplied it is cached."""
+
+    def __init__(self, pattern=None, distance="affine", memory_mode="high", match=0, mismatch=4,
+                 gap_opening=6, gap_extension=2, gap_opening2=24, gap_extension2=1, scope="full",
+                 span="ends-free", pattern_begin_free=0, pattern_end_free=0, text_begin_free=0,
+                 text_end_free=0, heuristic=None, min_wavefront_length=10,
+                 max_distance_threshold=50, steps_between_cutoffs=1, xdrop=20, wildcard=None,
+                 max_steps=0, device=0):
+        self.pattern_len = 0
+        self.text_len = 0
+        self.alignment_score = 0
+        self._pattern = None
+        self._bpattern = None
+        self._text = None
+        if pattern:
+            self._set_pattern(pattern)
+        self._wildcard = None
+        self._bwildcard = -1
+        self.wildcard = wildcard
+        cfg = _native.default_config()
+        if distance not in _native.DIST:
+            raise NotImplementedError(f"{distance} distance not implemented")
+        cfg.distance = _native.DIST[distance]
+        cfg.match, cfg.mismatch = int(match), int(mismatch)
+        cfg.gap_opening, cfg.gap_extension = int(gap_opening), int(gap_extension)
+        cfg.gap_opening2, cfg.gap_extension2 = int(gap_opening2), int(gap_extension2)
+        if scope not in _native.SCOPE:
+            raise ValueError(f"{scope} scope not understood")
+        cfg.scope = _native.SCOPE[scope]
+        if memory_mode not in _native.MEM:
+            raise ValueError("memory_mode must be one of 'high', 'medium', 'low', 'biwfa'")
+        cfg.memory_mode = _native.MEM[memory_mode]
+        cfg.pattern_begin_free, cfg.pattern_end_free = int(pattern_begin_free), int(pattern_end_free)
+        cfg.text_begin_free, cfg.text_end_free = int(text_begin_free), int(text_end_free)
+        if span not in _native.SPAN:
+            raise NotImplementedError(f"{span} span not implemented")
+        cfg.span = _native.SPAN[span]
+        if heuristic not in _native.HEUR:
+            raise NotImplementedError(f"{heuristic} heuristic not implemented")
+        cfg.heuristic = _native.HEUR[heuristic]
+        cfg.min_wavefront_length = int(min_wavefront_length)
+        cfg.max_distance_threshold = int(max_distance_threshold)
+        cfg.steps_between_cutoffs = int(steps_between_cutoffs)
+        cfg.xdrop = int(xdrop)
+        cfg.max_steps = int(max_steps) if int(max_steps) > 0 else 0
+        cfg.wildcard = self._bwildcard
+        self._cfg = cfg
+        self._native = _native.Aligner(cfg, device)  # raises if no library / no GPU / bad config
+        # last single-pair result (the reference keeps it inside the C aligner object)
+        self._status = -1
+        self._score = -2147483648
+        self._ops = np.zeros(0, np.uint8)
+
+    # ------------------------------------------------------------------ helpers
+    def _set_pattern(self, pattern):
+        self._pattern = pattern.upper()
+        self._bpattern = self._pattern.encode("ascii")
+        self.pattern_len = len(self._bpattern)
+
+    def _push(self):
+        self._cfg.wildcard = self._bwildcard
+        self._native.set_config(self._cfg)
+
+    # ------------------------------------------------------------------ single pair
+    def wavefront_align(self, text, pattern=None):
+        """Align one pair; returns the score (align.pyx:421-443)."""
+        if pattern is not None:
+            self._set_pattern(pattern)
+        t = text.upper().encode("ascii")
+        self._text = text
+        self.text_len = len(t)
+        if self._bpattern is None:
+            raise AttributeError("pattern has not been set")
+        if self._cfg.wildcard != self._bwildcard:
+            self._push()
+        batch = datagen.from_strings([self._bpattern], [t], upper=False)
+        full = self._cfg.scope == 1
+        score, status, cig = self._native.align_batch(batch, full)
+        self._score = int(score[0])
+        self._status = int(status[0])
+        if full:
+            ops, cbeg, clen = cig
+            self._ops = ops[cbeg[0]:cbeg[0] + clen[0]].copy()
+        else:
+            self._ops = np.zeros(0, np.uint8)
+        self.alignment_score = self._score
+        return self._score
+
+    def __call__(self, text, pattern=None, clip_cigar=False, min_aligned_bases_left=1,
+                 min_aligned_bases_right=1, elide_mismatches=False, supress_sequences=False):
+        """Align ``text`` to ``pattern`` and return an AlignmentResult (align.pyx:835-879)."""
+        if pattern is None:
+            p = self._pattern
+            if not p:
+                raise ValueError("pattern is None")
+            lp = len(self._pattern)
+            score = self.wavefront_align(text)
+        else:
+            lp = len(pattern)
+            p = pattern
+            score = self.wavefront_align(text, pattern)
+        ct = self.cigartuples
+        locs = self.locations
+        status = self.status
+        if supress_sequences:
+            res = AlignmentResult(lp, len(text), locs[0], locs[1], locs[2], locs[3], ct, score, "", "", status)
+        else:
+            res = AlignmentResult(lp, len(text), locs[0], locs[1], locs[2], locs[3], ct, score, p, text, status)
+        # as committed in the reference the test is inverted: clip / elide only act when the scope is
+        # NOT "full", i.e. on an empty CIGAR (align.pyx:874-878)
+        if not self.scope == "full":
+            if clip_cigar:
+                res = clip_cigartuples(res, min_aligned_bases_left, min_aligned_bases_right)
+            if elide_mismatches:
+                res.cigartuples = elide_mismatches_from_cigar(res.cigartuples)
+        return res
+
+    # ------------------------------------------------------------------ batches (additive API)
+    def wavefront_align_batch(self, texts, patterns=None):
+        """Align many pairs on the GPU. ``patterns`` None = the cached pattern for every text.
+
+        Returns dict(score=int32[n], status=int32[n], cigarstrings=list[str] (scope full))."""
+        texts = list(texts)
+        if patterns is None:
+            if self._bpattern is None:
+                raise ValueError("pattern is None")
+            patterns = [self._bpattern] * len(texts)
+        else:
+            patterns = list(patterns)
+        if self._cfg.wildcard != self._bwildcard:
+            self._push()
+        batch = datagen.from_strings(patterns, texts, upper=True)
+        return self.align_batch(batch)
+
+    def align_batch(self, batch):
+        """Align a prepared batch dict (see ``pywfa_amd.datagen``): ASCII blob + offsets + lengths."""
+        full = self._cfg.scope == 1
+        score, status, cig = self._native.align_batch(batch, full)
+        out = {"score": score, "status": status}
+        if full:
+            ops, cbeg, clen = cig
+            out["cigar_ops"] = [ops[cbeg[i]:cbeg[i] + clen[i]] for i in range(len(score))]
+            out["cigarstrings"] = [_ops_to_string(o) for o in out["cigar_ops"]]
+        return out
+
+    def resident_batch(self, batch):
+        """Upload + 2-bit pack a batch into HBM once; ``.run()`` it many times (bench.py)."""
+        return self._native.batch(batch)
+
+    # ------------------------------------------------------------------ results
+    @property
+    def status(self):
+        return self._status
+
+    @property
+    def score(self):
+        return self._score
+
+    @property
+    def cigarstring(self):
+        return _ops_to_string(self._ops)
+
+    @property
+    def cigartuples(self):
+        return _ops_to_tuples(self._ops)
+
+    @property
+    def locations(self):
+        """(pattern_start, pattern_end, text_start, text_end) (align.pyx:788-833)."""
+        if self.scope == "score":
+            return [0, 0, 0, 0]
+        ct = self.cigartuples
+        if not ct or self.text_len == 0 or self.pattern_len == 0:
+            return [0, 0, 0, 0]
+        _, _, ps, pe, ts, te = _flank_scan(ct, 1, 1, self.text_len, self.pattern_len)
+        return ps, pe, ts, te
+
+    def cigar_print_pretty(self, file_name=None):
+        """ALIGNMENT / ETRACE / CIGAR + three alignment rows, like cigar_print_pretty
+        (WFA2_lib/alignment/cigar.c:778-863) called by align.pyx:445-459."""
+        pattern = self._bpattern.decode("ascii")
+        text = self._text
+        ch, ln = _rle(self._ops)
+        alignment = "".join(f"{int(n)}{chr(int(c))}" for c, n in zip(ch, ln))
+        etrace = "".join(f"{int(n)}{chr(int(c))}" for c, n in zip(ch, ln) if chr(int(c)) != "M")
+        folded = np.where(self._ops == ord("X"), ord("M"), self._ops).astype(np.uint8)
+        sam = _ops_to_string(folded)
+        pa, oa, ta = [], [], []
+        pp = tp = 0
+        for c in self._ops.tobytes().decode("ascii"):
+            if c == "M":
+                pa.append(pattern[pp]); ta.append(text[tp])
+                oa.append("|" if pattern[pp] == text[tp] else "X")
+                pp += 1; tp += 1
+            elif c == "X":
+                pa.append(pattern[pp]); ta.append(text[tp])
+                oa.append(" " if pattern[pp] != text[tp] else "X")
+                pp += 1; tp += 1
+            elif c == "I":
+                pa.append("-"); oa.append(" "); ta.append(text[tp]); tp += 1
+            elif c == "D":
+                pa.append(pattern[pp]); oa.append(" "); ta.append("-"); pp += 1
+        rest_p, rest_t = pattern[pp:], text[tp:]
+        pa.append(rest_p); ta.append(rest_t)
+        oa.append("?" * max(len(rest_p), len(rest_t)))
+        out = (f"      ALIGNMENT {alignment}\n      ETRACE    {etrace}\n      CIGAR     {sam}\n"
+               f"      PATTERN    {''.join(pa)}\n                 {''.join(oa)}\n      TEXT       {''.join(ta)}\n")
+        if file_name:
+            with open(file_name, "w") as f:
+                f.write(out)
+        else:
+            sys.stdout.write(out)
+
+    # ------------------------------------------------------------------ configuration properties
+    def _int_prop(name):  # noqa: N805
+        def getter(self):
+            return getattr(self._cfg, name)
+
+        def setter(self, value):
+            old = getattr(self._cfg, name)
+            setattr(self._cfg, name, int(value))
+            try:
+                self._push()
+            except Exception:
+                setattr(self._cfg, name, old)
+                raise
+        return property(getter, setter)
+
+    pattern_begin_free = _int_prop("pattern_begin_free")
+    pattern_end_free = _int_prop("pattern_end_free")
+    text_begin_free = _int_prop("text_begin_free")
+    text_end_free = _int_prop("text_end_free")
+    min_wavefront_length = _int_prop("min_wavefront_length")
+    max_distance_threshold = _int_prop("max_distance_threshold")
+    steps_between_cutoffs = _int_prop("steps_between_cutoffs")
+    xdrop = _int_prop("xdrop")
+    mismatch_penalty = _int_prop("mismatch")
+    gap_opening_penalty = _int_prop("gap_opening")
+    gap_extension_penalty = _int_prop("gap_extension")
+    gap_opening2_penalty = _int_prop("gap_opening2")
+    gap_extension2_penalty = _int_prop("gap_extension2")
+    match_score = _int_prop("match")
+    del _int_prop
+
+    def _enum_prop(name, table, exc, msg, canon=None):  # noqa: N805
+        inv = {v: k for k, v in (canon or table).items()}
+
+        def getter(self):
+            return inv[getattr(self._cfg, name)]
+
+        def setter(self, value):
+            if value not in table:
+                raise exc(msg.format(value))
+            old = getattr(self._cfg, name)
+            setattr(self._cfg, name, table[value])
+            try:
+                self._push()
+            except Exception:
+                setattr(self._cfg, name, old)
+                raise
+        return property(getter, setter)
+
+    scope = _enum_prop("scope", _native.SCOPE, ValueError, "{} scope not understood")
+    span = _enum_prop("span", _native.SPAN, NotImplementedError, "{} span not implemented")
+    heuristic = _enum_prop("heuristic", _native.HEUR, NotImplementedError, "{} heuristic not implemented")
+    distance = _enum_prop("distance", _native.DIST, NotImplementedError, "{} distance not implemented")
+    # the reference's setter accepts "med" where the constructor wants "medium" (align.pyx:547-549)
+    memory_mode = _enum_prop("memory_mode", dict(_native.MEM, med=1), NotImplementedError,
+                             "{} memory_mode not implemented", canon=_native.MEM)
+    del _enum_prop
+
+    @property
+    def wildcard(self):
+        return self._wildcard
+
+    @wildcard.setter
+    def wildcard(self, wildcard):
+        if wildcard is not None:
+            if not isinstance(wildcard, str):
+                raise TypeError(f"expected wildcard to be a string, but it is {type(wildcard)}")
+            if len(wildcard) > 1:
+                raise ValueError(f"wildcard must have length 1, but has length {len(wildcard)}")
+            self._wildcard = wildcard
+            self._bwildcard = wildcard.upper().encode("ascii")[0]
+        else:
+            self._wildcard = None
+            self._bwildcard = -1
+
+    @property
+    def max_steps(self):
+        return self._cfg.max_steps if self._cfg.max_steps > 0 else _INT_MAX
+
+    @max_steps.setter
+    def max_steps(self, steps):
+        steps = int(steps)
+        self._cfg.max_steps = steps if 0 < steps < _INT_MAX else 0
+        self._push()
+
+    def close(self):
+        self._native.close()

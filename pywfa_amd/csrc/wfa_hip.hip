@@ -65,7 +65,10 @@ struct wfa_hip_batch {
   uint32_t* d_fb_list = nullptr;   // pairs handed from the fast kernel to the general kernel
   uint32_t* d_ovf_list[2] = {nullptr, nullptr};  // pairs whose arena overflowed
   uint32_t* d_counters = nullptr;  // [0] fallback count, [1] overflow count A, [2] overflow count B
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<hipEvent_t> ev;   // 2 events per run since the last sync (kernel timing)
+  size_t ev_used = 0;
+  int runs_pending = 0;
+  double ms_sum = 0.0; int ms_runs = 0;
   bool ran = false, synced = true;
   float last_ms = 0.f;
   int64_t last_kernel_pairs = 0;
@@ -237,8 +240,7 @@ static void batch_free(wfa_hip_batch* b) {
                   b->d_ops, b->d_cigar_off, b->d_cigar_begin, b->d_cigar_len, b->d_list_packed, b->d_list_bytes,
                   b->d_fb_list, b->d_ovf_list[0], b->d_ovf_list[1], b->d_counters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  if (b->ev0) (void)hipEventDestroy(b->ev0);
-  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
   delete b;
 }
 
@@ -343,8 +345,6 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
       (void)hipFree(b->d_bytes); b->d_bytes = nullptr;
     }
   }
-  HIP_TRY(al, hipEventCreate(&b->ev0));
-  HIP_TRY(al, hipEventCreate(&b->ev1));
   return WFA_HIP_OK;
 }
 
@@ -469,7 +469,10 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
   // 1) the fast register-resident kernel takes the 2-bit pairs it supports; what does not fit its
   //    diagonal window is appended to d_fb_list and finished by the general kernel below.
   const bool use_fast = wfa::fast_supported(al->dcfg, al->ncomp, full) && b->n_packed > 0 && env_int("WFA_HIP_NO_FAST", 0) == 0;
-  HIP_TRY(al, hipEventRecord(b->ev0, stream));
+  while (b->ev.size() < b->ev_used + 2) { hipEvent_t e; HIP_TRY(al, hipEventCreate(&e)); b->ev.push_back(e); }
+  hipEvent_t ev0 = b->ev[b->ev_used], ev1 = b->ev[b->ev_used + 1];
+  b->ev_used += 2; b->runs_pending += 1;
+  HIP_TRY(al, hipEventRecord(ev0, stream));
   if (use_fast) {
     const int rc = wfa::launch_fast(al->dcfg, al->cu_count, stream, b->d_words, b->d_meta, b->d_list_packed, b->n_packed,
                                     b->d_score, b->d_status, b->d_fb_list, b->d_counters + 0);
@@ -492,7 +495,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     }
     if (rc != WFA_HIP_OK) return rc;
   }
-  HIP_TRY(al, hipEventRecord(b->ev1, stream));
+  HIP_TRY(al, hipEventRecord(ev1, stream));
   // 3) 8-bit pairs (non-ACGT letters, wildcard matching)
   if (b->n_bytes > 0) {
     Geometry g = plan_general(al, b, b->n_bytes, b->arena_ints);
@@ -562,7 +565,14 @@ extern "C" int wfa_hip_batch_sync(wfa_hip_batch_t* b) {
   HIP_TRY(al, hipSetDevice(al->device));
   HIP_TRY(al, hipStreamSynchronize(b->last_stream));
   if (b->n > 0) {
-    HIP_TRY(al, hipEventElapsedTime(&b->last_ms, b->ev0, b->ev1));
+    b->ms_sum = 0.0; b->ms_runs = 0;
+    for (size_t i = 0; i + 1 < b->ev_used; i += 2) {
+      float ms = 0.f;
+      HIP_TRY(al, hipEventElapsedTime(&ms, b->ev[i], b->ev[i + 1]));
+      b->ms_sum += ms; b->ms_runs += 1;
+    }
+    b->last_ms = b->ms_runs ? (float)(b->ms_sum / b->ms_runs) : 0.f;
+    b->ev_used = 0; b->runs_pending = 0;
     uint32_t fb = 0;
     HIP_TRY(al, hipMemcpy(&fb, b->d_counters, sizeof(uint32_t), hipMemcpyDeviceToHost));
     b->last_fallback = fb;

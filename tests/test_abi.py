@@ -1,0 +1,79 @@
+"""The C-ABI library loads and exports every symbol include/wfa_hip.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from pywfa_amd import _native
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "wfa_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(wfa_hip_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported():
+    syms = header_symbols()
+    assert len(syms) >= 19
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), f"libwfa_hip.so does not export {s}"
+    assert sorted(_native.SYMBOLS) == syms, "pywfa_amd/_native.py binds a different symbol set than the header declares"
+
+
+def test_abi_version_and_default_config():
+    L = _native.lib()
+    assert L.wfa_hip_abi_version() == _native.ABI_VERSION
+    c = _native.default_config()
+    # pywfa defaults (align.pyx:309-334)
+    assert (c.distance, c.match, c.mismatch, c.gap_opening, c.gap_extension) == (3, 0, 4, 6, 2)
+    assert (c.gap_opening2, c.gap_extension2) == (24, 1)
+    assert (c.scope, c.span, c.heuristic, c.memory_mode, c.max_steps, c.wildcard) == (1, 1, 0, 0, 0, -1)
+    assert (c.min_wavefront_length, c.max_distance_threshold, c.steps_between_cutoffs, c.xdrop) == (10, 50, 1, 20)
+    assert ctypes.sizeof(_native.Config) == 22 * 4
+
+
+@pytest.mark.parametrize("field,value,code", [
+    ("match", 1, _native.EINVAL), ("mismatch", 0, _native.EINVAL), ("gap_opening", -1, _native.EINVAL),
+    ("gap_extension", 0, _native.EINVAL), ("scope", 7, _native.EINVAL), ("span", 3, _native.EINVAL),
+    ("heuristic", 9, _native.EINVAL), ("distance", 1, _native.ENOTSUP), ("distance", 2, _native.ENOTSUP),
+    ("memory_mode", 3, _native.ENOTSUP), ("pattern_begin_free", -2, _native.EINVAL), ("wildcard", 300, _native.EINVAL),
+])
+def test_validate_rejects(field, value, code):
+    """Invalid penalties return an error code where the reference exit(1)s (wavefront_penalties.c:101-112)."""
+    c = _native.default_config()
+    setattr(c, field, value)
+    rc, msg = _native.validate(c)
+    assert rc == code and msg
+
+
+def test_validate_accepts_affine2p():
+    c = _native.default_config()
+    c.distance = 4
+    assert _native.validate(c)[0] == _native.OK
+    c.gap_extension2 = 0
+    assert _native.validate(c)[0] == _native.EINVAL
+
+
+def test_no_gpu_fails_loudly():
+    """Without a HIP device the product path raises (there is no CPU fallback)."""
+    if _native.lib().wfa_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    import pywfa_amd
+    with pytest.raises(_native.NativeError):
+        pywfa_amd.WavefrontAligner("ACGT")
+
+
+def test_product_does_not_use_oracle():
+    """Nothing under pywfa_amd/ may import, link or execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "pywfa_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".h", ".c", ".sh")):
+                txt = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "oracle" not in txt.lower(), (dirpath, fn)
+                assert "libwfa_ref" not in txt, (dirpath, fn)

@@ -1,0 +1,76 @@
+"""Pin the oracle (oracle/wfa_oracle.c) on the committed golden vectors generated from the reference:
+ * tests/golden/c_level.json      — (status, score, CIGAR) of WFA2-lib on seeded corpora x configs
+ * tests/golden/python_surface.json — the reference's own known answers (tests/test.py, README.rst)
+"""
+import numpy as np
+import pytest
+
+import common
+from oracle import loader
+from pywfa_amd import datagen
+
+C_LEVEL = common.load_golden("c_level.json")
+SURFACE = common.load_golden("python_surface.json")
+
+
+@pytest.mark.parametrize("run_idx", range(len(C_LEVEL["runs"])))
+def test_oracle_matches_reference_vectors(run_idx):
+    run = C_LEVEL["runs"][run_idx]
+    pairs = C_LEVEL["corpora"][run["corpus"]]
+    batch = datagen.from_strings([p for p, _ in pairs], [t for _, t in pairs])
+    cfg = loader.make_config(**run["config"])
+    o = loader.run(loader.oracle(), cfg, batch)
+    assert o["score"].tolist() == run["score"]
+    assert o["status"].tolist() == run["status"]
+    if run["cigar"] is not None:
+        assert [common.rle(c) for c in o["cigars"]] == run["cigar"]
+
+
+def _surface_alignments():
+    """(name, ctor kwargs, pattern, text, expected aligner snapshot) for every recorded alignment."""
+    out = []
+    for entry in SURFACE:
+        case, exp = entry["case"], entry["expected"]
+        if exp and "ctor_exc" in exp[0]:
+            continue
+        kw = {k: v for k, v in case["ctor"].items() if k != "pattern"}
+        pattern = case["ctor"].get("pattern")
+        for st, o in zip(case["steps"], exp):
+            if st["op"] in ("align", "call"):
+                if st.get("pattern") is not None:
+                    pattern = st["pattern"]
+                if "aligner" in o and pattern:
+                    out.append((case["name"], kw, pattern, st["text"], o["aligner"]))
+            elif st["op"] == "set":
+                kw = dict(kw); kw[st["name"]] = st["value"]
+    return out
+
+
+SURFACE_ALN = _surface_alignments()
+
+
+@pytest.mark.parametrize("idx", range(len(SURFACE_ALN)))
+def test_oracle_matches_reference_known_answers(idx):
+    name, kw, pattern, text, snap = SURFACE_ALN[idx]
+    batch = datagen.from_strings([pattern], [text])
+    cfg = loader.make_config(**kw)
+    o = loader.run(loader.oracle(), cfg, batch)
+    assert int(o["score"][0]) == snap["score"], name
+    assert int(o["status"][0]) == snap["status"], name
+    if cfg.scope == 1:
+        assert common.rle(o["cigars"][0]) == snap["cigarstring"], name
+
+
+def test_reference_asserted_values_present():
+    """The values the reference's own tests assert (tests/test.py:18-24,96-101,117-129)."""
+    by = {e["case"]["name"]: e for e in SURFACE}
+    a = by["test_affine_1"]["expected"][0]["aligner"]
+    assert (a["score"], a["status"], a["cigarstring"]) == (-24, 0, "3M1X4M1D7M1I9M1X6M")
+    assert a["cigartuples"] == [[0, 3], [8, 1], [0, 4], [2, 1], [0, 7], [1, 1], [0, 9], [8, 1], [0, 6]]
+    e = by["test_end_to_end"]["expected"][0]
+    assert (e["result"]["score"], e["aligner"]["cigarstring"]) == (-26, "4M4D26M3D3M")
+    r0 = by["test_ends_free2_0"]["expected"][0]["result"]
+    assert (r0["text_start"], r0["text_end"]) == (4, 17)
+    r1 = by["test_ends_free2_1"]["expected"][0]["result"]
+    assert (r1["text_start"], r1["text_end"]) == (4, 11)
+    assert by["test_scope"]["expected"][0]["aligner"]["cigarstring"] == ""

@@ -1,0 +1,122 @@
+"""Parity tests proper: the HIP path (through the C ABI of libwfa_hip.so) against the oracle on the
+same seeded inputs, and against the committed golden vectors.  Bit-exact: status, score, op string."""
+import numpy as np
+import pytest
+
+import common
+from oracle import loader
+from pywfa_amd import datagen
+
+pytestmark = pytest.mark.gpu
+
+C_LEVEL = common.load_golden("c_level.json")
+
+
+@pytest.mark.parametrize("run_idx", range(len(C_LEVEL["runs"])))
+def test_hip_matches_golden_vectors(gpu, run_idx):
+    run = C_LEVEL["runs"][run_idx]
+    pairs = C_LEVEL["corpora"][run["corpus"]]
+    batch = datagen.from_strings([p for p, _ in pairs], [t for _, t in pairs])
+    oc, nc = common.configs_pair(**run["config"])
+    full = oc.scope == 1
+    score, status, cigars = common.gpu_run(nc, batch, full, resident=(run_idx % 2 == 0))
+    assert score.tolist() == run["score"]
+    assert status.tolist() == run["status"]
+    if run["cigar"] is not None:
+        assert [common.rle(c) for c in cigars] == run["cigar"]
+
+
+GRID = []
+for distance in ("affine", "affine2p"):
+    for span, free in (("end-to-end", (0, 0, 0, 0)), ("ends-free", (0, 0, 0, 0)), ("ends-free", (8, 7, 3, 2)), ("ends-free", (20, 0, 0, 9))):
+        for heur in (None, "adaptive", ("X-drop", 20), ("X-drop", 100)):
+            for scope in ("score", "full"):
+                kw = dict(distance=distance, span=span, scope=scope, pattern_begin_free=free[0], pattern_end_free=free[1],
+                          text_begin_free=free[2], text_end_free=free[3])
+                if isinstance(heur, tuple):
+                    kw.update(heuristic=heur[0], xdrop=heur[1])
+                else:
+                    kw.update(heuristic=heur)
+                GRID.append(kw)
+GRID += [
+    dict(distance="affine", mismatch=2, gap_opening=3, gap_extension=1),
+    dict(distance="affine", mismatch=5, gap_opening=0, gap_extension=3),
+    dict(distance="affine2p", mismatch=3, gap_opening=4, gap_extension=2, gap_opening2=12, gap_extension2=1),
+    dict(distance="affine", match=-1, span="end-to-end"),
+    dict(distance="affine2p", match=-1, span="ends-free", pattern_end_free=5, text_end_free=5),
+    dict(distance="affine", match=-1, heuristic="X-drop", xdrop=100, span="end-to-end", scope="score"),
+    dict(distance="affine", heuristic="adaptive", min_wavefront_length=5, max_distance_threshold=10, steps_between_cutoffs=3),
+    dict(distance="affine", max_steps=10), dict(distance="affine2p", max_steps=25, scope="score"),
+    dict(distance="affine", memory_mode="medium"), dict(distance="affine2p", memory_mode="low", span="end-to-end"),
+    dict(distance="affine", wildcard="N"),
+]
+
+SHAPES = {"150bp_2pct": (1500, 150, 0.02), "150bp_15pct": (400, 150, 0.15), "1kb_8pct": (60, 1000, 0.08)}
+
+
+@pytest.fixture(scope="module")
+def corpora():
+    import validate_oracle as vo
+    out = {name: datagen.generate(n, L, e, 7000 + L + int(e * 1000)) for name, (n, L, e) in SHAPES.items()}
+    out["special"] = vo.corpus_special(seed=99)   # empty / length-1 / N / repeats / long gaps / windows
+    return out
+
+
+@pytest.mark.parametrize("cfg_idx", range(len(GRID)))
+@pytest.mark.parametrize("corpus", list(SHAPES) + ["special"])
+def test_hip_matches_oracle(gpu, corpora, corpus, cfg_idx):
+    batch = corpora[corpus]
+    kw = common.clamp_free(GRID[cfg_idx], batch)
+    oc, nc = common.configs_pair(**kw)
+    o = loader.run(loader.oracle(), oc, batch)
+    full = oc.scope == 1
+    score, status, cigars = common.gpu_run(nc, batch, full, resident=(cfg_idx % 2 == 1))
+    common.assert_same(o, score, status, cigars, batch, f"{corpus} {kw}")
+
+
+@pytest.mark.parametrize("kw", [dict(span="end-to-end", scope="full", heuristic="adaptive"),
+                                dict(span="end-to-end", scope="score"),
+                                dict(distance="affine2p", span="ends-free", pattern_end_free=100, text_end_free=100, heuristic="adaptive")])
+def test_hip_matches_oracle_10kb(gpu, kw):
+    batch = datagen.generate(24, 10000, 0.08, 1003)
+    oc, nc = common.configs_pair(**kw)
+    o = loader.run(loader.oracle(), oc, batch)
+    score, status, cigars = common.gpu_run(nc, batch, oc.scope == 1, resident=True)
+    common.assert_same(o, score, status, cigars, batch, f"10kb {kw}")
+
+
+def test_exact_full_cigar_needs_arena_growth(gpu):
+    """Exact (no heuristic) full-CIGAR alignment of 4 kb reads stores ~10 MB of wavefront history per
+    pair: the first arena overflows and the pair is re-run with a larger one; results are unchanged."""
+    batch = datagen.generate(6, 4000, 0.08, 31)
+    oc, nc = common.configs_pair(span="end-to-end", scope="full")
+    o = loader.run(loader.oracle(), oc, batch)
+    score, status, cigars = common.gpu_run(nc, batch, True, resident=True)
+    common.assert_same(o, score, status, cigars, batch, "4kb exact full")
+
+
+def test_ragged_and_empty_batches(gpu):
+    from pywfa_amd import _native
+    oc, nc = common.configs_pair(scope="full")
+    al = _native.Aligner(nc)
+    empty = datagen.from_strings([], [])
+    score, status, cig = al.align_batch(empty, True)
+    assert score.size == 0 and status.size == 0
+    ragged = datagen.from_strings(["", "A", "ACGT" * 100, "ACGTTTGA"], ["ACGT", "", "ACGT" * 90 + "TT", "ACGTTTGA"])
+    o = loader.run(loader.oracle(), oc, ragged)
+    score, status, cig = al.align_batch(ragged, True)
+    ops, cbeg, clen = cig
+    cigars = [ops[cbeg[i]:cbeg[i] + clen[i]].tobytes() for i in range(4)]
+    common.assert_same(o, score, status, cigars, ragged, "ragged")
+    assert common.rle(cigars[0]) == "4I" and score[0] == -14   # empty pattern
+    al.close()
+
+
+def test_ends_free_larger_than_sequence_is_an_error(gpu):
+    """The reference exit(1)s (wavefront_align.c:95-101); here: ValueError."""
+    from pywfa_amd import _native
+    oc, nc = common.configs_pair(pattern_begin_free=50)
+    al = _native.Aligner(nc)
+    with pytest.raises(ValueError):
+        al.align_batch(datagen.from_strings(["ACGT"], ["ACGT"]), True)
+    al.close()
