@@ -59,6 +59,42 @@ def cpu_baseline(batch, cfg_kw, budget_s=12.0):
             "library": os.path.basename(loader.reference_path() or "liboracle.so")}
 
 
+def shard_first(rank, pairs_per_gpu):
+    """Weak scaling: rank r owns pairs [r*P, (r+1)*P) of the one seeded stream (no overlap, no gaps)."""
+    return rank * pairs_per_gpu
+
+
+def dist_setup(backend, local_rank):
+    """One process per GPU; RCCL ("nccl") on the GPU box, gloo in the CPU tests."""
+    import torch
+    import torch.distributed as dist
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend=backend)
+    return dist
+
+
+def dist_barrier(dist, backend):
+    if dist is None:
+        return
+    if backend == "nccl":
+        import torch
+        torch.cuda.synchronize()
+    dist.barrier()
+
+
+def dist_max(dist, backend, value):
+    """MAX over ranks of a host float (the step time)."""
+    if dist is None:
+        return value
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,11 +110,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    backend = "nccl"
     if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_setup(backend, local_rank)
     n_gpus = world
 
     from pywfa_amd import _native, datagen
@@ -90,7 +124,7 @@ def main():
 
     # each rank owns the pairs [rank*P, (rank+1)*P) of the seed-1002 stream (weak scaling)
     t0 = time.perf_counter()
-    batch = datagen.generate(args.pairs, args.length, args.error, datagen.SEEDS["C2"], first=rank * args.pairs)
+    batch = datagen.generate(args.pairs, args.length, args.error, datagen.SEEDS["C2"], first=shard_first(rank, args.pairs))
     t_gen = time.perf_counter() - t0
 
     al = _native.Aligner(cfg, device=local_rank)
@@ -99,10 +133,7 @@ def main():
     t_upload = time.perf_counter() - t0
 
     def barrier():
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
+        dist_barrier(dist, backend)
 
     for _ in range(args.warmup):
         rb.run()
@@ -115,11 +146,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms, kernel_pairs = rb.last_kernel()  # mean HIP-event time per step over the timed steps
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = dist_max(dist, backend, elapsed)
 
     score, status, _ = rb.results(False)
     alg_bytes = rb.algorithmic_bytes()
