@@ -1,0 +1,432 @@
+// wfa_band.hpp — wave-resident banded kernel: one alignment per 64-lane workgroup, the wavefront ring
+// in VGPRs over a SLIDING window of W = 64*NCH diagonals (diagonal k = B + 64*c + lane for chunk c),
+// sequences staged in LDS when they fit, wf-adaptive cut-off with ballots, and — for scope=full — the
+// per-score wavefronts streamed to an HBM history (fixed-stride records, coalesced stores) followed by
+// an on-device backtrace.  It is the long-read / full-CIGAR companion of wfa_fast.hpp and follows the
+// same rules (R = /root/reference/pywfa/WFA2_lib/wavefront):
+//   compute-next        R/wavefront_compute_affine.c:44-86   (only M clamped; I/D ends trimmed, :571-605)
+//   extend/termination  R/wavefront_extend_kernels.c:64-110, R/wavefront_termination.c:37-61
+//   wf-adaptive         R/wavefront_heuristic.c:176-293 + equate :161-172, dispatcher :509-567
+//   backtrace           R/wavefront_backtrace.c:49-101,320-529
+// "Outside a wavefront's [lo,hi] reads NULL" is represented by NULL lanes; the heuristic's cut and the
+// I/D equate NULL the lanes they drop, so the stored history needs no per-component limits.
+// Scope: gap-affine, match = 0, penalties in the ratio x : o+e : e = 2 : 4 : 1 (pywfa's 4/6/2), no
+// heuristic or wf-adaptive, end-to-end (or ends-free with all free ends 0), unlimited max_steps.
+// Whatever does not fit (window, history capacity, dead wavefront) is appended to the fallback list and
+// finished by the general kernel with identical results.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include "wfa_common.hpp"
+#include "wfa_fast.hpp"
+#include "wfa_general.hpp"
+
+namespace wfa {
+
+struct BandArgs {
+  const uint32_t* words;
+  const WfaPairMeta* meta;
+  const uint32_t* worklist;  // nullptr = identity
+  const uint32_t* nwork_dev;  // non-null: the count is read from device memory (leftovers of a previous stage)
+  uint32_t nwork;
+  int32_t* score;
+  int32_t* status;
+  uint8_t* cigar_ops;
+  const int64_t* cigar_off;
+  int64_t* cigar_begin;
+  int32_t* cigar_len;
+  int32_t* hist;          // FULL: history, one slice per workgroup
+  int64_t hist_stride;    // ints per workgroup
+  uint32_t* fb_list;
+  uint32_t* fb_count;
+  int g;                  // score step = gcd(x, o+e, e)
+  int x, oe, e;           // penalties (score units), for the backtrace
+  int min_wf_len, max_dist_thr, steps_between;
+  int lds_words;          // SEQLDS: words reserved per sequence in dynamic LDS
+};
+
+template <int NCH>
+struct Band {
+  static constexpr int W = 64 * NCH;
+  static constexpr int REC = 3 * W + 16;  // history record: M[W] I[W] D[W] + {B, ...}
+
+  // value of the diagonal below / above across chunk boundaries
+  static __device__ __forceinline__ int below(const int (&r)[NCH], int c) {
+    int fill = WFA_OFFSET_NULL;
+    if (c > 0) fill = __builtin_amdgcn_readlane(r[c - 1], 63);
+    return __builtin_amdgcn_update_dpp(fill, r[c], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  }
+  static __device__ __forceinline__ int above(const int (&r)[NCH], int c) {
+    int fill = WFA_OFFSET_NULL;
+    if (c < NCH - 1) fill = __builtin_amdgcn_readlane(r[c + 1], 0);
+    return __builtin_amdgcn_update_dpp(fill, r[c], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+  }
+  // positions (0..W-1) of the first / last set bit over the per-chunk ballots; -1 / W if none
+  static __device__ __forceinline__ int first_pos(const unsigned long long (&b)[NCH]) {
+    int p = W;
+#pragma unroll
+    for (int c = NCH - 1; c >= 0; --c) if (b[c]) p = c * 64 + (int)__builtin_ctzll(b[c]);
+    return p;
+  }
+  static __device__ __forceinline__ int last_pos(const unsigned long long (&b)[NCH]) {
+    int p = -1;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) if (b[c]) p = c * 64 + 63 - (int)__builtin_clzll(b[c]);
+    return p;
+  }
+  // shift a register set by `delta` window positions: new[pos] = old[pos + delta] (NULL outside)
+  static __device__ __forceinline__ void shift(int (&r)[NCH], int delta, int lane) {
+    int out[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int q = c * 64 + lane + delta;
+      int v = WFA_OFFSET_NULL;
+#pragma unroll
+      for (int sc = 0; sc < NCH; ++sc) {
+        const int t = __shfl(r[sc], q & 63, 64);
+        if ((q >> 6) == sc) v = t;
+      }
+      out[c] = v;
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) r[c] = out[c];
+  }
+};
+
+// candidate of the backtrace read from the band history: one load of the record's window base and one
+// of the offset, both at addresses known from (score, k) alone (a single memory round trip per step)
+template <int NCH>
+__device__ __forceinline__ long long band_cand(const int* hist, int g, int s, int comp, int k, int add, int type) {
+  typedef Band<NCH> BD;
+  if (s < 0) return WFA_OFFSET_NULL;
+  const int* rec = hist + (long long)(s / g) * BD::REC;
+  const int base = rec[3 * BD::W];
+  const int o = rec[comp * BD::W + (k & (BD::W - 1))];
+  if (k < base || k >= base + BD::W) return WFA_OFFSET_NULL;
+  return (((long long)(o + add)) << 4) | type;
+}
+
+// R/wavefront_backtrace.c:320-529 for gap-affine over the band history; single lane.
+template <int NCH>
+__device__ void band_backtrace(const int* hist, const BandArgs& a, int plen, int tlen, int end_s, int end_k,
+                               int end_off, uint8_t* buf, long long* begin_out) {
+  enum { BT_I1_OPEN = 1, BT_I1_EXT = 2, BT_D1_OPEN = 5, BT_D1_EXT = 6, BT_M = 9 };
+  long long begin = (long long)plen + tlen;
+  int comp = 0, s = end_s, k = end_k, offset = end_off;
+  int h = offset, v = offset - k;
+  for (int i = plen - v; i > 0; --i) buf[--begin] = 'D';
+  for (int i = tlen - h; i > 0; --i) buf[--begin] = 'I';
+  while (v > 0 && h > 0 && s > 0) {
+    const int s_x = s - a.x, s_o = s - a.oe, s_e = s - a.e;
+    long long best;
+    if (comp == 0) {
+      const long long c0 = band_cand<NCH>(hist, a.g, s_x, 0, k, 1, BT_M);
+      const long long c1 = band_cand<NCH>(hist, a.g, s_o, 0, k - 1, 1, BT_I1_OPEN);
+      const long long c2 = band_cand<NCH>(hist, a.g, s_e, 1, k - 1, 1, BT_I1_EXT);
+      const long long c3 = band_cand<NCH>(hist, a.g, s_o, 0, k + 1, 0, BT_D1_OPEN);
+      const long long c4 = band_cand<NCH>(hist, a.g, s_e, 2, k + 1, 0, BT_D1_EXT);
+      best = max(max(c0, max(c1, c2)), max(c3, c4));
+    } else if (comp == 1) {
+      best = max(band_cand<NCH>(hist, a.g, s_o, 0, k - 1, 1, BT_I1_OPEN), band_cand<NCH>(hist, a.g, s_e, 1, k - 1, 1, BT_I1_EXT));
+    } else {
+      best = max(band_cand<NCH>(hist, a.g, s_o, 0, k + 1, 0, BT_D1_OPEN), band_cand<NCH>(hist, a.g, s_e, 2, k + 1, 0, BT_D1_EXT));
+    }
+    if (best < 0) break;
+    if (comp == 0) {
+      const int src = (int)(best >> 4);
+      for (int i = offset - src; i > 0; --i) buf[--begin] = 'M';
+      offset = src;
+      v = offset - k; h = offset;
+      if (v <= 0 || h <= 0) break;
+    }
+    const int type = (int)(best & 0xF);
+    if (type == BT_M) { s = s_x; comp = 0; buf[--begin] = 'X'; --offset; }
+    else if (type == BT_I1_OPEN) { s = s_o; comp = 0; buf[--begin] = 'I'; --k; --offset; }
+    else if (type == BT_I1_EXT) { s = s_e; comp = 1; buf[--begin] = 'I'; --k; --offset; }
+    else if (type == BT_D1_OPEN) { s = s_o; comp = 0; buf[--begin] = 'D'; ++k; }
+    else { s = s_e; comp = 2; buf[--begin] = 'D'; ++k; }
+    v = offset - k; h = offset;
+  }
+  if (comp == 0) {
+    if (v > 0 && h > 0) {
+      const int n = min(v, h);
+      for (int i = n; i > 0; --i) buf[--begin] = 'M';
+      v -= n; h -= n;
+    }
+    for (; v > 0; --v) buf[--begin] = 'D';
+    for (; h > 0; --h) buf[--begin] = 'I';
+  }
+  *begin_out = begin;
+}
+
+template <int NCH, bool FULL, bool ADAPT, bool SEQLDS>
+__global__ void __launch_bounds__(64)
+wfa_band_kernel(const BandArgs a) {
+  typedef Band<NCH> BD;
+  constexpr int W = BD::W;
+  constexpr int DM = 4;  // M history depth for x : o+e : e = 2 : 4 : 1
+  extern __shared__ uint32_t slds[];
+  uint32_t* const sP = slds;
+  uint32_t* const sT = slds + a.lds_words;
+  const int lane = threadIdx.x;
+  int* const hist = FULL ? a.hist + (long long)blockIdx.x * a.hist_stride : nullptr;
+  const int max_records = FULL ? (int)min((long long)INT_MAX, a.hist_stride / BD::REC) : INT_MAX;
+
+  const uint32_t nwork = a.nwork_dev ? *a.nwork_dev : a.nwork;
+  for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+    const uint32_t pair = a.worklist ? a.worklist[wi] : wi;
+    const WfaPairMeta pm = a.meta[pair];
+    const int plen = pm.plen, tlen = pm.tlen;
+    const int ak = tlen - plen;
+    const uint32_t* gP = a.words + pm.p_woff;
+    const uint32_t* gT = a.words + pm.t_woff;
+    const int nwp = (plen + 15) >> 4, nwt = (tlen + 15) >> 4;
+    bool fallback = false;
+    if (SEQLDS) {
+      if (nwp + 1 > a.lds_words || nwt + 1 > a.lds_words) fallback = true;
+      else {
+        __syncthreads();
+        for (int i = lane; i <= nwp; i += 64) sP[i] = (i < nwp) ? gP[i] : 0u;
+        for (int i = lane; i <= nwt; i += 64) sT[i] = (i < nwt) ? gT[i] : 0u;
+        __syncthreads();
+      }
+    }
+    int B = -(W / 2);  // diagonal of window position 0; the window then follows the live diagonals
+    int result = 0;
+    int end_k = 0, end_off = 0, end_s = 0;
+    if (!fallback) {
+      int kk[NCH], cur[NCH], Mh[DM][NCH], Ih[NCH], Dh[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        kk[c] = B + c * 64 + lane;
+        cur[c] = (kk[c] == 0) ? 0 : WFA_OFFSET_NULL;  // wavefront 0
+        Ih[c] = WFA_OFFSET_NULL; Dh[c] = WFA_OFFSET_NULL;
+#pragma unroll
+        for (int j = 0; j < DM; ++j) Mh[j][c] = WFA_OFFSET_NULL;
+      }
+      int s = 0, steps_wait = a.steps_between, dead_steps = 0;
+      bool done = false;
+      for (int step = 0;; ++step) {
+        // ---------------- extend M[s] ----------------
+        unsigned long long live[NCH];
+        bool any_live = false;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { live[c] = __ballot(cur[c] >= 0); any_live |= (live[c] != 0); }
+        if (any_live) {
+          dead_steps = 0;
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            if (live[c] == 0) continue;
+            bool active = cur[c] >= 0;
+            int h = active ? cur[c] : 0, v = active ? cur[c] - kk[c] : 0;
+            int left = active ? min(plen - v, tlen - h) : 0;
+            active = active && left > 0;
+            while (__any(active)) {
+              uint32_t p0, p1, t0, t1;
+              if (SEQLDS) { p0 = sP[v >> 4]; p1 = sP[(v >> 4) + 1]; t0 = sT[h >> 4]; t1 = sT[(h >> 4) + 1]; }
+              else {
+                const int vi = active ? v : 0, hi_ = active ? h : 0;
+                p0 = gP[vi >> 4]; p1 = gP[(vi >> 4) + 1]; t0 = gT[hi_ >> 4]; t1 = gT[(hi_ >> 4) + 1];
+              }
+              const uint32_t pw = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)(v & 15) << 1);
+              const uint32_t tw = __builtin_amdgcn_alignbit(t1, t0, (uint32_t)(h & 15) << 1);
+              const uint32_t x = pw ^ tw;
+              int m = x ? (__builtin_ctz(x) >> 1) : 16;
+              m = active ? min(m, left) : 0;
+              v += m; h += m; left -= m;
+              active = active && (m == 16) && (left > 0);
+            }
+            if (cur[c] >= 0) cur[c] = h;
+          }
+          // ---------------- termination (end-to-end) ----------------
+          const int p = ak - B;
+          int at_end = WFA_OFFSET_NULL;
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) if ((p >> 6) == c) at_end = __builtin_amdgcn_readlane(cur[c], p & 63);
+          if (p >= 0 && p < W && at_end >= tlen) { done = true; result = -s; end_k = ak; end_off = tlen; end_s = s; break; }
+          // ---------------- wf-adaptive cut-off (R/wavefront_heuristic.c:257-293,509-567) ----------------
+          if (ADAPT) {
+            --steps_wait;
+            if (steps_wait <= 0) {
+              const int lo = B + BD::first_pos(live), hi = B + BD::last_pos(live);
+              if (hi - lo + 1 >= a.min_wf_len) {
+                int d[NCH], dmin = max(plen, tlen);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                  d[c] = (cur[c] >= 0) ? max(plen - (cur[c] - kk[c]), tlen - cur[c]) : -WFA_OFFSET_NULL;
+                  dmin = min(dmin, d[c]);
+                }
+                dmin = wave_min(dmin);
+                unsigned long long ok[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) ok[c] = __ballot(d[c] - dmin <= a.max_dist_thr);
+                const int fp = BD::first_pos(ok), lp = BD::last_pos(ok);
+                const int lc = (fp < W) ? B + fp : INT_MAX, hc = (lp >= 0) ? B + lp : INT_MIN;
+                int new_lo = lo, new_hi = hi;
+                const int top_limit = min(ak, hi);
+                if (top_limit > lo) new_lo = min(lc, top_limit);
+                const int bottom_limit = max(ak, new_lo);
+                if (bottom_limit < hi) new_hi = max(hc, bottom_limit);
+                steps_wait = a.steps_between;
+                if (new_lo != lo || new_hi != hi) {
+#pragma unroll
+                  for (int c = 0; c < NCH; ++c) {
+                    const bool drop = kk[c] < new_lo || kk[c] > new_hi;
+                    if (drop) { cur[c] = WFA_OFFSET_NULL; Ih[c] = WFA_OFFSET_NULL; Dh[c] = WFA_OFFSET_NULL; }
+                  }
+                }
+              }
+            }
+          }
+        } else {
+          // nothing alive at this score; if the whole ring is dead the reference ends "unreachable"
+          // after its null-step count runs out: leave that rare case to the general kernel
+          if (++dead_steps > 2 * DM + 2) { fallback = true; break; }
+        }
+        // ---------------- history of score s (after the cut-off, so dropped lanes read NULL) ----------------
+        const int si = s / a.g;
+        if (FULL) {
+          if (si + 1 >= max_records) { fallback = true; break; }
+          int* rec = hist + (long long)si * BD::REC;
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            const int pos = kk[c] & (W - 1);
+            rec[pos] = cur[c]; rec[W + pos] = Ih[c]; rec[2 * W + pos] = Dh[c];
+          }
+          if (lane == 0) rec[3 * W] = B;
+        }
+        // ---------------- keep the ring inside the window (every 8 steps; growth is <= 1 diagonal/step) ----
+        if ((step & 7) == 0) {
+          unsigned long long hull[NCH];
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            int any = cur[c] & Ih[c] & Dh[c];
+#pragma unroll
+            for (int j = 0; j < DM - 1; ++j) any &= Mh[j][c];
+            hull[c] = __ballot(any >= 0);  // some register of this diagonal is not negative
+          }
+          const int fp = BD::first_pos(hull), lp = BD::last_pos(hull);
+          if (lp >= 0) {
+            const int width = lp - fp + 1;
+            if (width > W - 20) { fallback = true; break; }
+            if (fp < 9 || lp > W - 10) {
+              // re-centre, keeping the target diagonal representable when it is within reach
+              int delta = fp - (W - width) / 2;
+              B += delta;
+#pragma unroll
+              for (int c = 0; c < NCH; ++c) kk[c] += delta;
+              BD::shift(cur, delta, lane); BD::shift(Ih, delta, lane); BD::shift(Dh, delta, lane);
+#pragma unroll
+              for (int j = 0; j < DM - 1; ++j) BD::shift(Mh[j], delta, lane);
+            }
+          }
+        }
+        // ---------------- compute-next for score s+g ----------------
+#pragma unroll
+        for (int j = DM - 1; j > 0; --j)
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) Mh[j][c] = Mh[j - 1][c];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) Mh[0][c] = cur[c];
+        s += a.g;
+        int insig = -1;  // AND of all inputs: non-negative iff some input offset is not NULL-ish
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) insig &= (Mh[1][c] | 0) & Mh[3][c] & Ih[c] & Dh[c];
+        int ni[NCH], nd[NCH], nm[NCH];
+        if (__any(insig >= 0)) {
+          unsigned long long oob = 0;
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            const int mo_lo = BD::below(Mh[3], c), ie_lo = BD::below(Ih, c);
+            const int mo_hi = BD::above(Mh[3], c), de_hi = BD::above(Dh, c);
+            ni[c] = max(mo_lo, ie_lo) + 1;
+            nd[c] = max(mo_hi, de_hi);
+            int m = max(nd[c], max(Mh[1][c] + 1, ni[c]));
+            if ((uint32_t)m > (uint32_t)tlen || (uint32_t)(m - kk[c]) > (uint32_t)plen) m = WFA_OFFSET_NULL;
+            nm[c] = m;
+            const bool oob_i = ni[c] >= 0 && ((uint32_t)ni[c] > (uint32_t)tlen || (uint32_t)(ni[c] - kk[c]) > (uint32_t)plen);
+            const bool oob_d = nd[c] >= 0 && ((uint32_t)nd[c] > (uint32_t)tlen || (uint32_t)(nd[c] - kk[c]) > (uint32_t)plen);
+            oob |= __ballot(oob_i || oob_d);
+          }
+          if (oob) {
+            // trim the ends of I and D (R/wavefront_compute.c:571-605): outside [first,last] in-bounds -> NULL
+            unsigned long long bi[NCH], bd[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+              bi[c] = __ballot((uint32_t)ni[c] <= (uint32_t)tlen && (uint32_t)(ni[c] - kk[c]) <= (uint32_t)plen);
+              bd[c] = __ballot((uint32_t)nd[c] <= (uint32_t)tlen && (uint32_t)(nd[c] - kk[c]) <= (uint32_t)plen);
+            }
+            const int ilo = BD::first_pos(bi), ihi = BD::last_pos(bi), dlo = BD::first_pos(bd), dhi = BD::last_pos(bd);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+              const int pos = c * 64 + lane;
+              if (pos < ilo || pos > ihi) ni[c] = WFA_OFFSET_NULL;
+              if (pos < dlo || pos > dhi) nd[c] = WFA_OFFSET_NULL;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) { ni[c] = WFA_OFFSET_NULL; nd[c] = WFA_OFFSET_NULL; nm[c] = WFA_OFFSET_NULL; }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { Ih[c] = ni[c]; Dh[c] = nd[c]; cur[c] = nm[c]; }
+        if (step > (1 << 24)) { fallback = true; break; }
+      }
+      if (!done) fallback = true;
+    }
+    if (FULL && !fallback) {
+      // make this wave's history stores visible to lane 0's loads
+      __syncthreads();
+      if (lane == 0) {
+        long long begin = 0;
+        uint8_t* buf = a.cigar_ops + a.cigar_off[pair];
+        band_backtrace<NCH>(hist, a, plen, tlen, end_s, end_k, end_off, buf, &begin);
+        a.cigar_begin[pair] = a.cigar_off[pair] + begin;
+        a.cigar_len[pair] = (int)((long long)plen + tlen - begin);
+      }
+    }
+    if (lane == 0) {
+      if (fallback) {
+        a.status[pair] = WFA_INTERNAL_FALLBACK;
+        a.fb_list[atomicAdd(a.fb_count, 1u)] = pair;
+      } else {
+        a.score[pair] = result;
+        a.status[pair] = 0;
+      }
+    }
+  }
+}
+
+// configurations the band kernel covers
+inline bool band_supported(const WfaDevConfig& c, int ncomp) {
+  if (ncomp != 3 || c.match != 0 || c.wildcard >= 0 || c.max_steps != INT_MAX) return false;
+  if (c.heuristic != 0 && c.heuristic != 1) return false;
+  if (c.endsfree && (c.pbf | c.pef | c.tbf | c.tef)) return false;
+  const int g = gcd_int(gcd_int(c.x, c.o1 + c.e1), c.e1);
+  return (c.x / g == 2 && (c.o1 + c.e1) / g == 4 && c.e1 / g == 1);
+}
+
+template <int NCH, bool FULL, bool ADAPT>
+static int launch_band_t(const BandArgs& a, bool seqlds, long long grid, hipStream_t stream) {
+  const size_t smem = seqlds ? (size_t)a.lds_words * 2 * sizeof(uint32_t) : 0;
+  if (seqlds) hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, true>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+  else hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, false>), dim3((unsigned)grid), dim3(64), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+inline int launch_band(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds, long long grid, hipStream_t stream) {
+#define WFA_BAND_CASE(N)                                                                     \
+  if (nch == N) {                                                                            \
+    if (full) return adapt ? launch_band_t<N, true, true>(a, seqlds, grid, stream)           \
+                           : launch_band_t<N, true, false>(a, seqlds, grid, stream);         \
+    return adapt ? launch_band_t<N, false, true>(a, seqlds, grid, stream)                    \
+                 : launch_band_t<N, false, false>(a, seqlds, grid, stream);                  \
+  }
+  WFA_BAND_CASE(1)
+  WFA_BAND_CASE(2)
+  WFA_BAND_CASE(4)
+#undef WFA_BAND_CASE
+  return -1;
+}
+
+}  // namespace wfa

@@ -18,6 +18,7 @@
 #include "wfa_pack.hpp"
 #include "wfa_general.hpp"
 #include "wfa_fast.hpp"
+#include "wfa_band.hpp"
 
 #define WFA_HIP_ABI_VERSION 1
 
@@ -62,7 +63,8 @@ struct wfa_hip_batch {
   uint32_t* d_list_packed = nullptr;  // worklists (nullptr = identity over all pairs)
   uint32_t* d_list_bytes = nullptr;
   uint32_t n_packed = 0, n_bytes = 0;
-  uint32_t* d_fb_list = nullptr;   // pairs handed from the fast kernel to the general kernel
+  uint32_t* d_fb_list2[2] = {nullptr, nullptr};  // leftover lists handed from one kernel stage to the next (ping-pong)
+  const uint32_t* leftover_count = nullptr;       // device count of the pairs that reached the general kernel
   uint32_t* d_ovf_list[2] = {nullptr, nullptr};  // pairs whose arena overflowed
   uint32_t* d_counters = nullptr;  // [0] fallback count, [1] overflow count A, [2] overflow count B
   std::vector<hipEvent_t> ev;   // 2 events per run since the last sync (kernel timing)
@@ -238,7 +240,7 @@ static void batch_free(wfa_hip_batch* b) {
   (void)hipSetDevice(b->al->device);
   void* ptrs[] = {b->d_bytes, b->d_pboff, b->d_tboff, b->d_meta, b->d_words, b->d_flags, b->d_score, b->d_status,
                   b->d_ops, b->d_cigar_off, b->d_cigar_begin, b->d_cigar_len, b->d_list_packed, b->d_list_bytes,
-                  b->d_fb_list, b->d_ovf_list[0], b->d_ovf_list[1], b->d_counters};
+                  b->d_fb_list2[0], b->d_fb_list2[1], b->d_ovf_list[0], b->d_ovf_list[1], b->d_counters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
   delete b;
@@ -286,7 +288,8 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
   HIP_TRY(al, hipMalloc((void**)&b->d_flags, nn));
   HIP_TRY(al, hipMalloc((void**)&b->d_score, nn * sizeof(int32_t)));
   HIP_TRY(al, hipMalloc((void**)&b->d_status, nn * sizeof(int32_t)));
-  HIP_TRY(al, hipMalloc((void**)&b->d_fb_list, nn * sizeof(uint32_t)));
+  HIP_TRY(al, hipMalloc((void**)&b->d_fb_list2[0], nn * sizeof(uint32_t)));
+  HIP_TRY(al, hipMalloc((void**)&b->d_fb_list2[1], nn * sizeof(uint32_t)));
   HIP_TRY(al, hipMalloc((void**)&b->d_counters, 16 * sizeof(uint32_t)));
   HIP_TRY(al, hipMemsetAsync(b->d_counters, 0, 16 * sizeof(uint32_t), al->stream));
   HIP_TRY(al, hipMemsetAsync(b->d_flags, 0, nn, al->stream));
@@ -423,11 +426,11 @@ static Geometry plan_general(wfa_hip_aligner* al, const wfa_hip_batch* b, uint32
   Geometry g;
   const bool full = (al->cfg.scope == WFA_SCOPE_FULL);
   int threads = 64;
-  if (b->max_len > 2000) threads = (al->cfg.heuristic == WFA_HEUR_ADAPTIVE) ? 128 : 256;
+  if (b->max_len > 2000) threads = (al->cfg.heuristic == WFA_HEUR_ADAPTIVE) ? 64 : 256;
   threads = env_int("WFA_HIP_THREADS", threads);
   threads = std::max(64, std::min(512, (threads / 64) * 64));
   const int waves = threads / 64;
-  int per_cu = std::max(1, env_int("WFA_HIP_WAVES_PER_CU", 16) / waves);
+  int per_cu = std::max(1, env_int("WFA_HIP_WAVES_PER_CU", 32) / waves);
   int64_t grid = (int64_t)al->cu_count * per_cu;
   grid = std::min<int64_t>(grid, std::max<uint32_t>(nwork, 1));
   int64_t stride;
@@ -466,34 +469,97 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
   HIP_TRY(al, hipMemsetAsync(b->d_counters, 0, 16 * sizeof(uint32_t), stream));
   b->arena_ints = full ? initial_arena_ints(al, b) : 0;
 
-  // 1) the fast register-resident kernel takes the 2-bit pairs it supports; what does not fit its
-  //    diagonal window is appended to d_fb_list and finished by the general kernel below.
-  const bool use_fast = wfa::fast_supported(al->dcfg, al->ncomp, full) && b->n_packed > 0 && env_int("WFA_HIP_NO_FAST", 0) == 0;
+  // A cascade of kernels over the 2-bit pairs: each stage aligns what fits it and appends the rest to
+  // a leftover list (pair ids + a device-side count) that the next stage consumes on the same stream;
+  // the general kernel at the end takes everything.  All stages compute the same wavefronts, so which
+  // stage finishes a pair does not change its result.
   while (b->ev.size() < b->ev_used + 2) { hipEvent_t e; HIP_TRY(al, hipEventCreate(&e)); b->ev.push_back(e); }
   hipEvent_t ev0 = b->ev[b->ev_used], ev1 = b->ev[b->ev_used + 1];
   b->ev_used += 2; b->runs_pending += 1;
   HIP_TRY(al, hipEventRecord(ev0, stream));
-  if (use_fast) {
-    const int rc = wfa::launch_fast(al->dcfg, al->cu_count, stream, b->d_words, b->d_meta, b->d_list_packed, b->n_packed,
-                                    b->d_score, b->d_status, b->d_fb_list, b->d_counters + 0);
-    if (rc != 0) { al->err = "fast kernel launch failed"; return WFA_HIP_EDEVICE; }
-    b->last_kernel_pairs = b->n_packed;
-  }
-  // 2) general kernel over the 2-bit work list (or over the fast kernel's leftovers)
   if (b->n_packed > 0) {
-    const uint32_t nwork = b->n_packed;
-    Geometry g = plan_general(al, b, use_fast ? std::min<uint32_t>(nwork, (uint32_t)al->cu_count * 16) : nwork, b->arena_ints);
-    int rc = ensure_ws(al, (size_t)g.grid * g.ws_stride * 4);
-    if (rc != WFA_HIP_OK) return rc;
-    if (use_fast) {
-      rc = launch_general_dyn(al, b, stream, true, b->d_fb_list, b->d_counters + 0, 0, g.ws_stride, g.grid, g.threads,
-                              b->d_ovf_list[0], b->d_counters + 1);
-    } else {
-      rc = launch_general_dyn(al, b, stream, true, b->d_list_packed, nullptr, nwork, g.ws_stride, g.grid, g.threads,
-                              b->d_ovf_list[0], b->d_counters + 1);
-      b->last_kernel_pairs = nwork;
+    const uint32_t* in_list = b->d_list_packed;   // nullptr = identity
+    const uint32_t* in_count = nullptr;            // nullptr = host count
+    uint32_t in_n = b->n_packed;
+    int out_sel = 0;                               // leftovers go to d_fb_list[out_sel], count d_counters[4 + out_sel]
+    bool first_stage = true;
+    const bool adapt = (al->dcfg.heuristic == WFA_HEUR_ADAPTIVE);
+    // the general kernel's geometry is fixed first so that one workspace allocation serves every stage
+    int n_stages = 0;
+    int band_nch[3] = {0, 0, 0};
+    const bool use_fast = !full && wfa::fast_supported(al->dcfg, al->ncomp, full) && b->max_len <= WFA_FAST_MAX_LEN &&
+                          env_int("WFA_HIP_NO_FAST", 0) == 0;
+    if (wfa::band_supported(al->dcfg, al->ncomp) && env_int("WFA_HIP_NO_BAND", 0) == 0) {
+      if (adapt) {
+        if (b->max_len <= 300) { band_nch[n_stages++] = 1; }
+        band_nch[n_stages++] = 2; band_nch[n_stages++] = 4;
+      } else if (b->max_len <= 300) {
+        if (!use_fast) band_nch[n_stages++] = 1;
+        band_nch[n_stages++] = 2; band_nch[n_stages++] = 4;
+      } else if (b->max_len <= 1200) {
+        band_nch[n_stages++] = 4;
+      }
+      const int only = env_int("WFA_HIP_BAND_NCH", 0);
+      if (only) { n_stages = 1; band_nch[0] = only; }
     }
+    const bool any_pre = use_fast || n_stages > 0;
+    Geometry g = plan_general(al, b, any_pre ? std::min<uint32_t>(in_n, (uint32_t)al->cu_count * 16) : in_n, b->arena_ints);
+    size_t need = (size_t)g.grid * g.ws_stride * 4;
+    // band history: fixed-stride records per score step, one slice per wave
+    long long band_grid[3] = {0, 0, 0};
+    int64_t band_stride[3] = {0, 0, 0};
+    for (int i = 0; i < n_stages; ++i) {
+      long long grid = (long long)al->cu_count * env_int("WFA_HIP_BAND_WAVES_PER_CU", 32);
+      grid = std::min<long long>(grid, in_n);
+      if (i > 0 || use_fast) grid = std::min<long long>(grid, (long long)al->cu_count * 16);
+      if (full) {
+        const int rec = 3 * 64 * band_nch[i] + 16;
+        long long records = std::max<long long>(256, (long long)(b->max_len * 0.45) + 64);
+        records = env_int("WFA_HIP_BAND_RECORDS", (int)records);
+        band_stride[i] = ((int64_t)records * rec + 63) & ~63ll;
+        const int64_t budget = free_budget(al);
+        while (grid > 1 && grid * band_stride[i] * 4 > budget) grid = (grid + 1) / 2;
+        need = std::max(need, (size_t)grid * band_stride[i] * 4);
+      }
+      band_grid[i] = grid;
+    }
+    int rc = ensure_ws(al, need);
     if (rc != WFA_HIP_OK) return rc;
+
+    if (use_fast) {
+      uint32_t* out_list = b->d_fb_list2[out_sel];
+      uint32_t* out_count = b->d_counters + 4 + out_sel;
+      if (wfa::launch_fast(al->dcfg, al->cu_count, stream, b->d_words, b->d_meta, in_list, in_n, b->d_score, b->d_status,
+                           out_list, out_count) != 0) { al->err = "fast kernel launch failed"; return WFA_HIP_EDEVICE; }
+      b->last_kernel_pairs = in_n;
+      in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
+    }
+    for (int i = 0; i < n_stages; ++i) {
+      wfa::BandArgs ba;
+      memset(&ba, 0, sizeof(ba));
+      ba.words = b->d_words; ba.meta = b->d_meta; ba.worklist = in_list; ba.nwork_dev = in_count; ba.nwork = in_n;
+      ba.score = b->d_score; ba.status = b->d_status;
+      ba.cigar_ops = b->d_ops; ba.cigar_off = b->d_cigar_off; ba.cigar_begin = b->d_cigar_begin; ba.cigar_len = b->d_cigar_len;
+      uint32_t* out_list = b->d_fb_list2[out_sel];
+      uint32_t* out_count = b->d_counters + 4 + out_sel;
+      if (!first_stage) HIP_TRY(al, hipMemsetAsync(out_count, 0, sizeof(uint32_t), stream));
+      ba.fb_list = out_list; ba.fb_count = out_count;
+      ba.g = wfa::gcd_int(wfa::gcd_int(al->dcfg.x, al->dcfg.o1 + al->dcfg.e1), al->dcfg.e1);
+      ba.x = al->dcfg.x; ba.oe = al->dcfg.o1 + al->dcfg.e1; ba.e = al->dcfg.e1;
+      ba.min_wf_len = al->dcfg.min_wf_len; ba.max_dist_thr = al->dcfg.max_dist_thr; ba.steps_between = al->dcfg.steps_between;
+      const int words = ((b->max_len + 15) >> 4) + 2;
+      const bool seqlds = ((size_t)words * 8 <= 5120) && env_int("WFA_HIP_BAND_NO_LDS", 0) == 0;
+      ba.lds_words = seqlds ? words : 0;
+      ba.hist = al->ws; ba.hist_stride = band_stride[i];
+      if (wfa::launch_band(ba, band_nch[i], full, adapt, seqlds, band_grid[i], stream) != 0) { al->err = "band kernel launch failed"; return WFA_HIP_EDEVICE; }
+      if (first_stage) b->last_kernel_pairs = in_n;
+      in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
+    }
+    b->leftover_count = in_count;
+    rc = launch_general_dyn(al, b, stream, true, in_list, in_count, in_n, g.ws_stride, g.grid, g.threads,
+                            b->d_ovf_list[0], b->d_counters + 1);
+    if (rc != WFA_HIP_OK) return rc;
+    if (first_stage) b->last_kernel_pairs = in_n;
   }
   HIP_TRY(al, hipEventRecord(ev1, stream));
   // 3) 8-bit pairs (non-ACGT letters, wildcard matching)
@@ -542,7 +608,7 @@ static int retry_overflows(wfa_hip_batch* b) {
     for (int kind = 0; kind < 2; ++kind) {
       std::vector<uint32_t>& l = kind ? lb : lp;
       if (l.empty()) continue;
-      uint32_t* d_l = b->d_fb_list;  // free to reuse: the first pass is complete
+      uint32_t* d_l = b->d_fb_list2[0];  // free to reuse: the first pass is complete
       HIP_TRY(al, hipMemcpy(d_l, l.data(), l.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
       Geometry g = plan_general(al, b, (uint32_t)l.size(), b->arena_ints);
       int rc = ensure_ws(al, (size_t)g.grid * g.ws_stride * 4);
@@ -574,7 +640,7 @@ extern "C" int wfa_hip_batch_sync(wfa_hip_batch_t* b) {
     b->last_ms = b->ms_runs ? (float)(b->ms_sum / b->ms_runs) : 0.f;
     b->ev_used = 0; b->runs_pending = 0;
     uint32_t fb = 0;
-    HIP_TRY(al, hipMemcpy(&fb, b->d_counters, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (b->leftover_count) HIP_TRY(al, hipMemcpy(&fb, b->leftover_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
     b->last_fallback = fb;
     if (al->cfg.scope == WFA_SCOPE_FULL) {
       const int rc = retry_overflows(b);

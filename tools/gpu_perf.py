@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Throughput of the BASELINE configurations beyond C2 (development aid + numbers for DESIGN.md)."""
+import os, sys, time, json
+import numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+from oracle import loader
+from pywfa_amd import datagen, _native
+import common
+
+def run(label, n, L, e, seed, kw, cpu_n=None, reps=2, check=True):
+    batch = datagen.generate(n, L, e, seed)
+    kw = common.clamp_free(kw, batch)
+    oc, nc = common.configs_pair(**kw)
+    full = oc.scope == 1
+    al = _native.Aligner(nc); t0 = time.time(); rb = al.batch(batch); t_up = time.time() - t0
+    rb.run(); rb.sync()
+    t0 = time.time()
+    for _ in range(reps): rb.run()
+    rb.sync(); wall = (time.time() - t0) / reps
+    ms, pairs = rb.last_kernel()
+    score, status, cig = rb.results(full)
+    fb = rb.fallback_pairs(); alg = rb.algorithmic_bytes(); rb.close(); al.close()
+    cpu_n = min(n, cpu_n or n)
+    sub = datagen.subset(batch, np.arange(cpu_n))
+    fn = loader.reference() if loader.have_reference() else loader.oracle()
+    t0 = time.time(); o = loader.run(fn, oc, sub); t_cpu = time.time() - t0
+    bad = int(((score[:cpu_n] != o["score"]) | (status[:cpu_n] != o["status"])).sum())
+    if full and check:
+        ops, cbeg, clen = cig
+        bad += sum(1 for i in range(cpu_n) if ops[cbeg[i]:cbeg[i]+clen[i]].tobytes() != o["cigars"][i])
+    rec = dict(label=label, n=n, L=L, e=e, kernel_ms=ms, wall_ms=wall*1e3, aln_per_s=n/wall, cpu_aln_per_s=cpu_n/t_cpu,
+               speedup_vs_1thread=(n/wall)/(cpu_n/t_cpu), mismatches=bad, fallback=fb, mean_score=float(score.mean()),
+               nonzero_status=int((status != 0).sum()), upload_s=t_up, cfg=kw)
+    print(json.dumps(rec), flush=True)
+    return rec
+
+which = sys.argv[1:] or ["C1", "C3", "C3s", "C4a", "C5", "E5", "E10"]
+if "C1" in which: run("C1 150bp full", 1000000, 150, 0.02, 1001, dict(scope="full"), cpu_n=200000)
+if "E5" in which: run("150bp 5% score", 1000000, 150, 0.05, 1002, dict(span="end-to-end", scope="score"), cpu_n=100000)
+if "E10" in which: run("150bp 10% full", 500000, 150, 0.10, 1002, dict(scope="full"), cpu_n=50000)
+if "C3" in which: run("C3 10kb adaptive full", 100000, 10000, 0.08, 1003, dict(span="end-to-end", scope="full", heuristic="adaptive"), cpu_n=400)
+if "C3s" in which: run("10kb adaptive score", 100000, 10000, 0.08, 1003, dict(span="end-to-end", scope="score", heuristic="adaptive"), cpu_n=400)
+if "C3x" in which: run("10kb exact score", 2000, 10000, 0.08, 1003, dict(span="end-to-end", scope="score"), cpu_n=40)
+if "C4a" in which: run("C4 10kb affine2p endsfree adaptive full", 10000, 10000, 0.08, 1004, dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="full", heuristic="adaptive"), cpu_n=200)
+if "C5" in which: run("C5 100kb xdrop", 2000, 100000, 0.08, 1005, dict(span="end-to-end", scope="full", heuristic="X-drop", xdrop=20), cpu_n=100)
+if "C5a" in which: run("100kb adaptive full", 500, 100000, 0.08, 1005, dict(span="end-to-end", scope="full", heuristic="adaptive"), cpu_n=10)
