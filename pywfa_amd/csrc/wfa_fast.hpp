@@ -42,7 +42,12 @@ struct FastArgs {
   int g;  // score step = gcd(x, o+e, e)
 };
 
-// X, OE, E: mismatch, gap_open+gap_extend, gap_extend in units of g
+// X, OE, E: mismatch, gap_open+gap_extend, gap_extend in units of g.
+// Work assignment: a wave takes CHUNKS of 64 consecutive pairs — one coalesced load of the 64 metadata
+// records, lane j keeps the result of pair j, one coalesced store of 64 scores / statuses at the end —
+// so every HBM line of the batch is touched by exactly one wave (no sector over-fetch across XCDs,
+// no single-dword result stores); the next pair's packed words are prefetched into registers while
+// the current pair is aligned.
 template <int X, int OE, int E>
 __global__ void __launch_bounds__(64)
 wfa_fast_kernel(const FastArgs a) {
@@ -51,97 +56,119 @@ wfa_fast_kernel(const FastArgs a) {
   __shared__ uint32_t sT[WFA_FAST_WORDS];
   const int lane = threadIdx.x;
   const int k = lane - 32;
+  const uint32_t nchunks = (a.nwork + 63u) >> 6;
 
-  for (uint32_t wi = blockIdx.x; wi < a.nwork; wi += gridDim.x) {
-    const uint32_t pair = a.worklist ? a.worklist[wi] : wi;
-    const WfaPairMeta pm = a.meta[pair];
-    const int plen = pm.plen, tlen = pm.tlen;
-    const int ak = tlen - plen;
-    bool fallback = (plen > WFA_FAST_MAX_LEN) || (tlen > WFA_FAST_MAX_LEN) || (ak < -30) || (ak > 29);
-    int result = 0;
-    if (!fallback) {
-      // stage the packed sequences (one trailing word is read by the funnel shift)
-      const int nwp = (plen + 15) >> 4, nwt = (tlen + 15) >> 4;
-      __syncthreads();  // previous pair's LDS reads are done
-      if (lane <= nwp && lane < WFA_FAST_WORDS) sP[lane] = (lane < nwp) ? a.words[pm.p_woff + lane] : 0u;
-      if (lane <= nwt && lane < WFA_FAST_WORDS) sT[lane] = (lane < nwt) ? a.words[pm.t_woff + lane] : 0u;
-      __syncthreads();
-
-      int Mh[DM], Ih[E], Dh[E];
-#pragma unroll
-      for (int j = 0; j < DM; ++j) Mh[j] = WFA_OFFSET_NULL;
-#pragma unroll
-      for (int j = 0; j < E; ++j) { Ih[j] = WFA_OFFSET_NULL; Dh[j] = WFA_OFFSET_NULL; }
-      int cur = (k == 0) ? 0 : WFA_OFFSET_NULL;  // wavefront 0 (R/wavefront_aligner.c:251-310)
-      int s = 0;
-      bool done = false;
-      for (int step = 0; step < 4096; ++step) {
-        // ---------------- extend M[s] (R/wavefront_extend_kernels.c:64-110) ----------------
-        if (__any(cur >= 0)) {
-          bool active = cur >= 0;
-          int h = cur, v = cur - k;
-          int left = active ? min(plen - v, tlen - h) : 0;
-          while (__any(active)) {
-            const int vi = active ? v : 0, hi_ = active ? h : 0;
-            const uint32_t p0 = sP[vi >> 4], p1 = sP[(vi >> 4) + 1];
-            const uint32_t t0 = sT[hi_ >> 4], t1 = sT[(hi_ >> 4) + 1];
-            const uint32_t pw = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)(vi & 15) << 1);
-            const uint32_t tw = __builtin_amdgcn_alignbit(t1, t0, (uint32_t)(hi_ & 15) << 1);
-            const uint32_t x = pw ^ tw;
-            int m = x ? (__builtin_ctz(x) >> 1) : 16;
-            m = min(m, left);
-            if (active) { v += m; h += m; left -= m; }
-            active = active && (m == 16) && (left > 0);
-          }
-          if (cur >= 0) cur = h;
-          // ---------------- termination (R/wavefront_termination.c:37-61) ----------------
-          const int at_end = __builtin_amdgcn_readlane(cur, ak + 32);
-          if (at_end >= tlen) { done = true; result = -s; break; }
-          // window check: a live diagonal on either edge lane may spill out of the 64-diagonal window
-          const unsigned long long bm = __ballot(cur >= 0);
-          if (bm & 0x8000000000000001ull) { fallback = true; break; }
-        }
-        // ---------------- compute-next for score s+g ----------------
-        // history shift: Mh[0] = M[s], Mh[1] = M[s-g], ...
-#pragma unroll
-        for (int j = DM - 1; j > 0; --j) Mh[j] = Mh[j - 1];
-        Mh[0] = cur;
-        s += a.g;
-        const int mx = Mh[X - 1], mo = Mh[OE - 1], ie = Ih[E - 1], de = Dh[E - 1];
-        const bool any_in = __any((mx >= 0) | (mo >= 0) | (ie >= 0) | (de >= 0));
-        int ni = WFA_OFFSET_NULL, nd = WFA_OFFSET_NULL, nm = WFA_OFFSET_NULL;
-        if (any_in) {
-          const int mo_lo = from_lane_below(mo, WFA_OFFSET_NULL), ie_lo = from_lane_below(ie, WFA_OFFSET_NULL);
-          const int mo_hi = from_lane_above(mo, WFA_OFFSET_NULL), de_hi = from_lane_above(de, WFA_OFFSET_NULL);
-          ni = max(mo_lo, ie_lo) + 1;
-          nd = max(mo_hi, de_hi);
-          nm = max(nd, max(mx + 1, ni));
-          if ((uint32_t)nm > (uint32_t)tlen || (uint32_t)(nm - k) > (uint32_t)plen) nm = WFA_OFFSET_NULL;
-          // trim the ends of I and D (R/wavefront_compute.c:571-605): outside [first,last] in-bounds -> NULL
-          const bool inb_i = (uint32_t)ni <= (uint32_t)tlen && (uint32_t)(ni - k) <= (uint32_t)plen;
-          const bool inb_d = (uint32_t)nd <= (uint32_t)tlen && (uint32_t)(nd - k) <= (uint32_t)plen;
-          const unsigned long long bi = __ballot(inb_i), bd = __ballot(inb_d);
-          const int ilo = bi ? (int)__builtin_ctzll(bi) : 64, ihi = bi ? 63 - (int)__builtin_clzll(bi) : -1;
-          const int dlo = bd ? (int)__builtin_ctzll(bd) : 64, dhi = bd ? 63 - (int)__builtin_clzll(bd) : -1;
-          if (lane < ilo || lane > ihi) ni = WFA_OFFSET_NULL;
-          if (lane < dlo || lane > dhi) nd = WFA_OFFSET_NULL;
-          if ((bi | bd) & 0x8000000000000001ull) { fallback = true; break; }
-        }
-#pragma unroll
-        for (int j = E - 1; j > 0; --j) { Ih[j] = Ih[j - 1]; Dh[j] = Dh[j - 1]; }
-        Ih[0] = ni; Dh[0] = nd;
-        cur = nm;
-      }
-      if (!done) fallback = true;
+  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const uint32_t base = chunk << 6;
+    const int cnt = (int)min(64u, a.nwork - base);
+    const uint32_t my_pair = (lane < cnt) ? (a.worklist ? a.worklist[base + lane] : base + lane) : 0u;
+    WfaPairMeta my_meta = a.meta[my_pair];
+    int my_score = 0;
+    bool my_fb = false;
+    // prefetch the first pair's words: lanes 0..31 pattern word `lane`, lanes 32..63 text word `lane-32`
+    uint32_t next_w = 0;
+    {
+      const uint32_t woff = (lane < 32) ? __builtin_amdgcn_readlane(my_meta.p_woff, 0) : __builtin_amdgcn_readlane(my_meta.t_woff, 0);
+      const int len = (lane < 32) ? __builtin_amdgcn_readlane(my_meta.plen, 0) : __builtin_amdgcn_readlane(my_meta.tlen, 0);
+      const int idx = lane & 31;
+      if (len <= WFA_FAST_MAX_LEN && idx < ((len + 15) >> 4)) next_w = a.words[woff + idx];
     }
-    if (lane == 0) {
-      if (fallback) {
-        a.status[pair] = WFA_INTERNAL_FALLBACK;
-        a.fb_list[atomicAdd(a.fb_count, 1u)] = pair;
-      } else {
-        a.score[pair] = result;
-        a.status[pair] = 0;
+    for (int j = 0; j < cnt; ++j) {
+      const int plen = __builtin_amdgcn_readlane(my_meta.plen, j);
+      const int tlen = __builtin_amdgcn_readlane(my_meta.tlen, j);
+      const int ak = tlen - plen;
+      bool fallback = (plen > WFA_FAST_MAX_LEN) || (tlen > WFA_FAST_MAX_LEN) || (ak < -30) || (ak > 29);
+      // stage this pair's words (prefetched), then prefetch the next pair's
+      __syncthreads();
+      if (lane < 32) sP[lane] = next_w; else sT[lane - 32] = next_w;
+      if (lane == 0) { sP[32] = 0u; sP[33] = 0u; sT[32] = 0u; sT[33] = 0u; }
+      next_w = 0;
+      if (j + 1 < cnt) {
+        const uint32_t woff = (lane < 32) ? __builtin_amdgcn_readlane(my_meta.p_woff, j + 1) : __builtin_amdgcn_readlane(my_meta.t_woff, j + 1);
+        const int len = (lane < 32) ? __builtin_amdgcn_readlane(my_meta.plen, j + 1) : __builtin_amdgcn_readlane(my_meta.tlen, j + 1);
+        const int idx = lane & 31;
+        if (len <= WFA_FAST_MAX_LEN && idx < ((len + 15) >> 4)) next_w = a.words[woff + idx];
       }
+      __syncthreads();
+      int result = 0;
+      if (!fallback) {
+        int Mh[DM], Ih[E], Dh[E];
+#pragma unroll
+        for (int q = 0; q < DM; ++q) Mh[q] = WFA_OFFSET_NULL;
+#pragma unroll
+        for (int q = 0; q < E; ++q) { Ih[q] = WFA_OFFSET_NULL; Dh[q] = WFA_OFFSET_NULL; }
+        int cur = (k == 0) ? 0 : WFA_OFFSET_NULL;  // wavefront 0 (R/wavefront_aligner.c:251-310)
+        int s = 0;
+        bool done = false;
+        for (int step = 0; step < 4096; ++step) {
+          // ---------------- extend M[s] (R/wavefront_extend_kernels.c:64-110) ----------------
+          const unsigned long long bm = __ballot(cur >= 0);
+          if (bm) {
+            // a live diagonal on either edge lane may spill out of the 64-diagonal window
+            if (bm & 0x8000000000000001ull) { fallback = true; break; }
+            const bool live = cur >= 0;
+            int h = live ? cur : 0, v = live ? cur - k : 0;
+            int left = live ? min(plen - v, tlen - h) : 0;  // dead lanes: nothing left to compare
+            bool more = left > 0;
+            while (__any(more)) {
+              const uint32_t p0 = sP[v >> 4], p1 = sP[(v >> 4) + 1];
+              const uint32_t t0 = sT[h >> 4], t1 = sT[(h >> 4) + 1];
+              const uint32_t pw = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v << 1);
+              const uint32_t tw = __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h << 1);
+              const uint32_t x = pw ^ tw;
+              const int m = min(x ? (__builtin_ctz(x) >> 1) : 16, left);
+              v += m; h += m; left -= m;
+              more = (m == 16) && (left > 0);
+            }
+            if (live) cur = h;
+            // ---------------- termination (R/wavefront_termination.c:37-61) ----------------
+            if (__builtin_amdgcn_readlane(cur, ak + 32) >= tlen) { done = true; result = -s; break; }
+          }
+          // ---------------- compute-next for score s+g ----------------
+#pragma unroll
+          for (int q = DM - 1; q > 0; --q) Mh[q] = Mh[q - 1];
+          Mh[0] = cur;
+          s += a.g;
+          const int mx = Mh[X - 1], mo = Mh[OE - 1], ie = Ih[E - 1], de = Dh[E - 1];
+          int ni = WFA_OFFSET_NULL, nd = WFA_OFFSET_NULL, nm = WFA_OFFSET_NULL;
+          if (__any((mx & mo & ie & de) >= 0)) {  // some input offset is not NULL-ish
+            ni = max(from_lane_below(mo, WFA_OFFSET_NULL), from_lane_below(ie, WFA_OFFSET_NULL)) + 1;
+            nd = max(from_lane_above(mo, WFA_OFFSET_NULL), from_lane_above(de, WFA_OFFSET_NULL));
+            nm = max(nd, max(mx + 1, ni));
+            if ((uint32_t)nm > (uint32_t)tlen || (uint32_t)(nm - k) > (uint32_t)plen) nm = WFA_OFFSET_NULL;
+            // ends of I and D (R/wavefront_compute.c:571-605).  Trimming only changes anything when a
+            // LIVE offset is out of bounds (dead lanes are NULL-ish already): rare, near the sequence ends
+            const bool oob_i = ni >= 0 && ((uint32_t)ni > (uint32_t)tlen || (uint32_t)(ni - k) > (uint32_t)plen);
+            const bool oob_d = nd >= 0 && ((uint32_t)nd > (uint32_t)tlen || (uint32_t)(nd - k) > (uint32_t)plen);
+            if (__any(oob_i || oob_d)) {
+              const unsigned long long bi = __ballot(ni >= 0 && !oob_i), bd = __ballot(nd >= 0 && !oob_d);
+              const int ilo = bi ? (int)__builtin_ctzll(bi) : 64, ihi = bi ? 63 - (int)__builtin_clzll(bi) : -1;
+              const int dlo = bd ? (int)__builtin_ctzll(bd) : 64, dhi = bd ? 63 - (int)__builtin_clzll(bd) : -1;
+              if (lane < ilo || lane > ihi) ni = WFA_OFFSET_NULL;
+              if (lane < dlo || lane > dhi) nd = WFA_OFFSET_NULL;
+            }
+            if (__ballot((ni >= 0) || (nd >= 0)) & 0x8000000000000001ull) { fallback = true; break; }
+          }
+#pragma unroll
+          for (int q = E - 1; q > 0; --q) { Ih[q] = Ih[q - 1]; Dh[q] = Dh[q - 1]; }
+          Ih[0] = ni; Dh[0] = nd;
+          cur = nm;
+        }
+        if (!done) fallback = true;
+      }
+      if (lane == j) { my_score = result; my_fb = fallback; }
+    }
+    // ---- coalesced results; compacted append of the leftovers ----
+    if (lane < cnt) {
+      if (!my_fb) a.score[my_pair] = my_score;
+      a.status[my_pair] = my_fb ? WFA_INTERNAL_FALLBACK : 0;
+    }
+    const unsigned long long fbm = __ballot(my_fb && lane < cnt);
+    if (fbm) {
+      uint32_t slot = 0;
+      if (lane == 0) slot = atomicAdd(a.fb_count, (uint32_t)__builtin_popcountll(fbm));
+      slot = __builtin_amdgcn_readfirstlane(slot);
+      if (my_fb && lane < cnt) a.fb_list[slot + __builtin_popcountll(fbm & ((1ull << lane) - 1ull))] = my_pair;
     }
   }
 }
@@ -168,7 +195,8 @@ inline int launch_fast(const WfaDevConfig& c, int cu_count, hipStream_t stream, 
   const char* env = getenv("WFA_HIP_FAST_WAVES_PER_CU");
   const int per_cu = (env && *env) ? atoi(env) : 32;
   long long grid = (long long)cu_count * per_cu;
-  if (grid > (long long)nwork) grid = nwork;
+  const long long nchunks = ((long long)nwork + 63) / 64;
+  if (grid > nchunks) grid = nchunks;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL((wfa_fast_kernel<2, 4, 1>), dim3((unsigned)grid), dim3(64), 0, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
