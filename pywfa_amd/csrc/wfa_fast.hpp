@@ -98,63 +98,63 @@ wfa_fast_kernel(const FastArgs a) {
 #pragma unroll
         for (int q = 0; q < E; ++q) { Ih[q] = WFA_OFFSET_NULL; Dh[q] = WFA_OFFSET_NULL; }
         int cur = (k == 0) ? 0 : WFA_OFFSET_NULL;  // wavefront 0 (R/wavefront_aligner.c:251-310)
-        int s = 0;
-        bool done = false;
-        for (int step = 0; step < 4096; ++step) {
+        const int lim = min(tlen, plen + k);
+        int edge = -1;  // AND of every offset this lane has held: non-negative once one was live
+        int step = 0;
+        for (;;) {
           // ---------------- extend M[s] (R/wavefront_extend_kernels.c:64-110) ----------------
-          const unsigned long long bm = __ballot(cur >= 0);
-          if (bm) {
-            // a live diagonal on either edge lane may spill out of the 64-diagonal window
-            if (bm & 0x8000000000000001ull) { fallback = true; break; }
+          // in-bounds <=> offset <= lim, lim = min(tlen, plen + k); remaining run length = lim - offset
+          {
             const bool live = cur >= 0;
-            int h = live ? cur : 0, v = live ? cur - k : 0;
-            int left = live ? min(plen - v, tlen - h) : 0;  // dead lanes: nothing left to compare
-            bool more = left > 0;
-            while (__any(more)) {
-              const uint32_t p0 = sP[v >> 4], p1 = sP[(v >> 4) + 1];
-              const uint32_t t0 = sT[h >> 4], t1 = sT[(h >> 4) + 1];
-              const uint32_t pw = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v << 1);
-              const uint32_t tw = __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h << 1);
-              const uint32_t x = pw ^ tw;
-              const int m = min(x ? (__builtin_ctz(x) >> 1) : 16, left);
-              v += m; h += m; left -= m;
-              more = (m == 16) && (left > 0);
+            int h = max(cur, 0), v = max(cur - k, 0);
+            int left = live ? lim - cur : 0;  // dead lanes: nothing left to compare
+            if (__any(left > 0)) {
+              bool more;
+              do {
+                const uint32_t p0 = sP[v >> 4], p1 = sP[(v >> 4) + 1];
+                const uint32_t t0 = sT[h >> 4], t1 = sT[(h >> 4) + 1];
+                const uint32_t pw = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v << 1);
+                const uint32_t tw = __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h << 1);
+                const uint32_t x = pw ^ tw;
+                const int m = min(x ? (__builtin_ctz(x) >> 1) : 16, left);
+                v += m; h += m; left -= m;
+                more = (m == 16) && (left > 0);
+              } while (__any(more));
+              cur = live ? h : cur;
             }
-            if (live) cur = h;
-            // ---------------- termination (R/wavefront_termination.c:37-61) ----------------
-            if (__builtin_amdgcn_readlane(cur, ak + 32) >= tlen) { done = true; result = -s; break; }
           }
+          // ---------------- termination (R/wavefront_termination.c:37-61) ----------------
+          if (__builtin_amdgcn_readlane(cur, ak + 32) >= tlen) { result = -(step * a.g); break; }
           // ---------------- compute-next for score s+g ----------------
 #pragma unroll
           for (int q = DM - 1; q > 0; --q) Mh[q] = Mh[q - 1];
           Mh[0] = cur;
-          s += a.g;
           const int mx = Mh[X - 1], mo = Mh[OE - 1], ie = Ih[E - 1], de = Dh[E - 1];
           int ni = WFA_OFFSET_NULL, nd = WFA_OFFSET_NULL, nm = WFA_OFFSET_NULL;
           if (__any((mx & mo & ie & de) >= 0)) {  // some input offset is not NULL-ish
             ni = max(from_lane_below(mo, WFA_OFFSET_NULL), from_lane_below(ie, WFA_OFFSET_NULL)) + 1;
             nd = max(from_lane_above(mo, WFA_OFFSET_NULL), from_lane_above(de, WFA_OFFSET_NULL));
             nm = max(nd, max(mx + 1, ni));
-            if ((uint32_t)nm > (uint32_t)tlen || (uint32_t)(nm - k) > (uint32_t)plen) nm = WFA_OFFSET_NULL;
+            if (nm > lim) nm = WFA_OFFSET_NULL;  // only M is clamped (negative values are dead already)
             // ends of I and D (R/wavefront_compute.c:571-605).  Trimming only changes anything when a
             // LIVE offset is out of bounds (dead lanes are NULL-ish already): rare, near the sequence ends
-            const bool oob_i = ni >= 0 && ((uint32_t)ni > (uint32_t)tlen || (uint32_t)(ni - k) > (uint32_t)plen);
-            const bool oob_d = nd >= 0 && ((uint32_t)nd > (uint32_t)tlen || (uint32_t)(nd - k) > (uint32_t)plen);
-            if (__any(oob_i || oob_d)) {
-              const unsigned long long bi = __ballot(ni >= 0 && !oob_i), bd = __ballot(nd >= 0 && !oob_d);
+            if (__any(max(ni, nd) > lim)) {
+              const unsigned long long bi = __ballot(ni >= 0 && ni <= lim), bd = __ballot(nd >= 0 && nd <= lim);
               const int ilo = bi ? (int)__builtin_ctzll(bi) : 64, ihi = bi ? 63 - (int)__builtin_clzll(bi) : -1;
               const int dlo = bd ? (int)__builtin_ctzll(bd) : 64, dhi = bd ? 63 - (int)__builtin_clzll(bd) : -1;
               if (lane < ilo || lane > ihi) ni = WFA_OFFSET_NULL;
               if (lane < dlo || lane > dhi) nd = WFA_OFFSET_NULL;
             }
-            if (__ballot((ni >= 0) || (nd >= 0)) & 0x8000000000000001ull) { fallback = true; break; }
+            edge &= nm & ni & nd;
           }
 #pragma unroll
           for (int q = E - 1; q > 0; --q) { Ih[q] = Ih[q - 1]; Dh[q] = Dh[q - 1]; }
           Ih[0] = ni; Dh[0] = nd;
           cur = nm;
+          ++step;
+          // a live diagonal on either edge lane may spill out of the 64-diagonal window
+          if ((__ballot(edge >= 0) & 0x8000000000000001ull) || step >= 4096) { fallback = true; break; }
         }
-        if (!done) fallback = true;
       }
       if (lane == j) { my_score = result; my_fb = fallback; }
     }
