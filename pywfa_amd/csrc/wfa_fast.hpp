@@ -111,14 +111,16 @@ wfa_fast_kernel(const FastArgs a) {
             if (__any(left > 0)) {
               bool more;
               do {
-                const uint32_t p0 = sP[v >> 4], p1 = sP[(v >> 4) + 1];
-                const uint32_t t0 = sT[h >> 4], t1 = sT[(h >> 4) + 1];
-                const uint32_t pw = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v << 1);
-                const uint32_t tw = __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h << 1);
-                const uint32_t x = pw ^ tw;
-                const int m = min(x ? (__builtin_ctz(x) >> 1) : 16, left);
+                // 32 bases per iteration: three packed words per sequence, two funnel shifts each
+                const int pi = v >> 4, ti = h >> 4;
+                const uint32_t p0 = sP[pi], p1 = sP[pi + 1], p2 = sP[pi + 2];
+                const uint32_t t0 = sT[ti], t1 = sT[ti + 1], t2 = sT[ti + 2];
+                const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h << 1);
+                const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t2, t1, (uint32_t)h << 1);
+                int m = xl ? (__builtin_ctz(xl) >> 1) : (xh ? 16 + (__builtin_ctz(xh) >> 1) : 32);
+                m = min(m, left);
                 v += m; h += m; left -= m;
-                more = (m == 16) && (left > 0);
+                more = (m == 32) && (left > 0);
               } while (__any(more));
               cur = live ? h : cur;
             }
