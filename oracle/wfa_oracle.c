@@ -41,7 +41,8 @@ typedef struct {
 typedef struct {
   /* penalties after wavefront_penalties_set_* (R/wavefront_penalties.c:95-173) */
   int match, x, o1, e1, o2, e2;
-  int ncomp; /* 3 affine, 5 affine2p */
+  int ncomp; /* 1 indel/edit/linear, 3 affine, 5 affine2p */
+  int metric; /* WFA_DIST_* */
   int scope; /* max_score_scope (R/wavefront_components.c:81-124) */
   /* history: comp-major tables indexed by score (full) or score % scope (score-only) */
   wf_t* wf[5]; /* 0=M 1=I1 2=D1 3=I2 4=D2 */
@@ -173,7 +174,39 @@ static void wf_trim(oracle_ws_t* ws, wf_t* w, int plen, int tlen) {
  * R/wavefront_compute_affine2p.c:45-106,286-368; limits R/wavefront_compute.c:40-86;
  * which outputs exist R/wavefront_compute.c:440-485).  Returns 1 for a null step.
  */
+/*
+ * Single-component metrics.  gap-linear: R/wavefront_compute_linear.c:44-74,208-241 with limits
+ * R/wavefront_compute.c:40-58; edit / indel: R/wavefront_compute_edit.c:44-100,374-418 (the same
+ * recurrence with x = o = 1; indel has no mismatch term; these two never take a null step).
+ */
+static int compute_next_linear(oracle_ws_t* ws, int s, int plen, int tlen, int* err) {
+  const int indel = (ws->metric == WFA_DIST_INDEL);
+  wf_in_t mx = wf_fetch(ws, 0, indel ? -1 : s - ws->x);
+  wf_in_t mo = wf_fetch(ws, 0, s - ws->o1);
+  wf_slot(ws, 0, s)->exists = 0;
+  if (mx.null && mo.null) return 1;
+  int lo = mo.lo - 1, hi = mo.hi + 1;
+  if (!indel) { lo = MIN2(mx.lo, lo); hi = MAX2(mx.hi, hi); }
+  if (wf_alloc(ws, 0, s, lo, hi)) { *err = 1; return 0; }
+  mx = wf_fetch(ws, 0, indel ? -1 : s - ws->x);
+  mo = wf_fetch(ws, 0, s - ws->o1);
+  int32_t* om = ws->arena + wf_slot(ws, 0, s)->idx;
+  int k;
+  for (k = lo; k <= hi; ++k) {
+    const int32_t ins = wf_get(&mo, k - 1), del = wf_get(&mo, k + 1);
+    int32_t mv = indel ? MAX2(del, ins + 1) : MAX2(del, MAX2(wf_get(&mx, k), ins) + 1);
+    const uint32_t h = (uint32_t)mv;
+    const uint32_t v = (uint32_t)(mv - k);
+    if (h > (uint32_t)tlen) mv = OFFSET_NULL;
+    if (v > (uint32_t)plen) mv = OFFSET_NULL;
+    om[k - lo] = mv;
+  }
+  wf_trim(ws, wf_slot(ws, 0, s), plen, tlen);
+  return 0;
+}
+
 static int compute_next(oracle_ws_t* ws, int s, int plen, int tlen, int* err) {
+  if (ws->ncomp == 1) return compute_next_linear(ws, s, plen, tlen, err);
   const int two = (ws->ncomp == 5);
   wf_in_t mx = wf_fetch(ws, 0, s - ws->x);
   wf_in_t mo1 = wf_fetch(ws, 0, s - ws->o1 - ws->e1);
@@ -390,6 +423,35 @@ static void backtrace(oracle_ws_t* ws, int plen, int tlen, int end_s, int end_k,
   enum { BT_I1_OPEN = 1, BT_I1_EXT, BT_I2_OPEN, BT_I2_EXT, BT_D1_OPEN, BT_D1_EXT, BT_D2_OPEN,
          BT_D2_EXT, BT_M };
   const int two = (ws->ncomp == 5);
+  if (ws->ncomp == 1) {
+    /* R/wavefront_backtrace.c:223-319 (wavefront_backtrace_linear) */
+    int s = end_s, k = end_k;
+    int32_t offset = end_off;
+    int h = offset, v = offset - k;
+    if (v < plen) ops_push(ops, 'D', plen - v);
+    if (h < tlen) ops_push(ops, 'I', tlen - h);
+    while (v > 0 && h > 0 && s > 0) {
+      const int s_x = s - ws->x, s_o = s - ws->o1;
+      int64_t best = (ws->metric != WFA_DIST_INDEL) ? bt_cand(ws, 0, s_x, k, 1, BT_M) : OFFSET_NULL;
+      best = MAX2(best, bt_cand(ws, 0, s_o, k - 1, 1, BT_I1_OPEN));
+      best = MAX2(best, bt_cand(ws, 0, s_o, k + 1, 0, BT_D1_OPEN));
+      if (best < 0) break;
+      const int32_t src = (int32_t)(best >> 4);
+      ops_push(ops, 'M', offset - src);
+      offset = src;
+      v = offset - k; h = offset;
+      if (v <= 0 || h <= 0) break;
+      const int type = (int)(best & 0xF);
+      if (type == BT_M) { s = s_x; ops_push(ops, 'X', 1); --offset; }
+      else if (type == BT_I1_OPEN) { s = s_o; ops_push(ops, 'I', 1); --k; --offset; }
+      else { s = s_o; ops_push(ops, 'D', 1); ++k; }
+      v = offset - k; h = offset;
+    }
+    if (v > 0 && h > 0) { const int n = MIN2(v, h); ops_push(ops, 'M', n); v -= n; h -= n; }
+    ops_push(ops, 'D', v > 0 ? v : 0);
+    ops_push(ops, 'I', h > 0 ? h : 0);
+    return;
+  }
   int comp = 0; /* 0=M 1=I1 2=D1 3=I2 4=D2 */
   int s = end_s, k = end_k;
   int32_t offset = end_off;
@@ -471,6 +533,7 @@ static void backtrace(oracle_ws_t* ws, int plen, int tlen, int end_s, int end_k,
 
 /* R/wavefront_compute.c:108-120 + R/wavefront_penalties.h:73 */
 static int classic_score(const oracle_ws_t* ws, int v, int h, int s) {
+  if (ws->metric <= WFA_DIST_EDIT) return s; /* distances are reported as they are */
   if (ws->match == 0) return -s;
   return ((-ws->match) * (v + h) - s) / 2;
 }
@@ -609,6 +672,27 @@ static int align_one(oracle_ws_t* ws, const wfa_hip_config_t* cfg, const uint8_t
 
 /* R/wavefront_penalties.c:95-173 */
 static int ws_set_penalties(oracle_ws_t* ws, const wfa_hip_config_t* cfg) {
+  ws->metric = cfg->distance;
+  if (cfg->distance == WFA_DIST_INDEL || cfg->distance == WFA_DIST_EDIT) {
+    /* R/wavefront_penalties.c:39-64, R/wavefront_components.c:43-56 */
+    ws->ncomp = 1; ws->match = 0; ws->x = 1; ws->o1 = 1; ws->e1 = 1; ws->o2 = 1; ws->e2 = 1; ws->scope = 2;
+    return 0;
+  }
+  if (cfg->distance == WFA_DIST_LINEAR) {
+    /* R/wavefront_penalties.c:65-94 (pywfa passes gap_extension as the indel penalty, align.pyx:351-355) */
+    if (cfg->match > 0 || cfg->mismatch <= 0 || cfg->gap_extension <= 0) return -1;
+    ws->ncomp = 1;
+    if (cfg->match < 0) {
+      ws->match = cfg->match;
+      ws->x = 2 * cfg->mismatch - 2 * cfg->match;
+      ws->o1 = 2 * cfg->gap_extension - cfg->match;
+    } else {
+      ws->match = 0; ws->x = cfg->mismatch; ws->o1 = cfg->gap_extension;
+    }
+    ws->e1 = ws->o2 = ws->e2 = 1;
+    ws->scope = MAX2(ws->x, ws->o1) + 1; /* R/wavefront_components.c:57-74 */
+    return 0;
+  }
   if (cfg->distance != WFA_DIST_AFFINE && cfg->distance != WFA_DIST_AFFINE2P) return -1;
   const int two = (cfg->distance == WFA_DIST_AFFINE2P);
   if (cfg->match > 0 || cfg->mismatch <= 0 || cfg->gap_opening < 0 || cfg->gap_extension <= 0) return -1;

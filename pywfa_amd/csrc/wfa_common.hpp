@@ -24,6 +24,7 @@ struct WfaPairMeta {
 // Penalties after wavefront_penalties_set_affine/affine2p (wavefront_penalties.c:95-173) and the
 // rest of the per-aligner configuration, in the form the kernels consume.
 struct WfaDevConfig {
+  int32_t metric; // WFA_DIST_* (0 indel, 1 edit, 2 linear, 3 affine, 4 affine2p)
   int32_t match;  // <= 0 (original match score)
   int32_t x, o1, e1, o2, e2;  // adjusted penalties
   int32_t scope;  // max_score_scope (wavefront_components.c:81-124)

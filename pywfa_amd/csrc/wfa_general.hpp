@@ -145,6 +145,36 @@ struct OpsWriter {
   }
 };
 
+// R/wavefront_backtrace.c:223-319 (single-component metrics), single lane.
+__device__ inline void backtrace_linear(const int* ws, long long ws_stride, const WfaDevConfig& cfg, int plen, int tlen,
+                                        int end_s, int end_k, int end_off, OpsWriter& ops) {
+  enum { BT_I1_OPEN = 1, BT_D1_OPEN = 5, BT_M = 9 };
+  int s = end_s, k = end_k, offset = end_off;
+  int h = offset, v = offset - k;
+  if (v < plen) ops.push('D', plen - v);
+  if (h < tlen) ops.push('I', tlen - h);
+  while (v > 0 && h > 0 && s > 0) {
+    const int s_x = s - cfg.x, s_o = s - cfg.o1;
+    long long best = (cfg.metric != 0) ? bt_cand<1>(ws, ws_stride, s_x, 0, k, 1, BT_M) : (long long)WFA_OFFSET_NULL;
+    best = max(best, bt_cand<1>(ws, ws_stride, s_o, 0, k - 1, 1, BT_I1_OPEN));
+    best = max(best, bt_cand<1>(ws, ws_stride, s_o, 0, k + 1, 0, BT_D1_OPEN));
+    if (best < 0) break;
+    const int src = (int)(best >> 4);
+    ops.push('M', offset - src);
+    offset = src;
+    v = offset - k; h = offset;
+    if (v <= 0 || h <= 0) break;
+    const int type = (int)(best & 0xF);
+    if (type == BT_M) { s = s_x; ops.push('X', 1); --offset; }
+    else if (type == BT_I1_OPEN) { s = s_o; ops.push('I', 1); --k; --offset; }
+    else { s = s_o; ops.push('D', 1); ++k; }
+    v = offset - k; h = offset;
+  }
+  if (v > 0 && h > 0) { const int n = min(v, h); ops.push('M', n); v -= n; h -= n; }
+  ops.push('D', max(v, 0));
+  ops.push('I', max(h, 0));
+}
+
 // R/wavefront_backtrace.c:320-529, single lane.
 template <int NCOMP>
 __device__ void backtrace(const int* ws, long long ws_stride, const WfaDevConfig& cfg, int plen, int tlen,
@@ -221,6 +251,7 @@ __device__ void backtrace(const int* ws, long long ws_stride, const WfaDevConfig
 
 // R/wavefront_compute.c:108-120 with WF_SCORE_TO_SW_SCORE (R/wavefront_penalties.h:73)
 __device__ __forceinline__ int classic_score(const WfaDevConfig& cfg, int v, int h, int s) {
+  if (cfg.metric <= 1) return s;  // indel / edit distances are reported as they are
   if (cfg.match == 0) return -s;
   return ((-cfg.match) * (v + h) - s) / 2;
 }
@@ -398,19 +429,22 @@ wfa_general_kernel(const WfaKernelArgs a) {
       ++s;
       __syncthreads();  // meta ring updates of the cut-off are visible; EK reads are done
       if (tid == 0) { EK[0] = INT_MAX; EK[1] = INT_MAX; EK[2] = INT_MAX; EK[3] = INT_MIN; EK[4] = INT_MIN; }
-      const WfIn mx = fetch_in<NCOMP>(ring, scope, s - cfg.x, 0);
+      // single-component metrics (NCOMP == 1: indel / edit / gap-linear, R/wavefront_compute_edit.c:44-100,
+      // R/wavefront_compute_linear.c:44-74) are the same recurrence with no I/D inputs and the gap
+      // penalty in place of o+e (cfg.e1 == 0); indel has no mismatch input
+      WfIn nullin; nullin.lo = 1; nullin.hi = -1; nullin.idx0 = 0;
+      const WfIn mx = (NCOMP == 1 && cfg.metric == 0) ? nullin : fetch_in<NCOMP>(ring, scope, s - cfg.x, 0);
       const WfIn mo1 = fetch_in<NCOMP>(ring, scope, s - cfg.o1 - cfg.e1, 0);
-      const WfIn i1e = fetch_in<NCOMP>(ring, scope, s - cfg.e1, 1);
-      const WfIn d1e = fetch_in<NCOMP>(ring, scope, s - cfg.e1, 2);
-      WfIn mo2, i2e, d2e;
-      mo2.lo = i2e.lo = d2e.lo = 1; mo2.hi = i2e.hi = d2e.hi = -1; mo2.idx0 = i2e.idx0 = d2e.idx0 = 0;
+      const WfIn i1e = (NCOMP == 1) ? nullin : fetch_in<NCOMP>(ring, scope, s - cfg.e1, 1);
+      const WfIn d1e = (NCOMP == 1) ? nullin : fetch_in<NCOMP>(ring, scope, s - cfg.e1, 2);
+      WfIn mo2 = nullin, i2e = nullin, d2e = nullin;
       if (NCOMP == 5) {
         mo2 = fetch_in<NCOMP>(ring, scope, s - cfg.o2 - cfg.e2, 0);
         i2e = fetch_in<NCOMP>(ring, scope, s - cfg.e2, 3);
         d2e = fetch_in<NCOMP>(ring, scope, s - cfg.e2, 4);
       }
       const bool all_null = mx.null() && mo1.null() && i1e.null() && d1e.null() &&
-                            (NCOMP == 3 || (mo2.null() && i2e.null() && d2e.null()));
+                            (NCOMP != 5 || (mo2.null() && i2e.null() && d2e.null()));
       int* const mslot = ring + (s % scope) * MT::INTS;
       if (all_null) {
         ++null_steps;
@@ -424,15 +458,17 @@ wfa_general_kernel(const WfaKernelArgs a) {
         null_steps = 0;
         int lo = mx.lo, hi = mx.hi;
         lo = min(lo, mo1.lo - 1); hi = max(hi, mo1.hi + 1);
-        lo = min(lo, i1e.lo + 1); hi = max(hi, i1e.hi + 1);
-        lo = min(lo, d1e.lo - 1); hi = max(hi, d1e.hi - 1);
+        if (NCOMP != 1) {
+          lo = min(lo, i1e.lo + 1); hi = max(hi, i1e.hi + 1);
+          lo = min(lo, d1e.lo - 1); hi = max(hi, d1e.hi - 1);
+        }
         if (NCOMP == 5) {
           lo = min(lo, mo2.lo - 1); hi = max(hi, mo2.hi + 1);
           lo = min(lo, i2e.lo + 1); hi = max(hi, i2e.hi + 1);
           lo = min(lo, d2e.lo - 1); hi = max(hi, d2e.hi - 1);
         }
-        const bool has_i1 = !mo1.null() || !i1e.null();
-        const bool has_d1 = !mo1.null() || !d1e.null();
+        const bool has_i1 = (NCOMP != 1) && (!mo1.null() || !i1e.null());
+        const bool has_d1 = (NCOMP != 1) && (!mo1.null() || !d1e.null());
         const bool has_i2 = (NCOMP == 5) && (!mo2.null() || !i2e.null());
         const bool has_d2 = (NCOMP == 5) && (!mo2.null() || !d2e.null());
         int base, width, data;
@@ -454,11 +490,11 @@ wfa_general_kernel(const WfaKernelArgs a) {
           int ins = ins1, del = del1;
           if (has_i1) {
             ws[o_i1 + k] = ins1;
-            if ((uint32_t)ins1 <= (uint32_t)tlen && (uint32_t)(ins1 - k) <= (uint32_t)plen) { tmin[1] = min(tmin[1], k); tmax[1] = max(tmax[1], k); }
+            if ((uint32_t)ins1 <= (uint32_t)tlen && (uint32_t)(ins1 - k) <= (uint32_t)plen) { tmin[NCOMP > 1 ? 1 : 0] = min(tmin[NCOMP > 1 ? 1 : 0], k); tmax[NCOMP > 1 ? 1 : 0] = max(tmax[NCOMP > 1 ? 1 : 0], k); }
           }
           if (has_d1) {
             ws[o_d1 + k] = del1;
-            if ((uint32_t)del1 <= (uint32_t)tlen && (uint32_t)(del1 - k) <= (uint32_t)plen) { tmin[2] = min(tmin[2], k); tmax[2] = max(tmax[2], k); }
+            if ((uint32_t)del1 <= (uint32_t)tlen && (uint32_t)(del1 - k) <= (uint32_t)plen) { tmin[NCOMP > 2 ? 2 : 0] = min(tmin[NCOMP > 2 ? 2 : 0], k); tmax[NCOMP > 2 ? 2 : 0] = max(tmax[NCOMP > 2 ? 2 : 0], k); }
           }
           if (NCOMP == 5) {
             const int ins2 = max(mo2.get(ws, k - 1), i2e.get(ws, k - 1)) + 1;
@@ -527,7 +563,7 @@ wfa_general_kernel(const WfaKernelArgs a) {
         if (end_reason == 1) { out_score = classic_score(cfg, plen, tlen, s); out_status = 0; }
         else {
           // the reference evaluates the score at its unset end position (k=INT_MAX, offset=NULL)
-          out_score = (cfg.match == 0) ? -s : (int)(((long long)(-cfg.match) * 1 - s) / 2);
+          out_score = (cfg.metric <= 1) ? s : (cfg.match == 0) ? -s : (int)(((long long)(-cfg.match) * 1 - s) / 2);
           out_status = 1;
         }
       } else {
@@ -535,7 +571,8 @@ wfa_general_kernel(const WfaKernelArgs a) {
           OpsWriter ops;
           ops.buf = a.cigar_ops + a.cigar_off[pair];
           ops.begin = (long long)plen + tlen;
-          backtrace<NCOMP>(ws, ws_stride, cfg, plen, tlen, s, end_k, end_off, ops);
+          if (NCOMP == 1) backtrace_linear(ws, ws_stride, cfg, plen, tlen, s, end_k, end_off, ops);
+          else backtrace<NCOMP == 1 ? 3 : NCOMP>(ws, ws_stride, cfg, plen, tlen, s, end_k, end_off, ops);
           cbeg = a.cigar_off[pair] + ops.begin;
           clen = (int)((long long)plen + tlen - ops.begin);
           out_score = classic_score(cfg, end_off - end_k, end_off, s);

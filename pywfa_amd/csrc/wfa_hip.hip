@@ -132,12 +132,18 @@ extern "C" int wfa_hip_config_validate(const wfa_hip_config_t* c, char* err, siz
   if (!c) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "null config");
   if (c->distance < WFA_DIST_INDEL || c->distance > WFA_DIST_AFFINE2P)
     return fail_cfg(err, errlen, WFA_HIP_EINVAL, "unknown distance");
-  if (c->distance != WFA_DIST_AFFINE && c->distance != WFA_DIST_AFFINE2P)
-    return fail_cfg(err, errlen, WFA_HIP_ENOTSUP, "distance not on the accelerated path (only affine / affine2p)");
-  // wavefront_penalties.c:95-173 (the reference prints and exit(1)s)
-  if (c->match > 0) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "Match score must be negative or zero");
-  if (c->mismatch <= 0 || c->gap_opening < 0 || c->gap_extension <= 0)
-    return fail_cfg(err, errlen, WFA_HIP_EINVAL, "Penalties must be (X>0,O>=0,E>0)");
+  // wavefront_penalties.c:65-173 (the reference prints and exit(1)s)
+  if (c->distance == WFA_DIST_LINEAR) {
+    if (c->match > 0) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "Match score must be negative or zero");
+    if (c->mismatch <= 0 || c->gap_extension <= 0) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "Penalties must be (X>0,D>0,I>0)");
+  } else if (c->distance >= WFA_DIST_AFFINE) {
+    if (c->match > 0) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "Match score must be negative or zero");
+    if (c->mismatch <= 0 || c->gap_opening < 0 || c->gap_extension <= 0)
+      return fail_cfg(err, errlen, WFA_HIP_EINVAL, "Penalties must be (X>0,O>=0,E>0)");
+  } else if (c->heuristic == WFA_HEUR_XDROP) {
+    // wavefront_align.c:80-85
+    return fail_cfg(err, errlen, WFA_HIP_EINVAL, "Heuristics drops are not compatible with 'edit'/'indel' distance metrics");
+  }
   if (c->distance == WFA_DIST_AFFINE2P && (c->gap_opening2 < 0 || c->gap_extension2 <= 0))
     return fail_cfg(err, errlen, WFA_HIP_EINVAL, "Penalties must be (X>0,O1>=0,E1>0,O2>=0,E2>0)");
   if (c->scope != WFA_SCOPE_SCORE && c->scope != WFA_SCOPE_FULL) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "unknown scope");
@@ -147,7 +153,7 @@ extern "C" int wfa_hip_config_validate(const wfa_hip_config_t* c, char* err, siz
   if (c->memory_mode == WFA_MEM_BIWFA) return fail_cfg(err, errlen, WFA_HIP_ENOTSUP, "memory_mode biwfa is not on the accelerated path");
   if (c->pattern_begin_free < 0 || c->pattern_end_free < 0 || c->text_begin_free < 0 || c->text_end_free < 0)
     return fail_cfg(err, errlen, WFA_HIP_EINVAL, "ends-free sizes must be >= 0");
-  if (c->match < 0 && c->span == WFA_SPAN_ENDSFREE && (c->pattern_begin_free > 0 || c->text_begin_free > 0))
+  if (c->distance >= WFA_DIST_LINEAR && c->match < 0 && c->span == WFA_SPAN_ENDSFREE && (c->pattern_begin_free > 0 || c->text_begin_free > 0))
     return fail_cfg(err, errlen, WFA_HIP_ENOTSUP, "match<0 with free begins (ends-free re-seeding) is not on the accelerated path");
   if (c->wildcard < -1 || c->wildcard > 255) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "wildcard must be -1 or a byte");
   if (c->reserved != 0) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "reserved must be 0");
@@ -156,6 +162,26 @@ extern "C" int wfa_hip_config_validate(const wfa_hip_config_t* c, char* err, siz
 
 static void derive_dev_config(const wfa_hip_config_t& c, WfaDevConfig* d, int* ncomp) {
   const bool two = (c.distance == WFA_DIST_AFFINE2P);
+  d->metric = c.distance;
+  if (c.distance <= WFA_DIST_LINEAR) {
+    // single-component metrics: wavefront_penalties.c:39-94, wavefront_components.c:43-74
+    *ncomp = 1;
+    d->match = 0; d->x = 1; d->o1 = 1;
+    if (c.distance == WFA_DIST_LINEAR) {
+      if (c.match < 0) { d->match = c.match; d->x = 2 * c.mismatch - 2 * c.match; d->o1 = 2 * c.gap_extension - c.match; }
+      else { d->x = c.mismatch; d->o1 = c.gap_extension; }  // pywfa passes gap_extension as the indel penalty (align.pyx:351-355)
+    }
+    d->e1 = 0; d->o2 = d->o1; d->e2 = 0;
+    d->scope = (c.distance == WFA_DIST_LINEAR) ? std::max(d->x, d->o1) + 1 : 2;
+    d->endsfree = (c.span == WFA_SPAN_ENDSFREE);
+    d->pbf = c.pattern_begin_free; d->pef = c.pattern_end_free; d->tbf = c.text_begin_free; d->tef = c.text_end_free;
+    d->heuristic = c.heuristic;
+    d->min_wf_len = c.min_wavefront_length; d->max_dist_thr = c.max_distance_threshold;
+    d->steps_between = c.steps_between_cutoffs; d->xdrop = c.xdrop;
+    d->max_steps = (c.max_steps <= 0) ? INT_MAX : c.max_steps;
+    d->wildcard = c.wildcard;
+    return;
+  }
   *ncomp = two ? 5 : 3;
   // Eizenga rescaling when match<0 (wavefront_penalties.c:113-122,148-164)
   if (c.match < 0) {
@@ -404,6 +430,10 @@ static int launch_general_dyn(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t
                               const uint32_t* worklist, const uint32_t* nwork_dev, uint32_t nwork_host,
                               int64_t ws_stride, int grid, int threads, uint32_t* ovf_list, uint32_t* ovf_count) {
   const bool full = (al->cfg.scope == WFA_SCOPE_FULL);
+  if (al->ncomp == 1) {
+    return full ? launch_general<1, true>(al, b, stream, packed, worklist, nwork_dev, nwork_host, ws_stride, grid, threads, ovf_list, ovf_count)
+                : launch_general<1, false>(al, b, stream, packed, worklist, nwork_dev, nwork_host, ws_stride, grid, threads, ovf_list, ovf_count);
+  }
   if (al->ncomp == 3) {
     return full ? launch_general<3, true>(al, b, stream, packed, worklist, nwork_dev, nwork_host, ws_stride, grid, threads, ovf_list, ovf_count)
                 : launch_general<3, false>(al, b, stream, packed, worklist, nwork_dev, nwork_host, ws_stride, grid, threads, ovf_list, ovf_count);

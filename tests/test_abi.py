@@ -40,7 +40,7 @@ def test_abi_version_and_default_config():
 @pytest.mark.parametrize("field,value,code", [
     ("match", 1, _native.EINVAL), ("mismatch", 0, _native.EINVAL), ("gap_opening", -1, _native.EINVAL),
     ("gap_extension", 0, _native.EINVAL), ("scope", 7, _native.EINVAL), ("span", 3, _native.EINVAL),
-    ("heuristic", 9, _native.EINVAL), ("distance", 1, _native.ENOTSUP), ("distance", 2, _native.ENOTSUP),
+    ("heuristic", 9, _native.EINVAL), ("distance", 7, _native.EINVAL),
     ("memory_mode", 3, _native.ENOTSUP), ("pattern_begin_free", -2, _native.EINVAL), ("wildcard", 300, _native.EINVAL),
 ])
 def test_validate_rejects(field, value, code):
@@ -49,6 +49,16 @@ def test_validate_rejects(field, value, code):
     setattr(c, field, value)
     rc, msg = _native.validate(c)
     assert rc == code and msg
+
+
+def test_validate_single_component_metrics():
+    for d in (0, 1, 2):
+        c = _native.default_config()
+        c.distance = d
+        assert _native.validate(c)[0] == _native.OK
+    c = _native.default_config()
+    c.distance, c.heuristic = 1, 2   # X-drop with edit: the reference exit(1)s (wavefront_align.c:80-85)
+    assert _native.validate(c)[0] == _native.EINVAL
 
 
 def test_validate_accepts_affine2p():

@@ -20,6 +20,8 @@ CONFIGS = [
     dict(heuristic="X-drop", xdrop=20, scope="score"),
     dict(max_steps=10),
     dict(match=-1, span="end-to-end"),
+    dict(distance="indel"), dict(distance="levenshtein", heuristic="adaptive"), dict(distance="linear", mismatch=3, gap_extension=5),
+    dict(distance="linear", match=-1, span="end-to-end", scope="score"),
 ]
 
 

@@ -49,6 +49,13 @@ GRID += [
     dict(distance="affine", max_steps=10), dict(distance="affine2p", max_steps=25, scope="score"),
     dict(distance="affine", memory_mode="medium"), dict(distance="affine2p", memory_mode="low", span="end-to-end"),
     dict(distance="affine", wildcard="N"),
+    # single-component metrics
+    dict(distance="indel"), dict(distance="indel", span="end-to-end", scope="score"),
+    dict(distance="levenshtein"), dict(distance="levenshtein", span="end-to-end", scope="score", heuristic="adaptive"),
+    dict(distance="levenshtein", span="ends-free", pattern_begin_free=8, pattern_end_free=7, text_begin_free=3, text_end_free=2),
+    dict(distance="linear"), dict(distance="linear", mismatch=3, gap_extension=5, span="end-to-end"),
+    dict(distance="linear", heuristic="X-drop", xdrop=100), dict(distance="linear", match=-1, span="end-to-end"),
+    dict(distance="linear", max_steps=12, scope="score"), dict(distance="indel", heuristic="adaptive", scope="score"),
 ]
 
 SHAPES = {"150bp_2pct": (1500, 150, 0.02), "150bp_15pct": (400, 150, 0.15), "1kb_8pct": (60, 1000, 0.08)}

@@ -140,6 +140,9 @@ def python_surface_cases():
         {"op": "call", "text": "ACGTCCGTACGT"}, {"op": "call", "text": "ACGTCCGNACGT"}]})
     cases.append({"name": "endsfree_sizes", "ctor": dict(pattern="GGGGAAAAACCGGGGG", pattern_begin_free=4, pattern_end_free=5, text_begin_free=5, text_end_free=5), "steps": [
         {"op": "call", "text": "CCCCCAAAAACCTTTTT"}, {"op": "get", "name": "pattern_begin_free"}]})
+    for d in ("indel", "levenshtein", "linear"):
+        cases.append({"name": f"distance_{d}", "ctor": {"pattern": P1, "distance": d}, "steps": [
+            {"op": "get", "name": "distance"}, {"op": "call", "text": T1}, {"op": "align", "text": T2, "pattern": P2}]})
     cases.append({"name": "empty_text", "ctor": {"pattern": "ACGT"}, "steps": [{"op": "call", "text": ""}]})
     cases.append({"name": "pattern_none", "ctor": {}, "steps": [{"op": "call", "text": "ACGT"}]})
     cases.append({"name": "bad_scope", "ctor": {"scope": "half"}, "steps": []})
@@ -215,7 +218,10 @@ def c_level_vectors():
     corpora = {"special": vo.corpus_special()}
     for L, e, n in ((150, 0.02, 64), (150, 0.15, 48), (1000, 0.08, 10)):
         corpora[f"L{L}_e{e}"] = datagen.generate(n, L, e, 4242 + L)
-    cfgs = vo.configs(True)[::3] + [dict(distance="affine", span="end-to-end", scope="score"),
+    cfgs = vo.configs(True)[::3] + [dict(distance="indel"), dict(distance="levenshtein", span="end-to-end"),
+                                    dict(distance="levenshtein", heuristic="adaptive", scope="score"),
+                                    dict(distance="linear", mismatch=3, gap_extension=5), dict(distance="linear", match=-1, span="end-to-end"),
+                                    dict(distance="affine", span="end-to-end", scope="score"),
                                     dict(distance="affine2p", span="ends-free", scope="full", pattern_begin_free=8, pattern_end_free=7, text_begin_free=3, text_end_free=2)]
     out = {"corpora": {}, "runs": []}
     for name, b in corpora.items():
