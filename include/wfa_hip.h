@@ -182,6 +182,21 @@ int64_t wfa_hip_batch_algorithmic_bytes(const wfa_hip_batch_t* batch);
 /* Pairs the fast (register/LDS) kernel handed to the general kernel in the last run. */
 int64_t wfa_hip_batch_fallback_pairs(const wfa_hip_batch_t* batch);
 
+/* ---- result surface on the device ------------------------------------------ */
+
+/*
+ * What pywfa derives per pair in Python from cigar->operations after each call — the run-length
+ * encoded `cigartuples` (align.pyx:759-786; op codes M=0 I=1 D=2 X=8) and the `locations`
+ * (pattern_start, pattern_end, text_start, text_end; align.pyx:788-833) — for the whole batch of the
+ * last scope=full run, computed on the GPU.
+ *   step 1  wfa_hip_batch_rle_counts: run_count[n] and locations[4n]; returns the total number of runs
+ *           (or a negative WFA_HIP_E* code)
+ *   step 2  wfa_hip_batch_rle_runs: run_code[total], run_len[total] in pair order
+ *           (pair i owns runs [sum(run_count[:i]), +run_count[i]))
+ */
+int64_t wfa_hip_batch_rle_counts(wfa_hip_batch_t* batch, int32_t* run_count, int32_t* locations);
+int wfa_hip_batch_rle_runs(wfa_hip_batch_t* batch, uint8_t* run_code, int32_t* run_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,7 @@ SYMBOLS = [
     "wfa_hip_get_config", "wfa_hip_last_error", "wfa_hip_align_batch", "wfa_hip_batch_create",
     "wfa_hip_batch_destroy", "wfa_hip_batch_run", "wfa_hip_batch_sync", "wfa_hip_batch_results",
     "wfa_hip_batch_last_kernel_ms", "wfa_hip_batch_algorithmic_bytes", "wfa_hip_batch_fallback_pairs",
+    "wfa_hip_batch_rle_counts", "wfa_hip_batch_rle_runs",
 ]
 
 
@@ -95,6 +96,9 @@ def lib():
     L.wfa_hip_batch_algorithmic_bytes.restype = i64
     L.wfa_hip_batch_fallback_pairs.argtypes = [vp]
     L.wfa_hip_batch_fallback_pairs.restype = i64
+    L.wfa_hip_batch_rle_counts.argtypes = [vp, vp, vp]
+    L.wfa_hip_batch_rle_counts.restype = i64
+    L.wfa_hip_batch_rle_runs.argtypes = [vp, vp, vp]
     if L.wfa_hip_abi_version() != ABI_VERSION:
         raise NativeError("libwfa_hip.so ABI version mismatch: rebuild it")
     _lib = L
@@ -267,6 +271,25 @@ class ResidentBatch:
         if rc != OK:
             self.aligner._raise(rc, "wfa_hip_batch_last_kernel_ms")
         return ms.value, pairs.value
+
+    def rle(self):
+        """cigartuples + locations of the whole batch, computed on the GPU.
+
+        Returns run_off int64[n+1], run_code uint8[total], run_len int32[total], locations int32[n,4]."""
+        n = self.n
+        cnt = np.zeros(n, np.int32)
+        locs = np.zeros((n, 4), np.int32)
+        total = lib().wfa_hip_batch_rle_counts(self._h, _ptr(cnt), _ptr(locs))
+        if total < 0:
+            self.aligner._raise(int(total), "wfa_hip_batch_rle_counts")
+        code = np.zeros(max(int(total), 1), np.uint8)
+        rlen = np.zeros(max(int(total), 1), np.int32)
+        rc = lib().wfa_hip_batch_rle_runs(self._h, _ptr(code), _ptr(rlen))
+        if rc != OK:
+            self.aligner._raise(rc, "wfa_hip_batch_rle_runs")
+        off = np.zeros(n + 1, np.int64)
+        np.cumsum(cnt, out=off[1:])
+        return off, code[:total], rlen[:total], locs
 
     def algorithmic_bytes(self):
         return int(lib().wfa_hip_batch_algorithmic_bytes(self._h))

@@ -21,7 +21,7 @@ import numpy as np
 from . import _native
 from . import datagen
 
-__all__ = ["WavefrontAligner", "AlignmentResult", "clip_cigartuples", "cigartuples_to_str",
+__all__ = ["WavefrontAligner", "AlignmentResult", "BatchResults", "clip_cigartuples", "cigartuples_to_str",
            "elide_mismatches_from_cigar"]
 
 # CIGAR tuple codes (align.pyx:11-14, README.rst:61-86): M I D N S H P = X B
@@ -230,6 +230,35 @@ def _ops_to_string(ops):
     return "".join(f"{int(n)}{chr(int(c))}" for c, n in zip(ch, ln))
 
 
+class BatchResults:
+    """Results of a whole batch with the Python-side surface pre-computed on the device: ``score``,
+    ``status``, run-length encoded CIGARs (``run_off``, ``run_code``, ``run_len``) and ``locations``
+    (n x 4: pattern_start, pattern_end, text_start, text_end).  ``res[i]`` builds the AlignmentResult
+    that ``WavefrontAligner.__call__`` would return for pair i."""
+
+    def __init__(self, batch, score, status, run_off, run_code, run_len, locations):
+        self._batch = batch
+        self.score, self.status = score, status
+        self.run_off, self.run_code, self.run_len = run_off, run_code, run_len
+        self.locations = locations
+
+    def __len__(self):
+        return len(self.score)
+
+    def cigartuples(self, i):
+        a, b = int(self.run_off[i]), int(self.run_off[i + 1])
+        return [(int(c), int(n)) for c, n in zip(self.run_code[a:b], self.run_len[a:b])]
+
+    def cigarstring(self, i):
+        return cigartuples_to_str(self.cigartuples(i))
+
+    def __getitem__(self, i):
+        p, t = datagen.pair_strings(self._batch, i)
+        ps, pe, ts, te = (int(x) for x in self.locations[i])
+        return AlignmentResult(len(p), len(t), ps, pe, ts, te, self.cigartuples(i), int(self.score[i]), p, t,
+                               int(self.status[i]))
+
+
 class WavefrontAligner:
     """Drop-in for ``pywfa.WavefrontAligner`` on the GPU. If a pattern is supplied it is cached."""
 
@@ -375,6 +404,21 @@ class WavefrontAligner:
             out["cigar_ops"] = [ops[cbeg[i]:cbeg[i] + clen[i]] for i in range(len(score))]
             out["cigarstrings"] = [_ops_to_string(o) for o in out["cigar_ops"]]
         return out
+
+    def align_batch_results(self, batch, patterns_texts=None):
+        """Align a batch (scope must be "full") and return a ``BatchResults``: scores, statuses, and the
+        cigartuples / locations of every pair computed on the GPU (what ``__call__`` derives per pair)."""
+        if self._cfg.scope != 1:
+            raise ValueError("align_batch_results needs scope='full'")
+        rb = self._native.batch(batch)
+        try:
+            rb.run()
+            rb.sync()
+            score, status, _ = rb.results(False)
+            off, code, rlen, locs = rb.rle()
+        finally:
+            rb.close()
+        return BatchResults(batch, score, status, off, code, rlen, locs)
 
     def resident_batch(self, batch):
         """Upload + 2-bit pack a batch into HBM once; ``.run()`` it many times (bench.py)."""

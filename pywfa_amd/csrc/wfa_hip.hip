@@ -19,6 +19,7 @@
 #include "wfa_general.hpp"
 #include "wfa_fast.hpp"
 #include "wfa_band.hpp"
+#include "wfa_rle.hpp"
 
 #define WFA_HIP_ABI_VERSION 1
 
@@ -77,6 +78,9 @@ struct wfa_hip_batch {
   int64_t last_fallback = 0;
   hipStream_t last_stream = nullptr;
   int64_t arena_ints = 0;  // FULL: arena size used by the last launch
+  // device-side result surface (RLE)
+  int32_t* d_plen = nullptr; int32_t* d_tlen = nullptr; int32_t* d_run_count = nullptr; int32_t* d_locs = nullptr;
+  int64_t* d_run_off = nullptr; int64_t rle_total = -1;
 };
 
 #define HIP_TRY(al, expr)                                                                      \
@@ -266,7 +270,8 @@ static void batch_free(wfa_hip_batch* b) {
   (void)hipSetDevice(b->al->device);
   void* ptrs[] = {b->d_bytes, b->d_pboff, b->d_tboff, b->d_meta, b->d_words, b->d_flags, b->d_score, b->d_status,
                   b->d_ops, b->d_cigar_off, b->d_cigar_begin, b->d_cigar_len, b->d_list_packed, b->d_list_bytes,
-                  b->d_fb_list2[0], b->d_fb_list2[1], b->d_ovf_list[0], b->d_ovf_list[1], b->d_counters};
+                  b->d_fb_list2[0], b->d_fb_list2[1], b->d_ovf_list[0], b->d_ovf_list[1], b->d_counters,
+                  b->d_plen, b->d_tlen, b->d_run_count, b->d_locs, b->d_run_off};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
   delete b;
@@ -740,6 +745,73 @@ extern "C" int64_t wfa_hip_batch_algorithmic_bytes(const wfa_hip_batch_t* b) {
   int64_t bytes = b->packed_bytes + 8 * b->n;
   if (b->al->cfg.scope == WFA_SCOPE_FULL) bytes += b->ops_bytes;
   return bytes;
+}
+
+// ---- device-side cigartuples + locations ----------------------------------------------------------
+extern "C" int64_t wfa_hip_batch_rle_counts(wfa_hip_batch_t* b, int32_t* run_count, int32_t* locations) {
+  if (!b) return WFA_HIP_EINVAL;
+  wfa_hip_aligner* al = b->al;
+  if (al->cfg.scope != WFA_SCOPE_FULL) { al->err = "run-length encoding needs scope=full"; return WFA_HIP_EINVAL; }
+  int rc = wfa_hip_batch_sync(b);
+  if (rc != WFA_HIP_OK) return rc;
+  const int64_t n = b->n;
+  b->rle_total = 0;
+  if (n == 0) return 0;
+  const size_t nn = (size_t)n;
+  if (!b->d_plen) {
+    HIP_TRY(al, hipMalloc((void**)&b->d_plen, nn * 4)); HIP_TRY(al, hipMalloc((void**)&b->d_tlen, nn * 4));
+    HIP_TRY(al, hipMalloc((void**)&b->d_run_count, nn * 4)); HIP_TRY(al, hipMalloc((void**)&b->d_locs, nn * 16));
+    HIP_TRY(al, hipMalloc((void**)&b->d_run_off, (nn + 1) * 8));
+    HIP_TRY(al, hipMemcpy(b->d_plen, b->h_plen.data(), nn * 4, hipMemcpyHostToDevice));
+    HIP_TRY(al, hipMemcpy(b->d_tlen, b->h_tlen.data(), nn * 4, hipMemcpyHostToDevice));
+  }
+  const int grid = (int)std::min<int64_t>((n + 3) / 4, (int64_t)al->cu_count * 16);
+  hipLaunchKernelGGL(wfa::wfa_rle_kernel, dim3(grid), dim3(256), 0, al->stream, b->d_ops, b->d_cigar_begin, b->d_cigar_len,
+                     b->d_plen, b->d_tlen, n, b->d_run_count, b->d_locs, (const int64_t*)nullptr, (uint8_t*)nullptr, (int32_t*)nullptr);
+  HIP_TRY(al, hipGetLastError());
+  std::vector<int32_t> cnt(nn);
+  HIP_TRY(al, hipMemcpyAsync(cnt.data(), b->d_run_count, nn * 4, hipMemcpyDeviceToHost, al->stream));
+  if (locations) HIP_TRY(al, hipMemcpyAsync(locations, b->d_locs, nn * 16, hipMemcpyDeviceToHost, al->stream));
+  HIP_TRY(al, hipStreamSynchronize(al->stream));
+  std::vector<int64_t> off(nn + 1);
+  off[0] = 0;
+  for (size_t i = 0; i < nn; ++i) off[i + 1] = off[i] + cnt[i];
+  HIP_TRY(al, hipMemcpy(b->d_run_off, off.data(), (nn + 1) * 8, hipMemcpyHostToDevice));
+  if (run_count) memcpy(run_count, cnt.data(), nn * 4);
+  b->rle_total = off[nn];
+  return b->rle_total;
+}
+
+extern "C" int wfa_hip_batch_rle_runs(wfa_hip_batch_t* b, uint8_t* run_code, int32_t* run_len) {
+  if (!b) return WFA_HIP_EINVAL;
+  wfa_hip_aligner* al = b->al;
+  if (b->rle_total < 0) { al->err = "call wfa_hip_batch_rle_counts first"; return WFA_HIP_EINVAL; }
+  const int64_t n = b->n, total = b->rle_total;
+  if (n == 0 || total == 0) return WFA_HIP_OK;
+  if (!run_code || !run_len) { al->err = "null output"; return WFA_HIP_EINVAL; }
+  uint8_t* d_code = nullptr; int32_t* d_start = nullptr;
+  HIP_TRY(al, hipMalloc((void**)&d_code, (size_t)total));
+  HIP_TRY(al, hipMalloc((void**)&d_start, (size_t)total * 4));
+  const int grid = (int)std::min<int64_t>((n + 3) / 4, (int64_t)al->cu_count * 16);
+  hipLaunchKernelGGL(wfa::wfa_rle_kernel, dim3(grid), dim3(256), 0, al->stream, b->d_ops, b->d_cigar_begin, b->d_cigar_len,
+                     b->d_plen, b->d_tlen, n, b->d_run_count, b->d_locs, (const int64_t*)b->d_run_off, d_code, d_start);
+  HIP_TRY(al, hipGetLastError());
+  HIP_TRY(al, hipMemcpyAsync(run_code, d_code, (size_t)total, hipMemcpyDeviceToHost, al->stream));
+  HIP_TRY(al, hipMemcpyAsync(run_len, d_start, (size_t)total * 4, hipMemcpyDeviceToHost, al->stream));  // starts for now
+  std::vector<int32_t> cnt((size_t)n), clen((size_t)n);
+  HIP_TRY(al, hipMemcpyAsync(cnt.data(), b->d_run_count, (size_t)n * 4, hipMemcpyDeviceToHost, al->stream));
+  HIP_TRY(al, hipMemcpyAsync(clen.data(), b->d_cigar_len, (size_t)n * 4, hipMemcpyDeviceToHost, al->stream));
+  HIP_TRY(al, hipStreamSynchronize(al->stream));
+  (void)hipFree(d_code); (void)hipFree(d_start);
+  // run length = next run's start (or the end of the op string) - this run's start
+  int64_t r = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    for (int32_t j = 0; j < cnt[i]; ++j, ++r) {
+      const int32_t next = (j + 1 < cnt[i]) ? run_len[r + 1] : clen[i];
+      run_len[r] = next - run_len[r];
+    }
+  }
+  return WFA_HIP_OK;
 }
 
 extern "C" int64_t wfa_hip_batch_fallback_pairs(const wfa_hip_batch_t* b) { return b ? b->last_fallback : 0; }

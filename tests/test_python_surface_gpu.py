@@ -54,3 +54,34 @@ def test_setters_revalidate(gpu):
     assert a.memory_mode == "medium"
     a.max_steps = 1
     assert a.wavefront_align("TTTTTTTT") == -1 and a.status == -100
+
+
+def test_device_side_cigartuples_and_locations(gpu):
+    """the run-length encoded cigartuples and the locations of a whole batch computed on
+    the GPU equal what the per-pair Python code of the reference's class derives from the op string."""
+    import numpy as np
+    import validate_oracle as vo
+    from pywfa_amd import datagen
+    from pywfa_amd.align import _ops_to_tuples, _flank_scan
+    batches = [datagen.generate(3000, 150, 0.05, 41), datagen.generate(40, 3000, 0.08, 42), vo.corpus_special(seed=5)]
+    for kw in (dict(), dict(span="end-to-end"), dict(distance="affine2p", pattern_end_free=0, text_end_free=0)):
+        a = pywfa_amd.WavefrontAligner(**kw)
+        for batch in batches:
+            res = a.align_batch_results(batch)
+            out = a.align_batch(batch)
+            assert np.array_equal(res.score, out["score"]) and np.array_equal(res.status, out["status"])
+            n = len(res)
+            for i in list(range(min(n, 400))) + list(range(max(0, n - 50), n)):
+                ct = _ops_to_tuples(out["cigar_ops"][i])
+                assert res.cigartuples(i) == ct, i
+                pl, tl = int(batch["p_len"][i]), int(batch["t_len"][i])
+                if not ct or pl == 0 or tl == 0:
+                    exp = (0, 0, 0, 0)
+                else:
+                    _, _, ps, pe, ts, te = _flank_scan(ct, 1, 1, tl, pl)
+                    exp = (ps, pe, ts, te)
+                assert tuple(int(x) for x in res.locations[i]) == exp, (i, ct[:6])
+        r0 = a.align_batch_results(batches[0])[0]
+        single = a(r0.text, r0.pattern)
+        assert (r0.cigartuples, r0.score, r0.text_start, r0.text_end, r0.pattern_start, r0.pattern_end) == \
+               (single.cigartuples, single.score, single.text_start, single.text_end, single.pattern_start, single.pattern_end)
