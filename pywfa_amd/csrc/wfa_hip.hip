@@ -562,12 +562,17 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     if (rc != WFA_HIP_OK) return rc;
 
     if (use_fast) {
-      uint32_t* out_list = b->d_fb_list2[out_sel];
-      uint32_t* out_count = b->d_counters + 4 + out_sel;
-      if (wfa::launch_fast(al->dcfg, al->cu_count, stream, b->d_words, b->d_meta, in_list, in_n, b->d_score, b->d_status,
-                           out_list, out_count) != 0) { al->err = "fast kernel launch failed"; return WFA_HIP_EDEVICE; }
-      b->last_kernel_pairs = in_n;
-      in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
+      // two pairs per wave first (32 diagonals each) when the reads are short enough, then one per wave
+      const bool use_dual = b->max_len <= WFA_FAST2_MAX_LEN && env_int("WFA_HIP_NO_DUAL", 0) == 0;
+      for (int pass = use_dual ? 0 : 1; pass < 2; ++pass) {
+        uint32_t* out_list = b->d_fb_list2[out_sel];
+        uint32_t* out_count = b->d_counters + 4 + out_sel;
+        if (!first_stage) HIP_TRY(al, hipMemsetAsync(out_count, 0, sizeof(uint32_t), stream));
+        if (wfa::launch_fast(al->dcfg, al->cu_count, stream, b->d_words, b->d_meta, in_list, in_count, in_n, b->d_score, b->d_status,
+                             out_list, out_count, pass == 0) != 0) { al->err = "fast kernel launch failed"; return WFA_HIP_EDEVICE; }
+        if (first_stage) b->last_kernel_pairs = in_n;
+        in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
+      }
     }
     for (int i = 0; i < n_stages; ++i) {
       wfa::BandArgs ba;
