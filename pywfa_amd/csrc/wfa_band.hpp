@@ -43,12 +43,18 @@ struct BandArgs {
   int x, oe, e;           // penalties (score units), for the backtrace
   int min_wf_len, max_dist_thr, steps_between;
   int lds_words;          // SEQLDS: words reserved per sequence in dynamic LDS
+  int split;              // FULL: 1 = history slot per PAIR of this launch + end states; the backtrace runs in its own
+                          //       thread-per-alignment kernel afterwards (latency of 64 walks overlapped per wave)
+  uint32_t work_begin;    // split: first work item of this launch (slot = item - work_begin)
+  int4* end_state;        // split: per slot {end score, end k, end offset, 1 = walk it}
+  int h16;                // FULL: 1 = history entries are 4 x int16 (sequences < 32000 bases) instead of 4 x int32
+  int debug;              // timing experiments only: 1 = skip the backtrace, 2 = skip the history stores
 };
 
 template <int NCH>
 struct Band {
   static constexpr int W = 64 * NCH;
-  static constexpr int REC = 3 * W + 16;  // history record: M[W] I[W] D[W] + {B, ...}
+  static constexpr int REC = 4 * W;  // history record of one score: {M, I, D, window base} per window position (16 B)
 
   // value of the diagonal below / above across chunk boundaries
   static __device__ __forceinline__ int below(const int (&r)[NCH], int c) {
@@ -93,70 +99,99 @@ struct Band {
   }
 };
 
-// candidate of the backtrace read from the band history: one load of the record's window base and one
-// of the offset, both at addresses known from (score, k) alone (a single memory round trip per step)
+// One 16-byte load fetches {M, I, D, window base} of (score index, diagonal): the address depends on
+// (si, k) alone, so all candidates of a backtrace step are in flight together (one memory round trip).
+// (16-bit form: every negative offset is stored as -1, every offset and diagonal fits in 15 bits.)
+__device__ __forceinline__ int sat16(int v) { return ((unsigned)v > 32767u) ? -1 : v; }  // inputs of a valid cell never exceed it
 template <int NCH>
-__device__ __forceinline__ long long band_cand(const int* hist, int g, int s, int comp, int k, int add, int type) {
+__device__ __forceinline__ int4 band_entry(const int* hist, int si, int k, int h16) {
   typedef Band<NCH> BD;
-  if (s < 0) return WFA_OFFSET_NULL;
-  const int* rec = hist + (long long)(s / g) * BD::REC;
-  const int base = rec[3 * BD::W];
-  const int o = rec[comp * BD::W + (k & (BD::W - 1))];
-  if (k < base || k >= base + BD::W) return WFA_OFFSET_NULL;
-  return (((long long)(o + add)) << 4) | type;
+  int4 e = make_int4(WFA_OFFSET_NULL, WFA_OFFSET_NULL, WFA_OFFSET_NULL, 0);
+  if (si >= 0) {
+    if (h16) {
+      const short4 q = reinterpret_cast<const short4*>(hist + (long long)si * (BD::REC / 2))[k & (BD::W - 1)];
+      e = make_int4(q.x < 0 ? WFA_OFFSET_NULL : q.x, q.y < 0 ? WFA_OFFSET_NULL : q.y, q.z < 0 ? WFA_OFFSET_NULL : q.z, q.w);
+    } else {
+      e = reinterpret_cast<const int4*>(hist + (long long)si * BD::REC)[k & (BD::W - 1)];
+    }
+    if (k < e.w || k >= e.w + BD::W) { e.x = WFA_OFFSET_NULL; e.y = WFA_OFFSET_NULL; e.z = WFA_OFFSET_NULL; }
+  }
+  return e;
+}
+__device__ __forceinline__ long long band_pack(int si, int o, int add, int type) {
+  // a candidate at a negative score does not exist (R/wavefront_backtrace.c:64-219 return NULL)
+  return (si < 0) ? (long long)WFA_OFFSET_NULL : ((((long long)(o + add)) << 4) | type);
 }
 
-// R/wavefront_backtrace.c:320-529 for gap-affine over the band history; single lane.
+// R/wavefront_backtrace.c:320-529 for gap-affine over the band history; single lane.  Scores are walked
+// as step indices si = s / g (x, o+e, e are multiples of g).
 template <int NCH>
 __device__ void band_backtrace(const int* hist, const BandArgs& a, int plen, int tlen, int end_s, int end_k,
-                               int end_off, uint8_t* buf, long long* begin_out) {
+                               int end_off, uint8_t* buf, long long* begin_out, int lane, int nlanes,
+                               uint32_t* runs_top = nullptr, int* nruns_out = nullptr) {
+  // nlanes = 64: executed by the whole wave with uniform control flow (every lane walks the same path, the
+  // loads are broadcasts, runs of one op are stored 64 bytes at a time); nlanes = 1: one thread per alignment
+  // runs_top != nullptr: instead of op bytes, emit (length << 8 | op) run records downwards from runs_top
+  // (the top of this pair's history slot: records above the walk's current score are dead) — the bytes
+  // are written afterwards, coalesced, by wfa_band_expand_kernel
+  int nruns = 0;
+  auto push = [&](long long& bg, char c, int n) {
+    if (runs_top) { if (n > 0) { *(runs_top - nruns) = ((uint32_t)n << 8) | (uint8_t)c; ++nruns; } }
+    else for (int i = lane; i < n; i += nlanes) buf[bg - 1 - i] = (uint8_t)c;
+    bg -= n;
+  };
   enum { BT_I1_OPEN = 1, BT_I1_EXT = 2, BT_D1_OPEN = 5, BT_D1_EXT = 6, BT_M = 9 };
+  const int dx = a.x / a.g, doe = a.oe / a.g, de = a.e / a.g;
   long long begin = (long long)plen + tlen;
-  int comp = 0, s = end_s, k = end_k, offset = end_off;
+  int comp = 0, si = end_s / a.g, k = end_k, offset = end_off;
   int h = offset, v = offset - k;
-  for (int i = plen - v; i > 0; --i) buf[--begin] = 'D';
-  for (int i = tlen - h; i > 0; --i) buf[--begin] = 'I';
-  while (v > 0 && h > 0 && s > 0) {
-    const int s_x = s - a.x, s_o = s - a.oe, s_e = s - a.e;
+  push(begin, 'D', max(plen - v, 0));
+  push(begin, 'I', max(tlen - h, 0));
+  while (v > 0 && h > 0 && si > 0) {
+    const int si_x = si - dx, si_o = si - doe, si_e = si - de;
     long long best;
     if (comp == 0) {
-      const long long c0 = band_cand<NCH>(hist, a.g, s_x, 0, k, 1, BT_M);
-      const long long c1 = band_cand<NCH>(hist, a.g, s_o, 0, k - 1, 1, BT_I1_OPEN);
-      const long long c2 = band_cand<NCH>(hist, a.g, s_e, 1, k - 1, 1, BT_I1_EXT);
-      const long long c3 = band_cand<NCH>(hist, a.g, s_o, 0, k + 1, 0, BT_D1_OPEN);
-      const long long c4 = band_cand<NCH>(hist, a.g, s_e, 2, k + 1, 0, BT_D1_EXT);
+      const int4 ex = band_entry<NCH>(hist, si_x, k, a.h16);
+      const int4 eol = band_entry<NCH>(hist, si_o, k - 1, a.h16), eoh = band_entry<NCH>(hist, si_o, k + 1, a.h16);
+      const int4 eel = band_entry<NCH>(hist, si_e, k - 1, a.h16), eeh = band_entry<NCH>(hist, si_e, k + 1, a.h16);
+      const long long c0 = band_pack(si_x, ex.x, 1, BT_M);
+      const long long c1 = band_pack(si_o, eol.x, 1, BT_I1_OPEN), c2 = band_pack(si_e, eel.y, 1, BT_I1_EXT);
+      const long long c3 = band_pack(si_o, eoh.x, 0, BT_D1_OPEN), c4 = band_pack(si_e, eeh.z, 0, BT_D1_EXT);
       best = max(max(c0, max(c1, c2)), max(c3, c4));
     } else if (comp == 1) {
-      best = max(band_cand<NCH>(hist, a.g, s_o, 0, k - 1, 1, BT_I1_OPEN), band_cand<NCH>(hist, a.g, s_e, 1, k - 1, 1, BT_I1_EXT));
+      const int4 eol = band_entry<NCH>(hist, si_o, k - 1, a.h16), eel = band_entry<NCH>(hist, si_e, k - 1, a.h16);
+      best = max(band_pack(si_o, eol.x, 1, BT_I1_OPEN), band_pack(si_e, eel.y, 1, BT_I1_EXT));
     } else {
-      best = max(band_cand<NCH>(hist, a.g, s_o, 0, k + 1, 0, BT_D1_OPEN), band_cand<NCH>(hist, a.g, s_e, 2, k + 1, 0, BT_D1_EXT));
+      const int4 eoh = band_entry<NCH>(hist, si_o, k + 1, a.h16), eeh = band_entry<NCH>(hist, si_e, k + 1, a.h16);
+      best = max(band_pack(si_o, eoh.x, 0, BT_D1_OPEN), band_pack(si_e, eeh.z, 0, BT_D1_EXT));
     }
     if (best < 0) break;
     if (comp == 0) {
       const int src = (int)(best >> 4);
-      for (int i = offset - src; i > 0; --i) buf[--begin] = 'M';
+      push(begin, 'M', offset - src);
       offset = src;
       v = offset - k; h = offset;
       if (v <= 0 || h <= 0) break;
     }
     const int type = (int)(best & 0xF);
-    if (type == BT_M) { s = s_x; comp = 0; buf[--begin] = 'X'; --offset; }
-    else if (type == BT_I1_OPEN) { s = s_o; comp = 0; buf[--begin] = 'I'; --k; --offset; }
-    else if (type == BT_I1_EXT) { s = s_e; comp = 1; buf[--begin] = 'I'; --k; --offset; }
-    else if (type == BT_D1_OPEN) { s = s_o; comp = 0; buf[--begin] = 'D'; ++k; }
-    else { s = s_e; comp = 2; buf[--begin] = 'D'; ++k; }
+    if (type == BT_M) { si = si_x; comp = 0; push(begin, 'X', 1); --offset; }
+    else if (type == BT_I1_OPEN) { si = si_o; comp = 0; push(begin, 'I', 1); --k; --offset; }
+    else if (type == BT_I1_EXT) { si = si_e; comp = 1; push(begin, 'I', 1); --k; --offset; }
+    else if (type == BT_D1_OPEN) { si = si_o; comp = 0; push(begin, 'D', 1); ++k; }
+    else { si = si_e; comp = 2; push(begin, 'D', 1); ++k; }
     v = offset - k; h = offset;
   }
   if (comp == 0) {
     if (v > 0 && h > 0) {
       const int n = min(v, h);
-      for (int i = n; i > 0; --i) buf[--begin] = 'M';
+      push(begin, 'M', n);
       v -= n; h -= n;
     }
-    for (; v > 0; --v) buf[--begin] = 'D';
-    for (; h > 0; --h) buf[--begin] = 'I';
+    for (; v > 0; --v) push(begin, 'D', 1);
+    for (; h > 0; --h) push(begin, 'I', 1);
   }
   *begin_out = begin;
+  if (nruns_out) *nruns_out = nruns;
 }
 
 template <int NCH, bool FULL, bool ADAPT, bool SEQLDS>
@@ -169,15 +204,19 @@ wfa_band_kernel(const BandArgs a) {
   uint32_t* const sP = slds;
   uint32_t* const sT = slds + a.lds_words;
   const int lane = threadIdx.x;
-  int* const hist = FULL ? a.hist + (long long)blockIdx.x * a.hist_stride : nullptr;
-  const int max_records = FULL ? (int)min((long long)INT_MAX, a.hist_stride / BD::REC) : INT_MAX;
+  int* hist = FULL ? a.hist + (long long)blockIdx.x * a.hist_stride : nullptr;
+  const int rec_ints = a.h16 ? BD::REC / 2 : BD::REC;
+  const int max_records = FULL ? (int)min((long long)INT_MAX, a.hist_stride / rec_ints) : INT_MAX;
 
+  const bool split = FULL && a.split;
   const uint32_t nwork = a.nwork_dev ? *a.nwork_dev : a.nwork;
-  for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+  const uint32_t w0 = split ? a.work_begin : 0u;
+  for (uint32_t wi = w0 + blockIdx.x; wi < w0 + nwork; wi += gridDim.x) {
     const uint32_t pair = a.worklist ? a.worklist[wi] : wi;
     const WfaPairMeta pm = a.meta[pair];
     const int plen = pm.plen, tlen = pm.tlen;
     const int ak = tlen - plen;
+    if (split) hist = a.hist + (long long)(wi - w0) * a.hist_stride;
     const uint32_t* gP = a.words + pm.p_woff;
     const uint32_t* gT = a.words + pm.t_woff;
     const int nwp = (plen + 15) >> 4, nwt = (tlen + 15) >> 4;
@@ -287,13 +326,18 @@ wfa_band_kernel(const BandArgs a) {
         const int si = s / a.g;
         if (FULL) {
           if (si + 1 >= max_records) { fallback = true; break; }
-          int* rec = hist + (long long)si * BD::REC;
+          int* rec = hist + (long long)si * rec_ints;
+          if (!(a.debug & 2)) {
+            if (a.h16) {
 #pragma unroll
-          for (int c = 0; c < NCH; ++c) {
-            const int pos = kk[c] & (W - 1);
-            rec[pos] = cur[c]; rec[W + pos] = Ih[c]; rec[2 * W + pos] = Dh[c];
+              for (int c = 0; c < NCH; ++c)
+                reinterpret_cast<short4*>(rec)[kk[c] & (W - 1)] =
+                    make_short4((short)sat16(cur[c]), (short)sat16(Ih[c]), (short)sat16(Dh[c]), (short)B);
+            } else {
+#pragma unroll
+              for (int c = 0; c < NCH; ++c) reinterpret_cast<int4*>(rec)[kk[c] & (W - 1)] = make_int4(cur[c], Ih[c], Dh[c], B);
+            }
           }
-          if (lane == 0) rec[3 * W] = B;
         }
         // ---------------- keep the ring inside the window (every 8 steps; growth is <= 1 diagonal/step) ----
         if ((step & 7) == 0) {
@@ -374,13 +418,15 @@ wfa_band_kernel(const BandArgs a) {
       }
       if (!done) fallback = true;
     }
-    if (FULL && !fallback) {
-      // make this wave's history stores visible to lane 0's loads
+    if (split) {
+      if (lane == 0) a.end_state[wi - w0] = make_int4(end_s, end_k, end_off, fallback ? 0 : 1);
+    } else if (FULL && !fallback) {
+      // make this wave's history stores visible to its own loads
       __syncthreads();
+      long long begin = 0;
+      uint8_t* buf = a.cigar_ops + a.cigar_off[pair];
+      if (!(a.debug & 1)) band_backtrace<NCH>(hist, a, plen, tlen, end_s, end_k, end_off, buf, &begin, lane, 64);
       if (lane == 0) {
-        long long begin = 0;
-        uint8_t* buf = a.cigar_ops + a.cigar_off[pair];
-        band_backtrace<NCH>(hist, a, plen, tlen, end_s, end_k, end_off, buf, &begin);
         a.cigar_begin[pair] = a.cigar_off[pair] + begin;
         a.cigar_len[pair] = (int)((long long)plen + tlen - begin);
       }
@@ -395,6 +441,82 @@ wfa_band_kernel(const BandArgs a) {
       }
     }
   }
+}
+
+// Backtrace of a split launch: one THREAD per alignment, so that a wave keeps 64 dependent walks in flight.
+// The walk emits run records into the top of the pair's own history slot; wfa_band_expand_kernel then
+// writes the op bytes.
+template <int NCH>
+__global__ void __launch_bounds__(64)
+wfa_band_bt_kernel(const BandArgs a) {
+  const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+  if (t >= a.nwork) return;
+  const int4 es = a.end_state[t];
+  if (!es.w) return;
+  const uint32_t wi = a.work_begin + t;
+  const uint32_t pair = a.worklist ? a.worklist[wi] : wi;
+  const WfaPairMeta pm = a.meta[pair];
+  int* hist = a.hist + (long long)t * a.hist_stride;
+  long long begin = 0;
+  int nruns = 0;
+  band_backtrace<NCH>(hist, a, pm.plen, pm.tlen, es.x, es.y, es.z, nullptr, &begin, 0, 1,
+                      reinterpret_cast<uint32_t*>(hist) + a.hist_stride - 1, &nruns);
+  a.end_state[t] = make_int4((int)begin, nruns, 0, 2);
+}
+
+// One wave per alignment: run r (r = 0 is the LAST run of the op string) covers
+// [end - sum(len[0..r]), end - sum(len[0..r-1])); lanes take 64 runs at a time, positions come from a wave
+// prefix sum, short runs are written by their lane, long ones by the whole wave.
+__global__ void __launch_bounds__(256)
+wfa_band_expand_kernel(const BandArgs a) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t t = (blockIdx.x * 256u + threadIdx.x) >> 6;
+  if (t >= a.nwork) return;
+  const int4 es = a.end_state[t];
+  if (es.w != 2) return;
+  const uint32_t wi = a.work_begin + t;
+  const uint32_t pair = a.worklist ? a.worklist[wi] : wi;
+  const WfaPairMeta pm = a.meta[pair];
+  const uint32_t* top = reinterpret_cast<const uint32_t*>(a.hist + (long long)t * a.hist_stride) + a.hist_stride - 1;
+  uint8_t* buf = a.cigar_ops + a.cigar_off[pair];
+  const int nruns = es.y;
+  int end = pm.plen + pm.tlen;
+  for (int r0 = 0; r0 < nruns; r0 += 64) {
+    const int r = r0 + lane;
+    const uint32_t rec = (r < nruns) ? *(top - r) : 0u;
+    const int len = (int)(rec >> 8);
+    const uint8_t op = (uint8_t)(rec & 0xFFu);
+    int cum = len;  // inclusive prefix sum over the lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(cum, d, 64); if (lane >= d) cum += o; }
+    const int pos = end - cum;  // first byte of this lane's run
+    const bool is_long = len > 16;
+    for (int i = 0; i < 16; ++i) if (!is_long && i < len) buf[pos + i] = op;
+    unsigned long long lm = __ballot(is_long);
+    while (lm) {
+      const int l = __builtin_ctzll(lm);
+      lm &= lm - 1;
+      const int lpos = __builtin_amdgcn_readlane(pos, l), llen = __builtin_amdgcn_readlane(len, l);
+      const uint8_t lop = (uint8_t)__builtin_amdgcn_readlane((int)op, l);
+      for (int i = lane; i < llen; i += 64) buf[lpos + i] = lop;
+    }
+    end -= __builtin_amdgcn_readlane(cum, 63);
+  }
+  if (lane == 0) {
+    a.cigar_begin[pair] = a.cigar_off[pair] + es.x;
+    a.cigar_len[pair] = pm.plen + pm.tlen - es.x;
+  }
+}
+
+inline int launch_band_bt(const BandArgs& a, int nch, hipStream_t stream) {
+  const unsigned grid = (a.nwork + 63u) / 64u;
+  if (grid == 0) return 0;
+  if (nch == 1) hipLaunchKernelGGL((wfa_band_bt_kernel<1>), dim3(grid), dim3(64), 0, stream, a);
+  else if (nch == 2) hipLaunchKernelGGL((wfa_band_bt_kernel<2>), dim3(grid), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL((wfa_band_bt_kernel<4>), dim3(grid), dim3(64), 0, stream, a);
+  if (hipGetLastError() != hipSuccess) return -1;
+  hipLaunchKernelGGL(wfa_band_expand_kernel, dim3((a.nwork + 3u) / 4u), dim3(256), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 // configurations the band kernel covers

@@ -548,13 +548,21 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       grid = std::min<long long>(grid, in_n);
       if (i > 0 || use_fast) grid = std::min<long long>(grid, (long long)al->cu_count * 16);
       if (full) {
-        const int rec = 3 * 64 * band_nch[i] + 16;
+        const bool h16 = b->max_len < 32000;
+        const int rec = (h16 ? 2 : 4) * 64 * band_nch[i];
         long long records = std::max<long long>(256, (long long)(b->max_len * 0.45) + 64);
         records = env_int("WFA_HIP_BAND_RECORDS", (int)records);
         band_stride[i] = ((int64_t)records * rec + 63) & ~63ll;
         const int64_t budget = free_budget(al);
         while (grid > 1 && grid * band_stride[i] * 4 > budget) grid = (grid + 1) / 2;
         need = std::max(need, (size_t)grid * band_stride[i] * 4);
+        if (i == 0 && !use_fast && b->max_len > 1000 && env_int("WFA_HIP_BAND_NO_SPLIT", 0) == 0) {
+          // split backtrace: one history slot per pair of a launch; take up to 4x the wave count (or all pairs)
+          const int64_t slot_bytes = band_stride[i] * 4 + 16;
+          int64_t pairs = std::min<int64_t>(in_n, (int64_t)al->cu_count * 32 * env_int("WFA_HIP_BAND_SPLIT_ROUNDS", 4));
+          while (pairs > 1 && pairs * slot_bytes > budget) pairs = (pairs + 1) / 2;
+          need = std::max(need, (size_t)(pairs * slot_bytes));
+        }
       }
       band_grid[i] = grid;
     }
@@ -590,8 +598,31 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       const int words = ((b->max_len + 15) >> 4) + 2;
       const bool seqlds = ((size_t)words * 8 <= 5120) && env_int("WFA_HIP_BAND_NO_LDS", 0) == 0;
       ba.lds_words = seqlds ? words : 0;
+      ba.debug = env_int("WFA_HIP_BAND_DEBUG", 0);
+      ba.h16 = (b->max_len < 32000) ? 1 : 0;
       ba.hist = al->ws; ba.hist_stride = band_stride[i];
-      if (wfa::launch_band(ba, band_nch[i], full, adapt, seqlds, band_grid[i], stream) != 0) { al->err = "band kernel launch failed"; return WFA_HIP_EDEVICE; }
+      const bool split = full && in_count == nullptr && b->max_len > 1000 && env_int("WFA_HIP_BAND_NO_SPLIT", 0) == 0;
+      if (split) {
+        // history slot per PAIR: as many pairs per launch as the workspace holds; the walks of a launch run
+        // afterwards in a thread-per-alignment kernel
+        const int64_t slot_bytes = band_stride[i] * 4 + (int64_t)sizeof(int4);
+        int64_t per_launch = (int64_t)(al->ws_bytes / (size_t)slot_bytes);
+        per_launch = std::min<int64_t>(per_launch, in_n);
+        const int64_t full_grid = (int64_t)al->cu_count * env_int("WFA_HIP_BAND_WAVES_PER_CU", 32);
+        if (per_launch > full_grid) per_launch = (per_launch / full_grid) * full_grid;  // whole rounds of waves
+        if (per_launch < 1) { al->err = "band history does not fit"; return WFA_HIP_EDEVICE; }
+        ba.split = 1;
+        ba.end_state = reinterpret_cast<int4*>(reinterpret_cast<char*>(al->ws) + (size_t)per_launch * band_stride[i] * 4);
+        for (int64_t w0 = 0; w0 < in_n; w0 += per_launch) {
+          const uint32_t cnt = (uint32_t)std::min<int64_t>(per_launch, in_n - w0);
+          ba.work_begin = (uint32_t)w0; ba.nwork = cnt;
+          const long long grid = std::min<long long>((long long)al->cu_count * env_int("WFA_HIP_BAND_WAVES_PER_CU", 32), cnt);
+          if (wfa::launch_band(ba, band_nch[i], full, adapt, seqlds, grid, stream) != 0) { al->err = "band kernel launch failed"; return WFA_HIP_EDEVICE; }
+          if (wfa::launch_band_bt(ba, band_nch[i], stream) != 0) { al->err = "band backtrace launch failed"; return WFA_HIP_EDEVICE; }
+        }
+      } else {
+        if (wfa::launch_band(ba, band_nch[i], full, adapt, seqlds, band_grid[i], stream) != 0) { al->err = "band kernel launch failed"; return WFA_HIP_EDEVICE; }
+      }
       if (first_stage) b->last_kernel_pairs = in_n;
       in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
     }
