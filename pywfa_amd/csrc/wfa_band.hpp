@@ -51,6 +51,16 @@ struct BandArgs {
   int debug;              // timing experiments only: 1 = skip the backtrace, 2 = skip the history stores
 };
 
+// wave-wide minimum without LDS traffic: butterfly inside each row of 16 lanes with DPP, then 4 row leaders
+__device__ __forceinline__ int wave_min_dpp(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141 /* row_half_mirror */, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140 /* row_mirror */, 0xf, 0xf, false));
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
 template <int NCH>
 struct Band {
   static constexpr int W = 64 * NCH;
@@ -222,11 +232,11 @@ wfa_band_kernel(const BandArgs a) {
     const int nwp = (plen + 15) >> 4, nwt = (tlen + 15) >> 4;
     bool fallback = false;
     if (SEQLDS) {
-      if (nwp + 1 > a.lds_words || nwt + 1 > a.lds_words) fallback = true;
+      if (nwp + 3 > a.lds_words || nwt + 3 > a.lds_words) fallback = true;
       else {
         __syncthreads();
-        for (int i = lane; i <= nwp; i += 64) sP[i] = (i < nwp) ? gP[i] : 0u;
-        for (int i = lane; i <= nwt; i += 64) sT[i] = (i < nwt) ? gT[i] : 0u;
+        for (int i = lane; i < nwp + 3; i += 64) sP[i] = (i < nwp) ? gP[i] : 0u;
+        for (int i = lane; i < nwt + 3; i += 64) sT[i] = (i < nwt) ? gT[i] : 0u;
         __syncthreads();
       }
     }
@@ -234,10 +244,13 @@ wfa_band_kernel(const BandArgs a) {
     int result = 0;
     int end_k = 0, end_off = 0, end_s = 0;
     if (!fallback) {
-      int kk[NCH], cur[NCH], Mh[DM][NCH], Ih[NCH], Dh[NCH];
+      // per lane: lim = min(tlen, plen + k) (in-bounds <=> offset <= lim; lim - offset = longest possible run),
+      // dlim = max(tlen, plen + k) (dlim - offset = distance to the end, R/wavefront_heuristic.c:176-192)
+      int kk[NCH], lim[NCH], dlim[NCH], cur[NCH], Mh[DM][NCH], Ih[NCH], Dh[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         kk[c] = B + c * 64 + lane;
+        lim[c] = min(tlen, plen + kk[c]); dlim[c] = max(tlen, plen + kk[c]);
         cur[c] = (kk[c] == 0) ? 0 : WFA_OFFSET_NULL;  // wavefront 0
         Ih[c] = WFA_OFFSET_NULL; Dh[c] = WFA_OFFSET_NULL;
 #pragma unroll
@@ -253,29 +266,37 @@ wfa_band_kernel(const BandArgs a) {
         for (int c = 0; c < NCH; ++c) { live[c] = __ballot(cur[c] >= 0); any_live |= (live[c] != 0); }
         if (any_live) {
           dead_steps = 0;
+          {
+            // all chunks advance together: 32 bases per iteration (three packed words per sequence)
+            int h[NCH], v[NCH], left[NCH];
+            bool any_more = false;
 #pragma unroll
-          for (int c = 0; c < NCH; ++c) {
-            if (live[c] == 0) continue;
-            bool active = cur[c] >= 0;
-            int h = active ? cur[c] : 0, v = active ? cur[c] - kk[c] : 0;
-            int left = active ? min(plen - v, tlen - h) : 0;
-            active = active && left > 0;
-            while (__any(active)) {
-              uint32_t p0, p1, t0, t1;
-              if (SEQLDS) { p0 = sP[v >> 4]; p1 = sP[(v >> 4) + 1]; t0 = sT[h >> 4]; t1 = sT[(h >> 4) + 1]; }
-              else {
-                const int vi = active ? v : 0, hi_ = active ? h : 0;
-                p0 = gP[vi >> 4]; p1 = gP[(vi >> 4) + 1]; t0 = gT[hi_ >> 4]; t1 = gT[(hi_ >> 4) + 1];
-              }
-              const uint32_t pw = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)(v & 15) << 1);
-              const uint32_t tw = __builtin_amdgcn_alignbit(t1, t0, (uint32_t)(h & 15) << 1);
-              const uint32_t x = pw ^ tw;
-              int m = x ? (__builtin_ctz(x) >> 1) : 16;
-              m = active ? min(m, left) : 0;
-              v += m; h += m; left -= m;
-              active = active && (m == 16) && (left > 0);
+            for (int c = 0; c < NCH; ++c) {
+              h[c] = max(cur[c], 0); v[c] = max(cur[c] - kk[c], 0);
+              left[c] = (cur[c] >= 0) ? lim[c] - cur[c] : 0;
+              any_more |= left[c] > 0;
             }
-            if (cur[c] >= 0) cur[c] = h;
+            if (__any(any_more)) {
+              bool more;
+              do {
+                more = false;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                  const int pi = v[c] >> 4, ti = h[c] >> 4;
+                  uint32_t p0, p1, p2, t0, t1, t2;
+                  if (SEQLDS) { p0 = sP[pi]; p1 = sP[pi + 1]; p2 = sP[pi + 2]; t0 = sT[ti]; t1 = sT[ti + 1]; t2 = sT[ti + 2]; }
+                  else { p0 = gP[pi]; p1 = gP[pi + 1]; p2 = gP[pi + 2]; t0 = gT[ti]; t1 = gT[ti + 1]; t2 = gT[ti + 2]; }
+                  const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v[c] << 1) ^ __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h[c] << 1);
+                  const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, (uint32_t)v[c] << 1) ^ __builtin_amdgcn_alignbit(t2, t1, (uint32_t)h[c] << 1);
+                  int m = xl ? (__builtin_ctz(xl) >> 1) : (xh ? 16 + (__builtin_ctz(xh) >> 1) : 32);
+                  m = min(m, left[c]);
+                  v[c] += m; h[c] += m; left[c] -= m;
+                  more |= (m == 32) && (left[c] > 0);
+                }
+              } while (__any(more));
+#pragma unroll
+              for (int c = 0; c < NCH; ++c) if (cur[c] >= 0) cur[c] = h[c];
+            }
           }
           // ---------------- termination (end-to-end) ----------------
           const int p = ak - B;
@@ -292,10 +313,10 @@ wfa_band_kernel(const BandArgs a) {
                 int d[NCH], dmin = max(plen, tlen);
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                  d[c] = (cur[c] >= 0) ? max(plen - (cur[c] - kk[c]), tlen - cur[c]) : -WFA_OFFSET_NULL;
+                  d[c] = (cur[c] >= 0) ? dlim[c] - cur[c] : -WFA_OFFSET_NULL;  // max(plen - v, tlen - h)
                   dmin = min(dmin, d[c]);
                 }
-                dmin = wave_min(dmin);
+                dmin = wave_min_dpp(dmin);
                 unsigned long long ok[NCH];
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) ok[c] = __ballot(d[c] - dmin <= a.max_dist_thr);
@@ -358,7 +379,7 @@ wfa_band_kernel(const BandArgs a) {
               int delta = fp - (W - width) / 2;
               B += delta;
 #pragma unroll
-              for (int c = 0; c < NCH; ++c) kk[c] += delta;
+              for (int c = 0; c < NCH; ++c) { kk[c] += delta; lim[c] = min(tlen, plen + kk[c]); dlim[c] = max(tlen, plen + kk[c]); }
               BD::shift(cur, delta, lane); BD::shift(Ih, delta, lane); BD::shift(Dh, delta, lane);
 #pragma unroll
               for (int j = 0; j < DM - 1; ++j) BD::shift(Mh[j], delta, lane);
@@ -386,19 +407,17 @@ wfa_band_kernel(const BandArgs a) {
             ni[c] = max(mo_lo, ie_lo) + 1;
             nd[c] = max(mo_hi, de_hi);
             int m = max(nd[c], max(Mh[1][c] + 1, ni[c]));
-            if ((uint32_t)m > (uint32_t)tlen || (uint32_t)(m - kk[c]) > (uint32_t)plen) m = WFA_OFFSET_NULL;
+            if (m > lim[c]) m = WFA_OFFSET_NULL;  // only M is clamped; negative values are dead already
             nm[c] = m;
-            const bool oob_i = ni[c] >= 0 && ((uint32_t)ni[c] > (uint32_t)tlen || (uint32_t)(ni[c] - kk[c]) > (uint32_t)plen);
-            const bool oob_d = nd[c] >= 0 && ((uint32_t)nd[c] > (uint32_t)tlen || (uint32_t)(nd[c] - kk[c]) > (uint32_t)plen);
-            oob |= __ballot(oob_i || oob_d);
+            oob |= __ballot(max(ni[c], nd[c]) > lim[c]);
           }
           if (oob) {
             // trim the ends of I and D (R/wavefront_compute.c:571-605): outside [first,last] in-bounds -> NULL
             unsigned long long bi[NCH], bd[NCH];
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-              bi[c] = __ballot((uint32_t)ni[c] <= (uint32_t)tlen && (uint32_t)(ni[c] - kk[c]) <= (uint32_t)plen);
-              bd[c] = __ballot((uint32_t)nd[c] <= (uint32_t)tlen && (uint32_t)(nd[c] - kk[c]) <= (uint32_t)plen);
+              bi[c] = __ballot(ni[c] >= 0 && ni[c] <= lim[c]);
+              bd[c] = __ballot(nd[c] >= 0 && nd[c] <= lim[c]);
             }
             const int ilo = BD::first_pos(bi), ihi = BD::last_pos(bi), dlo = BD::first_pos(bd), dhi = BD::last_pos(bd);
 #pragma unroll

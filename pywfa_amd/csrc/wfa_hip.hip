@@ -595,7 +595,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       ba.g = wfa::gcd_int(wfa::gcd_int(al->dcfg.x, al->dcfg.o1 + al->dcfg.e1), al->dcfg.e1);
       ba.x = al->dcfg.x; ba.oe = al->dcfg.o1 + al->dcfg.e1; ba.e = al->dcfg.e1;
       ba.min_wf_len = al->dcfg.min_wf_len; ba.max_dist_thr = al->dcfg.max_dist_thr; ba.steps_between = al->dcfg.steps_between;
-      const int words = ((b->max_len + 15) >> 4) + 2;
+      const int words = ((b->max_len + 15) >> 4) + 4;
       const bool seqlds = ((size_t)words * 8 <= 5120) && env_int("WFA_HIP_BAND_NO_LDS", 0) == 0;
       ba.lds_words = seqlds ? words : 0;
       ba.debug = env_int("WFA_HIP_BAND_DEBUG", 0);
