@@ -47,6 +47,7 @@ struct BandArgs {
                           //       thread-per-alignment kernel afterwards (latency of 64 walks overlapped per wave)
   uint32_t work_begin;    // split: first work item of this launch (slot = item - work_begin)
   int4* end_state;        // split: per slot {end score, end k, end offset, 1 = walk it}
+  int ef, pbf, pef, tbf, tef;  // ends-free span with these free ends (R/wavefront_termination.c:115-162)
   int h16;                // FULL: 1 = history entries are 4 x int16 (sequences < 32000 bases) instead of 4 x int32
   int debug;              // timing experiments only: 1 = skip the backtrace, 2 = skip the history stores
 };
@@ -241,6 +242,11 @@ wfa_band_kernel(const BandArgs a) {
       }
     }
     int B = -(W / 2);  // diagonal of window position 0; the window then follows the live diagonals
+    if (a.ef) {
+      // wavefront 0 spans the diagonals [-pattern_begin_free, text_begin_free] (R/wavefront_aligner.c:259-302)
+      if (a.pbf + a.tbf + 1 > W - 20) fallback = true;
+      B = (a.tbf - a.pbf) / 2 - W / 2;
+    }
     int result = 0;
     int end_k = 0, end_off = 0, end_s = 0;
     if (!fallback) {
@@ -252,6 +258,7 @@ wfa_band_kernel(const BandArgs a) {
         kk[c] = B + c * 64 + lane;
         lim[c] = min(tlen, plen + kk[c]); dlim[c] = max(tlen, plen + kk[c]);
         cur[c] = (kk[c] == 0) ? 0 : WFA_OFFSET_NULL;  // wavefront 0
+        if (a.ef && kk[c] >= -a.pbf && kk[c] <= a.tbf) cur[c] = max(kk[c], 0);
         Ih[c] = WFA_OFFSET_NULL; Dh[c] = WFA_OFFSET_NULL;
 #pragma unroll
         for (int j = 0; j < DM; ++j) Mh[j][c] = WFA_OFFSET_NULL;
@@ -298,12 +305,29 @@ wfa_band_kernel(const BandArgs a) {
               for (int c = 0; c < NCH; ++c) if (cur[c] >= 0) cur[c] = h[c];
             }
           }
-          // ---------------- termination (end-to-end) ----------------
-          const int p = ak - B;
-          int at_end = WFA_OFFSET_NULL;
+          // ---------------- termination ----------------
+          if (a.ef) {
+            // ends-free: the lowest diagonal that touches a border within the free budget wins
+            unsigned long long hit[NCH];
 #pragma unroll
-          for (int c = 0; c < NCH; ++c) if ((p >> 6) == c) at_end = __builtin_amdgcn_readlane(cur[c], p & 63);
-          if (p >= 0 && p < W && at_end >= tlen) { done = true; result = -s; end_k = ak; end_off = tlen; end_s = s; break; }
+            for (int c = 0; c < NCH; ++c) {
+              const int h = cur[c], v = cur[c] - kk[c];
+              hit[c] = __ballot(cur[c] >= 0 && ((h >= tlen && plen - v <= a.pef) || (v >= plen && tlen - h <= a.tef)));
+            }
+            const int hp = BD::first_pos(hit);
+            if (hp < W) {
+              int eo = 0;
+#pragma unroll
+              for (int c = 0; c < NCH; ++c) if ((hp >> 6) == c) eo = __builtin_amdgcn_readlane(cur[c], hp & 63);
+              done = true; result = -s; end_k = B + hp; end_off = eo; end_s = s; break;
+            }
+          } else {
+            const int p = ak - B;
+            int at_end = WFA_OFFSET_NULL;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) if ((p >> 6) == c) at_end = __builtin_amdgcn_readlane(cur[c], p & 63);
+            if (p >= 0 && p < W && at_end >= tlen) { done = true; result = -s; end_k = ak; end_off = tlen; end_s = s; break; }
+          }
           // ---------------- wf-adaptive cut-off (R/wavefront_heuristic.c:257-293,509-567) ----------------
           if (ADAPT) {
             --steps_wait;
@@ -542,7 +566,6 @@ inline int launch_band_bt(const BandArgs& a, int nch, hipStream_t stream) {
 inline bool band_supported(const WfaDevConfig& c, int ncomp) {
   if (ncomp != 3 || c.match != 0 || c.wildcard >= 0 || c.max_steps != INT_MAX) return false;
   if (c.heuristic != 0 && c.heuristic != 1) return false;
-  if (c.endsfree && (c.pbf | c.pef | c.tbf | c.tef)) return false;
   const int g = gcd_int(gcd_int(c.x, c.o1 + c.e1), c.e1);
   return (c.x / g == 2 && (c.o1 + c.e1) / g == 4 && c.e1 / g == 1);
 }

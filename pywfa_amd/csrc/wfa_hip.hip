@@ -600,6 +600,8 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       ba.lds_words = seqlds ? words : 0;
       ba.debug = env_int("WFA_HIP_BAND_DEBUG", 0);
       ba.h16 = (b->max_len < 32000) ? 1 : 0;
+      ba.ef = (al->dcfg.endsfree && (al->dcfg.pbf | al->dcfg.pef | al->dcfg.tbf | al->dcfg.tef)) ? 1 : 0;
+      ba.pbf = al->dcfg.pbf; ba.pef = al->dcfg.pef; ba.tbf = al->dcfg.tbf; ba.tef = al->dcfg.tef;
       ba.hist = al->ws; ba.hist_stride = band_stride[i];
       const bool split = full && in_count == nullptr && b->max_len > 1000 && env_int("WFA_HIP_BAND_NO_SPLIT", 0) == 0;
       if (split) {

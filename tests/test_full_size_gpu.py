@@ -75,9 +75,10 @@ def test_c2_symmetry_and_identity(gpu, c2_batch):
 
 
 def test_c3_10kb_adaptive_full_properties(gpu):
-    """C3 = 10 kb ONT-like pairs, ~8 % error, gap-affine + adaptive, full CIGAR (a 2 k-pair prefix of the
-    seed-1003 stream): valid transcripts, penalty == -score, sample equal to the oracle."""
-    n = int(os.environ.get("WFA_C3_PAIRS", "2000"))
+    """C3 = 1 M x 10 kb ONT-like pairs, ~8 % error, gap-affine + adaptive, full CIGAR (seed 1003; needs ~60 GB
+    of host RAM, set WFA_C3_PAIRS to shrink): every transcript valid with penalty == -score, sample equal to
+    the oracle."""
+    n = int(os.environ.get("WFA_C3_PAIRS", "1000000"))
     batch = datagen.generate(n, 10000, 0.08, datagen.SEEDS["C3"])
     oc, nc = common.configs_pair(span="end-to-end", scope="full", heuristic="adaptive")
     al = _native.Aligner(nc)

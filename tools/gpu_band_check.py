@@ -47,5 +47,12 @@ for scope in ("score", "full"):
             bad += run(datagen.generate(max(n, 4), L, e, 500 + L), kw, f"{scope} {heur} L{L} e{e}")
     bad += run(vo.corpus_special(), dict(span="end-to-end", scope=scope), f"{scope} special")
     bad += run(vo.corpus_special(), dict(scope=scope, heuristic="adaptive"), f"{scope} special adaptive")
+for scope in ("score", "full"):
+    for heur in (None, "adaptive"):
+        for free in ((8, 7, 3, 2), (20, 0, 0, 9), (0, 30, 25, 0)):
+            kw = dict(span="ends-free", scope=scope, heuristic=heur, pattern_begin_free=free[0], pattern_end_free=free[1], text_begin_free=free[2], text_end_free=free[3])
+            for L, e, n in ((150, 0.05, N // 2), (1000, 0.08, N // 20), (10000, 0.08, N // 200)):
+                if heur is None and L >= 3000: continue
+                bad += run(datagen.generate(max(n, 4), L, e, 900 + L), kw, f"EF{free} {scope} {heur} L{L}")
 print("TOTAL BAD", bad)
 sys.exit(1 if bad else 0)
