@@ -134,4 +134,24 @@ int ref_align_batch(const wfa_hip_config_t* cfg, int64_t n, const uint8_t* seqs,
   return 0;
 }
 
+/* The same loop on `nthreads` host threads (contiguous slices of the batch, one aligner object per thread):
+ * the all-core CPU figure bench.py prints beside the single-thread baseline. */
+int ref_align_batch_mt(const wfa_hip_config_t* cfg, int nthreads, int64_t n, const uint8_t* seqs,
+                       const int64_t* p_off, const int32_t* p_len,
+                       const int64_t* t_off, const int32_t* t_len,
+                       int32_t* score, int32_t* status) {
+  int rc = 0;
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(static, 1)
+  for (int t = 0; t < nthreads; ++t) {
+    const int64_t lo = n * t / nthreads, hi = n * (t + 1) / nthreads;
+    if (hi > lo) {
+      const int r = ref_align_batch(cfg, hi - lo, seqs, p_off + lo, p_len + lo, t_off + lo, t_len + lo,
+                                    score + lo, status + lo, NULL, NULL, NULL, NULL);
+      if (r) rc = r;
+    }
+  }
+  return rc;
+}
+
 const char* ref_version(void) { return "WFA2-lib v2.3 (pywfa 0.5.1 vendored copy)"; }
