@@ -181,20 +181,20 @@ def check_cigars(cfg, batch, score, ops, cbeg, clen, check_score=True):
     return int(bad), int(first.value)
 
 
-def reference_mt(cfg, batch, nthreads):
+def reference_mt(cfg, batch, nthreads, repeat=1):
     """Scores / statuses of the real reference on `nthreads` host threads (one aligner per thread)."""
     reference()
     lib = ctypes.CDLL(reference_path())
     fn = lib.ref_align_batch_mt
     fn.restype = ctypes.c_int
-    fn.argtypes = [ctypes.POINTER(Config), ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 7
+    fn.argtypes = [ctypes.POINTER(Config), ctypes.c_int, ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 7
     n = len(batch["p_len"])
     seqs = np.ascontiguousarray(batch["seqs"], dtype=np.uint8)
     arrs = [np.ascontiguousarray(batch["p_off"], np.int64), np.ascontiguousarray(batch["p_len"], np.int32),
             np.ascontiguousarray(batch["t_off"], np.int64), np.ascontiguousarray(batch["t_len"], np.int32)]
     score = np.zeros(n, np.int32)
     status = np.zeros(n, np.int32)
-    rc = fn(ctypes.byref(cfg), int(nthreads), n, _ptr(seqs), *[_ptr(a) for a in arrs], _ptr(score), _ptr(status))
+    rc = fn(ctypes.byref(cfg), int(nthreads), int(repeat), n, _ptr(seqs), *[_ptr(a) for a in arrs], _ptr(score), _ptr(status))
     if rc != 0:
         raise RuntimeError(f"reference returned {rc}")
     return {"score": score, "status": status, "cigars": None}

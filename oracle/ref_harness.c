@@ -134,9 +134,9 @@ int ref_align_batch(const wfa_hip_config_t* cfg, int64_t n, const uint8_t* seqs,
   return 0;
 }
 
-/* The same loop on `nthreads` host threads (contiguous slices of the batch, one aligner object per thread):
+/* The same loop (no wildcard) on `nthreads` host threads (contiguous slices of the batch, one aligner object per thread):
  * the all-core CPU figure bench.py prints beside the single-thread baseline. */
-int ref_align_batch_mt(const wfa_hip_config_t* cfg, int nthreads, int64_t n, const uint8_t* seqs,
+int ref_align_batch_mt(const wfa_hip_config_t* cfg, int nthreads, int repeat, int64_t n, const uint8_t* seqs,
                        const int64_t* p_off, const int32_t* p_len,
                        const int64_t* t_off, const int32_t* t_len,
                        int32_t* score, int32_t* status) {
@@ -146,9 +146,17 @@ int ref_align_batch_mt(const wfa_hip_config_t* cfg, int nthreads, int64_t n, con
   for (int t = 0; t < nthreads; ++t) {
     const int64_t lo = n * t / nthreads, hi = n * (t + 1) / nthreads;
     if (hi > lo) {
-      const int r = ref_align_batch(cfg, hi - lo, seqs, p_off + lo, p_len + lo, t_off + lo, t_len + lo,
-                                    score + lo, status + lo, NULL, NULL, NULL, NULL);
-      if (r) rc = r;
+      /* one aligner per thread, its slice walked `repeat` times (amortises the aligner set-up in timing runs) */
+      wavefront_aligner_t* const aligner = ref_new_aligner(cfg);
+      if (aligner == NULL) { rc = -1; continue; }
+      for (int rep = 0; rep < (repeat < 1 ? 1 : repeat); ++rep) {
+        for (int64_t i = lo; i < hi; ++i) {
+          wavefront_align(aligner, (const char*)(seqs + p_off[i]), p_len[i], (const char*)(seqs + t_off[i]), t_len[i]);
+          score[i] = aligner->cigar->score;
+          status[i] = aligner->align_status.status;
+        }
+      }
+      wavefront_aligner_delete(aligner);
     }
   }
   return rc;
