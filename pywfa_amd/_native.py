@@ -132,8 +132,11 @@ def _check_batch(batch):
     if not (p_off.shape[0] == t_off.shape[0] == t_len.shape[0] == n):
         raise ValueError("batch arrays differ in length")
     if n:
-        if int((p_off + p_len).max()) > seqs.size or int((t_off + t_len).max()) > seqs.size:
-            raise ValueError("sequence offsets run past the blob")
+        # the last pair ends the blob in the usual layouts: check it first, the full scan only otherwise
+        end = max(int(p_off[-1]) + int(p_len[-1]), int(t_off[-1]) + int(t_len[-1]))
+        if end > seqs.size or int(p_off.max()) + int(p_len.max()) > seqs.size or int(t_off.max()) + int(t_len.max()) > seqs.size:
+            if int((p_off + p_len).max()) > seqs.size or int((t_off + t_len).max()) > seqs.size:
+                raise ValueError("sequence offsets run past the blob")
     return seqs, p_off, p_len, t_off, t_len, n
 
 

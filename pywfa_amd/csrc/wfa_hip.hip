@@ -12,6 +12,9 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <chrono>
+#include <thread>
+#include <memory>
 
 #include "wfa_hip.h"
 #include "wfa_common.hpp"
@@ -279,36 +282,74 @@ static void batch_free(wfa_hip_batch* b) {
 
 extern "C" void wfa_hip_batch_destroy(wfa_hip_batch_t* b) { batch_free(b); }
 
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const uint8_t* seqs,
                        const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len) {
   const wfa_hip_config_t& c = al->cfg;
+  const bool timing = getenv("WFA_HIP_TIMING") != nullptr;
+  double t0 = now_ms();
   b->al = al;
   b->n = n;
-  b->h_plen.assign(p_len, p_len + n);
-  b->h_tlen.assign(t_len, t_len + n);
-  std::vector<WfaPairMeta> meta((size_t)n);
+  if (c.scope == WFA_SCOPE_FULL) {  // needed later to lay out the op-string regions
+    b->h_plen.assign(p_len, p_len + n);
+    b->h_tlen.assign(t_len, t_len + n);
+  }
+  std::unique_ptr<WfaPairMeta[]> meta(new WfaPairMeta[(size_t)std::max<int64_t>(n, 1)]);  // not zero-filled: first touched in parallel below
+  // per-pair metadata on several host threads: pass 1 validates and sums each slice, pass 2 writes the
+  // word offsets from the slice prefix
+  const int nthr = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, std::thread::hardware_concurrency()), n / 65536));
+  struct Part { uint64_t words = 0; int64_t packed = 0, ops = 0, blob_end = 0; int max_width = 0, max_len = 0, err = 0; };
+  std::vector<Part> parts((size_t)nthr);
+  auto pass1 = [&](int t) {
+    Part& pt = parts[(size_t)t];
+    const int64_t lo = n * t / nthr, hi = n * (t + 1) / nthr;
+    for (int64_t i = lo; i < hi; ++i) {
+      const int pl = p_len[i], tl = t_len[i];
+      if (pl < 0 || tl < 0 || p_off[i] < 0 || t_off[i] < 0) { pt.err = 1; return; }
+      if ((int64_t)pl + tl > (int64_t)INT_MAX / 2 - 8) { pt.err = 2; return; }
+      // wavefront_align.c:86-102: the reference exit(1)s here
+      if (c.span == WFA_SPAN_ENDSFREE &&
+          (c.pattern_begin_free > pl || c.pattern_end_free > pl || c.text_begin_free > tl || c.text_end_free > tl)) { pt.err = 3; return; }
+      pt.words += (uint64_t)((pl + 15) >> 4) + (uint64_t)((tl + 15) >> 4);
+      pt.max_width = std::max(pt.max_width, pl + tl + 3);
+      pt.max_len = std::max(pt.max_len, std::max(pl, tl));
+      pt.packed += (int64_t)((pl + 3) >> 2) + ((tl + 3) >> 2);
+      pt.ops += (int64_t)pl + tl;
+      pt.blob_end = std::max(pt.blob_end, std::max(p_off[i] + pl, t_off[i] + tl));
+    }
+  };
+  auto run_threads = [&](auto&& fn) {
+    if (nthr == 1) { fn(0); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthr; ++t) th.emplace_back(fn, t);
+    for (auto& x : th) x.join();
+  };
+  run_threads(pass1);
   uint64_t woff = 0;
   int64_t blob_end = 0;
-  for (int64_t i = 0; i < n; ++i) {
-    const int pl = p_len[i], tl = t_len[i];
-    if (pl < 0 || tl < 0 || p_off[i] < 0 || t_off[i] < 0) { al->err = "negative length or offset"; return WFA_HIP_EINVAL; }
-    if ((int64_t)pl + tl > (int64_t)INT_MAX / 2 - 8) { al->err = "sequence too long"; return WFA_HIP_EINVAL; }
-    // wavefront_align.c:86-102: the reference exit(1)s here
-    if (c.span == WFA_SPAN_ENDSFREE &&
-        (c.pattern_begin_free > pl || c.pattern_end_free > pl || c.text_begin_free > tl || c.text_end_free > tl)) {
-      al->err = "Ends-free parameters must be not larger than the sequences";
-      return WFA_HIP_EINVAL;
-    }
-    meta[i].p_woff = (uint32_t)woff; woff += (uint64_t)((pl + 15) >> 4);
-    meta[i].t_woff = (uint32_t)woff; woff += (uint64_t)((tl + 15) >> 4);
-    meta[i].plen = pl; meta[i].tlen = tl;
-    if (woff > 0xFFFFFFF0ull) { al->err = "batch too large: more than 2^32 packed words (split the batch)"; return WFA_HIP_EINVAL; }
-    b->max_width = std::max(b->max_width, pl + tl + 3);
-    b->max_len = std::max(b->max_len, std::max(pl, tl));
-    b->packed_bytes += (int64_t)((pl + 3) >> 2) + ((tl + 3) >> 2);
-    b->ops_bytes += (int64_t)pl + tl;
-    blob_end = std::max(blob_end, std::max(p_off[i] + pl, t_off[i] + tl));
+  std::vector<uint64_t> wbase((size_t)nthr);
+  for (int t = 0; t < nthr; ++t) {
+    const Part& pt = parts[(size_t)t];
+    if (pt.err == 1) { al->err = "negative length or offset"; return WFA_HIP_EINVAL; }
+    if (pt.err == 2) { al->err = "sequence too long"; return WFA_HIP_EINVAL; }
+    if (pt.err == 3) { al->err = "Ends-free parameters must be not larger than the sequences"; return WFA_HIP_EINVAL; }
+    wbase[(size_t)t] = woff; woff += pt.words;
+    b->max_width = std::max(b->max_width, pt.max_width); b->max_len = std::max(b->max_len, pt.max_len);
+    b->packed_bytes += pt.packed; b->ops_bytes += pt.ops; blob_end = std::max(blob_end, pt.blob_end);
   }
+  if (woff > 0xFFFFFFF0ull) { al->err = "batch too large: more than 2^32 packed words (split the batch)"; return WFA_HIP_EINVAL; }
+  run_threads([&](int t) {
+    uint64_t w = wbase[(size_t)t];
+    const int64_t lo = n * t / nthr, hi = n * (t + 1) / nthr;
+    for (int64_t i = lo; i < hi; ++i) {
+      const int pl = p_len[i], tl = t_len[i];
+      meta[(size_t)i].p_woff = (uint32_t)w; w += (uint64_t)((pl + 15) >> 4);
+      meta[(size_t)i].t_woff = (uint32_t)w; w += (uint64_t)((tl + 15) >> 4);
+      meta[(size_t)i].plen = pl; meta[(size_t)i].tlen = tl;
+    }
+  });
+  if (timing) { fprintf(stderr, "[wfa_hip] meta loop %.1f ms\n", now_ms() - t0); t0 = now_ms(); }
   const bool full = (c.scope == WFA_SCOPE_FULL);
   const size_t nn = (size_t)std::max<int64_t>(n, 1);
   HIP_TRY(al, hipMalloc((void**)&b->d_bytes, (size_t)blob_end + 64));
@@ -338,11 +379,12 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
     HIP_TRY(al, hipMemcpyAsync(b->d_cigar_off, coff.data(), ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, al->stream));
     HIP_TRY(al, hipStreamSynchronize(al->stream));  // coff is a local
   }
+  if (timing) { fprintf(stderr, "[wfa_hip] mallocs %.1f ms\n", now_ms() - t0); t0 = now_ms(); }
   if (n > 0) {
     HIP_TRY(al, hipMemcpyAsync(b->d_bytes, seqs, (size_t)blob_end, hipMemcpyHostToDevice, al->stream));
     HIP_TRY(al, hipMemcpyAsync(b->d_pboff, p_off, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, al->stream));
     HIP_TRY(al, hipMemcpyAsync(b->d_tboff, t_off, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, al->stream));
-    HIP_TRY(al, hipMemcpyAsync(b->d_meta, meta.data(), (size_t)n * sizeof(WfaPairMeta), hipMemcpyHostToDevice, al->stream));
+    HIP_TRY(al, hipMemcpyAsync(b->d_meta, meta.get(), (size_t)n * sizeof(WfaPairMeta), hipMemcpyHostToDevice, al->stream));
     const int threads = 256;
     const int64_t want = (n + 3) / 4;  // 4 waves (pairs) per workgroup
     const int grid = (int)std::min<int64_t>(want, (int64_t)al->cu_count * 16);
@@ -352,6 +394,7 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
     std::vector<uint8_t> flags((size_t)n);
     HIP_TRY(al, hipMemcpyAsync(flags.data(), b->d_flags, (size_t)n, hipMemcpyDeviceToHost, al->stream));
     HIP_TRY(al, hipStreamSynchronize(al->stream));
+    if (timing) { fprintf(stderr, "[wfa_hip] H2D + pack + flags D2H %.1f ms (%.2f GB)\n", now_ms() - t0, blob_end / 1e9); t0 = now_ms(); }
     // split into the 2-bit and the 8-bit work lists (wildcard matching needs the bytes)
     std::vector<uint32_t> lp, lb;
     if (c.wildcard >= 0) {
@@ -378,6 +421,7 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
       // every pair is pure ACGT: the ASCII blob is no longer needed
       (void)hipFree(b->d_bytes); b->d_bytes = nullptr;
     }
+    if (timing) { fprintf(stderr, "[wfa_hip] work lists + free %.1f ms\n", now_ms() - t0); t0 = now_ms(); }
   }
   return WFA_HIP_OK;
 }
