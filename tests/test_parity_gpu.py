@@ -127,3 +127,42 @@ def test_ends_free_larger_than_sequence_is_an_error(gpu):
     with pytest.raises(ValueError):
         al.align_batch(datagen.from_strings(["ACGT"], ["ACGT"]), True)
     al.close()
+
+
+def test_mixed_lengths_and_alphabets_one_batch(gpu):
+    """One batch mixing 20 bp .. 3 kb pairs, pure-ACGT and N-containing pairs: the cascade (two-per-wave,
+    one-per-wave, banded, general, 8-bit) must hand every pair to a stage that finishes it."""
+    rng = np.random.default_rng(3)
+    pats, txts = [], []
+    for i in range(600):
+        L = int(rng.choice([20, 60, 150, 150, 150, 300, 700, 3000]))
+        b = datagen.generate(1, L, float(rng.choice([0.0, 0.02, 0.1])), 10_000 + i)
+        p, t = datagen.pair_strings(b, 0)
+        if i % 7 == 0:
+            p = p[: L // 2] + "N" + p[L // 2 + 1:]
+        pats.append(p); txts.append(t)
+    batch = datagen.from_strings(pats, txts)
+    for kw in (dict(span="end-to-end", scope="score"), dict(scope="full"), dict(scope="full", heuristic="adaptive")):
+        oc, nc = common.configs_pair(**kw)
+        o = loader.run(loader.oracle(), oc, batch)
+        for resident in (False, True):
+            score, status, cigars = common.gpu_run(nc, batch, oc.scope == 1, resident)
+            common.assert_same(o, score, status, cigars, batch, f"mixed {kw}")
+
+
+def test_resident_batch_reruns_are_identical(gpu):
+    from pywfa_amd import _native
+    batch = datagen.generate(5000, 1500, 0.08, 77)
+    oc, nc = common.configs_pair(span="end-to-end", scope="full", heuristic="adaptive")
+    al = _native.Aligner(nc)
+    rb = al.batch(batch)
+    outs = []
+    for _ in range(3):
+        rb.run(); rb.run(); rb.sync()          # two enqueued runs, then a sync
+        s, st, (ops, cb, cl) = rb.results(True)
+        outs.append((s.copy(), st.copy(), [ops[cb[i]:cb[i] + cl[i]].tobytes() for i in range(0, 5000, 97)]))
+    rb.close(); al.close()
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) and o[2] == outs[0][2]
+    ref = loader.run(loader.oracle(), oc, datagen.subset(batch, np.arange(0, 5000, 97)))
+    assert [c for c in ref["cigars"]] == outs[0][2]
