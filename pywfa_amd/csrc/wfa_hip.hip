@@ -614,14 +614,25 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     if (rc != WFA_HIP_OK) return rc;
 
     if (use_fast) {
-      // two pairs per wave first (32 diagonals each) when the reads are short enough, then one per wave
-      const bool use_dual = b->max_len <= WFA_FAST2_MAX_LEN && env_int("WFA_HIP_NO_DUAL", 0) == 0;
-      for (int pass = use_dual ? 0 : 1; pass < 2; ++pass) {
+      // register-kernel stages, each taking what the one before handed on (WFA_HIP_FAST_STAGES, one digit per
+      // stage): 3 = 8-lane segments, 2 = 16-lane segments, 1 = half-waves, 0 = one alignment per wave
+      const char* stages_env = getenv("WFA_HIP_FAST_STAGES");
+      const char* stages = (stages_env && *stages_env) ? stages_env : "20";
+      int variants[4] = {-1, -1, -1, -1};
+      int nv = 0;
+      for (const char* c = stages; *c && nv < 4; ++c) {
+        const int v = *c - '0';
+        if (v < 0 || v > 3) continue;
+        if (v == 1 && b->max_len > WFA_FAST2_MAX_LEN) continue;
+        variants[nv++] = v;
+      }
+      if (nv == 0) variants[nv++] = 0;
+      for (int pass = 0; pass < nv; ++pass) {
         uint32_t* out_list = b->d_fb_list2[out_sel];
         uint32_t* out_count = b->d_counters + 4 + out_sel;
         if (!first_stage) HIP_TRY(al, hipMemsetAsync(out_count, 0, sizeof(uint32_t), stream));
         if (wfa::launch_fast(al->dcfg, al->cu_count, stream, b->d_words, b->d_meta, in_list, in_count, in_n, b->d_score, b->d_status,
-                             out_list, out_count, pass == 0) != 0) { al->err = "fast kernel launch failed"; return WFA_HIP_EDEVICE; }
+                             out_list, out_count, variants[pass]) != 0) { al->err = "fast kernel launch failed"; return WFA_HIP_EDEVICE; }
         if (first_stage) b->last_kernel_pairs = in_n;
         in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
       }
