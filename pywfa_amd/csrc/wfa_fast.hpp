@@ -337,183 +337,28 @@ wfa_fast2_kernel(const FastArgs a) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Segmented kernel: the wave is cut into 64/W segments of W lanes, each aligning its own pair inside a band
-// of W diagonals (k in [-W/2, W/2)); cells outside the band are dropped, so the score found, S', is that of
-// the best alignment that stays inside the band (S' >= S).  It is accepted only when it is proven optimal:
-// an end-to-end alignment that leaves the band must climb from diagonal 0 to +W/2 (or down to -W/2-1) and
-// come back to tlen-plen, which costs at least Bmin = min(2o + e(W - ak), 2o + e(W + 2 + ak)); S' <= Bmin
-// therefore implies S' = S (score scope: a tie is the same score).  Everything else is handed on.
-// A VALU instruction costs the same 4 cycles however few lanes are live, and at a few percent divergence
-// only a dozen diagonals ever are, so lanes are the resource to share: a segment that finishes takes the
-// next pair of the chunk at once (its words are prefetched two pairs ahead) while the others keep going.
-// In-bounds cells never descend from out-of-bounds ones (an I/D move keeps offset - lim), so for the score
-// only M needs the clamp to lim and the I/D end trimming of the reference is skipped.
+// neighbour diagonals inside a segment of W lanes (wfa_seg.hpp): lanes at a segment border receive NULL
 template <int W>
 __device__ __forceinline__ int seg_from_below(int v) {
-  int r = __builtin_amdgcn_update_dpp(WFA_OFFSET_NULL, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
-  if (W == 8 && (threadIdx.x & 7) == 0) r = WFA_OFFSET_NULL;
+  if (W <= 16) {
+    int r = __builtin_amdgcn_update_dpp(WFA_OFFSET_NULL, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    if (W == 8 && (threadIdx.x & 7) == 0) r = WFA_OFFSET_NULL;
+    return r;
+  }
+  int r = __builtin_amdgcn_update_dpp(WFA_OFFSET_NULL, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  if (W == 32 && (threadIdx.x & 31) == 0) r = WFA_OFFSET_NULL;
   return r;
 }
 template <int W>
 __device__ __forceinline__ int seg_from_above(int v) {
-  int r = __builtin_amdgcn_update_dpp(WFA_OFFSET_NULL, v, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
-  if (W == 8 && (threadIdx.x & 7) == 7) r = WFA_OFFSET_NULL;
-  return r;
-}
-
-template <int X, int OE, int E, int W>
-__global__ void __launch_bounds__(64)
-wfa_fast_seg_kernel(const FastArgs a) {
-  static_assert(W == 8 || W == 16, "segment width");
-  constexpr int DM = (X > OE) ? X : OE;
-  constexpr int NS = 64 / W, H = W / 2, LW = (W == 16) ? 4 : 3;
-  constexpr int SW = WFA_FAST_WORDS;
-  constexpr int AK_NONE = 0x7fff;
-  __shared__ uint32_t lds[NS * 2 * SW + 2];  // +2: a lane parked at offset 512 reads two words past its array
-  const int lane = threadIdx.x;
-  const int seg = lane >> LW;
-  const int k = (lane & (W - 1)) - H;
-  const int pbias = seg * 2 * SW * 16, tbias = pbias + SW * 16;  // base coordinates of my segment's words
-  const int pen_o = a.g * (OE - E), pen_e = a.g * E;
-  const uint32_t nwork = a.nwork_dev ? *a.nwork_dev : a.nwork;
-  const uint32_t nchunks = (nwork + 63u) >> 6;
-
-  for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const uint32_t base = chunk << 6;
-    const int cnt = (int)min(64u, nwork - base);
-    const uint32_t my_pair = (lane < cnt) ? (a.worklist ? a.worklist[base + lane] : base + lane) : 0u;
-    WfaPairMeta my_meta = a.meta[my_pair];
-    if (lane >= cnt) { my_meta.plen = 0; my_meta.tlen = 0; }
-    int my_score = 0;
-    bool my_fb = false;
-    // lanes 0..31 fetch pattern word `lane`, lanes 32..63 text word `lane-32`, of pair jj of the chunk
-    auto fetch_word = [&](int jj) -> uint32_t {
-      const int jc = min(jj, 63);
-      const uint32_t woff = (lane < 32) ? __builtin_amdgcn_readlane(my_meta.p_woff, jc) : __builtin_amdgcn_readlane(my_meta.t_woff, jc);
-      const int len = (lane < 32) ? __builtin_amdgcn_readlane(my_meta.plen, jc) : __builtin_amdgcn_readlane(my_meta.tlen, jc);
-      const int idx = lane & 31;
-      uint32_t w = 0;
-      if (jj < cnt && len <= WFA_FAST_MAX_LEN && idx < ((len + 15) >> 4)) w = a.words[woff + idx];
-      return w;
-    };
-    int next_j = 0;
-    uint32_t pre0 = fetch_word(0), pre1 = fetch_word(1);
-    // per-lane state of my segment's alignment
-    int tlen = 0, lim = WFA_OFFSET_NULL, ak = AK_NONE, smax = 0, jcur = 0, step = 0, cur = WFA_OFFSET_NULL;
-    int Mh[DM], Ih[E], Dh[E];
-#pragma unroll
-    for (int d = 0; d < DM; ++d) Mh[d] = WFA_OFFSET_NULL;
-#pragma unroll
-    for (int d = 0; d < E; ++d) { Ih[d] = WFA_OFFSET_NULL; Dh[d] = WFA_OFFSET_NULL; }
-    uint32_t want = (1u << NS) - 1u;  // segments waiting for a pair
-    uint32_t busy = 0;                // segments aligning
-    while (true) {
-      if (want) {
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-          if (!(want & (1u << s))) continue;
-          while (next_j < cnt) {
-            const int j = next_j++;
-            const int pl = __builtin_amdgcn_readlane(my_meta.plen, j), tl = __builtin_amdgcn_readlane(my_meta.tlen, j);
-            const int akk = tl - pl;
-            const uint32_t w = pre0;
-            pre0 = pre1; pre1 = fetch_word(j + 2);
-            if (pl > WFA_FAST_MAX_LEN || tl > WFA_FAST_MAX_LEN || akk < -H || akk > H - 1) {
-              if (lane == j) my_fb = true;
-              continue;
-            }
-            lds[s * 2 * SW + ((lane < 32) ? lane : SW - 32 + lane)] = w;
-            if (lane < 4) lds[s * 2 * SW + ((lane < 2) ? 32 + lane : SW + 30 + lane)] = 0u;
-            if (seg == s) {
-              tlen = tl; ak = akk; jcur = j; step = 0;
-              lim = min(tl, pl + k);
-              smax = min(2 * pen_o + pen_e * (W - akk), 2 * pen_o + pen_e * (W + 2 + akk)) / a.g;
-              cur = (k == 0) ? 0 : WFA_OFFSET_NULL;
-            }
-            busy |= 1u << s;
-            break;
-          }
-        }
-        want = 0;
-        __syncthreads();
-        if (!busy) break;
-      }
-      // ---------------- extend ----------------
-      {
-        int left = (cur >= 0) ? lim - cur : 0;
-        if (__any(left > 0)) {
-          int h = max(cur, 0) + tbias, v = max(cur - k, 0) + pbias;
-          bool more;
-          do {
-            const int pi = v >> 4, ti = h >> 4;
-            const uint32_t p0 = lds[pi], p1 = lds[pi + 1], p2 = lds[pi + 2];
-            const uint32_t t0 = lds[ti], t1 = lds[ti + 1], t2 = lds[ti + 2];
-            const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h << 1);
-            const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t2, t1, (uint32_t)h << 1);
-            const unsigned long long x = (unsigned long long)xl | ((unsigned long long)xh << 32);
-            int m = x ? ((int)__builtin_ctzll(x) >> 1) : 32;
-            m = min(m, left);
-            v += m; h += m; left -= m;
-            more = (m == 32) && (left > 0);
-          } while (__any(more));
-          if (cur >= 0) cur = h - tbias;
-        }
-      }
-      // ---------------- termination / give up ----------------
-      {
-        const unsigned long long bf = __ballot(k == ak && cur >= tlen);
-        const unsigned long long bg = __ballot(ak != AK_NONE && step >= smax);
-        if (bf | bg) {
-#pragma unroll
-          for (int s = 0; s < NS; ++s) {
-            const uint32_t f = (uint32_t)(bf >> (s * W)) & ((1u << W) - 1u), gup = (uint32_t)(bg >> (s * W)) & ((1u << W) - 1u);
-            if (f | gup) {
-              const int j = __builtin_amdgcn_readlane(jcur, s * W), st = __builtin_amdgcn_readlane(step, s * W);
-              if (lane == j) { my_score = -(st * a.g); my_fb = (f == 0u); }
-              want |= 1u << s; busy &= ~(1u << s);
-              if (seg == s) {
-                ak = AK_NONE; cur = WFA_OFFSET_NULL; lim = WFA_OFFSET_NULL;
-#pragma unroll
-                for (int d = 0; d < DM; ++d) Mh[d] = WFA_OFFSET_NULL;
-#pragma unroll
-                for (int d = 0; d < E; ++d) { Ih[d] = WFA_OFFSET_NULL; Dh[d] = WFA_OFFSET_NULL; }
-              }
-            }
-          }
-          if (!busy && next_j >= cnt) break;
-        }
-      }
-      // ---------------- compute-next ----------------
-#pragma unroll
-      for (int d = DM - 1; d > 0; --d) Mh[d] = Mh[d - 1];
-      Mh[0] = cur;
-      {
-        const int mx = Mh[X - 1], mo = Mh[OE - 1], ie = Ih[E - 1], de = Dh[E - 1];
-        const int ni = max(seg_from_below<W>(mo), seg_from_below<W>(ie)) + 1;
-        const int nd = max(seg_from_above<W>(mo), seg_from_above<W>(de));
-        int nm = max(nd, max(mx + 1, ni));
-        if (nm > lim) nm = WFA_OFFSET_NULL;
-#pragma unroll
-        for (int d = E - 1; d > 0; --d) { Ih[d] = Ih[d - 1]; Dh[d] = Dh[d - 1]; }
-        Ih[0] = ni; Dh[0] = nd;
-        cur = nm;
-      }
-      ++step;
-    }
-    if (lane < cnt) {
-      if (!my_fb) a.score[my_pair] = my_score;
-      a.status[my_pair] = my_fb ? WFA_INTERNAL_FALLBACK : 0;
-    }
-    const unsigned long long fbm = __ballot(my_fb && lane < cnt);
-    if (fbm) {
-      uint32_t slot_ = 0;
-      if (lane == 0) slot_ = atomicAdd(a.fb_count, (uint32_t)__builtin_popcountll(fbm));
-      slot_ = __builtin_amdgcn_readfirstlane(slot_);
-      if (my_fb && lane < cnt) a.fb_list[slot_ + __builtin_popcountll(fbm & ((1ull << lane) - 1ull))] = my_pair;
-    }
+  if (W <= 16) {
+    int r = __builtin_amdgcn_update_dpp(WFA_OFFSET_NULL, v, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+    if (W == 8 && (threadIdx.x & 7) == 7) r = WFA_OFFSET_NULL;
+    return r;
   }
+  int r = __builtin_amdgcn_update_dpp(WFA_OFFSET_NULL, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+  if (W == 32 && (threadIdx.x & 31) == 31) r = WFA_OFFSET_NULL;
+  return r;
 }
 
 static inline int gcd_int(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
@@ -531,7 +376,7 @@ inline bool fast_supported(const WfaDevConfig& c, int ncomp, bool full) {
 inline int launch_fast(const WfaDevConfig& c, int cu_count, hipStream_t stream, const uint32_t* words,
                        const WfaPairMeta* meta, const uint32_t* worklist, const uint32_t* nwork_dev, uint32_t nwork,
                        int32_t* score, int32_t* status, uint32_t* fb_list, uint32_t* fb_count, int variant) {
-  // variant: 0 = one alignment per wave, 1 = two per wave in half-waves, 2 = four per wave in 16-lane segments, 3 = eight per wave in 8-lane segments
+  // variant: 0 = one alignment per wave, 1 = two per wave in half-waves
   FastArgs a;
   a.words = words; a.meta = meta; a.worklist = worklist; a.nwork_dev = nwork_dev; a.nwork = nwork;
   a.score = score; a.status = status; a.fb_list = fb_list; a.fb_count = fb_count;
@@ -544,8 +389,6 @@ inline int launch_fast(const WfaDevConfig& c, int cu_count, hipStream_t stream, 
   if (nwork_dev) grid = (long long)cu_count * 32;  // leftovers: count known only on the device
   if (grid < 1) grid = 1;
   if (variant == 1) hipLaunchKernelGGL((wfa_fast2_kernel<2, 4, 1>), dim3((unsigned)grid), dim3(64), 0, stream, a);
-  else if (variant == 2) hipLaunchKernelGGL((wfa_fast_seg_kernel<2, 4, 1, 16>), dim3((unsigned)grid), dim3(64), 0, stream, a);
-  else if (variant == 3) hipLaunchKernelGGL((wfa_fast_seg_kernel<2, 4, 1, 8>), dim3((unsigned)grid), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL((wfa_fast_kernel<2, 4, 1>), dim3((unsigned)grid), dim3(64), 0, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

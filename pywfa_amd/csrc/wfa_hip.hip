@@ -21,6 +21,7 @@
 #include "wfa_pack.hpp"
 #include "wfa_general.hpp"
 #include "wfa_fast.hpp"
+#include "wfa_seg.hpp"
 #include "wfa_band.hpp"
 #include "wfa_rle.hpp"
 
@@ -615,14 +616,14 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
 
     if (use_fast) {
       // register-kernel stages, each taking what the one before handed on (WFA_HIP_FAST_STAGES, one digit per
-      // stage): 3 = 8-lane segments, 2 = 16-lane segments, 1 = half-waves, 0 = one alignment per wave
+      // stage): 3/2/4/5 = segments of 8/16/32/64 lanes, 1 = half-waves, 0 = one alignment per wave (both with edge detection)
       const char* stages_env = getenv("WFA_HIP_FAST_STAGES");
-      const char* stages = (stages_env && *stages_env) ? stages_env : "20";
-      int variants[4] = {-1, -1, -1, -1};
+      const char* stages = (stages_env && *stages_env) ? stages_env : "245";
+      int variants[6] = {-1, -1, -1, -1, -1, -1};
       int nv = 0;
-      for (const char* c = stages; *c && nv < 4; ++c) {
+      for (const char* c = stages; *c && nv < 6; ++c) {
         const int v = *c - '0';
-        if (v < 0 || v > 3) continue;
+        if (v < 0 || v > 5) continue;
         if (v == 1 && b->max_len > WFA_FAST2_MAX_LEN) continue;
         variants[nv++] = v;
       }
@@ -631,8 +632,22 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         uint32_t* out_list = b->d_fb_list2[out_sel];
         uint32_t* out_count = b->d_counters + 4 + out_sel;
         if (!first_stage) HIP_TRY(al, hipMemsetAsync(out_count, 0, sizeof(uint32_t), stream));
-        if (wfa::launch_fast(al->dcfg, al->cu_count, stream, b->d_words, b->d_meta, in_list, in_count, in_n, b->d_score, b->d_status,
-                             out_list, out_count, variants[pass]) != 0) { al->err = "fast kernel launch failed"; return WFA_HIP_EDEVICE; }
+        hipEvent_t se0 = nullptr, se1 = nullptr;
+        const bool stage_timing = env_int("WFA_HIP_STAGE_TIMING", 0) != 0;
+        if (stage_timing) { hipEventCreate(&se0); hipEventCreate(&se1); hipEventRecord(se0, stream); }
+        const int lrc = (variants[pass] >= 2)
+            ? wfa::launch_seg(al->dcfg, al->cu_count, stream, b->d_words, b->d_meta, in_list, in_count, in_n, b->d_score, b->d_status,
+                              out_list, out_count, variants[pass])
+            : wfa::launch_fast(al->dcfg, al->cu_count, stream, b->d_words, b->d_meta, in_list, in_count, in_n, b->d_score, b->d_status,
+                               out_list, out_count, variants[pass]);
+        if (lrc != 0) { al->err = "fast kernel launch failed"; return WFA_HIP_EDEVICE; }
+        if (stage_timing) {  // development aid: synchronises after every stage
+          hipEventRecord(se1, stream); hipEventSynchronize(se1);
+          float ms = 0.f; hipEventElapsedTime(&ms, se0, se1);
+          uint32_t handed = 0; hipMemcpy(&handed, out_count, sizeof(uint32_t), hipMemcpyDeviceToHost);
+          fprintf(stderr, "[wfa_hip] stage %d (variant %d): %.3f ms, handed on %u pairs\n", pass, variants[pass], ms, handed);
+          hipEventDestroy(se0); hipEventDestroy(se1);
+        }
         if (first_stage) b->last_kernel_pairs = in_n;
         in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
       }

@@ -1,0 +1,268 @@
+// wfa_seg.hpp — segmented register kernel: the C2 hot loop (gap-affine 4/6/2-shaped penalties, match 0,
+// end-to-end, score only, no heuristic, reads <= 512 bases; same scope as wfa_fast.hpp).
+//
+// Why segments.  On CDNA a VALU instruction occupies its SIMD for 4 cycles however few of the 64 lanes
+// are live, and the one-alignment-per-wave kernel of wfa_fast.hpp already runs at the VALU issue limit
+// (rocprofv3 SQ_INSTS_VALU x 4 cycles = kernel time).  At a few percent divergence a wavefront is a dozen
+// diagonals wide, so lanes are the resource to share: the wave is cut into 64/W segments of W lanes
+// (W = 8, 16, 32 or 64), each aligning its own pair inside a band of W diagonals, k in [-W/2, W/2).
+//
+// Exactness.  Cells outside the band are dropped, so the score found, S', is that of the best alignment
+// staying inside the band (S' >= S, the reference's score).  It is accepted only when proven optimal: an
+// end-to-end alignment that leaves the band has to climb from diagonal 0 to +W/2 (or down to -W/2-1) and
+// come back to ak = tlen - plen, which costs at least
+//     Bmin = min(2o + e(W - ak), 2o + e(W + 2 + ak)),
+// hence S' <= Bmin implies S' = S (score scope: a tie is the same score).  A pair that reaches Bmin without
+// finishing is handed to the next stage (a wider segment, finally the banded / general kernels).
+// In-bounds cells never descend from out-of-bounds ones (an I or D move keeps offset - lim), so for the
+// score only M needs the clamp to lim; the reference's I/D end trimming (R/wavefront_compute.c:571-605)
+// cannot change a score and is skipped.  Recurrences: R/wavefront_compute_affine.c:44-86; extension:
+// R/wavefront_extend.c; termination: R/wavefront_termination.c (end2end).
+//
+// Work distribution.  Each wave owns one contiguous slice of the work list.  Pair metadata is held one
+// window of 64 pairs per VGPR (lane i <-> pair i of the window, two windows so that prefetch can run
+// ahead), a segment that finishes takes the next pair of the slice at once (its packed words were
+// prefetched two pairs ahead into registers, then copied to the segment's LDS arrays), and results are
+// stored straight from the lane that saw the end cell — segments never wait for each other.
+//
+// Extension: 32 bases per round and lane (three LDS words per sequence, two funnel shifts each, XOR, count
+// trailing zeros), rounds repeated while any lane of the wave is still running.  (A variant in which a whole
+// segment compares 16 W bases for its one long-running diagonal measured no faster and was dropped.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include "wfa_common.hpp"
+#include "wfa_fast.hpp"
+
+namespace wfa {
+
+// index of the lowest set bit, ~0u for 0 (v_ffbl_b32 semantics)
+__device__ __forceinline__ uint32_t ffbl_u32(uint32_t x) {
+  uint32_t r;
+  asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+template <int X, int OE, int E, int W>
+__global__ void __launch_bounds__(64)
+wfa_seg_kernel(const FastArgs a) {
+  static_assert(W == 8 || W == 16 || W == 32 || W == 64, "segment width");
+  constexpr int DM = (X > OE) ? X : OE;
+  constexpr int NS = 64 / W, H = W / 2, LW = (W == 64) ? 6 : (W == 32) ? 5 : (W == 16) ? 4 : 3;
+  constexpr unsigned long long FIELD = (W == 64) ? ~0ull : ((1ull << (W & 63)) - 1ull);
+  constexpr int SW = WFA_FAST_WORDS;
+  constexpr int NEVER = 0x7fffffff;
+  __shared__ uint32_t lds[NS * 2 * SW + 4];  // per segment: pattern words, text words (32 + 2 zero pad words each)
+  __shared__ uint32_t fbuf[64];              // pairs handed on, appended to the global list 64 at a time
+  const int lane = threadIdx.x;
+  const int seg = lane >> LW;
+  const int l = lane & (W - 1);
+  const int k = l - H;
+  const int pbias = seg * 2 * SW * 16, tbias = pbias + SW * 16;  // base coordinates of my segment's words
+  const bool low_half = lane < 32;
+  const int widx = low_half ? lane : SW - 32 + lane;  // staging: lanes 0..31 pattern words, 32..63 text words
+  const int cur0 = (k == 0) ? 0 : WFA_OFFSET_NULL;
+  const uint32_t nwork = __builtin_amdgcn_readfirstlane(a.nwork_dev ? *a.nwork_dev : a.nwork);  // keep everything derived from it scalar
+  const uint32_t per = __builtin_amdgcn_readfirstlane((nwork + gridDim.x - 1) / gridDim.x);  // (the division runs on the VALU)
+  const unsigned long long begin64 = (unsigned long long)blockIdx.x * per;
+  if (begin64 >= nwork) return;
+  const uint32_t begin = (uint32_t)begin64;
+  const uint32_t end = (uint32_t)min((unsigned long long)nwork, begin64 + per);
+  if (lane < 4 * NS) lds[(lane >> 1) * SW + 32 + (lane & 1)] = 0u;  // the pad words stay zero for good
+  if (lane < 4) lds[NS * 2 * SW + lane] = 0u;
+
+  // two windows of 64 pairs: lane i holds pair wbase + i (window 0) and wbase + 64 + i (window 1)
+  uint32_t pid0, pid1;
+  WfaPairMeta m0, m1;
+  auto load_window = [&](uint32_t wb, uint32_t& pid, WfaPairMeta& m) {
+    const unsigned long long idx = (unsigned long long)wb + lane;
+    pid = 0u; m.p_woff = 0u; m.t_woff = 0u; m.plen = 0; m.tlen = 0;
+    if (idx < end) { pid = a.worklist ? a.worklist[idx] : (uint32_t)idx; m = a.meta[pid]; }
+  };
+  uint32_t wbase = begin;
+  load_window(wbase, pid0, m0);
+  load_window(wbase + 64u, pid1, m1);
+  // lanes 0..31 fetch pattern word `lane`, lanes 32..63 text word `lane-32`, of slice pair i
+  auto fetch_word = [&](uint32_t i) -> uint32_t {
+    uint32_t w = 0;
+    if (i < end) {
+      const int r = (int)(i - wbase);
+      uint32_t pw, tw; int pl, tl;
+      if (r < 64) {
+        pw = __builtin_amdgcn_readlane(m0.p_woff, r); tw = __builtin_amdgcn_readlane(m0.t_woff, r);
+        pl = __builtin_amdgcn_readlane(m0.plen, r); tl = __builtin_amdgcn_readlane(m0.tlen, r);
+      } else {
+        pw = __builtin_amdgcn_readlane(m1.p_woff, r - 64); tw = __builtin_amdgcn_readlane(m1.t_woff, r - 64);
+        pl = __builtin_amdgcn_readlane(m1.plen, r - 64); tl = __builtin_amdgcn_readlane(m1.tlen, r - 64);
+      }
+      if (pl <= WFA_FAST_MAX_LEN && tl <= WFA_FAST_MAX_LEN) {
+        const int nwp = (pl + 15) >> 4, nwt = (tl + 15) >> 4;
+        const uint32_t woff = low_half ? pw : tw;
+        const int nw = low_half ? nwp : nwt;
+        if ((lane & 31) < nw) w = a.words[woff + (lane & 31)];
+      }
+    }
+    return w;
+  };
+  uint32_t next_i = begin;
+  uint32_t pre0 = fetch_word(begin), pre1 = fetch_word(begin + 1u);
+
+  uint32_t nfb = 0;
+  auto fb_flush = [&]() {
+    if (nfb == 0u) return;
+    __syncthreads();
+    uint32_t slot = 0;
+    if (lane == 0) slot = atomicAdd(a.fb_count, nfb);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    if ((uint32_t)lane < nfb) { const uint32_t pid = fbuf[lane]; a.fb_list[slot + lane] = pid; a.status[pid] = WFA_INTERNAL_FALLBACK; }
+    __syncthreads();
+    nfb = 0u;
+  };
+
+  // per-lane state of my segment's alignment.  The wave counts steps once (gstep, scalar); a pair taken at
+  // gstep = s0 is at its own step gstep - s0 and must end by `deadline` = s0 + Bmin / g.
+  int target = NEVER;  // tlen on the lane of diagonal tlen - plen: reaching it ends the alignment
+  int lim = WFA_OFFSET_NULL, cur = WFA_OFFSET_NULL, s0 = 0, deadline = NEVER;
+  uint32_t spair = 0;
+  int Mh[DM], Ih[E], Dh[E];
+#pragma unroll
+  for (int d = 0; d < DM; ++d) Mh[d] = WFA_OFFSET_NULL;
+#pragma unroll
+  for (int d = 0; d < E; ++d) { Ih[d] = WFA_OFFSET_NULL; Dh[d] = WFA_OFFSET_NULL; }
+  uint32_t want = (1u << NS) - 1u;  // segments waiting for a pair
+  uint32_t busy = 0;                // segments aligning
+  int gstep = 0;
+
+  // Terminates: gstep grows every round, every aligning segment has a finite deadline, and a segment only
+  // takes a new pair while next_i < end.
+  while (true) {
+    if (want) {
+      __syncthreads();
+      do {
+        const int s = __builtin_ctz(want);
+        want &= want - 1u;
+        while (next_i < end) {
+          const uint32_t i = next_i++;
+          if (i - wbase == 64u) {  // window 0 used up: window 1 moves down, the one after is requested
+            pid0 = pid1; m0 = m1; wbase += 64u;
+            load_window(wbase + 64u, pid1, m1);
+          }
+          const int r = (int)(i - wbase);
+          const int pl = __builtin_amdgcn_readlane(m0.plen, r), tl = __builtin_amdgcn_readlane(m0.tlen, r);
+          const uint32_t pid = __builtin_amdgcn_readlane(pid0, r);
+          const int akk = tl - pl;
+          const uint32_t w = pre0;
+          pre0 = pre1; pre1 = fetch_word(i + 2u);
+          if (pl > WFA_FAST_MAX_LEN || tl > WFA_FAST_MAX_LEN || akk < -H || akk > H - 1) {
+            if (nfb == 64u) fb_flush();
+            if (lane == 0) fbuf[nfb] = pid;
+            ++nfb;
+            continue;
+          }
+          lds[s * 2 * SW + widx] = w;
+          if (seg == s) {
+            target = (k == akk) ? tl : NEVER;
+            lim = min(tl, pl + k);
+            spair = pid; s0 = gstep;
+            // Bmin / g in units of g: o / g = OE - E, e / g = E
+            deadline = gstep + min(2 * (OE - E) + E * (W - akk), 2 * (OE - E) + E * (W + 2 + akk));
+            cur = cur0;
+#pragma unroll
+            for (int d = 0; d < DM; ++d) Mh[d] = WFA_OFFSET_NULL;
+#pragma unroll
+            for (int d = 0; d < E; ++d) { Ih[d] = WFA_OFFSET_NULL; Dh[d] = WFA_OFFSET_NULL; }
+          }
+          busy |= 1u << s;
+          break;
+        }
+      } while (want);
+      __syncthreads();
+      if (!busy) break;
+    }
+    // ---------------- extend: 32 bases per round on every diagonal until no lane is still running ----------------
+    {
+      int left = (cur >= 0) ? lim - cur : 0;
+      if (__any(left > 0)) {
+        int h = max(cur, 0) + tbias, v = max(cur - k, 0) + pbias;
+        bool more;
+        do {
+          const int pi = v >> 4, ti = h >> 4;
+          const uint32_t p0 = lds[pi], p1 = lds[pi + 1], p2 = lds[pi + 2];
+          const uint32_t t0 = lds[ti], t1 = lds[ti + 1], t2 = lds[ti + 2];
+          const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h << 1);
+          const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t2, t1, (uint32_t)h << 1);
+          // first differing bit of xh:xl; v_ffbl_b32 returns ~0 for 0, so `| 32` is +32 or stays ~0, and the
+          // unsigned min >> 1 is the number of equal bases or >= 2^30 when all 32 are equal
+          const uint32_t fb = min(ffbl_u32(xl), ffbl_u32(xh) | 32u);
+          const int m = min((int)(fb >> 1), min(32, left));
+          v += m; h += m; left -= m;
+          more = (m == 32) && (left > 0);
+        } while (__any(more));
+        if (cur >= 0) cur = h - tbias;
+      }
+    }
+    // ---------------- termination / hand-over ----------------
+    {
+      const bool rej = gstep > deadline;  // segment-uniform
+      const bool fin = cur >= target;     // possible on the lane of the end diagonal only
+      const unsigned long long bd = __ballot(fin || rej);
+      if (bd) {
+        if (fin && !rej) { a.score[spair] = -((gstep - s0) * a.g); a.status[spair] = 0; }
+        const bool hand = rej && l == 0;
+        const unsigned long long br = __ballot(hand);
+        if (br) {
+          const uint32_t nr = (uint32_t)__builtin_popcountll(br);
+          if (nfb + nr > 64u) fb_flush();
+          if (hand) fbuf[nfb + (uint32_t)__builtin_popcountll(br & ((1ull << lane) - 1ull))] = spair;
+          nfb += nr;
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          if ((bd >> (s * W)) & FIELD) { want |= 1u << s; busy &= ~(1u << s); }
+        if (((bd >> (seg * W)) & FIELD) != 0ull) { target = NEVER; deadline = NEVER; lim = WFA_OFFSET_NULL; cur = WFA_OFFSET_NULL; }
+        if (!busy && next_i >= end) break;
+      }
+    }
+    // ---------------- compute-next ----------------
+#pragma unroll
+    for (int d = DM - 1; d > 0; --d) Mh[d] = Mh[d - 1];
+    Mh[0] = cur;
+    {
+      // I(k) = max(M_oe, I_e)(k-1) + 1 and D(k) = max(M_oe, D_e)(k+1): the max commutes with the lane shift
+      const int mx = Mh[X - 1], mo = Mh[OE - 1], ie = Ih[E - 1], de = Dh[E - 1];
+      const int ni = seg_from_below<W>(max(mo, ie)) + 1;
+      const int nd = seg_from_above<W>(max(mo, de));
+      int nm = max(nd, max(mx + 1, ni));
+      if (nm > lim) nm = WFA_OFFSET_NULL;
+#pragma unroll
+      for (int d = E - 1; d > 0; --d) { Ih[d] = Ih[d - 1]; Dh[d] = Dh[d - 1]; }
+      Ih[0] = ni; Dh[0] = nd;
+      cur = nm;
+    }
+    ++gstep;
+  }
+  fb_flush();
+}
+
+// variant 2/3/4/5 = segments of 16/8/32/64 lanes (4/8/2/1 alignments per wave)
+inline int launch_seg(const WfaDevConfig& c, int cu_count, hipStream_t stream, const uint32_t* words,
+                      const WfaPairMeta* meta, const uint32_t* worklist, const uint32_t* nwork_dev, uint32_t nwork,
+                      int32_t* score, int32_t* status, uint32_t* fb_list, uint32_t* fb_count, int variant) {
+  FastArgs a;
+  a.words = words; a.meta = meta; a.worklist = worklist; a.nwork_dev = nwork_dev; a.nwork = nwork;
+  a.score = score; a.status = status; a.fb_list = fb_list; a.fb_count = fb_count;
+  a.g = gcd_int(gcd_int(c.x, c.o1 + c.e1), c.e1);
+  const char* env = getenv("WFA_HIP_FAST_WAVES_PER_CU");
+  const int per_cu = (env && *env) ? atoi(env) : 32;
+  long long grid = (long long)cu_count * per_cu;  // one slice of the work list per wave
+  if (!nwork_dev && grid > (long long)nwork) grid = nwork;
+  if (grid < 1) grid = 1;
+  const dim3 g((unsigned)grid), blk(64);
+  if (variant == 3) hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 8>), g, blk, 0, stream, a);
+  else if (variant == 4) hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 32>), g, blk, 0, stream, a);
+  else if (variant == 5) hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 64>), g, blk, 0, stream, a);
+  else hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 16>), g, blk, 0, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace wfa

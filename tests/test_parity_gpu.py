@@ -166,3 +166,38 @@ def test_resident_batch_reruns_are_identical(gpu):
         assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) and o[2] == outs[0][2]
     ref = loader.run(loader.oracle(), oc, datagen.subset(batch, np.arange(0, 5000, 97)))
     assert [c for c in ref["cigars"]] == outs[0][2]
+
+
+@pytest.mark.parametrize("stages", ["245", "2", "3", "4", "5", "32", "54", "3245", "0", "120"])
+def test_segmented_stages_accept_only_proven_scores(gpu, stages, monkeypatch):
+    """The banded segments (wfa_seg.hpp) keep a score only when it is provably the unbanded optimum and hand the
+    pair on otherwise: whatever the stage order, the scores must be the reference's.  The batch mixes pairs
+    that finish in every band width (0 % .. 30 % divergence, 30 .. 500 bases, |tlen - plen| up to 40), is long
+    enough for a wave's slice to outrun its two metadata windows (> 128 pairs per wave) and has repeats."""
+    monkeypatch.setenv("WFA_HIP_FAST_STAGES", stages)
+    monkeypatch.setenv("WFA_HIP_FAST_WAVES_PER_CU", "1")   # 256 waves -> ~200 pairs per slice
+    rng = np.random.default_rng(11)
+    parts = []
+    for i, (L, e) in enumerate([(150, 0.0), (150, 0.02), (150, 0.06), (150, 0.15), (60, 0.3), (30, 0.1),
+                                (500, 0.01), (500, 0.05), (330, 0.02), (16, 0.0)]):
+        parts.append(datagen.generate(5000, L, e, 4000 + i))
+    pats, txts = [], []
+    for b in parts:
+        for j in rng.choice(5000, 40, replace=False):
+            p, t = datagen.pair_strings(b, int(j))
+            cut = int(rng.integers(0, 41))
+            pats.append(p[: max(1, len(p) - cut)] if j % 3 == 0 else p)   # end-to-end with a length difference
+            txts.append(t)
+    small = datagen.from_strings(pats, txts)
+    oc, nc = common.configs_pair(span="end-to-end", scope="score")
+    for batch in parts[:4] + [small]:
+        o = loader.run(loader.oracle(), oc, batch, want_cigar=False)
+        score, status, _ = common.gpu_run(nc, batch, False, True)
+        assert np.array_equal(status, o["status"]), stages
+        assert np.array_equal(score, o["score"]), stages
+    # order of the pairs in the batch must not matter
+    perm = rng.permutation(len(pats))
+    shuf = datagen.from_strings([pats[i] for i in perm], [txts[i] for i in perm])
+    o = loader.run(loader.oracle(), oc, small, want_cigar=False)
+    score, status, _ = common.gpu_run(nc, shuf, False, False)
+    assert np.array_equal(score, o["score"][perm]) and np.array_equal(status, o["status"][perm])
