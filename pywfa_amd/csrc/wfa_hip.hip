@@ -623,7 +623,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       int nv = 0;
       for (const char* c = stages; *c && nv < 6; ++c) {
         const int v = *c - '0';
-        if (v < 0 || v > 5) continue;
+        if (v < 0 || v > 9) continue;
         if (v == 1 && b->max_len > WFA_FAST2_MAX_LEN) continue;
         variants[nv++] = v;
       }

@@ -43,33 +43,32 @@ __device__ __forceinline__ uint32_t ffbl_u32(uint32_t x) {
   return r;
 }
 
-template <int X, int OE, int E, int W>
+template <int X, int OE, int E, int W, bool LAZY>
 __global__ void __launch_bounds__(64)
 wfa_seg_kernel(const FastArgs a) {
+  static_assert(!LAZY || X >= 2, "the lazy extension needs a wavefront to be consumed two steps after it is made");
   static_assert(W == 8 || W == 16 || W == 32 || W == 64, "segment width");
   constexpr int DM = (X > OE) ? X : OE;
   constexpr int NS = 64 / W, H = W / 2, LW = (W == 64) ? 6 : (W == 32) ? 5 : (W == 16) ? 4 : 3;
   constexpr unsigned long long FIELD = (W == 64) ? ~0ull : ((1ull << (W & 63)) - 1ull);
   constexpr int SW = WFA_FAST_WORDS;
   constexpr int NEVER = 0x7fffffff;
-  __shared__ uint32_t lds[NS * 2 * SW + 4];  // per segment: pattern words, text words (32 + 2 zero pad words each)
+  __shared__ uint32_t lds[NS * 2 * SW + 4];  // per segment: pattern words, text words (32 + 2 each)
   __shared__ uint32_t fbuf[64];              // pairs handed on, appended to the global list 64 at a time
   const int lane = threadIdx.x;
   const int seg = lane >> LW;
   const int l = lane & (W - 1);
   const int k = l - H;
   const int pbias = seg * 2 * SW * 16, tbias = pbias + SW * 16;  // base coordinates of my segment's words
-  const bool low_half = lane < 32;
-  const int widx = low_half ? lane : SW - 32 + lane;  // staging: lanes 0..31 pattern words, 32..63 text words
   const int cur0 = (k == 0) ? 0 : WFA_OFFSET_NULL;
+  const int kb = pbias - k;  // pattern coordinate of offset x on my diagonal: x + kb
   const uint32_t nwork = __builtin_amdgcn_readfirstlane(a.nwork_dev ? *a.nwork_dev : a.nwork);  // keep everything derived from it scalar
   const uint32_t per = __builtin_amdgcn_readfirstlane((nwork + gridDim.x - 1) / gridDim.x);  // (the division runs on the VALU)
   const unsigned long long begin64 = (unsigned long long)blockIdx.x * per;
   if (begin64 >= nwork) return;
   const uint32_t begin = (uint32_t)begin64;
   const uint32_t end = (uint32_t)min((unsigned long long)nwork, begin64 + per);
-  if (lane < 4 * NS) lds[(lane >> 1) * SW + 32 + (lane & 1)] = 0u;  // the pad words stay zero for good
-  if (lane < 4) lds[NS * 2 * SW + lane] = 0u;
+  // (words past the end of a staged sequence may hold anything: a run is clamped to the bases that remain)
 
   // two windows of 64 pairs: lane i holds pair wbase + i (window 0) and wbase + 64 + i (window 1)
   uint32_t pid0, pid1;
@@ -82,30 +81,32 @@ wfa_seg_kernel(const FastArgs a) {
   uint32_t wbase = begin;
   load_window(wbase, pid0, m0);
   load_window(wbase + 64u, pid1, m1);
-  // lanes 0..31 fetch pattern word `lane`, lanes 32..63 text word `lane-32`, of slice pair i
-  auto fetch_word = [&](uint32_t i) -> uint32_t {
-    uint32_t w = 0;
+  // The text words of a pair follow its pattern words (csrc/wfa_hip.hip batch_build), so one load of up to 64
+  // consecutive words fetches both: lane j holds word j of the pair (pattern words first).
+  // (updates `pre` in place, lanes beyond the pair's words keep what they had: a zeroed temporary merged in
+  // afterwards costs a register copy that has to wait for the load just issued)
+  auto fetch_word = [&](uint32_t i, uint32_t& pre) {
     if (i < end) {
       const int r = (int)(i - wbase);
-      uint32_t pw, tw; int pl, tl;
+      uint32_t pw; int pl, tl;
       if (r < 64) {
-        pw = __builtin_amdgcn_readlane(m0.p_woff, r); tw = __builtin_amdgcn_readlane(m0.t_woff, r);
+        pw = __builtin_amdgcn_readlane(m0.p_woff, r);
         pl = __builtin_amdgcn_readlane(m0.plen, r); tl = __builtin_amdgcn_readlane(m0.tlen, r);
       } else {
-        pw = __builtin_amdgcn_readlane(m1.p_woff, r - 64); tw = __builtin_amdgcn_readlane(m1.t_woff, r - 64);
+        pw = __builtin_amdgcn_readlane(m1.p_woff, r - 64);
         pl = __builtin_amdgcn_readlane(m1.plen, r - 64); tl = __builtin_amdgcn_readlane(m1.tlen, r - 64);
       }
-      if (pl <= WFA_FAST_MAX_LEN && tl <= WFA_FAST_MAX_LEN) {
-        const int nwp = (pl + 15) >> 4, nwt = (tl + 15) >> 4;
-        const uint32_t woff = low_half ? pw : tw;
-        const int nw = low_half ? nwp : nwt;
-        if ((lane & 31) < nw) w = a.words[woff + (lane & 31)];
-      }
+      const int ntot = ((pl + 15) >> 4) + ((tl + 15) >> 4);
+      if (lane < ntot) pre = (a.words + pw)[lane];
     }
-    return w;
   };
   uint32_t next_i = begin;
-  uint32_t pre0 = fetch_word(begin), pre1 = fetch_word(begin + 1u);
+  // words of the next two pairs, prefetched; the two registers take turns (no rotation: a register copy right
+  // after the load would make the wave wait for the load it has just issued)
+  uint32_t pre0 = 0u, pre1 = 0u;
+  fetch_word(begin, pre0);
+  fetch_word(begin + 1u, pre1);
+  uint32_t par = 0u;
 
   uint32_t nfb = 0;
   auto fb_flush = [&]() {
@@ -132,6 +133,8 @@ wfa_seg_kernel(const FastArgs a) {
   uint32_t want = (1u << NS) - 1u;  // segments waiting for a pair
   uint32_t busy = 0;                // segments aligning
   int gstep = 0;
+  // LAZY: lanes whose newest cell (cur, wavefront s) / previous cell (Mh[0], wavefront s-1) still has bases to compare
+  unsigned long long mcur = 0ull, mold = 0ull;
 
   // Terminates: gstep grows every round, every aligning segment has a finite deadline, and a segment only
   // takes a new pair while next_i < end.
@@ -141,7 +144,7 @@ wfa_seg_kernel(const FastArgs a) {
       do {
         const int s = __builtin_ctz(want);
         want &= want - 1u;
-        while (next_i < end) {
+        if (next_i < end) {
           const uint32_t i = next_i++;
           if (i - wbase == 64u) {  // window 0 used up: window 1 moves down, the one after is requested
             pid0 = pid1; m0 = m1; wbase += 64u;
@@ -150,64 +153,96 @@ wfa_seg_kernel(const FastArgs a) {
           const int r = (int)(i - wbase);
           const int pl = __builtin_amdgcn_readlane(m0.plen, r), tl = __builtin_amdgcn_readlane(m0.tlen, r);
           const uint32_t pid = __builtin_amdgcn_readlane(pid0, r);
-          const int akk = tl - pl;
-          const uint32_t w = pre0;
-          pre0 = pre1; pre1 = fetch_word(i + 2u);
-          if (pl > WFA_FAST_MAX_LEN || tl > WFA_FAST_MAX_LEN || akk < -H || akk > H - 1) {
-            if (nfb == 64u) fb_flush();
-            if (lane == 0) fbuf[nfb] = pid;
-            ++nfb;
-            continue;
-          }
-          lds[s * 2 * SW + widx] = w;
+          // a pair this stage cannot take (too long, |tlen - plen| outside the band) is given an expired deadline:
+          // the hand-over path below passes it on at once
+          const bool bad = pl > WFA_FAST_MAX_LEN || tl > WFA_FAST_MAX_LEN || tl - pl < -H || tl - pl > H - 1;
+          const int akk = bad ? 0x7fff : tl - pl;
+          const int nwp = (pl + 15) >> 4, ntot = nwp + ((tl + 15) >> 4);
+          if (!bad && lane < ntot) lds[s * 2 * SW + lane + ((lane >= nwp) ? SW - nwp : 0)] = par ? pre1 : pre0;
+          // (the register is dead now: the words of the pair after next are loaded into it in place)
+          if (par == 0u) fetch_word(i + 2u, pre0); else fetch_word(i + 2u, pre1);
+          par ^= 1u;
           if (seg == s) {
             target = (k == akk) ? tl : NEVER;
             lim = min(tl, pl + k);
             spair = pid; s0 = gstep;
-            // Bmin / g in units of g: o / g = OE - E, e / g = E
-            deadline = gstep + min(2 * (OE - E) + E * (W - akk), 2 * (OE - E) + E * (W + 2 + akk));
-            cur = cur0;
+            // Bmin / g in units of g: o / g = OE - E, e / g = E (LAZY: wavefront s is judged one round later)
+            deadline = bad ? gstep - 1
+                           : gstep + min(2 * (OE - E) + E * (W - akk), 2 * (OE - E) + E * (W + 2 + akk)) + (LAZY ? 1 : 0);
+            cur = bad ? WFA_OFFSET_NULL : cur0;
 #pragma unroll
             for (int d = 0; d < DM; ++d) Mh[d] = WFA_OFFSET_NULL;
 #pragma unroll
             for (int d = 0; d < E; ++d) { Ih[d] = WFA_OFFSET_NULL; Dh[d] = WFA_OFFSET_NULL; }
           }
+          if (LAZY) {
+            const unsigned long long sm = FIELD << (s * W);
+            mold &= ~sm;
+            mcur = (mcur & ~sm) | (bad ? 0ull : (1ull << (s * W + H)));  // the cell (0, k = 0) is to be extended
+          }
           busy |= 1u << s;
-          break;
         }
       } while (want);
       __syncthreads();
       if (!busy) break;
     }
-    // ---------------- extend: 32 bases per round on every diagonal until no lane is still running ----------------
-    {
-      int left = (cur >= 0) ? lim - cur : 0;
-      if (__any(left > 0)) {
-        int h = max(cur, 0) + tbias, v = max(cur - k, 0) + pbias;
-        bool more;
+    // ---------------- extend ----------------
+    if (!LAZY) {
+      // 32 bases per round on every diagonal until no lane is still running
+        int left = (cur >= 0) ? lim - cur : 0;
+        if (__any(left > 0)) {
+          int h = max(cur, 0) + tbias, v = max(cur - k, 0) + pbias;
+          bool more;
+          do {
+            const int pi = v >> 4, ti = h >> 4;
+            const uint32_t p0 = lds[pi], p1 = lds[pi + 1], p2 = lds[pi + 2];
+            const uint32_t t0 = lds[ti], t1 = lds[ti + 1], t2 = lds[ti + 2];
+            const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h << 1);
+            const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t2, t1, (uint32_t)h << 1);
+            // first differing bit of xh:xl; v_ffbl_b32 returns ~0 for 0, so `| 32` is +32 or stays ~0, and the
+            // unsigned min >> 1 is the number of equal bases or >= 2^30 when all 32 are equal
+            const uint32_t fb = min(ffbl_u32(xl), ffbl_u32(xh) | 32u);
+            const int m = min((int)(fb >> 1), min(32, left));
+            v += m; h += m; left -= m;
+            more = (m == 32) && (left > 0);
+          } while (__any(more));
+          if (cur >= 0) cur = h - tbias;
+        }
+    } else {
+      // Wavefront s is first consumed when wavefront s + X is computed, so its extension may take two rounds of
+      // the wave: one now and one in the next step, where the lane continues its previous cell (Mh[0]) instead of
+      // starting its new one.  Only what is still running after that is waited for.  A long run of one segment
+      // so no longer holds up the other segments: the rounds per step drop from ~3.6 to ~1.4 on C2.
+      if (mold | mcur) {
         do {
+          const bool sel_old = __builtin_amdgcn_inverse_ballot_w64(mold);
+          const bool sel_new = __builtin_amdgcn_inverse_ballot_w64(mcur & ~mold);
+          int x = sel_old ? Mh[0] : (sel_new ? cur : H);  // (lanes without a job read in-range words and advance by 0)
+          int left = (sel_old || sel_new) ? lim - x : 0;
+          const int v = x + kb, h = x + tbias;
           const int pi = v >> 4, ti = h >> 4;
           const uint32_t p0 = lds[pi], p1 = lds[pi + 1], p2 = lds[pi + 2];
           const uint32_t t0 = lds[ti], t1 = lds[ti + 1], t2 = lds[ti + 2];
           const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h << 1);
           const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t2, t1, (uint32_t)h << 1);
-          // first differing bit of xh:xl; v_ffbl_b32 returns ~0 for 0, so `| 32` is +32 or stays ~0, and the
-          // unsigned min >> 1 is the number of equal bases or >= 2^30 when all 32 are equal
           const uint32_t fb = min(ffbl_u32(xl), ffbl_u32(xh) | 32u);
-          const int m = min((int)(fb >> 1), min(32, left));
-          v += m; h += m; left -= m;
-          more = (m == 32) && (left > 0);
-        } while (__any(more));
-        if (cur >= 0) cur = h - tbias;
+          const int m = min((int)(fb >> 1), min(32, left));  // left = 0: m = 0
+          x += m; left -= m;
+          const unsigned long long bm = __ballot((m == 32) && (left > 0));
+          if (sel_old) Mh[0] = x;
+          if (sel_new) cur = x;
+          mcur &= mold | bm;  // a lane that served its previous cell has not started the new one yet
+          mold &= bm;
+        } while (mold);
       }
     }
     // ---------------- termination / hand-over ----------------
     {
       const bool rej = gstep > deadline;  // segment-uniform
-      const bool fin = cur >= target;     // possible on the lane of the end diagonal only
+      const bool fin = (LAZY ? Mh[0] : cur) >= target;  // possible on the lane of the end diagonal only
       const unsigned long long bd = __ballot(fin || rej);
       if (bd) {
-        if (fin && !rej) { a.score[spair] = -((gstep - s0) * a.g); a.status[spair] = 0; }
+        if (fin && !rej) { a.score[spair] = -__mul24(gstep - s0 - (LAZY ? 1 : 0), a.g); a.status[spair] = 0; }
         const bool hand = rej && l == 0;
         const unsigned long long br = __ballot(hand);
         if (br) {
@@ -218,7 +253,10 @@ wfa_seg_kernel(const FastArgs a) {
         }
 #pragma unroll
         for (int s = 0; s < NS; ++s)
-          if ((bd >> (s * W)) & FIELD) { want |= 1u << s; busy &= ~(1u << s); }
+          if ((bd >> (s * W)) & FIELD) {
+            want |= 1u << s; busy &= ~(1u << s);
+            if (LAZY) { mcur &= ~(FIELD << (s * W)); mold &= ~(FIELD << (s * W)); }
+          }
         if (((bd >> (seg * W)) & FIELD) != 0ull) { target = NEVER; deadline = NEVER; lim = WFA_OFFSET_NULL; cur = WFA_OFFSET_NULL; }
         if (!busy && next_i >= end) break;
       }
@@ -238,6 +276,7 @@ wfa_seg_kernel(const FastArgs a) {
       for (int d = E - 1; d > 0; --d) { Ih[d] = Ih[d - 1]; Dh[d] = Dh[d - 1]; }
       Ih[0] = ni; Dh[0] = nd;
       cur = nm;
+      if (LAZY) { mold = mcur; mcur = __ballot(nm >= 0); }
     }
     ++gstep;
   }
@@ -258,10 +297,14 @@ inline int launch_seg(const WfaDevConfig& c, int cu_count, hipStream_t stream, c
   if (!nwork_dev && grid > (long long)nwork) grid = nwork;
   if (grid < 1) grid = 1;
   const dim3 g((unsigned)grid), blk(64);
-  if (variant == 3) hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 8>), g, blk, 0, stream, a);
-  else if (variant == 4) hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 32>), g, blk, 0, stream, a);
-  else if (variant == 5) hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 64>), g, blk, 0, stream, a);
-  else hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 16>), g, blk, 0, stream, a);
+  if (variant == 3) hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 8, false>), g, blk, 0, stream, a);
+  else if (variant == 4) hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 32, false>), g, blk, 0, stream, a);
+  else if (variant == 5) hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 64, false>), g, blk, 0, stream, a);
+  else if (variant == 6) hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 16, true>), g, blk, 0, stream, a);
+  else if (variant == 7) hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 8, true>), g, blk, 0, stream, a);
+  else if (variant == 8) hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 32, true>), g, blk, 0, stream, a);
+  else if (variant == 9) hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 64, true>), g, blk, 0, stream, a);
+  else hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 16, false>), g, blk, 0, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
