@@ -616,9 +616,10 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
 
     if (use_fast) {
       // register-kernel stages, each taking what the one before handed on (WFA_HIP_FAST_STAGES, one digit per
-      // stage): 3/2/4/5 = segments of 8/16/32/64 lanes, 1 = half-waves, 0 = one alignment per wave (both with edge detection)
+      // stage): 7/6/8/9 = segments of 8/16/32/64 lanes with the two-round (lazy) extension, 3/2/4/5 = the same widths
+      // extending every cell at once, 1 = half-waves, 0 = one alignment per wave (both with edge detection)
       const char* stages_env = getenv("WFA_HIP_FAST_STAGES");
-      const char* stages = (stages_env && *stages_env) ? stages_env : "245";
+      const char* stages = (stages_env && *stages_env) ? stages_env : "689";
       int variants[6] = {-1, -1, -1, -1, -1, -1};
       int nv = 0;
       for (const char* c = stages; *c && nv < 6; ++c) {

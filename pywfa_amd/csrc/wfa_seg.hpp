@@ -54,7 +54,10 @@ wfa_seg_kernel(const FastArgs a) {
   constexpr int SW = WFA_FAST_WORDS;
   constexpr int NEVER = 0x7fffffff;
   __shared__ uint32_t lds[NS * 2 * SW + 4];  // per segment: pattern words, text words (32 + 2 each)
+  __shared__ uint32_t ring[2][64];           // packed words of the next two pairs of the slice (direct-to-LDS loads)
   __shared__ uint32_t fbuf[64];              // pairs handed on, appended to the global list 64 at a time
+  __shared__ uint32_t rpid[64];              // pairs finished: id and score, stored 64 at a time
+  __shared__ int rscore[64];
   const int lane = threadIdx.x;
   const int seg = lane >> LW;
   const int l = lane & (W - 1);
@@ -70,7 +73,12 @@ wfa_seg_kernel(const FastArgs a) {
   const uint32_t end = (uint32_t)min((unsigned long long)nwork, begin64 + per);
   // (words past the end of a staged sequence may hold anything: a run is clamped to the bases that remain)
 
-  // two windows of 64 pairs: lane i holds pair wbase + i (window 0) and wbase + 64 + i (window 1)
+  // No wave may wait for a global access it has just issued: taking a pair touches registers and LDS only.
+  //  * metadata: two windows of 64 pairs in VGPRs (lane i holds pair wbase + i / wbase + 64 + i), read with
+  //    v_readlane; the next window is requested at the end of a step, once per 64 pairs;
+  //  * packed words: `global_load_lds_dword` straight into ring[], two pairs ahead (no VGPR, so no register
+  //    copy that would have to wait for the load);
+  //  * results: collected in LDS and stored 64 at a time.
   uint32_t pid0, pid1;
   WfaPairMeta m0, m1;
   auto load_window = [&](uint32_t wb, uint32_t& pid, WfaPairMeta& m) {
@@ -81,11 +89,9 @@ wfa_seg_kernel(const FastArgs a) {
   uint32_t wbase = begin;
   load_window(wbase, pid0, m0);
   load_window(wbase + 64u, pid1, m1);
-  // The text words of a pair follow its pattern words (csrc/wfa_hip.hip batch_build), so one load of up to 64
-  // consecutive words fetches both: lane j holds word j of the pair (pattern words first).
-  // (updates `pre` in place, lanes beyond the pair's words keep what they had: a zeroed temporary merged in
-  // afterwards costs a register copy that has to wait for the load just issued)
-  auto fetch_word = [&](uint32_t i, uint32_t& pre) {
+  // The text words of a pair follow its pattern words (csrc/wfa_hip.hip batch_build): one load of up to 64
+  // consecutive words fetches both, lane j -> word j of the pair -> ring[slot][j].
+  auto prefetch = [&](uint32_t i, uint32_t slot) {
     if (i < end) {
       const int r = (int)(i - wbase);
       uint32_t pw; int pl, tl;
@@ -97,16 +103,13 @@ wfa_seg_kernel(const FastArgs a) {
         pl = __builtin_amdgcn_readlane(m1.plen, r - 64); tl = __builtin_amdgcn_readlane(m1.tlen, r - 64);
       }
       const int ntot = ((pl + 15) >> 4) + ((tl + 15) >> 4);
-      if (lane < ntot) pre = (a.words + pw)[lane];
+      if (lane < ntot) __builtin_amdgcn_global_load_lds(a.words + pw + lane, &ring[slot][0], 4, 0, 0);
     }
   };
   uint32_t next_i = begin;
-  // words of the next two pairs, prefetched; the two registers take turns (no rotation: a register copy right
-  // after the load would make the wave wait for the load it has just issued)
-  uint32_t pre0 = 0u, pre1 = 0u;
-  fetch_word(begin, pre0);
-  fetch_word(begin + 1u, pre1);
-  uint32_t par = 0u;
+  prefetch(begin, 0u);
+  prefetch(begin + 1u, 1u);
+  uint32_t par = 0u;  // ring slot of pair next_i
 
   uint32_t nfb = 0;
   auto fb_flush = [&]() {
@@ -119,8 +122,16 @@ wfa_seg_kernel(const FastArgs a) {
     __syncthreads();
     nfb = 0u;
   };
+  uint32_t nres = 0;
+  auto res_flush = [&]() {
+    if (nres == 0u) return;
+    __syncthreads();
+    if ((uint32_t)lane < nres) { const uint32_t pid = rpid[lane]; a.score[pid] = rscore[lane]; a.status[pid] = 0; }
+    __syncthreads();
+    nres = 0u;
+  };
 
-  // per-lane state of my segment's alignment.  The wave counts steps once (gstep, scalar); a pair taken at
+  // per-lane state of my segment's alignment.  The wave counts steps once (gstep); a pair taken at
   // gstep = s0 is at its own step gstep - s0 and must end by `deadline` = s0 + Bmin / g.
   int target = NEVER;  // tlen on the lane of diagonal tlen - plen: reaching it ends the alignment
   int lim = WFA_OFFSET_NULL, cur = WFA_OFFSET_NULL, s0 = 0, deadline = NEVER;
@@ -140,27 +151,34 @@ wfa_seg_kernel(const FastArgs a) {
   // takes a new pair while next_i < end.
   while (true) {
     if (want) {
-      __syncthreads();
+      // (one wave per workgroup and the LDS serves a wave's instructions in order: no barrier is needed around the
+      // staging writes, and __syncthreads() would also wait for the global loads just issued)
       do {
         const int s = __builtin_ctz(want);
         want &= want - 1u;
         if (next_i < end) {
           const uint32_t i = next_i++;
-          if (i - wbase == 64u) {  // window 0 used up: window 1 moves down, the one after is requested
-            pid0 = pid1; m0 = m1; wbase += 64u;
-            load_window(wbase + 64u, pid1, m1);
-          }
           const int r = (int)(i - wbase);
-          const int pl = __builtin_amdgcn_readlane(m0.plen, r), tl = __builtin_amdgcn_readlane(m0.tlen, r);
-          const uint32_t pid = __builtin_amdgcn_readlane(pid0, r);
+          int pl, tl; uint32_t pid;
+          if (r < 64) {
+            pl = __builtin_amdgcn_readlane(m0.plen, r); tl = __builtin_amdgcn_readlane(m0.tlen, r);
+            pid = __builtin_amdgcn_readlane(pid0, r);
+          } else {
+            pl = __builtin_amdgcn_readlane(m1.plen, r - 64); tl = __builtin_amdgcn_readlane(m1.tlen, r - 64);
+            pid = __builtin_amdgcn_readlane(pid1, r - 64);
+          }
           // a pair this stage cannot take (too long, |tlen - plen| outside the band) is given an expired deadline:
           // the hand-over path below passes it on at once
           const bool bad = pl > WFA_FAST_MAX_LEN || tl > WFA_FAST_MAX_LEN || tl - pl < -H || tl - pl > H - 1;
           const int akk = bad ? 0x7fff : tl - pl;
           const int nwp = (pl + 15) >> 4, ntot = nwp + ((tl + 15) >> 4);
-          if (!bad && lane < ntot) lds[s * 2 * SW + lane + ((lane >= nwp) ? SW - nwp : 0)] = par ? pre1 : pre0;
-          // (the register is dead now: the words of the pair after next are loaded into it in place)
-          if (par == 0u) fetch_word(i + 2u, pre0); else fetch_word(i + 2u, pre1);
+          // loads complete in order: only the load of pair i + 1 (the other slot), if there is one, may still be in flight
+          if (i + 1u < end) __builtin_amdgcn_s_waitcnt(0xF71);  // vmcnt(1)
+          else __builtin_amdgcn_s_waitcnt(0xF70);               // vmcnt(0)
+          uint32_t w = ring[par][lane];
+          asm volatile("" : "+v"(w));  // the slot has been read before it is refilled below
+          if (!bad && lane < ntot) lds[s * 2 * SW + lane + ((lane >= nwp) ? SW - nwp : 0)] = w;
+          prefetch(i + 2u, par);
           par ^= 1u;
           if (seg == s) {
             target = (k == akk) ? tl : NEVER;
@@ -183,36 +201,35 @@ wfa_seg_kernel(const FastArgs a) {
           busy |= 1u << s;
         }
       } while (want);
-      __syncthreads();
       if (!busy) break;
     }
     // ---------------- extend ----------------
     if (!LAZY) {
       // 32 bases per round on every diagonal until no lane is still running
-        int left = (cur >= 0) ? lim - cur : 0;
-        if (__any(left > 0)) {
-          int h = max(cur, 0) + tbias, v = max(cur - k, 0) + pbias;
-          bool more;
-          do {
-            const int pi = v >> 4, ti = h >> 4;
-            const uint32_t p0 = lds[pi], p1 = lds[pi + 1], p2 = lds[pi + 2];
-            const uint32_t t0 = lds[ti], t1 = lds[ti + 1], t2 = lds[ti + 2];
-            const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h << 1);
-            const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t2, t1, (uint32_t)h << 1);
-            // first differing bit of xh:xl; v_ffbl_b32 returns ~0 for 0, so `| 32` is +32 or stays ~0, and the
-            // unsigned min >> 1 is the number of equal bases or >= 2^30 when all 32 are equal
-            const uint32_t fb = min(ffbl_u32(xl), ffbl_u32(xh) | 32u);
-            const int m = min((int)(fb >> 1), min(32, left));
-            v += m; h += m; left -= m;
-            more = (m == 32) && (left > 0);
-          } while (__any(more));
-          if (cur >= 0) cur = h - tbias;
-        }
+      int left = (cur >= 0) ? lim - cur : 0;
+      if (__any(left > 0)) {
+        int h = max(cur, 0) + tbias, v = max(cur - k, 0) + pbias;
+        bool more;
+        do {
+          const int pi = v >> 4, ti = h >> 4;
+          const uint32_t p0 = lds[pi], p1 = lds[pi + 1], p2 = lds[pi + 2];
+          const uint32_t t0 = lds[ti], t1 = lds[ti + 1], t2 = lds[ti + 2];
+          const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h << 1);
+          const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t2, t1, (uint32_t)h << 1);
+          // first differing bit of xh:xl; v_ffbl_b32 returns ~0 for 0, so `| 32` is +32 or stays ~0, and the
+          // unsigned min >> 1 is the number of equal bases or >= 2^30 when all 32 are equal
+          const uint32_t fb = min(ffbl_u32(xl), ffbl_u32(xh) | 32u);
+          const int m = min((int)(fb >> 1), min(32, left));
+          v += m; h += m; left -= m;
+          more = (m == 32) && (left > 0);
+        } while (__any(more));
+        if (cur >= 0) cur = h - tbias;
+      }
     } else {
       // Wavefront s is first consumed when wavefront s + X is computed, so its extension may take two rounds of
       // the wave: one now and one in the next step, where the lane continues its previous cell (Mh[0]) instead of
-      // starting its new one.  Only what is still running after that is waited for.  A long run of one segment
-      // so no longer holds up the other segments: the rounds per step drop from ~3.6 to ~1.4 on C2.
+      // starting its new one.  Only what is still running after that is waited for, so a long run of one
+      // segment seldom holds up the other segments.
       if (mold | mcur) {
         do {
           const bool sel_old = __builtin_amdgcn_inverse_ballot_w64(mold);
@@ -242,13 +259,23 @@ wfa_seg_kernel(const FastArgs a) {
       const bool fin = (LAZY ? Mh[0] : cur) >= target;  // possible on the lane of the end diagonal only
       const unsigned long long bd = __ballot(fin || rej);
       if (bd) {
-        if (fin && !rej) { a.score[spair] = -__mul24(gstep - s0 - (LAZY ? 1 : 0), a.g); a.status[spair] = 0; }
+        const bool acc = fin && !rej;
+        const unsigned long long ba = __ballot(acc);
+        if (ba) {
+          const uint32_t na = (uint32_t)__builtin_popcountll(ba);
+          if (nres + na > 64u) res_flush();
+          if (acc) {
+            const uint32_t pos = nres + __builtin_amdgcn_mbcnt_hi((uint32_t)(ba >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ba, 0u));
+            rpid[pos] = spair; rscore[pos] = -__mul24(gstep - s0 - (LAZY ? 1 : 0), a.g);
+          }
+          nres += na;
+        }
         const bool hand = rej && l == 0;
         const unsigned long long br = __ballot(hand);
         if (br) {
           const uint32_t nr = (uint32_t)__builtin_popcountll(br);
           if (nfb + nr > 64u) fb_flush();
-          if (hand) fbuf[nfb + (uint32_t)__builtin_popcountll(br & ((1ull << lane) - 1ull))] = spair;
+          if (hand) fbuf[nfb + __builtin_amdgcn_mbcnt_hi((uint32_t)(br >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)br, 0u))] = spair;
           nfb += nr;
         }
 #pragma unroll
@@ -279,7 +306,13 @@ wfa_seg_kernel(const FastArgs a) {
       if (LAZY) { mold = mcur; mcur = __ballot(nm >= 0); }
     }
     ++gstep;
+    // window 0 used up: window 1 moves down and the one after is requested (its use is >= 50 pairs away)
+    if (next_i - wbase >= 64u) {
+      pid0 = pid1; m0 = m1; wbase += 64u;
+      load_window(wbase + 64u, pid1, m1);
+    }
   }
+  res_flush();
   fb_flush();
 }
 
@@ -292,8 +325,11 @@ inline int launch_seg(const WfaDevConfig& c, int cu_count, hipStream_t stream, c
   a.score = score; a.status = status; a.fb_list = fb_list; a.fb_count = fb_count;
   a.g = gcd_int(gcd_int(c.x, c.o1 + c.e1), c.e1);
   const char* env = getenv("WFA_HIP_FAST_WAVES_PER_CU");
-  const int per_cu = (env && *env) ? atoi(env) : 32;
-  long long grid = (long long)cu_count * per_cu;  // one slice of the work list per wave
+  // One slice of the work list per wave, 8 times more slices than the 32 waves a CU holds: the SIMD issues
+  // oldest-first, so resident waves finish one after the other and a lone last wave cannot fill the VALU;
+  // with short slices the dispatcher refills the CU as waves retire (C2: 5.10 -> 4.42 ms).
+  const int per_cu = (env && *env) ? atoi(env) : 256;
+  long long grid = (long long)cu_count * per_cu;
   if (!nwork_dev && grid > (long long)nwork) grid = nwork;
   if (grid < 1) grid = 1;
   const dim3 g((unsigned)grid), blk(64);
