@@ -589,7 +589,9 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     long long band_grid[3] = {0, 0, 0};
     int64_t band_stride[3] = {0, 0, 0};
     for (int i = 0; i < n_stages; ++i) {
-      long long grid = (long long)al->cu_count * env_int("WFA_HIP_BAND_WAVES_PER_CU", 32);
+      // 4x more waves than a CU holds at once: waves retire one after the other (oldest-first issue) and the
+      // dispatcher refills the CU, instead of a tail of lone waves (C1 +20 %, C3 +13 %)
+      long long grid = (long long)al->cu_count * env_int("WFA_HIP_BAND_WAVES_PER_CU", 128);
       grid = std::min<long long>(grid, in_n);
       if (i > 0 || use_fast) grid = std::min<long long>(grid, (long long)al->cu_count * 16);
       if (full) {
@@ -681,7 +683,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         const int64_t slot_bytes = band_stride[i] * 4 + (int64_t)sizeof(int4);
         int64_t per_launch = (int64_t)(al->ws_bytes / (size_t)slot_bytes);
         per_launch = std::min<int64_t>(per_launch, in_n);
-        const int64_t full_grid = (int64_t)al->cu_count * env_int("WFA_HIP_BAND_WAVES_PER_CU", 32);
+        const int64_t full_grid = (int64_t)al->cu_count * env_int("WFA_HIP_BAND_WAVES_PER_CU", 128);
         if (per_launch > full_grid) per_launch = (per_launch / full_grid) * full_grid;  // whole rounds of waves
         if (per_launch < 1) { al->err = "band history does not fit"; return WFA_HIP_EDEVICE; }
         ba.split = 1;
@@ -689,7 +691,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         for (int64_t w0 = 0; w0 < in_n; w0 += per_launch) {
           const uint32_t cnt = (uint32_t)std::min<int64_t>(per_launch, in_n - w0);
           ba.work_begin = (uint32_t)w0; ba.nwork = cnt;
-          const long long grid = std::min<long long>((long long)al->cu_count * env_int("WFA_HIP_BAND_WAVES_PER_CU", 32), cnt);
+          const long long grid = std::min<long long>((long long)al->cu_count * env_int("WFA_HIP_BAND_WAVES_PER_CU", 128), cnt);
           if (wfa::launch_band(ba, band_nch[i], full, adapt, seqlds, grid, stream) != 0) { al->err = "band kernel launch failed"; return WFA_HIP_EDEVICE; }
           if (wfa::launch_band_bt(ba, band_nch[i], stream) != 0) { al->err = "band backtrace launch failed"; return WFA_HIP_EDEVICE; }
         }

@@ -5,13 +5,14 @@
 // are live, and the one-alignment-per-wave kernel of wfa_fast.hpp already runs at the VALU issue limit
 // (rocprofv3 SQ_INSTS_VALU x 4 cycles = kernel time).  At a few percent divergence a wavefront is a dozen
 // diagonals wide, so lanes are the resource to share: the wave is cut into 64/W segments of W lanes
-// (W = 8, 16, 32 or 64), each aligning its own pair inside a band of W diagonals, k in [-W/2, W/2).
+// (W = 8, 16, 32 or 64), each aligning its own pair inside a band of W diagonals, k in [c - W/2, c + W/2),
+// centred between diagonal 0 and diagonal ak = tlen - plen: c = ceil(ak / 2).
 //
 // Exactness.  Cells outside the band are dropped, so the score found, S', is that of the best alignment
 // staying inside the band (S' >= S, the reference's score).  It is accepted only when proven optimal: an
-// end-to-end alignment that leaves the band has to climb from diagonal 0 to +W/2 (or down to -W/2-1) and
-// come back to ak = tlen - plen, which costs at least
-//     Bmin = min(2o + e(W - ak), 2o + e(W + 2 + ak)),
+// end-to-end alignment that leaves the band has to climb from diagonal 0 to c + W/2 (or down to c - W/2 - 1)
+// and come back to ak, which costs at least
+//     Bmin = min(2o + e(2c + W - ak), 2o + e(W + 2 - 2c + ak))      (= 2o + eW or more for every |ak| < W),
 // hence S' <= Bmin implies S' = S (score scope: a tie is the same score).  A pair that reaches Bmin without
 // finishing is handed to the next stage (a wider segment, finally the banded / general kernels).
 // In-bounds cells never descend from out-of-bounds ones (an I or D move keeps offset - lim), so for the
@@ -61,10 +62,10 @@ wfa_seg_kernel(const FastArgs a) {
   const int lane = threadIdx.x;
   const int seg = lane >> LW;
   const int l = lane & (W - 1);
-  const int k = l - H;
   const int pbias = seg * 2 * SW * 16, tbias = pbias + SW * 16;  // base coordinates of my segment's words
-  const int cur0 = (k == 0) ? 0 : WFA_OFFSET_NULL;
-  const int kb = pbias - k;  // pattern coordinate of offset x on my diagonal: x + kb
+  // my diagonal is k = l - H + c, c the centre of the pair's band (set when a pair is taken);
+  // kb = pbias - k: pattern coordinate of offset x on my diagonal is x + kb
+  int kb = pbias - (l - H);
   const uint32_t nwork = __builtin_amdgcn_readfirstlane(a.nwork_dev ? *a.nwork_dev : a.nwork);  // keep everything derived from it scalar
   const uint32_t per = __builtin_amdgcn_readfirstlane((nwork + gridDim.x - 1) / gridDim.x);  // (the division runs on the VALU)
   const unsigned long long begin64 = (unsigned long long)blockIdx.x * per;
@@ -169,8 +170,10 @@ wfa_seg_kernel(const FastArgs a) {
           }
           // a pair this stage cannot take (too long, |tlen - plen| outside the band) is given an expired deadline:
           // the hand-over path below passes it on at once
-          const bool bad = pl > WFA_FAST_MAX_LEN || tl > WFA_FAST_MAX_LEN || tl - pl < -H || tl - pl > H - 1;
+          // The band is centred between diagonal 0 and diagonal ak = tlen - plen: c = ceil(ak / 2), k in [c - H, c + H).
+          const bool bad = pl > WFA_FAST_MAX_LEN || tl > WFA_FAST_MAX_LEN || tl - pl < 1 - 2 * H || tl - pl > 2 * H - 1;
           const int akk = bad ? 0x7fff : tl - pl;
+          const int c = bad ? 0 : ((tl - pl + 1) >> 1);
           const int nwp = (pl + 15) >> 4, ntot = nwp + ((tl + 15) >> 4);
           // loads complete in order: only the load of pair i + 1 (the other slot), if there is one, may still be in flight
           if (i + 1u < end) __builtin_amdgcn_s_waitcnt(0xF71);  // vmcnt(1)
@@ -181,13 +184,17 @@ wfa_seg_kernel(const FastArgs a) {
           prefetch(i + 2u, par);
           par ^= 1u;
           if (seg == s) {
+            const int k = l - H + c;
+            kb = pbias - k;
             target = (k == akk) ? tl : NEVER;
             lim = min(tl, pl + k);
             spair = pid; s0 = gstep;
-            // Bmin / g in units of g: o / g = OE - E, e / g = E (LAZY: wavefront s is judged one round later)
+            // Bmin / g in units of g (o / g = OE - E, e / g = E): leaving the band upwards costs a climb from 0 to
+            // c + H and the way back to ak, downwards from 0 to c - H - 1 and back (LAZY: wavefront s is judged one
+            // round later)
             deadline = bad ? gstep - 1
-                           : gstep + min(2 * (OE - E) + E * (W - akk), 2 * (OE - E) + E * (W + 2 + akk)) + (LAZY ? 1 : 0);
-            cur = bad ? WFA_OFFSET_NULL : cur0;
+                           : gstep + min(2 * (OE - E) + E * (2 * c + 2 * H - akk), 2 * (OE - E) + E * (2 * H + 2 - 2 * c + akk)) + (LAZY ? 1 : 0);
+            cur = (bad || k != 0) ? WFA_OFFSET_NULL : 0;
 #pragma unroll
             for (int d = 0; d < DM; ++d) Mh[d] = WFA_OFFSET_NULL;
 #pragma unroll
@@ -196,7 +203,7 @@ wfa_seg_kernel(const FastArgs a) {
           if (LAZY) {
             const unsigned long long sm = FIELD << (s * W);
             mold &= ~sm;
-            mcur = (mcur & ~sm) | (bad ? 0ull : (1ull << (s * W + H)));  // the cell (0, k = 0) is to be extended
+            mcur = (mcur & ~sm) | (bad ? 0ull : (1ull << (s * W + H - c)));  // the cell (0, k = 0) is to be extended
           }
           busy |= 1u << s;
         }
@@ -208,7 +215,7 @@ wfa_seg_kernel(const FastArgs a) {
       // 32 bases per round on every diagonal until no lane is still running
       int left = (cur >= 0) ? lim - cur : 0;
       if (__any(left > 0)) {
-        int h = max(cur, 0) + tbias, v = max(cur - k, 0) + pbias;
+        int h = max(cur, 0) + tbias, v = max(cur + kb, pbias);
         bool more;
         do {
           const int pi = v >> 4, ti = h >> 4;
@@ -234,7 +241,7 @@ wfa_seg_kernel(const FastArgs a) {
         do {
           const bool sel_old = __builtin_amdgcn_inverse_ballot_w64(mold);
           const bool sel_new = __builtin_amdgcn_inverse_ballot_w64(mcur & ~mold);
-          int x = sel_old ? Mh[0] : (sel_new ? cur : H);  // (lanes without a job read in-range words and advance by 0)
+          int x = sel_old ? Mh[0] : (sel_new ? cur : W);  // (lanes without a job read in-range words and advance by 0)
           int left = (sel_old || sel_new) ? lim - x : 0;
           const int v = x + kb, h = x + tbias;
           const int pi = v >> 4, ti = h >> 4;

@@ -32,7 +32,10 @@ def run(label, n, L, e, seed, kw, cpu_n=None, reps=2, check=True):
     rec = dict(label=label, n=n, L=L, e=e, kernel_ms=ms, wall_ms=wall*1e3, aln_per_s=n/wall, cpu_aln_per_s=cpu_n/t_cpu,
                speedup_vs_1thread=(n/wall)/(cpu_n/t_cpu), mismatches=bad, fallback=fb, mean_score=float(score.mean()),
                nonzero_status=int((status != 0).sum()), upload_s=t_up, cfg=kw)
-    print(json.dumps(rec), flush=True)
+    if os.environ.get("BRIEF"):
+        print(f"{label:42s} kernel_ms={ms:9.3f} aln/s={n / wall:.4g} mism={bad} handed_to_general={fb}", flush=True)
+    else:
+        print(json.dumps(rec), flush=True)
     return rec
 
 which = sys.argv[1:] or ["C1", "C3", "C3s", "C4a", "C5", "E5", "E10"]
