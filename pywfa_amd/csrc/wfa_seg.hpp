@@ -252,7 +252,7 @@ wfa_seg_kernel(const FastArgs a) {
           const uint32_t fb = min(ffbl_u32(xl), ffbl_u32(xh) | 32u);
           const int m = min((int)(fb >> 1), min(32, left));  // left = 0: m = 0
           x += m; left -= m;
-          const unsigned long long bm = __ballot((m == 32) && (left > 0));
+          const unsigned long long bm = __ballot(m == 32) & __ballot(left > 0);  // (two compares and an s_and: a combined bool goes through a VGPR)
           if (sel_old) Mh[0] = x;
           if (sel_new) cur = x;
           mcur &= mold | bm;  // a lane that served its previous cell has not started the new one yet
@@ -264,10 +264,11 @@ wfa_seg_kernel(const FastArgs a) {
     {
       const bool rej = gstep > deadline;  // segment-uniform
       const bool fin = (LAZY ? Mh[0] : cur) >= target;  // possible on the lane of the end diagonal only
-      const unsigned long long bd = __ballot(fin || rej);
+      const unsigned long long bfin = __ballot(fin), brej = __ballot(rej);
+      const unsigned long long bd = bfin | brej;
       if (bd) {
-        const bool acc = fin && !rej;
-        const unsigned long long ba = __ballot(acc);
+        const unsigned long long ba = bfin & ~brej;
+        const bool acc = __builtin_amdgcn_inverse_ballot_w64(ba);
         if (ba) {
           const uint32_t na = (uint32_t)__builtin_popcountll(ba);
           if (nres + na > 64u) res_flush();
