@@ -567,8 +567,9 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     // the general kernel's geometry is fixed first so that one workspace allocation serves every stage
     int n_stages = 0;
     int band_nch[3] = {0, 0, 0};
-    const bool use_fast = !full && wfa::fast_supported(al->dcfg, al->ncomp, full) && b->max_len <= WFA_FAST_MAX_LEN &&
+    const bool use_fast = !full && wfa::seg_supported(al->dcfg, al->ncomp, full) && b->max_len <= WFA_FAST_MAX_LEN &&
                           env_int("WFA_HIP_NO_FAST", 0) == 0;
+    const bool legacy_ok = wfa::fast_supported(al->dcfg, al->ncomp, full);  // the one/two-per-wave kernels: 4/6/2-shaped only
     if (wfa::band_supported(al->dcfg, al->ncomp) && env_int("WFA_HIP_NO_BAND", 0) == 0) {
       if (adapt) {
         if (b->max_len <= 300) { band_nch[n_stages++] = 1; }
@@ -628,9 +629,10 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         const int v = *c - '0';
         if (v < 0 || v > 9) continue;
         if (v == 1 && b->max_len > WFA_FAST2_MAX_LEN) continue;
+        if (v <= 1 && !legacy_ok) continue;
         variants[nv++] = v;
       }
-      if (nv == 0) variants[nv++] = 0;
+      if (nv == 0) variants[nv++] = 6;
       for (int pass = 0; pass < nv; ++pass) {
         uint32_t* out_list = b->d_fb_list2[out_sel];
         uint32_t* out_count = b->d_counters + 4 + out_sel;

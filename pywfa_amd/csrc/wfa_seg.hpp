@@ -324,7 +324,49 @@ wfa_seg_kernel(const FastArgs a) {
   fb_flush();
 }
 
-// variant 2/3/4/5 = segments of 16/8/32/64 lanes (4/8/2/1 alignments per wave)
+// Penalty shapes (x, o + e, e) / gcd with an instantiation of the segmented kernel.  The first is pywfa's default
+// 4/6/2 (also 2/3/1, 8/12/4, ...); the others are the usual short-read / long-read presets: 4/4/2, 4/6/1, 3/4/1,
+// 6/5/3, 5/0/3 and unit costs 1/1/1.
+#define WFA_SEG_SHAPES(F) F(2, 4, 1) F(2, 3, 1) F(4, 7, 1) F(3, 5, 1) F(6, 8, 3) F(5, 3, 3) F(1, 2, 1)
+
+inline bool seg_shape(const WfaDevConfig& c, int* X, int* OE, int* E) {
+  const int g = gcd_int(gcd_int(c.x, c.o1 + c.e1), c.e1);
+  *X = c.x / g; *OE = (c.o1 + c.e1) / g; *E = c.e1 / g;
+#define WFA_SEG_MATCH(x, oe, e) if (*X == x && *OE == oe && *E == e) return true;
+  WFA_SEG_SHAPES(WFA_SEG_MATCH)
+#undef WFA_SEG_MATCH
+  return false;
+}
+
+// which configurations the segmented kernels cover (score only, gap-affine, end-to-end or ends-free without free ends)
+inline bool seg_supported(const WfaDevConfig& c, int ncomp, bool full) {
+  if (full || ncomp != 3 || c.match != 0 || c.heuristic != 0 || c.wildcard >= 0) return false;
+  if (c.endsfree && (c.pbf | c.pef | c.tbf | c.tef)) return false;
+  if (c.max_steps != INT_MAX) return false;
+  int X, OE, E;
+  return seg_shape(c, &X, &OE, &E);
+}
+
+template <int X, int OE, int E>
+inline void launch_seg_shape(int w, bool lazy, dim3 g, hipStream_t stream, const FastArgs& a) {
+  const dim3 blk(64);
+  if constexpr (X >= 2) {
+    if (lazy) {
+      if (w == 8) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 8, true>), g, blk, 0, stream, a);
+      else if (w == 32) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 32, true>), g, blk, 0, stream, a);
+      else if (w == 64) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 64, true>), g, blk, 0, stream, a);
+      else hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 16, true>), g, blk, 0, stream, a);
+      return;
+    }
+  }
+  if (w == 8) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 8, false>), g, blk, 0, stream, a);
+  else if (w == 32) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 32, false>), g, blk, 0, stream, a);
+  else if (w == 64) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 64, false>), g, blk, 0, stream, a);
+  else hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 16, false>), g, blk, 0, stream, a);
+}
+
+// variant 6/7/8/9 = segments of 16/8/32/64 lanes (4/8/2/1 alignments per wave) with the two-round extension,
+// 2/3/4/5 = the same widths extending every cell at once (the only form when x / g = 1)
 inline int launch_seg(const WfaDevConfig& c, int cu_count, hipStream_t stream, const uint32_t* words,
                       const WfaPairMeta* meta, const uint32_t* worklist, const uint32_t* nwork_dev, uint32_t nwork,
                       int32_t* score, int32_t* status, uint32_t* fb_list, uint32_t* fb_count, int variant) {
@@ -332,6 +374,8 @@ inline int launch_seg(const WfaDevConfig& c, int cu_count, hipStream_t stream, c
   a.words = words; a.meta = meta; a.worklist = worklist; a.nwork_dev = nwork_dev; a.nwork = nwork;
   a.score = score; a.status = status; a.fb_list = fb_list; a.fb_count = fb_count;
   a.g = gcd_int(gcd_int(c.x, c.o1 + c.e1), c.e1);
+  int X, OE, E;
+  if (!seg_shape(c, &X, &OE, &E)) return -1;
   const char* env = getenv("WFA_HIP_FAST_WAVES_PER_CU");
   // One slice of the work list per wave, 8 times more slices than the 32 waves a CU holds: the SIMD issues
   // oldest-first, so resident waves finish one after the other and a lone last wave cannot fill the VALU;
@@ -340,15 +384,11 @@ inline int launch_seg(const WfaDevConfig& c, int cu_count, hipStream_t stream, c
   long long grid = (long long)cu_count * per_cu;
   if (!nwork_dev && grid > (long long)nwork) grid = nwork;
   if (grid < 1) grid = 1;
-  const dim3 g((unsigned)grid), blk(64);
-  if (variant == 3) hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 8, false>), g, blk, 0, stream, a);
-  else if (variant == 4) hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 32, false>), g, blk, 0, stream, a);
-  else if (variant == 5) hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 64, false>), g, blk, 0, stream, a);
-  else if (variant == 6) hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 16, true>), g, blk, 0, stream, a);
-  else if (variant == 7) hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 8, true>), g, blk, 0, stream, a);
-  else if (variant == 8) hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 32, true>), g, blk, 0, stream, a);
-  else if (variant == 9) hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 64, true>), g, blk, 0, stream, a);
-  else hipLaunchKernelGGL((wfa_seg_kernel<2, 4, 1, 16, false>), g, blk, 0, stream, a);
+  const bool lazy = variant >= 6;
+  const int w = (variant == 3 || variant == 7) ? 8 : (variant == 4 || variant == 8) ? 32 : (variant == 5 || variant == 9) ? 64 : 16;
+#define WFA_SEG_LAUNCH(x, oe, e) if (X == x && OE == oe && E == e) launch_seg_shape<x, oe, e>(w, lazy, dim3((unsigned)grid), stream, a);
+  WFA_SEG_SHAPES(WFA_SEG_LAUNCH)
+#undef WFA_SEG_LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -201,3 +201,17 @@ def test_segmented_stages_accept_only_proven_scores(gpu, stages, monkeypatch):
     o = loader.run(loader.oracle(), oc, small, want_cigar=False)
     score, status, _ = common.gpu_run(nc, shuf, False, False)
     assert np.array_equal(score, o["score"][perm]) and np.array_equal(status, o["status"][perm])
+
+
+@pytest.mark.parametrize("pen", [(4, 4, 2), (4, 6, 1), (3, 4, 1), (6, 5, 3), (5, 0, 3), (1, 1, 1), (8, 12, 4), (2, 3, 1), (7, 11, 3)])
+def test_segmented_kernel_penalty_shapes(gpu, pen):
+    """Score-only end-to-end batches under the penalty shapes the segmented kernel is instantiated for (and one it is
+    not: 7/11/3 runs in the general kernel) against the oracle, short and long slices, low and high divergence."""
+    x, o, e = pen
+    oc, nc = common.configs_pair(span="end-to-end", scope="score", mismatch=x, gap_opening=o, gap_extension=e)
+    for i, (n, L, err) in enumerate([(6000, 150, 0.02), (3000, 150, 0.08), (1500, 150, 0.2), (1500, 480, 0.03), (800, 40, 0.1)]):
+        batch = datagen.generate(n, L, err, 7000 + i)
+        o_ = loader.run(loader.oracle(), oc, batch, want_cigar=False)
+        score, status, _ = common.gpu_run(nc, batch, False, i % 2 == 0)
+        assert np.array_equal(status, o_["status"]), (pen, L, err)
+        assert np.array_equal(score, o_["score"]), (pen, L, err)
