@@ -387,10 +387,14 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
     HIP_TRY(al, hipMemcpyAsync(b->d_tboff, t_off, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, al->stream));
     HIP_TRY(al, hipMemcpyAsync(b->d_meta, meta.get(), (size_t)n * sizeof(WfaPairMeta), hipMemcpyHostToDevice, al->stream));
     const int threads = 256;
-    const int64_t want = (n + 3) / 4;  // 4 waves (pairs) per workgroup
-    const int grid = (int)std::min<int64_t>(want, (int64_t)al->cu_count * 16);
+    // lanes per pair: the words of the longest pair, rounded up to a power of two (at most a whole wave)
+    int log2slots = 1;
+    while (log2slots < 6 && (1 << log2slots) < 2 * ((b->max_len + 15) >> 4)) ++log2slots;
+    const int64_t group = 64 >> log2slots;
+    const int64_t want = ((n + group - 1) / group + 3) / 4;  // 4 waves per workgroup
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)al->cu_count * 64));
     hipLaunchKernelGGL(wfa::wfa_pack_kernel, dim3(grid), dim3(threads), 0, al->stream,
-                       b->d_bytes, b->d_pboff, b->d_tboff, b->d_meta, n, b->d_words, b->d_flags);
+                       b->d_bytes, b->d_pboff, b->d_tboff, b->d_meta, n, b->d_words, b->d_flags, log2slots);
     HIP_TRY(al, hipGetLastError());
     std::vector<uint8_t> flags((size_t)n);
     HIP_TRY(al, hipMemcpyAsync(flags.data(), b->d_flags, (size_t)n, hipMemcpyDeviceToHost, al->stream));

@@ -12,38 +12,53 @@ namespace wfa {
 // code = (c >> 1) & 3 : 'A'(0x41)->0  'C'(0x43)->1  'T'(0x54)->2  'G'(0x47)->3
 __device__ __forceinline__ bool is_acgt(uint32_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
 
-// One wave per pair (grid-stride); lane j packs word j (16 bases) of the pattern, then of the text.
+// A wave packs 64 >> log2slots pairs per round: lane -> (pair = lane >> log2slots, word = lane & (slots - 1)),
+// the words of a pair counted through pattern then text (they are contiguous in `words`).  A lane reads its 16
+// bases as five aligned dwords + v_alignbyte, packs four bases per dword with shifts / ors, and checks them
+// against the alphabet with one v_perm_b32 (the 2-bit codes select the expected letter from 'G''T''C''A').
 __global__ void __launch_bounds__(256)
 wfa_pack_kernel(const uint8_t* __restrict__ bytes, const int64_t* __restrict__ p_boff,
                 const int64_t* __restrict__ t_boff, const WfaPairMeta* __restrict__ meta, int64_t n,
-                uint32_t* __restrict__ words, uint8_t* __restrict__ flags) {
+                uint32_t* __restrict__ words, uint8_t* __restrict__ flags, int log2slots) {
   const int lane = threadIdx.x & 63;
+  const int slots = 1 << log2slots, group = 64 >> log2slots;
+  const int sub = lane >> log2slots, wl = lane & (slots - 1);
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t pair = wave; pair < n; pair += nwaves) {
-    const WfaPairMeta pm = meta[pair];
+  for (int64_t p0 = wave * group; p0 < n; p0 += nwaves * group) {
+    const int64_t pair = p0 + sub;
     bool bad = false;
+    if (pair < n) {
+      const WfaPairMeta pm = meta[pair];
+      const int nwp = (pm.plen + 15) >> 4, ntot = nwp + ((pm.tlen + 15) >> 4);
+      const int64_t pb = p_boff[pair], tb = t_boff[pair];
+      for (int w = wl; w < ntot; w += slots) {
+        const bool is_text = w >= nwp;
+        const int ws = is_text ? w - nwp : w;
+        const int nvalid = min(16, (is_text ? pm.tlen : pm.plen) - ws * 16);
+        const uintptr_t addr = (uintptr_t)(bytes + (is_text ? tb : pb) + (int64_t)ws * 16);
+        const uint32_t* a0 = (const uint32_t*)(addr & ~(uintptr_t)3);  // (the blob allocation is padded by 64 bytes)
+        const uint32_t sh = (uint32_t)(addr & 3);
+        uint32_t d[5];
 #pragma unroll
-    for (int which = 0; which < 2; ++which) {
-      const uint8_t* src = bytes + (which ? t_boff[pair] : p_boff[pair]);
-      const int len = which ? pm.tlen : pm.plen;
-      uint32_t* dst = words + (which ? pm.t_woff : pm.p_woff);
-      const int nw = (len + 15) >> 4;
-      for (int w = lane; w < nw; w += 64) {
+        for (int j = 0; j < 5; ++j) d[j] = a0[j];
         uint32_t packed = 0;
-        const int b0 = w << 4;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          if (b0 + j < len) {
-            const uint32_t c = src[b0 + j];
-            bad |= !is_acgt(c);
-            packed |= ((c >> 1) & 3u) << (2 * j);
-          }
+        for (int j = 0; j < 4; ++j) {
+          const int cnt = min(max(nvalid - 4 * j, 0), 4);
+          const uint32_t m = (cnt >= 4) ? 0xffffffffu : ((1u << (8 * cnt)) - 1u);
+          const uint32_t x = __builtin_amdgcn_alignbyte(d[j + 1], d[j], sh) & m;
+          const uint32_t codes = (x >> 1) & 0x03030303u;
+          const uint32_t t = codes | (codes >> 6);
+          packed |= ((t | (t >> 12)) & 0xffu) << (8 * j);
+          bad |= (__builtin_amdgcn_perm(0u, 0x47544341u, codes) & m) != x;
         }
-        dst[w] = packed;
+        words[pm.p_woff + w] = packed;
       }
     }
-    if (__any(bad) && lane == 0) flags[pair] = 1;
+    const unsigned long long b = __ballot(bad);
+    const unsigned long long field = (slots == 64) ? b : ((b >> (sub * slots)) & ((1ull << slots) - 1ull));
+    if (field != 0ull && wl == 0 && pair < n) flags[pair] = 1;
   }
 }
 
