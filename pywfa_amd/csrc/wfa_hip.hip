@@ -10,6 +10,8 @@
 #include <string.h>
 #include <limits.h>
 #include <string>
+#include <map>
+#include <unordered_map>
 #include <vector>
 #include <algorithm>
 #include <chrono>
@@ -41,13 +43,53 @@ struct wfa_hip_aligner {
   // persistent workspace for the general kernel (grown on demand)
   int32_t* ws = nullptr;
   size_t ws_bytes = 0;
+  // device blocks of finished batches kept for the next one (a batch takes ~20 arrays; for the small batches of
+  // a pywfa-style loop of single alignments hipMalloc / hipFree are most of the call)
+  std::multimap<size_t, void*> pool_free;
+  std::unordered_map<void*, size_t> pool_size;
+  size_t pool_cached = 0;
 };
+
+static const size_t POOL_MAX_BLOCK = (size_t)8 << 20, POOL_MAX_CACHED = (size_t)128 << 20;
+
+static hipError_t pool_alloc(wfa_hip_aligner* al, void** p, size_t bytes) {
+  size_t want = 256;
+  if (bytes > POOL_MAX_BLOCK) want = (bytes + 255) & ~(size_t)255;
+  else while (want < bytes) want <<= 1;
+  if (want <= POOL_MAX_BLOCK) {
+    auto it = al->pool_free.find(want);
+    if (it != al->pool_free.end()) {
+      *p = it->second; al->pool_cached -= want; al->pool_free.erase(it);
+      return hipSuccess;
+    }
+  }
+  const hipError_t e = hipMalloc(p, want);
+  if (e == hipSuccess) al->pool_size[*p] = want;
+  return e;
+}
+
+static void pool_release(wfa_hip_aligner* al, void* p) {
+  if (!p) return;
+  auto it = al->pool_size.find(p);
+  if (it == al->pool_size.end()) { (void)hipFree(p); return; }
+  const size_t sz = it->second;
+  if (sz <= POOL_MAX_BLOCK && al->pool_cached + sz <= POOL_MAX_CACHED) { al->pool_free.emplace(sz, p); al->pool_cached += sz; return; }
+  al->pool_size.erase(it);
+  (void)hipFree(p);
+}
+
+static void pool_drain(wfa_hip_aligner* al) {
+  for (auto& kv : al->pool_free) (void)hipFree(kv.second);
+  al->pool_free.clear(); al->pool_size.clear(); al->pool_cached = 0;
+}
 
 struct wfa_hip_batch {
   wfa_hip_aligner* al = nullptr;
   int64_t n = 0;
   // host copies needed later
   std::vector<int32_t> h_plen, h_tlen;
+  std::vector<int64_t> h_coff;
+  std::unique_ptr<WfaPairMeta[]> h_meta;  // kept until the batch dies: its upload may still be in flight when batch_build returns
   int max_width = 0;       // max(plen+tlen)+3
   int max_len = 0;         // max(plen, tlen)
   int64_t packed_bytes = 0;  // sum of ceil(len/4) over all sequences (algorithmic 2-bit bytes)
@@ -81,6 +123,7 @@ struct wfa_hip_batch {
   int64_t last_kernel_pairs = 0;
   int64_t last_fallback = 0;
   hipStream_t last_stream = nullptr;
+  bool uploads_pending = false;
   int64_t arena_ints = 0;  // FULL: arena size used by the last launch
   // device-side result surface (RLE)
   int32_t* d_plen = nullptr; int32_t* d_tlen = nullptr; int32_t* d_run_count = nullptr; int32_t* d_locs = nullptr;
@@ -244,6 +287,7 @@ extern "C" void wfa_hip_destroy(wfa_hip_aligner_t* al) {
   if (!al) return;
   (void)hipSetDevice(al->device);
   if (al->ws) (void)hipFree(al->ws);
+  pool_drain(al);
   if (al->stream) (void)hipStreamDestroy(al->stream);
   delete al;
 }
@@ -276,7 +320,10 @@ static void batch_free(wfa_hip_batch* b) {
                   b->d_ops, b->d_cigar_off, b->d_cigar_begin, b->d_cigar_len, b->d_list_packed, b->d_list_bytes,
                   b->d_fb_list2[0], b->d_fb_list2[1], b->d_ovf_list[0], b->d_ovf_list[1], b->d_counters,
                   b->d_plen, b->d_tlen, b->d_run_count, b->d_locs, b->d_run_off};
-  for (void* p : ptrs) if (p) (void)hipFree(p);
+  // blocks go back to the aligner's pool: nothing of this batch may still be running
+  if (b->ran && !b->synced && b->last_stream) (void)hipStreamSynchronize(b->last_stream);
+  (void)hipStreamSynchronize(b->al->stream);
+  for (void* p : ptrs) pool_release(b->al, p);
   for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
   delete b;
 }
@@ -350,37 +397,38 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
       meta[(size_t)i].plen = pl; meta[(size_t)i].tlen = tl;
     }
   });
-  if (timing) { fprintf(stderr, "[wfa_hip] meta loop %.1f ms\n", now_ms() - t0); t0 = now_ms(); }
+  if (timing) { fprintf(stderr, "[wfa_hip] meta loop %.3f ms\n", now_ms() - t0); t0 = now_ms(); }
   const bool full = (c.scope == WFA_SCOPE_FULL);
   const size_t nn = (size_t)std::max<int64_t>(n, 1);
-  HIP_TRY(al, hipMalloc((void**)&b->d_bytes, (size_t)blob_end + 64));
-  HIP_TRY(al, hipMalloc((void**)&b->d_pboff, nn * sizeof(int64_t)));
-  HIP_TRY(al, hipMalloc((void**)&b->d_tboff, nn * sizeof(int64_t)));
-  HIP_TRY(al, hipMalloc((void**)&b->d_meta, nn * sizeof(WfaPairMeta)));
-  HIP_TRY(al, hipMalloc((void**)&b->d_words, ((size_t)woff + 4) * sizeof(uint32_t)));
-  HIP_TRY(al, hipMalloc((void**)&b->d_flags, nn));
-  HIP_TRY(al, hipMalloc((void**)&b->d_score, nn * sizeof(int32_t)));
-  HIP_TRY(al, hipMalloc((void**)&b->d_status, nn * sizeof(int32_t)));
-  HIP_TRY(al, hipMalloc((void**)&b->d_fb_list2[0], nn * sizeof(uint32_t)));
-  HIP_TRY(al, hipMalloc((void**)&b->d_fb_list2[1], nn * sizeof(uint32_t)));
-  HIP_TRY(al, hipMalloc((void**)&b->d_counters, 16 * sizeof(uint32_t)));
+  HIP_TRY(al, pool_alloc(al, (void**)&b->d_bytes, (size_t)blob_end + 64));
+  HIP_TRY(al, pool_alloc(al, (void**)&b->d_pboff, nn * sizeof(int64_t)));
+  HIP_TRY(al, pool_alloc(al, (void**)&b->d_tboff, nn * sizeof(int64_t)));
+  HIP_TRY(al, pool_alloc(al, (void**)&b->d_meta, nn * sizeof(WfaPairMeta)));
+  HIP_TRY(al, pool_alloc(al, (void**)&b->d_words, ((size_t)woff + 4) * sizeof(uint32_t)));
+  HIP_TRY(al, pool_alloc(al, (void**)&b->d_flags, nn));
+  HIP_TRY(al, pool_alloc(al, (void**)&b->d_score, nn * sizeof(int32_t)));
+  HIP_TRY(al, pool_alloc(al, (void**)&b->d_status, nn * sizeof(int32_t)));
+  HIP_TRY(al, pool_alloc(al, (void**)&b->d_fb_list2[0], nn * sizeof(uint32_t)));
+  HIP_TRY(al, pool_alloc(al, (void**)&b->d_fb_list2[1], nn * sizeof(uint32_t)));
+  HIP_TRY(al, pool_alloc(al, (void**)&b->d_counters, 16 * sizeof(uint32_t)));
   HIP_TRY(al, hipMemsetAsync(b->d_counters, 0, 16 * sizeof(uint32_t), al->stream));
   HIP_TRY(al, hipMemsetAsync(b->d_flags, 0, nn, al->stream));
   HIP_TRY(al, hipMemsetAsync(b->d_words + woff, 0, 4 * sizeof(uint32_t), al->stream));
   if (full) {
-    std::vector<int64_t> coff((size_t)n + 1);
+    std::vector<int64_t>& coff = b->h_coff;  // (a member: its upload may outlive this function for small batches)
+    coff.assign((size_t)n + 1, 0);
     coff[0] = 0;
     for (int64_t i = 0; i < n; ++i) coff[i + 1] = coff[i] + p_len[i] + t_len[i];
-    HIP_TRY(al, hipMalloc((void**)&b->d_ops, (size_t)std::max<int64_t>(b->ops_bytes, 1)));
-    HIP_TRY(al, hipMalloc((void**)&b->d_cigar_off, ((size_t)n + 1) * sizeof(int64_t)));
-    HIP_TRY(al, hipMalloc((void**)&b->d_cigar_begin, nn * sizeof(int64_t)));
-    HIP_TRY(al, hipMalloc((void**)&b->d_cigar_len, nn * sizeof(int32_t)));
-    HIP_TRY(al, hipMalloc((void**)&b->d_ovf_list[0], nn * sizeof(uint32_t)));
-    HIP_TRY(al, hipMalloc((void**)&b->d_ovf_list[1], nn * sizeof(uint32_t)));
+    HIP_TRY(al, pool_alloc(al, (void**)&b->d_ops, (size_t)std::max<int64_t>(b->ops_bytes, 1)));
+    HIP_TRY(al, pool_alloc(al, (void**)&b->d_cigar_off, ((size_t)n + 1) * sizeof(int64_t)));
+    HIP_TRY(al, pool_alloc(al, (void**)&b->d_cigar_begin, nn * sizeof(int64_t)));
+    HIP_TRY(al, pool_alloc(al, (void**)&b->d_cigar_len, nn * sizeof(int32_t)));
+    HIP_TRY(al, pool_alloc(al, (void**)&b->d_ovf_list[0], nn * sizeof(uint32_t)));
+    HIP_TRY(al, pool_alloc(al, (void**)&b->d_ovf_list[1], nn * sizeof(uint32_t)));
     HIP_TRY(al, hipMemcpyAsync(b->d_cigar_off, coff.data(), ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, al->stream));
-    HIP_TRY(al, hipStreamSynchronize(al->stream));  // coff is a local
+    if (n > 256) HIP_TRY(al, hipStreamSynchronize(al->stream)); else b->uploads_pending = true;
   }
-  if (timing) { fprintf(stderr, "[wfa_hip] mallocs %.1f ms\n", now_ms() - t0); t0 = now_ms(); }
+  if (timing) { fprintf(stderr, "[wfa_hip] mallocs %.3f ms\n", now_ms() - t0); t0 = now_ms(); }
   if (n > 0) {
     HIP_TRY(al, hipMemcpyAsync(b->d_bytes, seqs, (size_t)blob_end, hipMemcpyHostToDevice, al->stream));
     HIP_TRY(al, hipMemcpyAsync(b->d_pboff, p_off, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, al->stream));
@@ -397,9 +445,21 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
                        b->d_bytes, b->d_pboff, b->d_tboff, b->d_meta, n, b->d_words, b->d_flags, log2slots);
     HIP_TRY(al, hipGetLastError());
     std::vector<uint8_t> flags((size_t)n);
-    HIP_TRY(al, hipMemcpyAsync(flags.data(), b->d_flags, (size_t)n, hipMemcpyDeviceToHost, al->stream));
-    HIP_TRY(al, hipStreamSynchronize(al->stream));
-    if (timing) { fprintf(stderr, "[wfa_hip] H2D + pack + flags D2H %.1f ms (%.2f GB)\n", now_ms() - t0, blob_end / 1e9); t0 = now_ms(); }
+    if (n <= 256) {
+      // a handful of pairs: look for letters outside ACGT on the host, the round trip costs more than the scan
+      for (int64_t i = 0; i < n; ++i) {
+        uint8_t bad = 0;
+        const uint8_t* ps = seqs + p_off[i]; const uint8_t* ts = seqs + t_off[i];
+        for (int32_t j = 0; j < p_len[i]; ++j) { const uint8_t ch = ps[j]; bad |= !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'); }
+        for (int32_t j = 0; j < t_len[i]; ++j) { const uint8_t ch = ts[j]; bad |= !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'); }
+        flags[(size_t)i] = bad;
+      }
+      b->uploads_pending = true;  // the caller's arrays are still being read: see wfa_hip_batch_create
+    } else {
+      HIP_TRY(al, hipMemcpyAsync(flags.data(), b->d_flags, (size_t)n, hipMemcpyDeviceToHost, al->stream));
+      HIP_TRY(al, hipStreamSynchronize(al->stream));
+    }
+    if (timing) { fprintf(stderr, "[wfa_hip] H2D + pack + flags D2H %.3f ms (%.2f GB)\n", now_ms() - t0, blob_end / 1e9); t0 = now_ms(); }
     // split into the 2-bit and the 8-bit work lists (wildcard matching needs the bytes)
     std::vector<uint32_t> lp, lb;
     if (c.wildcard >= 0) {
@@ -416,24 +476,25 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
     b->n_bytes = (uint32_t)lb.size();
     b->n_packed = (uint32_t)(lb.empty() ? n : lp.size());
     if (!lb.empty()) {
-      HIP_TRY(al, hipMalloc((void**)&b->d_list_bytes, lb.size() * sizeof(uint32_t)));
+      HIP_TRY(al, pool_alloc(al, (void**)&b->d_list_bytes, lb.size() * sizeof(uint32_t)));
       HIP_TRY(al, hipMemcpy(b->d_list_bytes, lb.data(), lb.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
       if (!lp.empty()) {
-        HIP_TRY(al, hipMalloc((void**)&b->d_list_packed, lp.size() * sizeof(uint32_t)));
+        HIP_TRY(al, pool_alloc(al, (void**)&b->d_list_packed, lp.size() * sizeof(uint32_t)));
         HIP_TRY(al, hipMemcpy(b->d_list_packed, lp.data(), lp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
       }
     } else {
       // every pair is pure ACGT: the ASCII blob is no longer needed
-      (void)hipFree(b->d_bytes); b->d_bytes = nullptr;
+      pool_release(al, b->d_bytes); b->d_bytes = nullptr;
     }
-    if (timing) { fprintf(stderr, "[wfa_hip] work lists + free %.1f ms\n", now_ms() - t0); t0 = now_ms(); }
+    if (timing) { fprintf(stderr, "[wfa_hip] work lists + free %.3f ms\n", now_ms() - t0); t0 = now_ms(); }
   }
+  b->h_meta = std::move(meta);
   return WFA_HIP_OK;
 }
 
-extern "C" wfa_hip_batch_t* wfa_hip_batch_create(wfa_hip_aligner_t* al, int64_t n, const uint8_t* seqs,
-                                                 const int64_t* p_off, const int32_t* p_len,
-                                                 const int64_t* t_off, const int32_t* t_len) {
+static wfa_hip_batch* batch_create_nosync(wfa_hip_aligner_t* al, int64_t n, const uint8_t* seqs,
+                                          const int64_t* p_off, const int32_t* p_len,
+                                          const int64_t* t_off, const int32_t* t_len) {
   if (!al) { g_error = "null aligner"; return nullptr; }
   if (n < 0 || n > 0x7FFFFFF0ll || (n > 0 && (!seqs || !p_off || !p_len || !t_off || !t_len))) {
     al->err = "invalid batch arguments"; g_error = al->err; return nullptr;
@@ -443,6 +504,15 @@ extern "C" wfa_hip_batch_t* wfa_hip_batch_create(wfa_hip_aligner_t* al, int64_t 
   b->al = al;
   const int rc = batch_build(al, b, n, seqs, p_off, p_len, t_off, t_len);
   if (rc != WFA_HIP_OK) { g_error = al->err; batch_free(b); return nullptr; }
+  return b;
+}
+
+extern "C" wfa_hip_batch_t* wfa_hip_batch_create(wfa_hip_aligner_t* al, int64_t n, const uint8_t* seqs,
+                                                 const int64_t* p_off, const int32_t* p_len,
+                                                 const int64_t* t_off, const int32_t* t_len) {
+  wfa_hip_batch* b = batch_create_nosync(al, n, seqs, p_off, p_len, t_off, t_len);
+  // inputs are borrowed for the call only: their upload must be over before it returns
+  if (b && b->uploads_pending) { (void)hipStreamSynchronize(al->stream); b->uploads_pending = false; }
   return b;
 }
 
@@ -571,10 +641,13 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     // the general kernel's geometry is fixed first so that one workspace allocation serves every stage
     int n_stages = 0;
     int band_nch[3] = {0, 0, 0};
-    const bool use_fast = !full && wfa::seg_supported(al->dcfg, al->ncomp, full) && b->max_len <= WFA_FAST_MAX_LEN &&
+    // a handful of pairs: one launch of the general kernel beats six nearly empty stages (single-pair calls of a
+    // pywfa-style loop)
+    const bool tiny = in_n <= (uint32_t)env_int("WFA_HIP_TINY_BATCH", 128);
+    const bool use_fast = !tiny && !full && wfa::seg_supported(al->dcfg, al->ncomp, full) && b->max_len <= WFA_FAST_MAX_LEN &&
                           env_int("WFA_HIP_NO_FAST", 0) == 0;
     const bool legacy_ok = wfa::fast_supported(al->dcfg, al->ncomp, full);  // the one/two-per-wave kernels: 4/6/2-shaped only
-    if (wfa::band_supported(al->dcfg, al->ncomp) && env_int("WFA_HIP_NO_BAND", 0) == 0) {
+    if (!tiny && wfa::band_supported(al->dcfg, al->ncomp) && env_int("WFA_HIP_NO_BAND", 0) == 0) {
       if (adapt) {
         if (b->max_len <= 300) { band_nch[n_stages++] = 1; }
         band_nch[n_stages++] = 2; band_nch[n_stages++] = 4;
@@ -876,9 +949,9 @@ extern "C" int64_t wfa_hip_batch_rle_counts(wfa_hip_batch_t* b, int32_t* run_cou
   if (n == 0) return 0;
   const size_t nn = (size_t)n;
   if (!b->d_plen) {
-    HIP_TRY(al, hipMalloc((void**)&b->d_plen, nn * 4)); HIP_TRY(al, hipMalloc((void**)&b->d_tlen, nn * 4));
-    HIP_TRY(al, hipMalloc((void**)&b->d_run_count, nn * 4)); HIP_TRY(al, hipMalloc((void**)&b->d_locs, nn * 16));
-    HIP_TRY(al, hipMalloc((void**)&b->d_run_off, (nn + 1) * 8));
+    HIP_TRY(al, pool_alloc(al, (void**)&b->d_plen, nn * 4)); HIP_TRY(al, pool_alloc(al, (void**)&b->d_tlen, nn * 4));
+    HIP_TRY(al, pool_alloc(al, (void**)&b->d_run_count, nn * 4)); HIP_TRY(al, pool_alloc(al, (void**)&b->d_locs, nn * 16));
+    HIP_TRY(al, pool_alloc(al, (void**)&b->d_run_off, (nn + 1) * 8));
     HIP_TRY(al, hipMemcpy(b->d_plen, b->h_plen.data(), nn * 4, hipMemcpyHostToDevice));
     HIP_TRY(al, hipMemcpy(b->d_tlen, b->h_tlen.data(), nn * 4, hipMemcpyHostToDevice));
   }
@@ -907,8 +980,8 @@ extern "C" int wfa_hip_batch_rle_runs(wfa_hip_batch_t* b, uint8_t* run_code, int
   if (n == 0 || total == 0) return WFA_HIP_OK;
   if (!run_code || !run_len) { al->err = "null output"; return WFA_HIP_EINVAL; }
   uint8_t* d_code = nullptr; int32_t* d_start = nullptr;
-  HIP_TRY(al, hipMalloc((void**)&d_code, (size_t)total));
-  HIP_TRY(al, hipMalloc((void**)&d_start, (size_t)total * 4));
+  HIP_TRY(al, pool_alloc(al, (void**)&d_code, (size_t)total));
+  HIP_TRY(al, pool_alloc(al, (void**)&d_start, (size_t)total * 4));
   const int grid = (int)std::min<int64_t>((n + 3) / 4, (int64_t)al->cu_count * 16);
   hipLaunchKernelGGL(wfa::wfa_rle_kernel, dim3(grid), dim3(256), 0, al->stream, b->d_ops, b->d_cigar_begin, b->d_cigar_len,
                      b->d_plen, b->d_tlen, n, b->d_run_count, b->d_locs, (const int64_t*)b->d_run_off, d_code, d_start);
@@ -919,7 +992,7 @@ extern "C" int wfa_hip_batch_rle_runs(wfa_hip_batch_t* b, uint8_t* run_code, int
   HIP_TRY(al, hipMemcpyAsync(cnt.data(), b->d_run_count, (size_t)n * 4, hipMemcpyDeviceToHost, al->stream));
   HIP_TRY(al, hipMemcpyAsync(clen.data(), b->d_cigar_len, (size_t)n * 4, hipMemcpyDeviceToHost, al->stream));
   HIP_TRY(al, hipStreamSynchronize(al->stream));
-  (void)hipFree(d_code); (void)hipFree(d_start);
+  pool_release(al, d_code); pool_release(al, d_start);
   // run length = next run's start (or the end of the op string) - this run's start
   int64_t r = 0;
   for (int64_t i = 0; i < n; ++i) {
@@ -938,10 +1011,18 @@ extern "C" int wfa_hip_align_batch(wfa_hip_aligner_t* al, int64_t n, const uint8
                                    int32_t* score, int32_t* status, uint8_t* cigar_ops, const int64_t* cigar_off,
                                    int64_t* cigar_begin, int32_t* cigar_len) {
   if (!al) return WFA_HIP_EINVAL;
-  wfa_hip_batch_t* b = wfa_hip_batch_create(al, n, seqs, p_off, p_len, t_off, t_len);
+  const bool timing = getenv("WFA_HIP_TIMING") != nullptr;
+  const double t0 = now_ms();
+  // (the results call below synchronises the stream before this function returns, so the uploads need no wait of their own)
+  wfa_hip_batch_t* b = batch_create_nosync(al, n, seqs, p_off, p_len, t_off, t_len);
   if (!b) return (al->err.find("failed:") != std::string::npos) ? WFA_HIP_EDEVICE : WFA_HIP_EINVAL;
+  const double t1 = now_ms();
   int rc = wfa_hip_batch_run(b, nullptr);
+  const double t2 = now_ms();
   if (rc == WFA_HIP_OK) rc = wfa_hip_batch_results(b, score, status, cigar_ops, cigar_off, cigar_begin, cigar_len);
+  const double t3 = now_ms();
   wfa_hip_batch_destroy(b);
+  if (timing) fprintf(stderr, "[wfa_hip] align_batch: create %.3f ms, enqueue %.3f ms, sync + results %.3f ms, destroy %.3f ms\n",
+                      t1 - t0, t2 - t1, t3 - t2, now_ms() - t3);
   return rc;
 }
