@@ -50,6 +50,8 @@ struct BandArgs {
   int ef, pbf, pef, tbf, tef;  // ends-free span with these free ends (R/wavefront_termination.c:115-162)
   int h16;                // FULL: 1 = history entries are 4 x int16 (sequences < 32000 bases) instead of 4 x int32
   int debug;              // timing experiments only: 1 = skip the backtrace, 2 = skip the history stores
+  int seg_w;              // > 0: the history was written by wfa_seg_kernel<.., FULL>: records of seg_w entries {M, I, D, -} x
+                          // int16, entry k - klo, klo = ceil((tlen - plen) / 2) - seg_w / 2
 };
 
 // wave-wide minimum without LDS traffic: butterfly inside each row of 16 lanes with DPP, then 4 row leaders
@@ -146,6 +148,17 @@ __device__ void band_backtrace(const int* hist, const BandArgs& a, int plen, int
   // (the top of this pair's history slot: records above the walk's current score are dead) — the bytes
   // are written afterwards, coalesced, by wfa_band_expand_kernel
   int nruns = 0;
+  const int seg_klo = a.seg_w ? ((tlen - plen + 1) >> 1) - a.seg_w / 2 : 0;
+  // entry of (score index, diagonal): the banded kernel's window records or a segment's records
+  auto entry = [&](int si, int kk) -> int4 {
+    if (!a.seg_w) return band_entry<NCH>(hist, si, kk, a.h16);
+    int4 e = make_int4(WFA_OFFSET_NULL, WFA_OFFSET_NULL, WFA_OFFSET_NULL, 0);
+    if (si >= 0 && kk >= seg_klo && kk < seg_klo + a.seg_w) {
+      const short4 q = reinterpret_cast<const short4*>(hist + (long long)si * (a.seg_w * 2))[kk - seg_klo];
+      e = make_int4(q.x < 0 ? WFA_OFFSET_NULL : q.x, q.y < 0 ? WFA_OFFSET_NULL : q.y, q.z < 0 ? WFA_OFFSET_NULL : q.z, 0);
+    }
+    return e;
+  };
   auto push = [&](long long& bg, char c, int n) {
     if (runs_top) { if (n > 0) { *(runs_top - nruns) = ((uint32_t)n << 8) | (uint8_t)c; ++nruns; } }
     else for (int i = lane; i < n; i += nlanes) buf[bg - 1 - i] = (uint8_t)c;
@@ -162,18 +175,18 @@ __device__ void band_backtrace(const int* hist, const BandArgs& a, int plen, int
     const int si_x = si - dx, si_o = si - doe, si_e = si - de;
     long long best;
     if (comp == 0) {
-      const int4 ex = band_entry<NCH>(hist, si_x, k, a.h16);
-      const int4 eol = band_entry<NCH>(hist, si_o, k - 1, a.h16), eoh = band_entry<NCH>(hist, si_o, k + 1, a.h16);
-      const int4 eel = band_entry<NCH>(hist, si_e, k - 1, a.h16), eeh = band_entry<NCH>(hist, si_e, k + 1, a.h16);
+      const int4 ex = entry(si_x, k);
+      const int4 eol = entry(si_o, k - 1), eoh = entry(si_o, k + 1);
+      const int4 eel = entry(si_e, k - 1), eeh = entry(si_e, k + 1);
       const long long c0 = band_pack(si_x, ex.x, 1, BT_M);
       const long long c1 = band_pack(si_o, eol.x, 1, BT_I1_OPEN), c2 = band_pack(si_e, eel.y, 1, BT_I1_EXT);
       const long long c3 = band_pack(si_o, eoh.x, 0, BT_D1_OPEN), c4 = band_pack(si_e, eeh.z, 0, BT_D1_EXT);
       best = max(max(c0, max(c1, c2)), max(c3, c4));
     } else if (comp == 1) {
-      const int4 eol = band_entry<NCH>(hist, si_o, k - 1, a.h16), eel = band_entry<NCH>(hist, si_e, k - 1, a.h16);
+      const int4 eol = entry(si_o, k - 1), eel = entry(si_e, k - 1);
       best = max(band_pack(si_o, eol.x, 1, BT_I1_OPEN), band_pack(si_e, eel.y, 1, BT_I1_EXT));
     } else {
-      const int4 eoh = band_entry<NCH>(hist, si_o, k + 1, a.h16), eeh = band_entry<NCH>(hist, si_e, k + 1, a.h16);
+      const int4 eoh = entry(si_o, k + 1), eeh = entry(si_e, k + 1);
       best = max(band_pack(si_o, eoh.x, 0, BT_D1_OPEN), band_pack(si_e, eeh.z, 0, BT_D1_EXT));
     }
     if (best < 0) break;

@@ -41,6 +41,11 @@ struct FastArgs {
   uint32_t* fb_list;
   uint32_t* fb_count;
   int g;  // score step = gcd(x, o+e, e)
+  // full-CIGAR variant of the segmented kernel (wfa_seg.hpp): history slot per work item of this launch
+  int32_t* hist;          // slot t: hist + t * hist_stride, records of W entries {M, I, D, -} x int16
+  long long hist_stride;  // ints per slot
+  int4* end_state;        // per slot {end score, end k, end offset, 1 = walk it}
+  uint32_t work_begin;    // first work item of this launch (slot = item - work_begin)
 };
 
 // X, OE, E: mismatch, gap_open+gap_extend, gap_extend in units of g.
@@ -381,6 +386,7 @@ inline int launch_fast(const WfaDevConfig& c, int cu_count, hipStream_t stream, 
   a.words = words; a.meta = meta; a.worklist = worklist; a.nwork_dev = nwork_dev; a.nwork = nwork;
   a.score = score; a.status = status; a.fb_list = fb_list; a.fb_count = fb_count;
   a.g = gcd_int(gcd_int(c.x, c.o1 + c.e1), c.e1);
+  a.hist = nullptr; a.hist_stride = 0; a.end_state = nullptr; a.work_begin = 0;
   const char* env = getenv("WFA_HIP_FAST_WAVES_PER_CU");
   const int per_cu = (env && *env) ? atoi(env) : 32;
   long long grid = (long long)cu_count * per_cu;

@@ -647,12 +647,15 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     const bool use_fast = !tiny && !full && wfa::seg_supported(al->dcfg, al->ncomp, full) && b->max_len <= WFA_FAST_MAX_LEN &&
                           env_int("WFA_HIP_NO_FAST", 0) == 0;
     const bool legacy_ok = wfa::fast_supported(al->dcfg, al->ncomp, full);  // the one/two-per-wave kernels: 4/6/2-shaped only
+    // full CIGARs of short reads: the segmented kernel with a history slot per pair, then the thread-per-alignment walk
+    const bool use_segfull = !tiny && full && wfa::seg_supported(al->dcfg, al->ncomp, false) && b->max_len <= WFA_FAST_MAX_LEN &&
+                             env_int("WFA_HIP_NO_FAST", 0) == 0 && env_int("WFA_HIP_NO_SEGFULL", 0) == 0;
     if (!tiny && wfa::band_supported(al->dcfg, al->ncomp) && env_int("WFA_HIP_NO_BAND", 0) == 0) {
       if (adapt) {
         if (b->max_len <= 300) { band_nch[n_stages++] = 1; }
         band_nch[n_stages++] = 2; band_nch[n_stages++] = 4;
       } else if (b->max_len <= 300) {
-        if (!use_fast) band_nch[n_stages++] = 1;
+        if (!use_fast && !use_segfull) band_nch[n_stages++] = 1;
         band_nch[n_stages++] = 2; band_nch[n_stages++] = 4;
       } else if (b->max_len <= 1200) {
         band_nch[n_stages++] = 4;
@@ -660,7 +663,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       const int only = env_int("WFA_HIP_BAND_NCH", 0);
       if (only) { n_stages = 1; band_nch[0] = only; }
     }
-    const bool any_pre = use_fast || n_stages > 0;
+    const bool any_pre = use_fast || use_segfull || n_stages > 0;
     Geometry g = plan_general(al, b, any_pre ? std::min<uint32_t>(in_n, (uint32_t)al->cu_count * 16) : in_n, b->arena_ints);
     size_t need = (size_t)g.grid * g.ws_stride * 4;
     // band history: fixed-stride records per score step, one slice per wave
@@ -671,7 +674,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       // dispatcher refills the CU, instead of a tail of lone waves (C1 +20 %, C3 +13 %)
       long long grid = (long long)al->cu_count * env_int("WFA_HIP_BAND_WAVES_PER_CU", 128);
       grid = std::min<long long>(grid, in_n);
-      if (i > 0 || use_fast) grid = std::min<long long>(grid, (long long)al->cu_count * 16);
+      if (i > 0 || use_fast || use_segfull) grid = std::min<long long>(grid, (long long)al->cu_count * 16);
       if (full) {
         const bool h16 = b->max_len < 32000;
         const int rec = (h16 ? 2 : 4) * 64 * band_nch[i];
@@ -681,7 +684,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         const int64_t budget = free_budget(al);
         while (grid > 1 && grid * band_stride[i] * 4 > budget) grid = (grid + 1) / 2;
         need = std::max(need, (size_t)grid * band_stride[i] * 4);
-        if (i == 0 && !use_fast && b->max_len > 1000 && env_int("WFA_HIP_BAND_NO_SPLIT", 0) == 0) {
+        if (i == 0 && !use_fast && !use_segfull && b->max_len > 1000 && env_int("WFA_HIP_BAND_NO_SPLIT", 0) == 0) {
           // split backtrace: one history slot per pair of a launch; take up to 4x the wave count (or all pairs)
           const int64_t slot_bytes = band_stride[i] * 4 + 16;
           int64_t pairs = std::min<int64_t>(in_n, (int64_t)al->cu_count * 32 * env_int("WFA_HIP_BAND_SPLIT_ROUNDS", 4));
@@ -691,9 +694,45 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       }
       band_grid[i] = grid;
     }
+    int64_t segfull_slot_ints = 0, segfull_per_launch = 0;
+    if (use_segfull) {
+      segfull_slot_ints = (int64_t)wfa::seg_full_records(al->dcfg) * 32;  // records of 16 entries x 8 bytes
+      const int64_t slot_bytes = segfull_slot_ints * 4 + (int64_t)sizeof(int4);
+      segfull_per_launch = std::min<int64_t>(in_n, std::min<int64_t>((int64_t)env_int("WFA_HIP_SEGFULL_PAIRS", 2000000), free_budget(al) / slot_bytes));
+      if (segfull_per_launch < 1) segfull_per_launch = 1;
+      need = std::max(need, (size_t)(segfull_per_launch * slot_bytes));
+    }
     int rc = ensure_ws(al, need);
     if (rc != WFA_HIP_OK) return rc;
 
+    if (use_segfull) {
+      uint32_t* out_list = b->d_fb_list2[out_sel];
+      uint32_t* out_count = b->d_counters + 4 + out_sel;
+      if (!first_stage) HIP_TRY(al, hipMemsetAsync(out_count, 0, sizeof(uint32_t), stream));
+      wfa::FastArgs fa;
+      memset(&fa, 0, sizeof(fa));
+      fa.words = b->d_words; fa.meta = b->d_meta; fa.worklist = in_list; fa.nwork_dev = nullptr;
+      fa.score = b->d_score; fa.status = b->d_status; fa.fb_list = out_list; fa.fb_count = out_count;
+      fa.hist = al->ws; fa.hist_stride = segfull_slot_ints;
+      fa.end_state = reinterpret_cast<int4*>(reinterpret_cast<char*>(al->ws) + (size_t)segfull_per_launch * segfull_slot_ints * 4);
+      wfa::BandArgs ba;
+      memset(&ba, 0, sizeof(ba));
+      ba.meta = b->d_meta; ba.worklist = in_list; ba.words = b->d_words;
+      ba.cigar_ops = b->d_ops; ba.cigar_off = b->d_cigar_off; ba.cigar_begin = b->d_cigar_begin; ba.cigar_len = b->d_cigar_len;
+      ba.g = wfa::gcd_int(wfa::gcd_int(al->dcfg.x, al->dcfg.o1 + al->dcfg.e1), al->dcfg.e1);
+      ba.x = al->dcfg.x; ba.oe = al->dcfg.o1 + al->dcfg.e1; ba.e = al->dcfg.e1;
+      ba.hist = al->ws; ba.hist_stride = segfull_slot_ints; ba.end_state = fa.end_state;
+      ba.split = 1; ba.h16 = 1; ba.seg_w = 16;
+      for (int64_t w0 = 0; w0 < in_n; w0 += segfull_per_launch) {
+        const uint32_t cnt = (uint32_t)std::min<int64_t>(segfull_per_launch, in_n - w0);
+        fa.work_begin = (uint32_t)w0; fa.nwork = cnt;
+        if (wfa::launch_seg_full(al->dcfg, al->cu_count, stream, fa) != 0) { al->err = "segmented kernel launch failed"; return WFA_HIP_EDEVICE; }
+        ba.work_begin = (uint32_t)w0; ba.nwork = cnt;
+        if (wfa::launch_band_bt(ba, 1, stream) != 0) { al->err = "backtrace launch failed"; return WFA_HIP_EDEVICE; }
+      }
+      if (first_stage) b->last_kernel_pairs = in_n;
+      in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
+    }
     if (use_fast) {
       // register-kernel stages, each taking what the one before handed on (WFA_HIP_FAST_STAGES, one digit per
       // stage): 7/6/8/9 = segments of 8/16/32/64 lanes with the two-round (lazy) extension, 3/2/4/5 = the same widths

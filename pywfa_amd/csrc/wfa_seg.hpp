@@ -32,6 +32,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <limits.h>
+#include <algorithm>
 #include "wfa_common.hpp"
 #include "wfa_fast.hpp"
 
@@ -44,9 +45,10 @@ __device__ __forceinline__ uint32_t ffbl_u32(uint32_t x) {
   return r;
 }
 
-template <int X, int OE, int E, int W, bool LAZY>
+template <int X, int OE, int E, int W, bool LAZY, bool FULL>
 __global__ void __launch_bounds__(64)
 wfa_seg_kernel(const FastArgs a) {
+  static_assert(!(LAZY && FULL), "the history of a step is stored in the step itself");
   static_assert(!LAZY || X >= 2, "the lazy extension needs a wavefront to be consumed two steps after it is made");
   static_assert(W == 8 || W == 16 || W == 32 || W == 64, "segment width");
   constexpr int DM = (X > OE) ? X : OE;
@@ -85,7 +87,7 @@ wfa_seg_kernel(const FastArgs a) {
   auto load_window = [&](uint32_t wb, uint32_t& pid, WfaPairMeta& m) {
     const unsigned long long idx = (unsigned long long)wb + lane;
     pid = 0u; m.p_woff = 0u; m.t_woff = 0u; m.plen = 0; m.tlen = 0;
-    if (idx < end) { pid = a.worklist ? a.worklist[idx] : (uint32_t)idx; m = a.meta[pid]; }
+    if (idx < end) { pid = a.worklist ? a.worklist[a.work_begin + idx] : (uint32_t)(a.work_begin + idx); m = a.meta[pid]; }
   };
   uint32_t wbase = begin;
   load_window(wbase, pid0, m0);
@@ -137,6 +139,9 @@ wfa_seg_kernel(const FastArgs a) {
   int target = NEVER;  // tlen on the lane of diagonal tlen - plen: reaching it ends the alignment
   int lim = WFA_OFFSET_NULL, cur = WFA_OFFSET_NULL, s0 = 0, deadline = NEVER;
   uint32_t spair = 0;
+  // FULL: slot of my pair and my entry {M, I, D, -} x int16 in the record of the current step
+  uint32_t tslot = 0;
+  int2* hp = nullptr;
   int Mh[DM], Ih[E], Dh[E];
 #pragma unroll
   for (int d = 0; d < DM; ++d) Mh[d] = WFA_OFFSET_NULL;
@@ -193,7 +198,9 @@ wfa_seg_kernel(const FastArgs a) {
             // c + H and the way back to ak, downwards from 0 to c - H - 1 and back (LAZY: wavefront s is judged one
             // round later)
             deadline = bad ? gstep - 1
-                           : gstep + min(2 * (OE - E) + E * (2 * c + 2 * H - akk), 2 * (OE - E) + E * (2 * H + 2 - 2 * c + akk)) + (LAZY ? 1 : 0);
+                           : gstep + min(2 * (OE - E) + E * (2 * c + 2 * H - akk), 2 * (OE - E) + E * (2 * H + 2 - 2 * c + akk)) + (LAZY ? 1 : 0)
+                                   - (FULL ? 1 : 0);  // FULL: S' < Bmin strictly, so that no co-optimal alignment leaves the band
+            if (FULL) { tslot = i; hp = reinterpret_cast<int2*>(a.hist + (long long)i * a.hist_stride) + l; }
             cur = (bad || k != 0) ? WFA_OFFSET_NULL : 0;
 #pragma unroll
             for (int d = 0; d < DM; ++d) Mh[d] = WFA_OFFSET_NULL;
@@ -260,6 +267,15 @@ wfa_seg_kernel(const FastArgs a) {
         } while (mold);
       }
     }
+    if (FULL) {
+      // record of this step: entry l of W, 8 bytes {M (extended), I, D, -} as int16 (offsets <= 512; NULL -> -1);
+      // the thread-per-alignment walk of wfa_band.hpp reads it back (band_backtrace, a.seg_w = W)
+      if (deadline != NEVER) {
+        const int m16 = max(cur, -1), i16 = max(Ih[0], -1), d16 = max(Dh[0], -1);
+        *hp = make_int2((m16 & 0xffff) | (i16 << 16), d16 & 0xffff);
+        hp += W;
+      }
+    }
     // ---------------- termination / hand-over ----------------
     {
       const bool rej = gstep > deadline;  // segment-uniform
@@ -275,6 +291,7 @@ wfa_seg_kernel(const FastArgs a) {
           if (acc) {
             const uint32_t pos = nres + __builtin_amdgcn_mbcnt_hi((uint32_t)(ba >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ba, 0u));
             rpid[pos] = spair; rscore[pos] = -__mul24(gstep - s0 - (LAZY ? 1 : 0), a.g);
+            if (FULL) a.end_state[tslot] = make_int4(__mul24(gstep - s0, a.g), pbias - kb, target, 1);  // {score, k = ak, offset = tlen}
           }
           nres += na;
         }
@@ -283,7 +300,10 @@ wfa_seg_kernel(const FastArgs a) {
         if (br) {
           const uint32_t nr = (uint32_t)__builtin_popcountll(br);
           if (nfb + nr > 64u) fb_flush();
-          if (hand) fbuf[nfb + __builtin_amdgcn_mbcnt_hi((uint32_t)(br >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)br, 0u))] = spair;
+          if (hand) {
+            fbuf[nfb + __builtin_amdgcn_mbcnt_hi((uint32_t)(br >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)br, 0u))] = spair;
+            if (FULL) a.end_state[tslot] = make_int4(0, 0, 0, 0);
+          }
           nfb += nr;
         }
 #pragma unroll
@@ -352,17 +372,39 @@ inline void launch_seg_shape(int w, bool lazy, dim3 g, hipStream_t stream, const
   const dim3 blk(64);
   if constexpr (X >= 2) {
     if (lazy) {
-      if (w == 8) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 8, true>), g, blk, 0, stream, a);
-      else if (w == 32) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 32, true>), g, blk, 0, stream, a);
-      else if (w == 64) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 64, true>), g, blk, 0, stream, a);
-      else hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 16, true>), g, blk, 0, stream, a);
+      if (w == 8) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 8, true, false>), g, blk, 0, stream, a);
+      else if (w == 32) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 32, true, false>), g, blk, 0, stream, a);
+      else if (w == 64) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 64, true, false>), g, blk, 0, stream, a);
+      else hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 16, true, false>), g, blk, 0, stream, a);
       return;
     }
   }
-  if (w == 8) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 8, false>), g, blk, 0, stream, a);
-  else if (w == 32) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 32, false>), g, blk, 0, stream, a);
-  else if (w == 64) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 64, false>), g, blk, 0, stream, a);
-  else hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 16, false>), g, blk, 0, stream, a);
+  if (w == 8) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 8, false, false>), g, blk, 0, stream, a);
+  else if (w == 32) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 32, false, false>), g, blk, 0, stream, a);
+  else if (w == 64) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 64, false, false>), g, blk, 0, stream, a);
+  else hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 16, false, false>), g, blk, 0, stream, a);
+}
+
+// full-CIGAR launch: 16-lane segments, items [work_begin, work_begin + nwork) of the work list, one history slot each
+inline int launch_seg_full(const WfaDevConfig& c, int cu_count, hipStream_t stream, FastArgs a) {
+  int X, OE, E;
+  if (!seg_shape(c, &X, &OE, &E)) return -1;
+  a.g = gcd_int(gcd_int(c.x, c.o1 + c.e1), c.e1);
+  const char* env = getenv("WFA_HIP_FAST_WAVES_PER_CU");
+  const int per_cu = (env && *env) ? atoi(env) : 256;
+  long long grid = std::min<long long>((long long)cu_count * per_cu, (long long)a.nwork);
+  if (grid < 1) grid = 1;
+#define WFA_SEG_LAUNCH_FULL(x, oe, e) if (X == x && OE == oe && E == e) hipLaunchKernelGGL((wfa_seg_kernel<x, oe, e, 16, false, true>), dim3((unsigned)grid), dim3(64), 0, stream, a);
+  WFA_SEG_SHAPES(WFA_SEG_LAUNCH_FULL)
+#undef WFA_SEG_LAUNCH_FULL
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// steps a 16-lane segment can take before it hands its pair on (+ 1), i.e. the records a history slot needs
+inline int seg_full_records(const WfaDevConfig& c) {
+  int X, OE, E;
+  if (!seg_shape(c, &X, &OE, &E)) return 0;
+  return 2 * (OE - E) + E * (16 + 1) + 3;
 }
 
 // variant 6/7/8/9 = segments of 16/8/32/64 lanes (4/8/2/1 alignments per wave) with the two-round extension,
@@ -374,6 +416,7 @@ inline int launch_seg(const WfaDevConfig& c, int cu_count, hipStream_t stream, c
   a.words = words; a.meta = meta; a.worklist = worklist; a.nwork_dev = nwork_dev; a.nwork = nwork;
   a.score = score; a.status = status; a.fb_list = fb_list; a.fb_count = fb_count;
   a.g = gcd_int(gcd_int(c.x, c.o1 + c.e1), c.e1);
+  a.hist = nullptr; a.hist_stride = 0; a.end_state = nullptr; a.work_begin = 0;
   int X, OE, E;
   if (!seg_shape(c, &X, &OE, &E)) return -1;
   const char* env = getenv("WFA_HIP_FAST_WAVES_PER_CU");
