@@ -674,7 +674,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       // dispatcher refills the CU, instead of a tail of lone waves (C1 +20 %, C3 +13 %)
       long long grid = (long long)al->cu_count * env_int("WFA_HIP_BAND_WAVES_PER_CU", 128);
       grid = std::min<long long>(grid, in_n);
-      if (i > 0 || use_fast || use_segfull) grid = std::min<long long>(grid, (long long)al->cu_count * 16);
+      if (i > 0 || use_fast || use_segfull) grid = std::min<long long>(grid, (long long)al->cu_count * env_int("WFA_HIP_BAND_LEFTOVER_WAVES_PER_CU", 64));
       if (full) {
         const bool h16 = b->max_len < 32000;
         const int rec = (h16 ? 2 : 4) * 64 * band_nch[i];
