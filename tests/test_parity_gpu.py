@@ -215,3 +215,27 @@ def test_segmented_kernel_penalty_shapes(gpu, pen):
         score, status, _ = common.gpu_run(nc, batch, False, i % 2 == 0)
         assert np.array_equal(status, o_["status"]), (pen, L, err)
         assert np.array_equal(score, o_["score"]), (pen, L, err)
+
+
+@pytest.mark.parametrize("span", ["ends-free", "end-to-end"])
+def test_segmented_full_cigar_in_several_launches(gpu, span, monkeypatch):
+    """Full CIGARs of short reads come from the segmented kernel with a history slot per pair; with a small slot budget the
+    batch takes several launches (work_begin > 0), some pairs exceed the band's bound and are finished by the banded
+    kernel, and a re-run of the resident batch gives the same op strings."""
+    monkeypatch.setenv("WFA_HIP_SEGFULL_PAIRS", "1500")
+    parts = [datagen.generate(4000, 150, 0.02, 9100), datagen.generate(1200, 150, 0.12, 9101), datagen.generate(1000, 400, 0.02, 9102),
+             datagen.generate(700, 33, 0.06, 9103)]
+    oc, nc = common.configs_pair(span=span, scope="full")
+    for batch in parts:
+        o = loader.run(loader.oracle(), oc, batch)
+        for resident in (False, True):
+            score, status, cigars = common.gpu_run(nc, batch, True, resident)
+            common.assert_same(o, score, status, cigars, batch, f"segmented full {span}")
+    # the same through the default budget and without the segmented stage
+    for env in ({}, {"WFA_HIP_NO_SEGFULL": "1"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        monkeypatch.delenv("WFA_HIP_SEGFULL_PAIRS", raising=False)
+        o = loader.run(loader.oracle(), oc, parts[0])
+        score, status, cigars = common.gpu_run(nc, parts[0], True, True)
+        common.assert_same(o, score, status, cigars, parts[0], f"segmented full {span} {env}")
