@@ -124,6 +124,7 @@ struct wfa_hip_batch {
   int64_t last_fallback = 0;
   hipStream_t last_stream = nullptr;
   bool uploads_pending = false;
+  int stage_pick = 0;  // first register-kernel stage chosen by the pilot of the first run (0 = not yet): 16, 32 or 64 lanes
   int64_t arena_ints = 0;  // FULL: arena size used by the last launch
   // device-side result surface (RLE)
   int32_t* d_plen = nullptr; int32_t* d_tlen = nullptr; int32_t* d_run_count = nullptr; int32_t* d_locs = nullptr;
@@ -739,6 +740,27 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       // extending every cell at once, 1 = half-waves, 0 = one alignment per wave (both with edge detection)
       const char* stages_env = getenv("WFA_HIP_FAST_STAGES");
       const char* stages = (stages_env && *stages_env) ? stages_env : "689";
+      if (!(stages_env && *stages_env) && in_n >= 65536u && in_count == nullptr) {
+        // The narrowest band that keeps most pairs is the cheapest start; it depends on the divergence of the batch
+        // (16 lanes up to ~3 %, 32 up to ~6 %).  A pilot on the first 8192 pairs decides once per batch (~50 us).
+        if (b->stage_pick == 0) {
+          const uint32_t np = 8192u;
+          uint32_t* plist = b->d_fb_list2[0];
+          uint32_t* pcount = b->d_counters + 4;
+          b->stage_pick = 64;
+          for (int w = 16; w <= 32; w *= 2) {
+            HIP_TRY(al, hipMemsetAsync(pcount, 0, sizeof(uint32_t), stream));
+            if (wfa::launch_seg(al->dcfg, al->cu_count, stream, b->d_words, b->d_meta, in_list, nullptr, np, b->d_score, b->d_status,
+                                plist, pcount, w == 16 ? 6 : 8) != 0) { al->err = "pilot launch failed"; return WFA_HIP_EDEVICE; }
+            uint32_t handed = 0;
+            HIP_TRY(al, hipMemcpyAsync(&handed, pcount, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(al, hipStreamSynchronize(stream));
+            if (handed * 5u <= np * 2u) { b->stage_pick = w; break; }  // at most 40 % handed on
+          }
+          HIP_TRY(al, hipMemsetAsync(pcount, 0, sizeof(uint32_t), stream));
+        }
+        stages = (b->stage_pick == 16) ? "689" : (b->stage_pick == 32) ? "89" : "9";
+      }
       int variants[6] = {-1, -1, -1, -1, -1, -1};
       int nv = 0;
       for (const char* c = stages; *c && nv < 6; ++c) {
