@@ -737,7 +737,14 @@ int wfa_oracle_align_batch(const wfa_hip_config_t* cfg, int64_t n, const uint8_t
    * ("next"): not restated here */
   if (cfg->match < 0 && cfg->span == WFA_SPAN_ENDSFREE &&
       (cfg->pattern_begin_free > 0 || cfg->text_begin_free > 0)) return -1;
-  if (cfg->memory_mode == WFA_MEM_BIWFA) return -1;
+  /* BiWFA (R/wavefront_bialign.c): only the subset in which the reference returns what the other memory modes return
+   * (score scope, no heuristic, no free ends, no step limit: wavefront_bialign_compute_score, :662-702); the
+   * breakpoint recursion of the full-CIGAR form is not restated ("next"). */
+  if (cfg->memory_mode == WFA_MEM_BIWFA) {
+    const int free_ends = cfg->span == WFA_SPAN_ENDSFREE &&
+        (cfg->pattern_begin_free | cfg->pattern_end_free | cfg->text_begin_free | cfg->text_end_free) != 0;
+    if (cfg->scope != WFA_SCOPE_SCORE || cfg->heuristic != WFA_HEUR_NONE || free_ends || cfg->max_steps > 0) return -1;
+  }
   const int full = (cfg->scope == WFA_SCOPE_FULL);
   if (full && (!cigar_ops || !cigar_off || !cigar_begin || !cigar_len)) return -1;
   int64_t i;

@@ -9,8 +9,9 @@ and constructing an aligner fails loudly when the library or a HIP device is mis
 Deliberate deviations from the reference (DESIGN.md §"Deviations"):
   * invalid penalties / ends-free sizes raise ``ValueError`` where WFA2-lib calls ``exit(1)``
     (wavefront_penalties.c:101-112, wavefront_align.c:95-101);
-  * ``distance`` indel / levenshtein / linear and ``memory_mode="biwfa"`` raise
-    ``NotImplementedError`` (SURVEY.md §8 f3/f4: outside this path);
+  * ``memory_mode="biwfa"`` is built for ``scope="score"`` without heuristic, free ends or ``max_steps`` (the
+    reference returns the same scores there as in its other memory modes); its other forms raise
+    ``NotImplementedError`` (SURVEY.md §8 f4);
   * property setters re-derive the whole native configuration (the reference pokes single C fields
     and leaves derived state stale).
 """

@@ -202,7 +202,16 @@ extern "C" int wfa_hip_config_validate(const wfa_hip_config_t* c, char* err, siz
   if (c->span != WFA_SPAN_END2END && c->span != WFA_SPAN_ENDSFREE) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "unknown span");
   if (c->heuristic < WFA_HEUR_NONE || c->heuristic > WFA_HEUR_XDROP) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "unknown heuristic");
   if (c->memory_mode < WFA_MEM_HIGH || c->memory_mode > WFA_MEM_BIWFA) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "unknown memory_mode");
-  if (c->memory_mode == WFA_MEM_BIWFA) return fail_cfg(err, errlen, WFA_HIP_ENOTSUP, "memory_mode biwfa is not on the accelerated path");
+  if (c->memory_mode == WFA_MEM_BIWFA) {
+    // wavefront_bialign_compute_score (R/wavefront_bialign.c:662-702) returns the score of the optimal alignment: with
+    // scope=score, no heuristic, no free ends and no step limit the reference's outputs are those of the other memory
+    // modes (checked on every metric against the real library, tests/test_*_vs_ref.py), and the score-only kernels keep O(s) state
+    // already.  Full CIGARs need the breakpoint recursion (tie-breaks differ): not built.
+    const bool free_ends = c->span == WFA_SPAN_ENDSFREE &&
+                           (c->pattern_begin_free | c->pattern_end_free | c->text_begin_free | c->text_end_free) != 0;
+    if (c->scope != WFA_SCOPE_SCORE || c->heuristic != WFA_HEUR_NONE || free_ends || c->max_steps > 0)
+      return fail_cfg(err, errlen, WFA_HIP_ENOTSUP, "memory_mode biwfa is on the accelerated path for scope=score without heuristic, free ends or max_steps only");
+  }
   if (c->pattern_begin_free < 0 || c->pattern_end_free < 0 || c->text_begin_free < 0 || c->text_end_free < 0)
     return fail_cfg(err, errlen, WFA_HIP_EINVAL, "ends-free sizes must be >= 0");
   if (c->distance >= WFA_DIST_LINEAR && c->match < 0 && c->span == WFA_SPAN_ENDSFREE && (c->pattern_begin_free > 0 || c->text_begin_free > 0))

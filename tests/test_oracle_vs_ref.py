@@ -35,3 +35,31 @@ def test_oracle_equals_reference(cfg_idx, shape):
     r = loader.run(loader.reference(), cfg, batch)
     o = loader.run(loader.oracle(), cfg, batch)
     common.assert_same(r, o["score"], o["status"], o["cigars"], batch, f"oracle vs reference {kw}")
+
+
+BIWFA = [dict(span="end-to-end"), dict(), dict(distance="affine2p", span="end-to-end"), dict(distance="indel"),
+         dict(distance="levenshtein", span="end-to-end"), dict(distance="linear", mismatch=3, gap_extension=5),
+         dict(match=-1, span="end-to-end"), dict(wildcard="N")]
+
+
+@pytest.mark.parametrize("cfg_idx", range(len(BIWFA)))
+def test_biwfa_score_scope_equals_reference(cfg_idx):
+    """memory_mode="biwfa" is built for scope=score without heuristic / free ends / step limit: the
+    oracle must return what the real library returns in its ultralow mode, which is also what its high mode returns."""
+    kw = dict(BIWFA[cfg_idx], scope="score", memory_mode="biwfa")
+    for i, (n, L, e) in enumerate([(2000, 150, 0.02), (400, 150, 0.2), (40, 1200, 0.08), (1500, 40, 0.1)]):
+        batch = datagen.generate(n, L, e, 1900 + 7 * cfg_idx + i)
+        cfg = loader.make_config(**kw)
+        r = loader.run(loader.reference(), cfg, batch, want_cigar=False)
+        o = loader.run(loader.oracle(), cfg, batch, want_cigar=False)
+        h = loader.run(loader.reference(), loader.make_config(**dict(kw, memory_mode="high")), batch, want_cigar=False)
+        assert np.array_equal(r["score"], o["score"]) and np.array_equal(r["status"], o["status"]), kw
+        assert np.array_equal(r["score"], h["score"]) and np.array_equal(r["status"], h["status"]), kw
+
+
+def test_biwfa_outside_the_built_subset_is_refused():
+    batch = datagen.generate(4, 50, 0.05, 1)
+    for kw in (dict(scope="full"), dict(scope="score", heuristic="adaptive"), dict(scope="score", max_steps=50),
+               dict(scope="score", span="ends-free", text_end_free=5)):
+        with pytest.raises(Exception):
+            loader.run(loader.oracle(), loader.make_config(**dict(kw, memory_mode="biwfa")), batch, want_cigar=False)

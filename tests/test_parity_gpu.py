@@ -48,6 +48,9 @@ GRID += [
     dict(distance="affine", heuristic="adaptive", min_wavefront_length=5, max_distance_threshold=10, steps_between_cutoffs=3),
     dict(distance="affine", max_steps=10), dict(distance="affine2p", max_steps=25, scope="score"),
     dict(distance="affine", memory_mode="medium"), dict(distance="affine2p", memory_mode="low", span="end-to-end"),
+    # BiWFA, the built subset: score scope, no heuristic / free ends / step limit
+    dict(distance="affine", memory_mode="biwfa", scope="score", span="end-to-end"), dict(distance="affine2p", memory_mode="biwfa", scope="score"),
+    dict(distance="levenshtein", memory_mode="biwfa", scope="score", span="end-to-end"),
     dict(distance="affine", wildcard="N"),
     # single-component metrics
     dict(distance="indel"), dict(distance="indel", span="end-to-end", scope="score"),
