@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Randomised differential test of the HIP path against the oracle (development aid): random configurations drawn from
+what the library accepts, random read lengths / divergences / length differences, batches large enough to reach the
+register kernels.  python tools/gpu_fuzz.py [rounds] [seed]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import loader
+from pywfa_amd import datagen, _native
+import common
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+PEN = [(4, 6, 2), (4, 6, 2), (4, 6, 2), (4, 4, 2), (4, 6, 1), (3, 4, 1), (6, 5, 3), (5, 0, 3), (1, 1, 1), (2, 3, 1), (7, 3, 2)]
+bad_total = 0
+for it in range(rounds):
+    x, o, e = PEN[int(rng.integers(len(PEN)))]
+    kw = dict(mismatch=x, gap_opening=o, gap_extension=e, scope=str(rng.choice(["score", "full"])),
+              span=str(rng.choice(["end-to-end", "ends-free"])))
+    r = rng.random()
+    if r < 0.15: kw["heuristic"] = "adaptive"
+    elif r < 0.2: kw.update(heuristic="X-drop", xdrop=int(rng.choice([20, 100])))
+    if kw["span"] == "ends-free" and rng.random() < 0.3:
+        kw.update(pattern_begin_free=int(rng.integers(0, 9)), pattern_end_free=int(rng.integers(0, 9)),
+                  text_begin_free=int(rng.integers(0, 9)), text_end_free=int(rng.integers(0, 9)))
+    if rng.random() < 0.1: kw["distance"] = "affine2p"
+    # a batch of mixed lengths and divergences, with length differences (end-to-end gaps)
+    pats, txts = [], []
+    nparts = int(rng.integers(1, 4))
+    for part in range(nparts):
+        L = int(rng.choice([8, 30, 64, 100, 150, 150, 150, 250, 400, 512, 600]))
+        err = float(rng.choice([0.0, 0.01, 0.02, 0.02, 0.05, 0.1, 0.25]))
+        n = int(rng.choice([300, 2000, 9000])) if L <= 250 else int(rng.choice([100, 700]))
+        b = datagen.generate(n, L, err, int(rng.integers(1, 1 << 30)))
+        cut = rng.integers(0, 20, size=n) * (rng.random(n) < 0.3)
+        for i in range(n):
+            p, t = datagen.pair_strings(b, i)
+            c = int(cut[i])
+            if c and len(p) > c + 1:
+                p = p[:-c] if i % 2 else p[c:]
+            pats.append(p); txts.append(t)
+    perm = rng.permutation(len(pats))
+    batch = datagen.from_strings([pats[i] for i in perm], [txts[i] for i in perm])
+    kw = common.clamp_free(kw, batch)
+    try:
+        oc, nc = common.configs_pair(**kw)
+    except Exception as ex:
+        print("skip", kw, ex); continue
+    full = oc.scope == 1
+    t0 = time.time()
+    o_ = loader.run(loader.oracle(), oc, batch, want_cigar=full)
+    score, status, cig = common.gpu_run(nc, batch, full, bool(it % 2))
+    bad = int(((score != o_["score"]) | (status != o_["status"])).sum())
+    if full and not bad:
+        bad = sum(1 for i in range(len(score)) if bytes(cig[i]) != o_["cigars"][i])
+    bad_total += bad
+    print(f"{'OK ' if not bad else 'BAD'} round {it} n={len(score)} {kw} ({time.time() - t0:.1f}s)", flush=True)
+    if bad:
+        i = int(np.flatnonzero((score != o_["score"]) | (status != o_["status"]))[0]) if ((score != o_["score"]) | (status != o_["status"])).any() else next(i for i in range(len(score)) if bytes(cig[i]) != o_["cigars"][i])
+        print("  first bad", i, o_["score"][i], score[i], o_["status"][i], status[i], datagen.pair_strings(batch, i))
+print("TOTAL BAD", bad_total)
+sys.exit(1 if bad_total else 0)
