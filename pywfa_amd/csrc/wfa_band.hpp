@@ -50,6 +50,10 @@ struct BandArgs {
   int ef, pbf, pef, tbf, tef;  // ends-free span with these free ends (R/wavefront_termination.c:115-162)
   int h16;                // FULL: 1 = history entries are 4 x int16 (sequences < 32000 bases) instead of 4 x int32
   int debug;              // timing experiments only: 1 = skip the backtrace, 2 = skip the history stores
+  long long pb_code_ints; // piggy-back: ints of a slot reserved for the code records; then pb_event_ints of event bytes, then the runs
+  long long pb_event_ints;
+  int pb;                 // FULL + split: 1 = piggy-back history: one byte of origin codes per (step, diagonal)
+                          // instead of the offsets; the walk follows the codes and the matches are re-extended afterwards
   int seg_w;              // > 0: the history was written by wfa_seg_kernel<.., FULL>: records of seg_w entries {M, I, D, -} x
                           // int16, entry k - klo, klo = ceil((tlen - plen) / 2) - seg_w / 2
 };
@@ -218,9 +222,10 @@ __device__ void band_backtrace(const int* hist, const BandArgs& a, int plen, int
   if (nruns_out) *nruns_out = nruns;
 }
 
-template <int NCH, bool FULL, bool ADAPT, bool SEQLDS>
+template <int NCH, bool FULL, bool ADAPT, bool SEQLDS, bool PB>
 __global__ void __launch_bounds__(64)
 wfa_band_kernel(const BandArgs a) {
+  static_assert(FULL || !PB, "piggy-back history only with a history");
   typedef Band<NCH> BD;
   constexpr int W = BD::W;
   constexpr int DM = 4;  // M history depth for x : o+e : e = 2 : 4 : 1
@@ -229,8 +234,8 @@ wfa_band_kernel(const BandArgs a) {
   uint32_t* const sT = slds + a.lds_words;
   const int lane = threadIdx.x;
   int* hist = FULL ? a.hist + (long long)blockIdx.x * a.hist_stride : nullptr;
-  const int rec_ints = a.h16 ? BD::REC / 2 : BD::REC;
-  const int max_records = FULL ? (int)min((long long)INT_MAX, a.hist_stride / rec_ints) : INT_MAX;
+  const int rec_ints = PB ? W / 4 : (a.h16 ? BD::REC / 2 : BD::REC);  // piggy-back: one byte per window position
+  const int max_records = FULL ? (int)min((long long)INT_MAX, (PB ? a.pb_code_ints : a.hist_stride) / rec_ints) : INT_MAX;
 
   const bool split = FULL && a.split;
   const uint32_t nwork = a.nwork_dev ? *a.nwork_dev : a.nwork;
@@ -266,8 +271,10 @@ wfa_band_kernel(const BandArgs a) {
       // per lane: lim = min(tlen, plen + k) (in-bounds <=> offset <= lim; lim - offset = longest possible run),
       // dlim = max(tlen, plen + k) (dlim - offset = distance to the end, R/wavefront_heuristic.c:176-192)
       int kk[NCH], lim[NCH], dlim[NCH], cur[NCH], Mh[DM][NCH], Ih[NCH], Dh[NCH];
+      int code[PB ? NCH : 1];  // piggy-back: origin of M (bits 0-1: 0 mismatch, 1 deletion, 2 insertion), of I (bit 2: extension) and of D (bit 3)
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
+        if (PB) code[c] = 0;
         kk[c] = B + c * 64 + lane;
         lim[c] = min(tlen, plen + kk[c]); dlim[c] = max(tlen, plen + kk[c]);
         cur[c] = (kk[c] == 0) ? 0 : WFA_OFFSET_NULL;  // wavefront 0
@@ -279,6 +286,15 @@ wfa_band_kernel(const BandArgs a) {
       int s = 0, steps_wait = a.steps_between, dead_steps = 0;
       bool done = false;
       for (int step = 0;; ++step) {
+        if (PB) {
+          // piggy-back history of score s: the origin codes do not depend on the extension or the cut-off, and the walk
+          // starts from the codes of the END cell, so they are stored before the termination test
+          const int si = s / a.g;
+          if (si + 1 >= max_records) { fallback = true; break; }
+          uint8_t* rec = reinterpret_cast<uint8_t*>(hist) + (long long)si * W;
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) rec[kk[c] & (W - 1)] = (uint8_t)code[c];
+        }
         // ---------------- extend M[s] ----------------
         unsigned long long live[NCH];
         bool any_live = false;
@@ -382,7 +398,7 @@ wfa_band_kernel(const BandArgs a) {
         }
         // ---------------- history of score s (after the cut-off, so dropped lanes read NULL) ----------------
         const int si = s / a.g;
-        if (FULL) {
+        if (FULL && !PB) {
           if (si + 1 >= max_records) { fallback = true; break; }
           int* rec = hist + (long long)si * rec_ints;
           if (!(a.debug & 2)) {
@@ -446,6 +462,13 @@ wfa_band_kernel(const BandArgs a) {
             int m = max(nd[c], max(Mh[1][c] + 1, ni[c]));
             if (m > lim[c]) m = WFA_OFFSET_NULL;  // only M is clamped; negative values are dead already
             nm[c] = m;
+            if (PB) {
+              // the choice the backtrace would make (R/wavefront_backtrace.c:49-59: mismatch > deletion ext > open >
+              // insertion ext > open on equal offsets), taken here where the candidates are in registers
+              const int x1 = Mh[1][c] + 1;
+              const int mc = (x1 >= max(nd[c], ni[c])) ? 0 : ((nd[c] >= ni[c]) ? 1 : 2);
+              code[c] = mc | ((ie_lo >= mo_lo) ? 4 : 0) | ((de_hi >= mo_hi) ? 8 : 0);
+            }
             oob |= __ballot(max(ni[c], nd[c]) > lim[c]);
           }
           if (oob) {
@@ -520,6 +543,87 @@ wfa_band_bt_kernel(const BandArgs a) {
   a.end_state[t] = make_int4((int)begin, nruns, 0, 2);
 }
 
+// Piggy-back form of the walk (the reference: R/wavefront_backtrace_offload.c, R/wavefront_pcigar.c:204-266).
+// The history holds one byte of origin codes per (step, diagonal) — no offsets — so the walk is one byte load per
+// hop and yields the edit events in reverse; the op string is then unpacked forwards, re-extending the matches after
+// every event that lands in M against the packed sequences (a wavefront cell is always extended to its end, so the
+// run after an event is the whole common prefix).  One thread per alignment.
+__device__ __forceinline__ int pb_lcp(const uint32_t* __restrict__ P, const uint32_t* __restrict__ T, int v, int h, int maxn) {
+  int n = 0;
+  while (n < maxn) {
+    const int vv = v + n, hh = h + n;
+    const int pi = vv >> 4, ti = hh >> 4;
+    const uint32_t p0 = P[pi], p1 = P[pi + 1], p2 = P[pi + 2], t0 = T[ti], t1 = T[ti + 1], t2 = T[ti + 2];
+    const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)vv << 1) ^ __builtin_amdgcn_alignbit(t1, t0, (uint32_t)hh << 1);
+    const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, (uint32_t)vv << 1) ^ __builtin_amdgcn_alignbit(t2, t1, (uint32_t)hh << 1);
+    int m = xl ? (__builtin_ctz(xl) >> 1) : (xh ? 16 + (__builtin_ctz(xh) >> 1) : 32);
+    m = min(m, maxn - n);
+    n += m;
+    if (m < 32) break;
+  }
+  return n;
+}
+
+template <int NCH>
+__global__ void __launch_bounds__(64)
+wfa_band_pb_bt_kernel(const BandArgs a) {
+  constexpr int W = 64 * NCH;
+  const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+  if (t >= a.nwork) return;
+  const int4 es = a.end_state[t];
+  if (!es.w) return;
+  const uint32_t wi = a.work_begin + t;
+  const uint32_t pair = a.worklist ? a.worklist[wi] : wi;
+  const WfaPairMeta pm = a.meta[pair];
+  const int plen = pm.plen, tlen = pm.tlen;
+  int* hist = a.hist + (long long)t * a.hist_stride;
+  const uint8_t* codes = reinterpret_cast<const uint8_t*>(hist);
+  uint8_t* ev = reinterpret_cast<uint8_t*>(hist + a.pb_code_ints);
+  uint32_t* runs = reinterpret_cast<uint32_t*>(hist + a.pb_code_ints + a.pb_event_ints);
+  const int ev_cap = (int)min((long long)INT_MAX, a.pb_event_ints * 4);
+  const int dx = a.x / a.g, doe = a.oe / a.g, de = a.e / a.g;
+  // ---- walk the codes back from the end cell (R/wavefront_backtrace.c:320-529 with the choices made at compute time)
+  int si = es.x / a.g, k = es.y, comp = 0, nev = 0;
+  while (si > 0 && nev < ev_cap) {
+    const int cd = codes[(long long)si * W + (k & (W - 1))];
+    if (comp == 0) {
+      const int mc = cd & 3;
+      if (mc == 0) { ev[nev++] = (uint8_t)('X' | 0x80); si -= dx; }
+      else if (mc == 1) { ev[nev++] = (uint8_t)('D' | 0x80); ++k; if (cd & 8) { si -= de; comp = 2; } else si -= doe; }
+      else { ev[nev++] = (uint8_t)('I' | 0x80); --k; if (cd & 4) { si -= de; comp = 1; } else si -= doe; }
+    } else if (comp == 1) {
+      ev[nev++] = (uint8_t)'I'; --k;
+      if (cd & 4) si -= de; else { si -= doe; comp = 0; }
+    } else {
+      ev[nev++] = (uint8_t)'D'; ++k;
+      if (cd & 8) si -= de; else { si -= doe; comp = 0; }
+    }
+  }
+  // ---- unpack forwards from the cell of wavefront 0 on diagonal k (ends-free: offset max(k, 0), R/wavefront_aligner.c:259-302)
+  const uint32_t* P = a.words + pm.p_woff;
+  const uint32_t* T = a.words + pm.t_woff;
+  int h = max(k, 0), v = h - k;
+  int nruns = 0;
+  long long total = 0;
+  auto emit = [&](int op, int n) {
+    if (n <= 0) return;
+    total += n;
+    if (nruns > 0 && (int)(runs[nruns - 1] & 0xFFu) == op) runs[nruns - 1] += (uint32_t)n << 8;
+    else runs[nruns++] = ((uint32_t)n << 8) | (uint32_t)op;
+  };
+  emit('I', h); emit('D', v);
+  { const int n = pb_lcp(P, T, v, h, min(plen - v, tlen - h)); emit('M', n); v += n; h += n; }
+  for (int e = nev - 1; e >= 0; --e) {
+    const int op = ev[e] & 0x7F;
+    if (op == 'X') { emit('X', 1); ++v; ++h; }
+    else if (op == 'I') { emit('I', 1); ++h; }
+    else { emit('D', 1); ++v; }
+    if (ev[e] & 0x80) { const int n = pb_lcp(P, T, v, h, min(plen - v, tlen - h)); emit('M', n); v += n; h += n; }
+  }
+  emit('I', tlen - h); emit('D', plen - v);
+  a.end_state[t] = make_int4((int)((long long)plen + tlen - total), nruns, 1, 2);  // .z = 1: runs in forward order
+}
+
 // One wave per alignment: run r (r = 0 is the LAST run of the op string) covers
 // [end - sum(len[0..r]), end - sum(len[0..r-1])); lanes take 64 runs at a time, positions come from a wave
 // prefix sum, short runs are written by their lane, long ones by the whole wave.
@@ -534,18 +638,21 @@ wfa_band_expand_kernel(const BandArgs a) {
   const uint32_t pair = a.worklist ? a.worklist[wi] : wi;
   const WfaPairMeta pm = a.meta[pair];
   const uint32_t* top = reinterpret_cast<const uint32_t*>(a.hist + (long long)t * a.hist_stride) + a.hist_stride - 1;
+  const bool fwd = es.z == 1;  // piggy-back unpack: runs in forward order, from the start of the op string
+  const uint32_t* fruns = reinterpret_cast<const uint32_t*>(a.hist + (long long)t * a.hist_stride + a.pb_code_ints + a.pb_event_ints);
   uint8_t* buf = a.cigar_ops + a.cigar_off[pair];
   const int nruns = es.y;
   int end = pm.plen + pm.tlen;
+  int start = es.x;
   for (int r0 = 0; r0 < nruns; r0 += 64) {
     const int r = r0 + lane;
-    const uint32_t rec = (r < nruns) ? *(top - r) : 0u;
+    const uint32_t rec = (r < nruns) ? (fwd ? fruns[r] : *(top - r)) : 0u;
     const int len = (int)(rec >> 8);
     const uint8_t op = (uint8_t)(rec & 0xFFu);
     int cum = len;  // inclusive prefix sum over the lanes
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(cum, d, 64); if (lane >= d) cum += o; }
-    const int pos = end - cum;  // first byte of this lane's run
+    const int pos = fwd ? start + cum - len : end - cum;  // first byte of this lane's run
     const bool is_long = len > 16;
     for (int i = 0; i < 16; ++i) if (!is_long && i < len) buf[pos + i] = op;
     unsigned long long lm = __ballot(is_long);
@@ -557,6 +664,7 @@ wfa_band_expand_kernel(const BandArgs a) {
       for (int i = lane; i < llen; i += 64) buf[lpos + i] = lop;
     }
     end -= __builtin_amdgcn_readlane(cum, 63);
+    start += __builtin_amdgcn_readlane(cum, 63);
   }
   if (lane == 0) {
     a.cigar_begin[pair] = a.cigar_off[pair] + es.x;
@@ -614,7 +722,11 @@ wfa_seg_expand_kernel(const BandArgs a) {
 inline int launch_band_bt(const BandArgs& a, int nch, hipStream_t stream) {
   const unsigned grid = (a.nwork + 63u) / 64u;
   if (grid == 0) return 0;
-  if (nch == 1) hipLaunchKernelGGL((wfa_band_bt_kernel<1>), dim3(grid), dim3(64), 0, stream, a);
+  if (a.pb) {
+    if (nch == 1) hipLaunchKernelGGL((wfa_band_pb_bt_kernel<1>), dim3(grid), dim3(64), 0, stream, a);
+    else if (nch == 2) hipLaunchKernelGGL((wfa_band_pb_bt_kernel<2>), dim3(grid), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL((wfa_band_pb_bt_kernel<4>), dim3(grid), dim3(64), 0, stream, a);
+  } else if (nch == 1) hipLaunchKernelGGL((wfa_band_bt_kernel<1>), dim3(grid), dim3(64), 0, stream, a);
   else if (nch == 2) hipLaunchKernelGGL((wfa_band_bt_kernel<2>), dim3(grid), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL((wfa_band_bt_kernel<4>), dim3(grid), dim3(64), 0, stream, a);
   if (hipGetLastError() != hipSuccess) return -1;
@@ -634,8 +746,11 @@ inline bool band_supported(const WfaDevConfig& c, int ncomp) {
 template <int NCH, bool FULL, bool ADAPT>
 static int launch_band_t(const BandArgs& a, bool seqlds, long long grid, hipStream_t stream) {
   const size_t smem = seqlds ? (size_t)a.lds_words * 2 * sizeof(uint32_t) : 0;
-  if (seqlds) hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, true>), dim3((unsigned)grid), dim3(64), smem, stream, a);
-  else hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, false>), dim3((unsigned)grid), dim3(64), 0, stream, a);
+  if (FULL && a.pb) {  // piggy-back history (split launches of long reads)
+    if (seqlds) hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, true, FULL>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+    else hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, false, FULL>), dim3((unsigned)grid), dim3(64), 0, stream, a);
+  } else if (seqlds) hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, true, false>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+  else hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, false, false>), dim3((unsigned)grid), dim3(64), 0, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

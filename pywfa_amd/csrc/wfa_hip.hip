@@ -679,6 +679,11 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     // band history: fixed-stride records per score step, one slice per wave
     long long band_grid[3] = {0, 0, 0};
     int64_t band_stride[3] = {0, 0, 0};
+    // memory_mode medium / low (the reference's piggy-back backtrace, R/wavefront_backtrace_offload.c): the split stage
+    // keeps one byte of origin codes per (step, diagonal) instead of the offsets and re-extends the matches afterwards
+    const int pb_env = env_int("WFA_HIP_BAND_PB", -1);
+    const bool pb_mode = full && (pb_env >= 0 ? pb_env != 0 : (al->cfg.memory_mode == WFA_MEM_MED || al->cfg.memory_mode == WFA_MEM_LOW));
+    int64_t pb_code_ints = 0, pb_event_ints = 0, pb_stride = 0;
     for (int i = 0; i < n_stages; ++i) {
       // 4x more waves than a CU holds at once: waves retire one after the other (oldest-first issue) and the
       // dispatcher refills the CU, instead of a tail of lone waves (C1 +20 %, C3 +13 %)
@@ -696,7 +701,12 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         need = std::max(need, (size_t)grid * band_stride[i] * 4);
         if (i == 0 && !use_fast && !use_segfull && b->max_len > 1000 && env_int("WFA_HIP_BAND_NO_SPLIT", 0) == 0) {
           // split backtrace: one history slot per pair of a launch; take up to 4x the wave count (or all pairs)
-          const int64_t slot_bytes = band_stride[i] * 4 + 16;
+          if (pb_mode) {
+            pb_code_ints = ((int64_t)records * (64 * band_nch[i] / 4) + 63) & ~63ll;  // one byte per window position and step
+            pb_event_ints = (((int64_t)records + 3) / 4 + 63) & ~63ll;                 // one byte per edit event (<= one per step)
+            pb_stride = pb_code_ints + pb_event_ints + ((2 * (int64_t)records + 8 + 63) & ~63ll);  // + run records
+          }
+          const int64_t slot_bytes = (pb_mode ? pb_stride : band_stride[i]) * 4 + 16;
           int64_t pairs = std::min<int64_t>(in_n, (int64_t)al->cu_count * 32 * env_int("WFA_HIP_BAND_SPLIT_ROUNDS", 4));
           while (pairs > 1 && pairs * slot_bytes > budget) pairs = (pairs + 1) / 2;
           need = std::max(need, (size_t)(pairs * slot_bytes));
@@ -830,14 +840,16 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       if (split) {
         // history slot per PAIR: as many pairs per launch as the workspace holds; the walks of a launch run
         // afterwards in a thread-per-alignment kernel
-        const int64_t slot_bytes = band_stride[i] * 4 + (int64_t)sizeof(int4);
+        const int64_t slot_ints = (pb_mode && pb_stride) ? pb_stride : band_stride[i];
+        if (pb_mode && pb_stride) { ba.pb = 1; ba.hist_stride = pb_stride; ba.pb_code_ints = pb_code_ints; ba.pb_event_ints = pb_event_ints; }
+        const int64_t slot_bytes = slot_ints * 4 + (int64_t)sizeof(int4);
         int64_t per_launch = (int64_t)(al->ws_bytes / (size_t)slot_bytes);
         per_launch = std::min<int64_t>(per_launch, in_n);
         const int64_t full_grid = (int64_t)al->cu_count * env_int("WFA_HIP_BAND_WAVES_PER_CU", 128);
         if (per_launch > full_grid) per_launch = (per_launch / full_grid) * full_grid;  // whole rounds of waves
         if (per_launch < 1) { al->err = "band history does not fit"; return WFA_HIP_EDEVICE; }
         ba.split = 1;
-        ba.end_state = reinterpret_cast<int4*>(reinterpret_cast<char*>(al->ws) + (size_t)per_launch * band_stride[i] * 4);
+        ba.end_state = reinterpret_cast<int4*>(reinterpret_cast<char*>(al->ws) + (size_t)per_launch * slot_ints * 4);
         for (int64_t w0 = 0; w0 < in_n; w0 += per_launch) {
           const uint32_t cnt = (uint32_t)std::min<int64_t>(per_launch, in_n - w0);
           ba.work_begin = (uint32_t)w0; ba.nwork = cnt;

@@ -242,3 +242,21 @@ def test_segmented_full_cigar_in_several_launches(gpu, span, monkeypatch):
         o = loader.run(loader.oracle(), oc, parts[0])
         score, status, cigars = common.gpu_run(nc, parts[0], True, True)
         common.assert_same(o, score, status, cigars, parts[0], f"segmented full {span} {env}")
+
+
+@pytest.mark.parametrize("kw", [dict(span="end-to-end", memory_mode="medium"), dict(span="end-to-end", memory_mode="low", heuristic="adaptive"),
+                                dict(memory_mode="medium"), dict(memory_mode="low", span="ends-free", pattern_begin_free=40, pattern_end_free=30,
+                                                                 text_begin_free=25, text_end_free=35, heuristic="adaptive")])
+def test_piggyback_history_gives_the_same_cigars(gpu, kw):
+    """memory_mode medium / low: long reads keep one byte of origin codes per (step, diagonal) instead of the offsets and
+    the op string is unpacked by re-extending the matches; the reference returns the same alignments in
+    all its memory modes, and so must this."""
+    for i, (n, L, e) in enumerate([(700, 1500, 0.06), (300, 4000, 0.08), (120, 10000, 0.08), (400, 2500, 0.01)]):
+        batch = datagen.generate(n, L, e, 8800 + i)
+        kw2 = common.clamp_free(dict(kw, scope="full"), batch)
+        oc, nc = common.configs_pair(**kw2)
+        o = loader.run(loader.oracle(), oc, batch)
+        oh = loader.run(loader.oracle(), common.configs_pair(**dict(kw2, memory_mode="high"))[0], batch)
+        assert o["cigars"] == oh["cigars"]
+        score, status, cigars = common.gpu_run(nc, batch, True, i % 2 == 0)
+        common.assert_same(o, score, status, cigars, batch, f"piggy-back {kw2} L={L}")
