@@ -25,23 +25,28 @@ for it in range(rounds):
         kw.update(pattern_begin_free=int(rng.integers(0, 9)), pattern_end_free=int(rng.integers(0, 9)),
                   text_begin_free=int(rng.integers(0, 9)), text_end_free=int(rng.integers(0, 9)))
     if rng.random() < 0.1: kw["distance"] = "affine2p"
+    if rng.random() < 0.3: kw["memory_mode"] = str(rng.choice(["medium", "low"]))
     # a batch of mixed lengths and divergences, with length differences (end-to-end gaps)
     pats, txts = [], []
     nparts = int(rng.integers(1, 4))
     for part in range(nparts):
         L = int(rng.choice([8, 30, 64, 100, 150, 150, 150, 250, 400, 512, 600]))
         err = float(rng.choice([0.0, 0.01, 0.02, 0.02, 0.05, 0.1, 0.25]))
-        n = int(rng.choice([300, 2000, 9000])) if L <= 250 else int(rng.choice([100, 700]))
+        n = int(rng.choice([300, 2000, 9000, 9000, 70000])) if L <= 250 else int(rng.choice([100, 700]))
+        if it % 7 == 3 and part == 0: L, n = int(rng.choice([1500, 3000, 6000])), int(rng.choice([60, 300]))  # long reads: banded kernel, split launches
         b = datagen.generate(n, L, err, int(rng.integers(1, 1 << 30)))
         cut = rng.integers(0, 20, size=n) * (rng.random(n) < 0.3)
-        for i in range(n):
+        for i in (range(n) if n <= 9000 else range(0)):
             p, t = datagen.pair_strings(b, i)
             c = int(cut[i])
             if c and len(p) > c + 1:
                 p = p[:-c] if i % 2 else p[c:]
             pats.append(p); txts.append(t)
-    perm = rng.permutation(len(pats))
-    batch = datagen.from_strings([pats[i] for i in perm], [txts[i] for i in perm])
+    if pats:
+        perm = rng.permutation(len(pats))
+        batch = datagen.from_strings([pats[i] for i in perm], [txts[i] for i in perm])
+    else:
+        batch = b  # one large batch as generated (exercises the pilot that picks the first segment width)
     kw = common.clamp_free(kw, batch)
     try:
         oc, nc = common.configs_pair(**kw)
