@@ -714,39 +714,79 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       }
       band_grid[i] = grid;
     }
-    int64_t segfull_slot_ints = 0, segfull_per_launch = 0;
+    // The narrowest band that keeps most pairs is the cheapest start; it depends on the divergence of the batch (16
+    // lanes up to ~3 %, 32 up to ~6 %, 64 up to ~10 %).  A pilot on the first 8192 pairs (score-only kernels, one-round
+    // form: a name of its own in a profile) decides once per batch: b->stage_pick = 16 / 32 / 64, or 128 = none of them.
+    auto pick_first_width = [&]() -> int {
+      if (b->stage_pick != 0) return WFA_HIP_OK;
+      const uint32_t np = std::min<uint32_t>(8192u, in_n);
+      uint32_t* plist = b->d_fb_list2[0];
+      uint32_t* pcount = b->d_counters + 4;
+      b->stage_pick = 128;
+      for (int w = 16; w <= 64; w *= 2) {
+        HIP_TRY(al, hipMemsetAsync(pcount, 0, sizeof(uint32_t), stream));
+        if (wfa::launch_seg(al->dcfg, al->cu_count, stream, b->d_words, b->d_meta, in_list, nullptr, np, b->d_score, b->d_status,
+                            plist, pcount, w == 16 ? 2 : (w == 32 ? 4 : 5)) != 0) { al->err = "pilot launch failed"; return WFA_HIP_EDEVICE; }
+        uint32_t handed = 0;
+        HIP_TRY(al, hipMemcpyAsync(&handed, pcount, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(al, hipStreamSynchronize(stream));
+        if (handed * 5u <= np * 2u) { b->stage_pick = w; break; }  // at most 40 % handed on
+      }
+      HIP_TRY(al, hipMemsetAsync(pcount, 0, sizeof(uint32_t), stream));
+      return WFA_HIP_OK;
+    };
+    // full CIGARs of short reads: 16-lane segments over the whole batch (history slot per pair, several launches), then
+    // 32- and 64-lane segments over what was handed on (device-side counts: slots for 1/8 resp. 1/32 of the batch)
+    int64_t segfull_slot_ints[3] = {0, 0, 0}, segfull_cap[3] = {0, 0, 0};
+    int segfull_w[3] = {16, 32, 64};
+    int n_segfull = use_segfull ? 3 : 0;
+    if (use_segfull && in_n >= 65536u && getenv("WFA_HIP_SEGFULL_STAGES") == nullptr) {
+      const int prc = pick_first_width();
+      if (prc != WFA_HIP_OK) return prc;
+      n_segfull = 0;
+      for (int w = 16; w <= 64; w *= 2) if (w >= b->stage_pick) segfull_w[n_segfull++] = w;
+    } else if (use_segfull) {
+      n_segfull = std::max(0, std::min(3, env_int("WFA_HIP_SEGFULL_STAGES", 3)));
+    }
     if (use_segfull) {
-      segfull_slot_ints = (int64_t)wfa::seg_full_records(al->dcfg) * 32;  // records of 16 entries x 8 bytes
-      const int64_t slot_bytes = segfull_slot_ints * 4 + (int64_t)sizeof(int4);
-      segfull_per_launch = std::min<int64_t>(in_n, std::min<int64_t>((int64_t)env_int("WFA_HIP_SEGFULL_PAIRS", 2000000), free_budget(al) / slot_bytes));
-      if (segfull_per_launch < 1) segfull_per_launch = 1;
-      need = std::max(need, (size_t)(segfull_per_launch * slot_bytes));
+      for (int i = 0; i < n_segfull; ++i) {
+        segfull_slot_ints[i] = (int64_t)wfa::seg_full_records(al->dcfg, segfull_w[i]) * segfull_w[i] * 2;  // records of w entries x 8 bytes
+        const int64_t slot_bytes = segfull_slot_ints[i] * 4 + (int64_t)sizeof(int4);
+        int64_t want = (i == 0) ? std::min<int64_t>((int64_t)env_int("WFA_HIP_SEGFULL_PAIRS", 2000000), std::max<int64_t>(1, ((int64_t)8 << 30) / slot_bytes))
+                                : std::max<int64_t>(4096, (int64_t)in_n / (i == 1 ? 8 : 32));
+        segfull_cap[i] = std::max<int64_t>(1, std::min<int64_t>(in_n, std::min<int64_t>(want, free_budget(al) / slot_bytes)));
+        need = std::max(need, (size_t)(segfull_cap[i] * slot_bytes));
+      }
     }
     int rc = ensure_ws(al, need);
     if (rc != WFA_HIP_OK) return rc;
 
-    if (use_segfull) {
+    for (int sf = 0; sf < n_segfull; ++sf) {
       uint32_t* out_list = b->d_fb_list2[out_sel];
       uint32_t* out_count = b->d_counters + 4 + out_sel;
       if (!first_stage) HIP_TRY(al, hipMemsetAsync(out_count, 0, sizeof(uint32_t), stream));
       wfa::FastArgs fa;
       memset(&fa, 0, sizeof(fa));
-      fa.words = b->d_words; fa.meta = b->d_meta; fa.worklist = in_list; fa.nwork_dev = nullptr;
+      fa.words = b->d_words; fa.meta = b->d_meta; fa.worklist = in_list; fa.nwork_dev = in_count;
       fa.score = b->d_score; fa.status = b->d_status; fa.fb_list = out_list; fa.fb_count = out_count;
-      fa.hist = al->ws; fa.hist_stride = segfull_slot_ints;
-      fa.end_state = reinterpret_cast<int4*>(reinterpret_cast<char*>(al->ws) + (size_t)segfull_per_launch * segfull_slot_ints * 4);
+      fa.hist = al->ws; fa.hist_stride = segfull_slot_ints[sf];
+      fa.end_state = reinterpret_cast<int4*>(reinterpret_cast<char*>(al->ws) + (size_t)segfull_cap[sf] * segfull_slot_ints[sf] * 4);
       wfa::BandArgs ba;
       memset(&ba, 0, sizeof(ba));
       ba.meta = b->d_meta; ba.worklist = in_list; ba.words = b->d_words;
       ba.cigar_ops = b->d_ops; ba.cigar_off = b->d_cigar_off; ba.cigar_begin = b->d_cigar_begin; ba.cigar_len = b->d_cigar_len;
       ba.g = wfa::gcd_int(wfa::gcd_int(al->dcfg.x, al->dcfg.o1 + al->dcfg.e1), al->dcfg.e1);
       ba.x = al->dcfg.x; ba.oe = al->dcfg.o1 + al->dcfg.e1; ba.e = al->dcfg.e1;
-      ba.hist = al->ws; ba.hist_stride = segfull_slot_ints; ba.end_state = fa.end_state;
-      ba.split = 1; ba.h16 = 1; ba.seg_w = 16;
-      for (int64_t w0 = 0; w0 < in_n; w0 += segfull_per_launch) {
-        const uint32_t cnt = (uint32_t)std::min<int64_t>(segfull_per_launch, in_n - w0);
+      ba.hist = al->ws; ba.hist_stride = segfull_slot_ints[sf]; ba.end_state = fa.end_state;
+      ba.split = 1; ba.h16 = 1; ba.seg_w = segfull_w[sf];
+      // (first stage: the host knows the count and walks it in launches of `cap` pairs; later stages: one launch over
+      // the device-side list, slots for `cap` of its pairs)
+      const int64_t total = (in_count == nullptr) ? (int64_t)in_n : segfull_cap[sf];
+      for (int64_t w0 = 0; w0 < total; w0 += segfull_cap[sf]) {
+        const uint32_t cnt = (uint32_t)std::min<int64_t>(segfull_cap[sf], total - w0);
         fa.work_begin = (uint32_t)w0; fa.nwork = cnt;
-        if (wfa::launch_seg_full(al->dcfg, al->cu_count, stream, fa) != 0) { al->err = "segmented kernel launch failed"; return WFA_HIP_EDEVICE; }
+        if (in_count != nullptr) HIP_TRY(al, hipMemsetAsync(fa.end_state, 0, (size_t)cnt * sizeof(int4), stream));
+        if (wfa::launch_seg_full(al->dcfg, al->cu_count, stream, fa, segfull_w[sf]) != 0) { al->err = "segmented kernel launch failed"; return WFA_HIP_EDEVICE; }
         ba.work_begin = (uint32_t)w0; ba.nwork = cnt;
         if (wfa::launch_band_bt(ba, 1, stream) != 0) { al->err = "backtrace launch failed"; return WFA_HIP_EDEVICE; }
       }
@@ -760,26 +800,8 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       const char* stages_env = getenv("WFA_HIP_FAST_STAGES");
       const char* stages = (stages_env && *stages_env) ? stages_env : "689";
       if (!(stages_env && *stages_env) && in_n >= 65536u && in_count == nullptr) {
-        // The narrowest band that keeps most pairs is the cheapest start; it depends on the divergence of the batch
-        // (16 lanes up to ~3 %, 32 up to ~6 %).  A pilot on the first 8192 pairs decides once per batch (~50 us).
-        if (b->stage_pick == 0) {
-          const uint32_t np = 8192u;
-          uint32_t* plist = b->d_fb_list2[0];
-          uint32_t* pcount = b->d_counters + 4;
-          b->stage_pick = 64;
-          for (int w = 16; w <= 32; w *= 2) {
-            // (variants 2 / 4, the one-round form: same verdicts as 6 / 8, and a name of its own in a profile)
-            HIP_TRY(al, hipMemsetAsync(pcount, 0, sizeof(uint32_t), stream));
-            if (wfa::launch_seg(al->dcfg, al->cu_count, stream, b->d_words, b->d_meta, in_list, nullptr, np, b->d_score, b->d_status,
-                                plist, pcount, w == 16 ? 2 : 4) != 0) { al->err = "pilot launch failed"; return WFA_HIP_EDEVICE; }
-            uint32_t handed = 0;
-            HIP_TRY(al, hipMemcpyAsync(&handed, pcount, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(al, hipStreamSynchronize(stream));
-            if (handed * 5u <= np * 2u) { b->stage_pick = w; break; }  // at most 40 % handed on
-          }
-          HIP_TRY(al, hipMemsetAsync(pcount, 0, sizeof(uint32_t), stream));
-        }
-        stages = (b->stage_pick == 16) ? "689" : (b->stage_pick == 32) ? "89" : "9";
+        { const int prc = pick_first_width(); if (prc != WFA_HIP_OK) return prc; }
+        stages = (b->stage_pick == 16) ? "689" : (b->stage_pick == 32) ? "89" : "9";  // (128: 64 lanes still take the pairs that fit)
       }
       int variants[6] = {-1, -1, -1, -1, -1, -1};
       int nv = 0;

@@ -68,7 +68,27 @@ wfa_seg_kernel(const FastArgs a) {
   // my diagonal is k = l - H + c, c the centre of the pair's band (set when a pair is taken);
   // kb = pbias - k: pattern coordinate of offset x on my diagonal is x + kb
   int kb = pbias - (l - H);
-  const uint32_t nwork = __builtin_amdgcn_readfirstlane(a.nwork_dev ? *a.nwork_dev : a.nwork);  // keep everything derived from it scalar
+  uint32_t nwork = __builtin_amdgcn_readfirstlane(a.nwork_dev ? *a.nwork_dev : a.nwork);  // keep everything derived from it scalar
+  if (FULL && a.nwork_dev) {
+    // leftovers of a previous stage, counted on the device: a.nwork history slots were reserved; what does not fit is
+    // handed on unseen
+    const uint32_t cap = a.nwork;
+    if (nwork > cap) {
+      for (uint32_t i = cap + blockIdx.x * 64u + threadIdx.x; i < nwork + 63u; i += gridDim.x * 64u) {
+        const bool mine = i < nwork;
+        const unsigned long long bm = __ballot(mine);
+        uint32_t slot = 0;
+        if (threadIdx.x == 0 && bm) slot = atomicAdd(a.fb_count, (uint32_t)__builtin_popcountll(bm));
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (mine) {
+          const uint32_t pid = a.worklist[a.work_begin + i];
+          a.fb_list[slot + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))] = pid;
+          a.status[pid] = WFA_INTERNAL_FALLBACK;
+        }
+      }
+      nwork = cap;
+    }
+  }
   const uint32_t per = __builtin_amdgcn_readfirstlane((nwork + gridDim.x - 1) / gridDim.x);  // (the division runs on the VALU)
   const unsigned long long begin64 = (unsigned long long)blockIdx.x * per;
   if (begin64 >= nwork) return;
@@ -385,8 +405,15 @@ inline void launch_seg_shape(int w, bool lazy, dim3 g, hipStream_t stream, const
   else hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 16, false, false>), g, blk, 0, stream, a);
 }
 
-// full-CIGAR launch: 16-lane segments, items [work_begin, work_begin + nwork) of the work list, one history slot each
-inline int launch_seg_full(const WfaDevConfig& c, int cu_count, hipStream_t stream, FastArgs a) {
+// full-CIGAR launch with segments of `w` lanes: items [work_begin, work_begin + nwork) of the work list, one history slot
+// each (a.nwork_dev set: the list is a previous stage's, a.nwork slots were reserved)
+template <int X, int OE, int E>
+inline void launch_seg_full_shape(int w, dim3 g, hipStream_t stream, const FastArgs& a) {
+  if (w == 32) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 32, false, true>), g, dim3(64), 0, stream, a);
+  else if (w == 64) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 64, false, true>), g, dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 16, false, true>), g, dim3(64), 0, stream, a);
+}
+inline int launch_seg_full(const WfaDevConfig& c, int cu_count, hipStream_t stream, FastArgs a, int w) {
   int X, OE, E;
   if (!seg_shape(c, &X, &OE, &E)) return -1;
   a.g = gcd_int(gcd_int(c.x, c.o1 + c.e1), c.e1);
@@ -394,17 +421,17 @@ inline int launch_seg_full(const WfaDevConfig& c, int cu_count, hipStream_t stre
   const int per_cu = (env && *env) ? atoi(env) : 256;
   long long grid = std::min<long long>((long long)cu_count * per_cu, (long long)a.nwork);
   if (grid < 1) grid = 1;
-#define WFA_SEG_LAUNCH_FULL(x, oe, e) if (X == x && OE == oe && E == e) hipLaunchKernelGGL((wfa_seg_kernel<x, oe, e, 16, false, true>), dim3((unsigned)grid), dim3(64), 0, stream, a);
+#define WFA_SEG_LAUNCH_FULL(x, oe, e) if (X == x && OE == oe && E == e) launch_seg_full_shape<x, oe, e>(w, dim3((unsigned)grid), stream, a);
   WFA_SEG_SHAPES(WFA_SEG_LAUNCH_FULL)
 #undef WFA_SEG_LAUNCH_FULL
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// steps a 16-lane segment can take before it hands its pair on (+ 1), i.e. the records a history slot needs
-inline int seg_full_records(const WfaDevConfig& c) {
+// steps a w-lane segment can take before it hands its pair on (+ 1), i.e. the records a history slot needs
+inline int seg_full_records(const WfaDevConfig& c, int w) {
   int X, OE, E;
   if (!seg_shape(c, &X, &OE, &E)) return 0;
-  return 2 * (OE - E) + E * (16 + 1) + 3;
+  return 2 * (OE - E) + E * (w + 1) + 3;
 }
 
 // variant 6/7/8/9 = segments of 16/8/32/64 lanes (4/8/2/1 alignments per wave) with the two-round extension,
