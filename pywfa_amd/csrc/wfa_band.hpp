@@ -23,6 +23,9 @@
 
 namespace wfa {
 
+// penalty shapes (x, o + e, e) / gcd the banded kernel is instantiated for: pywfa's 4/6/2 and the presets 4/4/2, 4/6/1, 3/4/1
+#define WFA_BAND_SHAPES(F) F(2, 4, 1) F(2, 3, 1) F(4, 7, 1) F(3, 5, 1)
+
 struct BandArgs {
   const uint32_t* words;
   const WfaPairMeta* meta;
@@ -222,13 +225,13 @@ __device__ void band_backtrace(const int* hist, const BandArgs& a, int plen, int
   if (nruns_out) *nruns_out = nruns;
 }
 
-template <int NCH, bool FULL, bool ADAPT, bool SEQLDS, bool PB>
+template <int NCH, bool FULL, bool ADAPT, bool SEQLDS, bool PB, int X, int OE, int E>
 __global__ void __launch_bounds__(64)
 wfa_band_kernel(const BandArgs a) {
   static_assert(FULL || !PB, "piggy-back history only with a history");
   typedef Band<NCH> BD;
   constexpr int W = BD::W;
-  constexpr int DM = 4;  // M history depth for x : o+e : e = 2 : 4 : 1
+  constexpr int DM = (X > OE) ? X : OE;  // M history depth; (X, OE, E) = (x, o + e, e) / g
   extern __shared__ uint32_t slds[];
   uint32_t* const sP = slds;
   uint32_t* const sT = slds + a.lds_words;
@@ -270,7 +273,7 @@ wfa_band_kernel(const BandArgs a) {
     if (!fallback) {
       // per lane: lim = min(tlen, plen + k) (in-bounds <=> offset <= lim; lim - offset = longest possible run),
       // dlim = max(tlen, plen + k) (dlim - offset = distance to the end, R/wavefront_heuristic.c:176-192)
-      int kk[NCH], lim[NCH], dlim[NCH], cur[NCH], Mh[DM][NCH], Ih[NCH], Dh[NCH];
+      int kk[NCH], lim[NCH], dlim[NCH], cur[NCH], Mh[DM][NCH], Ih[E][NCH], Dh[E][NCH];
       int code[PB ? NCH : 1];  // piggy-back: origin of M (bits 0-1: 0 mismatch, 1 deletion, 2 insertion), of I (bit 2: extension) and of D (bit 3)
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
@@ -279,7 +282,8 @@ wfa_band_kernel(const BandArgs a) {
         lim[c] = min(tlen, plen + kk[c]); dlim[c] = max(tlen, plen + kk[c]);
         cur[c] = (kk[c] == 0) ? 0 : WFA_OFFSET_NULL;  // wavefront 0
         if (a.ef && kk[c] >= -a.pbf && kk[c] <= a.tbf) cur[c] = max(kk[c], 0);
-        Ih[c] = WFA_OFFSET_NULL; Dh[c] = WFA_OFFSET_NULL;
+#pragma unroll
+        for (int j = 0; j < E; ++j) { Ih[j][c] = WFA_OFFSET_NULL; Dh[j][c] = WFA_OFFSET_NULL; }
 #pragma unroll
         for (int j = 0; j < DM; ++j) Mh[j][c] = WFA_OFFSET_NULL;
       }
@@ -385,7 +389,7 @@ wfa_band_kernel(const BandArgs a) {
 #pragma unroll
                   for (int c = 0; c < NCH; ++c) {
                     const bool drop = kk[c] < new_lo || kk[c] > new_hi;
-                    if (drop) { cur[c] = WFA_OFFSET_NULL; Ih[c] = WFA_OFFSET_NULL; Dh[c] = WFA_OFFSET_NULL; }
+                    if (drop) { cur[c] = WFA_OFFSET_NULL; Ih[0][c] = WFA_OFFSET_NULL; Dh[0][c] = WFA_OFFSET_NULL; }
                   }
                 }
               }
@@ -406,10 +410,10 @@ wfa_band_kernel(const BandArgs a) {
 #pragma unroll
               for (int c = 0; c < NCH; ++c)
                 reinterpret_cast<short4*>(rec)[kk[c] & (W - 1)] =
-                    make_short4((short)sat16(cur[c]), (short)sat16(Ih[c]), (short)sat16(Dh[c]), (short)B);
+                    make_short4((short)sat16(cur[c]), (short)sat16(Ih[0][c]), (short)sat16(Dh[0][c]), (short)B);
             } else {
 #pragma unroll
-              for (int c = 0; c < NCH; ++c) reinterpret_cast<int4*>(rec)[kk[c] & (W - 1)] = make_int4(cur[c], Ih[c], Dh[c], B);
+              for (int c = 0; c < NCH; ++c) reinterpret_cast<int4*>(rec)[kk[c] & (W - 1)] = make_int4(cur[c], Ih[0][c], Dh[0][c], B);
             }
           }
         }
@@ -418,7 +422,9 @@ wfa_band_kernel(const BandArgs a) {
           unsigned long long hull[NCH];
 #pragma unroll
           for (int c = 0; c < NCH; ++c) {
-            int any = cur[c] & Ih[c] & Dh[c];
+            int any = cur[c];
+#pragma unroll
+            for (int j = 0; j < E; ++j) any &= Ih[j][c] & Dh[j][c];
 #pragma unroll
             for (int j = 0; j < DM - 1; ++j) any &= Mh[j][c];
             hull[c] = __ballot(any >= 0);  // some register of this diagonal is not negative
@@ -433,7 +439,9 @@ wfa_band_kernel(const BandArgs a) {
               B += delta;
 #pragma unroll
               for (int c = 0; c < NCH; ++c) { kk[c] += delta; lim[c] = min(tlen, plen + kk[c]); dlim[c] = max(tlen, plen + kk[c]); }
-              BD::shift(cur, delta, lane); BD::shift(Ih, delta, lane); BD::shift(Dh, delta, lane);
+              BD::shift(cur, delta, lane);
+#pragma unroll
+              for (int j = 0; j < E; ++j) { BD::shift(Ih[j], delta, lane); BD::shift(Dh[j], delta, lane); }
 #pragma unroll
               for (int j = 0; j < DM - 1; ++j) BD::shift(Mh[j], delta, lane);
             }
@@ -449,23 +457,23 @@ wfa_band_kernel(const BandArgs a) {
         s += a.g;
         int insig = -1;  // AND of all inputs: non-negative iff some input offset is not NULL-ish
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) insig &= (Mh[1][c] | 0) & Mh[3][c] & Ih[c] & Dh[c];
+        for (int c = 0; c < NCH; ++c) insig &= Mh[X - 1][c] & Mh[OE - 1][c] & Ih[E - 1][c] & Dh[E - 1][c];
         int ni[NCH], nd[NCH], nm[NCH];
         if (__any(insig >= 0)) {
           unsigned long long oob = 0;
 #pragma unroll
           for (int c = 0; c < NCH; ++c) {
-            const int mo_lo = BD::below(Mh[3], c), ie_lo = BD::below(Ih, c);
-            const int mo_hi = BD::above(Mh[3], c), de_hi = BD::above(Dh, c);
+            const int mo_lo = BD::below(Mh[OE - 1], c), ie_lo = BD::below(Ih[E - 1], c);
+            const int mo_hi = BD::above(Mh[OE - 1], c), de_hi = BD::above(Dh[E - 1], c);
             ni[c] = max(mo_lo, ie_lo) + 1;
             nd[c] = max(mo_hi, de_hi);
-            int m = max(nd[c], max(Mh[1][c] + 1, ni[c]));
+            int m = max(nd[c], max(Mh[X - 1][c] + 1, ni[c]));
             if (m > lim[c]) m = WFA_OFFSET_NULL;  // only M is clamped; negative values are dead already
             nm[c] = m;
             if (PB) {
               // the choice the backtrace would make (R/wavefront_backtrace.c:49-59: mismatch > deletion ext > open >
               // insertion ext > open on equal offsets), taken here where the candidates are in registers
-              const int x1 = Mh[1][c] + 1;
+              const int x1 = Mh[X - 1][c] + 1;
               const int mc = (x1 >= max(nd[c], ni[c])) ? 0 : ((nd[c] >= ni[c]) ? 1 : 2);
               code[c] = mc | ((ie_lo >= mo_lo) ? 4 : 0) | ((de_hi >= mo_hi) ? 8 : 0);
             }
@@ -492,7 +500,11 @@ wfa_band_kernel(const BandArgs a) {
           for (int c = 0; c < NCH; ++c) { ni[c] = WFA_OFFSET_NULL; nd[c] = WFA_OFFSET_NULL; nm[c] = WFA_OFFSET_NULL; }
         }
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) { Ih[c] = ni[c]; Dh[c] = nd[c]; cur[c] = nm[c]; }
+        for (int j = E - 1; j > 0; --j)
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) { Ih[j][c] = Ih[j - 1][c]; Dh[j][c] = Dh[j - 1][c]; }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { Ih[0][c] = ni[c]; Dh[0][c] = nd[c]; cur[c] = nm[c]; }
         if (step > (1 << 24)) { fallback = true; break; }
       }
       if (!done) fallback = true;
@@ -735,37 +747,54 @@ inline int launch_band_bt(const BandArgs& a, int nch, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// configurations the band kernel covers
+// configurations the band kernel covers: gap-affine with an instantiated penalty shape (wfa_seg.hpp WFA_SEG_SHAPES)
+inline bool band_shape(const WfaDevConfig& c, int* X, int* OE, int* E) {
+  const int g = gcd_int(gcd_int(c.x, c.o1 + c.e1), c.e1);
+  *X = c.x / g; *OE = (c.o1 + c.e1) / g; *E = c.e1 / g;
+#define WFA_BAND_MATCH(x, oe, e) if (*X == x && *OE == oe && *E == e) return true;
+  WFA_BAND_SHAPES(WFA_BAND_MATCH)
+#undef WFA_BAND_MATCH
+  return false;
+}
 inline bool band_supported(const WfaDevConfig& c, int ncomp) {
   if (ncomp != 3 || c.match != 0 || c.wildcard >= 0 || c.max_steps != INT_MAX) return false;
   if (c.heuristic != 0 && c.heuristic != 1) return false;
-  const int g = gcd_int(gcd_int(c.x, c.o1 + c.e1), c.e1);
-  return (c.x / g == 2 && (c.o1 + c.e1) / g == 4 && c.e1 / g == 1);
+  int X, OE, E;
+  return band_shape(c, &X, &OE, &E);
 }
 
-template <int NCH, bool FULL, bool ADAPT>
+template <int NCH, bool FULL, bool ADAPT, int X, int OE, int E>
 static int launch_band_t(const BandArgs& a, bool seqlds, long long grid, hipStream_t stream) {
   const size_t smem = seqlds ? (size_t)a.lds_words * 2 * sizeof(uint32_t) : 0;
   if (FULL && a.pb) {  // piggy-back history (split launches of long reads)
-    if (seqlds) hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, true, FULL>), dim3((unsigned)grid), dim3(64), smem, stream, a);
-    else hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, false, FULL>), dim3((unsigned)grid), dim3(64), 0, stream, a);
-  } else if (seqlds) hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, true, false>), dim3((unsigned)grid), dim3(64), smem, stream, a);
-  else hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, false, false>), dim3((unsigned)grid), dim3(64), 0, stream, a);
+    if (seqlds) hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, true, FULL, X, OE, E>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+    else hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, false, FULL, X, OE, E>), dim3((unsigned)grid), dim3(64), 0, stream, a);
+  } else if (seqlds) hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, true, false, X, OE, E>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+  else hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, false, false, X, OE, E>), dim3((unsigned)grid), dim3(64), 0, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-inline int launch_band(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds, long long grid, hipStream_t stream) {
-#define WFA_BAND_CASE(N)                                                                     \
-  if (nch == N) {                                                                            \
-    if (full) return adapt ? launch_band_t<N, true, true>(a, seqlds, grid, stream)           \
-                           : launch_band_t<N, true, false>(a, seqlds, grid, stream);         \
-    return adapt ? launch_band_t<N, false, true>(a, seqlds, grid, stream)                    \
-                 : launch_band_t<N, false, false>(a, seqlds, grid, stream);                  \
+template <int X, int OE, int E>
+static int launch_band_shape(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds, long long grid, hipStream_t stream) {
+#define WFA_BAND_CASE(N)                                                                             \
+  if (nch == N) {                                                                                    \
+    if (full) return adapt ? launch_band_t<N, true, true, X, OE, E>(a, seqlds, grid, stream)         \
+                           : launch_band_t<N, true, false, X, OE, E>(a, seqlds, grid, stream);       \
+    return adapt ? launch_band_t<N, false, true, X, OE, E>(a, seqlds, grid, stream)                  \
+                 : launch_band_t<N, false, false, X, OE, E>(a, seqlds, grid, stream);                \
   }
   WFA_BAND_CASE(1)
   WFA_BAND_CASE(2)
   WFA_BAND_CASE(4)
 #undef WFA_BAND_CASE
+  return -1;
+}
+
+inline int launch_band(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds, long long grid, hipStream_t stream) {
+  const int g = a.g, X = a.x / g, OE = a.oe / g, E = a.e / g;
+#define WFA_BAND_LAUNCH(x, oe, e) if (X == x && OE == oe && E == e) return launch_band_shape<x, oe, e>(a, nch, full, adapt, seqlds, grid, stream);
+  WFA_BAND_SHAPES(WFA_BAND_LAUNCH)
+#undef WFA_BAND_LAUNCH
   return -1;
 }
 

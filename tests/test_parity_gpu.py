@@ -260,3 +260,22 @@ def test_piggyback_history_gives_the_same_cigars(gpu, kw):
         assert o["cigars"] == oh["cigars"]
         score, status, cigars = common.gpu_run(nc, batch, True, i % 2 == 0)
         common.assert_same(o, score, status, cigars, batch, f"piggy-back {kw2} L={L}")
+
+
+@pytest.mark.parametrize("pen", [(4, 4, 2), (4, 6, 1), (3, 4, 1), (2, 3, 1)])
+def test_banded_kernel_penalty_shapes(gpu, pen):
+    """Long reads and full CIGARs under the penalty shapes the banded kernel is instantiated for: exact and wf-adaptive,
+    explicit and piggy-back history, ends-free with free ends."""
+    x, o, e = pen
+    base = dict(mismatch=x, gap_opening=o, gap_extension=e)
+    for i, kw in enumerate([dict(span="end-to-end", scope="full", heuristic="adaptive"), dict(scope="full", memory_mode="medium"),
+                            dict(span="end-to-end", scope="score", heuristic="adaptive"),
+                            dict(scope="full", span="ends-free", pattern_begin_free=20, text_end_free=15, heuristic="adaptive", memory_mode="low")]):
+        for j, (n, L, err) in enumerate([(300, 1500, 0.05), (100, 3000, 0.08), (1500, 200, 0.1)]):
+            batch = datagen.generate(n, L, err, 9500 + 10 * i + j)
+            kw2 = common.clamp_free(dict(base, **kw), batch)
+            oc, nc = common.configs_pair(**kw2)
+            full = oc.scope == 1
+            o_ = loader.run(loader.oracle(), oc, batch, want_cigar=full)
+            score, status, cigars = common.gpu_run(nc, batch, full, (i + j) % 2 == 0)
+            common.assert_same(o_, score, status, cigars, batch, f"banded {kw2} L={L}")
