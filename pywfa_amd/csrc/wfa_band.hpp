@@ -44,6 +44,7 @@ struct BandArgs {
   uint32_t* fb_count;
   int g;                  // score step = gcd(x, o+e, e)
   int x, oe, e;           // penalties (score units), for the backtrace
+  int oe2, e2;            // gap-affine-2p: o2 + e2 and e2 (0 = gap-affine)
   int min_wf_len, max_dist_thr, steps_between;
   int lds_words;          // SEQLDS: words reserved per sequence in dynamic LDS
   int split;              // FULL: 1 = history slot per PAIR of this launch + end states; the backtrace runs in its own
@@ -154,15 +155,32 @@ __device__ void band_backtrace(const int* hist, const BandArgs& a, int plen, int
   // runs_top != nullptr: instead of op bytes, emit (length << 8 | op) run records downwards from runs_top
   // (the top of this pair's history slot: records above the walk's current score are dead) — the bytes
   // are written afterwards, coalesced, by wfa_band_expand_kernel
+  typedef Band<NCH> BD;
+  struct Ent { int m, i1, d1, i2, d2; };
   int nruns = 0;
+  const bool two = a.oe2 > 0;
   const int seg_klo = a.seg_w ? ((tlen - plen + 1) >> 1) - a.seg_w / 2 : 0;
-  // entry of (score index, diagonal): the banded kernel's window records or a segment's records
-  auto entry = [&](int si, int kk) -> int4 {
-    if (!a.seg_w) return band_entry<NCH>(hist, si, kk, a.h16);
-    int4 e = make_int4(WFA_OFFSET_NULL, WFA_OFFSET_NULL, WFA_OFFSET_NULL, 0);
-    if (si >= 0 && kk >= seg_klo && kk < seg_klo + a.seg_w) {
-      const short4 q = reinterpret_cast<const short4*>(hist + (long long)si * (a.seg_w * 2))[kk - seg_klo];
-      e = make_int4(q.x < 0 ? WFA_OFFSET_NULL : q.x, q.y < 0 ? WFA_OFFSET_NULL : q.y, q.z < 0 ? WFA_OFFSET_NULL : q.z, 0);
+  // entry of (score index, diagonal): the banded kernel's window records (gap-affine: {M, I, D, base}; 2p: 16 bytes of
+  // int16 halves {M | I1, D1 | base, I2 | D2, -}) or a segment's records
+  auto entry = [&](int si, int kk) -> Ent {
+    Ent e = {WFA_OFFSET_NULL, WFA_OFFSET_NULL, WFA_OFFSET_NULL, WFA_OFFSET_NULL, WFA_OFFSET_NULL};
+    if (si < 0) return e;
+    auto nz = [](int v) { return v < 0 ? WFA_OFFSET_NULL : v; };
+    if (a.seg_w) {
+      if (kk >= seg_klo && kk < seg_klo + a.seg_w) {
+        const short4 q = reinterpret_cast<const short4*>(hist + (long long)si * (a.seg_w * 2))[kk - seg_klo];
+        e.m = nz(q.x); e.i1 = nz(q.y); e.d1 = nz(q.z);
+      }
+    } else if (two) {
+      const int4 q = reinterpret_cast<const int4*>(hist + (long long)si * BD::REC)[kk & (BD::W - 1)];
+      const int base = q.y >> 16;
+      if (kk >= base && kk < base + BD::W) {
+        e.m = nz((int)(short)(q.x & 0xffff)); e.i1 = nz(q.x >> 16); e.d1 = nz((int)(short)(q.y & 0xffff));
+        e.i2 = nz((int)(short)(q.z & 0xffff)); e.d2 = nz(q.z >> 16);
+      }
+    } else {
+      const int4 q = band_entry<NCH>(hist, si, kk, a.h16);
+      e.m = q.x; e.i1 = q.y; e.d1 = q.z;
     }
     return e;
   };
@@ -171,8 +189,9 @@ __device__ void band_backtrace(const int* hist, const BandArgs& a, int plen, int
     else for (int i = lane; i < n; i += nlanes) buf[bg - 1 - i] = (uint8_t)c;
     bg -= n;
   };
-  enum { BT_I1_OPEN = 1, BT_I1_EXT = 2, BT_D1_OPEN = 5, BT_D1_EXT = 6, BT_M = 9 };
+  enum { BT_I1_OPEN = 1, BT_I1_EXT = 2, BT_I2_OPEN = 3, BT_I2_EXT = 4, BT_D1_OPEN = 5, BT_D1_EXT = 6, BT_D2_OPEN = 7, BT_D2_EXT = 8, BT_M = 9 };
   const int dx = a.x / a.g, doe = a.oe / a.g, de = a.e / a.g;
+  const int doe2 = two ? a.oe2 / a.g : 0, de2 = two ? a.e2 / a.g : 0;
   long long begin = (long long)plen + tlen;
   int comp = 0, si = end_s / a.g, k = end_k, offset = end_off;
   int h = offset, v = offset - k;
@@ -180,21 +199,30 @@ __device__ void band_backtrace(const int* hist, const BandArgs& a, int plen, int
   push(begin, 'I', max(tlen - h, 0));
   while (v > 0 && h > 0 && si > 0) {
     const int si_x = si - dx, si_o = si - doe, si_e = si - de;
+    const int si_o2 = two ? si - doe2 : -1, si_e2 = two ? si - de2 : -1;
     long long best;
     if (comp == 0) {
-      const int4 ex = entry(si_x, k);
-      const int4 eol = entry(si_o, k - 1), eoh = entry(si_o, k + 1);
-      const int4 eel = entry(si_e, k - 1), eeh = entry(si_e, k + 1);
-      const long long c0 = band_pack(si_x, ex.x, 1, BT_M);
-      const long long c1 = band_pack(si_o, eol.x, 1, BT_I1_OPEN), c2 = band_pack(si_e, eel.y, 1, BT_I1_EXT);
-      const long long c3 = band_pack(si_o, eoh.x, 0, BT_D1_OPEN), c4 = band_pack(si_e, eeh.z, 0, BT_D1_EXT);
+      const Ent ex = entry(si_x, k);
+      const Ent eol = entry(si_o, k - 1), eoh = entry(si_o, k + 1);
+      const Ent eel = entry(si_e, k - 1), eeh = entry(si_e, k + 1);
+      const long long c0 = band_pack(si_x, ex.m, 1, BT_M);
+      const long long c1 = band_pack(si_o, eol.m, 1, BT_I1_OPEN), c2 = band_pack(si_e, eel.i1, 1, BT_I1_EXT);
+      const long long c3 = band_pack(si_o, eoh.m, 0, BT_D1_OPEN), c4 = band_pack(si_e, eeh.d1, 0, BT_D1_EXT);
       best = max(max(c0, max(c1, c2)), max(c3, c4));
+      if (two) {
+        const Ent fol = entry(si_o2, k - 1), foh = entry(si_o2, k + 1);
+        const Ent fel = (de2 == de) ? eel : entry(si_e2, k - 1), feh = (de2 == de) ? eeh : entry(si_e2, k + 1);
+        best = max(best, max(band_pack(si_o2, fol.m, 1, BT_I2_OPEN), band_pack(si_e2, fel.i2, 1, BT_I2_EXT)));
+        best = max(best, max(band_pack(si_o2, foh.m, 0, BT_D2_OPEN), band_pack(si_e2, feh.d2, 0, BT_D2_EXT)));
+      }
     } else if (comp == 1) {
-      const int4 eol = entry(si_o, k - 1), eel = entry(si_e, k - 1);
-      best = max(band_pack(si_o, eol.x, 1, BT_I1_OPEN), band_pack(si_e, eel.y, 1, BT_I1_EXT));
+      best = max(band_pack(si_o, entry(si_o, k - 1).m, 1, BT_I1_OPEN), band_pack(si_e, entry(si_e, k - 1).i1, 1, BT_I1_EXT));
+    } else if (comp == 2) {
+      best = max(band_pack(si_o, entry(si_o, k + 1).m, 0, BT_D1_OPEN), band_pack(si_e, entry(si_e, k + 1).d1, 0, BT_D1_EXT));
+    } else if (comp == 3) {
+      best = max(band_pack(si_o2, entry(si_o2, k - 1).m, 1, BT_I2_OPEN), band_pack(si_e2, entry(si_e2, k - 1).i2, 1, BT_I2_EXT));
     } else {
-      const int4 eoh = entry(si_o, k + 1), eeh = entry(si_e, k + 1);
-      best = max(band_pack(si_o, eoh.x, 0, BT_D1_OPEN), band_pack(si_e, eeh.z, 0, BT_D1_EXT));
+      best = max(band_pack(si_o2, entry(si_o2, k + 1).m, 0, BT_D2_OPEN), band_pack(si_e2, entry(si_e2, k + 1).d2, 0, BT_D2_EXT));
     }
     if (best < 0) break;
     if (comp == 0) {
@@ -208,8 +236,12 @@ __device__ void band_backtrace(const int* hist, const BandArgs& a, int plen, int
     if (type == BT_M) { si = si_x; comp = 0; push(begin, 'X', 1); --offset; }
     else if (type == BT_I1_OPEN) { si = si_o; comp = 0; push(begin, 'I', 1); --k; --offset; }
     else if (type == BT_I1_EXT) { si = si_e; comp = 1; push(begin, 'I', 1); --k; --offset; }
+    else if (type == BT_I2_OPEN) { si = si_o2; comp = 0; push(begin, 'I', 1); --k; --offset; }
+    else if (type == BT_I2_EXT) { si = si_e2; comp = 3; push(begin, 'I', 1); --k; --offset; }
     else if (type == BT_D1_OPEN) { si = si_o; comp = 0; push(begin, 'D', 1); ++k; }
-    else { si = si_e; comp = 2; push(begin, 'D', 1); ++k; }
+    else if (type == BT_D1_EXT) { si = si_e; comp = 2; push(begin, 'D', 1); ++k; }
+    else if (type == BT_D2_OPEN) { si = si_o2; comp = 0; push(begin, 'D', 1); ++k; }
+    else { si = si_e2; comp = 4; push(begin, 'D', 1); ++k; }
     v = offset - k; h = offset;
   }
   if (comp == 0) {
@@ -225,19 +257,23 @@ __device__ void band_backtrace(const int* hist, const BandArgs& a, int plen, int
   if (nruns_out) *nruns_out = nruns;
 }
 
-template <int NCH, bool FULL, bool ADAPT, bool SEQLDS, bool PB, int X, int OE, int E>
+template <int NCH, bool FULL, bool ADAPT, bool SEQLDS, bool PB, int X, int OE, int E, int OE2, int E2>
 __global__ void __launch_bounds__(64)
 wfa_band_kernel(const BandArgs a) {
   static_assert(FULL || !PB, "piggy-back history only with a history");
+  static_assert(!(PB && OE2 > 0), "piggy-back history: gap-affine only");
+  constexpr bool TWO = OE2 > 0;  // gap-affine-2p: second pair of gap components (R/wavefront_compute_affine2p.c:45-106)
+  constexpr int E2D = TWO ? E2 : 1;
   typedef Band<NCH> BD;
   constexpr int W = BD::W;
-  constexpr int DM = (X > OE) ? X : OE;  // M history depth; (X, OE, E) = (x, o + e, e) / g
+  constexpr int DM1 = (X > OE) ? X : OE;
+  constexpr int DM = (DM1 > OE2) ? DM1 : OE2;  // M history depth; (X, OE, E, OE2, E2) = (x, o1 + e1, e1, o2 + e2, e2) / g
   extern __shared__ uint32_t slds[];
   uint32_t* const sP = slds;
   uint32_t* const sT = slds + a.lds_words;
   const int lane = threadIdx.x;
   int* hist = FULL ? a.hist + (long long)blockIdx.x * a.hist_stride : nullptr;
-  const int rec_ints = PB ? W / 4 : (a.h16 ? BD::REC / 2 : BD::REC);  // piggy-back: one byte per window position
+  const int rec_ints = PB ? W / 4 : ((a.h16 && !TWO) ? BD::REC / 2 : BD::REC);  // 2p: 16-byte entries of 6 x int16  // piggy-back: one byte per window position
   const int max_records = FULL ? (int)min((long long)INT_MAX, (PB ? a.pb_code_ints : a.hist_stride) / rec_ints) : INT_MAX;
 
   const bool split = FULL && a.split;
@@ -273,7 +309,7 @@ wfa_band_kernel(const BandArgs a) {
     if (!fallback) {
       // per lane: lim = min(tlen, plen + k) (in-bounds <=> offset <= lim; lim - offset = longest possible run),
       // dlim = max(tlen, plen + k) (dlim - offset = distance to the end, R/wavefront_heuristic.c:176-192)
-      int kk[NCH], lim[NCH], dlim[NCH], cur[NCH], Mh[DM][NCH], Ih[E][NCH], Dh[E][NCH];
+      int kk[NCH], lim[NCH], dlim[NCH], cur[NCH], Mh[DM][NCH], Ih[E][NCH], Dh[E][NCH], I2h[E2D][NCH], D2h[E2D][NCH];
       int code[PB ? NCH : 1];  // piggy-back: origin of M (bits 0-1: 0 mismatch, 1 deletion, 2 insertion), of I (bit 2: extension) and of D (bit 3)
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
@@ -284,6 +320,8 @@ wfa_band_kernel(const BandArgs a) {
         if (a.ef && kk[c] >= -a.pbf && kk[c] <= a.tbf) cur[c] = max(kk[c], 0);
 #pragma unroll
         for (int j = 0; j < E; ++j) { Ih[j][c] = WFA_OFFSET_NULL; Dh[j][c] = WFA_OFFSET_NULL; }
+#pragma unroll
+        for (int j = 0; j < E2D; ++j) { I2h[j][c] = WFA_OFFSET_NULL; D2h[j][c] = WFA_OFFSET_NULL; }
 #pragma unroll
         for (int j = 0; j < DM; ++j) Mh[j][c] = WFA_OFFSET_NULL;
       }
@@ -389,7 +427,7 @@ wfa_band_kernel(const BandArgs a) {
 #pragma unroll
                   for (int c = 0; c < NCH; ++c) {
                     const bool drop = kk[c] < new_lo || kk[c] > new_hi;
-                    if (drop) { cur[c] = WFA_OFFSET_NULL; Ih[0][c] = WFA_OFFSET_NULL; Dh[0][c] = WFA_OFFSET_NULL; }
+                    if (drop) { cur[c] = WFA_OFFSET_NULL; Ih[0][c] = WFA_OFFSET_NULL; Dh[0][c] = WFA_OFFSET_NULL; I2h[0][c] = WFA_OFFSET_NULL; D2h[0][c] = WFA_OFFSET_NULL; }
                   }
                 }
               }
@@ -406,7 +444,14 @@ wfa_band_kernel(const BandArgs a) {
           if (si + 1 >= max_records) { fallback = true; break; }
           int* rec = hist + (long long)si * rec_ints;
           if (!(a.debug & 2)) {
-            if (a.h16) {
+            if (TWO) {
+              // {M | I1 << 16, D1 | B << 16, I2 | D2 << 16, 0}: int16 halves, negative -> -1 (reads < 32000 bases)
+#pragma unroll
+              for (int c = 0; c < NCH; ++c)
+                reinterpret_cast<int4*>(rec)[kk[c] & (W - 1)] =
+                    make_int4((sat16(cur[c]) & 0xffff) | (sat16(Ih[0][c]) << 16), (sat16(Dh[0][c]) & 0xffff) | (B << 16),
+                              (sat16(I2h[0][c]) & 0xffff) | (sat16(D2h[0][c]) << 16), 0);
+            } else if (a.h16) {
 #pragma unroll
               for (int c = 0; c < NCH; ++c)
                 reinterpret_cast<short4*>(rec)[kk[c] & (W - 1)] =
@@ -425,6 +470,10 @@ wfa_band_kernel(const BandArgs a) {
             int any = cur[c];
 #pragma unroll
             for (int j = 0; j < E; ++j) any &= Ih[j][c] & Dh[j][c];
+            if (TWO) {
+#pragma unroll
+              for (int j = 0; j < E2D; ++j) any &= I2h[j][c] & D2h[j][c];
+            }
 #pragma unroll
             for (int j = 0; j < DM - 1; ++j) any &= Mh[j][c];
             hull[c] = __ballot(any >= 0);  // some register of this diagonal is not negative
@@ -442,6 +491,10 @@ wfa_band_kernel(const BandArgs a) {
               BD::shift(cur, delta, lane);
 #pragma unroll
               for (int j = 0; j < E; ++j) { BD::shift(Ih[j], delta, lane); BD::shift(Dh[j], delta, lane); }
+              if (TWO) {
+#pragma unroll
+                for (int j = 0; j < E2D; ++j) { BD::shift(I2h[j], delta, lane); BD::shift(D2h[j], delta, lane); }
+              }
 #pragma unroll
               for (int j = 0; j < DM - 1; ++j) BD::shift(Mh[j], delta, lane);
             }
@@ -457,8 +510,11 @@ wfa_band_kernel(const BandArgs a) {
         s += a.g;
         int insig = -1;  // AND of all inputs: non-negative iff some input offset is not NULL-ish
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) insig &= Mh[X - 1][c] & Mh[OE - 1][c] & Ih[E - 1][c] & Dh[E - 1][c];
-        int ni[NCH], nd[NCH], nm[NCH];
+        for (int c = 0; c < NCH; ++c) {
+          insig &= Mh[X - 1][c] & Mh[OE - 1][c] & Ih[E - 1][c] & Dh[E - 1][c];
+          if (TWO) insig &= Mh[TWO ? OE2 - 1 : 0][c] & I2h[E2D - 1][c] & D2h[E2D - 1][c];
+        }
+        int ni[NCH], nd[NCH], nm[NCH], ni2[NCH], nd2[NCH];
         if (__any(insig >= 0)) {
           unsigned long long oob = 0;
 #pragma unroll
@@ -467,7 +523,12 @@ wfa_band_kernel(const BandArgs a) {
             const int mo_hi = BD::above(Mh[OE - 1], c), de_hi = BD::above(Dh[E - 1], c);
             ni[c] = max(mo_lo, ie_lo) + 1;
             nd[c] = max(mo_hi, de_hi);
-            int m = max(nd[c], max(Mh[X - 1][c] + 1, ni[c]));
+            ni2[c] = WFA_OFFSET_NULL; nd2[c] = WFA_OFFSET_NULL;
+            if (TWO) {
+              ni2[c] = max(BD::below(Mh[TWO ? OE2 - 1 : 0], c), BD::below(I2h[E2D - 1], c)) + 1;
+              nd2[c] = max(BD::above(Mh[TWO ? OE2 - 1 : 0], c), BD::above(D2h[E2D - 1], c));
+            }
+            int m = max(max(nd[c], nd2[c]), max(Mh[X - 1][c] + 1, max(ni[c], ni2[c])));
             if (m > lim[c]) m = WFA_OFFSET_NULL;  // only M is clamped; negative values are dead already
             nm[c] = m;
             if (PB) {
@@ -477,7 +538,7 @@ wfa_band_kernel(const BandArgs a) {
               const int mc = (x1 >= max(nd[c], ni[c])) ? 0 : ((nd[c] >= ni[c]) ? 1 : 2);
               code[c] = mc | ((ie_lo >= mo_lo) ? 4 : 0) | ((de_hi >= mo_hi) ? 8 : 0);
             }
-            oob |= __ballot(max(ni[c], nd[c]) > lim[c]);
+            oob |= __ballot(max(max(ni[c], nd[c]), max(ni2[c], nd2[c])) > lim[c]);
           }
           if (oob) {
             // trim the ends of I and D (R/wavefront_compute.c:571-605): outside [first,last] in-bounds -> NULL
@@ -494,10 +555,24 @@ wfa_band_kernel(const BandArgs a) {
               if (pos < ilo || pos > ihi) ni[c] = WFA_OFFSET_NULL;
               if (pos < dlo || pos > dhi) nd[c] = WFA_OFFSET_NULL;
             }
+            if (TWO) {
+#pragma unroll
+              for (int c = 0; c < NCH; ++c) {
+                bi[c] = __ballot(ni2[c] >= 0 && ni2[c] <= lim[c]);
+                bd[c] = __ballot(nd2[c] >= 0 && nd2[c] <= lim[c]);
+              }
+              const int i2lo = BD::first_pos(bi), i2hi = BD::last_pos(bi), d2lo = BD::first_pos(bd), d2hi = BD::last_pos(bd);
+#pragma unroll
+              for (int c = 0; c < NCH; ++c) {
+                const int pos = c * 64 + lane;
+                if (pos < i2lo || pos > i2hi) ni2[c] = WFA_OFFSET_NULL;
+                if (pos < d2lo || pos > d2hi) nd2[c] = WFA_OFFSET_NULL;
+              }
+            }
           }
         } else {
 #pragma unroll
-          for (int c = 0; c < NCH; ++c) { ni[c] = WFA_OFFSET_NULL; nd[c] = WFA_OFFSET_NULL; nm[c] = WFA_OFFSET_NULL; }
+          for (int c = 0; c < NCH; ++c) { ni[c] = WFA_OFFSET_NULL; nd[c] = WFA_OFFSET_NULL; nm[c] = WFA_OFFSET_NULL; ni2[c] = WFA_OFFSET_NULL; nd2[c] = WFA_OFFSET_NULL; }
         }
 #pragma unroll
         for (int j = E - 1; j > 0; --j)
@@ -505,6 +580,14 @@ wfa_band_kernel(const BandArgs a) {
           for (int c = 0; c < NCH; ++c) { Ih[j][c] = Ih[j - 1][c]; Dh[j][c] = Dh[j - 1][c]; }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) { Ih[0][c] = ni[c]; Dh[0][c] = nd[c]; cur[c] = nm[c]; }
+        if (TWO) {
+#pragma unroll
+          for (int j = E2D - 1; j > 0; --j)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { I2h[j][c] = I2h[j - 1][c]; D2h[j][c] = D2h[j - 1][c]; }
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) { I2h[0][c] = ni2[c]; D2h[0][c] = nd2[c]; }
+        }
         if (step > (1 << 24)) { fallback = true; break; }
       }
       if (!done) fallback = true;
@@ -747,41 +830,53 @@ inline int launch_band_bt(const BandArgs& a, int nch, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// configurations the band kernel covers: gap-affine with an instantiated penalty shape (wfa_seg.hpp WFA_SEG_SHAPES)
-inline bool band_shape(const WfaDevConfig& c, int* X, int* OE, int* E) {
-  const int g = gcd_int(gcd_int(c.x, c.o1 + c.e1), c.e1);
-  *X = c.x / g; *OE = (c.o1 + c.e1) / g; *E = c.e1 / g;
-#define WFA_BAND_MATCH(x, oe, e) if (*X == x && *OE == oe && *E == e) return true;
+// configurations the band kernel covers: gap-affine / gap-affine-2p with an instantiated penalty shape
+// (x, o1 + e1, e1 [, o2 + e2, e2]) / gcd; 2p: pywfa's default 4/6/2/24/1
+#define WFA_BAND_SHAPES_2P(F) F(4, 8, 2, 25, 1)
+inline int band_gcd(const WfaDevConfig& c, bool two) {
+  int g = gcd_int(gcd_int(c.x, c.o1 + c.e1), c.e1);
+  if (two) g = gcd_int(gcd_int(g, c.o2 + c.e2), c.e2);
+  return g;
+}
+inline bool band_supported(const WfaDevConfig& c, int ncomp) {
+  if ((ncomp != 3 && ncomp != 5) || c.match != 0 || c.wildcard >= 0 || c.max_steps != INT_MAX) return false;
+  if (c.heuristic != 0 && c.heuristic != 1) return false;
+  const bool two = ncomp == 5;
+  const int g = band_gcd(c, two);
+  const int X = c.x / g, OE = (c.o1 + c.e1) / g, E = c.e1 / g;
+  if (two) {
+    const int OE2 = (c.o2 + c.e2) / g, E2 = c.e2 / g;
+#define WFA_BAND_MATCH2(x, oe, e, oe2, e2) if (X == x && OE == oe && E == e && OE2 == oe2 && E2 == e2) return true;
+    WFA_BAND_SHAPES_2P(WFA_BAND_MATCH2)
+#undef WFA_BAND_MATCH2
+    return false;
+  }
+#define WFA_BAND_MATCH(x, oe, e) if (X == x && OE == oe && E == e) return true;
   WFA_BAND_SHAPES(WFA_BAND_MATCH)
 #undef WFA_BAND_MATCH
   return false;
 }
-inline bool band_supported(const WfaDevConfig& c, int ncomp) {
-  if (ncomp != 3 || c.match != 0 || c.wildcard >= 0 || c.max_steps != INT_MAX) return false;
-  if (c.heuristic != 0 && c.heuristic != 1) return false;
-  int X, OE, E;
-  return band_shape(c, &X, &OE, &E);
-}
 
-template <int NCH, bool FULL, bool ADAPT, int X, int OE, int E>
+template <int NCH, bool FULL, bool ADAPT, int X, int OE, int E, int OE2, int E2>
 static int launch_band_t(const BandArgs& a, bool seqlds, long long grid, hipStream_t stream) {
   const size_t smem = seqlds ? (size_t)a.lds_words * 2 * sizeof(uint32_t) : 0;
-  if (FULL && a.pb) {  // piggy-back history (split launches of long reads)
-    if (seqlds) hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, true, FULL, X, OE, E>), dim3((unsigned)grid), dim3(64), smem, stream, a);
-    else hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, false, FULL, X, OE, E>), dim3((unsigned)grid), dim3(64), 0, stream, a);
-  } else if (seqlds) hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, true, false, X, OE, E>), dim3((unsigned)grid), dim3(64), smem, stream, a);
-  else hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, false, false, X, OE, E>), dim3((unsigned)grid), dim3(64), 0, stream, a);
+  constexpr bool CAN_PB = FULL && OE2 == 0;
+  if (CAN_PB && a.pb) {  // piggy-back history (split launches of long reads)
+    if (seqlds) hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, true, CAN_PB, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+    else hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, false, CAN_PB, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), 0, stream, a);
+  } else if (seqlds) hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, true, false, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+  else hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, false, false, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), 0, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-template <int X, int OE, int E>
+template <int X, int OE, int E, int OE2, int E2>
 static int launch_band_shape(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds, long long grid, hipStream_t stream) {
-#define WFA_BAND_CASE(N)                                                                             \
-  if (nch == N) {                                                                                    \
-    if (full) return adapt ? launch_band_t<N, true, true, X, OE, E>(a, seqlds, grid, stream)         \
-                           : launch_band_t<N, true, false, X, OE, E>(a, seqlds, grid, stream);       \
-    return adapt ? launch_band_t<N, false, true, X, OE, E>(a, seqlds, grid, stream)                  \
-                 : launch_band_t<N, false, false, X, OE, E>(a, seqlds, grid, stream);                \
+#define WFA_BAND_CASE(N)                                                                                       \
+  if (nch == N) {                                                                                              \
+    if (full) return adapt ? launch_band_t<N, true, true, X, OE, E, OE2, E2>(a, seqlds, grid, stream)          \
+                           : launch_band_t<N, true, false, X, OE, E, OE2, E2>(a, seqlds, grid, stream);        \
+    return adapt ? launch_band_t<N, false, true, X, OE, E, OE2, E2>(a, seqlds, grid, stream)                   \
+                 : launch_band_t<N, false, false, X, OE, E, OE2, E2>(a, seqlds, grid, stream);                 \
   }
   WFA_BAND_CASE(1)
   WFA_BAND_CASE(2)
@@ -792,7 +887,14 @@ static int launch_band_shape(const BandArgs& a, int nch, bool full, bool adapt, 
 
 inline int launch_band(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds, long long grid, hipStream_t stream) {
   const int g = a.g, X = a.x / g, OE = a.oe / g, E = a.e / g;
-#define WFA_BAND_LAUNCH(x, oe, e) if (X == x && OE == oe && E == e) return launch_band_shape<x, oe, e>(a, nch, full, adapt, seqlds, grid, stream);
+  if (a.oe2 > 0) {
+    const int OE2 = a.oe2 / g, E2 = a.e2 / g;
+#define WFA_BAND_LAUNCH2(x, oe, e, oe2, e2) if (X == x && OE == oe && E == e && OE2 == oe2 && E2 == e2) return launch_band_shape<x, oe, e, oe2, e2>(a, nch, full, adapt, seqlds, grid, stream);
+    WFA_BAND_SHAPES_2P(WFA_BAND_LAUNCH2)
+#undef WFA_BAND_LAUNCH2
+    return -1;
+  }
+#define WFA_BAND_LAUNCH(x, oe, e) if (X == x && OE == oe && E == e) return launch_band_shape<x, oe, e, 0, 0>(a, nch, full, adapt, seqlds, grid, stream);
   WFA_BAND_SHAPES(WFA_BAND_LAUNCH)
 #undef WFA_BAND_LAUNCH
   return -1;

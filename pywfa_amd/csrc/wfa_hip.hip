@@ -660,7 +660,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     // full CIGARs of short reads: the segmented kernel with a history slot per pair, then the thread-per-alignment walk
     const bool use_segfull = !tiny && full && wfa::seg_supported(al->dcfg, al->ncomp, false) && b->max_len <= WFA_FAST_MAX_LEN &&
                              env_int("WFA_HIP_NO_FAST", 0) == 0 && env_int("WFA_HIP_NO_SEGFULL", 0) == 0;
-    if (!tiny && wfa::band_supported(al->dcfg, al->ncomp) && env_int("WFA_HIP_NO_BAND", 0) == 0) {
+    if (!tiny && wfa::band_supported(al->dcfg, al->ncomp) && (al->ncomp != 5 || b->max_len < 32000) && env_int("WFA_HIP_NO_BAND", 0) == 0) {
       if (adapt) {
         if (b->max_len <= 300) { band_nch[n_stages++] = 1; }
         band_nch[n_stages++] = 2; band_nch[n_stages++] = 4;
@@ -682,7 +682,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     // memory_mode medium / low (the reference's piggy-back backtrace, R/wavefront_backtrace_offload.c): the split stage
     // keeps one byte of origin codes per (step, diagonal) instead of the offsets and re-extends the matches afterwards
     const int pb_env = env_int("WFA_HIP_BAND_PB", -1);
-    const bool pb_mode = full && (pb_env >= 0 ? pb_env != 0 : (al->cfg.memory_mode == WFA_MEM_MED || al->cfg.memory_mode == WFA_MEM_LOW));
+    const bool pb_mode = full && al->ncomp == 3 && (pb_env >= 0 ? pb_env != 0 : (al->cfg.memory_mode == WFA_MEM_MED || al->cfg.memory_mode == WFA_MEM_LOW));
     int64_t pb_code_ints = 0, pb_event_ints = 0, pb_stride = 0;
     for (int i = 0; i < n_stages; ++i) {
       // 4x more waves than a CU holds at once: waves retire one after the other (oldest-first issue) and the
@@ -692,8 +692,9 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       if (i > 0 || use_fast || use_segfull) grid = std::min<long long>(grid, (long long)al->cu_count * env_int("WFA_HIP_BAND_LEFTOVER_WAVES_PER_CU", 64));
       if (full) {
         const bool h16 = b->max_len < 32000;
-        const int rec = (h16 ? 2 : 4) * 64 * band_nch[i];
-        long long records = std::max<long long>(256, (long long)(b->max_len * 0.45) + 64);
+        const int rec = ((h16 && al->ncomp != 5) ? 2 : 4) * 64 * band_nch[i];  // ints per record (2p: 16-byte entries)
+        // steps of an alignment = score / g; sized for scores up to 0.9 x the read length (about 15 % divergence)
+        long long records = std::max<long long>(256, (long long)(b->max_len * 0.9) / wfa::band_gcd(al->dcfg, al->ncomp == 5) + 64);
         records = env_int("WFA_HIP_BAND_RECORDS", (int)records);
         band_stride[i] = ((int64_t)records * rec + 63) & ~63ll;
         const int64_t budget = free_budget(al);
@@ -847,8 +848,9 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       uint32_t* out_count = b->d_counters + 4 + out_sel;
       if (!first_stage) HIP_TRY(al, hipMemsetAsync(out_count, 0, sizeof(uint32_t), stream));
       ba.fb_list = out_list; ba.fb_count = out_count;
-      ba.g = wfa::gcd_int(wfa::gcd_int(al->dcfg.x, al->dcfg.o1 + al->dcfg.e1), al->dcfg.e1);
+      ba.g = wfa::band_gcd(al->dcfg, al->ncomp == 5);
       ba.x = al->dcfg.x; ba.oe = al->dcfg.o1 + al->dcfg.e1; ba.e = al->dcfg.e1;
+      if (al->ncomp == 5) { ba.oe2 = al->dcfg.o2 + al->dcfg.e2; ba.e2 = al->dcfg.e2; }
       ba.min_wf_len = al->dcfg.min_wf_len; ba.max_dist_thr = al->dcfg.max_dist_thr; ba.steps_between = al->dcfg.steps_between;
       const int words = ((b->max_len + 15) >> 4) + 4;
       const bool seqlds = ((size_t)words * 8 <= 5120) && env_int("WFA_HIP_BAND_NO_LDS", 0) == 0;

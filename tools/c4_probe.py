@@ -1,8 +1,11 @@
+#!/usr/bin/env python3
+"""C4-shaped probes of the banded gap-affine-2p kernel (development aid)."""
 import sys, os
-sys.argv=["x","none"]
-sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT","/root/repo"),"tools"))
-os.environ["BRIEF"]="1"
+sys.argv = ["x", "none"]
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+os.environ["BRIEF"] = "1"
 import gpu_perf
-kw=dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="full", heuristic="adaptive")
-for n in (8192, 32768, 65536):
-    gpu_perf.run(f"C4a n={n}", n, 10000, 0.08, 1004, kw, cpu_n=50, reps=1)
+kw = dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, heuristic="adaptive")
+for n in (8192, 32768):
+    gpu_perf.run(f"C4a full n={n}", n, 10000, 0.08, 1004, dict(kw, scope="full"), cpu_n=20, reps=1)
+    gpu_perf.run(f"C4a score n={n}", n, 10000, 0.08, 1004, dict(kw, scope="score"), cpu_n=20, reps=1)
