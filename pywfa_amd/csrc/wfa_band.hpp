@@ -78,13 +78,13 @@ struct Band {
   static constexpr int REC = 4 * W;  // history record of one score: {M, I, D, window base} per window position (16 B)
 
   // value of the diagonal below / above across chunk boundaries
-  static __device__ __forceinline__ int below(const int (&r)[NCH], int c) {
-    int fill = WFA_OFFSET_NULL;
+  static __device__ __forceinline__ int below(const int (&r)[NCH], int c, int nullv = WFA_OFFSET_NULL) {
+    int fill = nullv;
     if (c > 0) fill = __builtin_amdgcn_readlane(r[c - 1], 63);
     return __builtin_amdgcn_update_dpp(fill, r[c], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
   }
-  static __device__ __forceinline__ int above(const int (&r)[NCH], int c) {
-    int fill = WFA_OFFSET_NULL;
+  static __device__ __forceinline__ int above(const int (&r)[NCH], int c, int nullv = WFA_OFFSET_NULL) {
+    int fill = nullv;
     if (c < NCH - 1) fill = __builtin_amdgcn_readlane(r[c + 1], 0);
     return __builtin_amdgcn_update_dpp(fill, r[c], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
   }
@@ -102,12 +102,12 @@ struct Band {
     return p;
   }
   // shift a register set by `delta` window positions: new[pos] = old[pos + delta] (NULL outside)
-  static __device__ __forceinline__ void shift(int (&r)[NCH], int delta, int lane) {
+  static __device__ __forceinline__ void shift(int (&r)[NCH], int delta, int lane, int nullv = WFA_OFFSET_NULL) {
     int out[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int q = c * 64 + lane + delta;
-      int v = WFA_OFFSET_NULL;
+      int v = nullv;
 #pragma unroll
       for (int sc = 0; sc < NCH; ++sc) {
         const int t = __shfl(r[sc], q & 63, 64);
@@ -267,7 +267,11 @@ wfa_band_kernel(const BandArgs a) {
   typedef Band<NCH> BD;
   constexpr int W = BD::W;
   constexpr int DM1 = (X > OE) ? X : OE;
-  constexpr int DM = (DM1 > OE2) ? DM1 : OE2;  // M history depth; (X, OE, E, OE2, E2) = (x, o1 + e1, e1, o2 + e2, e2) / g
+  // M history: depths 1..DM in registers; 2p: the depths beyond max(X, OE), read only once (at OE2), are kept as int16
+  // pairs, two depths per register, shifted with one v_alignbit each (half the registers and moves; reads < 32000 bases)
+  constexpr int DM = TWO ? DM1 : ((DM1 > OE2) ? DM1 : OE2);  // (X, OE, E, OE2, E2) = (x, o1 + e1, e1, o2 + e2, e2) / g
+  constexpr int NP = TWO ? (OE2 - DM + 1) / 2 + 1 : 1;       // packed registers: depths DM+1 .. OE2 (+ slack)
+  static_assert(!TWO || OE2 > DM1, "2p: o2 + e2 is the deepest history read");
   extern __shared__ uint32_t slds[];
   uint32_t* const sP = slds;
   uint32_t* const sT = slds + a.lds_words;
@@ -309,7 +313,7 @@ wfa_band_kernel(const BandArgs a) {
     if (!fallback) {
       // per lane: lim = min(tlen, plen + k) (in-bounds <=> offset <= lim; lim - offset = longest possible run),
       // dlim = max(tlen, plen + k) (dlim - offset = distance to the end, R/wavefront_heuristic.c:176-192)
-      int kk[NCH], lim[NCH], dlim[NCH], cur[NCH], Mh[DM][NCH], Ih[E][NCH], Dh[E][NCH], I2h[E2D][NCH], D2h[E2D][NCH];
+      int kk[NCH], lim[NCH], dlim[NCH], cur[NCH], Mh[DM][NCH], Ih[E][NCH], Dh[E][NCH], I2h[E2D][NCH], D2h[E2D][NCH], PH[NP][NCH];
       int code[PB ? NCH : 1];  // piggy-back: origin of M (bits 0-1: 0 mismatch, 1 deletion, 2 insertion), of I (bit 2: extension) and of D (bit 3)
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
@@ -324,6 +328,8 @@ wfa_band_kernel(const BandArgs a) {
         for (int j = 0; j < E2D; ++j) { I2h[j][c] = WFA_OFFSET_NULL; D2h[j][c] = WFA_OFFSET_NULL; }
 #pragma unroll
         for (int j = 0; j < DM; ++j) Mh[j][c] = WFA_OFFSET_NULL;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) PH[j][c] = -1;  // both halves NULL
       }
       int s = 0, steps_wait = a.steps_between, dead_steps = 0;
       bool done = false;
@@ -476,6 +482,11 @@ wfa_band_kernel(const BandArgs a) {
             }
 #pragma unroll
             for (int j = 0; j < DM - 1; ++j) any &= Mh[j][c];
+            if (TWO) {
+              any &= Mh[DM - 1][c];
+#pragma unroll
+              for (int j = 0; j < NP; ++j) any &= PH[j][c] & (PH[j][c] << 16);  // sign set iff both halves are NULL
+            }
             hull[c] = __ballot(any >= 0);  // some register of this diagonal is not negative
           }
           const int fp = BD::first_pos(hull), lp = BD::last_pos(hull);
@@ -497,10 +508,24 @@ wfa_band_kernel(const BandArgs a) {
               }
 #pragma unroll
               for (int j = 0; j < DM - 1; ++j) BD::shift(Mh[j], delta, lane);
+              if (TWO) {
+                BD::shift(Mh[DM - 1], delta, lane);
+#pragma unroll
+                for (int j = 0; j < NP; ++j) BD::shift(PH[j], delta, lane, -1);
+              }
             }
           }
         }
         // ---------------- compute-next for score s+g ----------------
+        if (TWO) {
+          // the value leaving depth DM enters the packed ring: PH[0].lo = depth DM + 1, PH[0].hi = DM + 2, ...
+#pragma unroll
+          for (int j = NP - 1; j > 0; --j)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) PH[j][c] = (int)__builtin_amdgcn_alignbit((uint32_t)PH[j][c], (uint32_t)PH[j - 1][c], 16);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) PH[0][c] = (PH[0][c] << 16) | (max(Mh[DM - 1][c], -1) & 0xffff);
+        }
 #pragma unroll
         for (int j = DM - 1; j > 0; --j)
 #pragma unroll
@@ -512,7 +537,11 @@ wfa_band_kernel(const BandArgs a) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
           insig &= Mh[X - 1][c] & Mh[OE - 1][c] & Ih[E - 1][c] & Dh[E - 1][c];
-          if (TWO) insig &= Mh[TWO ? OE2 - 1 : 0][c] & I2h[E2D - 1][c] & D2h[E2D - 1][c];
+          if (TWO) {
+            constexpr int PD = TWO ? OE2 - 1 - DM : 0;  // depth OE2 (index OE2 - 1) sits in half PD & 1 of PH[PD / 2]
+            const int mo2 = (PD & 1) ? (PH[PD / 2][c] >> 16) : (int)(short)(PH[PD / 2][c] & 0xffff);
+            insig &= ((mo2 < 0) ? WFA_OFFSET_NULL : mo2) & I2h[E2D - 1][c] & D2h[E2D - 1][c];
+          }
         }
         int ni[NCH], nd[NCH], nm[NCH], ni2[NCH], nd2[NCH];
         if (__any(insig >= 0)) {
@@ -525,8 +554,11 @@ wfa_band_kernel(const BandArgs a) {
             nd[c] = max(mo_hi, de_hi);
             ni2[c] = WFA_OFFSET_NULL; nd2[c] = WFA_OFFSET_NULL;
             if (TWO) {
-              ni2[c] = max(BD::below(Mh[TWO ? OE2 - 1 : 0], c), BD::below(I2h[E2D - 1], c)) + 1;
-              nd2[c] = max(BD::above(Mh[TWO ? OE2 - 1 : 0], c), BD::above(D2h[E2D - 1], c));
+              constexpr int PD = TWO ? OE2 - 1 - DM : 0;
+              const int plo = BD::below(PH[PD / 2], c, -1), phi = BD::above(PH[PD / 2], c, -1);
+              const int m2lo = (PD & 1) ? (plo >> 16) : (int)(short)(plo & 0xffff), m2hi = (PD & 1) ? (phi >> 16) : (int)(short)(phi & 0xffff);
+              ni2[c] = max((m2lo < 0) ? WFA_OFFSET_NULL : m2lo, BD::below(I2h[E2D - 1], c)) + 1;
+              nd2[c] = max((m2hi < 0) ? WFA_OFFSET_NULL : m2hi, BD::above(D2h[E2D - 1], c));
             }
             int m = max(max(nd[c], nd2[c]), max(Mh[X - 1][c] + 1, max(ni[c], ni2[c])));
             if (m > lim[c]) m = WFA_OFFSET_NULL;  // only M is clamped; negative values are dead already
