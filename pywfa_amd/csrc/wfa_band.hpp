@@ -257,9 +257,11 @@ __device__ void band_backtrace(const int* hist, const BandArgs& a, int plen, int
   if (nruns_out) *nruns_out = nruns;
 }
 
-template <int NCH, bool FULL, bool ADAPT, bool SEQLDS, bool PB, int X, int OE, int E, int OE2, int E2>
+template <int NCH, bool FULL, bool ADAPT, bool SEQLDS, bool PB, bool SPLIT, int X, int OE, int E, int OE2, int E2>
 __global__ void __launch_bounds__(64)
 wfa_band_kernel(const BandArgs a) {
+  static_assert(FULL || !SPLIT, "split launches have a history");
+  static_assert(SPLIT || !PB, "piggy-back history: split launches only");
   static_assert(FULL || !PB, "piggy-back history only with a history");
   static_assert(!(PB && OE2 > 0), "piggy-back history: gap-affine only");
   constexpr bool TWO = OE2 > 0;  // gap-affine-2p: second pair of gap components (R/wavefront_compute_affine2p.c:45-106)
@@ -280,7 +282,7 @@ wfa_band_kernel(const BandArgs a) {
   const int rec_ints = PB ? W / 4 : ((a.h16 && !TWO) ? BD::REC / 2 : BD::REC);  // 2p: 16-byte entries of 6 x int16  // piggy-back: one byte per window position
   const int max_records = FULL ? (int)min((long long)INT_MAX, (PB ? a.pb_code_ints : a.hist_stride) / rec_ints) : INT_MAX;
 
-  const bool split = FULL && a.split;
+  constexpr bool split = SPLIT;  // (a template parameter: the in-kernel walk of the other form costs 20 VGPRs = 2 waves per SIMD)
   const uint32_t nwork = a.nwork_dev ? *a.nwork_dev : a.nwork;
   const uint32_t w0 = split ? a.work_begin : 0u;
   for (uint32_t wi = w0 + blockIdx.x; wi < w0 + nwork; wi += gridDim.x) {
@@ -626,7 +628,7 @@ wfa_band_kernel(const BandArgs a) {
     }
     if (split) {
       if (lane == 0) a.end_state[wi - w0] = make_int4(end_s, end_k, end_off, fallback ? 0 : 1);
-    } else if (FULL && !fallback) {
+    } else if (FULL && !SPLIT && !fallback) {
       // make this wave's history stores visible to its own loads
       __syncthreads();
       long long begin = 0;
@@ -889,16 +891,21 @@ inline bool band_supported(const WfaDevConfig& c, int ncomp) {
   return false;
 }
 
+template <int NCH, bool FULL, bool ADAPT, bool PB, bool SPLIT, int X, int OE, int E, int OE2, int E2>
+static int launch_band_k(const BandArgs& a, bool seqlds, long long grid, hipStream_t stream) {
+  const size_t smem = seqlds ? (size_t)a.lds_words * 2 * sizeof(uint32_t) : 0;
+  if (seqlds) hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, true, PB, SPLIT, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+  else hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, false, PB, SPLIT, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 template <int NCH, bool FULL, bool ADAPT, int X, int OE, int E, int OE2, int E2>
 static int launch_band_t(const BandArgs& a, bool seqlds, long long grid, hipStream_t stream) {
-  const size_t smem = seqlds ? (size_t)a.lds_words * 2 * sizeof(uint32_t) : 0;
   constexpr bool CAN_PB = FULL && OE2 == 0;
-  if (CAN_PB && a.pb) {  // piggy-back history (split launches of long reads)
-    if (seqlds) hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, true, CAN_PB, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
-    else hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, false, CAN_PB, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), 0, stream, a);
-  } else if (seqlds) hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, true, false, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
-  else hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, false, false, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), 0, stream, a);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  if (FULL && a.split) {  // history slot per pair, walk in its own kernel; piggy-back history (gap-affine) on request
+    if (CAN_PB && a.pb) return launch_band_k<NCH, FULL, ADAPT, CAN_PB, FULL, X, OE, E, OE2, E2>(a, seqlds, grid, stream);
+    return launch_band_k<NCH, FULL, ADAPT, false, FULL, X, OE, E, OE2, E2>(a, seqlds, grid, stream);
+  }
+  return launch_band_k<NCH, FULL, ADAPT, false, false, X, OE, E, OE2, E2>(a, seqlds, grid, stream);
 }
 
 template <int X, int OE, int E, int OE2, int E2>
