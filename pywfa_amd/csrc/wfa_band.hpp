@@ -62,6 +62,13 @@ struct BandArgs {
                           // int16, entry k - klo, klo = ceil((tlen - plen) / 2) - seg_w / 2
 };
 
+// index of the lowest set bit, ~0u for 0 (v_ffbl_b32 semantics)
+__device__ __forceinline__ uint32_t band_ffbl(uint32_t x) {
+  uint32_t r;
+  asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
 // wave-wide minimum without LDS traffic: butterfly inside each row of 16 lanes with DPP, then 4 row leaders
 __device__ __forceinline__ int wave_min_dpp(int v) {
   v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false));
@@ -374,8 +381,9 @@ wfa_band_kernel(const BandArgs a) {
                   else { p0 = gP[pi]; p1 = gP[pi + 1]; p2 = gP[pi + 2]; t0 = gT[ti]; t1 = gT[ti + 1]; t2 = gT[ti + 2]; }
                   const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v[c] << 1) ^ __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h[c] << 1);
                   const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, (uint32_t)v[c] << 1) ^ __builtin_amdgcn_alignbit(t2, t1, (uint32_t)h[c] << 1);
-                  int m = xl ? (__builtin_ctz(xl) >> 1) : (xh ? 16 + (__builtin_ctz(xh) >> 1) : 32);
-                  m = min(m, left[c]);
+                  // first differing bit of xh:xl (v_ffbl_b32 gives ~0 for 0: `| 32` is +32 or stays ~0)
+                  const uint32_t fb = min(band_ffbl(xl), band_ffbl(xh) | 32u);
+                  const int m = min((int)(fb >> 1), min(32, left[c]));
                   v[c] += m; h[c] += m; left[c] -= m;
                   more |= (m == 32) && (left[c] > 0);
                 }
@@ -548,12 +556,22 @@ wfa_band_kernel(const BandArgs a) {
         int ni[NCH], nd[NCH], nm[NCH], ni2[NCH], nd2[NCH];
         if (__any(insig >= 0)) {
           unsigned long long oob = 0;
+          int gi[NCH], gd[NCH];
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) { gi[c] = max(Mh[OE - 1][c], Ih[E - 1][c]); gd[c] = max(Mh[OE - 1][c], Dh[E - 1][c]); }
 #pragma unroll
           for (int c = 0; c < NCH; ++c) {
-            const int mo_lo = BD::below(Mh[OE - 1], c), ie_lo = BD::below(Ih[E - 1], c);
-            const int mo_hi = BD::above(Mh[OE - 1], c), de_hi = BD::above(Dh[E - 1], c);
-            ni[c] = max(mo_lo, ie_lo) + 1;
-            nd[c] = max(mo_hi, de_hi);
+            int mo_lo = 0, ie_lo = 0, mo_hi = 0, de_hi = 0;
+            if (PB) {
+              mo_lo = BD::below(Mh[OE - 1], c); ie_lo = BD::below(Ih[E - 1], c);
+              mo_hi = BD::above(Mh[OE - 1], c); de_hi = BD::above(Dh[E - 1], c);
+              ni[c] = max(mo_lo, ie_lo) + 1;
+              nd[c] = max(mo_hi, de_hi);
+            } else {
+              // I(k) = max(M_oe, I_e)(k-1) + 1, D(k) = max(M_oe, D_e)(k+1): the max commutes with the lane shift
+              ni[c] = BD::below(gi, c) + 1;
+              nd[c] = BD::above(gd, c);
+            }
             ni2[c] = WFA_OFFSET_NULL; nd2[c] = WFA_OFFSET_NULL;
             if (TWO) {
               constexpr int PD = TWO ? OE2 - 1 - DM : 0;
