@@ -279,3 +279,38 @@ def test_banded_kernel_penalty_shapes(gpu, pen):
             o_ = loader.run(loader.oracle(), oc, batch, want_cigar=full)
             score, status, cigars = common.gpu_run(nc, batch, full, (i + j) % 2 == 0)
             common.assert_same(o_, score, status, cigars, batch, f"banded {kw2} L={L}")
+
+
+@pytest.mark.parametrize("scope", ["score", "full"])
+@pytest.mark.parametrize("order", ["divergent_first", "similar_first"])
+def test_pilot_choice_never_changes_results(gpu, scope, order):
+    """Batches of >= 64 k pairs let a pilot on the first 8192 pairs pick the first segment width; a batch whose head is
+    unlike its tail (very divergent head, similar tail, and the reverse) must still come out right, on a first run and
+    on a re-run of the resident batch (which reuses the choice)."""
+    head = datagen.generate(9000, 150, 0.14, 9901)
+    tail = datagen.generate(61000, 150, 0.01, 9902)
+    parts = [head, tail] if order == "divergent_first" else [tail, head]
+    # concatenate the two generated batches without going through Python strings
+    import numpy as np
+    seqs = np.concatenate([parts[0]["seqs"], parts[1]["seqs"]])
+    shift = len(parts[0]["seqs"])
+    batch = {"seqs": seqs,
+             "p_off": np.concatenate([parts[0]["p_off"], parts[1]["p_off"] + shift]),
+             "p_len": np.concatenate([parts[0]["p_len"], parts[1]["p_len"]]),
+             "t_off": np.concatenate([parts[0]["t_off"], parts[1]["t_off"] + shift]),
+             "t_len": np.concatenate([parts[0]["t_len"], parts[1]["t_len"]])}
+    oc, nc = common.configs_pair(span="end-to-end", scope=scope)
+    full = scope == "full"
+    o = loader.run(loader.oracle(), oc, batch, want_cigar=full)
+    from pywfa_amd import _native
+    al = _native.Aligner(nc)
+    rb = al.batch(batch)
+    for _ in range(2):
+        rb.run(); rb.sync()
+        score, status, cig = rb.results(full)
+        assert np.array_equal(status, o["status"]) and np.array_equal(score, o["score"])
+        if full:
+            ops, cb, cl = cig
+            for i in range(0, len(score), 37):
+                assert ops[cb[i]:cb[i] + cl[i]].tobytes() == o["cigars"][i]
+    rb.close(); al.close()
