@@ -265,8 +265,7 @@ __device__ void band_backtrace(const int* hist, const BandArgs& a, int plen, int
 }
 
 template <int NCH, bool FULL, bool ADAPT, bool SEQLDS, bool PB, bool SPLIT, int X, int OE, int E, int OE2, int E2>
-__global__ void __launch_bounds__(64)
-wfa_band_kernel(const BandArgs a) {
+__device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
   static_assert(FULL || !SPLIT, "split launches have a history");
   static_assert(SPLIT || !PB, "piggy-back history: split launches only");
   static_assert(FULL || !PB, "piggy-back history only with a history");
@@ -669,6 +668,19 @@ wfa_band_kernel(const BandArgs a) {
   }
 }
 
+template <int NCH, bool FULL, bool ADAPT, bool SEQLDS, bool PB, bool SPLIT, int X, int OE, int E, int OE2, int E2>
+__global__ void __launch_bounds__(64)
+wfa_band_kernel(const BandArgs a) {
+  wfa_band_body<NCH, FULL, ADAPT, SEQLDS, PB, SPLIT, X, OE, E, OE2, E2>(a);
+}
+// the same body compiled for three waves per SIMD (<= 168 VGPRs): the 256-diagonal gap-affine-2p form, whose 180-odd
+// registers would leave two
+template <int NCH, bool FULL, bool ADAPT, bool SEQLDS, bool PB, bool SPLIT, int X, int OE, int E, int OE2, int E2>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
+wfa_band_kernel_w3(const BandArgs a) {
+  wfa_band_body<NCH, FULL, ADAPT, SEQLDS, PB, SPLIT, X, OE, E, OE2, E2>(a);
+}
+
 // Backtrace of a split launch: one THREAD per alignment, so that a wave keeps 64 dependent walks in flight.
 // The walk emits run records into the top of the pair's own history slot; wfa_band_expand_kernel then
 // writes the op bytes.
@@ -912,8 +924,13 @@ inline bool band_supported(const WfaDevConfig& c, int ncomp) {
 template <int NCH, bool FULL, bool ADAPT, bool PB, bool SPLIT, int X, int OE, int E, int OE2, int E2>
 static int launch_band_k(const BandArgs& a, bool seqlds, long long grid, hipStream_t stream) {
   const size_t smem = seqlds ? (size_t)a.lds_words * 2 * sizeof(uint32_t) : 0;
-  if (seqlds) hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, true, PB, SPLIT, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
-  else hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, false, PB, SPLIT, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), 0, stream, a);
+  if constexpr (OE2 > 0 && NCH == 4) {
+    if (seqlds) hipLaunchKernelGGL((wfa_band_kernel_w3<NCH, FULL, ADAPT, true, PB, SPLIT, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+    else hipLaunchKernelGGL((wfa_band_kernel_w3<NCH, FULL, ADAPT, false, PB, SPLIT, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), 0, stream, a);
+  } else {
+    if (seqlds) hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, true, PB, SPLIT, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+    else hipLaunchKernelGGL((wfa_band_kernel<NCH, FULL, ADAPT, false, PB, SPLIT, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), 0, stream, a);
+  }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 template <int NCH, bool FULL, bool ADAPT, int X, int OE, int E, int OE2, int E2>
