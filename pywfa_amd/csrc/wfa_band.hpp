@@ -82,7 +82,8 @@ __device__ __forceinline__ int wave_min_dpp(int v) {
 template <int NCH>
 struct Band {
   static constexpr int W = 64 * NCH;
-  static constexpr int REC = 4 * W;  // history record of one score: {M, I, D, window base} per window position (16 B)
+  static constexpr int WI = (NCH == 3) ? 256 : W;  // records are indexed by k mod WI (a power of two)
+  static constexpr int REC = 4 * WI;  // history record of one score: {M, I, D, window base} per window position (16 B)
 
   // value of the diagonal below / above across chunk boundaries
   static __device__ __forceinline__ int below(const int (&r)[NCH], int c, int nullv = WFA_OFFSET_NULL) {
@@ -137,10 +138,10 @@ __device__ __forceinline__ int4 band_entry(const int* hist, int si, int k, int h
   int4 e = make_int4(WFA_OFFSET_NULL, WFA_OFFSET_NULL, WFA_OFFSET_NULL, 0);
   if (si >= 0) {
     if (h16) {
-      const short4 q = reinterpret_cast<const short4*>(hist + (long long)si * (BD::REC / 2))[k & (BD::W - 1)];
+      const short4 q = reinterpret_cast<const short4*>(hist + (long long)si * (BD::REC / 2))[k & (BD::WI - 1)];
       e = make_int4(q.x < 0 ? WFA_OFFSET_NULL : q.x, q.y < 0 ? WFA_OFFSET_NULL : q.y, q.z < 0 ? WFA_OFFSET_NULL : q.z, q.w);
     } else {
-      e = reinterpret_cast<const int4*>(hist + (long long)si * BD::REC)[k & (BD::W - 1)];
+      e = reinterpret_cast<const int4*>(hist + (long long)si * BD::REC)[k & (BD::WI - 1)];
     }
     if (k < e.w || k >= e.w + BD::W) { e.x = WFA_OFFSET_NULL; e.y = WFA_OFFSET_NULL; e.z = WFA_OFFSET_NULL; }
   }
@@ -179,7 +180,7 @@ __device__ void band_backtrace(const int* hist, const BandArgs& a, int plen, int
         e.m = nz(q.x); e.i1 = nz(q.y); e.d1 = nz(q.z);
       }
     } else if (two) {
-      const int4 q = reinterpret_cast<const int4*>(hist + (long long)si * BD::REC)[kk & (BD::W - 1)];
+      const int4 q = reinterpret_cast<const int4*>(hist + (long long)si * BD::REC)[kk & (BD::WI - 1)];
       const int base = q.y >> 16;
       if (kk >= base && kk < base + BD::W) {
         e.m = nz((int)(short)(q.x & 0xffff)); e.i1 = nz(q.x >> 16); e.d1 = nz((int)(short)(q.y & 0xffff));
@@ -274,6 +275,7 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
   constexpr int E2D = TWO ? E2 : 1;
   typedef Band<NCH> BD;
   constexpr int W = BD::W;
+  constexpr int WI = BD::WI;
   constexpr int DM1 = (X > OE) ? X : OE;
   // M history: depths 1..DM in registers; 2p: the depths beyond max(X, OE), read only once (at OE2), are kept as int16
   // pairs, two depths per register, shifted with one v_alignbit each (half the registers and moves; reads < 32000 bases)
@@ -285,7 +287,7 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
   uint32_t* const sT = slds + a.lds_words;
   const int lane = threadIdx.x;
   int* hist = FULL ? a.hist + (long long)blockIdx.x * a.hist_stride : nullptr;
-  const int rec_ints = PB ? W / 4 : ((a.h16 && !TWO) ? BD::REC / 2 : BD::REC);  // 2p: 16-byte entries of 6 x int16  // piggy-back: one byte per window position
+  const int rec_ints = PB ? WI / 4 : ((a.h16 && !TWO) ? BD::REC / 2 : BD::REC);  // 2p: 16-byte entries of 6 x int16  // piggy-back: one byte per window position
   const int max_records = FULL ? (int)min((long long)INT_MAX, (PB ? a.pb_code_ints : a.hist_stride) / rec_ints) : INT_MAX;
 
   constexpr bool split = SPLIT;  // (a template parameter: the in-kernel walk of the other form costs 20 VGPRs = 2 waves per SIMD)
@@ -347,9 +349,9 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
           // starts from the codes of the END cell, so they are stored before the termination test
           const int si = s / a.g;
           if (si + 1 >= max_records) { fallback = true; break; }
-          uint8_t* rec = reinterpret_cast<uint8_t*>(hist) + (long long)si * W;
+          uint8_t* rec = reinterpret_cast<uint8_t*>(hist) + (long long)si * WI;
 #pragma unroll
-          for (int c = 0; c < NCH; ++c) rec[kk[c] & (W - 1)] = (uint8_t)code[c];
+          for (int c = 0; c < NCH; ++c) rec[kk[c] & (WI - 1)] = (uint8_t)code[c];
         }
         // ---------------- extend M[s] ----------------
         unsigned long long live[NCH];
@@ -463,17 +465,17 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
               // {M | I1 << 16, D1 | B << 16, I2 | D2 << 16, 0}: int16 halves, negative -> -1 (reads < 32000 bases)
 #pragma unroll
               for (int c = 0; c < NCH; ++c)
-                reinterpret_cast<int4*>(rec)[kk[c] & (W - 1)] =
+                reinterpret_cast<int4*>(rec)[kk[c] & (WI - 1)] =
                     make_int4((sat16(cur[c]) & 0xffff) | (sat16(Ih[0][c]) << 16), (sat16(Dh[0][c]) & 0xffff) | (B << 16),
                               (sat16(I2h[0][c]) & 0xffff) | (sat16(D2h[0][c]) << 16), 0);
             } else if (a.h16) {
 #pragma unroll
               for (int c = 0; c < NCH; ++c)
-                reinterpret_cast<short4*>(rec)[kk[c] & (W - 1)] =
+                reinterpret_cast<short4*>(rec)[kk[c] & (WI - 1)] =
                     make_short4((short)sat16(cur[c]), (short)sat16(Ih[0][c]), (short)sat16(Dh[0][c]), (short)B);
             } else {
 #pragma unroll
-              for (int c = 0; c < NCH; ++c) reinterpret_cast<int4*>(rec)[kk[c] & (W - 1)] = make_int4(cur[c], Ih[0][c], Dh[0][c], B);
+              for (int c = 0; c < NCH; ++c) reinterpret_cast<int4*>(rec)[kk[c] & (WI - 1)] = make_int4(cur[c], Ih[0][c], Dh[0][c], B);
             }
           }
         }
@@ -501,7 +503,7 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
           const int fp = BD::first_pos(hull), lp = BD::last_pos(hull);
           if (lp >= 0) {
             const int width = lp - fp + 1;
-            if (width > W - 20) { fallback = true; break; }
+            if (width > ((a.debug >> 8) ? (a.debug >> 8) : W - 20)) { fallback = true; break; }  // (debug >> 8: width experiments)
             if (fp < 9 || lp > W - 10) {
               // re-centre, keeping the target diagonal representable when it is within reach
               int delta = fp - (W - width) / 2;
@@ -680,6 +682,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 wfa_band_kernel_w3(const BandArgs a) {
   wfa_band_body<NCH, FULL, ADAPT, SEQLDS, PB, SPLIT, X, OE, E, OE2, E2>(a);
 }
+template <int NCH, bool FULL, bool ADAPT, bool SEQLDS, bool PB, bool SPLIT, int X, int OE, int E, int OE2, int E2>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+wfa_band_kernel_w4(const BandArgs a) {  // four waves per SIMD (<= 128 VGPRs): the 192-diagonal 2p form
+  wfa_band_body<NCH, FULL, ADAPT, SEQLDS, PB, SPLIT, X, OE, E, OE2, E2>(a);
+}
 
 // Backtrace of a split launch: one THREAD per alignment, so that a wave keeps 64 dependent walks in flight.
 // The walk emits run records into the top of the pair's own history slot; wfa_band_expand_kernel then
@@ -726,7 +733,7 @@ __device__ __forceinline__ int pb_lcp(const uint32_t* __restrict__ P, const uint
 template <int NCH>
 __global__ void __launch_bounds__(64)
 wfa_band_pb_bt_kernel(const BandArgs a) {
-  constexpr int W = 64 * NCH;
+  constexpr int W = Band<NCH>::WI;
   const uint32_t t = blockIdx.x * 64u + threadIdx.x;
   if (t >= a.nwork) return;
   const int4 es = a.end_state[t];
@@ -886,6 +893,7 @@ inline int launch_band_bt(const BandArgs& a, int nch, hipStream_t stream) {
     else if (nch == 2) hipLaunchKernelGGL((wfa_band_pb_bt_kernel<2>), dim3(grid), dim3(64), 0, stream, a);
     else hipLaunchKernelGGL((wfa_band_pb_bt_kernel<4>), dim3(grid), dim3(64), 0, stream, a);
   } else if (nch == 1) hipLaunchKernelGGL((wfa_band_bt_kernel<1>), dim3(grid), dim3(64), 0, stream, a);
+  else if (nch == 3) hipLaunchKernelGGL((wfa_band_bt_kernel<3>), dim3(grid), dim3(64), 0, stream, a);
   else if (nch == 2) hipLaunchKernelGGL((wfa_band_bt_kernel<2>), dim3(grid), dim3(64), 0, stream, a);
   else hipLaunchKernelGGL((wfa_band_bt_kernel<4>), dim3(grid), dim3(64), 0, stream, a);
   if (hipGetLastError() != hipSuccess) return -1;
@@ -924,7 +932,10 @@ inline bool band_supported(const WfaDevConfig& c, int ncomp) {
 template <int NCH, bool FULL, bool ADAPT, bool PB, bool SPLIT, int X, int OE, int E, int OE2, int E2>
 static int launch_band_k(const BandArgs& a, bool seqlds, long long grid, hipStream_t stream) {
   const size_t smem = seqlds ? (size_t)a.lds_words * 2 * sizeof(uint32_t) : 0;
-  if constexpr (OE2 > 0 && NCH == 4) {
+  if constexpr (OE2 > 0 && NCH == 3) {
+    if (seqlds) hipLaunchKernelGGL((wfa_band_kernel_w4<NCH, FULL, ADAPT, true, PB, SPLIT, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+    else hipLaunchKernelGGL((wfa_band_kernel_w4<NCH, FULL, ADAPT, false, PB, SPLIT, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), 0, stream, a);
+  } else if constexpr (OE2 > 0 && NCH == 4) {
     if (seqlds) hipLaunchKernelGGL((wfa_band_kernel_w3<NCH, FULL, ADAPT, true, PB, SPLIT, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
     else hipLaunchKernelGGL((wfa_band_kernel_w3<NCH, FULL, ADAPT, false, PB, SPLIT, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), 0, stream, a);
   } else {
@@ -955,6 +966,7 @@ static int launch_band_shape(const BandArgs& a, int nch, bool full, bool adapt, 
   WFA_BAND_CASE(1)
   WFA_BAND_CASE(2)
   WFA_BAND_CASE(4)
+  if constexpr (OE2 > 0) { WFA_BAND_CASE(3) }  // 192 diagonals: what most gap-affine-2p wavefronts need
 #undef WFA_BAND_CASE
   return -1;
 }

@@ -661,7 +661,10 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     const bool use_segfull = !tiny && full && wfa::seg_supported(al->dcfg, al->ncomp, false) && b->max_len <= WFA_FAST_MAX_LEN &&
                              env_int("WFA_HIP_NO_FAST", 0) == 0 && env_int("WFA_HIP_NO_SEGFULL", 0) == 0;
     if (!tiny && wfa::band_supported(al->dcfg, al->ncomp) && (al->ncomp != 5 || b->max_len < 32000) && env_int("WFA_HIP_NO_BAND", 0) == 0) {
-      if (adapt) {
+      if (al->ncomp == 5) {
+        // gap-affine-2p wavefronts are wide (C4: 99 % need more than 108 diagonals, 2.6 % more than 172)
+        band_nch[n_stages++] = 3; band_nch[n_stages++] = 4;
+      } else if (adapt) {
         if (b->max_len <= 300) { band_nch[n_stages++] = 1; }
         band_nch[n_stages++] = 2; band_nch[n_stages++] = 4;
       } else if (b->max_len <= 300) {
@@ -692,7 +695,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       if (i > 0 || use_fast || use_segfull) grid = std::min<long long>(grid, (long long)al->cu_count * env_int("WFA_HIP_BAND_LEFTOVER_WAVES_PER_CU", 64));
       if (full) {
         const bool h16 = b->max_len < 32000;
-        const int rec = ((h16 && al->ncomp != 5) ? 2 : 4) * 64 * band_nch[i];  // ints per record (2p: 16-byte entries)
+        const int rec = ((h16 && al->ncomp != 5) ? 2 : 4) * (band_nch[i] == 3 ? 256 : 64 * band_nch[i]);  // ints per record (2p: 16-byte entries)
         // steps of an alignment = score / g; sized for scores up to 0.9 x the read length (about 15 % divergence)
         long long records = std::max<long long>(256, (long long)(b->max_len * 0.9) / wfa::band_gcd(al->dcfg, al->ncomp == 5) + 64);
         records = env_int("WFA_HIP_BAND_RECORDS", (int)records);
