@@ -347,7 +347,7 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
         if (PB) {
           // piggy-back history of score s: the origin codes do not depend on the extension or the cut-off, and the walk
           // starts from the codes of the END cell, so they are stored before the termination test
-          const int si = s / a.g;
+          const int si = step;  // = s / g: the score grows by g per step
           if (si + 1 >= max_records) { fallback = true; break; }
           uint8_t* rec = reinterpret_cast<uint8_t*>(hist) + (long long)si * WI;
 #pragma unroll
@@ -456,7 +456,7 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
           if (++dead_steps > 2 * DM + 2) { fallback = true; break; }
         }
         // ---------------- history of score s (after the cut-off, so dropped lanes read NULL) ----------------
-        const int si = s / a.g;
+        const int si = step;  // = s / g
         if (FULL && !PB) {
           if (si + 1 >= max_records) { fallback = true; break; }
           int* rec = hist + (long long)si * rec_ints;
