@@ -387,7 +387,7 @@ class WavefrontAligner:
         if patterns is None:
             if self._bpattern is None:
                 raise ValueError("pattern is None")
-            patterns = [self._bpattern] * len(texts)
+            patterns = self._bpattern  # stored once in the batch: every pair points to it
         else:
             patterns = list(patterns)
         if self._cfg.wildcard != self._bwildcard:
