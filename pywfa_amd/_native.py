@@ -6,6 +6,7 @@ or no HIP device is present, every alignment entry point raises.
 """
 import ctypes
 import os
+import weakref
 
 import numpy as np
 
@@ -155,9 +156,14 @@ class Aligner:
                 raise NotImplementedError(vmsg)
             raise NativeError(f"wfa_hip_create failed: {msg}")
         self.device = device
+        self._batches = weakref.WeakSet()
 
     def close(self):
         if getattr(self, "_h", None):
+            # resident batches hold device blocks of this aligner's pool: they go first (the library would also keep
+            # the handle alive until the last batch is destroyed)
+            for rb in list(self._batches):
+                rb.close()
             lib().wfa_hip_destroy(self._h)
             self._h = None
 
@@ -227,6 +233,7 @@ class ResidentBatch:
             if "failed:" in msg:
                 raise NativeError(f"wfa_hip_batch_create: {msg}")
             raise ValueError(f"wfa_hip_batch_create: {msg}")
+        aligner._batches.add(self)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -24,7 +24,7 @@
 namespace wfa {
 
 // penalty shapes (x, o + e, e) / gcd the banded kernel is instantiated for: pywfa's 4/6/2 and the presets 4/4/2, 4/6/1, 3/4/1
-#define WFA_BAND_SHAPES(F) F(2, 4, 1) F(2, 3, 1) F(4, 7, 1) F(3, 5, 1)
+#define WFA_BAND_SHAPES(F) F(0, 2, 4, 1) F(1, 2, 3, 1) F(2, 4, 7, 1) F(3, 3, 5, 1)
 
 struct BandArgs {
   const uint32_t* words;
@@ -790,6 +790,7 @@ wfa_band_pb_bt_kernel(const BandArgs a) {
   a.end_state[t] = make_int4((int)((long long)plen + tlen - total), nruns, 1, 2);  // .z = 1: runs in forward order
 }
 
+#ifdef WFA_BAND_WALK_KERNELS  // the non-template kernels below are emitted by one translation unit (k_band.hip, index 5)
 // One wave per alignment: run r (r = 0 is the LAST run of the op string) covers
 // [end - sum(len[0..r]), end - sum(len[0..r-1])); lanes take 64 runs at a time, positions come from a wave
 // prefix sum, short runs are written by their lane, long ones by the whole wave.
@@ -885,7 +886,7 @@ wfa_seg_expand_kernel(const BandArgs a) {
   }
 }
 
-inline int launch_band_bt(const BandArgs& a, int nch, hipStream_t stream) {
+inline int launch_band_bt_impl(const BandArgs& a, int nch, hipStream_t stream) {
   const unsigned grid = (a.nwork + 63u) / 64u;
   if (grid == 0) return 0;
   if (a.pb) {
@@ -902,32 +903,7 @@ inline int launch_band_bt(const BandArgs& a, int nch, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// configurations the band kernel covers: gap-affine / gap-affine-2p with an instantiated penalty shape
-// (x, o1 + e1, e1 [, o2 + e2, e2]) / gcd; 2p: pywfa's default 4/6/2/24/1
-#define WFA_BAND_SHAPES_2P(F) F(4, 8, 2, 25, 1)
-inline int band_gcd(const WfaDevConfig& c, bool two) {
-  int g = gcd_int(gcd_int(c.x, c.o1 + c.e1), c.e1);
-  if (two) g = gcd_int(gcd_int(g, c.o2 + c.e2), c.e2);
-  return g;
-}
-inline bool band_supported(const WfaDevConfig& c, int ncomp) {
-  if ((ncomp != 3 && ncomp != 5) || c.match != 0 || c.wildcard >= 0 || c.max_steps != INT_MAX) return false;
-  if (c.heuristic != 0 && c.heuristic != 1) return false;
-  const bool two = ncomp == 5;
-  const int g = band_gcd(c, two);
-  const int X = c.x / g, OE = (c.o1 + c.e1) / g, E = c.e1 / g;
-  if (two) {
-    const int OE2 = (c.o2 + c.e2) / g, E2 = c.e2 / g;
-#define WFA_BAND_MATCH2(x, oe, e, oe2, e2) if (X == x && OE == oe && E == e && OE2 == oe2 && E2 == e2) return true;
-    WFA_BAND_SHAPES_2P(WFA_BAND_MATCH2)
-#undef WFA_BAND_MATCH2
-    return false;
-  }
-#define WFA_BAND_MATCH(x, oe, e) if (X == x && OE == oe && E == e) return true;
-  WFA_BAND_SHAPES(WFA_BAND_MATCH)
-#undef WFA_BAND_MATCH
-  return false;
-}
+#endif  // WFA_BAND_WALK_KERNELS
 
 template <int NCH, bool FULL, bool ADAPT, bool PB, bool SPLIT, int X, int OE, int E, int OE2, int E2>
 static int launch_band_k(const BandArgs& a, bool seqlds, long long grid, hipStream_t stream) {
@@ -971,16 +947,45 @@ static int launch_band_shape(const BandArgs& a, int nch, bool full, bool adapt, 
   return -1;
 }
 
+// ---- host entry points.  Every penalty shape is compiled in its own translation unit (csrc/k_band.hip, once per
+// index; index 4 = gap-affine-2p, index 5 = the walks / expansion kernels) so that the library builds in parallel.
+int launch_band_bt(const BandArgs& a, int nch, hipStream_t stream);
+#define WFA_BAND_DECL(i, x, oe, e) int launch_band_s##i(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds, long long grid, hipStream_t stream);
+WFA_BAND_SHAPES(WFA_BAND_DECL)
+#undef WFA_BAND_DECL
+int launch_band_s4(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds, long long grid, hipStream_t stream);  // 2p
+
+// configurations the band kernel covers: gap-affine / gap-affine-2p with an instantiated penalty shape
+// (x, o1 + e1, e1 [, o2 + e2, e2]) / gcd; 2p: pywfa's default 4/6/2/24/1
+#define WFA_BAND_SHAPES_2P(F) F(4, 8, 2, 25, 1)
+inline int band_gcd(const WfaDevConfig& c, bool two) {
+  int g = gcd_int(gcd_int(c.x, c.o1 + c.e1), c.e1);
+  if (two) g = gcd_int(gcd_int(g, c.o2 + c.e2), c.e2);
+  return g;
+}
+inline bool band_supported(const WfaDevConfig& c, int ncomp) {
+  if ((ncomp != 3 && ncomp != 5) || c.match != 0 || c.wildcard >= 0 || c.max_steps != INT_MAX) return false;
+  if (c.heuristic != 0 && c.heuristic != 1) return false;
+  const bool two = ncomp == 5;
+  const int g = band_gcd(c, two);
+  const int X = c.x / g, OE = (c.o1 + c.e1) / g, E = c.e1 / g;
+  if (two) {
+    const int OE2 = (c.o2 + c.e2) / g, E2 = c.e2 / g;
+#define WFA_BAND_MATCH2(x, oe, e, oe2, e2) if (X == x && OE == oe && E == e && OE2 == oe2 && E2 == e2) return true;
+    WFA_BAND_SHAPES_2P(WFA_BAND_MATCH2)
+#undef WFA_BAND_MATCH2
+    return false;
+  }
+#define WFA_BAND_MATCH(i, x, oe, e) if (X == x && OE == oe && E == e) return true;
+  WFA_BAND_SHAPES(WFA_BAND_MATCH)
+#undef WFA_BAND_MATCH
+  return false;
+}
+
 inline int launch_band(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds, long long grid, hipStream_t stream) {
   const int g = a.g, X = a.x / g, OE = a.oe / g, E = a.e / g;
-  if (a.oe2 > 0) {
-    const int OE2 = a.oe2 / g, E2 = a.e2 / g;
-#define WFA_BAND_LAUNCH2(x, oe, e, oe2, e2) if (X == x && OE == oe && E == e && OE2 == oe2 && E2 == e2) return launch_band_shape<x, oe, e, oe2, e2>(a, nch, full, adapt, seqlds, grid, stream);
-    WFA_BAND_SHAPES_2P(WFA_BAND_LAUNCH2)
-#undef WFA_BAND_LAUNCH2
-    return -1;
-  }
-#define WFA_BAND_LAUNCH(x, oe, e) if (X == x && OE == oe && E == e) return launch_band_shape<x, oe, e, 0, 0>(a, nch, full, adapt, seqlds, grid, stream);
+  if (a.oe2 > 0) return launch_band_s4(a, nch, full, adapt, seqlds, grid, stream);
+#define WFA_BAND_LAUNCH(i, x, oe, e) if (X == x && OE == oe && E == e) return launch_band_s##i(a, nch, full, adapt, seqlds, grid, stream);
   WFA_BAND_SHAPES(WFA_BAND_LAUNCH)
 #undef WFA_BAND_LAUNCH
   return -1;

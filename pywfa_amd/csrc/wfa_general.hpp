@@ -588,4 +588,30 @@ wfa_general_kernel(const WfaKernelArgs a) {
   }
 }
 
+// host entry points, one translation unit per component count (csrc/k_general.hip, -DWFA_TU_INDEX = 0 / 1 / 2 for
+// NCOMP = 1 / 3 / 5)
+int launch_general_c1(bool packed, bool full, const WfaKernelArgs& a, int grid, int threads, hipStream_t stream);
+int launch_general_c3(bool packed, bool full, const WfaKernelArgs& a, int grid, int threads, hipStream_t stream);
+int launch_general_c5(bool packed, bool full, const WfaKernelArgs& a, int grid, int threads, hipStream_t stream);
+
+template <int NCOMP>
+inline int launch_general_ncomp(bool packed, bool full, const WfaKernelArgs& a, int grid, int threads, hipStream_t stream) {
+  const size_t smem = ((size_t)a.cfg.scope * Meta<NCOMP>::INTS + 2 * NCOMP + 8) * sizeof(int);
+  const dim3 g(grid), t(threads);
+  if (packed) {
+    if (full) hipLaunchKernelGGL((wfa_general_kernel<NCOMP, true, true>), g, t, smem, stream, a);
+    else hipLaunchKernelGGL((wfa_general_kernel<NCOMP, true, false>), g, t, smem, stream, a);
+  } else {
+    if (full) hipLaunchKernelGGL((wfa_general_kernel<NCOMP, false, true>), g, t, smem, stream, a);
+    else hipLaunchKernelGGL((wfa_general_kernel<NCOMP, false, false>), g, t, smem, stream, a);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+inline int launch_general_any(int ncomp, bool packed, bool full, const WfaKernelArgs& a, int grid, int threads, hipStream_t stream) {
+  if (ncomp == 1) return launch_general_c1(packed, full, a, grid, threads, stream);
+  if (ncomp == 3) return launch_general_c3(packed, full, a, grid, threads, stream);
+  return launch_general_c5(packed, full, a, grid, threads, stream);
+}
+
 }  // namespace wfa

@@ -31,12 +31,55 @@
 
 static thread_local std::string g_error;
 
+// Development knobs, read from the environment ONCE per aligner in wfa_hip_create: the hot entry points
+// never call getenv.
+#define WFA_KNOBS(F)                                                                                              \
+  F(ARENA_KB) F(BAND_DEBUG) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
+  F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
+  F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
+  F(PIPE_CHUNK) F(PIPE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB)
+enum WfaKnob {
+#define WFA_KNOB_ENUM(n) K_##n,
+  WFA_KNOBS(WFA_KNOB_ENUM)
+#undef WFA_KNOB_ENUM
+  K_COUNT
+};
+struct WfaKnobs {
+  int value[K_COUNT];
+  bool set[K_COUNT];
+  std::string fast_stages;  // WFA_HIP_FAST_STAGES (digits)
+  void load() {
+    static const char* const names[K_COUNT] = {
+#define WFA_KNOB_NAME(n) "WFA_HIP_" #n,
+        WFA_KNOBS(WFA_KNOB_NAME)
+#undef WFA_KNOB_NAME
+    };
+    for (int i = 0; i < K_COUNT; ++i) {
+      const char* v = getenv(names[i]);
+      set[i] = v && *v;
+      value[i] = set[i] ? atoi(v) : 0;
+    }
+    const char* fs = getenv("WFA_HIP_FAST_STAGES");
+    fast_stages = (fs && *fs) ? fs : "";
+  }
+};
+
 struct wfa_hip_aligner {
   int device = 0;
   wfa_hip_config_t cfg;
   WfaDevConfig dcfg;
   int ncomp = 3;
+  WfaKnobs knobs;
   hipStream_t stream = nullptr;
+  // lifetime: batches keep a pointer to their aligner; wfa_hip_destroy with batches still alive only marks the handle,
+  // the last batch to go frees it
+  int live_batches = 0;
+  bool destroy_pending = false;
+  // the workspace below is shared by every run of this aligner: a run enqueued on another stream than the previous
+  // one first waits for ws_event (recorded after each run), so runs are stream-ordered whatever streams callers pass
+  hipEvent_t ws_event = nullptr;
+  hipStream_t ws_last_stream = nullptr;
+  bool ws_event_recorded = false;
   int cu_count = 256;
   size_t total_mem = 0;
   std::string err;
@@ -49,6 +92,10 @@ struct wfa_hip_aligner {
   std::unordered_map<void*, size_t> pool_size;
   size_t pool_cached = 0;
 };
+
+static inline int knob(const wfa_hip_aligner* al, WfaKnob k, int dflt) {
+  return al->knobs.set[k] ? al->knobs.value[k] : dflt;
+}
 
 static const size_t POOL_MAX_BLOCK = (size_t)8 << 20, POOL_MAX_CACHED = (size_t)128 << 20;
 
@@ -85,6 +132,11 @@ static void pool_drain(wfa_hip_aligner* al) {
 
 struct wfa_hip_batch {
   wfa_hip_aligner* al = nullptr;
+  // configuration in force when the batch was created: the layout of the batch (op regions, 8-bit work list, checked
+  // free ends) follows it, so run / sync / results use this snapshot, never the aligner's current configuration
+  wfa_hip_config_t cfg;
+  WfaDevConfig dcfg;
+  int ncomp = 3;
   int64_t n = 0;
   // host copies needed later
   std::vector<int32_t> h_plen, h_tlen;
@@ -290,16 +342,26 @@ extern "C" wfa_hip_aligner_t* wfa_hip_create(const wfa_hip_config_t* cfg, int de
   al->cu_count = prop.multiProcessorCount;
   al->total_mem = prop.totalGlobalMem;
   if ((e = hipStreamCreateWithFlags(&al->stream, hipStreamNonBlocking)) != hipSuccess) { g_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete al; return nullptr; }
+  if ((e = hipEventCreateWithFlags(&al->ws_event, hipEventDisableTiming)) != hipSuccess) { g_error = std::string("hipEventCreate: ") + hipGetErrorString(e); (void)hipStreamDestroy(al->stream); delete al; return nullptr; }
+  al->knobs.load();
   return al;
+}
+
+static void aligner_free(wfa_hip_aligner* al) {
+  (void)hipSetDevice(al->device);
+  if (al->ws) (void)hipFree(al->ws);
+  pool_drain(al);
+  if (al->ws_event) (void)hipEventDestroy(al->ws_event);
+  if (al->stream) (void)hipStreamDestroy(al->stream);
+  delete al;
 }
 
 extern "C" void wfa_hip_destroy(wfa_hip_aligner_t* al) {
   if (!al) return;
-  (void)hipSetDevice(al->device);
-  if (al->ws) (void)hipFree(al->ws);
-  pool_drain(al);
-  if (al->stream) (void)hipStreamDestroy(al->stream);
-  delete al;
+  // resident batches keep a pointer to their aligner (pool, stream, workspace): while any is alive the handle is only
+  // marked, and the last wfa_hip_batch_destroy frees it
+  if (al->live_batches > 0) { al->destroy_pending = true; return; }
+  aligner_free(al);
 }
 
 extern "C" int wfa_hip_set_config(wfa_hip_aligner_t* al, const wfa_hip_config_t* cfg) {
@@ -335,7 +397,9 @@ static void batch_free(wfa_hip_batch* b) {
   (void)hipStreamSynchronize(b->al->stream);
   for (void* p : ptrs) pool_release(b->al, p);
   for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
+  wfa_hip_aligner* al = b->al;
   delete b;
+  if (--al->live_batches == 0 && al->destroy_pending) aligner_free(al);
 }
 
 extern "C" void wfa_hip_batch_destroy(wfa_hip_batch_t* b) { batch_free(b); }
@@ -344,8 +408,9 @@ static double now_ms() { return std::chrono::duration<double, std::milli>(std::c
 
 static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const uint8_t* seqs,
                        const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len) {
-  const wfa_hip_config_t& c = al->cfg;
-  const bool timing = getenv("WFA_HIP_TIMING") != nullptr;
+  b->cfg = al->cfg; b->dcfg = al->dcfg; b->ncomp = al->ncomp;
+  const wfa_hip_config_t& c = b->cfg;
+  const bool timing = al->knobs.set[K_TIMING];
   double t0 = now_ms();
   b->al = al;
   b->n = n;
@@ -512,6 +577,7 @@ static wfa_hip_batch* batch_create_nosync(wfa_hip_aligner_t* al, int64_t n, cons
   if (hipSetDevice(al->device) != hipSuccess) { al->err = "hipSetDevice failed"; g_error = al->err; return nullptr; }
   wfa_hip_batch* b = new wfa_hip_batch();
   b->al = al;
+  al->live_batches += 1;
   const int rc = batch_build(al, b, n, seqs, p_off, p_len, t_off, t_len);
   if (rc != WFA_HIP_OK) { g_error = al->err; batch_free(b); return nullptr; }
   return b;
@@ -527,10 +593,6 @@ extern "C" wfa_hip_batch_t* wfa_hip_batch_create(wfa_hip_aligner_t* al, int64_t 
 }
 
 // ---- launch geometry -------------------------------------------------------------------------------
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
 
 static int ensure_ws(wfa_hip_aligner* al, size_t bytes) {
   if (bytes <= al->ws_bytes) return WFA_HIP_OK;
@@ -540,10 +602,9 @@ static int ensure_ws(wfa_hip_aligner* al, size_t bytes) {
   return WFA_HIP_OK;
 }
 
-template <int NCOMP, bool FULL>
-static int launch_general(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream, bool packed,
-                          const uint32_t* worklist, const uint32_t* nwork_dev, uint32_t nwork_host,
-                          int64_t ws_stride, int grid, int threads, uint32_t* ovf_list, uint32_t* ovf_count) {
+static int launch_general_dyn(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream, bool packed,
+                              const uint32_t* worklist, const uint32_t* nwork_dev, uint32_t nwork_host,
+                              int64_t ws_stride, int grid, int threads, uint32_t* ovf_list, uint32_t* ovf_count) {
   WfaKernelArgs a;
   memset(&a, 0, sizeof(a));
   a.words = b->d_words; a.bytes = b->d_bytes; a.meta = b->d_meta; a.p_boff = b->d_pboff; a.t_boff = b->d_tboff;
@@ -552,28 +613,12 @@ static int launch_general(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t str
   a.cigar_ops = b->d_ops; a.cigar_off = b->d_cigar_off; a.cigar_begin = b->d_cigar_begin; a.cigar_len = b->d_cigar_len;
   a.ws = al->ws; a.ws_stride = ws_stride;
   a.fb_list = ovf_list; a.fb_count = ovf_count;
-  a.cfg = al->dcfg;
-  const size_t smem = ((size_t)al->dcfg.scope * wfa::Meta<NCOMP>::INTS + 2 * NCOMP + 8) * sizeof(int);
-  if (packed) hipLaunchKernelGGL((wfa::wfa_general_kernel<NCOMP, true, FULL>), dim3(grid), dim3(threads), smem, stream, a);
-  else hipLaunchKernelGGL((wfa::wfa_general_kernel<NCOMP, false, FULL>), dim3(grid), dim3(threads), smem, stream, a);
-  HIP_TRY(al, hipGetLastError());
+  a.cfg = b->dcfg;
+  if (wfa::launch_general_any(b->ncomp, packed, b->cfg.scope == WFA_SCOPE_FULL, a, grid, threads, stream) != 0) {
+    al->err = std::string("general kernel launch failed: ") + hipGetErrorString(hipGetLastError());
+    return WFA_HIP_EDEVICE;
+  }
   return WFA_HIP_OK;
-}
-
-static int launch_general_dyn(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream, bool packed,
-                              const uint32_t* worklist, const uint32_t* nwork_dev, uint32_t nwork_host,
-                              int64_t ws_stride, int grid, int threads, uint32_t* ovf_list, uint32_t* ovf_count) {
-  const bool full = (al->cfg.scope == WFA_SCOPE_FULL);
-  if (al->ncomp == 1) {
-    return full ? launch_general<1, true>(al, b, stream, packed, worklist, nwork_dev, nwork_host, ws_stride, grid, threads, ovf_list, ovf_count)
-                : launch_general<1, false>(al, b, stream, packed, worklist, nwork_dev, nwork_host, ws_stride, grid, threads, ovf_list, ovf_count);
-  }
-  if (al->ncomp == 3) {
-    return full ? launch_general<3, true>(al, b, stream, packed, worklist, nwork_dev, nwork_host, ws_stride, grid, threads, ovf_list, ovf_count)
-                : launch_general<3, false>(al, b, stream, packed, worklist, nwork_dev, nwork_host, ws_stride, grid, threads, ovf_list, ovf_count);
-  }
-  return full ? launch_general<5, true>(al, b, stream, packed, worklist, nwork_dev, nwork_host, ws_stride, grid, threads, ovf_list, ovf_count)
-              : launch_general<5, false>(al, b, stream, packed, worklist, nwork_dev, nwork_host, ws_stride, grid, threads, ovf_list, ovf_count);
 }
 
 // Geometry of the general kernel: threads per alignment, workgroups in flight, workspace per workgroup.
@@ -588,18 +633,18 @@ static int64_t free_budget(wfa_hip_aligner* al) {
 
 static Geometry plan_general(wfa_hip_aligner* al, const wfa_hip_batch* b, uint32_t nwork, int64_t arena_ints) {
   Geometry g;
-  const bool full = (al->cfg.scope == WFA_SCOPE_FULL);
+  const bool full = (b->cfg.scope == WFA_SCOPE_FULL);
   int threads = 64;
-  if (b->max_len > 2000) threads = (al->cfg.heuristic == WFA_HEUR_ADAPTIVE) ? 64 : 256;
-  threads = env_int("WFA_HIP_THREADS", threads);
+  if (b->max_len > 2000) threads = (b->cfg.heuristic == WFA_HEUR_ADAPTIVE) ? 64 : 256;
+  threads = knob(al, K_THREADS, threads);
   threads = std::max(64, std::min(512, (threads / 64) * 64));
   const int waves = threads / 64;
-  int per_cu = std::max(1, env_int("WFA_HIP_WAVES_PER_CU", 32) / waves);
+  int per_cu = std::max(1, knob(al, K_WAVES_PER_CU, 32) / waves);
   int64_t grid = (int64_t)al->cu_count * per_cu;
   grid = std::min<int64_t>(grid, std::max<uint32_t>(nwork, 1));
   int64_t stride;
   if (full) stride = arena_ints;
-  else stride = (int64_t)al->dcfg.scope * al->ncomp * b->max_width;
+  else stride = (int64_t)b->dcfg.scope * b->ncomp * b->max_width;
   stride = (stride + 63) & ~63ll;
   const int64_t budget = free_budget(al);
   while (grid > 1 && grid * stride * 4 > budget) grid = (grid + 1) / 2;
@@ -609,12 +654,12 @@ static Geometry plan_general(wfa_hip_aligner* al, const wfa_hip_batch* b, uint32
 
 static int64_t initial_arena_ints(const wfa_hip_aligner* al, const wfa_hip_batch* b) {
   typedef long long ll;
-  const int mi = 2 * al->ncomp + 4;
+  const int mi = 2 * b->ncomp + 4;
   // room for a run whose score is ~ the longer sequence and whose wavefronts are ~128 wide, and never
   // less than what wavefront 0 and a few hundred scores need; overflowing pairs are re-run larger
-  ll ints = (ll)b->max_len * (al->ncomp * 64 + mi) / 4 + (ll)b->max_width * al->ncomp * 4 + 4096 * mi;
+  ll ints = (ll)b->max_len * (b->ncomp * 64 + mi) / 4 + (ll)b->max_width * b->ncomp * 4 + 4096 * mi;
   ints = std::max<ll>(ints, 1 << 14);
-  const int e = env_int("WFA_HIP_ARENA_KB", 0);
+  const int e = knob(al, K_ARENA_KB, 0);
   if (e > 0) ints = (ll)e * 256;
   return ints;
 }
@@ -624,12 +669,15 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
   wfa_hip_aligner* al = b->al;
   HIP_TRY(al, hipSetDevice(al->device));
   hipStream_t stream = stream_ ? (hipStream_t)stream_ : al->stream;
+  // every run of this aligner uses the one workspace (al->ws): order this run after the previous one when it was
+  // enqueued on another stream
+  if (al->ws_event_recorded && al->ws_last_stream != stream) HIP_TRY(al, hipStreamWaitEvent(stream, al->ws_event, 0));
   b->last_stream = stream;
   b->ran = true; b->synced = false;
   b->last_fallback = 0;
   b->last_kernel_pairs = 0;
   if (b->n == 0) { b->synced = true; return WFA_HIP_OK; }
-  const bool full = (al->cfg.scope == WFA_SCOPE_FULL);
+  const bool full = (b->cfg.scope == WFA_SCOPE_FULL);
   HIP_TRY(al, hipMemsetAsync(b->d_counters, 0, 16 * sizeof(uint32_t), stream));
   b->arena_ints = full ? initial_arena_ints(al, b) : 0;
 
@@ -647,21 +695,20 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     uint32_t in_n = b->n_packed;
     int out_sel = 0;                               // leftovers go to d_fb_list[out_sel], count d_counters[4 + out_sel]
     bool first_stage = true;
-    const bool adapt = (al->dcfg.heuristic == WFA_HEUR_ADAPTIVE);
+    const bool adapt = (b->dcfg.heuristic == WFA_HEUR_ADAPTIVE);
     // the general kernel's geometry is fixed first so that one workspace allocation serves every stage
     int n_stages = 0;
     int band_nch[3] = {0, 0, 0};
     // a handful of pairs: one launch of the general kernel beats six nearly empty stages (single-pair calls of a
     // pywfa-style loop)
-    const bool tiny = in_n <= (uint32_t)env_int("WFA_HIP_TINY_BATCH", 128);
-    const bool use_fast = !tiny && !full && wfa::seg_supported(al->dcfg, al->ncomp, full) && b->max_len <= WFA_FAST_MAX_LEN &&
-                          env_int("WFA_HIP_NO_FAST", 0) == 0;
-    const bool legacy_ok = wfa::fast_supported(al->dcfg, al->ncomp, full);  // the one/two-per-wave kernels: 4/6/2-shaped only
+    const bool tiny = in_n <= (uint32_t)knob(al, K_TINY_BATCH, 128);
+    const bool use_fast = !tiny && !full && wfa::seg_supported(b->dcfg, b->ncomp, full) && b->max_len <= WFA_FAST_MAX_LEN &&
+                          knob(al, K_NO_FAST, 0) == 0;
     // full CIGARs of short reads: the segmented kernel with a history slot per pair, then the thread-per-alignment walk
-    const bool use_segfull = !tiny && full && wfa::seg_supported(al->dcfg, al->ncomp, false) && b->max_len <= WFA_FAST_MAX_LEN &&
-                             env_int("WFA_HIP_NO_FAST", 0) == 0 && env_int("WFA_HIP_NO_SEGFULL", 0) == 0;
-    if (!tiny && wfa::band_supported(al->dcfg, al->ncomp) && (al->ncomp != 5 || b->max_len < 32000) && env_int("WFA_HIP_NO_BAND", 0) == 0) {
-      if (al->ncomp == 5) {
+    const bool use_segfull = !tiny && full && wfa::seg_supported(b->dcfg, b->ncomp, false) && b->max_len <= WFA_FAST_MAX_LEN &&
+                             knob(al, K_NO_FAST, 0) == 0 && knob(al, K_NO_SEGFULL, 0) == 0;
+    if (!tiny && wfa::band_supported(b->dcfg, b->ncomp) && (b->ncomp != 5 || b->max_len < 32000) && knob(al, K_NO_BAND, 0) == 0) {
+      if (b->ncomp == 5) {
         // gap-affine-2p wavefronts are wide (C4: 99 % need more than 108 diagonals, 2.6 % more than 172)
         band_nch[n_stages++] = 3; band_nch[n_stages++] = 4;
       } else if (adapt) {
@@ -673,7 +720,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       } else if (b->max_len <= 1200) {
         band_nch[n_stages++] = 4;
       }
-      const int only = env_int("WFA_HIP_BAND_NCH", 0);
+      const int only = knob(al, K_BAND_NCH, 0);
       if (only) { n_stages = 1; band_nch[0] = only; }
     }
     const bool any_pre = use_fast || use_segfull || n_stages > 0;
@@ -684,26 +731,26 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     int64_t band_stride[3] = {0, 0, 0};
     // memory_mode medium / low (the reference's piggy-back backtrace, R/wavefront_backtrace_offload.c): the split stage
     // keeps one byte of origin codes per (step, diagonal) instead of the offsets and re-extends the matches afterwards
-    const int pb_env = env_int("WFA_HIP_BAND_PB", -1);
-    const bool pb_mode = full && al->ncomp == 3 && (pb_env >= 0 ? pb_env != 0 : (al->cfg.memory_mode == WFA_MEM_MED || al->cfg.memory_mode == WFA_MEM_LOW));
+    const int pb_env = knob(al, K_BAND_PB, -1);
+    const bool pb_mode = full && b->ncomp == 3 && (pb_env >= 0 ? pb_env != 0 : (b->cfg.memory_mode == WFA_MEM_MED || b->cfg.memory_mode == WFA_MEM_LOW));
     int64_t pb_code_ints = 0, pb_event_ints = 0, pb_stride = 0;
     for (int i = 0; i < n_stages; ++i) {
       // 4x more waves than a CU holds at once: waves retire one after the other (oldest-first issue) and the
       // dispatcher refills the CU, instead of a tail of lone waves (C1 +20 %, C3 +13 %)
-      long long grid = (long long)al->cu_count * env_int("WFA_HIP_BAND_WAVES_PER_CU", 128);
+      long long grid = (long long)al->cu_count * knob(al, K_BAND_WAVES_PER_CU, 128);
       grid = std::min<long long>(grid, in_n);
-      if (i > 0 || use_fast || use_segfull) grid = std::min<long long>(grid, (long long)al->cu_count * env_int("WFA_HIP_BAND_LEFTOVER_WAVES_PER_CU", 64));
+      if (i > 0 || use_fast || use_segfull) grid = std::min<long long>(grid, (long long)al->cu_count * knob(al, K_BAND_LEFTOVER_WAVES_PER_CU, 64));
       if (full) {
         const bool h16 = b->max_len < 32000;
-        const int rec = ((h16 && al->ncomp != 5) ? 2 : 4) * (band_nch[i] == 3 ? 256 : 64 * band_nch[i]);  // ints per record (2p: 16-byte entries)
+        const int rec = ((h16 && b->ncomp != 5) ? 2 : 4) * (band_nch[i] == 3 ? 256 : 64 * band_nch[i]);  // ints per record (2p: 16-byte entries)
         // steps of an alignment = score / g; sized for scores up to 0.9 x the read length (about 15 % divergence)
-        long long records = std::max<long long>(256, (long long)(b->max_len * 0.9) / wfa::band_gcd(al->dcfg, al->ncomp == 5) + 64);
-        records = env_int("WFA_HIP_BAND_RECORDS", (int)records);
+        long long records = std::max<long long>(256, (long long)(b->max_len * 0.9) / wfa::band_gcd(b->dcfg, b->ncomp == 5) + 64);
+        records = knob(al, K_BAND_RECORDS, (int)records);
         band_stride[i] = ((int64_t)records * rec + 63) & ~63ll;
         const int64_t budget = free_budget(al);
         while (grid > 1 && grid * band_stride[i] * 4 > budget) grid = (grid + 1) / 2;
         need = std::max(need, (size_t)grid * band_stride[i] * 4);
-        if (i == 0 && !use_fast && !use_segfull && b->max_len > 1000 && env_int("WFA_HIP_BAND_NO_SPLIT", 0) == 0) {
+        if (i == 0 && !use_fast && !use_segfull && b->max_len > 1000 && knob(al, K_BAND_NO_SPLIT, 0) == 0) {
           // split backtrace: one history slot per pair of a launch; take up to 4x the wave count (or all pairs)
           if (pb_mode) {
             pb_code_ints = ((int64_t)records * (64 * band_nch[i] / 4) + 63) & ~63ll;  // one byte per window position and step
@@ -711,7 +758,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
             pb_stride = pb_code_ints + pb_event_ints + ((2 * (int64_t)records + 8 + 63) & ~63ll);  // + run records
           }
           const int64_t slot_bytes = (pb_mode ? pb_stride : band_stride[i]) * 4 + 16;
-          int64_t pairs = std::min<int64_t>(in_n, (int64_t)al->cu_count * 32 * env_int("WFA_HIP_BAND_SPLIT_ROUNDS", 4));
+          int64_t pairs = std::min<int64_t>(in_n, (int64_t)al->cu_count * 32 * knob(al, K_BAND_SPLIT_ROUNDS, 4));
           while (pairs > 1 && pairs * slot_bytes > budget) pairs = (pairs + 1) / 2;
           need = std::max(need, (size_t)(pairs * slot_bytes));
         }
@@ -729,7 +776,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       b->stage_pick = 128;
       for (int w = 16; w <= 64; w *= 2) {
         HIP_TRY(al, hipMemsetAsync(pcount, 0, sizeof(uint32_t), stream));
-        if (wfa::launch_seg(al->dcfg, al->cu_count, stream, b->d_words, b->d_meta, in_list, nullptr, np, b->d_score, b->d_status,
+        if (wfa::launch_seg(b->dcfg, al->cu_count, knob(al, K_FAST_WAVES_PER_CU, 256), stream, b->d_words, b->d_meta, in_list, nullptr, np, b->d_score, b->d_status,
                             plist, pcount, w == 16 ? 2 : (w == 32 ? 4 : 5)) != 0) { al->err = "pilot launch failed"; return WFA_HIP_EDEVICE; }
         uint32_t handed = 0;
         HIP_TRY(al, hipMemcpyAsync(&handed, pcount, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -744,19 +791,19 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     int64_t segfull_slot_ints[3] = {0, 0, 0}, segfull_cap[3] = {0, 0, 0};
     int segfull_w[3] = {16, 32, 64};
     int n_segfull = use_segfull ? 3 : 0;
-    if (use_segfull && in_n >= 65536u && getenv("WFA_HIP_SEGFULL_STAGES") == nullptr) {
+    if (use_segfull && in_n >= 65536u && !al->knobs.set[K_SEGFULL_STAGES]) {
       const int prc = pick_first_width();
       if (prc != WFA_HIP_OK) return prc;
       n_segfull = 0;
       for (int w = 16; w <= 64; w *= 2) if (w >= b->stage_pick) segfull_w[n_segfull++] = w;
     } else if (use_segfull) {
-      n_segfull = std::max(0, std::min(3, env_int("WFA_HIP_SEGFULL_STAGES", 3)));
+      n_segfull = std::max(0, std::min(3, knob(al, K_SEGFULL_STAGES, 3)));
     }
     if (use_segfull) {
       for (int i = 0; i < n_segfull; ++i) {
-        segfull_slot_ints[i] = (int64_t)wfa::seg_full_records(al->dcfg, segfull_w[i]) * segfull_w[i] * 2;  // records of w entries x 8 bytes
+        segfull_slot_ints[i] = (int64_t)wfa::seg_full_records(b->dcfg, segfull_w[i]) * segfull_w[i] * 2;  // records of w entries x 8 bytes
         const int64_t slot_bytes = segfull_slot_ints[i] * 4 + (int64_t)sizeof(int4);
-        int64_t want = (i == 0) ? std::min<int64_t>((int64_t)env_int("WFA_HIP_SEGFULL_PAIRS", 2000000), std::max<int64_t>(1, ((int64_t)8 << 30) / slot_bytes))
+        int64_t want = (i == 0) ? std::min<int64_t>((int64_t)knob(al, K_SEGFULL_PAIRS, 2000000), std::max<int64_t>(1, ((int64_t)8 << 30) / slot_bytes))
                                 : std::max<int64_t>(4096, (int64_t)in_n / (i == 1 ? 8 : 32));
         segfull_cap[i] = std::max<int64_t>(1, std::min<int64_t>(in_n, std::min<int64_t>(want, free_budget(al) / slot_bytes)));
         need = std::max(need, (size_t)(segfull_cap[i] * slot_bytes));
@@ -779,8 +826,8 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       memset(&ba, 0, sizeof(ba));
       ba.meta = b->d_meta; ba.worklist = in_list; ba.words = b->d_words;
       ba.cigar_ops = b->d_ops; ba.cigar_off = b->d_cigar_off; ba.cigar_begin = b->d_cigar_begin; ba.cigar_len = b->d_cigar_len;
-      ba.g = wfa::gcd_int(wfa::gcd_int(al->dcfg.x, al->dcfg.o1 + al->dcfg.e1), al->dcfg.e1);
-      ba.x = al->dcfg.x; ba.oe = al->dcfg.o1 + al->dcfg.e1; ba.e = al->dcfg.e1;
+      ba.g = wfa::gcd_int(wfa::gcd_int(b->dcfg.x, b->dcfg.o1 + b->dcfg.e1), b->dcfg.e1);
+      ba.x = b->dcfg.x; ba.oe = b->dcfg.o1 + b->dcfg.e1; ba.e = b->dcfg.e1;
       ba.hist = al->ws; ba.hist_stride = segfull_slot_ints[sf]; ba.end_state = fa.end_state;
       ba.split = 1; ba.h16 = 1; ba.seg_w = segfull_w[sf];
       // (first stage: the host knows the count and walks it in launches of `cap` pairs; later stages: one launch over
@@ -790,7 +837,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         const uint32_t cnt = (uint32_t)std::min<int64_t>(segfull_cap[sf], total - w0);
         fa.work_begin = (uint32_t)w0; fa.nwork = cnt;
         if (in_count != nullptr) HIP_TRY(al, hipMemsetAsync(fa.end_state, 0, (size_t)cnt * sizeof(int4), stream));
-        if (wfa::launch_seg_full(al->dcfg, al->cu_count, stream, fa, segfull_w[sf]) != 0) { al->err = "segmented kernel launch failed"; return WFA_HIP_EDEVICE; }
+        if (wfa::launch_seg_full(b->dcfg, al->cu_count, knob(al, K_FAST_WAVES_PER_CU, 256), stream, fa, segfull_w[sf]) != 0) { al->err = "segmented kernel launch failed"; return WFA_HIP_EDEVICE; }
         ba.work_begin = (uint32_t)w0; ba.nwork = cnt;
         if (wfa::launch_band_bt(ba, 1, stream) != 0) { al->err = "backtrace launch failed"; return WFA_HIP_EDEVICE; }
       }
@@ -801,9 +848,9 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       // register-kernel stages, each taking what the one before handed on (WFA_HIP_FAST_STAGES, one digit per
       // stage): 7/6/8/9 = segments of 8/16/32/64 lanes with the two-round (lazy) extension, 3/2/4/5 = the same widths
       // extending every cell at once, 1 = half-waves, 0 = one alignment per wave (both with edge detection)
-      const char* stages_env = getenv("WFA_HIP_FAST_STAGES");
-      const char* stages = (stages_env && *stages_env) ? stages_env : "689";
-      if (!(stages_env && *stages_env) && in_n >= 65536u && in_count == nullptr) {
+      const char* stages_env = al->knobs.fast_stages.empty() ? nullptr : al->knobs.fast_stages.c_str();
+      const char* stages = stages_env ? stages_env : "689";
+      if (!stages_env && in_n >= 65536u && in_count == nullptr) {
         { const int prc = pick_first_width(); if (prc != WFA_HIP_OK) return prc; }
         stages = (b->stage_pick == 16) ? "689" : (b->stage_pick == 32) ? "89" : "9";  // (128: 64 lanes still take the pairs that fit)
       }
@@ -812,8 +859,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       for (const char* c = stages; *c && nv < 6; ++c) {
         const int v = *c - '0';
         if (v < 0 || v > 9) continue;
-        if (v == 1 && b->max_len > WFA_FAST2_MAX_LEN) continue;
-        if (v <= 1 && !legacy_ok) continue;
+        if (v < 2) continue;
         variants[nv++] = v;
       }
       if (nv == 0) variants[nv++] = 6;
@@ -822,13 +868,10 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         uint32_t* out_count = b->d_counters + 4 + out_sel;
         if (!first_stage) HIP_TRY(al, hipMemsetAsync(out_count, 0, sizeof(uint32_t), stream));
         hipEvent_t se0 = nullptr, se1 = nullptr;
-        const bool stage_timing = env_int("WFA_HIP_STAGE_TIMING", 0) != 0;
+        const bool stage_timing = knob(al, K_STAGE_TIMING, 0) != 0;
         if (stage_timing) { hipEventCreate(&se0); hipEventCreate(&se1); hipEventRecord(se0, stream); }
-        const int lrc = (variants[pass] >= 2)
-            ? wfa::launch_seg(al->dcfg, al->cu_count, stream, b->d_words, b->d_meta, in_list, in_count, in_n, b->d_score, b->d_status,
-                              out_list, out_count, variants[pass])
-            : wfa::launch_fast(al->dcfg, al->cu_count, stream, b->d_words, b->d_meta, in_list, in_count, in_n, b->d_score, b->d_status,
-                               out_list, out_count, variants[pass]);
+        const int lrc = wfa::launch_seg(b->dcfg, al->cu_count, knob(al, K_FAST_WAVES_PER_CU, 256), stream, b->d_words, b->d_meta, in_list, in_count,
+                                        in_n, b->d_score, b->d_status, out_list, out_count, variants[pass]);
         if (lrc != 0) { al->err = "fast kernel launch failed"; return WFA_HIP_EDEVICE; }
         if (stage_timing) {  // development aid: synchronises after every stage
           hipEventRecord(se1, stream); hipEventSynchronize(se1);
@@ -851,19 +894,19 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       uint32_t* out_count = b->d_counters + 4 + out_sel;
       if (!first_stage) HIP_TRY(al, hipMemsetAsync(out_count, 0, sizeof(uint32_t), stream));
       ba.fb_list = out_list; ba.fb_count = out_count;
-      ba.g = wfa::band_gcd(al->dcfg, al->ncomp == 5);
-      ba.x = al->dcfg.x; ba.oe = al->dcfg.o1 + al->dcfg.e1; ba.e = al->dcfg.e1;
-      if (al->ncomp == 5) { ba.oe2 = al->dcfg.o2 + al->dcfg.e2; ba.e2 = al->dcfg.e2; }
-      ba.min_wf_len = al->dcfg.min_wf_len; ba.max_dist_thr = al->dcfg.max_dist_thr; ba.steps_between = al->dcfg.steps_between;
+      ba.g = wfa::band_gcd(b->dcfg, b->ncomp == 5);
+      ba.x = b->dcfg.x; ba.oe = b->dcfg.o1 + b->dcfg.e1; ba.e = b->dcfg.e1;
+      if (b->ncomp == 5) { ba.oe2 = b->dcfg.o2 + b->dcfg.e2; ba.e2 = b->dcfg.e2; }
+      ba.min_wf_len = b->dcfg.min_wf_len; ba.max_dist_thr = b->dcfg.max_dist_thr; ba.steps_between = b->dcfg.steps_between;
       const int words = ((b->max_len + 15) >> 4) + 4;
-      const bool seqlds = ((size_t)words * 8 <= 5120) && env_int("WFA_HIP_BAND_NO_LDS", 0) == 0;
+      const bool seqlds = ((size_t)words * 8 <= 5120) && knob(al, K_BAND_NO_LDS, 0) == 0;
       ba.lds_words = seqlds ? words : 0;
-      ba.debug = env_int("WFA_HIP_BAND_DEBUG", 0);
+      ba.debug = knob(al, K_BAND_DEBUG, 0);
       ba.h16 = (b->max_len < 32000) ? 1 : 0;
-      ba.ef = (al->dcfg.endsfree && (al->dcfg.pbf | al->dcfg.pef | al->dcfg.tbf | al->dcfg.tef)) ? 1 : 0;
-      ba.pbf = al->dcfg.pbf; ba.pef = al->dcfg.pef; ba.tbf = al->dcfg.tbf; ba.tef = al->dcfg.tef;
+      ba.ef = (b->dcfg.endsfree && (b->dcfg.pbf | b->dcfg.pef | b->dcfg.tbf | b->dcfg.tef)) ? 1 : 0;
+      ba.pbf = b->dcfg.pbf; ba.pef = b->dcfg.pef; ba.tbf = b->dcfg.tbf; ba.tef = b->dcfg.tef;
       ba.hist = al->ws; ba.hist_stride = band_stride[i];
-      const bool split = full && in_count == nullptr && b->max_len > 1000 && env_int("WFA_HIP_BAND_NO_SPLIT", 0) == 0;
+      const bool split = full && in_count == nullptr && b->max_len > 1000 && knob(al, K_BAND_NO_SPLIT, 0) == 0;
       if (split) {
         // history slot per PAIR: as many pairs per launch as the workspace holds; the walks of a launch run
         // afterwards in a thread-per-alignment kernel
@@ -872,7 +915,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         const int64_t slot_bytes = slot_ints * 4 + (int64_t)sizeof(int4);
         int64_t per_launch = (int64_t)(al->ws_bytes / (size_t)slot_bytes);
         per_launch = std::min<int64_t>(per_launch, in_n);
-        const int64_t full_grid = (int64_t)al->cu_count * env_int("WFA_HIP_BAND_WAVES_PER_CU", 128);
+        const int64_t full_grid = (int64_t)al->cu_count * knob(al, K_BAND_WAVES_PER_CU, 128);
         if (per_launch > full_grid) per_launch = (per_launch / full_grid) * full_grid;  // whole rounds of waves
         if (per_launch < 1) { al->err = "band history does not fit"; return WFA_HIP_EDEVICE; }
         ba.split = 1;
@@ -880,7 +923,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         for (int64_t w0 = 0; w0 < in_n; w0 += per_launch) {
           const uint32_t cnt = (uint32_t)std::min<int64_t>(per_launch, in_n - w0);
           ba.work_begin = (uint32_t)w0; ba.nwork = cnt;
-          const long long grid = std::min<long long>((long long)al->cu_count * env_int("WFA_HIP_BAND_WAVES_PER_CU", 128), cnt);
+          const long long grid = std::min<long long>((long long)al->cu_count * knob(al, K_BAND_WAVES_PER_CU, 128), cnt);
           if (wfa::launch_band(ba, band_nch[i], full, adapt, seqlds, grid, stream) != 0) { al->err = "band kernel launch failed"; return WFA_HIP_EDEVICE; }
           if (wfa::launch_band_bt(ba, band_nch[i], stream) != 0) { al->err = "band backtrace launch failed"; return WFA_HIP_EDEVICE; }
         }
@@ -906,6 +949,8 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
                             b->d_ovf_list[0], b->d_counters + 1);
     if (rc != WFA_HIP_OK) return rc;
   }
+  HIP_TRY(al, hipEventRecord(al->ws_event, stream));
+  al->ws_event_recorded = true; al->ws_last_stream = stream;
   return WFA_HIP_OK;
 }
 
@@ -923,7 +968,7 @@ static int retry_overflows(wfa_hip_batch* b) {
     HIP_TRY(al, hipMemcpy(ids.data(), b->d_ovf_list[cur], novf * sizeof(uint32_t), hipMemcpyDeviceToHost));
     std::vector<uint8_t> flags((size_t)b->n, 0);
     if (b->n_bytes) HIP_TRY(al, hipMemcpy(flags.data(), b->d_flags, (size_t)b->n, hipMemcpyDeviceToHost));
-    const bool all_bytes = (al->cfg.wildcard >= 0);
+    const bool all_bytes = (b->cfg.wildcard >= 0);
     std::vector<uint32_t> lp, lb;
     for (uint32_t id : ids) ((all_bytes || flags[id]) ? lb : lp).push_back(id);
     b->arena_ints *= 8;
@@ -977,7 +1022,7 @@ extern "C" int wfa_hip_batch_sync(wfa_hip_batch_t* b) {
     uint32_t fb = 0;
     if (b->leftover_count) HIP_TRY(al, hipMemcpy(&fb, b->leftover_count, sizeof(uint32_t), hipMemcpyDeviceToHost));
     b->last_fallback = fb;
-    if (al->cfg.scope == WFA_SCOPE_FULL) {
+    if (b->cfg.scope == WFA_SCOPE_FULL) {
       const int rc = retry_overflows(b);
       if (rc != WFA_HIP_OK) return rc;
     }
@@ -997,7 +1042,7 @@ extern "C" int wfa_hip_batch_results(wfa_hip_batch_t* b, int32_t* score, int32_t
   if (!score || !status) { al->err = "score/status outputs are required"; return WFA_HIP_EINVAL; }
   HIP_TRY(al, hipMemcpy(score, b->d_score, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
   HIP_TRY(al, hipMemcpy(status, b->d_status, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
-  const bool full = (al->cfg.scope == WFA_SCOPE_FULL);
+  const bool full = (b->cfg.scope == WFA_SCOPE_FULL);
   if (cigar_len) {
     if (full) HIP_TRY(al, hipMemcpy(cigar_len, b->d_cigar_len, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
     else memset(cigar_len, 0, (size_t)n * sizeof(int32_t));
@@ -1043,7 +1088,7 @@ extern "C" int wfa_hip_batch_last_kernel_ms(wfa_hip_batch_t* b, float* ms, int64
 extern "C" int64_t wfa_hip_batch_algorithmic_bytes(const wfa_hip_batch_t* b) {
   if (!b) return 0;
   int64_t bytes = b->packed_bytes + 8 * b->n;
-  if (b->al->cfg.scope == WFA_SCOPE_FULL) bytes += b->ops_bytes;
+  if (b->cfg.scope == WFA_SCOPE_FULL) bytes += b->ops_bytes;
   return bytes;
 }
 
@@ -1051,7 +1096,7 @@ extern "C" int64_t wfa_hip_batch_algorithmic_bytes(const wfa_hip_batch_t* b) {
 extern "C" int64_t wfa_hip_batch_rle_counts(wfa_hip_batch_t* b, int32_t* run_count, int32_t* locations) {
   if (!b) return WFA_HIP_EINVAL;
   wfa_hip_aligner* al = b->al;
-  if (al->cfg.scope != WFA_SCOPE_FULL) { al->err = "run-length encoding needs scope=full"; return WFA_HIP_EINVAL; }
+  if (b->cfg.scope != WFA_SCOPE_FULL) { al->err = "run-length encoding needs scope=full"; return WFA_HIP_EINVAL; }
   int rc = wfa_hip_batch_sync(b);
   if (rc != WFA_HIP_OK) return rc;
   const int64_t n = b->n;
@@ -1121,7 +1166,7 @@ extern "C" int wfa_hip_align_batch(wfa_hip_aligner_t* al, int64_t n, const uint8
                                    int32_t* score, int32_t* status, uint8_t* cigar_ops, const int64_t* cigar_off,
                                    int64_t* cigar_begin, int32_t* cigar_len) {
   if (!al) return WFA_HIP_EINVAL;
-  const bool timing = getenv("WFA_HIP_TIMING") != nullptr;
+  const bool timing = al->knobs.set[K_TIMING];
   const double t0 = now_ms();
   // (the results call below synchronises the stream before this function returns, so the uploads need no wait of their own)
   wfa_hip_batch_t* b = batch_create_nosync(al, n, seqs, p_off, p_len, t_off, t_len);

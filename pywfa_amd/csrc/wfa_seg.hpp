@@ -364,18 +364,26 @@ wfa_seg_kernel(const FastArgs a) {
   fb_flush();
 }
 
-// Penalty shapes (x, o + e, e) / gcd with an instantiation of the segmented kernel.  The first is pywfa's default
+// Penalty shapes (index, x, o + e, e) / gcd with an instantiation of the segmented kernel.  The first is pywfa's default
 // 4/6/2 (also 2/3/1, 8/12/4, ...); the others are the usual short-read / long-read presets: 4/4/2, 4/6/1, 3/4/1,
-// 6/5/3, 5/0/3 and unit costs 1/1/1.
-#define WFA_SEG_SHAPES(F) F(2, 4, 1) F(2, 3, 1) F(4, 7, 1) F(3, 5, 1) F(6, 8, 3) F(5, 3, 3) F(1, 2, 1)
+// 6/5/3, 5/0/3 and unit costs 1/1/1.  Each shape is compiled in its own translation unit (csrc/k_seg.hip, once per
+// index) so that the library builds in parallel; the entry points below are what the host side links against.
+#define WFA_SEG_SHAPES(F) F(0, 2, 4, 1) F(1, 2, 3, 1) F(2, 4, 7, 1) F(3, 3, 5, 1) F(4, 6, 8, 3) F(5, 5, 3, 3) F(6, 1, 2, 1)
 
-inline bool seg_shape(const WfaDevConfig& c, int* X, int* OE, int* E) {
+#define WFA_SEG_DECL(i, x, oe, e)                                                                        \
+  int launch_seg_s##i(int w, bool lazy, unsigned grid, hipStream_t stream, const FastArgs& a);           \
+  int launch_seg_full_s##i(int w, unsigned grid, hipStream_t stream, const FastArgs& a);
+WFA_SEG_SHAPES(WFA_SEG_DECL)
+#undef WFA_SEG_DECL
+
+// index of the instantiated shape of these penalties, -1 if none
+inline int seg_shape(const WfaDevConfig& c, int* X, int* OE, int* E) {
   const int g = gcd_int(gcd_int(c.x, c.o1 + c.e1), c.e1);
   *X = c.x / g; *OE = (c.o1 + c.e1) / g; *E = c.e1 / g;
-#define WFA_SEG_MATCH(x, oe, e) if (*X == x && *OE == oe && *E == e) return true;
+#define WFA_SEG_MATCH(i, x, oe, e) if (*X == x && *OE == oe && *E == e) return i;
   WFA_SEG_SHAPES(WFA_SEG_MATCH)
 #undef WFA_SEG_MATCH
-  return false;
+  return -1;
 }
 
 // which configurations the segmented kernels cover (score only, gap-affine, end-to-end or ends-free without free ends)
@@ -384,59 +392,65 @@ inline bool seg_supported(const WfaDevConfig& c, int ncomp, bool full) {
   if (c.endsfree && (c.pbf | c.pef | c.tbf | c.tef)) return false;
   if (c.max_steps != INT_MAX) return false;
   int X, OE, E;
-  return seg_shape(c, &X, &OE, &E);
+  return seg_shape(c, &X, &OE, &E) >= 0;
 }
 
 template <int X, int OE, int E>
-inline void launch_seg_shape(int w, bool lazy, dim3 g, hipStream_t stream, const FastArgs& a) {
-  const dim3 blk(64);
+inline int launch_seg_shape(int w, bool lazy, unsigned grid, hipStream_t stream, const FastArgs& a) {
+  const dim3 blk(64), g(grid);
   if constexpr (X >= 2) {
     if (lazy) {
       if (w == 8) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 8, true, false>), g, blk, 0, stream, a);
       else if (w == 32) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 32, true, false>), g, blk, 0, stream, a);
       else if (w == 64) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 64, true, false>), g, blk, 0, stream, a);
       else hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 16, true, false>), g, blk, 0, stream, a);
-      return;
+      return hipGetLastError() == hipSuccess ? 0 : -1;
     }
   }
   if (w == 8) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 8, false, false>), g, blk, 0, stream, a);
   else if (w == 32) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 32, false, false>), g, blk, 0, stream, a);
   else if (w == 64) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 64, false, false>), g, blk, 0, stream, a);
   else hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 16, false, false>), g, blk, 0, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 // full-CIGAR launch with segments of `w` lanes: items [work_begin, work_begin + nwork) of the work list, one history slot
 // each (a.nwork_dev set: the list is a previous stage's, a.nwork slots were reserved)
 template <int X, int OE, int E>
-inline void launch_seg_full_shape(int w, dim3 g, hipStream_t stream, const FastArgs& a) {
+inline int launch_seg_full_shape(int w, unsigned grid, hipStream_t stream, const FastArgs& a) {
+  const dim3 g(grid);
   if (w == 32) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 32, false, true>), g, dim3(64), 0, stream, a);
   else if (w == 64) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 64, false, true>), g, dim3(64), 0, stream, a);
   else hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 16, false, true>), g, dim3(64), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-inline int launch_seg_full(const WfaDevConfig& c, int cu_count, hipStream_t stream, FastArgs a, int w) {
+
+// per_cu: slices of the work list per CU (one wave each).  8 times more slices than the 32 waves a CU holds: the SIMD
+// issues oldest-first, so resident waves finish one after the other and a lone last wave cannot fill the VALU; with
+// short slices the dispatcher refills the CU as waves retire (C2: 5.10 -> 4.42 ms).
+inline int launch_seg_full(const WfaDevConfig& c, int cu_count, int per_cu, hipStream_t stream, FastArgs a, int w) {
   int X, OE, E;
-  if (!seg_shape(c, &X, &OE, &E)) return -1;
+  const int idx = seg_shape(c, &X, &OE, &E);
+  if (idx < 0) return -1;
   a.g = gcd_int(gcd_int(c.x, c.o1 + c.e1), c.e1);
-  const char* env = getenv("WFA_HIP_FAST_WAVES_PER_CU");
-  const int per_cu = (env && *env) ? atoi(env) : 256;
   long long grid = std::min<long long>((long long)cu_count * per_cu, (long long)a.nwork);
   if (grid < 1) grid = 1;
-#define WFA_SEG_LAUNCH_FULL(x, oe, e) if (X == x && OE == oe && E == e) launch_seg_full_shape<x, oe, e>(w, dim3((unsigned)grid), stream, a);
+#define WFA_SEG_LAUNCH_FULL(i, x, oe, e) if (idx == i) return launch_seg_full_s##i(w, (unsigned)grid, stream, a);
   WFA_SEG_SHAPES(WFA_SEG_LAUNCH_FULL)
 #undef WFA_SEG_LAUNCH_FULL
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  return -1;
 }
 
 // steps a w-lane segment can take before it hands its pair on (+ 1), i.e. the records a history slot needs
 inline int seg_full_records(const WfaDevConfig& c, int w) {
   int X, OE, E;
-  if (!seg_shape(c, &X, &OE, &E)) return 0;
+  if (seg_shape(c, &X, &OE, &E) < 0) return 0;
   return 2 * (OE - E) + E * (w + 1) + 3;
 }
 
 // variant 6/7/8/9 = segments of 16/8/32/64 lanes (4/8/2/1 alignments per wave) with the two-round extension,
 // 2/3/4/5 = the same widths extending every cell at once (the only form when x / g = 1)
-inline int launch_seg(const WfaDevConfig& c, int cu_count, hipStream_t stream, const uint32_t* words,
+inline int launch_seg(const WfaDevConfig& c, int cu_count, int per_cu, hipStream_t stream, const uint32_t* words,
                       const WfaPairMeta* meta, const uint32_t* worklist, const uint32_t* nwork_dev, uint32_t nwork,
                       int32_t* score, int32_t* status, uint32_t* fb_list, uint32_t* fb_count, int variant) {
   FastArgs a;
@@ -445,21 +459,17 @@ inline int launch_seg(const WfaDevConfig& c, int cu_count, hipStream_t stream, c
   a.g = gcd_int(gcd_int(c.x, c.o1 + c.e1), c.e1);
   a.hist = nullptr; a.hist_stride = 0; a.end_state = nullptr; a.work_begin = 0;
   int X, OE, E;
-  if (!seg_shape(c, &X, &OE, &E)) return -1;
-  const char* env = getenv("WFA_HIP_FAST_WAVES_PER_CU");
-  // One slice of the work list per wave, 8 times more slices than the 32 waves a CU holds: the SIMD issues
-  // oldest-first, so resident waves finish one after the other and a lone last wave cannot fill the VALU;
-  // with short slices the dispatcher refills the CU as waves retire (C2: 5.10 -> 4.42 ms).
-  const int per_cu = (env && *env) ? atoi(env) : 256;
+  const int idx = seg_shape(c, &X, &OE, &E);
+  if (idx < 0) return -1;
   long long grid = (long long)cu_count * per_cu;
   if (!nwork_dev && grid > (long long)nwork) grid = nwork;
   if (grid < 1) grid = 1;
   const bool lazy = variant >= 6;
   const int w = (variant == 3 || variant == 7) ? 8 : (variant == 4 || variant == 8) ? 32 : (variant == 5 || variant == 9) ? 64 : 16;
-#define WFA_SEG_LAUNCH(x, oe, e) if (X == x && OE == oe && E == e) launch_seg_shape<x, oe, e>(w, lazy, dim3((unsigned)grid), stream, a);
+#define WFA_SEG_LAUNCH(i, x, oe, e) if (idx == i) return launch_seg_s##i(w, lazy, (unsigned)grid, stream, a);
   WFA_SEG_SHAPES(WFA_SEG_LAUNCH)
 #undef WFA_SEG_LAUNCH
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  return -1;
 }
 
 }  // namespace wfa

@@ -1,0 +1,245 @@
+"""BASELINE.json configurations C4 and C5 as they are written, through the C ABI, against the oracle.
+
+C4 = 10 kb pairs (seed 1004, 8 %), distance=affine2p, span=ends-free with 100 free bases on both pattern ends,
+     the text cut by 50 bases at both ends, full CIGAR, **no heuristic**.
+C5 = 100 kb pairs (seed 1005, 8 %), X-drop.  With pywfa's match=0 the reference's X-drop score falls with progress
+     (R/wavefront_heuristic.c:306-307), so X-drop(20) drops every pair after a few steps
+     (status 1, score INT32_MIN, empty CIGAR); a very large xdrop or match<0 lets pairs complete.  wf-adaptive at
+     100 kb exercises the 32-bit history entries of the banded kernel (sequences >= 32 000 bases).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import common
+from oracle import loader
+from pywfa_amd import _native, datagen
+
+pytestmark = pytest.mark.gpu
+
+C4_KW = dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="full")
+INT32_MIN = -2147483648
+
+
+def c4_batch(n):
+    return datagen.trim_text(datagen.generate(n, 10000, 0.08, datagen.SEEDS["C4"]), 50)
+
+
+def test_c4_as_written_exact_full_cigar(gpu):
+    """No heuristic: 2p wavefronts grow to ~9 k diagonals and the explicit history to ~0.4 GB per pair; the pairs must
+    come back COMPLETED (never -200) with the reference's op strings."""
+    batch = c4_batch(8)
+    oc, nc = common.configs_pair(**C4_KW)
+    o = loader.run(loader.oracle(), oc, batch)
+    for resident in (True, False):
+        score, status, cigars = common.gpu_run(nc, batch, True, resident)
+        assert (status == 0).all(), status
+        common.assert_same(o, score, status, cigars, batch, f"C4 exact resident={resident}")
+
+
+@pytest.mark.parametrize("memory_mode", ["medium", "low"])
+def test_c4_exact_low_memory_modes(gpu, memory_mode):
+    """memory_mode medium / low (piggy-back history) returns the same alignments for gap-affine-2p."""
+    batch = c4_batch(6)
+    oc, nc = common.configs_pair(**dict(C4_KW, memory_mode=memory_mode))
+    o = loader.run(loader.oracle(), oc, batch)
+    score, status, cigars = common.gpu_run(nc, batch, True, True)
+    common.assert_same(o, score, status, cigars, batch, f"C4 exact {memory_mode}")
+
+
+@pytest.mark.parametrize("memory_mode", ["high", "medium"])
+def test_c4_adaptive_sample_vs_oracle(gpu, memory_mode):
+    batch = c4_batch(96)
+    kw = dict(C4_KW, heuristic="adaptive", memory_mode=memory_mode)
+    oc, nc = common.configs_pair(**kw)
+    o = loader.run(loader.oracle(), oc, batch)
+    score, status, cigars = common.gpu_run(nc, batch, True, True)
+    common.assert_same(o, score, status, cigars, batch, f"C4 adaptive {memory_mode}")
+
+
+def test_c4_full_size_adaptive_properties(gpu):
+    """C4 at BASELINE's size (1 M x 10 kb; WFA_C4_PAIRS shrinks it) with wf-adaptive — stated: the exact form moves
+    ~0.4 GB of history per pair — through properties: every transcript valid for its (trimmed) sequences, a seeded
+    sample equal to the oracle, and idempotent across two runs."""
+    n = int(os.environ.get("WFA_C4_PAIRS", "1000000"))
+    batch = c4_batch(n)
+    kw = dict(C4_KW, heuristic="adaptive")
+    oc, nc = common.configs_pair(**kw)
+    al = _native.Aligner(nc)
+    rb = al.batch(batch)
+    rb.run(); rb.sync()
+    score, status, (ops, cbeg, clen) = rb.results(True)
+    s1 = score.copy()
+    rb.run(); rb.sync()
+    score2, status2, _ = rb.results(False)
+    rb.close(); al.close()
+    assert np.array_equal(s1, score2)
+    assert (status == 0).all()
+    # ends-free: the transcript covers both sequences completely (free ends appear as leading / trailing I / D), so the
+    # validity walk applies; the score of an ends-free alignment excludes the free ends, hence no penalty check here
+    bad, first = loader.check_cigars(oc, batch, score, ops, cbeg, clen, check_score=False)
+    assert bad == 0, f"{bad} invalid transcripts, first at pair {first}"
+    idx = np.arange(0, n, max(1, n // 48))
+    sub = datagen.subset(batch, idx)
+    o = loader.run(loader.oracle(), oc, sub)
+    cigs = [ops[cbeg[i]:cbeg[i] + clen[i]].tobytes() for i in idx]
+    common.assert_same(o, score[idx], status[idx], cigs, sub, "C4 sample vs oracle")
+
+
+# ---------------------------------------------------------------------------------------------- C5
+def c5_batch(n):
+    return datagen.generate(n, 100000, 0.08, datagen.SEEDS["C5"])
+
+
+@pytest.mark.parametrize("scope", ["score", "full"])
+def test_c5_xdrop20_drops_every_pair(gpu, scope):
+    batch = c5_batch(24)
+    oc, nc = common.configs_pair(span="end-to-end", scope=scope, heuristic="X-drop", xdrop=20)
+    o = loader.run(loader.oracle(), oc, batch)
+    score, status, cigars = common.gpu_run(nc, batch, scope == "full", True)
+    common.assert_same(o, score, status, cigars, batch, f"C5 xdrop 20 {scope}")
+    assert (status == 1).all()
+    if scope == "full":
+        assert (score == INT32_MIN).all() and all(len(c) == 0 for c in cigars)
+
+
+def test_c5_xdrop_large_enough_to_complete(gpu):
+    """match=0: the X-drop score at the end is -(plen + tlen + s) / 2, so only an xdrop beyond that keeps the optimum;
+    match=-1: the score grows with progress and xdrop=100 completes."""
+    for n, kw in ((4, dict(span="end-to-end", scope="score", heuristic="X-drop", xdrop=400000)),
+                  (16, dict(span="end-to-end", scope="score", heuristic="X-drop", xdrop=100, match=-1))):
+        batch = c5_batch(n)
+        oc, nc = common.configs_pair(**kw)
+        # (an exact 100 kb run is ~2 s per pair in WFA2-lib and ~10 s in the plain restatement: the real library when it is there)
+        checker = loader.reference() if (n == 4 and loader.have_reference()) else loader.oracle()
+        o = loader.run(checker, oc, batch)
+        score, status, _ = common.gpu_run(nc, batch, False, True)
+        common.assert_same(o, score, status, None, batch, f"C5 {kw}")
+        assert (status == 0).all()
+    # full CIGAR with match<0 on a shorter prefix of the same pairs (the explicit history of a 100 kb exact run is ~6 GB)
+    sub = {"seqs": batch["seqs"], "p_off": batch["p_off"], "p_len": np.minimum(batch["p_len"], 20000).astype(np.int32),
+           "t_off": batch["t_off"], "t_len": np.minimum(batch["t_len"], 20000).astype(np.int32)}
+    kw = dict(span="end-to-end", scope="full", heuristic="X-drop", xdrop=100, match=-1)
+    oc, nc = common.configs_pair(**kw)
+    o = loader.run(loader.oracle(), oc, sub)
+    score, status, cigars = common.gpu_run(nc, sub, True, True)
+    common.assert_same(o, score, status, cigars, sub, f"C5 20 kb prefix {kw}")
+
+
+@pytest.mark.parametrize("kw", [dict(span="end-to-end", scope="full", heuristic="adaptive"),
+                                dict(span="end-to-end", scope="full", heuristic="adaptive", memory_mode="medium"),
+                                dict(distance="affine2p", scope="score", heuristic="adaptive")])
+def test_c5_adaptive_100kb_vs_oracle(gpu, kw):
+    """Sequences >= 32 000 bases: the banded kernel's history entries are 4 x int32 (h16 = 0)."""
+    batch = c5_batch(16)
+    oc, nc = common.configs_pair(**kw)
+    full = oc.scope == 1
+    o = loader.run(loader.oracle(), oc, batch, want_cigar=full)
+    for resident in (True, False):
+        score, status, cigars = common.gpu_run(nc, batch, full, resident)
+        common.assert_same(o, score, status, cigars, batch, f"C5 adaptive {kw}")
+
+
+def test_c5_thousand_pairs_properties(gpu):
+    """A 1 000-pair prefix of C5 (200 MB of sequence): X-drop(20) drops all of it; wf-adaptive gives valid transcripts whose
+    gap-affine penalty is -score for every pair, the same scores with scope=score, and the oracle's op strings on a sample."""
+    n = int(os.environ.get("WFA_C5_PAIRS", "1000"))
+    batch = c5_batch(n)
+    _, nc = common.configs_pair(span="end-to-end", scope="full", heuristic="X-drop", xdrop=20)
+    score, status, cigars = common.gpu_run(nc, batch, True, True)
+    assert (status == 1).all() and (score == INT32_MIN).all() and all(len(c) == 0 for c in cigars)
+    oc, nc = common.configs_pair(span="end-to-end", scope="full", heuristic="adaptive")
+    al = _native.Aligner(nc)
+    rb = al.batch(batch)
+    rb.run(); rb.sync()
+    score, status, (ops, cbeg, clen) = rb.results(True)
+    rb.close(); al.close()
+    assert (status == 0).all()
+    bad, first = loader.check_cigars(oc, batch, score, ops, cbeg, clen, check_score=True)
+    assert bad == 0, f"{bad} invalid transcripts, first at pair {first}"
+    _, nc_s = common.configs_pair(span="end-to-end", scope="score", heuristic="adaptive")
+    score_s, status_s, _ = common.gpu_run(nc_s, batch, False, True)
+    assert np.array_equal(score_s, score) and (status_s == 0).all()
+    idx = np.arange(0, n, max(1, n // 12))
+    sub = datagen.subset(batch, idx)
+    o = loader.run(loader.oracle(), oc, sub)
+    cigs = [ops[cbeg[i]:cbeg[i] + clen[i]].tobytes() for i in idx]
+    common.assert_same(o, score[idx], status[idx], cigs, sub, "C5 adaptive sample vs oracle")
+
+
+# ------------------------------------------------------------------------ handles
+def test_config_change_after_batch_create_does_not_reach_the_batch(gpu):
+    """A resident batch is laid out under the configuration in force when it was created (op regions, work lists, checked
+    free ends): it keeps running under that configuration whatever set_config does afterwards."""
+    batch = datagen.generate(3000, 150, 0.03, 4242)
+    oc_s, nc_s = common.configs_pair(span="end-to-end", scope="score")
+    oc_f, nc_f = common.configs_pair(span="ends-free", scope="full", pattern_begin_free=10, text_end_free=10, wildcard="N")
+    o_s = loader.run(loader.oracle(), oc_s, batch)
+    al = _native.Aligner(nc_s)
+    rb = al.batch(batch)
+    al.set_config(nc_f)            # scope score -> full, free ends, wildcard
+    rb.run(); rb.sync()
+    score, status, _ = rb.results(False)
+    assert np.array_equal(score, o_s["score"]) and np.array_equal(status, o_s["status"])
+    # and a batch created now runs under the new configuration
+    o_f = loader.run(loader.oracle(), oc_f, batch)
+    rb2 = al.batch(batch)
+    rb2.run(); rb2.sync()
+    s2, st2, (ops, cb, cl) = rb2.results(True)
+    common.assert_same(o_f, s2, st2, [ops[cb[i]:cb[i] + cl[i]].tobytes() for i in range(len(s2))], batch, "after set_config")
+    rb.close(); rb2.close(); al.close()
+
+
+def test_batch_outlives_aligner_handle(gpu):
+    """wfa_hip_destroy with resident batches alive only marks the handle; the last batch frees it (through the raw C ABI:
+    the Python wrapper closes its batches first)."""
+    import ctypes
+    L = _native.lib()
+    batch = datagen.generate(2000, 150, 0.02, 777)
+    oc, nc = common.configs_pair(span="end-to-end", scope="score")
+    o = loader.run(loader.oracle(), oc, batch)
+    seqs, p_off, p_len, t_off, t_len, n = _native._check_batch(batch)
+    h = L.wfa_hip_create(ctypes.byref(nc), 0)
+    assert h
+    b = L.wfa_hip_batch_create(h, n, _native._ptr(seqs), _native._ptr(p_off), _native._ptr(p_len), _native._ptr(t_off), _native._ptr(t_len))
+    assert b
+    L.wfa_hip_destroy(h)                      # handle marked, batch still valid
+    assert L.wfa_hip_batch_run(b, None) == 0
+    score = np.zeros(n, np.int32); status = np.zeros(n, np.int32)
+    assert L.wfa_hip_batch_results(b, _native._ptr(score), _native._ptr(status), None, None, None, None) == 0
+    L.wfa_hip_batch_destroy(b)                # frees the aligner too
+    assert np.array_equal(score, o["score"]) and np.array_equal(status, o["status"])
+    # the Python wrapper: closing the aligner closes its batches, closing them again is harmless
+    al = _native.Aligner(nc)
+    rb = al.batch(batch)
+    al.close()
+    rb.close()
+
+
+def test_runs_on_different_streams_are_ordered(gpu):
+    """Two resident batches of one aligner share its workspace; runs enqueued on different streams are ordered by the
+    library (full-CIGAR runs of 1.5 kb reads keep their history in that workspace)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    streams = []
+    for _ in range(2):
+        s = ctypes.c_void_p()
+        assert hip.hipStreamCreate(ctypes.byref(s)) == 0
+        streams.append(s)
+    b1 = datagen.generate(3000, 1500, 0.06, 31337)
+    b2 = datagen.generate(3000, 1500, 0.06, 31338)
+    oc, nc = common.configs_pair(span="end-to-end", scope="full", heuristic="adaptive")
+    o1 = loader.run(loader.oracle(), oc, b1)
+    o2 = loader.run(loader.oracle(), oc, b2)
+    al = _native.Aligner(nc)
+    r1, r2 = al.batch(b1), al.batch(b2)
+    for _ in range(3):
+        r1.run(streams[0]); r2.run(streams[1]); r1.run(streams[1]); r2.run(streams[0])
+    for rb, o, bt in ((r1, o1, b1), (r2, o2, b2)):
+        rb.sync()
+        s, st, (ops, cb, cl) = rb.results(True)
+        common.assert_same(o, s, st, [ops[cb[i]:cb[i] + cl[i]].tobytes() for i in range(len(s))], bt, "two streams")
+    r1.close(); r2.close(); al.close()
+    for s in streams:
+        hip.hipStreamDestroy(s)

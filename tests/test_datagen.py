@@ -32,3 +32,16 @@ def test_from_strings_uppercases():
     b = datagen.from_strings(["acgt", "AC"], ["ACGT", "ag"])
     assert datagen.pair_strings(b, 0) == ("ACGT", "ACGT")
     assert datagen.pair_strings(b, 1) == ("AC", "AG")
+
+
+def test_from_strings_survives_upper_changing_a_length():
+    """str.upper() can lengthen a string that still encodes as ASCII ('ß' -> 'SS'): the joined fast path must not
+    shift the offsets of later pairs (the reference upper-cases every string on its own, align.pyx:432,435)."""
+    from pywfa_amd import datagen
+    b = datagen.from_strings(["ACßGT", "AAAA"], ["ACGT", "CCCC"])
+    assert datagen.pair_strings(b, 0) == ("ACSSGT", "ACGT")
+    assert datagen.pair_strings(b, 1) == ("AAAA", "CCCC")
+    b = datagen.from_strings("ACßGT", ["ACGT", "CCßC", "GG"])
+    assert [datagen.pair_strings(b, i) for i in range(3)] == [("ACSSGT", "ACGT"), ("ACSSGT", "CCSSC"), ("ACSSGT", "GG")]
+    t = datagen.trim_text(datagen.generate(4, 300, 0.05, 9), 50)
+    assert (t["t_len"] == datagen.generate(4, 300, 0.05, 9)["t_len"] - 100).all()
