@@ -1,21 +1,33 @@
 #!/usr/bin/env python3
 """bench.py — pairwise alignments/s of the batched wavefront-alignment hot path on MI355X.
 
-Workload (BASELINE.json configs[1], "C2"): 10 M x 150 bp synthetic short-read pairs at 2 % error
-(seed 1002), gap-affine 0/4/6/2, end-to-end, scope=score.  One "step" = one pass of the alignment
-kernels over the whole batch, with the 2-bit packed sequences already resident in HBM.
+Headline workload (BASELINE.json configs[1], "C2"): 10 M x 150 bp synthetic short-read pairs at 2 % error
+(seed 1002), gap-affine 0/4/6/2, end-to-end, scope=score.  One "step" = one pass of the alignment kernels
+over the whole batch, with the 2-bit packed sequences already resident in HBM.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P]
 
-N > 1: launched by torch.distributed.run, one rank per GPU; every rank aligns its own P pairs (weak
-scaling, pairs are independent: no collective on the data path); barrier + device sync on both sides
-of the timed region, MAX over ranks, rank 0 prints ONE JSON line.  Extra keys: "roofline" (HBM, from
-HIP events around the kernels on their stream) and "cpu_baseline" (the real WFA2-lib from oracle/_ref
-when present, else the C restatement, on a bounded sample, rank 0 at N=1 only).
+N > 1: one rank per GPU (the driver launches torch.distributed.run; `python bench.py --gpus N` without a
+WORLD_SIZE spawns it itself); every rank aligns its own P pairs (weak scaling, pairs are independent: no
+collective on the data path); barrier + device sync on both sides of the timed region, MAX over ranks, rank 0
+prints ONE JSON line.
+
+Besides the contract keys the line carries (rank 0, N = 1):
+  roofline      HBM roofline of the C2 step (HIP events on the launch stream), + "secondary": the on-chip bound
+                from the committed counter passes (profiles/), + "traffic" with its provenance
+  end_to_end    the PCIe-inclusive rate of the same batch: host ASCII in -> host results out (wfa_hip_align_batch)
+  offsets_per_s wavefront offsets (all components) the reference algorithm computes for these pairs, per second
+  cpu_baseline  the real WFA2-lib (oracle/_ref) on the same pairs, 1 thread (+ all host threads), and a PARITY CHECK of
+                the scores it computed against the GPU's: parity_checked_pairs / parity_mismatches
+  extra.configs the other BASELINE configurations (C1 150 bp full CIGAR, C3 10 kb adaptive full CIGAR, C4 10 kb affine2p
+                ends-free full CIGAR) on stated prefixes, each with kernel_ms, alignments/s, roofline, offsets/s, a
+                1-thread reference baseline and a parity check against it
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,11 +36,34 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PCIE_PEAK_GBS = 63.0    # same guide: PCIe Gen5 x16
 
 
-def cpu_baseline(batch, cfg_kw, budget_s=12.0):
-    """Time the CPU reference on a bounded prefix of the same workload (1 thread)."""
+def host_cpu():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return ""
+
+
+def kernel_source_hash():
+    """Hash of the kernel sources: ties counter files under profiles/ to the build they were collected on."""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "pywfa_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hpp", ".hip")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode()); h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_reference(batch, cfg_kw, n_max, budget_s, want_cigar):
+    """The CPU reference on a bounded prefix (1 thread).  Returns (info dict, n, result dict)."""
     from oracle import loader
     from pywfa_amd import datagen
     if loader.have_reference():
@@ -37,46 +72,102 @@ def cpu_baseline(batch, cfg_kw, budget_s=12.0):
         fn, kind = loader.oracle(), "port"
     cfg = loader.make_config(**cfg_kw)
     n_all = len(batch["p_len"])
-    probe = min(n_all, 100000)
+    probe = int(min(n_all, n_max, max(4, n_max // 100)))
     t0 = time.perf_counter()
-    loader.run(fn, cfg, datagen.subset(batch, np.arange(probe)), want_cigar=False)
+    res = loader.run(fn, cfg, datagen.subset(batch, np.arange(probe)), want_cigar=want_cigar)
     dt = max(time.perf_counter() - t0, 1e-6)
-    n = int(min(n_all, max(probe, budget_s * probe / dt)))
+    n = int(min(n_all, n_max, max(probe, budget_s * probe / dt)))
+    if n > probe:
+        t0 = time.perf_counter()
+        res = loader.run(fn, cfg, datagen.subset(batch, np.arange(n)), want_cigar=want_cigar)
+        dt = time.perf_counter() - t0
+    info = {"value": n / dt, "unit": "alignments/s", "cores": 1, "kind": kind,
+            "sample": f"first {n} pairs of the same batch, 1 thread, {dt:.1f} s; host CPU: {host_cpu()} ({os.cpu_count()} logical cores)",
+            "library": os.path.basename(loader.reference_path() or "liboracle.so")}
+    return info, n, res
+
+
+def parity(res, n, score, status, cig):
+    """Mismatches between the CPU reference's results on the first n pairs and the GPU's."""
+    bad = (np.asarray(res["score"])[:n] != score[:n]) | (np.asarray(res["status"])[:n] != status[:n])
+    if cig is not None and res.get("cigars") is not None:
+        ops, cbeg, clen = cig
+        for i in range(n):
+            if not bad[i] and ops[cbeg[i]:cbeg[i] + clen[i]].tobytes() != res["cigars"][i]:
+                bad[i] = True
+    return int(bad.sum())
+
+
+def work_counts(batch, cfg_kw, n):
+    """Offsets the reference algorithm computes per pair (oracle counters on a small sample)."""
+    from oracle import loader
+    from pywfa_amd import datagen
+    n = int(min(n, len(batch["p_len"])))
+    loader.oracle_counters(True)
+    loader.run(loader.oracle(), loader.make_config(**dict(cfg_kw, scope="score")), datagen.subset(batch, np.arange(n)), want_cigar=False)
+    m, allc, bases = loader.oracle_counters()
+    return {"m_offsets_per_pair": m / n, "offsets_per_pair": allc / n, "bases_compared_per_pair": bases / n, "sample_pairs": n}
+
+
+def run_resident(al, batch, steps, warmup, want_cigar, barrier=None):
+    """Warm-up, then `steps` timed passes over the resident batch.  Returns timings and results."""
     t0 = time.perf_counter()
-    loader.run(fn, cfg, datagen.subset(batch, np.arange(n)), want_cigar=False)
-    dt = time.perf_counter() - t0
-    model = ""
-    try:
-        with open("/proc/cpuinfo") as f:
-            for line in f:
-                if line.startswith("model name"):
-                    model = line.split(":", 1)[1].strip()
-                    break
-    except OSError:
-        pass
-    out = {"value": n / dt, "unit": "alignments/s", "cores": 1, "kind": kind,
-           "sample": f"first {n} pairs of the same batch, 1 thread, {dt:.1f} s; host CPU: {model} ({os.cpu_count()} logical cores)",
-           "library": os.path.basename(loader.reference_path() or "liboracle.so")}
-    if kind == "reference":
-        # context only: the same library on every host thread (one aligner object per thread)
-        try:
-            nt = os.cpu_count() or 1
-            # (logical CPUs may exceed what the box's cgroup really grants: size the sample from a timed probe)
-            n_probe = min(n_all, max(nt * 2000, 500000))
-            t0 = time.perf_counter()
-            loader.reference_mt(cfg, datagen.subset(batch, np.arange(n_probe)), nt, 1)
-            dt_p = max(time.perf_counter() - t0, 1e-6)
-            want = 10.0 * n_probe / dt_p  # ~10 s of wall clock
-            n_mt = int(min(n_all, max(n_probe, want)))
-            rep = max(1, int(want / n_mt))
-            t0 = time.perf_counter()
-            loader.reference_mt(cfg, datagen.subset(batch, np.arange(n_mt)), nt, rep)
-            dt_mt = time.perf_counter() - t0
-            out["all_threads"] = {"value": n_mt * rep / dt_mt, "threads": nt,
-                                  "sample": f"first {n_mt} pairs x {rep} passes, one aligner per thread, {dt_mt:.1f} s"}
-        except Exception as e:  # the single-thread figure above is the reported baseline
-            out["all_threads"] = {"error": str(e)}
+    rb = al.batch(batch)
+    t_upload = time.perf_counter() - t0
+    for _ in range(warmup):
+        rb.run()
+    rb.sync()
+    if barrier:
+        barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rb.run()
+    rb.sync()  # device sync of the stream the kernels run on
+    if barrier:
+        barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, kernel_pairs = rb.last_kernel()  # mean HIP-event time per step over the timed steps
+    score, status, cig = rb.results(want_cigar)
+    out = {"elapsed": elapsed, "kernel_ms": kernel_ms, "upload_s": t_upload, "score": score, "status": status, "cig": cig,
+           "fallback": rb.fallback_pairs(), "io_bytes": rb.algorithmic_bytes()}
+    rb.close()
     return out
+
+
+def extra_config(name, n, length, error, seed, cfg_kw, scheme, trim=0, cpu_pairs=400, cpu_budget=4.0):
+    """One of the other BASELINE configurations on a stated prefix: kernel time, roofline, CPU baseline, parity."""
+    from pywfa_amd import _native, datagen
+    from oracle import loader
+    batch = datagen.generate(n, length, error, seed)
+    if trim:
+        batch = datagen.trim_text(batch, trim)
+    oc = loader.make_config(**cfg_kw)
+    nc = _native.Config()
+    for fname, _ in _native.Config._fields_:
+        setattr(nc, fname, getattr(oc, fname))
+    full = oc.scope == 1
+    al = _native.Aligner(nc, 0)
+    r = run_resident(al, batch, 3, 1, full)
+    al.close()
+    wc = work_counts(batch, cfg_kw, 8 if length >= 5000 else 2000)
+    # algorithmic HBM bytes per pair (SURVEY.md §8d): packed sequences in + results out (+ op bytes) + the wavefront
+    # history written once: 4 B per offset (explicit scheme) or 8 B per 15 offsets (piggy-back blocks); score scope: none
+    hist = 0.0
+    if full and length > 1000:
+        hist = wc["offsets_per_pair"] * (4.0 if scheme == "explicit" else 8.0 / 15.0)
+    bytes_pair = r["io_bytes"] / n + hist
+    achieved = bytes_pair * n / (r["kernel_ms"] * 1e-3) / 1e9
+    cpu, n_cpu, res = cpu_reference(batch, cfg_kw, cpu_pairs, cpu_budget, full)
+    rate = n / (r["elapsed"] / 3)
+    return {"name": name, "pairs": n, "read_length": length, "error": error, "seed": seed, "config": cfg_kw,
+            "history_scheme": scheme if (full and length > 1000) else None,
+            "kernel_ms": r["kernel_ms"], "ms_per_step": r["elapsed"] / 3 * 1e3, "alignments_per_s": rate,
+            "offsets_per_s": rate * wc["offsets_per_pair"], "work": wc,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "bytes_per_pair": bytes_pair},
+            "completed": int((r["status"] == 0).sum()), "handed_to_general_kernel": int(r["fallback"]),
+            "cpu_baseline": cpu, "speedup_vs_1_thread": rate / cpu["value"],
+            "parity_checked_pairs": n_cpu, "parity_mismatches": parity(res, n_cpu, r["score"], r["status"], r["cig"])}
 
 
 def shard_first(rank, pairs_per_gpu):
@@ -124,11 +215,22 @@ def main():
     ap.add_argument("--length", type=int, default=150)
     ap.add_argument("--error", type=float, default=0.02)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by hand: start one rank per GPU as a child (nothing has touched the GPU yet) and
+        # leave with its return code
+        port = 29500 + os.getpid() % 2000
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     dist = None
     backend = "nccl"
     if world > 1:
@@ -148,52 +250,45 @@ def main():
     t_gen = time.perf_counter() - t0
 
     al = _native.Aligner(cfg, device=local_rank)
-    t0 = time.perf_counter()
-    rb = al.batch(batch)  # H2D + 2-bit pack: untimed, inputs are resident before the clock starts
-    t_upload = time.perf_counter() - t0
-
-    def barrier():
-        dist_barrier(dist, backend)
-
-    for _ in range(args.warmup):
-        rb.run()
-    rb.sync()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rb.run()
-    rb.sync()  # device sync of the stream the kernels run on
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms, kernel_pairs = rb.last_kernel()  # mean HIP-event time per step over the timed steps
-    elapsed = dist_max(dist, backend, elapsed)
-
-    score, status, _ = rb.results(False)
-    alg_bytes = rb.algorithmic_bytes()
-    fallback = rb.fallback_pairs()
-    # PCIe-inclusive rate (host ASCII in -> host results out), reported beside the resident figure
-    t0 = time.perf_counter()
-    s2, st2, _ = al.align_batch(batch, False)
-    t_e2e = time.perf_counter() - t0
-    assert np.array_equal(s2, score)
-    rb.close()
+    r = run_resident(al, batch, args.steps, args.warmup, False, barrier=lambda: dist_barrier(dist, backend))
+    elapsed = dist_max(dist, backend, r["elapsed"])
+    kernel_ms, score, status = r["kernel_ms"], r["score"], r["status"]
+    # PCIe-inclusive rate (host ASCII in -> host results out), best of two calls (the first pins and sizes the staging)
+    t_e2e = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        s2, st2, _ = al.align_batch(batch, False)
+        dt = time.perf_counter() - t0
+        t_e2e = dt if t_e2e is None else min(t_e2e, dt)
+    assert np.array_equal(s2, score) and np.array_equal(st2, status)
     al.close()
 
     if rank == 0:
-        # HBM traffic of one launch from the PMC passes committed under profiles/ (bench.py cannot collect
-        # counters itself): used only when it was measured on this same workload
-        traffic = None
+        src_hash = kernel_source_hash()
+        # HBM traffic of one launch and the on-chip counters, from the PMC passes committed under profiles/ (bench.py
+        # cannot collect counters itself): used only when they were collected on this workload AND this kernel source
+        traffic, provenance, secondary = None, None, None
         try:
             with open(os.path.join(ROOT, "profiles", "traffic_c2.json")) as f:
                 tj = json.load(f)
             w = tj["workload"]
-            if (w["pairs_per_gpu"], w["read_length"], w["error"]) == (args.pairs, args.length, args.error):
+            same_wl = (w["pairs_per_gpu"], w["read_length"], w["error"]) == (args.pairs, args.length, args.error)
+            same_src = tj.get("kernel_source_hash") == src_hash
+            provenance = {"file": "profiles/traffic_c2.json", "collected_on_kernel_source": tj.get("kernel_source_hash"),
+                          "this_build_kernel_source": src_hash, "same_workload": same_wl, "same_kernel_source": same_src,
+                          "git_head_when_collected": tj.get("git_head"), "counter_files": tj.get("source")}
+            if same_wl and same_src:
                 traffic = tj["hbm_bytes_per_launch"]
+                secondary = tj.get("secondary")
         except (OSError, KeyError, ValueError):
             pass
         total_pairs = args.pairs * n_gpus * args.steps
         value = total_pairs / elapsed
+        alg_bytes = r["io_bytes"]
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        wc = work_counts(batch, cfg_kw, 20000)
+        e2e_rate = args.pairs / t_e2e
+        ascii_bytes = float(batch["p_len"].sum() + batch["t_len"].sum()) / args.pairs + 8
         out = {
             "metric": "pairwise alignments/sec",
             "value": value,
@@ -208,18 +303,65 @@ def main():
             "dtype": "int32",
             "data": "synthetic",
             "config": {"workload": f"C2: {args.pairs} x {args.length}bp pairs per GPU, {args.error * 100:g}% error (seed 1002), "
-                                   "gap-affine 0/4/6/2, end-to-end, scope=score, 2-bit packed sequences resident in HBM",
+                                   "gap-affine 0/4/6/2, end-to-end, scope=score, 2-bit packed sequences resident in HBM; the first "
+                                   "stage's width was chosen by a pilot on 8192 pairs during warm-up (once per resident batch)",
                        "pairs_per_gpu": args.pairs, "read_length": args.length, "parallelism": f"pairs sharded over {n_gpus} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_provenance": provenance,
+                         "secondary": secondary,
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_pair": alg_bytes / max(args.pairs, 1),
                          "kernel_ms": kernel_ms, "kernel": "wfa alignment kernels of one step (HIP events on the launch stream)"},
+            "offsets_per_s": value * wc["offsets_per_pair"],
+            "end_to_end": {"value": e2e_rate * n_gpus, "unit": "alignments/s", "seconds_per_batch": t_e2e,
+                           "what": "wfa_hip_align_batch: host ASCII in -> host scores/status out (upload, 2-bit pack, align, download)",
+                           "pcie_bytes_per_pair": ascii_bytes, "pcie_gb_s": e2e_rate * ascii_bytes / 1e9,
+                           "pcie_frac": e2e_rate * ascii_bytes / 1e9 / PCIE_PEAK_GBS},
             "extra": {"mean_score": float(score.mean()), "completed": int((status == 0).sum()),
-                      "fallback_pairs": int(fallback), "datagen_s": t_gen, "upload_pack_s": t_upload,
-                      "pcie_inclusive_alignments_per_s": args.pairs / t_e2e},
+                      "fallback_pairs": int(r["fallback"]), "datagen_s": t_gen, "upload_pack_s": r["upload_s"],
+                      "work_per_pair": wc, "kernel_source_hash": src_hash},
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(batch, cfg_kw)
+            from oracle import loader
+            cpu, n_cpu, res = cpu_reference(batch, cfg_kw, args.pairs, 12.0, False)
+            cpu["parity_checked_pairs"] = n_cpu
+            cpu["parity_mismatches"] = parity(res, n_cpu, score, status, None)
+            if cpu["kind"] == "reference":
+                # context only: the same library on every host thread (one aligner object per thread); its scores are
+                # checked too
+                try:
+                    nt = os.cpu_count() or 1
+                    ocfg = loader.make_config(**cfg_kw)
+                    n_probe = min(args.pairs, max(nt * 2000, 500000))
+                    t0 = time.perf_counter()
+                    loader.reference_mt(ocfg, datagen.subset(batch, np.arange(n_probe)), nt, 1)
+                    dt_p = max(time.perf_counter() - t0, 1e-6)
+                    n_mt = int(min(args.pairs, max(n_probe, 8.0 * n_probe / dt_p)))
+                    t0 = time.perf_counter()
+                    rmt = loader.reference_mt(ocfg, datagen.subset(batch, np.arange(n_mt)), nt, 1)
+                    dt_mt = time.perf_counter() - t0
+                    cpu["all_threads"] = {"value": n_mt / dt_mt, "threads": nt,
+                                          "sample": f"first {n_mt} pairs, one aligner per thread, {dt_mt:.1f} s",
+                                          "parity_checked_pairs": n_mt, "parity_mismatches": parity(rmt, n_mt, score, status, None)}
+                except Exception as e:  # the single-thread figure above is the reported baseline
+                    cpu["all_threads"] = {"error": str(e)}
+            out["cpu_baseline"] = cpu
+        if n_gpus == 1 and not args.no_extra_configs:
+            xs = []
+            try:
+                xs.append(extra_config("C1", 1_000_000, 150, 0.02, datagen.SEEDS["C1"], dict(scope="full"), "explicit",
+                                       cpu_pairs=200000, cpu_budget=3.0))
+                xs.append(extra_config("C3", 100_000, 10000, 0.08, datagen.SEEDS["C3"],
+                                       dict(span="end-to-end", scope="full", heuristic="adaptive"), "explicit"))
+                xs.append(extra_config("C3-piggyback", 100_000, 10000, 0.08, datagen.SEEDS["C3"],
+                                       dict(span="end-to-end", scope="full", heuristic="adaptive", memory_mode="medium"), "piggyback"))
+                xs.append(extra_config("C4-adaptive", 20_000, 10000, 0.08, datagen.SEEDS["C4"],
+                                       dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100,
+                                            scope="full", heuristic="adaptive"), "explicit", trim=50, cpu_pairs=100))
+            except Exception as e:
+                xs.append({"error": repr(e)})
+            out["extra"]["configs"] = xs
+            out["extra"]["configs_note"] = ("stated prefixes of the BASELINE streams (C1 1 M of 1 k..., C3 100 k of 1 M, C4 20 k of 1 M with "
+                                            "wf-adaptive: the exact form writes ~0.4 GB of history per pair); C2 above is the full 10 M")
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

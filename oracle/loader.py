@@ -198,3 +198,18 @@ def reference_mt(cfg, batch, nthreads, repeat=1):
     if rc != 0:
         raise RuntimeError(f"reference returned {rc}")
     return {"score": score, "status": status, "cigars": None}
+
+
+def oracle_counters(reset=False):
+    """(M offsets, offsets of all components, bases compared) the oracle has processed since the last reset
+    (bench.py's "offsets/s" figure)."""
+    oracle()
+    lib = ctypes.CDLL(os.path.join(HERE, "liboracle.so"))
+    lib.wfa_oracle_counters.argtypes = [ctypes.c_void_p]
+    lib.wfa_oracle_counters.restype = None
+    if reset:
+        lib.wfa_oracle_counters(None)
+        return (0, 0, 0)
+    out = (ctypes.c_int64 * 3)()
+    lib.wfa_oracle_counters(out)
+    return (int(out[0]), int(out[1]), int(out[2]))

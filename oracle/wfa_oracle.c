@@ -146,6 +146,14 @@ static inline int32_t wf_get(const wf_in_t* in, int k) {
   return (k >= in->lo && k <= in->hi) ? in->off[k - in->base] : OFFSET_NULL;
 }
 
+/* Work counters for bench.py's "offsets/s" figure: offsets of M computed, offsets of all components
+ * computed, bases compared by the extension, since the last wfa_oracle_counters(NULL) call.  Not thread-safe. */
+static int64_t g_m_offsets, g_all_offsets, g_bases;
+void wfa_oracle_counters(int64_t* out3) {
+  if (out3) { out3[0] = g_m_offsets; out3[1] = g_all_offsets; out3[2] = g_bases; }
+  else { g_m_offsets = 0; g_all_offsets = 0; g_bases = 0; }
+}
+
 #define MAX2(a, b) ((a) > (b) ? (a) : (b))
 #define MIN2(a, b) ((a) < (b) ? (a) : (b))
 
@@ -192,6 +200,7 @@ static int compute_next_linear(oracle_ws_t* ws, int s, int plen, int tlen, int* 
   mo = wf_fetch(ws, 0, s - ws->o1);
   int32_t* om = ws->arena + wf_slot(ws, 0, s)->idx;
   int k;
+  g_m_offsets += (int64_t)hi - lo + 1; g_all_offsets += (int64_t)hi - lo + 1;
   for (k = lo; k <= hi; ++k) {
     const int32_t ins = wf_get(&mo, k - 1), del = wf_get(&mo, k + 1);
     int32_t mv = indel ? MAX2(del, ins + 1) : MAX2(del, MAX2(wf_get(&mx, k), ins) + 1);
@@ -260,6 +269,8 @@ static int compute_next(oracle_ws_t* ws, int s, int plen, int tlen, int* err) {
   int32_t* oi2 = has_i2 ? ws->arena + wf_slot(ws, 3, s)->idx : NULL;
   int32_t* od2 = has_d2 ? ws->arena + wf_slot(ws, 4, s)->idx : NULL;
   int k;
+  g_m_offsets += (int64_t)hi - lo + 1;
+  g_all_offsets += ((int64_t)hi - lo + 1) * (1 + has_i1 + has_d1 + has_i2 + has_d2);
   for (k = lo; k <= hi; ++k) {
     const int32_t ins1 = MAX2(wf_get(&mo1, k - 1), wf_get(&i1e, k - 1)) + 1;
     const int32_t del1 = MAX2(wf_get(&mo1, k + 1), wf_get(&d1e, k + 1));
@@ -602,6 +613,7 @@ static int align_one(oracle_ws_t* ws, const wfa_hip_config_t* cfg, const uint8_t
         } else {
           while (v < plen && h < tlen && (P[v] == T[h] || P[v] == wc || T[h] == wc)) { ++v; ++h; }
         }
+        g_bases += h - o + 1;
         o = h;
         off[k - m->base] = o;
         if (endsfree) {

@@ -11,7 +11,7 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwfa_hip.so")
+LIB_PATH = os.environ.get("WFA_HIP_LIB") or os.path.join(_HERE, "libwfa_hip.so")  # (WFA_HIP_LIB: development builds)
 
 ABI_VERSION = 1
 

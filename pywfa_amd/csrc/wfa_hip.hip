@@ -24,6 +24,7 @@
 #include "wfa_general.hpp"
 #include "wfa_fast.hpp"
 #include "wfa_seg.hpp"
+#include "wfa_lane.hpp"
 #include "wfa_band.hpp"
 #include "wfa_rle.hpp"
 
@@ -37,7 +38,7 @@ static thread_local std::string g_error;
   F(ARENA_KB) F(BAND_DEBUG) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
-  F(PIPE_CHUNK) F(PIPE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB)
+  F(PIPE_CHUNK) F(PIPE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG)
 enum WfaKnob {
 #define WFA_KNOB_ENUM(n) K_##n,
   WFA_KNOBS(WFA_KNOB_ENUM)
@@ -846,20 +847,20 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     }
     if (use_fast) {
       // register-kernel stages, each taking what the one before handed on (WFA_HIP_FAST_STAGES, one digit per
-      // stage): 7/6/8/9 = segments of 8/16/32/64 lanes with the two-round (lazy) extension, 3/2/4/5 = the same widths
-      // extending every cell at once, 1 = half-waves, 0 = one alignment per wave (both with edge detection)
+      // stage): 1 = the lane-per-pair kernel (64 pairs per wave, band of 16 diagonals, wfa_lane.hpp); 7/6/8/9 = segments
+      // of 8/16/32/64 lanes with the two-round (lazy) extension, 3/2/4/5 = the same widths extending every cell at once
       const char* stages_env = al->knobs.fast_stages.empty() ? nullptr : al->knobs.fast_stages.c_str();
-      const char* stages = stages_env ? stages_env : "689";
+      const char* stages = stages_env ? stages_env : "189";
       if (!stages_env && in_n >= 65536u && in_count == nullptr) {
         { const int prc = pick_first_width(); if (prc != WFA_HIP_OK) return prc; }
-        stages = (b->stage_pick == 16) ? "689" : (b->stage_pick == 32) ? "89" : "9";  // (128: 64 lanes still take the pairs that fit)
+        stages = (b->stage_pick == 16) ? "189" : (b->stage_pick == 32) ? "89" : "9";  // (128: 64 lanes still take the pairs that fit)
       }
       int variants[6] = {-1, -1, -1, -1, -1, -1};
       int nv = 0;
       for (const char* c = stages; *c && nv < 6; ++c) {
         const int v = *c - '0';
         if (v < 0 || v > 9) continue;
-        if (v < 2) continue;
+        if (v < 1) continue;
         variants[nv++] = v;
       }
       if (nv == 0) variants[nv++] = 6;
@@ -870,8 +871,23 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         hipEvent_t se0 = nullptr, se1 = nullptr;
         const bool stage_timing = knob(al, K_STAGE_TIMING, 0) != 0;
         if (stage_timing) { hipEventCreate(&se0); hipEventCreate(&se1); hipEventRecord(se0, stream); }
-        const int lrc = wfa::launch_seg(b->dcfg, al->cu_count, knob(al, K_FAST_WAVES_PER_CU, 256), stream, b->d_words, b->d_meta, in_list, in_count,
-                                        in_n, b->d_score, b->d_status, out_list, out_count, variants[pass]);
+        int lrc;
+        if (variants[pass] == 1) {
+          int X, OE, E;
+          const int shape = wfa::seg_shape(b->dcfg, &X, &OE, &E);
+          lrc = wfa::launch_lane(shape, wfa::gcd_int(wfa::gcd_int(b->dcfg.x, b->dcfg.o1 + b->dcfg.e1), b->dcfg.e1), al->cu_count,
+                                 knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, b->d_words, b->d_meta,
+                                 in_list, in_count, in_n, b->d_score, b->d_status, out_list, out_count,
+                                 (knob(al, K_LANE_DEBUG, 0) && al->ws) ? al->ws : nullptr);
+          if (knob(al, K_LANE_DEBUG, 0) && al->ws) {  // development aid (build with -DWFA_LANE_DEBUG_COUNTERS=1)
+            unsigned long long c[4] = {0, 0, 0, 0};
+            hipStreamSynchronize(stream); hipMemcpy(c, al->ws, sizeof(c), hipMemcpyDeviceToHost); hipMemset(al->ws, 0, sizeof(c));
+            fprintf(stderr, "[wfa_hip] lane kernel: %llu wave-steps, %llu refills, %llu long runs, %llu 32-base rounds\n", c[0], c[1], c[2], c[3]);
+          }
+        } else {
+          lrc = wfa::launch_seg(b->dcfg, al->cu_count, knob(al, K_FAST_WAVES_PER_CU, 256), stream, b->d_words, b->d_meta, in_list, in_count,
+                                in_n, b->d_score, b->d_status, out_list, out_count, variants[pass]);
+        }
         if (lrc != 0) { al->err = "fast kernel launch failed"; return WFA_HIP_EDEVICE; }
         if (stage_timing) {  // development aid: synchronises after every stage
           hipEventRecord(se1, stream); hipEventSynchronize(se1);

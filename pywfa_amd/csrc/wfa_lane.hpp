@@ -1,0 +1,413 @@
+// wfa_lane.hpp — lane-per-pair register kernel: the C2 hot loop of round 2 (gap-affine, match 0, end-to-end, score
+// only, no heuristic, reads <= 512 bases; the scope of wfa_seg.hpp).
+//
+// Why.  Round 1's segmented kernel (wfa_seg.hpp: lane <-> diagonal, 4 pairs per wave) is latency-bound, not
+// issue-bound: rocprofv3 on the 16-lane stage (profiles/r02_*) shows 7.4 resident waves per SIMD each issuing one
+// instruction per ~14 cycles, the vector unit ~53 % busy, the scalar unit ~27 %: every step of a wave is one long
+// dependent chain (address -> LDS -> funnel shift -> ffbl -> ballot -> branch) over the few live diagonals of 4 pairs.
+// Here the layout is transposed: lane <-> PAIR (64 alignments per wave), and the W = 16 diagonals of a pair's band
+// are 16 register slots unrolled in the instruction stream.  The 16 diagonals of a step are independent, so the wave
+// carries 16 interleavable dependency chains and the unit of work per instruction is 64 pairs instead of 4:
+//   * wavefront ring in VGPRs, two diagonals per register as int16 (offsets <= 512, NULL = -16384): M at depths
+//     1..max(x, o+e), I and D at depth e, recurrences of R/wavefront_compute_affine.c:44-86 with v_pk_max_i16 /
+//     v_pk_add_i16; the k-1 / k+1 neighbour is the adjacent half-register (one v_alignbit_b32 per register);
+//   * extension (R/wavefront_extend_kernels.c:64-110): per slot 32 bases per probe from the lane's own 2-bit words in
+//     LDS (three words per sequence, funnel shift, XOR, v_ffbl), repeated while any lane's run goes on; slots dead
+//     in all 64 lanes are skipped with one ballot;
+//   * termination (R/wavefront_termination.c:37-61) folded into the pass: one v_xad + v_min per slot;
+//   * a lane that finishes stores its score and idles; once `refill_min` lanes idle they take the next pairs of
+//     the wave's slice together: metadata by ds_bpermute from two 64-pair windows held in VGPRs, packed words by
+//     one global_load_lds per pair straight into the lane's LDS slot, one s_waitcnt for all of them.
+// Exactness is the band argument of wfa_seg.hpp, unchanged: band k in [c - 8, c + 8), c = ceil((tlen - plen) / 2);
+// a score is kept only if S' <= Bmin = min(2o + e(2c + 16 - ak), 2o + e(18 - 2c + ak)), otherwise the pair is handed
+// to the next stage (32- / 64-lane segments, banded, general kernel) — every stage computes the same wavefronts.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <algorithm>
+#include "wfa_common.hpp"
+#include "wfa_fast.hpp"
+
+namespace wfa {
+
+typedef short lane_s2 __attribute__((ext_vector_type(2)));
+
+#define WFA_LANE_NULL16 (-16384)
+#define WFA_LANE_NULL2 0xC000C000u
+#ifndef WFA_LANE_DEBUG_COUNTERS
+#define WFA_LANE_DEBUG_COUNTERS 0  // 1: a.hist (if set) receives {wave-steps, refills, long runs, 32-base rounds} as four uint64
+#endif
+
+__device__ __forceinline__ uint32_t lane_ffbl(uint32_t x) {  // index of the lowest set bit, ~0u for 0
+  uint32_t r;
+  asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
+  lane_s2 r = __builtin_elementwise_max(__builtin_bit_cast(lane_s2, a), __builtin_bit_cast(lane_s2, b));
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
+  lane_s2 r = __builtin_elementwise_min(__builtin_bit_cast(lane_s2, a), __builtin_bit_cast(lane_s2, b));
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
+  lane_s2 r = __builtin_bit_cast(lane_s2, a) - __builtin_bit_cast(lane_s2, b);
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
+  lane_s2 r = __builtin_bit_cast(lane_s2, a) + __builtin_bit_cast(lane_s2, b);
+  return __builtin_bit_cast(uint32_t, r);
+}
+// per half: nm > lim ? NULL : nm   (only M is clamped, R/wavefront_compute_affine.c:80-84; negative values are dead anyway)
+__device__ __forceinline__ uint32_t pk_clamp(uint32_t nm, uint32_t lim) {
+  lane_s2 d = __builtin_bit_cast(lane_s2, lim) - __builtin_bit_cast(lane_s2, nm);
+  d = d >> (short)15;  // 0xffff where nm > lim
+  const uint32_t m = __builtin_bit_cast(uint32_t, d);
+  return (nm & ~m) | (WFA_LANE_NULL2 & m);
+}
+
+template <int X, int OE, int E>
+__global__ void __launch_bounds__(64)
+wfa_lane_kernel(const FastArgs a, const int slot_words, const int refill_min) {
+  constexpr int W = 16, H = 8, NR = 8;            // band of 16 diagonals = 8 packed registers
+  constexpr int DM = (X > OE) ? X : OE;           // depth of the M ring
+  constexpr int NEVER = 0x7fffffff;
+  extern __shared__ uint32_t lds[];               // [4 guard words][64 slots x slot_words][4 guard words]
+  const int lane = threadIdx.x;
+  uint32_t nwork = __builtin_amdgcn_readfirstlane(a.nwork_dev ? *a.nwork_dev : a.nwork);
+  const uint32_t per = __builtin_amdgcn_readfirstlane((nwork + gridDim.x - 1) / gridDim.x);
+  const unsigned long long begin64 = (unsigned long long)blockIdx.x * per;
+  if (begin64 >= nwork) return;
+  const uint32_t begin = (uint32_t)begin64;
+  const uint32_t end = (uint32_t)min((unsigned long long)nwork, begin64 + per);
+
+  // ---- two windows of 64 pairs' metadata: lane i holds pair wbase + i / wbase + 64 + i
+  uint32_t pid0, pw0, ln0, pid1, pw1, ln1;        // ln = plen | tlen << 16 (0xffffffff: too long for this stage)
+  auto load_window = [&](uint32_t wb, uint32_t& pid, uint32_t& pw, uint32_t& ln) {
+    const unsigned long long idx = (unsigned long long)wb + lane;
+    pid = 0u; pw = 0u; ln = 0u;
+    if (idx < end) {
+      pid = a.worklist ? a.worklist[a.work_begin + idx] : (uint32_t)(a.work_begin + idx);
+      const WfaPairMeta m = a.meta[pid];
+      pw = m.p_woff;
+      ln = (m.plen > WFA_FAST_MAX_LEN || m.tlen > WFA_FAST_MAX_LEN) ? 0xffffffffu : ((uint32_t)m.plen | ((uint32_t)m.tlen << 16));
+    }
+  };
+  uint32_t wbase = begin, next_i = begin;
+  load_window(wbase, pid0, pw0, ln0);
+  load_window(wbase + 64u, pid1, pw1, ln1);
+
+  // ---- per-lane state
+  const int pbase = (4 + lane * slot_words) * 16;  // base coordinate (in bases) of my LDS slot
+  uint32_t cur[NR], lim[NR], Mh[DM][NR], Ih[E][NR], Dh[E][NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    cur[r] = WFA_LANE_NULL2; lim[r] = WFA_LANE_NULL2;
+#pragma unroll
+    for (int d = 0; d < DM; ++d) Mh[d][r] = WFA_LANE_NULL2;
+#pragma unroll
+    for (int d = 0; d < E; ++d) { Ih[d][r] = WFA_LANE_NULL2; Dh[d][r] = WFA_LANE_NULL2; }
+  }
+  int kb0 = pbase, tb = pbase;   // pattern coordinate of offset x on slot j is x + kb0 - j; text coordinate is x + tb
+  int jt = 0;                    // slot of the end diagonal tlen - plen
+  uint32_t tend = 0xffffu;       // tlen: the offset that ends the alignment on slot jt (0xffff: no pair)
+  int s0 = 0, deadline = NEVER;
+  uint32_t mypid = 0;
+  unsigned long long idle = ~0ull;  // lanes without a pair
+  int gstep = 0;
+
+  while (true) {
+    // =================== take pairs ===================
+    const int nidle = __builtin_popcountll(idle);
+    if (next_i < end && (nidle >= refill_min || idle == ~0ull)) {
+      const bool is_idle = __builtin_amdgcn_inverse_ballot_w64(idle);
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+      const uint32_t navail = end - next_i;
+      const bool take = is_idle && rank < navail;
+      const uint32_t src = next_i + rank - wbase;   // 0 .. 126: position in the two windows
+      const int sl = (int)(src & 63u);
+      const uint32_t a_pid = __shfl(pid0, sl, 64), a_pw = __shfl(pw0, sl, 64), a_ln = __shfl(ln0, sl, 64);
+      const uint32_t b_pid = __shfl(pid1, sl, 64), b_pw = __shfl(pw1, sl, 64), b_ln = __shfl(ln1, sl, 64);
+      const bool hi_w = src >= 64u;
+      const uint32_t n_pid = hi_w ? b_pid : a_pid, n_pw = hi_w ? b_pw : a_pw, n_ln = hi_w ? b_ln : a_ln;
+      const int pl = (int)(n_ln & 0xffffu), tl = (int)(n_ln >> 16);
+      const int nwp = (pl + 15) >> 4, ntot = nwp + ((tl + 15) >> 4);
+      const int ak = tl - pl;
+      // a pair this stage cannot take (too long for the slot, |tlen - plen| outside the band) gets an expired deadline:
+      // the hand-over path below passes it on at once
+      const bool bad = n_ln == 0xffffffffu || ntot + 1 > slot_words || ak < 1 - 2 * H || ak > 2 * H - 1;
+      const unsigned long long tmask = __ballot(take);
+      // packed words of every taken pair: one direct-to-LDS load each (lane j -> word j of the pair -> slot word j;
+      // the text words of a pair follow its pattern words, csrc/wfa_hip.hip batch_build)
+      {
+        unsigned long long lm = __ballot(take && !bad);
+        while (lm) {
+          const int L = __builtin_ctzll(lm);
+          lm &= lm - 1ull;
+          const uint32_t pw = __builtin_amdgcn_readlane(n_pw, L);
+          const int nt = __builtin_amdgcn_readlane(ntot, L);
+          if (lane < nt) __builtin_amdgcn_global_load_lds(a.words + pw + lane, &lds[4 + L * slot_words], 4, 0, 0);
+        }
+      }
+      if (take) {
+        const int c = bad ? 0 : ((ak + 1) >> 1);      // band centre: k in [c - H, c + H)
+        const int k0 = c - H;                         // diagonal of slot 0
+        mypid = n_pid; s0 = gstep;
+        kb0 = pbase - k0; tb = pbase + nwp * 16;
+        jt = bad ? 0 : ak - k0;
+        tend = bad ? 0xffffu : (uint32_t)tl;
+        // Bmin / g in units of g (o / g = OE - E, e / g = E), see wfa_seg.hpp
+        deadline = bad ? gstep - 1
+                       : gstep + min(2 * (OE - E) + E * (2 * c + 2 * H - ak), 2 * (OE - E) + E * (2 * H + 2 - 2 * c + ak));
+        const int j0 = -k0;                           // slot of diagonal 0: the cell (score 0, offset 0)
+        // lim of slot j = min(tlen, plen + k0 + j), two per register (a pair this stage cannot take: NULL, nothing lives)
+        const uint32_t lb2 = ((uint32_t)(pl + k0) & 0xffffu) | ((uint32_t)(pl + k0 + 1) << 16);
+        const uint32_t tl2 = (uint32_t)tl | ((uint32_t)tl << 16);
+        const int j0r = bad ? -1 : (j0 >> 1);
+        const uint32_t c0 = (j0 & 1) ? ((uint32_t)WFA_LANE_NULL16 & 0xffffu) : (WFA_LANE_NULL2 & 0xffff0000u);  // offset 0 in half j0 & 1
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          lim[r] = bad ? WFA_LANE_NULL2 : pk_min(tl2, pk_add(lb2, (uint32_t)(2 * r) * 0x00010001u));
+          cur[r] = (j0r == r) ? c0 : WFA_LANE_NULL2;
+#pragma unroll
+          for (int d = 0; d < DM; ++d) Mh[d][r] = WFA_LANE_NULL2;
+#pragma unroll
+          for (int d = 0; d < E; ++d) { Ih[d][r] = WFA_LANE_NULL2; Dh[d][r] = WFA_LANE_NULL2; }
+        }
+      }
+      const uint32_t ntake = min((uint32_t)nidle, navail);
+      next_i += ntake;
+      idle &= ~tmask;
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the words are in LDS
+      asm volatile("" ::: "memory");
+      if (next_i - wbase >= 64u) {           // window 0 used up: window 1 moves down, the one after is requested
+        pid0 = pid1; pw0 = pw1; ln0 = ln1; wbase += 64u;
+        load_window(wbase + 64u, pid1, pw1, ln1);
+      }
+    } else if (idle == ~0ull) {
+      break;                                 // nothing left
+    }
+
+    // =================== extend (all 16 slots) ===================
+    // One packed register (two slots) at a time: the first probes (16 bases: two words per sequence) of its two
+    // slots are straight-line code; a register whose slots are dead in all 64 lanes is skipped after a test on the
+    // packed values (at a few percent divergence two or three of the eight registers are live).  A run that goes on (the pair's true diagonal, mostly) becomes the lane's ONE pending
+    // run {slot, offset, bases left}; all lanes' pending runs are then continued together, 32 bases per round, so the
+    // longest run of the 64 pairs is waited for once per step and not once per slot.  (A second run of the same
+    // lane in the same step — rare — is finished on the spot.)
+    int hot_j = -1, hot_x = 0, hot_left = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      // some slot of this register holds a cell (offset >= 0) that can still run (offset < lim): per half min(cur, lim - 1 - cur) >= 0
+      const uint32_t ua = pk_min(cur[r], pk_add(pk_sub(lim[r], cur[r]), 0xffffffffu));
+      if (__any((ua & 0x80008000u) != 0x80008000u)) {
+        int off[2], left[2], x[2];
+        bool valid[2], more[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          off[q] = q ? ((int)cur[r] >> 16) : (int)(short)(cur[r] & 0xffffu);
+          const int lj = q ? ((int)lim[r] >> 16) : (int)(short)(lim[r] & 0xffffu);
+          valid[q] = off[q] >= 0;
+          left[q] = valid[q] ? lj - off[q] : 0;   // longest possible run; in-bounds cells have 0 <= off <= lim
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int j = 2 * r + q;
+          x[q] = max(off[q], 0);
+          const int v = x[q] + kb0 - j, h = x[q] + tb;
+          const uint32_t pa = ((uint32_t)v >> 2) & ~3u, ta = ((uint32_t)h >> 2) & ~3u;  // byte address of the word holding base v / h
+          const uint32_t* pp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds) + pa);
+          const uint32_t* tp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds) + ta);
+          const uint32_t p0 = pp[0], p1 = pp[1], t0 = tp[0], t1 = tp[1];
+          const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h << 1);
+          const int m = min((int)(lane_ffbl(xl) >> 1), min(16, left[q]));   // (ffbl of 0 is ~0: all 16 equal)
+          x[q] += m; left[q] -= m;
+          more[q] = (m == 16) && (left[q] > 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int j = 2 * r + q;
+          // the first run that goes on is parked; a lane that already has one finishes this one now
+          const bool park = more[q] && hot_j < 0;
+          const bool now = more[q] && !park;
+          hot_x = park ? x[q] : hot_x; hot_left = park ? left[q] : hot_left; hot_j = park ? j : hot_j;
+          if (__any(now)) {
+            bool mo = now;
+            int lf = mo ? left[q] : 0;       // other lanes advance by 0
+            int xx = x[q];
+            do {
+              const int v = xx + kb0 - j, h = xx + tb;
+              const uint32_t pa = ((uint32_t)v >> 2) & ~3u, ta = ((uint32_t)h >> 2) & ~3u;
+              const uint32_t* pp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds) + pa);
+              const uint32_t* tp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds) + ta);
+              const uint32_t p0 = pp[0], p1 = pp[1], p2 = pp[2], t0 = tp[0], t1 = tp[1], t2 = tp[2];
+              const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h << 1);
+              const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t2, t1, (uint32_t)h << 1);
+              const uint32_t fb = min(lane_ffbl(xl), lane_ffbl(xh) | 32u);   // first differing bit of xh:xl (~0 if none)
+              const int m = min((int)(fb >> 1), min(32, lf));
+              xx += m; lf -= m;
+              mo = (m == 32) && (lf > 0);
+            } while (__any(mo));
+            x[q] = xx;
+          }
+        }
+        x[0] = valid[0] ? x[0] : off[0]; x[1] = valid[1] ? x[1] : off[1];
+        cur[r] = ((uint32_t)x[0] & 0xffffu) | ((uint32_t)x[1] << 16);
+      }
+    }
+    if (__any(hot_j >= 0)) {
+      // the parked runs, all lanes together
+      bool mo = hot_j >= 0;
+      int lf = mo ? hot_left : 0;
+      const int kbj = kb0 - hot_j;
+      if (WFA_LANE_DEBUG_COUNTERS && a.hist) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.hist) + 2, 1ull); }
+      do {
+        const int v = hot_x + kbj, h = hot_x + tb;
+        const uint32_t pa = ((uint32_t)v >> 2) & ~3u, ta = ((uint32_t)h >> 2) & ~3u;
+        const uint32_t* pp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds) + pa);
+        const uint32_t* tp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds) + ta);
+        const uint32_t p0 = pp[0], p1 = pp[1], p2 = pp[2], t0 = tp[0], t1 = tp[1], t2 = tp[2];
+        const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h << 1);
+        const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t2, t1, (uint32_t)h << 1);
+        const uint32_t fb = min(lane_ffbl(xl), lane_ffbl(xh) | 32u);
+        const int m = min((int)(fb >> 1), min(32, lf));
+        hot_x += m; lf -= m;
+        mo = (m == 32) && (lf > 0);
+        if (WFA_LANE_DEBUG_COUNTERS && a.hist) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.hist) + 3, 1ull); }
+      } while (__any(mo));
+      // back into its half register (lanes without a parked run: hot_j = -1 matches no register)
+      const int hr = hot_j >> 1;
+      const uint32_t hmask = (hot_j & 1) ? 0xffff0000u : 0x0000ffffu;
+      const uint32_t hval = (hot_j & 1) ? ((uint32_t)hot_x << 16) : ((uint32_t)hot_x & 0xffffu);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const uint32_t mk = (hr == r) ? hmask : 0u;
+        cur[r] = (cur[r] & ~mk) | (hval & mk);
+      }
+    }
+
+    // =================== termination / hand-over ===================
+    {
+      // R/wavefront_termination.c:37-61: the cell of the end diagonal (slot jt) has reached offset tlen
+      uint32_t sel = cur[0];
+#pragma unroll
+      for (int r = 1; r < NR; ++r) sel = ((jt >> 1) == r) ? cur[r] : sel;
+      const uint32_t endv = (jt & 1) ? (sel >> 16) : (sel & 0xffffu);
+      const unsigned long long active = ~idle;
+      const unsigned long long bfin = __ballot(endv == tend) & active;
+      const unsigned long long brej = __ballot(gstep > deadline) & active;
+      const unsigned long long bd = bfin | brej;
+      if (bd) {
+        const unsigned long long ba = bfin & ~brej;
+        if (__builtin_amdgcn_inverse_ballot_w64(ba)) {
+          a.score[mypid] = -__mul24(gstep - s0, a.g);
+          a.status[mypid] = 0;
+        }
+        if (brej) {
+          uint32_t slot = 0;
+          if (lane == 0) slot = atomicAdd(a.fb_count, (uint32_t)__builtin_popcountll(brej));
+          slot = __builtin_amdgcn_readfirstlane(slot);
+          if (__builtin_amdgcn_inverse_ballot_w64(brej)) {
+            a.fb_list[slot + __builtin_amdgcn_mbcnt_hi((uint32_t)(brej >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)brej, 0u))] = mypid;
+            a.status[mypid] = WFA_INTERNAL_FALLBACK;
+          }
+        }
+        if (__builtin_amdgcn_inverse_ballot_w64(bd)) {
+          // an idle lane computes nothing that lives: every new cell is clamped away
+#pragma unroll
+          for (int r = 0; r < NR; ++r) { cur[r] = WFA_LANE_NULL2; lim[r] = WFA_LANE_NULL2; }
+          deadline = NEVER; jt = 0; tend = 0xffffu;
+        }
+        idle |= bd;
+        if (idle == ~0ull && next_i >= end) break;
+      }
+    }
+
+    // =================== compute-next (R/wavefront_compute_affine.c:44-86) ===================
+    {
+      uint32_t gi[NR], gd[NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const uint32_t mo = (OE == 1) ? cur[r] : Mh[OE - 2][r];   // M at s - (o + e): depth OE counted from the new score
+        gi[r] = pk_max(mo, Ih[E - 1][r]);
+        gd[r] = pk_max(mo, Dh[E - 1][r]);
+      }
+      uint32_t nm[NR], ni[NR], nd[NR];
+      const uint32_t one2 = 0x00010001u;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        // I(k) = max(M_oe, I_e)(k - 1) + 1: the value of slot j - 1; D(k) = max(M_oe, D_e)(k + 1): slot j + 1
+        const uint32_t below = __builtin_amdgcn_alignbit(gi[r], (r > 0) ? gi[r - 1] : WFA_LANE_NULL2, 16);
+        const uint32_t above = __builtin_amdgcn_alignbit((r < NR - 1) ? gd[r + 1] : WFA_LANE_NULL2, gd[r], 16);
+        ni[r] = pk_add(below, one2);
+        nd[r] = above;
+        const uint32_t mx = (X == 1) ? cur[r] : Mh[X - 2][r];
+        nm[r] = pk_clamp(pk_max(pk_max(nd[r], ni[r]), pk_add(mx, one2)), lim[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+#pragma unroll
+        for (int d = DM - 1; d > 0; --d) Mh[d][r] = Mh[d - 1][r];
+        Mh[0][r] = cur[r];
+#pragma unroll
+        for (int d = E - 1; d > 0; --d) { Ih[d][r] = Ih[d - 1][r]; Dh[d][r] = Dh[d - 1][r]; }
+        Ih[0][r] = ni[r]; Dh[0][r] = nd[r];
+        cur[r] = nm[r];
+      }
+    }
+    ++gstep;
+  }
+  if (WFA_LANE_DEBUG_COUNTERS && a.hist) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.hist), (unsigned long long)gstep); }
+}
+
+// per-shape entry points (csrc/k_lane.hip compiled once per shape index of WFA_SEG_SHAPES)
+#define WFA_LANE_DECL(i, x, oe, e) \
+  int launch_lane_s##i(unsigned grid, size_t smem, hipStream_t stream, const FastArgs& a, int slot_words, int refill_min);
+// (the shape list is wfa_seg.hpp's; declared here without including it)
+WFA_LANE_DECL(0, 2, 4, 1) WFA_LANE_DECL(1, 2, 3, 1) WFA_LANE_DECL(2, 4, 7, 1) WFA_LANE_DECL(3, 3, 5, 1)
+WFA_LANE_DECL(4, 6, 8, 3) WFA_LANE_DECL(5, 5, 3, 3) WFA_LANE_DECL(6, 1, 2, 1)
+#undef WFA_LANE_DECL
+
+template <int X, int OE, int E>
+inline int launch_lane_shape(unsigned grid, size_t smem, hipStream_t stream, const FastArgs& a, int slot_words, int refill_min) {
+  hipLaunchKernelGGL((wfa_lane_kernel<X, OE, E>), dim3(grid), dim3(64), smem, stream, a, slot_words, refill_min);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// LDS words of a pair's slot for reads up to max_len bases: both sequences + one spare word, odd (lane slots then
+// fall into different banks)
+inline int lane_slot_words(int max_len) {
+  const int w = 2 * ((max_len + 15) >> 4) + 1;
+  return w | 1;
+}
+
+// shape_idx: index in WFA_SEG_SHAPES (seg_shape()); per_cu: slices of the work list (waves) per CU
+inline int launch_lane(int shape_idx, int g, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, const uint32_t* words,
+                       const WfaPairMeta* meta, const uint32_t* worklist, const uint32_t* nwork_dev, uint32_t nwork,
+                       int32_t* score, int32_t* status, uint32_t* fb_list, uint32_t* fb_count, int32_t* debug_counters = nullptr) {
+  FastArgs a;
+  a.words = words; a.meta = meta; a.worklist = worklist; a.nwork_dev = nwork_dev; a.nwork = nwork;
+  a.score = score; a.status = status; a.fb_list = fb_list; a.fb_count = fb_count;
+  a.g = g;
+  a.hist = debug_counters; a.hist_stride = 0; a.end_state = nullptr; a.work_begin = 0;
+  const int slot_words = lane_slot_words(std::min(max_len, WFA_FAST_MAX_LEN));
+  const size_t smem = ((size_t)64 * slot_words + 8) * sizeof(uint32_t);
+  // every wave should see several hundred pairs (64 lanes x a few refills), and there should be several waves per SIMD
+  long long grid = (long long)cu_count * per_cu;
+  const long long max_grid = ((long long)nwork + 255) / 256;
+  if (!nwork_dev && grid > max_grid) grid = max_grid;
+  if (grid < 1) grid = 1;
+  switch (shape_idx) {
+    case 0: return launch_lane_s0((unsigned)grid, smem, stream, a, slot_words, refill_min);
+    case 1: return launch_lane_s1((unsigned)grid, smem, stream, a, slot_words, refill_min);
+    case 2: return launch_lane_s2((unsigned)grid, smem, stream, a, slot_words, refill_min);
+    case 3: return launch_lane_s3((unsigned)grid, smem, stream, a, slot_words, refill_min);
+    case 4: return launch_lane_s4((unsigned)grid, smem, stream, a, slot_words, refill_min);
+    case 5: return launch_lane_s5((unsigned)grid, smem, stream, a, slot_words, refill_min);
+    case 6: return launch_lane_s6((unsigned)grid, smem, stream, a, slot_words, refill_min);
+    default: return -1;
+  }
+}
+
+}  // namespace wfa

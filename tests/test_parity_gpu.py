@@ -171,7 +171,7 @@ def test_resident_batch_reruns_are_identical(gpu):
     assert [c for c in ref["cigars"]] == outs[0][2]
 
 
-@pytest.mark.parametrize("stages", ["689", "245", "2", "3", "4", "5", "6", "7", "8", "9", "76", "98", "3245"])
+@pytest.mark.parametrize("stages", ["689", "245", "2", "3", "4", "5", "6", "7", "8", "9", "76", "98", "3245", "1", "189", "12", "19"])
 def test_segmented_stages_accept_only_proven_scores(gpu, stages, monkeypatch):
     """The banded segments (wfa_seg.hpp) keep a score only when it is provably the unbanded optimum and hand the
     pair on otherwise: whatever the stage order, the scores must be the reference's.  The batch mixes pairs
