@@ -23,7 +23,7 @@
  * (wavefront_penalties.c:101-112, wavefront_align.c:95-101).  Here every function returns
  * WFA_HIP_OK (0) or a negative WFA_HIP_E* code and wfa_hip_last_error() gives the text.
  * Per-pair results use the reference's own status codes (wfa.h:46-51):
- *   0 completed, 1 partial (heuristically dropped), -100 max steps reached, -200 OOM.
+ *   0 completed, 1 partial (heuristically dropped), -100 max steps reached, -200 OOM, -300 unattainable.
  */
 #ifndef WFA_HIP_H_
 #define WFA_HIP_H_
@@ -55,13 +55,14 @@ extern "C" {
 #define WFA_MEM_HIGH       0   /* wavefront_memory_high (explicit wavefront history)  */
 #define WFA_MEM_MED        1   /* wavefront_memory_med  (same results as high)        */
 #define WFA_MEM_LOW        2   /* wavefront_memory_low  (same results as high)        */
-#define WFA_MEM_BIWFA      3   /* wavefront_memory_ultralow — scope=score without heuristic / free ends / max_steps only */
+#define WFA_MEM_BIWFA      3   /* wavefront_memory_ultralow (BiWFA, wavefront_bialign.c) — without heuristic / free ends / max_steps */
 
 /* per-pair status codes, identical to the reference (wfa.h:46-51) */
 #define WFA_STATUS_COMPLETED          0
 #define WFA_STATUS_PARTIAL            1
 #define WFA_STATUS_MAX_STEPS_REACHED  (-100)
 #define WFA_STATUS_OOM                (-200)
+#define WFA_STATUS_UNATTAINABLE        (-300)  /* BiWFA: no alignment under the configuration (wfa.h:51) */
 
 /* library return codes */
 #define WFA_HIP_OK            0

@@ -428,9 +428,17 @@ static inline void ops_push(ops_t* ops, char c, int n) {
   while (n-- > 0) ops->buf[--ops->begin] = (uint8_t)c;
 }
 
-/* R/wavefront_backtrace.c:320-529 (wavefront_backtrace_affine), M→M components */
+/* R/wavefront_backtrace.c:320-529 (wavefront_backtrace_affine); comp_begin / comp_end (0=M 1=I1 2=D1 3=I2 4=D2) are M
+ * for an ordinary alignment, another component for the halves of a BiWFA split (R/wavefront_bialign.c:581-658) */
+static void backtrace_c(oracle_ws_t* ws, int plen, int tlen, int end_s, int end_k, int32_t end_off,
+                        ops_t* ops, int comp_begin, int comp_end);
 static void backtrace(oracle_ws_t* ws, int plen, int tlen, int end_s, int end_k, int32_t end_off,
                       ops_t* ops) {
+  backtrace_c(ws, plen, tlen, end_s, end_k, end_off, ops, 0, 0);
+}
+static void backtrace_c(oracle_ws_t* ws, int plen, int tlen, int end_s, int end_k, int32_t end_off,
+                        ops_t* ops, int comp_begin, int comp_end) {
+  (void)comp_begin;
   enum { BT_I1_OPEN = 1, BT_I1_EXT, BT_I2_OPEN, BT_I2_EXT, BT_D1_OPEN, BT_D1_EXT, BT_D2_OPEN,
          BT_D2_EXT, BT_M };
   const int two = (ws->ncomp == 5);
@@ -463,12 +471,14 @@ static void backtrace(oracle_ws_t* ws, int plen, int tlen, int end_s, int end_k,
     ops_push(ops, 'I', h > 0 ? h : 0);
     return;
   }
-  int comp = 0; /* 0=M 1=I1 2=D1 3=I2 4=D2 */
+  int comp = comp_end; /* 0=M 1=I1 2=D1 3=I2 4=D2 */
   int s = end_s, k = end_k;
   int32_t offset = end_off;
   int h = offset, v = offset - k;
-  if (v < plen) ops_push(ops, 'D', plen - v);
-  if (h < tlen) ops_push(ops, 'I', tlen - h);
+  if (comp_end == 0) { /* R/wavefront_backtrace.c:346-355 */
+    if (v < plen) ops_push(ops, 'D', plen - v);
+    if (h < tlen) ops_push(ops, 'I', tlen - h);
+  }
   while (v > 0 && h > 0 && s > 0) {
     const int s_x = s - ws->x;
     const int s_o1 = s - ws->o1 - ws->e1, s_e1 = s - ws->e1;
@@ -682,6 +692,361 @@ static int align_one(oracle_ws_t* ws, const wfa_hip_config_t* cfg, const uint8_t
   return 0;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * BiWFA (memory_mode "biwfa" = wavefront_memory_ultralow), scope=full: R/wavefront_bialign.c.
+ * Two score-only aligners walk towards each other (forward on the sequences, reverse on the reversed
+ * sequences), the first overlap of their wavefronts gives a breakpoint (R/wavefront_bialign.c:189-395), the
+ * two halves are aligned recursively with the breakpoint's component as end / begin component, and a half
+ * whose score is <= 250 is aligned by the ordinary algorithm (R/wavefront_bialign.c:155-188, 581-607).
+ * ------------------------------------------------------------------------------------------------ */
+#define BI_FALLBACK_MIN_SCORE 250  /* R/wavefront_bialign.c:48 */
+#define BI_FALLBACK_MIN_LENGTH 100 /* :49 */
+#define BI_RECOVERY_MIN_SCORE 500  /* :50 */
+/* internal status values (R/wfa.h:52-55) */
+#define BI_OK (-1)
+#define BI_END_REACHED (-2)
+#define BI_END_UNREACHABLE (-3)
+
+/* a window of the two sequences, read forwards or backwards (R/wavefront_sequences.c:275-310) */
+typedef struct {
+  const uint8_t* P; const uint8_t* T;
+  int pbeg, pend, tbeg, tend;
+  int reverse;
+  int wc; /* wildcard byte or -1 */
+} bi_view_t;
+
+static inline int bi_match(const bi_view_t* w, int v, int h) {
+  const uint8_t pc = w->reverse ? w->P[w->pend - 1 - v] : w->P[w->pbeg + v];
+  const uint8_t tc = w->reverse ? w->T[w->tend - 1 - h] : w->T[w->tbeg + h];
+  return pc == tc || (w->wc >= 0 && (pc == w->wc || tc == w->wc));
+}
+
+/* one unidirectional aligner (forward, reverse or base) */
+typedef struct {
+  oracle_ws_t ws;
+  bi_view_t view;
+  int plen, tlen;
+  int comp_begin, comp_end;
+  int null_steps;
+  int status;       /* BI_OK while running, BI_END_REACHED, BI_END_UNREACHABLE */
+  int status_score; /* align_status.score */
+  int end_k; int32_t end_off;
+} bi_uni_t;
+
+/* R/wavefront_aligner.c:251-417 with a begin component (:329-390): wavefront 0 is the cell (k=0, offset 0) of that component */
+static int bi_uni_init(bi_uni_t* u, const bi_view_t* view, int comp_begin, int comp_end, int modular) {
+  oracle_ws_t* ws = &u->ws;
+  u->view = *view;
+  u->plen = view->pend - view->pbeg;
+  u->tlen = view->tend - view->tbeg;
+  u->comp_begin = comp_begin; u->comp_end = comp_end;
+  u->null_steps = 0; u->status = BI_OK; u->status_score = 0; u->end_k = 0; u->end_off = OFFSET_NULL;
+  ws->modular = modular;
+  ws->arena_used = 0;
+  if (modular) {
+    ws->slot_stride = (int64_t)u->plen + u->tlen + 8;
+    if (ws_reserve_scores(ws, ws->scope)) return -1;
+    if (ws_reserve_arena(ws, ws->slot_stride * 5 * ws->scope)) return -1;
+    int c, i;
+    for (c = 0; c < 5; ++c) for (i = 0; i < ws->scope; ++i) ws->wf[c][i].exists = 0;
+  } else {
+    if (ws_reserve_scores(ws, 64)) return -1;
+    int c;
+    for (c = 0; c < 5; ++c) ws->wf[c][0].exists = 0;
+  }
+  if (wf_alloc(ws, comp_begin, 0, 0, 0)) return -1;
+  ws->arena[ws->wf[comp_begin][0].idx] = 0;
+  return 0;
+}
+
+/* R/wavefront_termination.c:37-113 (end2end, any end component).  Only reached when M[s] exists
+ * (R/wavefront_extend.c:90-125: the test sits behind the `mwavefront == NULL` return). */
+static int bi_terminated(bi_uni_t* u, int s) {
+  const wf_t* w = wf_slot(&u->ws, u->comp_end, s);
+  const int ak = u->tlen - u->plen;
+  if (!w->exists || w->lo > ak || ak > w->hi) return 0;
+  if (u->ws.arena[w->idx + (ak - w->base)] < u->tlen) return 0;
+  u->end_k = ak; u->end_off = u->tlen;
+  return 1;
+}
+
+/* R/wavefront_extend.c:90-125 / :178-214 (wavefront_extend_end2end[_max]): extend M[s], test the end, no heuristic here.
+ * Returns 1 when the aligner is done (status set).  *max_ak (nullable) = largest antidiagonal 2*offset - k reached. */
+static int bi_extend(bi_uni_t* u, int s, int* max_ak) {
+  oracle_ws_t* ws = &u->ws;
+  wf_t* m = wf_slot(ws, 0, s);
+  if (max_ak) *max_ak = 0;
+  if (!m->exists) {
+    if (u->null_steps > ws->scope) { u->status = BI_END_UNREACHABLE; u->status_score = s; return 1; }
+    return 0;
+  }
+  int32_t* off = ws->arena + m->idx;
+  int k, best = 0;
+  for (k = m->lo; k <= m->hi; ++k) {
+    int32_t o = off[k - m->base];
+    if (o == OFFSET_NULL) continue;
+    int v = o - k, h = o;
+    while (v < u->plen && h < u->tlen && bi_match(&u->view, v, h)) { ++v; ++h; }
+    off[k - m->base] = h;
+    const int ad = 2 * h - k;
+    if (best < ad) best = ad;
+  }
+  if (bi_terminated(u, s)) { u->status = BI_END_REACHED; u->status_score = s; return 1; }
+  if (max_ak) *max_ak = best;
+  return 0;
+}
+
+static int bi_compute(bi_uni_t* u, int s) {
+  int err = 0;
+  if (!u->ws.modular && ws_reserve_scores(&u->ws, (int64_t)s + 1)) return -1;
+  if (compute_next(&u->ws, s, u->plen, u->tlen, &err)) ++u->null_steps; else u->null_steps = 0;
+  return err ? -1 : 0;
+}
+
+typedef struct {
+  int score, score_forward, score_reverse;
+  int k_forward, k_reverse;
+  int32_t offset_forward, offset_reverse;
+  int component;
+} bi_breakpoint_t;
+
+/* R/wavefront_bialign.c:189-252 (indel2indel) and :253-311 (m2m): wavefront `c` of aligner 0 at score_0 against the same
+ * component of aligner 1 at score_1; the first diagonal (ascending k of aligner 0) where the two offsets meet wins */
+static void bi_breakpoint_cc(const bi_uni_t* u0, const bi_uni_t* u1, int forward, int score_0, int score_1,
+                             const wf_t* w0, const wf_t* w1, int c, bi_breakpoint_t* bp) {
+  const int plen = u0->plen, tlen = u0->tlen;
+  const int gap_open = (c == 0) ? 0 : ((c == 1 || c == 2) ? u0->ws.o1 : u0->ws.o2);
+  const int lo_0 = w0->lo, hi_0 = w0->hi;
+  const int lo_1 = tlen - plen - w1->hi, hi_1 = tlen - plen - w1->lo; /* WAVEFRONT_K_INVERSE */
+  if (hi_1 < lo_0 || hi_0 < lo_1) return;
+  const int min_hi = MIN2(hi_0, hi_1), max_lo = MAX2(lo_0, lo_1);
+  int k_0;
+  for (k_0 = max_lo; k_0 <= min_hi; ++k_0) {
+    const int k_1 = tlen - plen - k_0;
+    const int32_t o0 = u0->ws.arena[w0->idx + (k_0 - w0->base)];
+    const int32_t o1 = u1->ws.arena[w1->idx + (k_1 - w1->base)];
+    if ((int64_t)o0 + o1 >= tlen && score_0 + score_1 - gap_open < bp->score) {
+      if (c != 0) { /* out-of-bounds I/D offsets are kept by compute-next: skip them (R/wavefront_bialign.c:222-226,236-240) */
+        const int kk = forward ? k_0 : k_1;
+        const int32_t oo = forward ? o0 : o1;
+        if (oo - kk > plen || oo > tlen) continue;
+      }
+      if (forward) {
+        bp->score_forward = score_0; bp->score_reverse = score_1;
+        bp->k_forward = k_0; bp->k_reverse = k_1; bp->offset_forward = o0; bp->offset_reverse = o1;
+      } else {
+        bp->score_forward = score_1; bp->score_reverse = score_0;
+        bp->k_forward = k_1; bp->k_reverse = k_0; bp->offset_forward = o1; bp->offset_reverse = o0;
+      }
+      bp->score = score_0 + score_1 - gap_open;
+      bp->component = c;
+      return;
+    }
+  }
+}
+
+/* R/wavefront_bialign.c:315-395 (wavefront_bialign_overlap) */
+static void bi_overlap(const bi_uni_t* u0, const bi_uni_t* u1, int score_0, int score_1, int forward, bi_breakpoint_t* bp) {
+  const oracle_ws_t* ws0 = &u0->ws;
+  const oracle_ws_t* ws1 = &u1->ws;
+  const int scope = ws0->scope;
+  const wf_t* m0 = &ws0->wf[0][score_0 % scope];
+  if (!m0->exists) return;
+  int i;
+  for (i = 0; i < scope; ++i) {
+    const int score_i = score_1 - i;
+    if (score_i < 0) break;
+    const int mod_i = score_i % scope, mod_0 = score_0 % scope;
+    if (ws0->ncomp == 5) {
+      if (score_0 + score_i - ws0->o2 >= bp->score) continue;
+      if (ws0->wf[4][mod_0].exists && ws1->wf[4][mod_i].exists)
+        bi_breakpoint_cc(u0, u1, forward, score_0, score_i, &ws0->wf[4][mod_0], &ws1->wf[4][mod_i], 4, bp);
+      if (ws0->wf[3][mod_0].exists && ws1->wf[3][mod_i].exists)
+        bi_breakpoint_cc(u0, u1, forward, score_0, score_i, &ws0->wf[3][mod_0], &ws1->wf[3][mod_i], 3, bp);
+    }
+    if (ws0->ncomp >= 3) {
+      if (score_0 + score_i - ws0->o1 >= bp->score) continue;
+      if (ws0->wf[2][mod_0].exists && ws1->wf[2][mod_i].exists)
+        bi_breakpoint_cc(u0, u1, forward, score_0, score_i, &ws0->wf[2][mod_0], &ws1->wf[2][mod_i], 2, bp);
+      if (ws0->wf[1][mod_0].exists && ws1->wf[1][mod_i].exists)
+        bi_breakpoint_cc(u0, u1, forward, score_0, score_i, &ws0->wf[1][mod_0], &ws1->wf[1][mod_i], 1, bp);
+    }
+    if (score_0 + score_i >= bp->score) continue;
+    if (ws1->wf[0][mod_i].exists)
+      bi_breakpoint_cc(u0, u1, forward, score_0, score_i, m0, &ws1->wf[0][mod_i], 0, bp);
+  }
+}
+
+typedef struct {
+  bi_uni_t fwd, rev, base;
+  const uint8_t* P; const uint8_t* T;
+  int wc;
+  int64_t max_steps;
+  uint8_t* ops; /* appended forwards (R/alignment/cigar.c:125-136) */
+  int64_t ops_len;
+} bi_ctx_t;
+
+/* R/wavefront_bialign.c:411-519 (wavefront_bialign_find_breakpoint); returns BI_OK, another BI_* status,
+ * WFA_STATUS_MAX_STEPS_REACHED, or WFA_STATUS_OOM for an allocation failure */
+static int bi_find_breakpoint(bi_ctx_t* cx, int pbeg, int pend, int tbeg, int tend, int comp_begin, int comp_end,
+                              bi_breakpoint_t* bp) {
+  bi_uni_t* f = &cx->fwd;
+  bi_uni_t* r = &cx->rev;
+  bi_view_t view = {cx->P, cx->T, pbeg, pend, tbeg, tend, 0, cx->wc};
+  if (bi_uni_init(f, &view, comp_begin, comp_end, 1)) return WFA_STATUS_OOM;
+  view.reverse = 1;
+  if (bi_uni_init(r, &view, comp_end, comp_begin, 1)) return WFA_STATUS_OOM;
+  const int plen = pend - pbeg, tlen = tend - tbeg;
+  const int max_antidiagonal = plen + tlen - 1;
+  int score_f = 0, score_r = 0, f_max_ak = 0, r_max_ak = 0, max_ak = 0;
+  bp->score = INT_MAX;
+  if (bi_extend(f, 0, &f_max_ak)) return f->status;
+  if (bi_extend(r, 0, &r_max_ak)) return r->status;
+  int last_forward = 0;
+  for (;;) {
+    if (f_max_ak + r_max_ak >= max_antidiagonal) break;
+    ++score_f;
+    if (bi_compute(f, score_f)) return WFA_STATUS_OOM;
+    const int qf = bi_extend(f, score_f, &max_ak);
+    if (f_max_ak < max_ak) f_max_ak = max_ak;
+    last_forward = 1;
+    if (qf) return f->status;
+    if (f_max_ak + r_max_ak >= max_antidiagonal) break;
+    ++score_r;
+    if (bi_compute(r, score_r)) return WFA_STATUS_OOM;
+    const int qr = bi_extend(r, score_r, &max_ak);
+    if (r_max_ak < max_ak) r_max_ak = max_ak;
+    last_forward = 0;
+    if (qr) return r->status;
+    if ((int64_t)score_r + score_f >= cx->max_steps) return WFA_STATUS_MAX_STEPS_REACHED;
+  }
+  const int scope = f->ws.scope;
+  const int gap_opening = (f->ws.ncomp == 3) ? f->ws.o1 : (f->ws.ncomp == 5) ? MAX2(f->ws.o1, f->ws.o2) : 0;
+  for (;;) {
+    if (last_forward) {
+      const int min_score_reverse = (score_r > scope - 1) ? score_r - (scope - 1) : 0;
+      if (score_f + min_score_reverse - gap_opening >= bp->score) break;
+      bi_overlap(f, r, score_f, score_r, 1, bp);
+      ++score_r;
+      if (bi_compute(r, score_r)) return WFA_STATUS_OOM;
+      if (bi_extend(r, score_r, NULL)) return r->status;
+    }
+    const int min_score_forward = (score_f > scope - 1) ? score_f - (scope - 1) : 0;
+    if (min_score_forward + score_r - gap_opening >= bp->score) break;
+    bi_overlap(r, f, score_r, score_f, 0, bp);
+    ++score_f;
+    if (bi_compute(f, score_f)) return WFA_STATUS_OOM;
+    if (bi_extend(f, score_f, NULL)) return f->status;
+    if ((int64_t)score_r + score_f >= cx->max_steps) return WFA_STATUS_MAX_STEPS_REACHED;
+    last_forward = 1;
+  }
+  return BI_OK;
+}
+
+/* R/wavefront_bialign.c:155-188 (wavefront_bialign_base): the ordinary algorithm on the window, full history, no
+ * heuristic, begin / end component as given; the op string is appended.  `endsfree`: the extension / termination form
+ * (R/wavefront_unialign.c:84-88: only the top-level call passes pywfa's ends-free span, with all free ends 0). */
+static int bi_base(bi_ctx_t* cx, int pbeg, int pend, int tbeg, int tend, int comp_begin, int comp_end, int endsfree) {
+  bi_uni_t* u = &cx->base;
+  bi_view_t view = {cx->P, cx->T, pbeg, pend, tbeg, tend, 0, cx->wc};
+  if (bi_uni_init(u, &view, comp_begin, comp_end, 0)) return WFA_STATUS_OOM;
+  int s = 0, finished = 0;
+  for (;;) {
+    if (endsfree) {
+      /* R/wavefront_extend.c:263-297 with R/wavefront_termination.c:115-162, free ends 0: M only */
+      wf_t* m = wf_slot(&u->ws, 0, s);
+      if (!m->exists) {
+        if (u->null_steps > u->ws.scope) { u->status = BI_END_UNREACHABLE; finished = 1; }
+      } else {
+        int32_t* off = u->ws.arena + m->idx;
+        int k;
+        for (k = m->lo; k <= m->hi && !finished; ++k) {
+          int32_t o = off[k - m->base];
+          if (o == OFFSET_NULL) continue;
+          int v = o - k, h = o;
+          while (v < u->plen && h < u->tlen && bi_match(&u->view, v, h)) { ++v; ++h; }
+          off[k - m->base] = h;
+          if ((h >= u->tlen && u->plen - v <= 0) || (v >= u->plen && u->tlen - h <= 0)) {
+            u->status = BI_END_REACHED; u->end_k = k; u->end_off = h; finished = 1;
+          }
+        }
+      }
+    } else {
+      finished = bi_extend(u, s, NULL);
+    }
+    if (finished) break;
+    ++s;
+    if (bi_compute(u, s)) return WFA_STATUS_OOM;
+    if (s >= cx->max_steps) return WFA_STATUS_UNATTAINABLE; /* base status MAX_STEPS != COMPLETED (R/wavefront_bialign.c:182-187) */
+  }
+  if (u->status != BI_END_REACHED) return WFA_STATUS_UNATTAINABLE;
+  /* backtrace into a scratch buffer (right to left), then append forwards */
+  const int64_t cap = (int64_t)u->plen + u->tlen;
+  uint8_t* tmp = (uint8_t*)malloc((size_t)(cap > 0 ? cap : 1));
+  if (!tmp) return WFA_STATUS_OOM;
+  ops_t ops;
+  ops.buf = tmp; ops.end = cap; ops.begin = cap;
+  backtrace_c(&u->ws, u->plen, u->tlen, s, u->end_k, u->end_off, &ops, comp_begin, comp_end);
+  memcpy(cx->ops + cx->ops_len, tmp + ops.begin, (size_t)(ops.end - ops.begin));
+  cx->ops_len += ops.end - ops.begin;
+  free(tmp);
+  return BI_OK;
+}
+
+/* R/wavefront_bialign.c:581-658 (wavefront_bialign_alignment); *bp_score receives the breakpoint's score at this level */
+static int bi_alignment(bi_ctx_t* cx, int pbeg, int pend, int tbeg, int tend, int comp_begin, int comp_end,
+                        int score_remaining, int level, int endsfree_form, int* bp_score) {
+  const int plen = pend - pbeg, tlen = tend - tbeg;
+  if (tlen == 0) { memset(cx->ops + cx->ops_len, 'D', (size_t)plen); cx->ops_len += plen; return BI_OK; }
+  if (plen == 0) { memset(cx->ops + cx->ops_len, 'I', (size_t)tlen); cx->ops_len += tlen; return BI_OK; }
+  if (score_remaining <= BI_FALLBACK_MIN_SCORE) return bi_base(cx, pbeg, pend, tbeg, tend, comp_begin, comp_end, endsfree_form);
+  bi_breakpoint_t bp;
+  int st = bi_find_breakpoint(cx, pbeg, pend, tbeg, tend, comp_begin, comp_end, &bp);
+  if (st != BI_OK) {
+    /* R/wavefront_bialign.c:520-548 (wavefront_bialign_find_breakpoint_exception) */
+    if (st == BI_END_REACHED) {
+      const int reached = (cx->fwd.status == BI_END_REACHED) ? cx->fwd.status_score : cx->rev.status_score;
+      if (reached <= BI_RECOVERY_MIN_SCORE) return bi_base(cx, pbeg, pend, tbeg, tend, comp_begin, comp_end, endsfree_form);
+      return BI_END_UNREACHABLE;
+    }
+    return st;
+  }
+  const int bh = bp.offset_forward, bv = bp.offset_forward - bp.k_forward;
+  st = bi_alignment(cx, pbeg, pbeg + bv, tbeg, tbeg + bh, comp_begin, bp.component, bp.score_forward, level + 1, 0, NULL);
+  if (st != BI_OK) return st;
+  st = bi_alignment(cx, pbeg + bv, pend, tbeg + bh, tend, bp.component, comp_end, bp.score_reverse, level + 1, 0, NULL);
+  if (st != BI_OK) return st;
+  if (bp_score) *bp_score = bp.score;
+  return BI_OK;
+}
+
+/* R/wavefront_bialign.c:703-730 (wavefront_bialign, scope=full) for one pair.  Quirk reproduced (SURVEY.md Appendix B,
+ * Q6): cigar->score is written only after a level-0 split (:651-656); when the top level is answered by the ordinary
+ * algorithm (both sequences <= 100 bases, or one direction reaches the end before the wavefronts overlap) the score
+ * stays at cigar_clear's INT32_MIN although the status is 0 and the op string is right. */
+static int bi_align_one(bi_ctx_t* cx, const wfa_hip_config_t* cfg, const uint8_t* P, int plen, const uint8_t* T, int tlen,
+                        int32_t* out_score, int32_t* out_status, uint8_t* ops_buf, int64_t* ops_begin, int32_t* ops_len) {
+  cx->P = P; cx->T = T;
+  cx->ops = ops_buf; cx->ops_len = 0;
+  const int min_length = MAX2(plen, tlen) <= BI_FALLBACK_MIN_LENGTH;
+  int bp_score = INT_MIN, have_bp = 0;
+  int tmp_score = INT_MIN;
+  int st = bi_alignment(cx, 0, plen, 0, tlen, 0, 0, min_length ? 0 : INT_MAX, 0, cfg->span == WFA_SPAN_ENDSFREE, &tmp_score);
+  if (st == BI_OK && tmp_score != INT_MIN) { bp_score = tmp_score; have_bp = 1; }
+  *ops_begin = 0;
+  *ops_len = (int32_t)cx->ops_len;
+  if (st == BI_OK) {
+    *out_status = WFA_STATUS_COMPLETED;
+    *out_score = have_bp ? classic_score(&cx->fwd.ws, plen, tlen, bp_score) : INT32_MIN;
+  } else if (st == WFA_STATUS_MAX_STEPS_REACHED || st == WFA_STATUS_OOM) {
+    *out_status = st; *out_score = INT32_MIN;
+  } else {
+    *out_status = -300; /* WF_STATUS_UNATTAINABLE */
+    *out_score = INT32_MIN;
+  }
+  return (st == WFA_STATUS_OOM) ? -1 : 0;
+}
+
 /* R/wavefront_penalties.c:95-173 */
 static int ws_set_penalties(oracle_ws_t* ws, const wfa_hip_config_t* cfg) {
   ws->metric = cfg->distance;
@@ -749,13 +1114,23 @@ int wfa_oracle_align_batch(const wfa_hip_config_t* cfg, int64_t n, const uint8_t
    * ("next"): not restated here */
   if (cfg->match < 0 && cfg->span == WFA_SPAN_ENDSFREE &&
       (cfg->pattern_begin_free > 0 || cfg->text_begin_free > 0)) return -1;
-  /* BiWFA (R/wavefront_bialign.c): only the subset in which the reference returns what the other memory modes return
-   * (score scope, no heuristic, no free ends, no step limit: wavefront_bialign_compute_score, :662-702); the
-   * breakpoint recursion of the full-CIGAR form is not restated ("next"). */
+  /* BiWFA (R/wavefront_bialign.c): without heuristic, free ends (the reference exit(1)s, R/wavefront_align.c:60-75) or a
+   * step limit.  scope=score: wavefront_bialign_compute_score (:662-702) returns what the other memory modes return
+   * (pinned by tests/test_oracle_vs_ref.py); scope=full: the breakpoint recursion restated above. */
+  int biwfa_full = 0;
+  bi_ctx_t* bcx = NULL;
   if (cfg->memory_mode == WFA_MEM_BIWFA) {
     const int free_ends = cfg->span == WFA_SPAN_ENDSFREE &&
         (cfg->pattern_begin_free | cfg->pattern_end_free | cfg->text_begin_free | cfg->text_end_free) != 0;
-    if (cfg->scope != WFA_SCOPE_SCORE || cfg->heuristic != WFA_HEUR_NONE || free_ends || cfg->max_steps > 0) return -1;
+    if (cfg->heuristic != WFA_HEUR_NONE || free_ends || cfg->max_steps > 0) return -1;
+    if (cfg->scope == WFA_SCOPE_FULL) {
+      biwfa_full = 1;
+      bcx = (bi_ctx_t*)calloc(1, sizeof(bi_ctx_t));
+      if (!bcx) return -2;
+      if (ws_set_penalties(&bcx->fwd.ws, cfg) || ws_set_penalties(&bcx->rev.ws, cfg) || ws_set_penalties(&bcx->base.ws, cfg)) { free(bcx); return -1; }
+      bcx->wc = cfg->wildcard;
+      bcx->max_steps = INT_MAX;
+    }
   }
   const int full = (cfg->scope == WFA_SCOPE_FULL);
   if (full && (!cigar_ops || !cigar_off || !cigar_begin || !cigar_len)) return -1;
@@ -769,14 +1144,17 @@ int wfa_oracle_align_batch(const wfa_hip_config_t* cfg, int64_t n, const uint8_t
     int64_t ob = 0;
     int32_t ol = 0;
     int32_t sc = 0, st = 0;
-    if (align_one(&ws, cfg, seqs + p_off[i], plen, seqs + t_off[i], tlen, &sc, &st,
-                  full ? cigar_ops + cigar_off[i] : NULL, &ob, &ol)) { rc = -2; break; }
+    if (biwfa_full) {
+      if (bi_align_one(bcx, cfg, seqs + p_off[i], plen, seqs + t_off[i], tlen, &sc, &st, cigar_ops + cigar_off[i], &ob, &ol)) { rc = -2; break; }
+    } else if (align_one(&ws, cfg, seqs + p_off[i], plen, seqs + t_off[i], tlen, &sc, &st,
+                         full ? cigar_ops + cigar_off[i] : NULL, &ob, &ol)) { rc = -2; break; }
     score[i] = sc;
     status[i] = st;
     if (cigar_begin) cigar_begin[i] = (full && cigar_off) ? cigar_off[i] + ob : 0;
     if (cigar_len) cigar_len[i] = ol;
   }
   ws_free(&ws);
+  if (bcx) { ws_free(&bcx->fwd.ws); ws_free(&bcx->rev.ws); ws_free(&bcx->base.ws); free(bcx); }
   return rc;
 }
 
