@@ -22,8 +22,9 @@ for i in 0 1 2 3 5; do run $HIPCC $FLAGS -DWFA_TU_INDEX=$i -c k_band.hip -o $OBJ
 for i in 0 1 2 3 4 5 6; do run $HIPCC $FLAGS -DWFA_TU_INDEX=$i -c k_seg.hip -o $OBJ/k_seg_$i.o; done
 for i in 0 1 2; do run $HIPCC $FLAGS -DWFA_TU_INDEX=$i -c k_general.hip -o $OBJ/k_general_$i.o; done
 for i in 0 1 2 3 4 5 6; do run $HIPCC $FLAGS -DWFA_TU_INDEX=$i -c k_lane.hip -o $OBJ/k_lane_$i.o; done
+for i in 0 1 2; do run $HIPCC $FLAGS -DWFA_TU_INDEX=$i -c k_biwfa.hip -o $OBJ/k_biwfa_$i.o; done
 for f in k_*.hip; do
-  case $f in k_band.hip|k_seg.hip|k_general.hip|k_lane.hip) ;; *) run $HIPCC $FLAGS -c $f -o $OBJ/${f%.hip}.o ;; esac
+  case $f in k_band.hip|k_seg.hip|k_general.hip|k_lane.hip|k_biwfa.hip) ;; *) run $HIPCC $FLAGS -c $f -o $OBJ/${f%.hip}.o ;; esac
 done
 run $HIPCC $FLAGS -c wfa_hip.hip -o $OBJ/wfa_hip.o
 fail=0

@@ -26,6 +26,7 @@
 #include "wfa_seg.hpp"
 #include "wfa_lane.hpp"
 #include "wfa_band.hpp"
+#include "wfa_biwfa.hpp"
 #include "wfa_rle.hpp"
 
 #define WFA_HIP_ABI_VERSION 1
@@ -256,14 +257,15 @@ extern "C" int wfa_hip_config_validate(const wfa_hip_config_t* c, char* err, siz
   if (c->heuristic < WFA_HEUR_NONE || c->heuristic > WFA_HEUR_XDROP) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "unknown heuristic");
   if (c->memory_mode < WFA_MEM_HIGH || c->memory_mode > WFA_MEM_BIWFA) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "unknown memory_mode");
   if (c->memory_mode == WFA_MEM_BIWFA) {
-    // wavefront_bialign_compute_score (R/wavefront_bialign.c:662-702) returns the score of the optimal alignment: with
-    // scope=score, no heuristic, no free ends and no step limit the reference's outputs are those of the other memory
-    // modes (checked on every metric against the real library, tests/test_*_vs_ref.py), and the score-only kernels keep O(s) state
-    // already.  Full CIGARs need the breakpoint recursion (tie-breaks differ): not built.
+    // BiWFA (R/wavefront_bialign.c).  scope=score: wavefront_bialign_compute_score (:662-702) returns the score of the optimal
+    // alignment, which is what the other memory modes return (checked on every metric against the real library,
+    // tests/test_oracle_vs_ref.py), and the score-only kernels hold O(s) state already.  scope=full: the breakpoint
+    // recursion on the device (csrc/wfa_biwfa.hpp).  Not built: BiWFA with a heuristic or a step limit (the reference runs
+    // the cut-off inside both directions), and with free ends (the reference itself exit(1)s, R/wavefront_align.c:60-75).
     const bool free_ends = c->span == WFA_SPAN_ENDSFREE &&
                            (c->pattern_begin_free | c->pattern_end_free | c->text_begin_free | c->text_end_free) != 0;
-    if (c->scope != WFA_SCOPE_SCORE || c->heuristic != WFA_HEUR_NONE || free_ends || c->max_steps > 0)
-      return fail_cfg(err, errlen, WFA_HIP_ENOTSUP, "memory_mode biwfa is on the accelerated path for scope=score without heuristic, free ends or max_steps only");
+    if (c->heuristic != WFA_HEUR_NONE || free_ends || c->max_steps > 0)
+      return fail_cfg(err, errlen, WFA_HIP_ENOTSUP, "memory_mode biwfa is on the accelerated path without heuristic, free ends or max_steps only");
   }
   if (c->pattern_begin_free < 0 || c->pattern_end_free < 0 || c->text_begin_free < 0 || c->text_end_free < 0)
     return fail_cfg(err, errlen, WFA_HIP_EINVAL, "ends-free sizes must be >= 0");
@@ -690,6 +692,39 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
   hipEvent_t ev0 = b->ev[b->ev_used], ev1 = b->ev[b->ev_used + 1];
   b->ev_used += 2; b->runs_pending += 1;
   HIP_TRY(al, hipEventRecord(ev0, stream));
+  if (full && b->cfg.memory_mode == WFA_MEM_BIWFA) {
+    // BiWFA: one wave per alignment; a workgroup's slice of the workspace = forward ring + reverse ring + base-case history
+    wfa::BiwfaArgs ba;
+    memset(&ba, 0, sizeof(ba));
+    ba.ring_stride = b->max_width;
+    ba.ring_ints = ((int64_t)b->dcfg.scope * b->ncomp * ba.ring_stride + 63) & ~63ll;
+    ba.base_stride = wfa::biwfa_base_stride(b->max_width);
+    ba.base_ints = (wfa::biwfa_base_ints(b->ncomp, ba.base_stride) + 63) & ~63ll;
+    const int64_t stride = 2 * ba.ring_ints + ba.base_ints;
+    int64_t grid = std::min<int64_t>((int64_t)al->cu_count * knob(al, K_WAVES_PER_CU, 32), std::max<int64_t>(b->n, 1));
+    const int64_t budget = free_budget(al);
+    while (grid > 1 && grid * stride * 4 > budget) grid = (grid + 1) / 2;
+    int rc = ensure_ws(al, (size_t)grid * stride * 4);
+    if (rc != WFA_HIP_OK) return rc;
+    WfaKernelArgs& a = ba.k;
+    a.words = b->d_words; a.bytes = b->d_bytes; a.meta = b->d_meta; a.p_boff = b->d_pboff; a.t_boff = b->d_tboff;
+    a.score = b->d_score; a.status = b->d_status;
+    a.cigar_ops = b->d_ops; a.cigar_off = b->d_cigar_off; a.cigar_begin = b->d_cigar_begin; a.cigar_len = b->d_cigar_len;
+    a.ws = al->ws; a.ws_stride = stride; a.cfg = b->dcfg;
+    if (b->n_packed > 0) {
+      a.worklist = b->d_list_packed; a.nwork_dev = nullptr; a.nwork = b->n_packed;
+      if (wfa::launch_biwfa_any(b->ncomp, true, ba, (int)std::min<int64_t>(grid, b->n_packed), stream) != 0) { al->err = "BiWFA kernel launch failed"; return WFA_HIP_EDEVICE; }
+    }
+    if (b->n_bytes > 0) {
+      a.worklist = b->d_list_bytes; a.nwork_dev = nullptr; a.nwork = b->n_bytes;
+      if (wfa::launch_biwfa_any(b->ncomp, false, ba, (int)std::min<int64_t>(grid, b->n_bytes), stream) != 0) { al->err = "BiWFA kernel launch failed"; return WFA_HIP_EDEVICE; }
+    }
+    b->last_kernel_pairs = b->n;
+    HIP_TRY(al, hipEventRecord(ev1, stream));
+    HIP_TRY(al, hipEventRecord(al->ws_event, stream));
+    al->ws_event_recorded = true; al->ws_last_stream = stream;
+    return WFA_HIP_OK;
+  }
   if (b->n_packed > 0) {
     const uint32_t* in_list = b->d_list_packed;   // nullptr = identity
     const uint32_t* in_count = nullptr;            // nullptr = host count
