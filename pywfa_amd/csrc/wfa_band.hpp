@@ -270,7 +270,6 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
   static_assert(FULL || !SPLIT, "split launches have a history");
   static_assert(SPLIT || !PB, "piggy-back history: split launches only");
   static_assert(FULL || !PB, "piggy-back history only with a history");
-  static_assert(!(PB && OE2 > 0), "piggy-back history: gap-affine only");
   constexpr bool TWO = OE2 > 0;  // gap-affine-2p: second pair of gap components (R/wavefront_compute_affine2p.c:45-106)
   constexpr int E2D = TWO ? E2 : 1;
   typedef Band<NCH> BD;
@@ -324,7 +323,8 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
       // per lane: lim = min(tlen, plen + k) (in-bounds <=> offset <= lim; lim - offset = longest possible run),
       // dlim = max(tlen, plen + k) (dlim - offset = distance to the end, R/wavefront_heuristic.c:176-192)
       int kk[NCH], lim[NCH], dlim[NCH], cur[NCH], Mh[DM][NCH], Ih[E][NCH], Dh[E][NCH], I2h[E2D][NCH], D2h[E2D][NCH], PH[NP][NCH];
-      int code[PB ? NCH : 1];  // piggy-back: origin of M (bits 0-1: 0 mismatch, 1 deletion, 2 insertion), of I (bit 2: extension) and of D (bit 3)
+      int code[PB ? NCH : 1];  // piggy-back: origin of M (bits 0-1: 0 mismatch, 1 deletion, 2 insertion), of I (bit 2: extension) and of D (bit 3);
+                               // 2p: bits 0-2 origin of M (0 mismatch, 1 D1, 2 D2, 3 I1, 4 I2), bit 3 / 4 / 5 / 6: I1 / D1 / I2 / D2 came by extension
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         if (PB) code[c] = 0;
@@ -574,22 +574,31 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
               nd[c] = BD::above(gd, c);
             }
             ni2[c] = WFA_OFFSET_NULL; nd2[c] = WFA_OFFSET_NULL;
+            int mo2_lo = 0, i2e_lo = 0, mo2_hi = 0, d2e_hi = 0;
             if (TWO) {
               constexpr int PD = TWO ? OE2 - 1 - DM : 0;
               const int plo = BD::below(PH[PD / 2], c, -1), phi = BD::above(PH[PD / 2], c, -1);
               const int m2lo = (PD & 1) ? (plo >> 16) : (int)(short)(plo & 0xffff), m2hi = (PD & 1) ? (phi >> 16) : (int)(short)(phi & 0xffff);
-              ni2[c] = max((m2lo < 0) ? WFA_OFFSET_NULL : m2lo, BD::below(I2h[E2D - 1], c)) + 1;
-              nd2[c] = max((m2hi < 0) ? WFA_OFFSET_NULL : m2hi, BD::above(D2h[E2D - 1], c));
+              mo2_lo = (m2lo < 0) ? WFA_OFFSET_NULL : m2lo; mo2_hi = (m2hi < 0) ? WFA_OFFSET_NULL : m2hi;
+              i2e_lo = BD::below(I2h[E2D - 1], c); d2e_hi = BD::above(D2h[E2D - 1], c);
+              ni2[c] = max(mo2_lo, i2e_lo) + 1;
+              nd2[c] = max(mo2_hi, d2e_hi);
             }
             int m = max(max(nd[c], nd2[c]), max(Mh[X - 1][c] + 1, max(ni[c], ni2[c])));
             if (m > lim[c]) m = WFA_OFFSET_NULL;  // only M is clamped; negative values are dead already
             nm[c] = m;
             if (PB) {
-              // the choice the backtrace would make (R/wavefront_backtrace.c:49-59: mismatch > deletion ext > open >
-              // insertion ext > open on equal offsets), taken here where the candidates are in registers
+              // the choice the backtrace would make (R/wavefront_backtrace.c:49-59: mismatch > D2 ext > D2 open > D1 ext >
+              // D1 open > I2 ext > I2 open > I1 ext > I1 open on equal offsets), taken here where the candidates are in registers
               const int x1 = Mh[X - 1][c] + 1;
-              const int mc = (x1 >= max(nd[c], ni[c])) ? 0 : ((nd[c] >= ni[c]) ? 1 : 2);
-              code[c] = mc | ((ie_lo >= mo_lo) ? 4 : 0) | ((de_hi >= mo_hi) ? 8 : 0);
+              if (TWO) {
+                const int best = max(max(nd[c], nd2[c]), max(x1, max(ni[c], ni2[c])));
+                const int mc = (x1 >= best) ? 0 : (nd2[c] >= best) ? 2 : (nd[c] >= best) ? 1 : (ni2[c] >= best) ? 4 : 3;
+                code[c] = mc | ((ie_lo >= mo_lo) ? 8 : 0) | ((de_hi >= mo_hi) ? 16 : 0) | ((i2e_lo >= mo2_lo) ? 32 : 0) | ((d2e_hi >= mo2_hi) ? 64 : 0);
+              } else {
+                const int mc = (x1 >= max(nd[c], ni[c])) ? 0 : ((nd[c] >= ni[c]) ? 1 : 2);
+                code[c] = mc | ((ie_lo >= mo_lo) ? 4 : 0) | ((de_hi >= mo_hi) ? 8 : 0);
+              }
             }
             oob |= __ballot(max(max(ni[c], nd[c]), max(ni2[c], nd2[c])) > lim[c]);
           }
@@ -748,10 +757,23 @@ wfa_band_pb_bt_kernel(const BandArgs a) {
   uint32_t* runs = reinterpret_cast<uint32_t*>(hist + a.pb_code_ints + a.pb_event_ints);
   const int ev_cap = (int)min((long long)INT_MAX, a.pb_event_ints * 4);
   const int dx = a.x / a.g, doe = a.oe / a.g, de = a.e / a.g;
+  const bool two = a.oe2 > 0;
+  const int doe2 = two ? a.oe2 / a.g : 0, de2 = two ? a.e2 / a.g : 0;
   // ---- walk the codes back from the end cell (R/wavefront_backtrace.c:320-529 with the choices made at compute time)
   int si = es.x / a.g, k = es.y, comp = 0, nev = 0;
   while (si > 0 && nev < ev_cap) {
     const int cd = codes[(long long)si * W + (k & (W - 1))];
+    if (two) {
+      // comp: 0 M, 1 I1, 2 D1, 3 I2, 4 D2; an event flagged 0x80 lands in M (a run of matches follows it)
+      const int src = (comp == 0) ? (cd & 7) : (comp == 1) ? 3 : (comp == 2) ? 1 : (comp == 3) ? 4 : 2;  // 0 X, 1 D1, 2 D2, 3 I1, 4 I2
+      const uint8_t flag = (comp == 0) ? 0x80 : 0;
+      if (src == 0) { ev[nev++] = (uint8_t)('X' | 0x80); si -= dx; }
+      else if (src == 1) { ev[nev++] = (uint8_t)('D' | flag); ++k; if (cd & 16) { si -= de; comp = 2; } else { si -= doe; comp = 0; } }
+      else if (src == 2) { ev[nev++] = (uint8_t)('D' | flag); ++k; if (cd & 64) { si -= de2; comp = 4; } else { si -= doe2; comp = 0; } }
+      else if (src == 3) { ev[nev++] = (uint8_t)('I' | flag); --k; if (cd & 8) { si -= de; comp = 1; } else { si -= doe; comp = 0; } }
+      else { ev[nev++] = (uint8_t)('I' | flag); --k; if (cd & 32) { si -= de2; comp = 3; } else { si -= doe2; comp = 0; } }
+      continue;
+    }
     if (comp == 0) {
       const int mc = cd & 3;
       if (mc == 0) { ev[nev++] = (uint8_t)('X' | 0x80); si -= dx; }
@@ -892,6 +914,7 @@ inline int launch_band_bt_impl(const BandArgs& a, int nch, hipStream_t stream) {
   if (a.pb) {
     if (nch == 1) hipLaunchKernelGGL((wfa_band_pb_bt_kernel<1>), dim3(grid), dim3(64), 0, stream, a);
     else if (nch == 2) hipLaunchKernelGGL((wfa_band_pb_bt_kernel<2>), dim3(grid), dim3(64), 0, stream, a);
+    else if (nch == 3) hipLaunchKernelGGL((wfa_band_pb_bt_kernel<3>), dim3(grid), dim3(64), 0, stream, a);
     else hipLaunchKernelGGL((wfa_band_pb_bt_kernel<4>), dim3(grid), dim3(64), 0, stream, a);
   } else if (nch == 1) hipLaunchKernelGGL((wfa_band_bt_kernel<1>), dim3(grid), dim3(64), 0, stream, a);
   else if (nch == 3) hipLaunchKernelGGL((wfa_band_bt_kernel<3>), dim3(grid), dim3(64), 0, stream, a);
@@ -908,10 +931,11 @@ inline int launch_band_bt_impl(const BandArgs& a, int nch, hipStream_t stream) {
 template <int NCH, bool FULL, bool ADAPT, bool PB, bool SPLIT, int X, int OE, int E, int OE2, int E2>
 static int launch_band_k(const BandArgs& a, bool seqlds, long long grid, hipStream_t stream) {
   const size_t smem = seqlds ? (size_t)a.lds_words * 2 * sizeof(uint32_t) : 0;
-  if constexpr (OE2 > 0 && NCH == 3) {
+  // (the piggy-back forms need a few more registers: compiled without the occupancy cap rather than with spills)
+  if constexpr (OE2 > 0 && NCH == 3 && !PB) {
     if (seqlds) hipLaunchKernelGGL((wfa_band_kernel_w4<NCH, FULL, ADAPT, true, PB, SPLIT, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
     else hipLaunchKernelGGL((wfa_band_kernel_w4<NCH, FULL, ADAPT, false, PB, SPLIT, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), 0, stream, a);
-  } else if constexpr (OE2 > 0 && NCH == 4) {
+  } else if constexpr (OE2 > 0 && NCH == 4 && !PB) {
     if (seqlds) hipLaunchKernelGGL((wfa_band_kernel_w3<NCH, FULL, ADAPT, true, PB, SPLIT, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
     else hipLaunchKernelGGL((wfa_band_kernel_w3<NCH, FULL, ADAPT, false, PB, SPLIT, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), 0, stream, a);
   } else {
@@ -922,8 +946,8 @@ static int launch_band_k(const BandArgs& a, bool seqlds, long long grid, hipStre
 }
 template <int NCH, bool FULL, bool ADAPT, int X, int OE, int E, int OE2, int E2>
 static int launch_band_t(const BandArgs& a, bool seqlds, long long grid, hipStream_t stream) {
-  constexpr bool CAN_PB = FULL && OE2 == 0;
-  if (FULL && a.split) {  // history slot per pair, walk in its own kernel; piggy-back history (gap-affine) on request
+  constexpr bool CAN_PB = FULL;
+  if (FULL && a.split) {  // history slot per pair, walk in its own kernel; piggy-back history on request
     if (CAN_PB && a.pb) return launch_band_k<NCH, FULL, ADAPT, CAN_PB, FULL, X, OE, E, OE2, E2>(a, seqlds, grid, stream);
     return launch_band_k<NCH, FULL, ADAPT, false, FULL, X, OE, E, OE2, E2>(a, seqlds, grid, stream);
   }

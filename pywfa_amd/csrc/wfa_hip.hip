@@ -768,7 +768,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     // memory_mode medium / low (the reference's piggy-back backtrace, R/wavefront_backtrace_offload.c): the split stage
     // keeps one byte of origin codes per (step, diagonal) instead of the offsets and re-extends the matches afterwards
     const int pb_env = knob(al, K_BAND_PB, -1);
-    const bool pb_mode = full && b->ncomp == 3 && (pb_env >= 0 ? pb_env != 0 : (b->cfg.memory_mode == WFA_MEM_MED || b->cfg.memory_mode == WFA_MEM_LOW));
+    const bool pb_mode = full && (pb_env >= 0 ? pb_env != 0 : (b->cfg.memory_mode == WFA_MEM_MED || b->cfg.memory_mode == WFA_MEM_LOW));
     int64_t pb_code_ints = 0, pb_event_ints = 0, pb_stride = 0;
     for (int i = 0; i < n_stages; ++i) {
       // 4x more waves than a CU holds at once: waves retire one after the other (oldest-first issue) and the
@@ -789,7 +789,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         if (i == 0 && !use_fast && !use_segfull && b->max_len > 1000 && knob(al, K_BAND_NO_SPLIT, 0) == 0) {
           // split backtrace: one history slot per pair of a launch; take up to 4x the wave count (or all pairs)
           if (pb_mode) {
-            pb_code_ints = ((int64_t)records * (64 * band_nch[i] / 4) + 63) & ~63ll;  // one byte per window position and step
+            pb_code_ints = ((int64_t)records * ((band_nch[i] == 3 ? 256 : 64 * band_nch[i]) / 4) + 63) & ~63ll;  // one byte per window position and step
             pb_event_ints = (((int64_t)records + 3) / 4 + 63) & ~63ll;                 // one byte per edit event (<= one per step)
             pb_stride = pb_code_ints + pb_event_ints + ((2 * (int64_t)records + 8 + 63) & ~63ll);  // + run records
           }

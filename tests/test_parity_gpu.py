@@ -262,6 +262,37 @@ def test_piggyback_history_gives_the_same_cigars(gpu, kw):
         common.assert_same(o, score, status, cigars, batch, f"piggy-back {kw2} L={L}")
 
 
+@pytest.mark.parametrize("kw", [dict(heuristic="adaptive", memory_mode="medium"), dict(span="end-to-end", heuristic="adaptive", memory_mode="low"),
+                                dict(memory_mode="low", span="ends-free", pattern_begin_free=40, pattern_end_free=30, text_begin_free=25,
+                                     text_end_free=35, heuristic="adaptive"),
+                                dict(memory_mode="medium", span="end-to-end")])
+def test_piggyback_history_gap_affine_2p(gpu, kw):
+    """The piggy-back history of the banded kernel for gap-affine-2p: seven bits of origin codes per (step,
+    diagonal) — which of mismatch / D1 / D2 / I1 / I2 made M, and open-or-extend for each of I1, D1, I2, D2 — walked back
+    with the reference's candidate priority (R/wavefront_backtrace.c:49-59).  Inputs with long gaps make the second gap
+    piece win; the exact form (last case) runs 2p wavefronts past the 256-diagonal window into the general kernel."""
+    exact = "heuristic" not in kw
+    shapes = [(300, 1500, 0.06), (24, 3000, 0.08)] if exact else [(500, 1500, 0.06), (200, 4000, 0.08), (100, 10000, 0.08), (300, 2500, 0.01)]
+    for i, (n, L, e) in enumerate(shapes):
+        batch = datagen.generate(n, L, e, 8900 + i)
+        if i == 0:
+            # long gaps: cut 15-60 bases out of every second text
+            rng = np.random.default_rng(5)
+            pats, txts = [], []
+            for j in range(n):
+                p_, t_ = datagen.pair_strings(batch, j)
+                if j % 2 == 0:
+                    a_ = int(rng.integers(100, L - 200)); g_ = int(rng.integers(15, 61))
+                    t_ = t_[:a_] + t_[a_ + g_:]
+                pats.append(p_); txts.append(t_)
+            batch = datagen.from_strings(pats, txts)
+        kw2 = common.clamp_free(dict(kw, distance="affine2p", scope="full"), batch)
+        oc, nc = common.configs_pair(**kw2)
+        o = loader.run(loader.oracle(), oc, batch)
+        score, status, cigars = common.gpu_run(nc, batch, True, i % 2 == 0)
+        common.assert_same(o, score, status, cigars, batch, f"piggy-back 2p {kw2} L={L}")
+
+
 @pytest.mark.parametrize("pen", [(4, 4, 2), (4, 6, 1), (3, 4, 1), (2, 3, 1)])
 def test_banded_kernel_penalty_shapes(gpu, pen):
     """Long reads and full CIGARs under the penalty shapes the banded kernel is instantiated for: exact and wf-adaptive,
