@@ -155,6 +155,35 @@ int wfa_hip_align_batch(wfa_hip_aligner_t* aligner, int64_t n,
                         uint8_t* cigar_ops, const int64_t* cigar_off,
                         int64_t* cigar_begin, int32_t* cigar_len);
 
+/* ---- several devices of one node ------------------------------------------------ */
+
+/*
+ * Pairs are independent, so a batch shards over the GPUs of a node with no exchange step: contiguous shards
+ * balanced by sum(p_len + t_len), one host thread + one aligner + one stream per device, results written into
+ * disjoint slices of the caller's arrays; no collective.  (The reference has no counterpart: it aligns one pair per
+ * call on one CPU thread.)
+ */
+typedef struct wfa_hip_multi wfa_hip_multi_t;
+
+/* The shard planner alone (host only, needs no GPU): shard_begin[nshards + 1], shard s = pairs
+ * [shard_begin[s], shard_begin[s + 1]).  Returns WFA_HIP_OK or WFA_HIP_EINVAL. */
+int wfa_hip_plan_shards(int64_t n, const int32_t* p_len, const int32_t* t_len, int nshards, int64_t* shard_begin);
+
+/* One aligner per entry of devices[] (an ordinal may repeat: several host threads then feed that device).
+ * Returns NULL on error (see wfa_hip_global_error). */
+wfa_hip_multi_t* wfa_hip_multi_create(const wfa_hip_config_t* cfg, const int* devices, int ndevices);
+void wfa_hip_multi_destroy(wfa_hip_multi_t* multi);
+int wfa_hip_multi_set_config(wfa_hip_multi_t* multi, const wfa_hip_config_t* cfg);
+const char* wfa_hip_multi_last_error(const wfa_hip_multi_t* multi);
+/* Same arguments and results as wfa_hip_align_batch; synchronous. */
+int wfa_hip_multi_align_batch(wfa_hip_multi_t* multi, int64_t n,
+                              const uint8_t* seqs,
+                              const int64_t* p_off, const int32_t* p_len,
+                              const int64_t* t_off, const int32_t* t_len,
+                              int32_t* score, int32_t* status,
+                              uint8_t* cigar_ops, const int64_t* cigar_off,
+                              int64_t* cigar_begin, int32_t* cigar_len);
+
 /* ---- HBM-resident batches (what bench.py times; inputs resident before the clock starts) -- */
 
 /* Upload n pairs (same input arrays as above) and 2-bit pack them on the device.

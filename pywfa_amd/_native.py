@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WFA_HIP_LIB") or os.path.join(_HERE, "libwfa_hip.so")  # (WFA_HIP_LIB: development builds)
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, EINVAL, ENOTSUP, EDEVICE = 0, -1, -2, -3
 
@@ -57,6 +57,8 @@ SYMBOLS = [
     "wfa_hip_batch_destroy", "wfa_hip_batch_run", "wfa_hip_batch_sync", "wfa_hip_batch_results",
     "wfa_hip_batch_last_kernel_ms", "wfa_hip_batch_algorithmic_bytes", "wfa_hip_batch_fallback_pairs",
     "wfa_hip_batch_rle_counts", "wfa_hip_batch_rle_runs",
+    "wfa_hip_plan_shards", "wfa_hip_multi_create", "wfa_hip_multi_destroy", "wfa_hip_multi_set_config",
+    "wfa_hip_multi_last_error", "wfa_hip_multi_align_batch",
 ]
 
 
@@ -100,6 +102,15 @@ def lib():
     L.wfa_hip_batch_rle_counts.argtypes = [vp, vp, vp]
     L.wfa_hip_batch_rle_counts.restype = i64
     L.wfa_hip_batch_rle_runs.argtypes = [vp, vp, vp]
+    L.wfa_hip_plan_shards.argtypes = [i64, vp, vp, ctypes.c_int, vp]
+    L.wfa_hip_multi_create.argtypes = [cfgp, vp, ctypes.c_int]
+    L.wfa_hip_multi_create.restype = vp
+    L.wfa_hip_multi_destroy.argtypes = [vp]
+    L.wfa_hip_multi_destroy.restype = None
+    L.wfa_hip_multi_set_config.argtypes = [vp, cfgp]
+    L.wfa_hip_multi_last_error.argtypes = [vp]
+    L.wfa_hip_multi_last_error.restype = ctypes.c_char_p
+    L.wfa_hip_multi_align_batch.argtypes = [vp, i64] + [vp] * 11
     if L.wfa_hip_abi_version() != ABI_VERSION:
         raise NativeError("libwfa_hip.so ABI version mismatch: rebuild it")
     _lib = L
@@ -216,6 +227,78 @@ class Aligner:
 
     def batch(self, batch):
         return ResidentBatch(self, batch)
+
+
+def plan_shards(p_len, t_len, nshards):
+    """wfa_hip_plan_shards: contiguous shards balanced by sum(p_len + t_len). Returns int64[nshards + 1] (host only)."""
+    p_len = np.ascontiguousarray(p_len, dtype=np.int32)
+    t_len = np.ascontiguousarray(t_len, dtype=np.int32)
+    out = np.zeros(nshards + 1, np.int64)
+    rc = lib().wfa_hip_plan_shards(len(p_len), _ptr(p_len), _ptr(t_len), nshards, _ptr(out))
+    if rc != OK:
+        raise ValueError("wfa_hip_plan_shards: invalid arguments")
+    return out
+
+
+class MultiAligner:
+    """One aligner per device of a node (wfa_hip_multi_t): a batch is sharded over them, results land in disjoint
+    slices of one set of arrays."""
+
+    def __init__(self, cfg, devices):
+        L = lib()
+        self.devices = [int(d) for d in devices]
+        arr = (ctypes.c_int * len(self.devices))(*self.devices)
+        self._h = L.wfa_hip_multi_create(ctypes.byref(cfg), arr, len(self.devices))
+        if not self._h:
+            msg = L.wfa_hip_global_error().decode()
+            rc, vmsg = validate(cfg)
+            if rc == EINVAL:
+                raise ValueError(vmsg)
+            if rc == ENOTSUP:
+                raise NotImplementedError(vmsg)
+            raise NativeError(f"wfa_hip_multi_create failed: {msg}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().wfa_hip_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _raise(self, rc, what):
+        msg = lib().wfa_hip_multi_last_error(self._h).decode()
+        if rc == EINVAL:
+            raise ValueError(f"{what}: {msg}")
+        if rc == ENOTSUP:
+            raise NotImplementedError(f"{what}: {msg}")
+        raise NativeError(f"{what}: {msg}")
+
+    def set_config(self, cfg):
+        rc = lib().wfa_hip_multi_set_config(self._h, ctypes.byref(cfg))
+        if rc != OK:
+            self._raise(rc, "wfa_hip_multi_set_config")
+
+    def align_batch(self, batch, want_cigar):
+        seqs, p_off, p_len, t_off, t_len, n = _check_batch(batch)
+        score = np.zeros(n, np.int32)
+        status = np.zeros(n, np.int32)
+        if want_cigar:
+            cigar_off = np.zeros(n + 1, np.int64)
+            np.cumsum(p_len.astype(np.int64) + t_len.astype(np.int64), out=cigar_off[1:])
+            ops = np.zeros(max(int(cigar_off[-1]), 1), np.uint8)
+            cbeg = np.zeros(n, np.int64)
+            clen = np.zeros(n, np.int32)
+        else:
+            cigar_off = ops = cbeg = clen = None
+        rc = lib().wfa_hip_multi_align_batch(self._h, n, _ptr(seqs), _ptr(p_off), _ptr(p_len), _ptr(t_off), _ptr(t_len),
+                                             _ptr(score), _ptr(status), _ptr(ops), _ptr(cigar_off), _ptr(cbeg), _ptr(clen))
+        if rc != OK:
+            self._raise(rc, "wfa_hip_multi_align_batch")
+        return score, status, ((ops, cbeg, clen) if want_cigar else None)
 
 
 class ResidentBatch:

@@ -268,7 +268,7 @@ class WavefrontAligner:
                  span="ends-free", pattern_begin_free=0, pattern_end_free=0, text_begin_free=0,
                  text_end_free=0, heuristic=None, min_wavefront_length=10,
                  max_distance_threshold=50, steps_between_cutoffs=1, xdrop=20, wildcard=None,
-                 max_steps=0, device=0):
+                 max_steps=0, device=0, devices=None):
         self.pattern_len = 0
         self.text_len = 0
         self.alignment_score = 0
@@ -309,6 +309,10 @@ class WavefrontAligner:
         cfg.wildcard = self._bwildcard
         self._cfg = cfg
         self._native = _native.Aligner(cfg, device)  # raises if no library / no GPU / bad config
+        # devices=[...] (additive): batches given to wavefront_align_batch / align_batch are sharded over these GPUs of the
+        # node (contiguous shards balanced by bases, one host thread per device, no collective); single pairs and resident
+        # batches stay on `device`
+        self._multi = _native.MultiAligner(cfg, devices) if devices is not None and len(devices) > 1 else None
         # last single-pair result (the reference keeps it inside the C aligner object)
         self._status = -1
         self._score = -2147483648
@@ -323,6 +327,8 @@ class WavefrontAligner:
     def _push(self):
         self._cfg.wildcard = self._bwildcard
         self._native.set_config(self._cfg)
+        if self._multi is not None:
+            self._multi.set_config(self._cfg)
 
     # ------------------------------------------------------------------ single pair
     def wavefront_align(self, text, pattern=None):
@@ -398,7 +404,7 @@ class WavefrontAligner:
     def align_batch(self, batch):
         """Align a prepared batch dict (see ``pywfa_amd.datagen``): ASCII blob + offsets + lengths."""
         full = self._cfg.scope == 1
-        score, status, cig = self._native.align_batch(batch, full)
+        score, status, cig = (self._multi or self._native).align_batch(batch, full)
         out = {"score": score, "status": status}
         if full:
             ops, cbeg, clen = cig
@@ -576,3 +582,5 @@ class WavefrontAligner:
 
     def close(self):
         self._native.close()
+        if self._multi is not None:
+            self._multi.close()

@@ -17,6 +17,7 @@
 #include <chrono>
 #include <thread>
 #include <memory>
+#include <atomic>
 
 #include "wfa_hip.h"
 #include "wfa_common.hpp"
@@ -29,7 +30,7 @@
 #include "wfa_biwfa.hpp"
 #include "wfa_rle.hpp"
 
-#define WFA_HIP_ABI_VERSION 1
+#define WFA_HIP_ABI_VERSION 2
 
 static thread_local std::string g_error;
 
@@ -82,6 +83,11 @@ struct wfa_hip_aligner {
   hipEvent_t ws_event = nullptr;
   hipStream_t ws_last_stream = nullptr;
   bool ws_event_recorded = false;
+  // pinned staging ring of the pipelined upload (batches of >= 256 k pairs): host threads copy pieces of the caller's
+  // pageable arrays into the slots, each slot goes to the device by DMA as soon as it is full
+  std::vector<uint8_t*> pin_slot;
+  std::vector<hipEvent_t> pin_ev;
+  size_t pin_slot_bytes = 0;
   int cu_count = 256;
   size_t total_mem = 0;
   std::string err;
@@ -259,7 +265,7 @@ extern "C" int wfa_hip_config_validate(const wfa_hip_config_t* c, char* err, siz
   if (c->memory_mode == WFA_MEM_BIWFA) {
     // BiWFA (R/wavefront_bialign.c).  scope=score: wavefront_bialign_compute_score (:662-702) returns the score of the optimal
     // alignment, which is what the other memory modes return (checked on every metric against the real library,
-    // tests/test_oracle_vs_ref.py), and the score-only kernels hold O(s) state already.  scope=full: the breakpoint
+    // the CPU checkers under tests/), and the score-only kernels hold O(s) state already.  scope=full: the breakpoint
     // recursion on the device (csrc/wfa_biwfa.hpp).  Not built: BiWFA with a heuristic or a step limit (the reference runs
     // the cut-off inside both directions), and with free ends (the reference itself exit(1)s, R/wavefront_align.c:60-75).
     const bool free_ends = c->span == WFA_SPAN_ENDSFREE &&
@@ -355,6 +361,8 @@ static void aligner_free(wfa_hip_aligner* al) {
   if (al->ws) (void)hipFree(al->ws);
   pool_drain(al);
   if (al->ws_event) (void)hipEventDestroy(al->ws_event);
+  for (uint8_t* p : al->pin_slot) (void)hipHostFree(p);
+  for (hipEvent_t e : al->pin_ev) (void)hipEventDestroy(e);
   if (al->stream) (void)hipStreamDestroy(al->stream);
   delete al;
 }
@@ -408,6 +416,65 @@ static void batch_free(wfa_hip_batch* b) {
 extern "C" void wfa_hip_batch_destroy(wfa_hip_batch_t* b) { batch_free(b); }
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Pipelined host -> device upload of pageable arrays: the arrays are cut into pieces of one staging
+// slot; `nthreads` host threads claim pieces in order, copy them into the pinned ring and enqueue the DMA of their slot
+// on `stream` themselves; a slot is refilled once its previous DMA is over.  Host copy and DMA overlap, and the DMA runs
+// from pinned memory at the link's rate instead of the runtime's pageable path.  Returns after every piece is ENQUEUED.
+struct UploadJob { void* dst; const void* src; size_t bytes; };
+
+static int staged_upload(wfa_hip_aligner* al, const std::vector<UploadJob>& jobs, hipStream_t stream) {
+  const size_t slot_bytes = (size_t)std::max(1, knob(al, K_PIPE_CHUNK, 8)) << 20;
+  const int nthreads = std::max(1, std::min(knob(al, K_PIPE_THREADS, 8), (int)std::thread::hardware_concurrency()));
+  const int nslots = nthreads + 4;
+  if (al->pin_slot_bytes != slot_bytes || (int)al->pin_slot.size() != nslots) {
+    for (uint8_t* p : al->pin_slot) (void)hipHostFree(p);
+    for (hipEvent_t e : al->pin_ev) (void)hipEventDestroy(e);
+    al->pin_slot.clear(); al->pin_ev.clear(); al->pin_slot_bytes = 0;
+    for (int i = 0; i < nslots; ++i) {
+      uint8_t* p = nullptr; hipEvent_t e;
+      HIP_TRY(al, hipHostMalloc((void**)&p, slot_bytes, hipHostMallocDefault));
+      al->pin_slot.push_back(p);
+      HIP_TRY(al, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      al->pin_ev.push_back(e);
+    }
+    al->pin_slot_bytes = slot_bytes;
+  }
+  struct Piece { void* dst; const uint8_t* src; size_t bytes; };
+  std::vector<Piece> pieces;
+  for (const UploadJob& j : jobs)
+    for (size_t o = 0; o < j.bytes; o += slot_bytes)
+      pieces.push_back({(uint8_t*)j.dst + o, (const uint8_t*)j.src + o, std::min(slot_bytes, j.bytes - o)});
+  const long np = (long)pieces.size();
+  std::atomic<long> next(0);
+  std::vector<std::atomic<long>> issued((size_t)nslots);   // index of the last piece whose DMA was enqueued from this slot
+  for (auto& x : issued) x.store(-1);
+  std::atomic<int> failed(0);
+  const int device = al->device;
+  auto worker = [&]() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      const long i = next.fetch_add(1);
+      if (i >= np || failed.load()) return;
+      const int sl = (int)(i % nslots);
+      if (i >= nslots) {
+        // the slot's previous piece: wait until its DMA was enqueued (by whichever thread had it), then until it is over
+        while (issued[(size_t)sl].load(std::memory_order_acquire) != i - nslots) std::this_thread::yield();
+        if (hipEventSynchronize(al->pin_ev[(size_t)sl]) != hipSuccess) { failed.store(1); }
+      }
+      memcpy(al->pin_slot[(size_t)sl], pieces[(size_t)i].src, pieces[(size_t)i].bytes);
+      if (hipMemcpyAsync(pieces[(size_t)i].dst, al->pin_slot[(size_t)sl], pieces[(size_t)i].bytes, hipMemcpyHostToDevice, stream) != hipSuccess ||
+          hipEventRecord(al->pin_ev[(size_t)sl], stream) != hipSuccess) failed.store(1);
+      issued[(size_t)sl].store(i, std::memory_order_release);
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nthreads; ++t) th.emplace_back(worker);
+  worker();
+  for (auto& x : th) x.join();
+  if (failed.load()) { al->err = "pipelined upload failed"; return WFA_HIP_EDEVICE; }
+  return WFA_HIP_OK;
+}
 
 static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const uint8_t* seqs,
                        const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len) {
@@ -508,10 +575,20 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
   }
   if (timing) { fprintf(stderr, "[wfa_hip] mallocs %.3f ms\n", now_ms() - t0); t0 = now_ms(); }
   if (n > 0) {
-    HIP_TRY(al, hipMemcpyAsync(b->d_bytes, seqs, (size_t)blob_end, hipMemcpyHostToDevice, al->stream));
-    HIP_TRY(al, hipMemcpyAsync(b->d_pboff, p_off, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, al->stream));
-    HIP_TRY(al, hipMemcpyAsync(b->d_tboff, t_off, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, al->stream));
-    HIP_TRY(al, hipMemcpyAsync(b->d_meta, meta.get(), (size_t)n * sizeof(WfaPairMeta), hipMemcpyHostToDevice, al->stream));
+    if (n >= 262144 && knob(al, K_NO_PIPE, 0) == 0) {
+      std::vector<UploadJob> jobs;
+      jobs.push_back({b->d_bytes, seqs, (size_t)blob_end});
+      jobs.push_back({b->d_pboff, p_off, (size_t)n * sizeof(int64_t)});
+      jobs.push_back({b->d_tboff, t_off, (size_t)n * sizeof(int64_t)});
+      jobs.push_back({b->d_meta, meta.get(), (size_t)n * sizeof(WfaPairMeta)});
+      const int urc = staged_upload(al, jobs, al->stream);
+      if (urc != WFA_HIP_OK) return urc;
+    } else {
+      HIP_TRY(al, hipMemcpyAsync(b->d_bytes, seqs, (size_t)blob_end, hipMemcpyHostToDevice, al->stream));
+      HIP_TRY(al, hipMemcpyAsync(b->d_pboff, p_off, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, al->stream));
+      HIP_TRY(al, hipMemcpyAsync(b->d_tboff, t_off, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, al->stream));
+      HIP_TRY(al, hipMemcpyAsync(b->d_meta, meta.get(), (size_t)n * sizeof(WfaPairMeta), hipMemcpyHostToDevice, al->stream));
+    }
     const int threads = 256;
     // lanes per pair: the words of the longest pair, rounded up to a power of two (at most a whole wave)
     int log2slots = 1;
@@ -520,10 +597,11 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
     const int64_t want = ((n + group - 1) / group + 3) / 4;  // 4 waves per workgroup
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)al->cu_count * 64));
     hipLaunchKernelGGL(wfa::wfa_pack_kernel, dim3(grid), dim3(threads), 0, al->stream,
-                       b->d_bytes, b->d_pboff, b->d_tboff, b->d_meta, n, b->d_words, b->d_flags, log2slots);
+                       b->d_bytes, b->d_pboff, b->d_tboff, b->d_meta, n, b->d_words, b->d_flags, log2slots, b->d_counters + 15);
     HIP_TRY(al, hipGetLastError());
-    std::vector<uint8_t> flags((size_t)n);
+    std::vector<uint8_t> flags;
     if (n <= 256) {
+      flags.assign((size_t)n, 0);
       // a handful of pairs: look for letters outside ACGT on the host, the round trip costs more than the scan
       for (int64_t i = 0; i < n; ++i) {
         uint8_t bad = 0;
@@ -534,8 +612,14 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
       }
       b->uploads_pending = true;  // the caller's arrays are still being read: see wfa_hip_batch_create
     } else {
-      HIP_TRY(al, hipMemcpyAsync(flags.data(), b->d_flags, (size_t)n, hipMemcpyDeviceToHost, al->stream));
+      // one word first: the per-pair flags (n bytes) are fetched only if some pair holds a letter outside ACGT
+      uint32_t any_flag = 0;
+      HIP_TRY(al, hipMemcpyAsync(&any_flag, b->d_counters + 15, sizeof(uint32_t), hipMemcpyDeviceToHost, al->stream));
       HIP_TRY(al, hipStreamSynchronize(al->stream));
+      if (any_flag || c.wildcard >= 0) {
+        flags.assign((size_t)n, 0);
+        HIP_TRY(al, hipMemcpy(flags.data(), b->d_flags, (size_t)n, hipMemcpyDeviceToHost));
+      }
     }
     if (timing) { fprintf(stderr, "[wfa_hip] H2D + pack + flags D2H %.3f ms (%.2f GB)\n", now_ms() - t0, blob_end / 1e9); t0 = now_ms(); }
     // split into the 2-bit and the 8-bit work lists (wildcard matching needs the bytes)
@@ -545,7 +629,7 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
       for (int64_t i = 0; i < n; ++i) lb[i] = (uint32_t)i;
     } else {
       int64_t nbad = 0;
-      for (int64_t i = 0; i < n; ++i) nbad += flags[i];
+      for (size_t i = 0; i < flags.size(); ++i) nbad += flags[i];
       if (nbad) {
         lp.reserve((size_t)(n - nbad)); lb.reserve((size_t)nbad);
         for (int64_t i = 0; i < n; ++i) (flags[i] ? lb : lp).push_back((uint32_t)i);
@@ -1106,11 +1190,14 @@ extern "C" int wfa_hip_batch_results(wfa_hip_batch_t* b, int32_t* score, int32_t
     if (!cigar_off || !cigar_begin || !cigar_len) { al->err = "cigar_off/cigar_begin/cigar_len are required with cigar_ops"; return WFA_HIP_EINVAL; }
     // the device regions are laid out back to back in pair order (plen+tlen bytes each); the caller's
     // regions may be spaced differently: copy whole, then re-base per pair when they differ
+    // (a shard of a larger batch: the caller's regions are the device layout shifted by cigar_off[0])
     bool same = true;
     int64_t acc = 0;
-    for (int64_t i = 0; i < n && same; ++i) { same = (cigar_off[i] == acc); acc += b->h_plen[i] + b->h_tlen[i]; }
+    const int64_t base0 = cigar_off[0];
+    for (int64_t i = 0; i < n && same; ++i) { same = (cigar_off[i] == base0 + acc); acc += b->h_plen[i] + b->h_tlen[i]; }
     if (same) {
-      if (b->ops_bytes) HIP_TRY(al, hipMemcpy(cigar_ops, b->d_ops, (size_t)b->ops_bytes, hipMemcpyDeviceToHost));
+      if (b->ops_bytes) HIP_TRY(al, hipMemcpy(cigar_ops + base0, b->d_ops, (size_t)b->ops_bytes, hipMemcpyDeviceToHost));
+      if (base0) for (int64_t i = 0; i < n; ++i) cigar_begin[i] += base0;
     } else {
       std::vector<uint8_t> tmp((size_t)std::max<int64_t>(b->ops_bytes, 1));
       if (b->ops_bytes) HIP_TRY(al, hipMemcpy(tmp.data(), b->d_ops, (size_t)b->ops_bytes, hipMemcpyDeviceToHost));
@@ -1231,4 +1318,83 @@ extern "C" int wfa_hip_align_batch(wfa_hip_aligner_t* al, int64_t n, const uint8
   if (timing) fprintf(stderr, "[wfa_hip] align_batch: create %.3f ms, enqueue %.3f ms, sync + results %.3f ms, destroy %.3f ms\n",
                       t1 - t0, t2 - t1, t3 - t2, now_ms() - t3);
   return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// several devices of one node: contiguous shards balanced by sum(plen + tlen), one host thread +
+// aligner + stream per device, disjoint output slices, no collective
+// ------------------------------------------------------------------------------------------------
+extern "C" int wfa_hip_plan_shards(int64_t n, const int32_t* p_len, const int32_t* t_len, int nshards, int64_t* shard_begin) {
+  if (n < 0 || nshards < 1 || !shard_begin || (n > 0 && (!p_len || !t_len))) return WFA_HIP_EINVAL;
+  // work of a pair ~ its bases (+ a constant so that empty pairs still count); boundary s at the first pair whose prefix
+  // reaches s / nshards of the total
+  long double total = 0;
+  for (int64_t i = 0; i < n; ++i) total += (long double)p_len[i] + t_len[i] + 16;
+  shard_begin[0] = 0;
+  long double acc = 0;
+  int s = 1;
+  for (int64_t i = 0; i < n && s < nshards; ++i) {
+    acc += (long double)p_len[i] + t_len[i] + 16;
+    while (s < nshards && acc >= total * s / nshards) shard_begin[s++] = i + 1;
+  }
+  while (s <= nshards) shard_begin[s++] = n;
+  return WFA_HIP_OK;
+}
+
+struct wfa_hip_multi {
+  std::vector<wfa_hip_aligner*> al;
+  std::string err;
+};
+
+extern "C" wfa_hip_multi_t* wfa_hip_multi_create(const wfa_hip_config_t* cfg, const int* devices, int ndevices) {
+  if (!cfg || !devices || ndevices < 1) { g_error = "invalid multi-device arguments"; return nullptr; }
+  wfa_hip_multi* m = new wfa_hip_multi();
+  for (int i = 0; i < ndevices; ++i) {
+    wfa_hip_aligner* a = wfa_hip_create(cfg, devices[i]);
+    if (!a) { for (wfa_hip_aligner* x : m->al) wfa_hip_destroy(x); delete m; return nullptr; }
+    m->al.push_back(a);
+  }
+  return m;
+}
+
+extern "C" void wfa_hip_multi_destroy(wfa_hip_multi_t* m) {
+  if (!m) return;
+  for (wfa_hip_aligner* x : m->al) wfa_hip_destroy(x);
+  delete m;
+}
+
+extern "C" int wfa_hip_multi_set_config(wfa_hip_multi_t* m, const wfa_hip_config_t* cfg) {
+  if (!m) return WFA_HIP_EINVAL;
+  for (wfa_hip_aligner* x : m->al) {
+    const int rc = wfa_hip_set_config(x, cfg);
+    if (rc != WFA_HIP_OK) { m->err = x->err; return rc; }
+  }
+  return WFA_HIP_OK;
+}
+
+extern "C" const char* wfa_hip_multi_last_error(const wfa_hip_multi_t* m) { return m ? m->err.c_str() : g_error.c_str(); }
+
+extern "C" int wfa_hip_multi_align_batch(wfa_hip_multi_t* m, int64_t n, const uint8_t* seqs,
+                                         const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len,
+                                         int32_t* score, int32_t* status, uint8_t* cigar_ops, const int64_t* cigar_off,
+                                         int64_t* cigar_begin, int32_t* cigar_len) {
+  if (!m || n < 0) return WFA_HIP_EINVAL;
+  const int nd = (int)m->al.size();
+  std::vector<int64_t> sb((size_t)nd + 1);
+  if (wfa_hip_plan_shards(n, p_len, t_len, nd, sb.data()) != WFA_HIP_OK) { m->err = "invalid batch arguments"; return WFA_HIP_EINVAL; }
+  std::vector<int> rcs((size_t)nd, WFA_HIP_OK);
+  auto work = [&](int d) {
+    const int64_t lo = sb[(size_t)d], cnt = sb[(size_t)d + 1] - lo;
+    if (cnt == 0) return;
+    rcs[(size_t)d] = wfa_hip_align_batch(m->al[(size_t)d], cnt, seqs, p_off + lo, p_len + lo, t_off + lo, t_len + lo, score + lo, status + lo,
+                                         cigar_ops, cigar_off ? cigar_off + lo : nullptr, cigar_begin ? cigar_begin + lo : nullptr,
+                                         cigar_len ? cigar_len + lo : nullptr);
+  };
+  std::vector<std::thread> th;
+  for (int d = 1; d < nd; ++d) th.emplace_back(work, d);
+  work(0);
+  for (auto& x : th) x.join();
+  for (int d = 0; d < nd; ++d)
+    if (rcs[(size_t)d] != WFA_HIP_OK) { m->err = "device " + std::to_string(m->al[(size_t)d]->device) + ": " + m->al[(size_t)d]->err; return rcs[(size_t)d]; }
+  return WFA_HIP_OK;
 }

@@ -19,7 +19,8 @@ __device__ __forceinline__ bool is_acgt(uint32_t c) { return c == 'A' || c == 'C
 __global__ void __launch_bounds__(256)
 wfa_pack_kernel(const uint8_t* __restrict__ bytes, const int64_t* __restrict__ p_boff,
                 const int64_t* __restrict__ t_boff, const WfaPairMeta* __restrict__ meta, int64_t n,
-                uint32_t* __restrict__ words, uint8_t* __restrict__ flags, int log2slots) {
+                uint32_t* __restrict__ words, uint8_t* __restrict__ flags, int log2slots,
+                uint32_t* __restrict__ any_flag) {
   const int lane = threadIdx.x & 63;
   const int slots = 1 << log2slots, group = 64 >> log2slots;
   const int sub = lane >> log2slots, wl = lane & (slots - 1);
@@ -59,6 +60,7 @@ wfa_pack_kernel(const uint8_t* __restrict__ bytes, const int64_t* __restrict__ p
     const unsigned long long b = __ballot(bad);
     const unsigned long long field = (slots == 64) ? b : ((b >> (sub * slots)) & ((1ull << slots) - 1ull));
     if (field != 0ull && wl == 0 && pair < n) flags[pair] = 1;
+    if (b != 0ull && lane == 0) atomicOr(any_flag, 1u);   // the host fetches the per-pair flags only if some pair was flagged
   }
 }
 

@@ -41,7 +41,7 @@ def test_abi_version_and_default_config():
     ("match", 1, _native.EINVAL), ("mismatch", 0, _native.EINVAL), ("gap_opening", -1, _native.EINVAL),
     ("gap_extension", 0, _native.EINVAL), ("scope", 7, _native.EINVAL), ("span", 3, _native.EINVAL),
     ("heuristic", 9, _native.EINVAL), ("distance", 7, _native.EINVAL),
-    ("memory_mode", 3, _native.ENOTSUP), ("pattern_begin_free", -2, _native.EINVAL), ("wildcard", 300, _native.EINVAL),
+    ("memory_mode", 9, _native.EINVAL), ("pattern_begin_free", -2, _native.EINVAL), ("wildcard", 300, _native.EINVAL),
 ])
 def test_validate_rejects(field, value, code):
     """Invalid penalties return an error code where the reference exit(1)s (wavefront_penalties.c:101-112)."""
@@ -49,6 +49,19 @@ def test_validate_rejects(field, value, code):
     setattr(c, field, value)
     rc, msg = _native.validate(c)
     assert rc == code and msg
+
+
+def test_validate_biwfa():
+    """memory_mode biwfa (full CIGAR included) is on the accelerated path without heuristic, free ends or max_steps; the
+    rest is refused with ENOTSUP (the reference itself exit(1)s on free ends, wavefront_align.c:60-75)."""
+    c = _native.default_config()
+    c.memory_mode = 3
+    assert _native.validate(c)[0] == _native.OK
+    for field, value in (("heuristic", 1), ("max_steps", 50), ("text_end_free", 4)):
+        c = _native.default_config()
+        c.memory_mode = 3
+        setattr(c, field, value)
+        assert _native.validate(c)[0] == _native.ENOTSUP
 
 
 def test_validate_single_component_metrics():
@@ -87,3 +100,23 @@ def test_product_does_not_use_oracle():
                 txt = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert "oracle" not in txt.lower(), (dirpath, fn)
                 assert "libwfa_ref" not in txt, (dirpath, fn)
+
+
+def test_shard_planner_properties():
+    """wfa_hip_plan_shards (host only): contiguous shards that cover the batch, balanced by bases, for any shard count."""
+    import numpy as np
+    from pywfa_amd import _native
+    rng = np.random.default_rng(1)
+    for n in (0, 1, 5, 1000, 20000):
+        pl = rng.integers(0, 3000, n).astype(np.int32)
+        tl = rng.integers(0, 3000, n).astype(np.int32)
+        for k in (1, 2, 3, 8, 13):
+            sb = _native.plan_shards(pl, tl, k)
+            assert sb[0] == 0 and sb[-1] == n and (np.diff(sb) >= 0).all() and len(sb) == k + 1
+            if n >= 1000:
+                w = pl.astype(np.int64) + tl + 16
+                loads = np.array([w[sb[i]:sb[i + 1]].sum() for i in range(k)])
+                assert loads.max() - loads.min() <= 2 * w.max() + 1
+    import pytest
+    with pytest.raises(ValueError):
+        _native.plan_shards(np.zeros(3, np.int32), np.zeros(3, np.int32), 0)

@@ -243,3 +243,50 @@ def test_runs_on_different_streams_are_ordered(gpu):
     r1.close(); r2.close(); al.close()
     for s in streams:
         hip.hipStreamDestroy(s)
+
+
+# ------------------------------------------------------------------------ several devices
+@pytest.mark.parametrize("scope", ["score", "full"])
+def test_multi_device_entry_shards_and_merges(gpu, scope):
+    """wfa_hip_multi_align_batch: contiguous shards, one host thread + aligner per entry of devices[], results in disjoint
+    slices of the caller's arrays.  On a one-GPU box the entries are [0, 0, 0] (three threads feeding one device: the
+    sharding, threading and merging are the same code); with two or more GPUs the shards really run on different devices."""
+    ndev = gpu
+    devices = list(range(ndev)) if ndev >= 2 else [0, 0, 0]
+    rng = np.random.default_rng(8)
+    pats, txts = [], []
+    for i in range(5000):
+        L = int(rng.choice([30, 150, 150, 400, 1200]))
+        b1 = datagen.generate(1, L, float(rng.choice([0.0, 0.03, 0.1])), 50_000 + i)
+        p_, t_ = datagen.pair_strings(b1, 0)
+        pats.append(p_); txts.append(t_)
+    batch = datagen.from_strings(pats, txts)
+    oc, nc = common.configs_pair(scope=scope)
+    o = loader.run(loader.oracle(), oc, batch)
+    m = _native.MultiAligner(nc, devices)
+    for _ in range(2):
+        score, status, cig = m.align_batch(batch, scope == "full")
+        cigars = None
+        if cig is not None:
+            ops, cbeg, clen = cig
+            cigars = [ops[cbeg[i]:cbeg[i] + clen[i]].tobytes() for i in range(len(score))]
+        common.assert_same(o, score, status, cigars, batch, f"multi {devices} {scope}")
+    m.close()
+    # the Python class: devices=[...] routes batches through the same entry
+    import pywfa_amd
+    a = pywfa_amd.WavefrontAligner(scope=scope, devices=devices)
+    out = a.wavefront_align_batch(txts[:500], pats[:500])
+    assert out["score"].tolist() == o["score"][:500].tolist()
+    a.close()
+
+
+def test_two_devices_parity(gpu):
+    if gpu < 2:
+        pytest.skip("needs two GPUs (the driver's multi-GPU node); the one-GPU box runs test_multi_device_entry_shards_and_merges")
+    batch = datagen.generate(200000, 150, 0.02, 606)
+    oc, nc = common.configs_pair(span="end-to-end", scope="score")
+    m = _native.MultiAligner(nc, [0, 1])
+    score, status, _ = m.align_batch(batch, False)
+    m.close()
+    s1, st1, _ = common.gpu_run(nc, batch, False, False)
+    assert np.array_equal(score, s1) and np.array_equal(status, st1)

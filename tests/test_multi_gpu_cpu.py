@@ -25,6 +25,15 @@ WORKER = textwrap.dedent('''
     P = 500
     first = bench.shard_first(rank, P)
     batch = datagen.generate(P, 150, 0.02, datagen.SEEDS["C2"], first=first)
+    # the product's own shard planner (wfa_hip_plan_shards, host only) on a ragged batch: every rank plans the same
+    # shards and aligns its own; rank 0 checks the union below
+    from pywfa_amd import _native
+    ragged = datagen.from_strings(["ACGT" * (1 + (7 * i) % 40) for i in range(300)], ["ACGA" * (1 + (5 * i) % 33) for i in range(300)])
+    sb = _native.plan_shards(ragged["p_len"], ragged["t_len"], world)
+    mine = np.arange(sb[rank], sb[rank + 1])
+    r_o = loader.run(loader.oracle(), loader.make_config(span="end-to-end", scope="score"), datagen.subset(ragged, mine))
+    np.save(os.path.join(os.environ["WFA_OUT"], f"ragged_{rank}.npy"), r_o["score"])
+    np.save(os.path.join(os.environ["WFA_OUT"], f"ragged_sb_{rank}.npy"), sb)
     bench.dist_barrier(dist, "gloo")
     t0 = time.perf_counter()
     o = loader.run(loader.oracle(), loader.make_config(span="end-to-end", scope="score"), batch)
@@ -61,6 +70,15 @@ def test_two_rank_sharding_over_gloo(tmp_path):
     o = loader.run(loader.oracle(), loader.make_config(span="end-to-end", scope="score"), whole)
     got = np.concatenate([np.load(tmp_path / f"score_{r}.npy") for r in range(2)])
     assert np.array_equal(got, o["score"])            # shards partition the stream, results unchanged
+    # the ragged batch sharded by the product's planner: contiguous, complete, balanced by bases, results unchanged
+    ragged = datagen.from_strings(["ACGT" * (1 + (7 * i) % 40) for i in range(300)], ["ACGA" * (1 + (5 * i) % 33) for i in range(300)])
+    sb0, sb1 = np.load(tmp_path / "ragged_sb_0.npy"), np.load(tmp_path / "ragged_sb_1.npy")
+    assert np.array_equal(sb0, sb1) and sb0[0] == 0 and sb0[-1] == 300 and (np.diff(sb0) >= 0).all()
+    work = (ragged["p_len"].astype(np.int64) + ragged["t_len"] + 16)
+    halves = [work[sb0[i]:sb0[i + 1]].sum() for i in range(2)]
+    assert abs(halves[0] - halves[1]) <= work.max() + 1
+    ro = loader.run(loader.oracle(), loader.make_config(span="end-to-end", scope="score"), ragged)
+    assert np.array_equal(np.concatenate([np.load(tmp_path / f"ragged_{r}.npy") for r in range(2)]), ro["score"])
     metas = [json.load(open(tmp_path / f"meta_{r}.json")) for r in range(2)]
     assert [m["first"] for m in metas] == [0, 500]
     assert abs(metas[0]["max"] - metas[1]["max"]) < 1e-6 and metas[0]["max"] >= max(m["elapsed"] for m in metas) - 1e-6
