@@ -18,6 +18,7 @@
 #include <thread>
 #include <memory>
 #include <atomic>
+#include <functional>
 
 #include "wfa_hip.h"
 #include "wfa_common.hpp"
@@ -87,6 +88,7 @@ struct wfa_hip_aligner {
   // pageable arrays into the slots, each slot goes to the device by DMA as soon as it is full
   std::vector<uint8_t*> pin_slot;
   std::vector<hipEvent_t> pin_ev;
+  std::vector<char> pin_ev_recorded;   // the slot's event was recorded: its DMA must be over before the slot is refilled
   size_t pin_slot_bytes = 0;
   int cu_count = 256;
   size_t total_mem = 0;
@@ -105,7 +107,10 @@ static inline int knob(const wfa_hip_aligner* al, WfaKnob k, int dflt) {
   return al->knobs.set[k] ? al->knobs.value[k] : dflt;
 }
 
-static const size_t POOL_MAX_BLOCK = (size_t)8 << 20, POOL_MAX_CACHED = (size_t)128 << 20;
+// Blocks of finished batches are kept for the next batch: small ones (a pywfa-style loop of single alignments) and the
+// large arrays of a big batch alike (a loop of wfa_hip_align_batch calls over equally shaped batches then allocates
+// nothing: hipFree of a 10 M-pair batch's arrays alone was 23 ms of a 133 ms call).  At most 8 GB stay cached.
+static const size_t POOL_MAX_BLOCK = (size_t)4 << 30, POOL_MAX_CACHED = (size_t)8 << 30;
 
 static hipError_t pool_alloc(wfa_hip_aligner* al, void** p, size_t bytes) {
   size_t want = 256;
@@ -404,12 +409,18 @@ static void batch_free(wfa_hip_batch* b) {
                   b->d_fb_list2[0], b->d_fb_list2[1], b->d_ovf_list[0], b->d_ovf_list[1], b->d_counters,
                   b->d_plen, b->d_tlen, b->d_run_count, b->d_locs, b->d_run_off};
   // blocks go back to the aligner's pool: nothing of this batch may still be running
+  const bool timing = b->al->knobs.set[K_TIMING];
+  const double t0 = timing ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
   if (b->ran && !b->synced && b->last_stream) (void)hipStreamSynchronize(b->last_stream);
   (void)hipStreamSynchronize(b->al->stream);
+  const double t1 = timing ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
   for (void* p : ptrs) pool_release(b->al, p);
   for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
+  const double t2 = timing ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
   wfa_hip_aligner* al = b->al;
   delete b;
+  if (timing) fprintf(stderr, "[wfa_hip] batch_free: sync %.3f ms, release %.3f ms, host free %.3f ms\n", t1 - t0, t2 - t1,
+                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t2);
   if (--al->live_batches == 0 && al->destroy_pending) aligner_free(al);
 }
 
@@ -421,30 +432,34 @@ static double now_ms() { return std::chrono::duration<double, std::milli>(std::c
 // slot; `nthreads` host threads claim pieces in order, copy them into the pinned ring and enqueue the DMA of their slot
 // on `stream` themselves; a slot is refilled once its previous DMA is over.  Host copy and DMA overlap, and the DMA runs
 // from pinned memory at the link's rate instead of the runtime's pageable path.  Returns after every piece is ENQUEUED.
-struct UploadJob { void* dst; const void* src; size_t bytes; };
+// (src == nullptr: the piece is produced by gen(out, byte offset within the job, bytes) straight into the pinned slot)
+struct UploadJob { void* dst; const void* src; size_t bytes; std::function<void(uint8_t*, size_t, size_t)> gen; };
+
+static size_t staged_slot_bytes(const wfa_hip_aligner* al) { return (size_t)std::max(1, knob(al, K_PIPE_CHUNK, 8)) << 20; }
 
 static int staged_upload(wfa_hip_aligner* al, const std::vector<UploadJob>& jobs, hipStream_t stream) {
-  const size_t slot_bytes = (size_t)std::max(1, knob(al, K_PIPE_CHUNK, 8)) << 20;
+  const size_t slot_bytes = staged_slot_bytes(al);
   const int nthreads = std::max(1, std::min(knob(al, K_PIPE_THREADS, 8), (int)std::thread::hardware_concurrency()));
   const int nslots = nthreads + 4;
   if (al->pin_slot_bytes != slot_bytes || (int)al->pin_slot.size() != nslots) {
     for (uint8_t* p : al->pin_slot) (void)hipHostFree(p);
     for (hipEvent_t e : al->pin_ev) (void)hipEventDestroy(e);
-    al->pin_slot.clear(); al->pin_ev.clear(); al->pin_slot_bytes = 0;
+    al->pin_slot.clear(); al->pin_ev.clear(); al->pin_ev_recorded.clear(); al->pin_slot_bytes = 0;
     for (int i = 0; i < nslots; ++i) {
       uint8_t* p = nullptr; hipEvent_t e;
       HIP_TRY(al, hipHostMalloc((void**)&p, slot_bytes, hipHostMallocDefault));
       al->pin_slot.push_back(p);
       HIP_TRY(al, hipEventCreateWithFlags(&e, hipEventDisableTiming));
       al->pin_ev.push_back(e);
+      al->pin_ev_recorded.push_back(0);
     }
     al->pin_slot_bytes = slot_bytes;
   }
-  struct Piece { void* dst; const uint8_t* src; size_t bytes; };
+  struct Piece { void* dst; const uint8_t* src; size_t bytes; const UploadJob* job; size_t off; };
   std::vector<Piece> pieces;
   for (const UploadJob& j : jobs)
     for (size_t o = 0; o < j.bytes; o += slot_bytes)
-      pieces.push_back({(uint8_t*)j.dst + o, (const uint8_t*)j.src + o, std::min(slot_bytes, j.bytes - o)});
+      pieces.push_back({(uint8_t*)j.dst + o, j.src ? (const uint8_t*)j.src + o : nullptr, std::min(slot_bytes, j.bytes - o), &j, o});
   const long np = (long)pieces.size();
   std::atomic<long> next(0);
   std::vector<std::atomic<long>> issued((size_t)nslots);   // index of the last piece whose DMA was enqueued from this slot
@@ -457,14 +472,15 @@ static int staged_upload(wfa_hip_aligner* al, const std::vector<UploadJob>& jobs
       const long i = next.fetch_add(1);
       if (i >= np || failed.load()) return;
       const int sl = (int)(i % nslots);
-      if (i >= nslots) {
-        // the slot's previous piece: wait until its DMA was enqueued (by whichever thread had it), then until it is over
-        while (issued[(size_t)sl].load(std::memory_order_acquire) != i - nslots) std::this_thread::yield();
-        if (hipEventSynchronize(al->pin_ev[(size_t)sl]) != hipSuccess) { failed.store(1); }
-      }
-      memcpy(al->pin_slot[(size_t)sl], pieces[(size_t)i].src, pieces[(size_t)i].bytes);
+      // the slot's previous piece (of this call, or of an earlier one): wait until its DMA was enqueued (by whichever
+      // thread had it), then until it is over
+      if (i >= nslots) while (issued[(size_t)sl].load(std::memory_order_acquire) != i - nslots) std::this_thread::yield();
+      if (al->pin_ev_recorded[(size_t)sl] && hipEventSynchronize(al->pin_ev[(size_t)sl]) != hipSuccess) failed.store(1);
+      if (pieces[(size_t)i].src) memcpy(al->pin_slot[(size_t)sl], pieces[(size_t)i].src, pieces[(size_t)i].bytes);
+      else pieces[(size_t)i].job->gen(al->pin_slot[(size_t)sl], pieces[(size_t)i].off, pieces[(size_t)i].bytes);
       if (hipMemcpyAsync(pieces[(size_t)i].dst, al->pin_slot[(size_t)sl], pieces[(size_t)i].bytes, hipMemcpyHostToDevice, stream) != hipSuccess ||
           hipEventRecord(al->pin_ev[(size_t)sl], stream) != hipSuccess) failed.store(1);
+      al->pin_ev_recorded[(size_t)sl] = 1;
       issued[(size_t)sl].store(i, std::memory_order_release);
     }
   };
@@ -488,15 +504,20 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
     b->h_plen.assign(p_len, p_len + n);
     b->h_tlen.assign(t_len, t_len + n);
   }
-  std::unique_ptr<WfaPairMeta[]> meta(new WfaPairMeta[(size_t)std::max<int64_t>(n, 1)]);  // not zero-filled: first touched in parallel below
-  // per-pair metadata on several host threads: pass 1 validates and sums each slice, pass 2 writes the
-  // word offsets from the slice prefix
-  const int nthr = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, std::thread::hardware_concurrency()), n / 65536));
+  // per-pair metadata on several host threads: pass 1 validates and sums each slice of the batch, pass 2 writes the word
+  // offsets from the slice prefix.  Large batches (pipelined upload): the slices are the pieces of the upload ring and pass 2
+  // writes each piece straight into its pinned slot — no host copy of the metadata exists
+  const bool pipelined = n >= 262144 && knob(al, K_NO_PIPE, 0) == 0;
+  const int64_t piece_pairs = (int64_t)(staged_slot_bytes(al) / sizeof(WfaPairMeta));
+  const int nthr = pipelined ? (int)((n + piece_pairs - 1) / piece_pairs)
+                             : (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, std::thread::hardware_concurrency()), n / 65536));
+  auto part_lo = [&](int t) -> int64_t { return pipelined ? std::min<int64_t>(n, (int64_t)t * piece_pairs) : n * t / nthr; };
+  std::unique_ptr<WfaPairMeta[]> meta(pipelined ? nullptr : new WfaPairMeta[(size_t)std::max<int64_t>(n, 1)]);  // not zero-filled: first touched in parallel below
   struct Part { uint64_t words = 0; int64_t packed = 0, ops = 0, blob_end = 0; int max_width = 0, max_len = 0, err = 0; };
   std::vector<Part> parts((size_t)nthr);
   auto pass1 = [&](int t) {
     Part& pt = parts[(size_t)t];
-    const int64_t lo = n * t / nthr, hi = n * (t + 1) / nthr;
+    const int64_t lo = part_lo(t), hi = part_lo(t + 1);
     for (int64_t i = lo; i < hi; ++i) {
       const int pl = p_len[i], tl = t_len[i];
       if (pl < 0 || tl < 0 || p_off[i] < 0 || t_off[i] < 0) { pt.err = 1; return; }
@@ -514,8 +535,13 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
   };
   auto run_threads = [&](auto&& fn) {
     if (nthr == 1) { fn(0); return; }
+    // (a bounded team: the parts are claimed from a counter)
+    const int team = std::min(nthr, std::max(1, std::min(16, (int)std::thread::hardware_concurrency())));
+    std::atomic<int> nextp(0);
+    auto loop = [&]() { for (int t = nextp.fetch_add(1); t < nthr; t = nextp.fetch_add(1)) fn(t); };
     std::vector<std::thread> th;
-    for (int t = 0; t < nthr; ++t) th.emplace_back(fn, t);
+    for (int t = 1; t < team; ++t) th.emplace_back(loop);
+    loop();
     for (auto& x : th) x.join();
   };
   run_threads(pass1);
@@ -532,17 +558,19 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
     b->packed_bytes += pt.packed; b->ops_bytes += pt.ops; blob_end = std::max(blob_end, pt.blob_end);
   }
   if (woff > 0xFFFFFFF0ull) { al->err = "batch too large: more than 2^32 packed words (split the batch)"; return WFA_HIP_EINVAL; }
-  run_threads([&](int t) {
+  auto pass2_part = [&](int t, WfaPairMeta* out /* element 0 = pair part_lo(t) */) {
     uint64_t w = wbase[(size_t)t];
-    const int64_t lo = n * t / nthr, hi = n * (t + 1) / nthr;
+    const int64_t lo = part_lo(t), hi = part_lo(t + 1);
     for (int64_t i = lo; i < hi; ++i) {
       const int pl = p_len[i], tl = t_len[i];
-      meta[(size_t)i].p_woff = (uint32_t)w; w += (uint64_t)((pl + 15) >> 4);
-      meta[(size_t)i].t_woff = (uint32_t)w; w += (uint64_t)((tl + 15) >> 4);
-      meta[(size_t)i].plen = pl; meta[(size_t)i].tlen = tl;
+      WfaPairMeta& m = out[i - lo];
+      m.p_woff = (uint32_t)w; w += (uint64_t)((pl + 15) >> 4);
+      m.t_woff = (uint32_t)w; w += (uint64_t)((tl + 15) >> 4);
+      m.plen = pl; m.tlen = tl;
     }
-  });
-  if (timing) { fprintf(stderr, "[wfa_hip] meta loop %.3f ms\n", now_ms() - t0); t0 = now_ms(); }
+  };
+  if (!pipelined) run_threads([&](int t) { pass2_part(t, meta.get() + part_lo(t)); });
+  if (timing) { fprintf(stderr, "[wfa_hip] meta pass %.3f ms\n", now_ms() - t0); t0 = now_ms(); }
   const bool full = (c.scope == WFA_SCOPE_FULL);
   const size_t nn = (size_t)std::max<int64_t>(n, 1);
   HIP_TRY(al, pool_alloc(al, (void**)&b->d_bytes, (size_t)blob_end + 64));
@@ -575,12 +603,14 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
   }
   if (timing) { fprintf(stderr, "[wfa_hip] mallocs %.3f ms\n", now_ms() - t0); t0 = now_ms(); }
   if (n > 0) {
-    if (n >= 262144 && knob(al, K_NO_PIPE, 0) == 0) {
+    if (pipelined) {
+      // host threads -> pinned ring -> DMA; the metadata pieces are computed into their slots, the caller's arrays copied
       std::vector<UploadJob> jobs;
-      jobs.push_back({b->d_bytes, seqs, (size_t)blob_end});
-      jobs.push_back({b->d_pboff, p_off, (size_t)n * sizeof(int64_t)});
-      jobs.push_back({b->d_tboff, t_off, (size_t)n * sizeof(int64_t)});
-      jobs.push_back({b->d_meta, meta.get(), (size_t)n * sizeof(WfaPairMeta)});
+      jobs.push_back({b->d_meta, nullptr, (size_t)n * sizeof(WfaPairMeta),
+                      [&](uint8_t* out, size_t off, size_t) { pass2_part((int)(off / staged_slot_bytes(al)), reinterpret_cast<WfaPairMeta*>(out)); }});
+      jobs.push_back({b->d_bytes, seqs, (size_t)blob_end, nullptr});
+      jobs.push_back({b->d_pboff, p_off, (size_t)n * sizeof(int64_t), nullptr});
+      jobs.push_back({b->d_tboff, t_off, (size_t)n * sizeof(int64_t), nullptr});
       const int urc = staged_upload(al, jobs, al->stream);
       if (urc != WFA_HIP_OK) return urc;
     } else {

@@ -1,9 +1,10 @@
-import sys,time
-sys.path.insert(0,'/root/repo')
+"""Development aid: wall time of wfa_hip_align_batch (host ASCII in -> host results out) on the C2 batch."""
+import sys, time, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 from pywfa_amd import _native, datagen
-b=datagen.generate(10000000,150,0.02,1002)
-cfg=_native.default_config(); cfg.span=0; cfg.scope=0
-al=_native.Aligner(cfg)
-for i in range(3):
-    t=time.time(); s,st,_=al.align_batch(b,False); print('e2e ms',(time.time()-t)*1e3, flush=True)
+b = datagen.generate(10000000, 150, 0.02, 1002)
+cfg = _native.default_config(); cfg.span = 0; cfg.scope = 0
+al = _native.Aligner(cfg)
+for i in range(4):
+    t = time.time(); s, st, _ = al.align_batch(b, False); print('e2e ms', (time.time() - t) * 1e3, flush=True)
