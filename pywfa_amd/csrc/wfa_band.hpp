@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <limits.h>
+#include "wfa_hip.h"
 #include "wfa_common.hpp"
 #include "wfa_fast.hpp"
 #include "wfa_general.hpp"
@@ -46,6 +47,10 @@ struct BandArgs {
   int x, oe, e;           // penalties (score units), for the backtrace
   int oe2, e2;            // gap-affine-2p: o2 + e2 and e2 (0 = gap-affine)
   int min_wf_len, max_dist_thr, steps_between;
+  int heur;               // ADAPT instantiations: 1 = wf-adaptive, 2 = X-drop (R/wavefront_heuristic.c:297-383)
+  int xdrop;
+  int max_steps;          // INT_MAX = unlimited (R/wavefront_unialign.c:98-107)
+  int scope;              // max_score_scope (R/wavefront_components.c:81-124): null steps beyond it end the alignment "unreachable"
   int lds_words;          // SEQLDS: words reserved per sequence in dynamic LDS
   int split;              // FULL: 1 = history slot per PAIR of this launch + end states; the backtrace runs in its own
                           //       thread-per-alignment kernel afterwards (latency of 64 walks overlapped per wave)
@@ -78,6 +83,8 @@ __device__ __forceinline__ int wave_min_dpp(int v) {
   return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
              min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
+
+__device__ __forceinline__ int wave_max_dpp(int v) { return -wave_min_dpp(-v); }
 
 template <int NCH>
 struct Band {
@@ -319,6 +326,7 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
     }
     int result = 0;
     int end_k = 0, end_off = 0, end_s = 0;
+    int stop_status = 0, stop_score = 0;  // ended without reaching the end cell: dropped (status 1) or step limit (-100)
     if (!fallback) {
       // per lane: lim = min(tlen, plen + k) (in-bounds <=> offset <= lim; lim - offset = longest possible run),
       // dlim = max(tlen, plen + k) (dlim - offset = distance to the end, R/wavefront_heuristic.c:176-192)
@@ -342,6 +350,8 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
         for (int j = 0; j < NP; ++j) PH[j][c] = -1;  // both halves NULL
       }
       int s = 0, steps_wait = a.steps_between, dead_steps = 0;
+      int have_max_sw = 0, max_sw = 0;      // X-drop state (R/wavefront_heuristic.c:114-121)
+      int last_nonnull = 0;                 // last score whose compute-next had a non-null input (score 0 counts)
       bool done = false;
       for (int step = 0;; ++step) {
         if (PB) {
@@ -417,7 +427,38 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
             if (p >= 0 && p < W && at_end >= tlen) { done = true; result = -s; end_k = ak; end_off = tlen; end_s = s; break; }
           }
           // ---------------- wf-adaptive cut-off (R/wavefront_heuristic.c:257-293,509-567) ----------------
-          if (ADAPT) {
+          if (ADAPT && a.heur == 2) {
+            // X-drop (R/wavefront_heuristic.c:297-383; match = 0: the "score" of a cell is (-(v + h) - s) / 2, C division)
+            --steps_wait;
+            if (steps_wait <= 0) {
+              const int lo = B + BD::first_pos(live), hi = B + BD::last_pos(live);
+              int sw[NCH], cmax = -0x40000000;   // (not INT_MIN: the wave maximum negates it)
+#pragma unroll
+              for (int c = 0; c < NCH; ++c) {
+                sw[c] = (-(2 * cur[c] - kk[c]) - s) / 2;
+                if (cur[c] >= 0) cmax = max(cmax, sw[c]);
+              }
+              cmax = wave_max_dpp(cmax);
+              if (have_max_sw) {
+                unsigned long long ok[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) ok[c] = __ballot(cur[c] >= 0 && max_sw - sw[c] < a.xdrop);
+                const int fp = BD::first_pos(ok), lp = BD::last_pos(ok);
+                const int new_lo = (fp < W) ? B + fp : hi + 1, new_hi = (fp < W) ? B + lp : hi;
+                if (new_lo != lo || new_hi != hi) {
+#pragma unroll
+                  for (int c = 0; c < NCH; ++c) {
+                    const bool drop = kk[c] < new_lo || kk[c] > new_hi;
+                    if (drop) { cur[c] = WFA_OFFSET_NULL; Ih[0][c] = WFA_OFFSET_NULL; Dh[0][c] = WFA_OFFSET_NULL; I2h[0][c] = WFA_OFFSET_NULL; D2h[0][c] = WFA_OFFSET_NULL; }
+                  }
+                }
+                if (cmax > max_sw) max_sw = cmax;
+              } else {
+                max_sw = cmax; have_max_sw = 1;
+              }
+              steps_wait = a.steps_between;
+            }
+          } else if (ADAPT) {
             --steps_wait;
             if (steps_wait <= 0) {
               const int lo = B + BD::first_pos(live), hi = B + BD::last_pos(live);
@@ -453,7 +494,8 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
         } else {
           // nothing alive at this score; if the whole ring is dead the reference ends "unreachable"
           // after its null-step count runs out: leave that rare case to the general kernel
-          if (++dead_steps > 2 * DM + 2) { fallback = true; break; }
+          // (without a heuristic that cannot last: leave it to the general kernel; with one, the null-step count below ends it)
+          if (!ADAPT && ++dead_steps > 2 * DM + 2 + (TWO ? OE2 : 0)) { fallback = true; break; }
         }
         // ---------------- history of score s (after the cut-off, so dropped lanes read NULL) ----------------
         const int si = step;  // = s / g
@@ -650,13 +692,31 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
 #pragma unroll
           for (int c = 0; c < NCH; ++c) { I2h[0][c] = ni2[c]; D2h[0][c] = nd2[c]; }
         }
+        // ---------------- limits (R/wavefront_unialign.c:98-107, R/wavefront_extend.c:97-104) ----------------
+        // The reference walks every integer score; here only multiples of g exist, the scores in between are null steps.
+        // A run of more than `scope` null scores after the last non-null one ends the alignment "unreachable" at score
+        // t = last + scope + 1; the step limit ends it at the first score >= max_steps; whichever comes first (the
+        // limit is tested after compute-next of a score, the null-step count at its extension: the limit wins a tie).
+        {
+          const bool null_step = !__any(insig >= 0);
+          const int t_unreach = last_nonnull + a.scope + 1;
+          const bool unreach = ADAPT && (t_unreach < s || (t_unreach == s && null_step));
+          const bool limit = s >= a.max_steps;
+          if (limit && (!unreach || a.max_steps <= t_unreach)) { stop_status = WFA_STATUS_MAX_STEPS_REACHED; stop_score = -a.max_steps; break; }
+          if (unreach) { stop_status = WFA_STATUS_PARTIAL; stop_score = FULL ? INT_MIN : -t_unreach; break; }
+          if (!null_step) last_nonnull = s;
+        }
         if (step > (1 << 24)) { fallback = true; break; }
       }
-      if (!done) fallback = true;
+      if (!done && stop_status == 0) fallback = true;
+    }
+    if (FULL && stop_status != 0 && lane == 0) {   // no end cell: no walk, empty op string (R/wavefront_unialign.c:147-237)
+      a.cigar_begin[pair] = a.cigar_off[pair + 1];
+      a.cigar_len[pair] = 0;
     }
     if (split) {
-      if (lane == 0) a.end_state[wi - w0] = make_int4(end_s, end_k, end_off, fallback ? 0 : 1);
-    } else if (FULL && !SPLIT && !fallback) {
+      if (lane == 0) a.end_state[wi - w0] = make_int4(end_s, end_k, end_off, (fallback || stop_status != 0) ? 0 : 1);
+    } else if (FULL && !SPLIT && !fallback && stop_status == 0) {
       // make this wave's history stores visible to its own loads
       __syncthreads();
       long long begin = 0;
@@ -671,6 +731,9 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
       if (fallback) {
         a.status[pair] = WFA_INTERNAL_FALLBACK;
         a.fb_list[atomicAdd(a.fb_count, 1u)] = pair;
+      } else if (stop_status != 0) {
+        a.score[pair] = stop_score;
+        a.status[pair] = stop_status;
       } else {
         a.score[pair] = result;
         a.status[pair] = 0;
@@ -987,9 +1050,10 @@ inline int band_gcd(const WfaDevConfig& c, bool two) {
   if (two) g = gcd_int(gcd_int(g, c.o2 + c.e2), c.e2);
   return g;
 }
+// none / wf-adaptive / X-drop, with or without a step limit
 inline bool band_supported(const WfaDevConfig& c, int ncomp) {
-  if ((ncomp != 3 && ncomp != 5) || c.match != 0 || c.wildcard >= 0 || c.max_steps != INT_MAX) return false;
-  if (c.heuristic != 0 && c.heuristic != 1) return false;
+  if ((ncomp != 3 && ncomp != 5) || c.match != 0 || c.wildcard >= 0) return false;
+  if (c.heuristic < 0 || c.heuristic > 2) return false;
   const bool two = ncomp == 5;
   const int g = band_gcd(c, two);
   const int X = c.x / g, OE = (c.o1 + c.e1) / g, E = c.e1 / g;

@@ -845,7 +845,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     uint32_t in_n = b->n_packed;
     int out_sel = 0;                               // leftovers go to d_fb_list[out_sel], count d_counters[4 + out_sel]
     bool first_stage = true;
-    const bool adapt = (b->dcfg.heuristic == WFA_HEUR_ADAPTIVE);
+    const bool adapt = (b->dcfg.heuristic != WFA_HEUR_NONE);  // the heuristic instantiations of the banded kernel (wf-adaptive / X-drop)
     // the general kernel's geometry is fixed first so that one workspace allocation serves every stage
     int n_stages = 0;
     int band_nch[3] = {0, 0, 0};
@@ -1063,6 +1063,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       ba.x = b->dcfg.x; ba.oe = b->dcfg.o1 + b->dcfg.e1; ba.e = b->dcfg.e1;
       if (b->ncomp == 5) { ba.oe2 = b->dcfg.o2 + b->dcfg.e2; ba.e2 = b->dcfg.e2; }
       ba.min_wf_len = b->dcfg.min_wf_len; ba.max_dist_thr = b->dcfg.max_dist_thr; ba.steps_between = b->dcfg.steps_between;
+      ba.heur = b->dcfg.heuristic; ba.xdrop = b->dcfg.xdrop; ba.max_steps = b->dcfg.max_steps; ba.scope = b->dcfg.scope;
       const int words = ((b->max_len + 15) >> 4) + 4;
       const bool seqlds = ((size_t)words * 8 <= 5120) && knob(al, K_BAND_NO_LDS, 0) == 0;
       ba.lds_words = seqlds ? words : 0;

@@ -1,120 +1,90 @@
-// issue_rate.hip — microbenchmark (development aid): how many cycles does a SIMD / the CU's
-// scalar unit need per wave-instruction on this chip, at 1, 2, 4 and 8 resident waves per SIMD?
-//   valu:  independent v_max_i32 / v_alignbit_b32 streams
-//   salu:  independent s_add_u32 / s_and_b64 / s_bcnt1 streams
-//   mixed: the two interleaved 1:1 (do the vector and the scalar unit overlap across waves?)
-// Build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 tools/issue_rate.hip -o /tmp/issue_rate && /tmp/issue_rate
-// Every wave stamps s_memtime around its loop; the figure printed is the mean wave duration divided by the
-// wave-instructions the SIMD (valu) or the CU (salu: one scalar unit per CU, 4 SIMDs x w waves) had to issue.
+// issue_rate.hip — microbenchmark (development aid): what does one wave64 vector instruction
+// cost a SIMD of this chip, by instruction type and by resident waves per SIMD?
+//
+// One workgroup per CU of 256 x w threads (w = 1, 2, 4 waves on each of the CU's four SIMDs; 8 = two such workgroups of
+// 1024 threads per CU), every wave runs the same long loop of 32 independent instructions of ONE type; the kernel is
+// long enough (tens of ms) for the wall clock to be the measure.  v_fma_f32 is the yardstick: the CDNA4 guide gives it
+// 2 cycles per wave64 instruction at >= 2 waves per SIMD (SIMD-32), so cycles(X) = 2 x time(X) / time(v_fma_f32 at w >= 2).
+//   hipcc --offload-arch=gfx950 -O3 tools/issue_rate.hip -o /tmp/issue_rate && /tmp/issue_rate
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include <string>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-constexpr int ITERS = 4096;
+constexpr int ITERS = 60000;   // x 32 instructions per iteration
 
-__global__ void __launch_bounds__(64) k_valu(unsigned long long* out, int* sink) {
-  int a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
-  const unsigned long long t0 = __builtin_readcyclecounter();
-  for (int i = 0; i < ITERS; ++i) {
-    asm volatile(
-        "v_max_i32 %0, %0, %8\n v_alignbit_b32 %1, %1, %1, 3\n v_max_i32 %2, %2, %8\n v_alignbit_b32 %3, %3, %3, 5\n"
-        "v_max_i32 %4, %4, %8\n v_alignbit_b32 %5, %5, %5, 7\n v_max_i32 %6, %6, %8\n v_alignbit_b32 %7, %7, %7, 9\n"
-        "v_max_i32 %0, %0, %8\n v_alignbit_b32 %1, %1, %1, 3\n v_max_i32 %2, %2, %8\n v_alignbit_b32 %3, %3, %3, 5\n"
-        "v_max_i32 %4, %4, %8\n v_alignbit_b32 %5, %5, %5, 7\n v_max_i32 %6, %6, %8\n v_alignbit_b32 %7, %7, %7, 9\n"
-        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(i));
+#define REP8(S) S S S S S S S S
+#define BODY(INSTR0, INSTR1, INSTR2, INSTR3)                                                                     \
+  for (int i = 0; i < ITERS; ++i) {                                                                              \
+    asm volatile(REP8(INSTR0 "\n" INSTR1 "\n" INSTR2 "\n" INSTR3 "\n")                                           \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(i), "v"(c0), "s"(m0) : "vcc");                           \
   }
-  const unsigned long long t1 = __builtin_readcyclecounter();
-  if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
-  if ((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) == 0x12345) *sink = 1;
-}
 
-__global__ void __launch_bounds__(64) k_salu(unsigned long long* out, int* sink) {
-  unsigned s0 = blockIdx.x, s1 = s0 + 1, s2 = s0 + 2, s3 = s0 + 3;
-  unsigned long long m0 = blockIdx.x * 77ull, m1 = m0 + 5, m2 = m0 + 9, m3 = m0 + 11;
-  const unsigned long long t0 = __builtin_readcyclecounter();
-  for (int i = 0; i < ITERS; ++i) {
-    asm volatile(
-        "s_add_u32 %0, %0, 3\n s_and_b64 %4, %4, %5\n s_add_u32 %1, %1, 5\n s_or_b64 %5, %5, %6\n"
-        "s_add_u32 %2, %2, 7\n s_lshl_b64 %6, %6, 1\n s_add_u32 %3, %3, 9\n s_xor_b64 %7, %7, %4\n"
-        "s_add_u32 %0, %0, 3\n s_and_b64 %4, %4, %5\n s_add_u32 %1, %1, 5\n s_or_b64 %5, %5, %6\n"
-        "s_add_u32 %2, %2, 7\n s_lshl_b64 %6, %6, 1\n s_add_u32 %3, %3, 9\n s_xor_b64 %7, %7, %4\n"
-        : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(m0), "+s"(m1), "+s"(m2), "+s"(m3) : : "scc");
-  }
-  const unsigned long long t1 = __builtin_readcyclecounter();
-  if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
-  if ((s0 ^ s1 ^ s2 ^ s3 ^ (unsigned)m0 ^ (unsigned)m1 ^ (unsigned)m2 ^ (unsigned)m3) == 0x12345u) *sink = 1;
-}
-
-__global__ void __launch_bounds__(64) k_mixed(unsigned long long* out, int* sink) {
+template <int KIND>
+__global__ void __launch_bounds__(1024) k_issue(int* sink) {
   int a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
-  unsigned s0 = blockIdx.x, s1 = s0 + 1;
-  unsigned long long m0 = blockIdx.x * 77ull, m1 = m0 + 5;
-  const unsigned long long t0 = __builtin_readcyclecounter();
-  for (int i = 0; i < ITERS; ++i) {
-    asm volatile(
-        "v_max_i32 %0, %0, %8\n s_add_u32 %4, %4, 3\n v_alignbit_b32 %1, %1, %1, 3\n s_and_b64 %6, %6, %7\n"
-        "v_max_i32 %2, %2, %8\n s_add_u32 %5, %5, 5\n v_alignbit_b32 %3, %3, %3, 5\n s_or_b64 %7, %7, %6\n"
-        "v_max_i32 %0, %0, %8\n s_add_u32 %4, %4, 3\n v_alignbit_b32 %1, %1, %1, 3\n s_and_b64 %6, %6, %7\n"
-        "v_max_i32 %2, %2, %8\n s_add_u32 %5, %5, 5\n v_alignbit_b32 %3, %3, %3, 5\n s_or_b64 %7, %7, %6\n"
-        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(s0), "+s"(s1), "+s"(m0), "+s"(m1) : "v"(i) : "scc");
-  }
-  const unsigned long long t1 = __builtin_readcyclecounter();
-  if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
-  if ((a0 ^ a1 ^ a2 ^ a3 ^ (int)s0 ^ (int)s1 ^ (int)m0 ^ (int)m1) == 0x12345) *sink = 1;
+  const int c0 = threadIdx.x * 3 + 1;
+  const unsigned long long m0 = 0x5555555555555555ull;
+  if (KIND == 0) { BODY("v_fma_f32 %0, %0, %5, %4", "v_fma_f32 %1, %1, %5, %4", "v_fma_f32 %2, %2, %5, %4", "v_fma_f32 %3, %3, %5, %4") }
+  if (KIND == 1) { BODY("v_max_i32 %0, %0, %4", "v_max_i32 %1, %1, %4", "v_max_i32 %2, %2, %4", "v_max_i32 %3, %3, %4") }
+  if (KIND == 2) { BODY("v_alignbit_b32 %0, %0, %5, 3", "v_alignbit_b32 %1, %1, %5, 5", "v_alignbit_b32 %2, %2, %5, 7", "v_alignbit_b32 %3, %3, %5, 9") }
+  if (KIND == 3) { BODY("v_add_u32 %0, %0, %4", "v_add_u32 %1, %1, %4", "v_add_u32 %2, %2, %4", "v_add_u32 %3, %3, %4") }
+  if (KIND == 4) { BODY("v_pk_max_i16 %0, %0, %5", "v_pk_max_i16 %1, %1, %5", "v_pk_add_i16 %2, %2, %5", "v_pk_add_i16 %3, %3, %5") }
+  if (KIND == 5) { BODY("v_cndmask_b32 %0, %0, %5, %6", "v_cndmask_b32 %1, %1, %5, %6", "v_cndmask_b32 %2, %2, %5, %6", "v_cndmask_b32 %3, %3, %5, %6") }
+  if (KIND == 6) { BODY("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf",
+                        "v_mov_b32_dpp %2, %3 row_shl:1 row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp %3, %0 row_shl:1 row_mask:0xf bank_mask:0xf") }
+  if (KIND == 7) { BODY("v_ffbl_b32 %0, %0", "v_ffbl_b32 %1, %1", "v_xor_b32 %2, %2, %5", "v_min_u32 %3, %3, %5") }
+  if (KIND == 8) { BODY("v_and_b32 %0, %0, %4", "v_or_b32 %1, %1, %4", "v_xor_b32 %2, %2, %4", "v_and_b32 %3, %3, %5") }
+  if (KIND == 9) { BODY("v_lshlrev_b32 %0, 1, %0", "v_lshrrev_b32 %1, 1, %1", "v_ashrrev_i32 %2, 1, %2", "v_lshlrev_b32 %3, 3, %3") }
+  if (KIND == 10) { BODY("v_sub_u32 %0, %0, %4", "v_sub_u32 %1, %1, %4", "v_add3_u32 %2, %2, %4, %5", "v_lshl_add_u32 %3, %3, 2, %4") }
+  if (KIND == 11) { BODY("v_cmp_gt_i32 vcc, %0, %4", "v_cndmask_b32 %1, %1, %5, vcc", "v_cmp_lt_i32 vcc, %2, %4", "v_cndmask_b32 %3, %3, %5, vcc") }
+  if ((a0 ^ a1 ^ a2 ^ a3) == 0x12345) *sink = 1;
 }
 
-// LDS reads, three dwords per instruction-triple like the extension round of wfa_seg.hpp
-__global__ void __launch_bounds__(64) k_lds(unsigned long long* out, int* sink) {
-  __shared__ uint32_t lds[1024];
-  for (int i = threadIdx.x; i < 1024; i += 64) lds[i] = i * 2654435761u;
-  __syncthreads();
-  uint32_t acc = 0; int idx = threadIdx.x;
-  const unsigned long long t0 = __builtin_readcyclecounter();
-  for (int i = 0; i < ITERS; ++i) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc ^= lds[(idx + j * 37 + i) & 1023];
-  }
-  const unsigned long long t1 = __builtin_readcyclecounter();
-  if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
-  if (acc == 0x12345u) *sink = 1;
-}
-
-template <typename K>
-static void run(const char* name, K kern, int cus, double per_unit_div) {
-  for (int w : {1, 2, 4, 8}) {
-    const int grid = cus * 4 * w;
-    unsigned long long* d; int* sink;
-    CHECK(hipMalloc(&d, grid * sizeof(unsigned long long))); CHECK(hipMalloc(&sink, 4));
-    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, 0, d, sink);  // warm-up
-    CHECK(hipDeviceSynchronize());
-    CHECK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, 0, d, sink);
-    CHECK(hipEventRecord(e1, 0));
-    CHECK(hipDeviceSynchronize());
-    float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
-    std::vector<unsigned long long> h(grid);
-    CHECK(hipMemcpy(h.data(), d, grid * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    double mean = 0; for (auto v : h) mean += (double)v; mean /= grid;
-    const double insts_wave = (double)ITERS * 16;
-    // per SIMD: w waves share it; per CU: 4 w waves share the scalar unit
-    printf("%-6s waves/SIMD=%d  wave duration %.0f ticks (%.3f ms wall)  ticks per wave-instruction: per wave %.2f, per SIMD %.2f, per CU %.3f\n",
-           name, w, mean, ms, mean / insts_wave, mean / (insts_wave * w), mean / (insts_wave * w * 4));
-    (void)per_unit_div;
-    CHECK(hipFree(d)); CHECK(hipFree(sink)); CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
-  }
+template <int KIND>
+static double run_kind(int cus, int w) {
+  const int threads = (w == 8) ? 1024 : 256 * w;
+  const int grid = (w == 8) ? 2 * cus : cus;
+  int* sink; CHECK(hipMalloc(&sink, 4));
+  hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k_issue<KIND>, dim3(grid), dim3(threads), 0, 0, sink);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(k_issue<KIND>, dim3(grid), dim3(threads), 0, 0, sink);
+  CHECK(hipEventRecord(e1, 0));
+  CHECK(hipDeviceSynchronize());
+  float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+  CHECK(hipFree(sink)); CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
+  return ms;
 }
 
 int main() {
   hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
-  printf("device %s, %d CUs, clock %d kHz; readcyclecounter = s_memtime (100 MHz constant clock on some parts: see wall ms)\n",
-         p.gcnArchName, p.multiProcessorCount, p.clockRate);
-  run("valu", k_valu, p.multiProcessorCount, 1);
-  run("salu", k_salu, p.multiProcessorCount, 4);
-  run("mixed", k_mixed, p.multiProcessorCount, 1);
-  run("lds", k_lds, p.multiProcessorCount, 1);
+  const int cus = p.multiProcessorCount;
+  printf("device %s, %d CUs; %d x 32 wave-instructions per wave; per SIMD = w waves\n", p.gcnArchName, cus, ITERS);
+  const char* names[12] = {"v_fma_f32", "v_max_i32", "v_alignbit_b32", "v_add_u32", "v_pk_max/add_i16", "v_cndmask_b32(sgpr mask)", "v_mov_b32_dpp", "ffbl/xor/min mix", "v_and/or/xor_b32", "v_lsh*_b32", "v_sub/add3/lshl_add", "v_cmp + v_cndmask(vcc)"};
+  double ms[12][4];
+  const int ws[4] = {1, 2, 4, 8};
+  for (int wi = 0; wi < 4; ++wi) {
+    const int w = ws[wi];
+    ms[0][wi] = run_kind<0>(cus, w); ms[1][wi] = run_kind<1>(cus, w); ms[2][wi] = run_kind<2>(cus, w); ms[3][wi] = run_kind<3>(cus, w);
+    ms[4][wi] = run_kind<4>(cus, w); ms[5][wi] = run_kind<5>(cus, w); ms[6][wi] = run_kind<6>(cus, w); ms[7][wi] = run_kind<7>(cus, w);
+    ms[8][wi] = run_kind<8>(cus, w); ms[9][wi] = run_kind<9>(cus, w); ms[10][wi] = run_kind<10>(cus, w); ms[11][wi] = run_kind<11>(cus, w);
+  }
+  // yardstick: v_fma_f32 at 4 waves per SIMD = 2 cycles per wave-instruction per SIMD
+  const double insts4 = (double)ITERS * 32 * 4;
+  const double clock_ghz = insts4 * 2.0 / (ms[0][2] * 1e6);
+  printf("implied shader clock from v_fma_f32 @ 4 waves/SIMD = 2 cycles: %.3f GHz\n", clock_ghz);
+  for (int k = 0; k < 12; ++k) {
+    printf("%-26s", names[k]);
+    for (int wi = 0; wi < 4; ++wi) {
+      const double insts = (double)ITERS * 32 * ws[wi];
+      printf("  w=%d: %7.3f ms = %5.3f ns = %5.2f cyc /instr/SIMD", ws[wi], ms[k][wi], ms[k][wi] * 1e6 / insts, ms[k][wi] * 1e6 * clock_ghz / insts);
+    }
+    printf("\n");
+  }
   return 0;
 }

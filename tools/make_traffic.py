@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""profiles/traffic_c2.json from the counter passes of tools/gpu_counters.sh (development aid).
+
+    python tools/make_traffic.py gpurun_out r02p        # reads gpurun_out/r02p_pmc_{fetch,write,sq1,sq2}, writes profiles/
+
+HBM bytes of one C2 step = sum over the alignment kernels of (FETCH_SIZE x 2 [gfx950 correction, MI355X_MICROARCH.md HBM
+section] + WRITE_SIZE), per dispatch; the on-chip figures of the dominant kernel go into "secondary".  The file is stamped
+with the hash of the kernel sources it was measured on: bench.py uses it only when that hash matches the running build."""
+import csv, glob, json, os, subprocess, sys, collections
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+import bench
+
+root, tag = sys.argv[1], sys.argv[2]
+def per_dispatch(name):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(set)
+    for f in glob.glob(os.path.join(root, f"{tag}_pmc_{name}", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            kn = r["Kernel_Name"]
+            acc[kn][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[kn].add(r["Dispatch_Id"])
+    return {kn: {c: v / max(len(cnt[kn]), 1) for c, v in d.items()} for kn, d in acc.items()}, {kn: len(v) for kn, v in cnt.items()}
+
+def is_align(kn):
+    return any(x in kn for x in ("wfa_lane_kernel", "wfa_seg_kernel", "wfa_band_kernel", "wfa_general_kernel")) and "false, false>" not in kn.split("wfa_seg_kernel")[-1][:40] or "wfa_lane_kernel" in kn
+
+fetch, nf = per_dispatch("fetch"); write, _ = per_dispatch("write"); sq1, _ = per_dispatch("sq1"); sq2, _ = per_dispatch("sq2")
+# kernels of one step: every alignment kernel except the pilot's one-round segments (<..,16,false,false> etc. run once per batch)
+step_kernels = [k for k in fetch if ("wfa_lane_kernel" in k or "true, false>" in k or "wfa_band_kernel" in k or "wfa_general_kernel" in k)]
+fetch_kb = sum(fetch[k].get("FETCH_SIZE", 0.0) for k in step_kernels)
+write_kb = sum(write.get(k, {}).get("WRITE_SIZE", 0.0) for k in step_kernels)
+dom = max(step_kernels, key=lambda k: sq1.get(k, {}).get("GRBM_GUI_ACTIVE", 0.0))
+s1, s2 = sq1[dom], sq2[dom]
+cycles = s1["GRBM_GUI_ACTIVE"] / 8.0              # summed over the 8 XCDs
+simds = 256 * 4
+sec = {
+    "kernel": dom.split("(")[0],
+    "bound": "valu_issue",
+    "what": "SQ_ACTIVE_INST_VALU (quad-cycles: a wave64 integer VALU instruction holds its SIMD for 4 cycles, tools/issue_rate.hip) x 4 / "
+            "(GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)",
+    "frac": s1["SQ_ACTIVE_INST_VALU"] * 4.0 / (cycles * simds),
+    "valu_insts_per_dispatch": s2.get("SQ_INSTS_VALU"), "salu_insts_per_dispatch": s2.get("SQ_INSTS_SALU"), "lds_insts_per_dispatch": s2.get("SQ_INSTS_LDS"),
+    "salu_frac_of_cycles_per_cu": s2.get("SQ_INSTS_SALU", 0.0) / (cycles * 256),
+    "resident_waves_per_simd": s1["SQ_WAVE_CYCLES"] * 4.0 / (cycles * simds),
+    "wave_cycles_split": {"issuing": s2.get("SQ_ACTIVE_INST_ANY", 0.0) / s1["SQ_WAVE_CYCLES"], "issue_stalled": s1["SQ_WAIT_INST_ANY"] / s1["SQ_WAVE_CYCLES"],
+                          "waiting_on_counters": s2.get("SQ_WAIT_ANY", 0.0) / s1["SQ_WAVE_CYCLES"]},
+    "gpu_cycles_per_dispatch": cycles,
+}
+try:
+    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+except Exception:
+    head = None
+out = {
+    "workload": {"pairs_per_gpu": 10000000, "read_length": 150, "error": 0.02},
+    "kernels": [k.split("(")[0] for k in step_kernels],
+    "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
+    "hbm_bytes_per_launch": int(fetch_kb * 1024 * 2 + write_kb * 1024),
+    "correction": "gfx950: FETCH_SIZE tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE taken as is",
+    "secondary": sec,
+    "kernel_source_hash": bench.kernel_source_hash(), "git_head": head,
+    "source": f"rocprofv3 --pmc, separate passes (tools/gpu_counters.sh {tag}): profiles/{tag}_pmc_*.txt; python3 bench.py --steps 2 --warmup 1",
+}
+with open(os.path.join(ROOT, "profiles", "traffic_c2.json"), "w") as f:
+    json.dump(out, f, indent=1)
+print(json.dumps(out, indent=1))
