@@ -41,7 +41,7 @@ static thread_local std::string g_error;
   F(ARENA_KB) F(BAND_DEBUG) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
-  F(PIPE_CHUNK) F(PIPE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG)
+  F(PIPE_CHUNK) F(PIPE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
 enum WfaKnob {
 #define WFA_KNOB_ENUM(n) K_##n,
   WFA_KNOBS(WFA_KNOB_ENUM)
@@ -89,6 +89,10 @@ struct wfa_hip_aligner {
   std::vector<uint8_t*> pin_slot;
   std::vector<hipEvent_t> pin_ev;
   std::vector<char> pin_ev_recorded;   // the slot's event was recorded: its DMA must be over before the slot is refilled
+  // single calls of a pywfa-style loop (a handful of pairs): one pinned, device-visible staging block + its device copy,
+  // allocated once; the call is then host writes -> copy kernel -> alignment kernel -> one stream sync -> host reads
+  uint8_t* tiny_h = nullptr;
+  uint8_t* tiny_d = nullptr;
   size_t pin_slot_bytes = 0;
   int cu_count = 256;
   size_t total_mem = 0;
@@ -367,6 +371,8 @@ static void aligner_free(wfa_hip_aligner* al) {
   pool_drain(al);
   if (al->ws_event) (void)hipEventDestroy(al->ws_event);
   for (uint8_t* p : al->pin_slot) (void)hipHostFree(p);
+  if (al->tiny_h) (void)hipHostFree(al->tiny_h);
+  if (al->tiny_d) (void)hipFree(al->tiny_d);
   for (hipEvent_t e : al->pin_ev) (void)hipEventDestroy(e);
   if (al->stream) (void)hipStreamDestroy(al->stream);
   delete al;
@@ -1330,11 +1336,126 @@ extern "C" int wfa_hip_batch_rle_runs(wfa_hip_batch_t* b, uint8_t* run_code, int
 
 extern "C" int64_t wfa_hip_batch_fallback_pairs(const wfa_hip_batch_t* b) { return b ? b->last_fallback : 0; }
 
+// ---- the single-call path --------------------------------------------------------
+// pywfa's usual loop calls the aligner with ONE pair at a time (align.pyx:421-443).  For a handful of pairs the batch
+// machinery above (a dozen device arrays, uploads, the pack kernel, several result copies) is most of the call, so such
+// calls take this path: everything the kernels read is written by the host into one pinned block and moved to its
+// device copy by one small kernel; the general kernel (raw bytes: any alphabet, every configuration) aligns the pairs,
+// writing scores / statuses / op bytes straight into the pinned block; one stream synchronisation; the host copies
+// the results out.  No allocation, no memcpy call, no per-call environment lookup.
+static const int64_t TINY_MAX_PAIRS = 16;
+static const size_t TINY_IN_BYTES = (size_t)256 << 10, TINY_BLOCK_BYTES = (size_t)1 << 20;
+
+__global__ void __launch_bounds__(256) wfa_tiny_copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, int n16) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
+}
+
+// returns 1 when the call was served, 0 when it does not fit this path (the caller takes the batch path), < 0 on error
+static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const int64_t* p_off, const int32_t* p_len,
+                      const int64_t* t_off, const int32_t* t_len, int32_t* score, int32_t* status, uint8_t* cigar_ops,
+                      const int64_t* cigar_off, int64_t* cigar_begin, int32_t* cigar_len) {
+  const wfa_hip_config_t& c = al->cfg;
+  const bool full = c.scope == WFA_SCOPE_FULL;
+  if (n < 1 || n > TINY_MAX_PAIRS || knob(al, K_NO_TINY, 0)) return 0;
+  if (full && c.memory_mode == WFA_MEM_BIWFA) return 0;
+  if (!score || !status || (full && cigar_ops && (!cigar_off || !cigar_begin || !cigar_len))) return 0;
+  int64_t blob = 0, ops_total = 0;
+  int max_len = 0, max_width = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int pl = p_len[i], tl = t_len[i];
+    if (pl < 0 || tl < 0 || p_off[i] < 0 || t_off[i] < 0) { al->err = "negative length or offset"; return WFA_HIP_EINVAL; }
+    if (c.span == WFA_SPAN_ENDSFREE && (c.pattern_begin_free > pl || c.pattern_end_free > pl || c.text_begin_free > tl || c.text_end_free > tl)) {
+      al->err = "Ends-free parameters must be not larger than the sequences"; return WFA_HIP_EINVAL;
+    }
+    blob += (int64_t)((pl + 15) & ~15) + ((tl + 15) & ~15);
+    ops_total += (int64_t)pl + tl;
+    max_len = std::max(max_len, std::max(pl, tl)); max_width = std::max(max_width, pl + tl + 3);
+  }
+  // input region: meta, byte offsets, op-region starts, the bytes; output region: results and op bytes
+  const size_t o_meta = 0, o_pb = o_meta + (size_t)n * sizeof(WfaPairMeta), o_tb = o_pb + (size_t)n * 8, o_co = o_tb + (size_t)n * 8,
+               o_blob = (o_co + (size_t)(n + 1) * 8 + 15) & ~(size_t)15, in_bytes = (o_blob + (size_t)blob + 15) & ~(size_t)15;
+  const size_t o_score = TINY_IN_BYTES, o_status = o_score + (size_t)n * 4, o_cb = (o_status + (size_t)n * 4 + 7) & ~(size_t)7, o_cl = o_cb + (size_t)n * 8,
+               o_ops = (o_cl + (size_t)n * 4 + 15) & ~(size_t)15;
+  if (in_bytes > TINY_IN_BYTES || (full && o_ops + (size_t)ops_total + 16 > TINY_BLOCK_BYTES)) return 0;
+  HIP_TRY(al, hipSetDevice(al->device));
+  if (!al->tiny_h) {
+    HIP_TRY(al, hipHostMalloc((void**)&al->tiny_h, TINY_BLOCK_BYTES, hipHostMallocMapped));
+    HIP_TRY(al, hipMalloc((void**)&al->tiny_d, TINY_IN_BYTES));
+  }
+  uint8_t* h = al->tiny_h;
+  uint8_t* hd = nullptr;   // the pinned block as the device sees it
+  HIP_TRY(al, hipHostGetDevicePointer((void**)&hd, h, 0));
+  WfaPairMeta* meta = reinterpret_cast<WfaPairMeta*>(h + o_meta);
+  int64_t* pb = reinterpret_cast<int64_t*>(h + o_pb); int64_t* tb = reinterpret_cast<int64_t*>(h + o_tb); int64_t* co = reinterpret_cast<int64_t*>(h + o_co);
+  int64_t bo = 0, oo = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int pl = p_len[i], tl = t_len[i];
+    meta[i].p_woff = 0; meta[i].t_woff = 0; meta[i].plen = pl; meta[i].tlen = tl;
+    pb[i] = bo; memcpy(h + o_blob + bo, seqs + p_off[i], (size_t)pl); bo += (pl + 15) & ~15;
+    tb[i] = bo; memcpy(h + o_blob + bo, seqs + t_off[i], (size_t)tl); bo += (tl + 15) & ~15;
+    co[i] = oo; oo += (int64_t)pl + tl;
+  }
+  co[n] = oo;
+  // geometry of the general kernel (plan_general / initial_arena_ints for these few pairs)
+  int threads = (max_len > 2000 && c.heuristic != WFA_HEUR_ADAPTIVE) ? 256 : 64;
+  threads = std::max(64, std::min(512, (knob(al, K_THREADS, threads) / 64) * 64));
+  int64_t stride;
+  if (full) {
+    const int mi = 2 * al->ncomp + 4;
+    stride = std::max<int64_t>((int64_t)max_len * (al->ncomp * 64 + mi) / 4 + (int64_t)max_width * al->ncomp * 4 + 4096 * mi, 1 << 14);
+  } else {
+    stride = (int64_t)al->dcfg.scope * al->ncomp * max_width;
+  }
+  stride = (stride + 63) & ~63ll;
+  int rc = ensure_ws(al, (size_t)n * stride * 4);
+  if (rc != WFA_HIP_OK) return rc;
+  hipStream_t stream = al->stream;
+  if (al->ws_event_recorded && al->ws_last_stream != stream) HIP_TRY(al, hipStreamWaitEvent(stream, al->ws_event, 0));
+  const int n16 = (int)(in_bytes / 16);
+  hipLaunchKernelGGL(wfa_tiny_copy_kernel, dim3(std::min(64, (n16 + 255) / 256)), dim3(256), 0, stream,
+                     reinterpret_cast<uint4*>(al->tiny_d), reinterpret_cast<const uint4*>(hd), n16);
+  WfaKernelArgs a;
+  memset(&a, 0, sizeof(a));
+  a.bytes = al->tiny_d + o_blob; a.meta = reinterpret_cast<const WfaPairMeta*>(al->tiny_d + o_meta);
+  a.p_boff = reinterpret_cast<const int64_t*>(al->tiny_d + o_pb); a.t_boff = reinterpret_cast<const int64_t*>(al->tiny_d + o_tb);
+  a.cigar_off = reinterpret_cast<const int64_t*>(al->tiny_d + o_co);
+  a.nwork = (uint32_t)n;
+  a.score = reinterpret_cast<int32_t*>(hd + o_score); a.status = reinterpret_cast<int32_t*>(hd + o_status);
+  a.cigar_begin = reinterpret_cast<int64_t*>(hd + o_cb); a.cigar_len = reinterpret_cast<int32_t*>(hd + o_cl); a.cigar_ops = hd + o_ops;
+  a.ws = al->ws; a.ws_stride = stride; a.cfg = al->dcfg;
+  // (no overflow list: an arena that is too small shows as status WFA_INTERNAL_OVERFLOW below and the call takes the batch path)
+  static uint32_t* const no_list = nullptr;
+  a.fb_list = no_list; a.fb_count = nullptr;
+  if (wfa::launch_general_any(al->ncomp, false, full, a, (int)n, threads, stream) != 0) { al->err = "general kernel launch failed"; return WFA_HIP_EDEVICE; }
+  HIP_TRY(al, hipEventRecord(al->ws_event, stream));
+  al->ws_event_recorded = true; al->ws_last_stream = stream;
+  HIP_TRY(al, hipStreamSynchronize(stream));
+  const int32_t* hs = reinterpret_cast<const int32_t*>(h + o_score); const int32_t* hst = reinterpret_cast<const int32_t*>(h + o_status);
+  for (int64_t i = 0; i < n; ++i) if (hst[i] == WFA_STATUS_OOM && full) return 0;   // arena too small for this pair: the batch path grows it
+  const int64_t* hcb = reinterpret_cast<const int64_t*>(h + o_cb); const int32_t* hcl = reinterpret_cast<const int32_t*>(h + o_cl);
+  for (int64_t i = 0; i < n; ++i) {
+    score[i] = hs[i]; status[i] = hst[i];
+    if (cigar_len) cigar_len[i] = full ? hcl[i] : 0;
+    if (cigar_begin) cigar_begin[i] = 0;
+    if (full && cigar_ops) {
+      const int64_t rel = hcb[i] - co[i];
+      if (hcl[i] > 0) memcpy(cigar_ops + cigar_off[i] + rel, h + o_ops + hcb[i], (size_t)hcl[i]);
+      cigar_begin[i] = cigar_off[i] + rel;
+    }
+  }
+  return 1;
+}
+
 extern "C" int wfa_hip_align_batch(wfa_hip_aligner_t* al, int64_t n, const uint8_t* seqs,
                                    const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len,
                                    int32_t* score, int32_t* status, uint8_t* cigar_ops, const int64_t* cigar_off,
                                    int64_t* cigar_begin, int32_t* cigar_len) {
   if (!al) return WFA_HIP_EINVAL;
+  if (n > 0 && n <= TINY_MAX_PAIRS && seqs && p_off && p_len && t_off && t_len) {
+    const int trc = align_tiny(al, n, seqs, p_off, p_len, t_off, t_len, score, status, cigar_ops, cigar_off, cigar_begin, cigar_len);
+    if (trc == 1) return WFA_HIP_OK;
+    if (trc < 0) return trc;
+  }
   const bool timing = al->knobs.set[K_TIMING];
   const double t0 = now_ms();
   // (the results call below synchronises the stream before this function returns, so the uploads need no wait of their own)
