@@ -134,7 +134,7 @@ def run_resident(al, batch, steps, warmup, want_cigar, barrier=None):
     return out
 
 
-def extra_config(name, n, length, error, seed, cfg_kw, scheme, trim=0, cpu_pairs=400, cpu_budget=4.0):
+def extra_config(name, n, length, error, seed, cfg_kw, scheme, survey_bytes, trim=0, cpu_pairs=400, cpu_budget=4.0):
     """One of the other BASELINE configurations on a stated prefix: kernel time, roofline, CPU baseline, parity."""
     from pywfa_amd import _native, datagen
     from oracle import loader
@@ -150,12 +150,9 @@ def extra_config(name, n, length, error, seed, cfg_kw, scheme, trim=0, cpu_pairs
     r = run_resident(al, batch, 3, 1, full)
     al.close()
     wc = work_counts(batch, cfg_kw, 8 if length >= 5000 else 2000)
-    # algorithmic HBM bytes per pair: packed sequences in + results out (+ op bytes) + the wavefront
-    # history written once: 4 B per offset (explicit scheme) or 8 B per 15 offsets (piggy-back blocks); score scope: none
-    hist = 0.0
-    if full and length > 1000:
-        hist = wc["offsets_per_pair"] * (4.0 if scheme == "explicit" else 8.0 / 15.0)
-    bytes_pair = r["io_bytes"] / n + hist
+    # algorithmic HBM bytes per pair: SURVEY.md §8(d)'s per-unit figure for this configuration and history scheme
+    # (packed sequences in + results / op bytes out + the wavefront history written once)
+    bytes_pair = float(survey_bytes)
     achieved = bytes_pair * n / (r["kernel_ms"] * 1e-3) / 1e9
     cpu, n_cpu, res = cpu_reference(batch, cfg_kw, cpu_pairs, cpu_budget, full)
     rate = n / (r["elapsed"] / 3)
@@ -164,7 +161,8 @@ def extra_config(name, n, length, error, seed, cfg_kw, scheme, trim=0, cpu_pairs
             "kernel_ms": r["kernel_ms"], "ms_per_step": r["elapsed"] / 3 * 1e3, "alignments_per_s": rate,
             "offsets_per_s": rate * wc["offsets_per_pair"], "work": wc,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "bytes_per_pair": bytes_pair},
+                         "bytes_per_pair": bytes_pair, "bytes_per_pair_source": "SURVEY.md §8(d)",
+                         "io_bytes_per_pair_measured": r["io_bytes"] / n},
             "completed": int((r["status"] == 0).sum()), "handed_to_general_kernel": int(r["fallback"]),
             "cpu_baseline": cpu, "speedup_vs_1_thread": rate / cpu["value"],
             "parity_checked_pairs": n_cpu, "parity_mismatches": parity(res, n_cpu, r["score"], r["status"], r["cig"])}
@@ -348,20 +346,21 @@ def main():
         if n_gpus == 1 and not args.no_extra_configs:
             xs = []
             try:
-                xs.append(extra_config("C1", 1_000_000, 150, 0.02, datagen.SEEDS["C1"], dict(scope="full"), "explicit",
+                xs.append(extra_config("C1", 1_000_000, 150, 0.02, datagen.SEEDS["C1"], dict(scope="full"), "explicit", 236,
                                        cpu_pairs=200000, cpu_budget=3.0))
                 xs.append(extra_config("C3", 100_000, 10000, 0.08, datagen.SEEDS["C3"],
-                                       dict(span="end-to-end", scope="full", heuristic="adaptive"), "explicit"))
+                                       dict(span="end-to-end", scope="full", heuristic="adaptive"), "explicit", 750e3))
                 xs.append(extra_config("C3-piggyback", 100_000, 10000, 0.08, datagen.SEEDS["C3"],
-                                       dict(span="end-to-end", scope="full", heuristic="adaptive", memory_mode="medium"), "piggyback"))
+                                       dict(span="end-to-end", scope="full", heuristic="adaptive", memory_mode="medium"), "piggyback", 114e3))
                 xs.append(extra_config("C4-adaptive", 20_000, 10000, 0.08, datagen.SEEDS["C4"],
                                        dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100,
-                                            scope="full", heuristic="adaptive"), "explicit", trim=50, cpu_pairs=100))
+                                            scope="full", heuristic="adaptive"), "explicit", 750e3 * 5 / 3, trim=50, cpu_pairs=100))
             except Exception as e:
                 xs.append({"error": repr(e)})
             out["extra"]["configs"] = xs
-            out["extra"]["configs_note"] = ("stated prefixes of the BASELINE streams (C1 1 M of 1 k..., C3 100 k of 1 M, C4 20 k of 1 M with "
-                                            "wf-adaptive: the exact form writes ~0.4 GB of history per pair); C2 above is the full 10 M")
+            out["extra"]["configs_note"] = ("stated prefixes of the BASELINE streams: C1 at 1 M pairs (BASELINE names 1 k), C3 100 k of 1 M, "
+                                            "C4 20 k of 1 M with wf-adaptive (stated: the exact form writes ~0.4 GB of history per pair; its "
+                                            "bytes per pair are C3's figure x 5/3 components); C2 above is the full 10 M")
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -32,14 +32,34 @@ dom = max(step_kernels, key=lambda k: sq1.get(k, {}).get("GRBM_GUI_ACTIVE", 0.0)
 s1, s2 = sq1[dom], sq2[dom]
 cycles = s1["GRBM_GUI_ACTIVE"] / 8.0              # summed over the 8 XCDs
 simds = 256 * 4
+# cost of a wave64 vector instruction per SIMD, measured by wall clock (tools/issue_rate.hip, 4 waves per SIMD): plain
+# add / logic ops ("full rate") vs min / max / alignbit / cndmask / shifts / pk / dpp ("half rate")
+def issue_ns(label):
+    for line in open(os.path.join(root, f"{tag}_issue_rate.txt")):
+        if line.startswith(label):
+            part = line.split("w=4:")[1]
+            return float(part.split("=")[1].split("ns")[0])
+    return None
+t_full, t_half = issue_ns("v_add_u32"), issue_ns("v_max_i32")
+kernel_ns = None
+for r in csv.DictReader(open(os.path.join(root, f"{tag}_kernel_stats.csv"))):
+    if dom.split("(")[0] in r["Name"]:
+        kernel_ns = float(r["AverageNs"])
+FULL_RATE_SHARE = 0.32   # v_add / v_and / v_or / v_xor / v_mov among the kernel's vector instructions (static count of its ISA)
+valu = s2.get("SQ_INSTS_VALU", 0.0)
+issue_ms = valu / simds * (FULL_RATE_SHARE * t_full + (1 - FULL_RATE_SHARE) * t_half) * 1e-6
 sec = {
     "kernel": dom.split("(")[0],
     "bound": "valu_issue",
-    "what": "SQ_ACTIVE_INST_VALU (quad-cycles: a wave64 integer VALU instruction holds its SIMD for 4 cycles, tools/issue_rate.hip) x 4 / "
-            "(GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)",
-    "frac": s1["SQ_ACTIVE_INST_VALU"] * 4.0 / (cycles * simds),
-    "valu_insts_per_dispatch": s2.get("SQ_INSTS_VALU"), "salu_insts_per_dispatch": s2.get("SQ_INSTS_SALU"), "lds_insts_per_dispatch": s2.get("SQ_INSTS_LDS"),
-    "salu_frac_of_cycles_per_cu": s2.get("SQ_INSTS_SALU", 0.0) / (cycles * 256),
+    "what": "vector-issue time of the kernel's instruction stream = SQ_INSTS_VALU / 1024 SIMDs x the measured cost of a wave64 vector "
+            "instruction on this chip (tools/issue_rate.hip, wall clock: full-rate add/logic ops and half-rate min/max/alignbit/cndmask/"
+            "shift/pk/dpp ops, weighted by the kernel's static instruction mix), divided by the kernel's average duration (rocprofv3 --stats)",
+    "frac": issue_ms / (kernel_ns * 1e-6),
+    "valu_issue_ms": issue_ms, "kernel_ms": kernel_ns * 1e-6,
+    "ns_per_full_rate_instr": t_full, "ns_per_half_rate_instr": t_half, "full_rate_share": FULL_RATE_SHARE,
+    "frac_if_all_half_rate": valu / simds * t_half * 1e-6 / (kernel_ns * 1e-6), "frac_if_all_full_rate": valu / simds * t_full * 1e-6 / (kernel_ns * 1e-6),
+    "valu_insts_per_dispatch": valu, "salu_insts_per_dispatch": s2.get("SQ_INSTS_SALU"), "lds_insts_per_dispatch": s2.get("SQ_INSTS_LDS"),
+    "salu_insts_per_cycle_per_cu": s2.get("SQ_INSTS_SALU", 0.0) / (cycles * 256),
     "resident_waves_per_simd": s1["SQ_WAVE_CYCLES"] * 4.0 / (cycles * simds),
     "wave_cycles_split": {"issuing": s2.get("SQ_ACTIVE_INST_ANY", 0.0) / s1["SQ_WAVE_CYCLES"], "issue_stalled": s1["SQ_WAIT_INST_ANY"] / s1["SQ_WAVE_CYCLES"],
                           "waiting_on_counters": s2.get("SQ_WAIT_ANY", 0.0) / s1["SQ_WAVE_CYCLES"]},
