@@ -207,8 +207,8 @@ def dist_max(dist, backend, value):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=10_000_000, help="pairs per GPU")
     ap.add_argument("--length", type=int, default=150)
     ap.add_argument("--error", type=float, default=0.02)

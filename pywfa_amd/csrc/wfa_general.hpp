@@ -256,9 +256,17 @@ __device__ __forceinline__ int classic_score(const WfaDevConfig& cfg, int v, int
   return ((-cfg.match) * (v + h) - s) / 2;
 }
 
-template <int NCOMP, bool PACKED, bool FULL>
+// PB (with FULL): the piggy-back form of the history (R/wavefront_backtrace_offload.c, R/wavefront_pcigar.c): the
+// offsets live in the score-only ring, the history keeps ONE BYTE of origin codes per (score, diagonal) — which candidate made M
+// (gap-affine: mismatch / deletion / insertion; 2p: mismatch / D1 / D2 / I1 / I2, in the backtrace's priority order) and
+// open-or-extend for every gap component — plus a 12-byte directory record per score; the walk follows the codes back from the
+// end cell and the op string is unpacked forwards, re-extending the matches (a wavefront cell is always extended to its end).
+// 20x less history than the explicit arena for gap-affine-2p (exact C4: ~0.4 GB -> ~20 MB per pair).
+template <int NCOMP, bool PACKED, bool FULL, bool PB = false>
 __global__ void __launch_bounds__(512)
 wfa_general_kernel(const WfaKernelArgs a) {
+  static_assert(!PB || (FULL && NCOMP >= 3), "piggy-back history: full scope, gap-affine / gap-affine-2p");
+  constexpr bool RING = !FULL || PB;   // offsets in the modular ring of `scope` wavefronts
   typedef Meta<NCOMP> MT;
   extern __shared__ int smem[];
   const WfaDevConfig& cfg = a.cfg;
@@ -287,15 +295,20 @@ wfa_general_kernel(const WfaKernelArgs a) {
     const int rstride = plen + tlen + 3;   // ring: offsets of k in [-plen-1, tlen+1]
     const int rbase = -plen - 1;
     bool overflow = false;
-    if (!FULL && (long long)scope * NCOMP * rstride > ws_stride) overflow = true;
-    if (FULL && (long long)(tbf + pbf + 1) * NCOMP + 2 * MT::INTS > ws_stride) overflow = true;
+    const long long ring_ints = (long long)scope * NCOMP * rstride;
+    if (RING && ring_ints + (PB ? 64 : 0) > ws_stride) overflow = true;
+    if (FULL && !PB && (long long)(tbf + pbf + 1) * NCOMP + 2 * MT::INTS > ws_stride) overflow = true;
+    // PB: code bytes grow upwards from the end of the ring, directory records {lo, hi, byte base} downwards from the top
+    uint8_t* const pb_codes = PB ? reinterpret_cast<uint8_t*>(ws + ring_ints) : nullptr;
+    const long long pb_cap = PB ? (ws_stride - ring_ints) * 4 : 0;   // bytes shared by codes and directory
+    long long pb_used = 0;                                            // code bytes in use
 
     // ---- wavefront 0 ----
     int used = 0;  // FULL: ints of the arena in use
     int cur_lo = -pbf, cur_hi = tbf, cur_idx0, cur_exists = 1;
     {
-      const int base = FULL ? -pbf : rbase;
-      const int width = FULL ? (tbf + pbf + 1) : rstride;
+      const int base = !RING ? -pbf : rbase;
+      const int width = !RING ? (tbf + pbf + 1) : rstride;
       const int data = 0;
       cur_idx0 = data - base;
       __syncthreads();  // previous pair fully done with ring / scratch
@@ -310,7 +323,11 @@ wfa_general_kernel(const WfaKernelArgs a) {
       if (!overflow) {
         for (int k = -pbf + tid; k <= tbf; k += T) ws[cur_idx0 + k] = (k > 0) ? k : 0;
       }
-      if (FULL) used = NCOMP * width;
+      if (FULL && !PB) used = NCOMP * width;
+      if (PB && !overflow && tid == 0) {   // score 0 has no origin: a record with an empty range
+        int* d = ws + ws_stride - 3;
+        d[0] = 1; d[1] = 0; d[2] = 0;
+      }
     }
 
     int s = 0, null_steps = 0;
@@ -419,7 +436,7 @@ wfa_general_kernel(const WfaKernelArgs a) {
           }
         }
       }
-      if (FULL && tid == 0) {
+      if (FULL && !PB && tid == 0) {
         // final directory record of score s (its lo/hi can no longer change)
         const int* m = ring + (s % scope) * MT::INTS;
         int* d = ws + ws_stride - (long long)(s + 1) * MT::INTS;
@@ -449,7 +466,11 @@ wfa_general_kernel(const WfaKernelArgs a) {
       if (all_null) {
         ++null_steps;
         cur_exists = 0; cur_lo = 1; cur_hi = -1; cur_idx0 = 0;
-        if (FULL && (long long)used + (long long)(s + 2) * MT::INTS > ws_stride) { end_reason = 3; break; }
+        if (FULL && !PB && (long long)used + (long long)(s + 2) * MT::INTS > ws_stride) { end_reason = 3; break; }
+        if (PB) {
+          if (pb_used + (long long)(s + 2) * 12 > pb_cap) { end_reason = 3; break; }
+          if (tid == 0) { int* d = ws + ws_stride - 3ll * (s + 1); d[0] = 1; d[1] = 0; d[2] = 0; }
+        }
         if (tid == 0) {
           for (int c = 0; c < NCOMP; ++c) { mslot[MT::LO + c] = 1; mslot[MT::HI + c] = -1; }
           mslot[MT::BASE] = 0; mslot[MT::WIDTH] = 0; mslot[MT::DATA] = 0; mslot[MT::EXISTS] = 0;
@@ -472,12 +493,19 @@ wfa_general_kernel(const WfaKernelArgs a) {
         const bool has_i2 = (NCOMP == 5) && (!mo2.null() || !i2e.null());
         const bool has_d2 = (NCOMP == 5) && (!mo2.null() || !d2e.null());
         int base, width, data;
-        if (FULL) {
+        long long code_base = 0;
+        if (!RING) {
           base = lo; width = hi - lo + 1; data = used;
           if ((long long)used + (long long)NCOMP * width + (long long)(s + 2) * MT::INTS > ws_stride) { end_reason = 3; break; }
           used += NCOMP * width;
         } else {
           base = rbase; width = rstride; data = (s % scope) * NCOMP * rstride;
+          if (PB) {
+            const long long nb = (long long)hi - lo + 1;
+            if (pb_used + nb + (long long)(s + 2) * 12 > pb_cap || pb_used + nb > 0x7fffff00ll) { end_reason = 3; break; }
+            code_base = pb_used; pb_used += nb;
+            if (tid == 0) { int* d = ws + ws_stride - 3ll * (s + 1); d[0] = lo; d[1] = hi; d[2] = (int)code_base; }
+          }
         }
         const int o_m = data - base;
         const int o_i1 = o_m + width, o_d1 = o_m + 2 * width, o_i2 = o_m + 3 * width, o_d2 = o_m + 4 * width;
@@ -485,9 +513,12 @@ wfa_general_kernel(const WfaKernelArgs a) {
 #pragma unroll
         for (int c = 0; c < NCOMP; ++c) { tmin[c] = INT_MAX; tmax[c] = INT_MIN; }
         for (int k = lo + tid; k <= hi; k += T) {
-          const int ins1 = max(mo1.get(ws, k - 1), i1e.get(ws, k - 1)) + 1;
-          const int del1 = max(mo1.get(ws, k + 1), d1e.get(ws, k + 1));
+          const int mo1_lo = mo1.get(ws, k - 1), i1e_lo = i1e.get(ws, k - 1), mo1_hi = mo1.get(ws, k + 1), d1e_hi = d1e.get(ws, k + 1);
+          const int ins1 = max(mo1_lo, i1e_lo) + 1;
+          const int del1 = max(mo1_hi, d1e_hi);
           int ins = ins1, del = del1;
+          int ins2v = WFA_OFFSET_NULL, del2v = WFA_OFFSET_NULL;   // (2p) the second gap piece
+          int pbcode = 0;
           if (has_i1) {
             ws[o_i1 + k] = ins1;
             if ((uint32_t)ins1 <= (uint32_t)tlen && (uint32_t)(ins1 - k) <= (uint32_t)plen) { tmin[NCOMP > 1 ? 1 : 0] = min(tmin[NCOMP > 1 ? 1 : 0], k); tmax[NCOMP > 1 ? 1 : 0] = max(tmax[NCOMP > 1 ? 1 : 0], k); }
@@ -497,8 +528,10 @@ wfa_general_kernel(const WfaKernelArgs a) {
             if ((uint32_t)del1 <= (uint32_t)tlen && (uint32_t)(del1 - k) <= (uint32_t)plen) { tmin[NCOMP > 2 ? 2 : 0] = min(tmin[NCOMP > 2 ? 2 : 0], k); tmax[NCOMP > 2 ? 2 : 0] = max(tmax[NCOMP > 2 ? 2 : 0], k); }
           }
           if (NCOMP == 5) {
-            const int ins2 = max(mo2.get(ws, k - 1), i2e.get(ws, k - 1)) + 1;
-            const int del2 = max(mo2.get(ws, k + 1), d2e.get(ws, k + 1));
+            const int mo2_lo = mo2.get(ws, k - 1), i2e_lo = i2e.get(ws, k - 1), mo2_hi = mo2.get(ws, k + 1), d2e_hi = d2e.get(ws, k + 1);
+            const int ins2 = max(mo2_lo, i2e_lo) + 1;
+            const int del2 = max(mo2_hi, d2e_hi);
+            if (PB) pbcode = ((i1e_lo >= mo1_lo) ? 8 : 0) | ((d1e_hi >= mo1_hi) ? 16 : 0) | ((i2e_lo >= mo2_lo) ? 32 : 0) | ((d2e_hi >= mo2_hi) ? 64 : 0);
             if (has_i2) {
               ws[o_i2 + k] = ins2;
               if ((uint32_t)ins2 <= (uint32_t)tlen && (uint32_t)(ins2 - k) <= (uint32_t)plen) { tmin[NCOMP - 2] = min(tmin[NCOMP - 2], k); tmax[NCOMP - 2] = max(tmax[NCOMP - 2], k); }
@@ -509,8 +542,23 @@ wfa_general_kernel(const WfaKernelArgs a) {
             }
             ins = max(ins1, ins2);
             del = max(del1, del2);
+            ins2v = ins2; del2v = del2;
           }
-          int mv = max(del, max(mx.get(ws, k) + 1, ins));
+          const int x1 = mx.get(ws, k) + 1;
+          int mv = max(del, max(x1, ins));
+          if (PB) {
+            // the choice the backtrace would make on equal offsets (R/wavefront_backtrace.c:49-59): mismatch > D2 > D1 > I2 > I1,
+            // extension > opening
+            if (NCOMP == 5) {
+              const int best = mv;
+              const int mc = (x1 >= best) ? 0 : (del2v >= best) ? 2 : (del1 >= best) ? 1 : (ins2v >= best) ? 4 : 3;
+              pbcode |= mc;
+            } else {
+              const int mc = (x1 >= max(del1, ins1)) ? 0 : ((del1 >= ins1) ? 1 : 2);
+              pbcode = mc | ((i1e_lo >= mo1_lo) ? 4 : 0) | ((d1e_hi >= mo1_hi) ? 8 : 0);
+            }
+            pb_codes[code_base + (k - lo)] = (uint8_t)pbcode;
+          }
           // only M is clamped (R/wavefront_compute_affine.c:80-84)
           if ((uint32_t)mv > (uint32_t)tlen || (uint32_t)(mv - k) > (uint32_t)plen) mv = WFA_OFFSET_NULL;
           else { tmin[0] = min(tmin[0], k); tmax[0] = max(tmax[0], k); }
@@ -566,6 +614,58 @@ wfa_general_kernel(const WfaKernelArgs a) {
           out_score = (cfg.metric <= 1) ? s : (cfg.match == 0) ? -s : (int)(((long long)(-cfg.match) * 1 - s) / 2);
           out_status = 1;
         }
+      } else if (PB) {
+        if (end_reason == 1) {
+          // ---- walk the origin codes back from the end cell (R/wavefront_backtrace.c:320-529 with the choices made at
+          // compute time); events go behind the code bytes, an event flagged 0x80 lands in M (a run of matches follows it)
+          uint8_t* const ev = pb_codes + pb_used;
+          const long long ev_cap = pb_cap - pb_used - (long long)(s + 2) * 12;
+          const int sx = cfg.x, so1 = cfg.o1 + cfg.e1, se1 = cfg.e1, so2 = cfg.o2 + cfg.e2, se2 = cfg.e2;
+          int sc = s, k = end_k, comp = 0;
+          long long nev = 0;
+          bool pb_fail = false;
+          while (sc > 0) {
+            if (nev >= ev_cap) { pb_fail = true; break; }
+            const int* d = ws + ws_stride - 3ll * (sc + 1);
+            const int cd = (k >= d[0] && k <= d[1]) ? pb_codes[(long long)d[2] + (k - d[0])] : 0;
+            const uint8_t flag = (comp == 0) ? 0x80 : 0;
+            int src;   // 0 mismatch, 1 D1, 2 D2, 3 I1, 4 I2
+            if (NCOMP == 5) src = (comp == 0) ? (cd & 7) : (comp == 1) ? 3 : (comp == 2) ? 1 : (comp == 3) ? 4 : 2;
+            else src = (comp == 0) ? ((cd & 3) == 0 ? 0 : ((cd & 3) == 1 ? 1 : 3)) : (comp == 1 ? 3 : 1);
+            const int bi1 = (NCOMP == 5) ? 8 : 4, bd1 = (NCOMP == 5) ? 16 : 8;
+            if (src == 0) { ev[nev++] = (uint8_t)('X' | 0x80); sc -= sx; }
+            else if (src == 1) { ev[nev++] = (uint8_t)('D' | flag); ++k; if (cd & bd1) { sc -= se1; comp = 2; } else { sc -= so1; comp = 0; } }
+            else if (src == 2) { ev[nev++] = (uint8_t)('D' | flag); ++k; if (cd & 64) { sc -= se2; comp = 4; } else { sc -= so2; comp = 0; } }
+            else if (src == 3) { ev[nev++] = (uint8_t)('I' | flag); --k; if (cd & bi1) { sc -= se1; comp = 1; } else { sc -= so1; comp = 0; } }
+            else { ev[nev++] = (uint8_t)('I' | flag); --k; if (cd & 32) { sc -= se2; comp = 3; } else { sc -= so2; comp = 0; } }
+          }
+          if (pb_fail || sc < 0) {
+            if (a.fb_list) { out_status = WFA_INTERNAL_OVERFLOW; out_score = 0; a.fb_list[atomicAdd(a.fb_count, 1u)] = pair; }
+            else { out_status = -200; out_score = INT_MIN; }
+          } else {
+            // ---- unpack forwards from the cell of wavefront 0 on diagonal k (ends-free: offset max(k, 0), R/wavefront_aligner.c:259-302)
+            uint8_t* const out = a.cigar_ops + a.cigar_off[pair];
+            long long n = 0;
+            auto emit = [&](char c, int cnt) { for (int i = 0; i < cnt; ++i) out[n++] = (uint8_t)c; };
+            int h = max(k, 0), v = h - k;
+            emit('I', h); emit('D', v);
+            { const int e = seq.extend(h - v, h); emit('M', e - h); v += e - h; h = e; }
+            for (long long e_ = nev - 1; e_ >= 0; --e_) {
+              const int op = ev[e_] & 0x7F;
+              if (op == 'X') { emit('X', 1); ++v; ++h; }
+              else if (op == 'I') { emit('I', 1); ++h; }
+              else { emit('D', 1); ++v; }
+              if (ev[e_] & 0x80) { const int e = seq.extend(h - v, h); emit('M', e - h); v += e - h; h = e; }
+            }
+            emit('I', tlen - h); emit('D', plen - v);
+            cbeg = a.cigar_off[pair];
+            clen = (int)n;
+            out_score = classic_score(cfg, end_off - end_k, end_off, s);
+            out_status = 0;
+          }
+        } else {
+          out_score = INT_MIN; out_status = 1;
+        }
       } else {
         if (end_reason == 1) {
           OpsWriter ops;
@@ -590,14 +690,21 @@ wfa_general_kernel(const WfaKernelArgs a) {
 
 // host entry points, one translation unit per component count (csrc/k_general.hip, -DWFA_TU_INDEX = 0 / 1 / 2 for
 // NCOMP = 1 / 3 / 5)
-int launch_general_c1(bool packed, bool full, const WfaKernelArgs& a, int grid, int threads, hipStream_t stream);
-int launch_general_c3(bool packed, bool full, const WfaKernelArgs& a, int grid, int threads, hipStream_t stream);
-int launch_general_c5(bool packed, bool full, const WfaKernelArgs& a, int grid, int threads, hipStream_t stream);
+int launch_general_c1(bool packed, bool full, bool pb, const WfaKernelArgs& a, int grid, int threads, hipStream_t stream);
+int launch_general_c3(bool packed, bool full, bool pb, const WfaKernelArgs& a, int grid, int threads, hipStream_t stream);
+int launch_general_c5(bool packed, bool full, bool pb, const WfaKernelArgs& a, int grid, int threads, hipStream_t stream);
 
 template <int NCOMP>
-inline int launch_general_ncomp(bool packed, bool full, const WfaKernelArgs& a, int grid, int threads, hipStream_t stream) {
+inline int launch_general_ncomp(bool packed, bool full, bool pb, const WfaKernelArgs& a, int grid, int threads, hipStream_t stream) {
   const size_t smem = ((size_t)a.cfg.scope * Meta<NCOMP>::INTS + 2 * NCOMP + 8) * sizeof(int);
   const dim3 g(grid), t(threads);
+  if constexpr (NCOMP >= 3) {
+    if (full && pb) {
+      if (packed) hipLaunchKernelGGL((wfa_general_kernel<NCOMP, true, true, true>), g, t, smem, stream, a);
+      else hipLaunchKernelGGL((wfa_general_kernel<NCOMP, false, true, true>), g, t, smem, stream, a);
+      return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+  }
   if (packed) {
     if (full) hipLaunchKernelGGL((wfa_general_kernel<NCOMP, true, true>), g, t, smem, stream, a);
     else hipLaunchKernelGGL((wfa_general_kernel<NCOMP, true, false>), g, t, smem, stream, a);
@@ -608,10 +715,11 @@ inline int launch_general_ncomp(bool packed, bool full, const WfaKernelArgs& a, 
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-inline int launch_general_any(int ncomp, bool packed, bool full, const WfaKernelArgs& a, int grid, int threads, hipStream_t stream) {
-  if (ncomp == 1) return launch_general_c1(packed, full, a, grid, threads, stream);
-  if (ncomp == 3) return launch_general_c3(packed, full, a, grid, threads, stream);
-  return launch_general_c5(packed, full, a, grid, threads, stream);
+// pb: the piggy-back history (full scope, gap-affine / gap-affine-2p; ignored otherwise)
+inline int launch_general_any(int ncomp, bool packed, bool full, bool pb, const WfaKernelArgs& a, int grid, int threads, hipStream_t stream) {
+  if (ncomp == 1) return launch_general_c1(packed, full, false, a, grid, threads, stream);
+  if (ncomp == 3) return launch_general_c3(packed, full, pb, a, grid, threads, stream);
+  return launch_general_c5(packed, full, pb, a, grid, threads, stream);
 }
 
 }  // namespace wfa

@@ -194,7 +194,8 @@ struct wfa_hip_batch {
   hipStream_t last_stream = nullptr;
   bool uploads_pending = false;
   int stage_pick = 0;  // first register-kernel stage chosen by the pilot of the first run (0 = not yet): 16, 32 or 64 lanes
-  int64_t arena_ints = 0;  // FULL: arena size used by the last launch
+  int64_t arena_ints = 0;  // FULL: arena size used by the last launch (the part that grows 8x when a pair overflows it)
+  int64_t arena_fixed = 0; // FULL, piggy-back history of the general kernel: the score-only ring in front of the growing part
   // device-side result surface (RLE)
   int32_t* d_plen = nullptr; int32_t* d_tlen = nullptr; int32_t* d_run_count = nullptr; int32_t* d_locs = nullptr;
   int64_t* d_run_off = nullptr; int64_t rle_total = -1;
@@ -725,6 +726,14 @@ static int ensure_ws(wfa_hip_aligner* al, size_t bytes) {
   return WFA_HIP_OK;
 }
 
+// memory_mode medium / low: the general kernel keeps the piggy-back history (one byte of origin codes per cell) instead of the
+// explicit arena (full scope, gap-affine / gap-affine-2p; WFA_HIP_GENERAL_PB = 0 / 1 overrides)
+static bool general_pb(const wfa_hip_aligner* al, const wfa_hip_config_t& c, int ncomp) {
+  if (c.scope != WFA_SCOPE_FULL || ncomp < 3) return false;
+  const int e = knob(al, K_GENERAL_PB, -1);
+  return e >= 0 ? e != 0 : (c.memory_mode == WFA_MEM_MED || c.memory_mode == WFA_MEM_LOW);
+}
+
 static int launch_general_dyn(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream, bool packed,
                               const uint32_t* worklist, const uint32_t* nwork_dev, uint32_t nwork_host,
                               int64_t ws_stride, int grid, int threads, uint32_t* ovf_list, uint32_t* ovf_count) {
@@ -737,7 +746,7 @@ static int launch_general_dyn(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t
   a.ws = al->ws; a.ws_stride = ws_stride;
   a.fb_list = ovf_list; a.fb_count = ovf_count;
   a.cfg = b->dcfg;
-  if (wfa::launch_general_any(b->ncomp, packed, b->cfg.scope == WFA_SCOPE_FULL, a, grid, threads, stream) != 0) {
+  if (wfa::launch_general_any(b->ncomp, packed, b->cfg.scope == WFA_SCOPE_FULL, general_pb(al, b->cfg, b->ncomp), a, grid, threads, stream) != 0) {
     al->err = std::string("general kernel launch failed: ") + hipGetErrorString(hipGetLastError());
     return WFA_HIP_EDEVICE;
   }
@@ -781,6 +790,8 @@ static int64_t initial_arena_ints(const wfa_hip_aligner* al, const wfa_hip_batch
   // room for a run whose score is ~ the longer sequence and whose wavefronts are ~128 wide, and never
   // less than what wavefront 0 and a few hundred scores need; overflowing pairs are re-run larger
   ll ints = (ll)b->max_len * (b->ncomp * 64 + mi) / 4 + (ll)b->max_width * b->ncomp * 4 + 4096 * mi;
+  // piggy-back history: one byte per cell + 12 bytes per score (the ring of offsets is b->arena_fixed)
+  if (general_pb(al, b->cfg, b->ncomp)) ints = (ll)b->max_len * (64 + 12) / 4 + 4096;
   ints = std::max<ll>(ints, 1 << 14);
   const int e = knob(al, K_ARENA_KB, 0);
   if (e > 0) ints = (ll)e * 256;
@@ -803,6 +814,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
   const bool full = (b->cfg.scope == WFA_SCOPE_FULL);
   HIP_TRY(al, hipMemsetAsync(b->d_counters, 0, 16 * sizeof(uint32_t), stream));
   b->arena_ints = full ? initial_arena_ints(al, b) : 0;
+  b->arena_fixed = general_pb(al, b->cfg, b->ncomp) ? (((int64_t)b->dcfg.scope * b->ncomp * b->max_width + 64 + 63) & ~63ll) : 0;
 
   // A cascade of kernels over the 2-bit pairs: each stage aligns what fits it and appends the rest to
   // a leftover list (pair ids + a device-side count) that the next stage consumes on the same stream;
@@ -880,7 +892,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       if (only) { n_stages = 1; band_nch[0] = only; }
     }
     const bool any_pre = use_fast || use_segfull || n_stages > 0;
-    Geometry g = plan_general(al, b, any_pre ? std::min<uint32_t>(in_n, (uint32_t)al->cu_count * 16) : in_n, b->arena_ints);
+    Geometry g = plan_general(al, b, any_pre ? std::min<uint32_t>(in_n, (uint32_t)al->cu_count * 16) : in_n, b->arena_fixed + b->arena_ints);
     size_t need = (size_t)g.grid * g.ws_stride * 4;
     // band history: fixed-stride records per score step, one slice per wave
     long long band_grid[3] = {0, 0, 0};
@@ -1114,7 +1126,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
   HIP_TRY(al, hipEventRecord(ev1, stream));
   // 3) 8-bit pairs (non-ACGT letters, wildcard matching)
   if (b->n_bytes > 0) {
-    Geometry g = plan_general(al, b, b->n_bytes, b->arena_ints);
+    Geometry g = plan_general(al, b, b->n_bytes, b->arena_fixed + b->arena_ints);
     int rc = ensure_ws(al, (size_t)g.grid * g.ws_stride * 4);
     if (rc != WFA_HIP_OK) return rc;
     rc = launch_general_dyn(al, b, stream, false, b->d_list_bytes, nullptr, b->n_bytes, g.ws_stride, g.grid, g.threads,
@@ -1147,7 +1159,7 @@ static int retry_overflows(wfa_hip_batch* b) {
     const int nxt = cur ^ 1;
     HIP_TRY(al, hipMemset(b->d_counters + 1 + nxt, 0, sizeof(uint32_t)));
     const int64_t budget = free_budget(al);
-    if (b->arena_ints * 4 > budget) {
+    if ((b->arena_fixed + b->arena_ints) * 4 > budget) {
       // cannot grow further: report OOM for these pairs
       std::vector<int32_t> st(1, WFA_STATUS_OOM), sc(1, INT_MIN);
       for (uint32_t id : ids) {
@@ -1162,7 +1174,7 @@ static int retry_overflows(wfa_hip_batch* b) {
       if (l.empty()) continue;
       uint32_t* d_l = b->d_fb_list2[0];  // free to reuse: the first pass is complete
       HIP_TRY(al, hipMemcpy(d_l, l.data(), l.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-      Geometry g = plan_general(al, b, (uint32_t)l.size(), b->arena_ints);
+      Geometry g = plan_general(al, b, (uint32_t)l.size(), b->arena_fixed + b->arena_ints);
       int rc = ensure_ws(al, (size_t)g.grid * g.ws_stride * 4);
       if (rc != WFA_HIP_OK) return rc;
       rc = launch_general_dyn(al, b, stream, kind == 0, d_l, nullptr, (uint32_t)l.size(), g.ws_stride, g.grid, g.threads,
@@ -1426,7 +1438,7 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
   // (no overflow list: an arena that is too small shows as status WFA_INTERNAL_OVERFLOW below and the call takes the batch path)
   static uint32_t* const no_list = nullptr;
   a.fb_list = no_list; a.fb_count = nullptr;
-  if (wfa::launch_general_any(al->ncomp, false, full, a, (int)n, threads, stream) != 0) { al->err = "general kernel launch failed"; return WFA_HIP_EDEVICE; }
+  if (wfa::launch_general_any(al->ncomp, false, full, false, a, (int)n, threads, stream) != 0) { al->err = "general kernel launch failed"; return WFA_HIP_EDEVICE; }
   HIP_TRY(al, hipEventRecord(al->ws_event, stream));
   al->ws_event_recorded = true; al->ws_last_stream = stream;
   HIP_TRY(al, hipStreamSynchronize(stream));

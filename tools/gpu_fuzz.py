@@ -20,12 +20,16 @@ for it in range(rounds):
               span=str(rng.choice(["end-to-end", "ends-free"])))
     r = rng.random()
     if r < 0.15: kw["heuristic"] = "adaptive"
-    elif r < 0.2: kw.update(heuristic="X-drop", xdrop=int(rng.choice([20, 100])))
+    elif r < 0.3: kw.update(heuristic="X-drop", xdrop=int(rng.choice([20, 100, 400])), steps_between_cutoffs=int(rng.choice([1, 1, 3])))
     if kw["span"] == "ends-free" and rng.random() < 0.3:
         kw.update(pattern_begin_free=int(rng.integers(0, 9)), pattern_end_free=int(rng.integers(0, 9)),
                   text_begin_free=int(rng.integers(0, 9)), text_end_free=int(rng.integers(0, 9)))
-    if rng.random() < 0.1: kw["distance"] = "affine2p"
+    if rng.random() < 0.2: kw["distance"] = "affine2p"
     if rng.random() < 0.3: kw["memory_mode"] = str(rng.choice(["medium", "low"]))
+    if rng.random() < 0.1: kw["max_steps"] = int(rng.choice([6, 20, 60, 400]))
+    if rng.random() < 0.12:   # BiWFA: without heuristic, free ends or a step limit
+        for k_ in ("heuristic", "xdrop", "max_steps", "pattern_begin_free", "pattern_end_free", "text_begin_free", "text_end_free"): kw.pop(k_, None)
+        kw["memory_mode"] = "biwfa"
     # a batch of mixed lengths and divergences, with length differences (end-to-end gaps)
     pats, txts = [], []
     nparts = int(rng.integers(1, 4))
