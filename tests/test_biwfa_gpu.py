@@ -63,3 +63,19 @@ def test_biwfa_python_surface(gpu):
     for kw in (dict(heuristic="adaptive"), dict(max_steps=100), dict(span="ends-free", text_end_free=3)):
         with pytest.raises(NotImplementedError):
             pywfa_amd.WavefrontAligner(p, memory_mode="biwfa", **kw)
+
+
+BIWFA_GOLD = common.load_golden("biwfa.json")
+
+
+@pytest.mark.parametrize("run_idx", range(len(BIWFA_GOLD["runs"])))
+def test_biwfa_matches_golden_vectors(gpu, run_idx):
+    """The device BiWFA against the committed outputs of the real library (tests/golden/biwfa.json)."""
+    run = BIWFA_GOLD["runs"][run_idx]
+    pairs = BIWFA_GOLD["corpora"][run["corpus"]]
+    batch = datagen.from_strings([p for p, _ in pairs], [t for _, t in pairs])
+    _, nc = common.configs_pair(**run["config"])
+    score, status, cigars = common.gpu_run(nc, batch, True, resident=(run_idx % 2 == 0))
+    assert score.tolist() == run["score"]
+    assert status.tolist() == run["status"]
+    assert [common.rle(c) for c in cigars] == run["cigar"]

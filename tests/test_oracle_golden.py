@@ -10,6 +10,7 @@ from oracle import loader
 from pywfa_amd import datagen
 
 C_LEVEL = common.load_golden("c_level.json")
+BIWFA = common.load_golden("biwfa.json")   # WFA2-lib in ultralow (BiWFA) mode, scope=full (tools/make_golden.py biwfa)
 SURFACE = common.load_golden("python_surface.json")
 
 
@@ -24,6 +25,19 @@ def test_oracle_matches_reference_vectors(run_idx):
     assert o["status"].tolist() == run["status"]
     if run["cigar"] is not None:
         assert [common.rle(c) for c in o["cigars"]] == run["cigar"]
+
+
+@pytest.mark.parametrize("run_idx", range(len(BIWFA["runs"])))
+def test_oracle_matches_reference_biwfa_vectors(run_idx):
+    """The oracle's BiWFA restatement against the committed outputs of the real library: status, score (INT32_MIN where the
+    top level never splits) and op string."""
+    run = BIWFA["runs"][run_idx]
+    pairs = BIWFA["corpora"][run["corpus"]]
+    batch = datagen.from_strings([p for p, _ in pairs], [t for _, t in pairs])
+    o = loader.run(loader.oracle(), loader.make_config(**run["config"]), batch)
+    assert o["score"].tolist() == run["score"]
+    assert o["status"].tolist() == run["status"]
+    assert [common.rle(c) for c in o["cigars"]] == run["cigar"]
 
 
 def _surface_alignments():

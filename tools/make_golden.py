@@ -243,10 +243,45 @@ def c_level_vectors():
     return out
 
 
+def biwfa_vectors():
+    """(status, score, CIGAR) of oracle/_ref in its ultralow (BiWFA) mode, scope=full: reads that never split (<= 100 bases: the
+    score stays unset), reads that split once, and reads that split several levels deep."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import validate_oracle as vo
+    corpora = {"special": vo.corpus_special()}
+    for L, e, n in ((60, 0.1, 40), (150, 0.02, 48), (150, 0.2, 40), (1500, 0.1, 8), (5000, 0.12, 3)):
+        corpora[f"L{L}_e{e}"] = datagen.generate(n, L, e, 5151 + L)
+    cfgs = [dict(span="end-to-end"), dict(), dict(distance="affine2p"), dict(distance="levenshtein", span="end-to-end"), dict(distance="indel"),
+            dict(distance="linear", mismatch=3, gap_extension=5), dict(match=-1, span="end-to-end"), dict(wildcard="N")]
+    out = {"corpora": {}, "runs": []}
+    for name, b in corpora.items():
+        n = len(b["p_len"])
+        pairs = [list(datagen.pair_strings(b, i)) for i in range(n)]
+        if name == "special":
+            pairs = pairs[:120] + pairs[300:340] + pairs[620:680]
+        out["corpora"][name] = pairs
+    for name, pairs in out["corpora"].items():
+        b = datagen.from_strings([p for p, _ in pairs], [t for _, t in pairs])
+        for kw in cfgs:
+            kw = dict(kw, scope="full", memory_mode="biwfa")
+            r = vo.run_reference(kw, b)
+            if r is None:
+                continue
+            out["runs"].append({"corpus": name, "config": kw, "score": [int(x) for x in r["score"]],
+                                "status": [int(x) for x in r["status"]], "cigar": [rle(c) for c in r["cigars"]]})
+    return out
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference")
     loader.build()
+    if len(sys.argv) > 1 and sys.argv[1] == "biwfa":   # only the BiWFA vectors (round 2)
+        os.makedirs(GOLD, exist_ok=True)
+        with open(os.path.join(GOLD, "biwfa.json"), "w") as f:
+            json.dump(biwfa_vectors(), f, indent=0)
+        print("biwfa.json", os.path.getsize(os.path.join(GOLD, "biwfa.json")))
+        return
     mod = build_reference_extension()
     os.makedirs(GOLD, exist_ok=True)
     surface = []
@@ -265,6 +300,8 @@ def main():
         json.dump(helper_vectors(mod), f, indent=0)
     with open(os.path.join(GOLD, "c_level.json"), "w") as f:
         json.dump(c_level_vectors(), f, indent=0)
+    with open(os.path.join(GOLD, "biwfa.json"), "w") as f:
+        json.dump(biwfa_vectors(), f, indent=0)
     for fn in sorted(os.listdir(GOLD)):
         print(fn, os.path.getsize(os.path.join(GOLD, fn)))
 
