@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <limits.h>
+#include <type_traits>
 #include "wfa_hip.h"
 #include "wfa_common.hpp"
 #include "wfa_fast.hpp"
@@ -353,6 +354,14 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
       int have_max_sw = 0, max_sw = 0;      // X-drop state (R/wavefront_heuristic.c:114-121)
       int last_nonnull = 0;                 // last score whose compute-next had a non-null input (score 0 counts)
       bool done = false;
+      // Chunks that can hold a live diagonal: when the hull of all ring registers fits the first ACT_SMALL chunks (with the
+      // margins of the window check) the other chunks' registers are all NULL and stay so, and the two heavy blocks of a
+      // step, extension and compute-next, run on the active chunks only (one straight-line body per form, chosen by a
+      // wave-uniform branch; the rest of the step is common).  10 kb at 8 % with wf-adaptive: the wavefront is ~34
+      // diagonals wide on average, so most steps of the 128-diagonal form run on 64 lanes.  Decided at the hull check
+      // (every 8 steps).
+      constexpr int ACT_SMALL = (!TWO && NCH == 2) ? 1 : ((!TWO && NCH == 4) ? 2 : NCH);
+      bool big = true;
       for (int step = 0;; ++step) {
         if (PB) {
           // piggy-back history of score s: the origin codes do not depend on the extension or the cut-off, and the walk
@@ -371,37 +380,42 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
         if (any_live) {
           dead_steps = 0;
           {
-            // all chunks advance together: 32 bases per iteration (three packed words per sequence)
-            int h[NCH], v[NCH], left[NCH];
-            bool any_more = false;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-              h[c] = max(cur[c], 0); v[c] = max(cur[c] - kk[c], 0);
-              left[c] = (cur[c] >= 0) ? lim[c] - cur[c] : 0;
-              any_more |= left[c] > 0;
-            }
-            if (__any(any_more)) {
-              bool more;
-              do {
-                more = false;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                  const int pi = v[c] >> 4, ti = h[c] >> 4;
-                  uint32_t p0, p1, p2, t0, t1, t2;
-                  if (SEQLDS) { p0 = sP[pi]; p1 = sP[pi + 1]; p2 = sP[pi + 2]; t0 = sT[ti]; t1 = sT[ti + 1]; t2 = sT[ti + 2]; }
-                  else { p0 = gP[pi]; p1 = gP[pi + 1]; p2 = gP[pi + 2]; t0 = gT[ti]; t1 = gT[ti + 1]; t2 = gT[ti + 2]; }
-                  const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v[c] << 1) ^ __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h[c] << 1);
-                  const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, (uint32_t)v[c] << 1) ^ __builtin_amdgcn_alignbit(t2, t1, (uint32_t)h[c] << 1);
-                  // first differing bit of xh:xl (v_ffbl_b32 gives ~0 for 0: `| 32` is +32 or stays ~0)
-                  const uint32_t fb = min(band_ffbl(xl), band_ffbl(xh) | 32u);
-                  const int m = min((int)(fb >> 1), min(32, left[c]));
-                  v[c] += m; h[c] += m; left[c] -= m;
-                  more |= (m == 32) && (left[c] > 0);
-                }
-              } while (__any(more));
-#pragma unroll
-              for (int c = 0; c < NCH; ++c) if (cur[c] >= 0) cur[c] = h[c];
-            }
+            auto extend_chunks = [&](auto act_tag) {
+              constexpr int ACT = decltype(act_tag)::value;
+              // all chunks advance together: 32 bases per iteration (three packed words per sequence)
+              int h[NCH], v[NCH], left[NCH];
+              bool any_more = false;
+  #pragma unroll
+              for (int c = 0; c < ACT; ++c) {
+                h[c] = max(cur[c], 0); v[c] = max(cur[c] - kk[c], 0);
+                left[c] = (cur[c] >= 0) ? lim[c] - cur[c] : 0;
+                any_more |= left[c] > 0;
+              }
+              if (__any(any_more)) {
+                bool more;
+                do {
+                  more = false;
+  #pragma unroll
+                  for (int c = 0; c < ACT; ++c) {
+                    const int pi = v[c] >> 4, ti = h[c] >> 4;
+                    uint32_t p0, p1, p2, t0, t1, t2;
+                    if (SEQLDS) { p0 = sP[pi]; p1 = sP[pi + 1]; p2 = sP[pi + 2]; t0 = sT[ti]; t1 = sT[ti + 1]; t2 = sT[ti + 2]; }
+                    else { p0 = gP[pi]; p1 = gP[pi + 1]; p2 = gP[pi + 2]; t0 = gT[ti]; t1 = gT[ti + 1]; t2 = gT[ti + 2]; }
+                    const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v[c] << 1) ^ __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h[c] << 1);
+                    const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, (uint32_t)v[c] << 1) ^ __builtin_amdgcn_alignbit(t2, t1, (uint32_t)h[c] << 1);
+                    // first differing bit of xh:xl (v_ffbl_b32 gives ~0 for 0: `| 32` is +32 or stays ~0)
+                    const uint32_t fb = min(band_ffbl(xl), band_ffbl(xh) | 32u);
+                    const int m = min((int)(fb >> 1), min(32, left[c]));
+                    v[c] += m; h[c] += m; left[c] -= m;
+                    more |= (m == 32) && (left[c] > 0);
+                  }
+                } while (__any(more));
+  #pragma unroll
+                for (int c = 0; c < ACT; ++c) if (cur[c] >= 0) cur[c] = h[c];
+              }
+            };
+            if (ACT_SMALL < NCH && !big) extend_chunks(std::integral_constant<int, ACT_SMALL>{});
+            else extend_chunks(std::integral_constant<int, NCH>{});
           }
           // ---------------- termination ----------------
           if (a.ef) {
@@ -521,8 +535,9 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
             }
           }
         }
-        // ---------------- keep the ring inside the window (every 8 steps; growth is <= 1 diagonal/step) ----
-        if ((step & 7) == 0) {
+        // ---------------- keep the ring inside the window (every HP steps; growth is <= 1 diagonal/step) ----
+        constexpr int HP = 8;   // period of the check (4 keeps the small form a little longer but measures slower on 10 kb reads)
+        if ((step & (HP - 1)) == 0) {
           unsigned long long hull[NCH];
 #pragma unroll
           for (int c = 0; c < NCH; ++c) {
@@ -546,9 +561,15 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
           if (lp >= 0) {
             const int width = lp - fp + 1;
             if (width > ((a.debug >> 8) ? (a.debug >> 8) : W - 20)) { fallback = true; break; }  // (debug >> 8: width experiments)
-            if (fp < 9 || lp > W - 10) {
-              // re-centre, keeping the target diagonal representable when it is within reach
-              int delta = fp - (W - width) / 2;
+            // small form: the hull (and HP steps of growth either way) fits the first ACT_SMALL chunks, lane 63 of the last
+            // active chunk included in the margin, so nothing can reach the other chunks before the next check; a little
+            // hysteresis keeps a hull near the limit from being shifted to and fro
+            constexpr int WS = 64 * ACT_SMALL;
+            const bool want_small = ACT_SMALL < NCH && !(a.debug & 4) && width <= (big ? WS - 2 * HP - 6 : WS - 2 * HP - 2);
+            const int hi_lim = (want_small ? WS : W) - HP - 2;
+            if (fp < HP + 1 || lp > hi_lim) {
+              // re-centre in the window (or in its small form)
+              int delta = fp - ((want_small ? WS : W) - width) / 2;
               B += delta;
 #pragma unroll
               for (int c = 0; c < NCH; ++c) { kk[c] += delta; lim[c] = min(tlen, plen + kk[c]); dlim[c] = max(tlen, plen + kk[c]); }
@@ -567,131 +588,147 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
                 for (int j = 0; j < NP; ++j) BD::shift(PH[j], delta, lane, -1);
               }
             }
+            if (ACT_SMALL < NCH) {
+              big = !want_small;
+              if (want_small) {
+                // the oldest M of the now inactive chunks is outside the hull test (compute-next drops it) but is read as a
+                // neighbour by the last active chunk: NULL
+#pragma unroll
+                for (int c = ACT_SMALL; c < NCH; ++c) Mh[DM - 1][c] = WFA_OFFSET_NULL;
+              }
+            }
           }
         }
         // ---------------- compute-next for score s+g ----------------
-        if (TWO) {
-          // the value leaving depth DM enters the packed ring: PH[0].lo = depth DM + 1, PH[0].hi = DM + 2, ...
-#pragma unroll
-          for (int j = NP - 1; j > 0; --j)
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) PH[j][c] = (int)__builtin_amdgcn_alignbit((uint32_t)PH[j][c], (uint32_t)PH[j - 1][c], 16);
-#pragma unroll
-          for (int c = 0; c < NCH; ++c) PH[0][c] = (PH[0][c] << 16) | (max(Mh[DM - 1][c], -1) & 0xffff);
-        }
-#pragma unroll
-        for (int j = DM - 1; j > 0; --j)
-#pragma unroll
-          for (int c = 0; c < NCH; ++c) Mh[j][c] = Mh[j - 1][c];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) Mh[0][c] = cur[c];
-        s += a.g;
         int insig = -1;  // AND of all inputs: non-negative iff some input offset is not NULL-ish
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-          insig &= Mh[X - 1][c] & Mh[OE - 1][c] & Ih[E - 1][c] & Dh[E - 1][c];
+        auto compute_next = [&](auto act_tag) {
+          constexpr int ACT = decltype(act_tag)::value;
+          constexpr int ACTP = (ACT < NCH) ? ACT + 1 : NCH;   // (the neighbour of the last active chunk is read, as NULLs)
           if (TWO) {
-            constexpr int PD = TWO ? OE2 - 1 - DM : 0;  // depth OE2 (index OE2 - 1) sits in half PD & 1 of PH[PD / 2]
-            const int mo2 = (PD & 1) ? (PH[PD / 2][c] >> 16) : (int)(short)(PH[PD / 2][c] & 0xffff);
-            insig &= ((mo2 < 0) ? WFA_OFFSET_NULL : mo2) & I2h[E2D - 1][c] & D2h[E2D - 1][c];
+            // the value leaving depth DM enters the packed ring: PH[0].lo = depth DM + 1, PH[0].hi = DM + 2, ...
+#pragma unroll
+            for (int j = NP - 1; j > 0; --j)
+#pragma unroll
+              for (int c = 0; c < ACT; ++c) PH[j][c] = (int)__builtin_amdgcn_alignbit((uint32_t)PH[j][c], (uint32_t)PH[j - 1][c], 16);
+#pragma unroll
+            for (int c = 0; c < ACT; ++c) PH[0][c] = (PH[0][c] << 16) | (max(Mh[DM - 1][c], -1) & 0xffff);
           }
-        }
-        int ni[NCH], nd[NCH], nm[NCH], ni2[NCH], nd2[NCH];
-        if (__any(insig >= 0)) {
-          unsigned long long oob = 0;
-          int gi[NCH], gd[NCH];
 #pragma unroll
-          for (int c = 0; c < NCH; ++c) { gi[c] = max(Mh[OE - 1][c], Ih[E - 1][c]); gd[c] = max(Mh[OE - 1][c], Dh[E - 1][c]); }
+          for (int j = DM - 1; j > 0; --j)
 #pragma unroll
-          for (int c = 0; c < NCH; ++c) {
-            int mo_lo = 0, ie_lo = 0, mo_hi = 0, de_hi = 0;
-            if (PB) {
-              mo_lo = BD::below(Mh[OE - 1], c); ie_lo = BD::below(Ih[E - 1], c);
-              mo_hi = BD::above(Mh[OE - 1], c); de_hi = BD::above(Dh[E - 1], c);
-              ni[c] = max(mo_lo, ie_lo) + 1;
-              nd[c] = max(mo_hi, de_hi);
-            } else {
-              // I(k) = max(M_oe, I_e)(k-1) + 1, D(k) = max(M_oe, D_e)(k+1): the max commutes with the lane shift
-              ni[c] = BD::below(gi, c) + 1;
-              nd[c] = BD::above(gd, c);
-            }
-            ni2[c] = WFA_OFFSET_NULL; nd2[c] = WFA_OFFSET_NULL;
-            int mo2_lo = 0, i2e_lo = 0, mo2_hi = 0, d2e_hi = 0;
+            for (int c = 0; c < ACT; ++c) Mh[j][c] = Mh[j - 1][c];
+#pragma unroll
+          for (int c = 0; c < ACT; ++c) Mh[0][c] = cur[c];
+          s += a.g;
+          insig = -1;  // AND of all inputs: non-negative iff some input offset is not NULL-ish
+#pragma unroll
+          for (int c = 0; c < ACT; ++c) {
+            insig &= Mh[X - 1][c] & Mh[OE - 1][c] & Ih[E - 1][c] & Dh[E - 1][c];
             if (TWO) {
-              constexpr int PD = TWO ? OE2 - 1 - DM : 0;
-              const int plo = BD::below(PH[PD / 2], c, -1), phi = BD::above(PH[PD / 2], c, -1);
-              const int m2lo = (PD & 1) ? (plo >> 16) : (int)(short)(plo & 0xffff), m2hi = (PD & 1) ? (phi >> 16) : (int)(short)(phi & 0xffff);
-              mo2_lo = (m2lo < 0) ? WFA_OFFSET_NULL : m2lo; mo2_hi = (m2hi < 0) ? WFA_OFFSET_NULL : m2hi;
-              i2e_lo = BD::below(I2h[E2D - 1], c); d2e_hi = BD::above(D2h[E2D - 1], c);
-              ni2[c] = max(mo2_lo, i2e_lo) + 1;
-              nd2[c] = max(mo2_hi, d2e_hi);
+              constexpr int PD = TWO ? OE2 - 1 - DM : 0;  // depth OE2 (index OE2 - 1) sits in half PD & 1 of PH[PD / 2]
+              const int mo2 = (PD & 1) ? (PH[PD / 2][c] >> 16) : (int)(short)(PH[PD / 2][c] & 0xffff);
+              insig &= ((mo2 < 0) ? WFA_OFFSET_NULL : mo2) & I2h[E2D - 1][c] & D2h[E2D - 1][c];
             }
-            int m = max(max(nd[c], nd2[c]), max(Mh[X - 1][c] + 1, max(ni[c], ni2[c])));
-            if (m > lim[c]) m = WFA_OFFSET_NULL;  // only M is clamped; negative values are dead already
-            nm[c] = m;
-            if (PB) {
-              // the choice the backtrace would make (R/wavefront_backtrace.c:49-59: mismatch > D2 ext > D2 open > D1 ext >
-              // D1 open > I2 ext > I2 open > I1 ext > I1 open on equal offsets), taken here where the candidates are in registers
-              const int x1 = Mh[X - 1][c] + 1;
-              if (TWO) {
-                const int best = max(max(nd[c], nd2[c]), max(x1, max(ni[c], ni2[c])));
-                const int mc = (x1 >= best) ? 0 : (nd2[c] >= best) ? 2 : (nd[c] >= best) ? 1 : (ni2[c] >= best) ? 4 : 3;
-                code[c] = mc | ((ie_lo >= mo_lo) ? 8 : 0) | ((de_hi >= mo_hi) ? 16 : 0) | ((i2e_lo >= mo2_lo) ? 32 : 0) | ((d2e_hi >= mo2_hi) ? 64 : 0);
+          }
+          int ni[NCH], nd[NCH], nm[NCH], ni2[NCH], nd2[NCH];
+          if (__any(insig >= 0)) {
+            unsigned long long oob = 0;
+            int gi[NCH], gd[NCH];
+#pragma unroll
+            for (int c = 0; c < ACTP; ++c) { gi[c] = max(Mh[OE - 1][c], Ih[E - 1][c]); gd[c] = max(Mh[OE - 1][c], Dh[E - 1][c]); }
+#pragma unroll
+            for (int c = 0; c < ACT; ++c) {
+              int mo_lo = 0, ie_lo = 0, mo_hi = 0, de_hi = 0;
+              if (PB) {
+                mo_lo = BD::below(Mh[OE - 1], c); ie_lo = BD::below(Ih[E - 1], c);
+                mo_hi = BD::above(Mh[OE - 1], c); de_hi = BD::above(Dh[E - 1], c);
+                ni[c] = max(mo_lo, ie_lo) + 1;
+                nd[c] = max(mo_hi, de_hi);
               } else {
-                const int mc = (x1 >= max(nd[c], ni[c])) ? 0 : ((nd[c] >= ni[c]) ? 1 : 2);
-                code[c] = mc | ((ie_lo >= mo_lo) ? 4 : 0) | ((de_hi >= mo_hi) ? 8 : 0);
+                // I(k) = max(M_oe, I_e)(k-1) + 1, D(k) = max(M_oe, D_e)(k+1): the max commutes with the lane shift
+                ni[c] = BD::below(gi, c) + 1;
+                nd[c] = BD::above(gd, c);
               }
-            }
-            oob |= __ballot(max(max(ni[c], nd[c]), max(ni2[c], nd2[c])) > lim[c]);
-          }
-          if (oob) {
-            // trim the ends of I and D (R/wavefront_compute.c:571-605): outside [first,last] in-bounds -> NULL
-            unsigned long long bi[NCH], bd[NCH];
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-              bi[c] = __ballot(ni[c] >= 0 && ni[c] <= lim[c]);
-              bd[c] = __ballot(nd[c] >= 0 && nd[c] <= lim[c]);
-            }
-            const int ilo = BD::first_pos(bi), ihi = BD::last_pos(bi), dlo = BD::first_pos(bd), dhi = BD::last_pos(bd);
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-              const int pos = c * 64 + lane;
-              if (pos < ilo || pos > ihi) ni[c] = WFA_OFFSET_NULL;
-              if (pos < dlo || pos > dhi) nd[c] = WFA_OFFSET_NULL;
-            }
-            if (TWO) {
-#pragma unroll
-              for (int c = 0; c < NCH; ++c) {
-                bi[c] = __ballot(ni2[c] >= 0 && ni2[c] <= lim[c]);
-                bd[c] = __ballot(nd2[c] >= 0 && nd2[c] <= lim[c]);
+              ni2[c] = WFA_OFFSET_NULL; nd2[c] = WFA_OFFSET_NULL;
+              int mo2_lo = 0, i2e_lo = 0, mo2_hi = 0, d2e_hi = 0;
+              if (TWO) {
+                constexpr int PD = TWO ? OE2 - 1 - DM : 0;
+                const int plo = BD::below(PH[PD / 2], c, -1), phi = BD::above(PH[PD / 2], c, -1);
+                const int m2lo = (PD & 1) ? (plo >> 16) : (int)(short)(plo & 0xffff), m2hi = (PD & 1) ? (phi >> 16) : (int)(short)(phi & 0xffff);
+                mo2_lo = (m2lo < 0) ? WFA_OFFSET_NULL : m2lo; mo2_hi = (m2hi < 0) ? WFA_OFFSET_NULL : m2hi;
+                i2e_lo = BD::below(I2h[E2D - 1], c); d2e_hi = BD::above(D2h[E2D - 1], c);
+                ni2[c] = max(mo2_lo, i2e_lo) + 1;
+                nd2[c] = max(mo2_hi, d2e_hi);
               }
-              const int i2lo = BD::first_pos(bi), i2hi = BD::last_pos(bi), d2lo = BD::first_pos(bd), d2hi = BD::last_pos(bd);
+              int m = max(max(nd[c], nd2[c]), max(Mh[X - 1][c] + 1, max(ni[c], ni2[c])));
+              if (m > lim[c]) m = WFA_OFFSET_NULL;  // only M is clamped; negative values are dead already
+              nm[c] = m;
+              if (PB) {
+                // the choice the backtrace would make (R/wavefront_backtrace.c:49-59: mismatch > D2 ext > D2 open > D1 ext >
+                // D1 open > I2 ext > I2 open > I1 ext > I1 open on equal offsets), taken here where the candidates are in registers
+                const int x1 = Mh[X - 1][c] + 1;
+                if (TWO) {
+                  const int best = max(max(nd[c], nd2[c]), max(x1, max(ni[c], ni2[c])));
+                  const int mc = (x1 >= best) ? 0 : (nd2[c] >= best) ? 2 : (nd[c] >= best) ? 1 : (ni2[c] >= best) ? 4 : 3;
+                  code[c] = mc | ((ie_lo >= mo_lo) ? 8 : 0) | ((de_hi >= mo_hi) ? 16 : 0) | ((i2e_lo >= mo2_lo) ? 32 : 0) | ((d2e_hi >= mo2_hi) ? 64 : 0);
+                } else {
+                  const int mc = (x1 >= max(nd[c], ni[c])) ? 0 : ((nd[c] >= ni[c]) ? 1 : 2);
+                  code[c] = mc | ((ie_lo >= mo_lo) ? 4 : 0) | ((de_hi >= mo_hi) ? 8 : 0);
+                }
+              }
+              oob |= __ballot(max(max(ni[c], nd[c]), max(ni2[c], nd2[c])) > lim[c]);
+            }
+            if (oob) {
+              // trim the ends of I and D (R/wavefront_compute.c:571-605): outside [first,last] in-bounds -> NULL
+              unsigned long long bi[NCH] = {}, bd[NCH] = {};   // (zero beyond the active chunks)
 #pragma unroll
-              for (int c = 0; c < NCH; ++c) {
+              for (int c = 0; c < ACT; ++c) {
+                bi[c] = __ballot(ni[c] >= 0 && ni[c] <= lim[c]);
+                bd[c] = __ballot(nd[c] >= 0 && nd[c] <= lim[c]);
+              }
+              const int ilo = BD::first_pos(bi), ihi = BD::last_pos(bi), dlo = BD::first_pos(bd), dhi = BD::last_pos(bd);
+#pragma unroll
+              for (int c = 0; c < ACT; ++c) {
                 const int pos = c * 64 + lane;
-                if (pos < i2lo || pos > i2hi) ni2[c] = WFA_OFFSET_NULL;
-                if (pos < d2lo || pos > d2hi) nd2[c] = WFA_OFFSET_NULL;
+                if (pos < ilo || pos > ihi) ni[c] = WFA_OFFSET_NULL;
+                if (pos < dlo || pos > dhi) nd[c] = WFA_OFFSET_NULL;
+              }
+              if (TWO) {
+#pragma unroll
+                for (int c = 0; c < ACT; ++c) {
+                  bi[c] = __ballot(ni2[c] >= 0 && ni2[c] <= lim[c]);
+                  bd[c] = __ballot(nd2[c] >= 0 && nd2[c] <= lim[c]);
+                }
+                const int i2lo = BD::first_pos(bi), i2hi = BD::last_pos(bi), d2lo = BD::first_pos(bd), d2hi = BD::last_pos(bd);
+#pragma unroll
+                for (int c = 0; c < ACT; ++c) {
+                  const int pos = c * 64 + lane;
+                  if (pos < i2lo || pos > i2hi) ni2[c] = WFA_OFFSET_NULL;
+                  if (pos < d2lo || pos > d2hi) nd2[c] = WFA_OFFSET_NULL;
+                }
               }
             }
+          } else {
+#pragma unroll
+            for (int c = 0; c < ACT; ++c) { ni[c] = WFA_OFFSET_NULL; nd[c] = WFA_OFFSET_NULL; nm[c] = WFA_OFFSET_NULL; ni2[c] = WFA_OFFSET_NULL; nd2[c] = WFA_OFFSET_NULL; }
           }
-        } else {
 #pragma unroll
-          for (int c = 0; c < NCH; ++c) { ni[c] = WFA_OFFSET_NULL; nd[c] = WFA_OFFSET_NULL; nm[c] = WFA_OFFSET_NULL; ni2[c] = WFA_OFFSET_NULL; nd2[c] = WFA_OFFSET_NULL; }
-        }
+          for (int j = E - 1; j > 0; --j)
 #pragma unroll
-        for (int j = E - 1; j > 0; --j)
+            for (int c = 0; c < ACT; ++c) { Ih[j][c] = Ih[j - 1][c]; Dh[j][c] = Dh[j - 1][c]; }
 #pragma unroll
-          for (int c = 0; c < NCH; ++c) { Ih[j][c] = Ih[j - 1][c]; Dh[j][c] = Dh[j - 1][c]; }
+          for (int c = 0; c < ACT; ++c) { Ih[0][c] = ni[c]; Dh[0][c] = nd[c]; cur[c] = nm[c]; }
+          if (TWO) {
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) { Ih[0][c] = ni[c]; Dh[0][c] = nd[c]; cur[c] = nm[c]; }
-        if (TWO) {
+            for (int j = E2D - 1; j > 0; --j)
 #pragma unroll
-          for (int j = E2D - 1; j > 0; --j)
+              for (int c = 0; c < ACT; ++c) { I2h[j][c] = I2h[j - 1][c]; D2h[j][c] = D2h[j - 1][c]; }
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) { I2h[j][c] = I2h[j - 1][c]; D2h[j][c] = D2h[j - 1][c]; }
-#pragma unroll
-          for (int c = 0; c < NCH; ++c) { I2h[0][c] = ni2[c]; D2h[0][c] = nd2[c]; }
-        }
+            for (int c = 0; c < ACT; ++c) { I2h[0][c] = ni2[c]; D2h[0][c] = nd2[c]; }
+          }
+        };
+        if (ACT_SMALL < NCH && !big) compute_next(std::integral_constant<int, ACT_SMALL>{});
+        else compute_next(std::integral_constant<int, NCH>{});
         // ---------------- limits (R/wavefront_unialign.c:98-107, R/wavefront_extend.c:97-104) ----------------
         // The reference walks every integer score; here only multiples of g exist, the scores in between are null steps.
         // A run of more than `scope` null scores after the last non-null one ends the alignment "unreachable" at score

@@ -67,8 +67,17 @@ __device__ __forceinline__ uint32_t pk_clamp(uint32_t nm, uint32_t lim) {
   return (nm & ~m) | (WFA_LANE_NULL2 & m);
 }
 
+#ifndef WFA_LANE_WAVES_PER_EU
+#define WFA_LANE_WAVES_PER_EU 0   // > 0: cap the registers for that many waves per SIMD (the 4/6/2 shape needs 109 VGPRs: 4 waves)
+#endif
+#if WFA_LANE_WAVES_PER_EU > 0
+#define WFA_LANE_OCCUPANCY __attribute__((amdgpu_waves_per_eu(WFA_LANE_WAVES_PER_EU, WFA_LANE_WAVES_PER_EU)))
+#else
+#define WFA_LANE_OCCUPANCY
+#endif
+
 template <int X, int OE, int E>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) WFA_LANE_OCCUPANCY
 wfa_lane_kernel(const FastArgs a, const int slot_words, const int refill_min) {
   constexpr int W = 16, H = 8, NR = 8;            // band of 16 diagonals = 8 packed registers
   constexpr int DM = (X > OE) ? X : OE;           // depth of the M ring
