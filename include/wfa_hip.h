@@ -155,6 +155,27 @@ int wfa_hip_align_batch(wfa_hip_aligner_t* aligner, int64_t n,
                         uint8_t* cigar_ops, const int64_t* cigar_off,
                         int64_t* cigar_begin, int32_t* cigar_len);
 
+/* ---- host helper: the 2-bit packing the large-batch upload uses ----------------------------------- */
+
+/*
+ * Packs `len` ASCII bases into (len + 15) / 16 words: word w holds bases 16 w .. 16 w + 15, base j in bits 2 j .. 2 j + 1,
+ * code (c >> 1) & 3 ('A' 0, 'C' 1, 'T' 2, 'G' 3), zero beyond the end — the layout the kernels read.  Host only, needs no
+ * GPU.  wfa_hip_align_batch / wfa_hip_batch_create run it on several host threads for batches of >= 256 k pairs, so
+ * that 2 bits per base cross PCIe instead of 8 (the reference has no counterpart: it reads the caller's bytes in place,
+ * wavefront_sequences.c:153-250).  form: -1 = the best the CPU has; 0 plain C, 1 AVX2, 2 AVX-512BW (for tests; a form the
+ * CPU lacks falls back to plain C).  Returns 1 if some byte is not one of ACGT (such a pair is aligned on its bytes),
+ * 0 if none, WFA_HIP_EINVAL on bad arguments.
+ */
+int wfa_hip_pack_2bit(const uint8_t* seq, int32_t len, uint32_t* words, int form);
+
+/*
+ * The number of blob bytes a batch description reaches: max over pairs of p_off + p_len and t_off + t_len (host only,
+ * several threads), or -1 if an offset or a length is negative or an argument is missing.  For bindings: the align /
+ * create calls take the blob by pointer only, so a binding that knows the blob's size checks it against this first
+ * (pywfa_amd/_native.py does; pywfa itself passes one str per call, align.pyx:432-437).
+ */
+int64_t wfa_hip_batch_extent(int64_t n, const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len);
+
 /* ---- several devices of one node ------------------------------------------------ */
 
 /*

@@ -58,7 +58,7 @@ SYMBOLS = [
     "wfa_hip_batch_last_kernel_ms", "wfa_hip_batch_algorithmic_bytes", "wfa_hip_batch_fallback_pairs",
     "wfa_hip_batch_rle_counts", "wfa_hip_batch_rle_runs",
     "wfa_hip_plan_shards", "wfa_hip_multi_create", "wfa_hip_multi_destroy", "wfa_hip_multi_set_config",
-    "wfa_hip_multi_last_error", "wfa_hip_multi_align_batch",
+    "wfa_hip_multi_last_error", "wfa_hip_multi_align_batch", "wfa_hip_pack_2bit", "wfa_hip_batch_extent",
 ]
 
 
@@ -103,6 +103,9 @@ def lib():
     L.wfa_hip_batch_rle_counts.restype = i64
     L.wfa_hip_batch_rle_runs.argtypes = [vp, vp, vp]
     L.wfa_hip_plan_shards.argtypes = [i64, vp, vp, ctypes.c_int, vp]
+    L.wfa_hip_pack_2bit.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_int]
+    L.wfa_hip_batch_extent.argtypes = [i64, vp, vp, vp, vp]
+    L.wfa_hip_batch_extent.restype = i64
     L.wfa_hip_multi_create.argtypes = [cfgp, vp, ctypes.c_int]
     L.wfa_hip_multi_create.restype = vp
     L.wfa_hip_multi_destroy.argtypes = [vp]
@@ -144,11 +147,11 @@ def _check_batch(batch):
     if not (p_off.shape[0] == t_off.shape[0] == t_len.shape[0] == n):
         raise ValueError("batch arrays differ in length")
     if n:
-        # the last pair ends the blob in the usual layouts: check it first, the full scan only otherwise
-        end = max(int(p_off[-1]) + int(p_len[-1]), int(t_off[-1]) + int(t_len[-1]))
-        if end > seqs.size or int(p_off.max()) + int(p_len.max()) > seqs.size or int(t_off.max()) + int(t_len.max()) > seqs.size:
-            if int((p_off + p_len).max()) > seqs.size or int((t_off + t_len).max()) > seqs.size:
-                raise ValueError("sequence offsets run past the blob")
+        end = lib().wfa_hip_batch_extent(n, _ptr(p_off), _ptr(p_len), _ptr(t_off), _ptr(t_len))   # (host threads: ~1 ms per 10 M pairs)
+        if end < 0:
+            raise ValueError("negative length or offset")
+        if end > seqs.size:
+            raise ValueError("sequence offsets run past the blob")
     return seqs, p_off, p_len, t_off, t_len, n
 
 
@@ -205,11 +208,19 @@ class Aligner:
         lib().wfa_hip_get_config(self._h, ctypes.byref(c))
         return c
 
-    def align_batch(self, batch, want_cigar):
-        """Host-buffer path (wfa_hip_align_batch). Returns score, status, (ops, begin, len) or None."""
+    def align_batch(self, batch, want_cigar, out=None):
+        """Host-buffer path (wfa_hip_align_batch). Returns score, status, (ops, begin, len) or None.
+        out = (score, status): int32 arrays of the batch size to write into (a loop over equally sized batches then
+        touches no fresh pages: zero-filling 2 x 40 MB for 10 M pairs costs about as much as the device work)."""
         seqs, p_off, p_len, t_off, t_len, n = _check_batch(batch)
-        score = np.zeros(n, np.int32)
-        status = np.zeros(n, np.int32)
+        if out is not None:
+            score, status = out
+            if not (score.dtype == np.int32 and status.dtype == np.int32 and score.shape == (n,) and status.shape == (n,)
+                    and score.flags.c_contiguous and status.flags.c_contiguous):
+                raise ValueError("out: two contiguous int32 arrays of the batch size")
+        else:
+            score = np.zeros(n, np.int32)
+            status = np.zeros(n, np.int32)
         if want_cigar:
             cigar_off = np.zeros(n + 1, np.int64)
             np.cumsum(p_len.astype(np.int64) + t_len.astype(np.int64), out=cigar_off[1:])
@@ -227,6 +238,16 @@ class Aligner:
 
     def batch(self, batch):
         return ResidentBatch(self, batch)
+
+
+def pack_2bit(seq, form=-1):
+    """wfa_hip_pack_2bit (host only): the 2-bit words of an ASCII sequence and whether a letter outside ACGT was seen."""
+    a = np.frombuffer(bytes(seq), dtype=np.uint8) if not isinstance(seq, np.ndarray) else np.ascontiguousarray(seq, dtype=np.uint8)
+    words = np.zeros(max((len(a) + 15) // 16, 1), np.uint32)
+    rc = lib().wfa_hip_pack_2bit(_ptr(a) if len(a) else None, len(a), _ptr(words), form)
+    if rc < 0:
+        raise ValueError("wfa_hip_pack_2bit: invalid arguments")
+    return words[:(len(a) + 15) // 16], bool(rc)
 
 
 def plan_shards(p_len, t_len, nshards):

@@ -27,6 +27,7 @@ for f in k_*.hip; do
   case $f in k_band.hip|k_seg.hip|k_general.hip|k_lane.hip|k_biwfa.hip) ;; *) run $HIPCC $FLAGS -c $f -o $OBJ/${f%.hip}.o ;; esac
 done
 run $HIPCC $FLAGS -c wfa_hip.hip -o $OBJ/wfa_hip.o
+run g++ -O3 -std=c++17 -fPIC -c host_pack.cpp -o $OBJ/host_pack.o   # host code only (AVX-512 / AVX2 / plain C, chosen at run time)
 fail=0
 for p in "${pids[@]}"; do wait $p || fail=1; done
 [ $fail -eq 0 ] || { echo "build failed"; exit 1; }

@@ -41,7 +41,7 @@ static thread_local std::string g_error;
   F(ARENA_KB) F(BAND_DEBUG) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
-  F(PIPE_CHUNK) F(PIPE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
+  F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
 enum WfaKnob {
 #define WFA_KNOB_ENUM(n) K_##n,
   WFA_KNOBS(WFA_KNOB_ENUM)
@@ -444,10 +444,17 @@ struct UploadJob { void* dst; const void* src; size_t bytes; std::function<void(
 
 static size_t staged_slot_bytes(const wfa_hip_aligner* al) { return (size_t)std::max(1, knob(al, K_PIPE_CHUNK, 8)) << 20; }
 
-static int staged_upload(wfa_hip_aligner* al, const std::vector<UploadJob>& jobs, hipStream_t stream) {
+static int staged_copy_threads(const wfa_hip_aligner* al) {
+  return std::max(1, std::min(knob(al, K_PIPE_THREADS, 8), (int)std::thread::hardware_concurrency()));
+}
+static int staged_pack_threads(const wfa_hip_aligner* al) {   // (packing is compute: more threads than the plain copy needs)
+  return std::max(1, std::min(knob(al, K_PACK_THREADS, 32), std::max(1, (int)std::thread::hardware_concurrency() / 2)));
+}
+
+// the ring serves both forms of the upload: sized for the larger team so that alternating calls do not re-allocate it
+static int staged_ring(wfa_hip_aligner* al) {
   const size_t slot_bytes = staged_slot_bytes(al);
-  const int nthreads = std::max(1, std::min(knob(al, K_PIPE_THREADS, 8), (int)std::thread::hardware_concurrency()));
-  const int nslots = nthreads + 4;
+  const int nslots = std::max(staged_copy_threads(al), staged_pack_threads(al)) + 4;
   if (al->pin_slot_bytes != slot_bytes || (int)al->pin_slot.size() != nslots) {
     for (uint8_t* p : al->pin_slot) (void)hipHostFree(p);
     for (hipEvent_t e : al->pin_ev) (void)hipEventDestroy(e);
@@ -462,6 +469,14 @@ static int staged_upload(wfa_hip_aligner* al, const std::vector<UploadJob>& jobs
     }
     al->pin_slot_bytes = slot_bytes;
   }
+  return WFA_HIP_OK;
+}
+
+static int staged_upload(wfa_hip_aligner* al, const std::vector<UploadJob>& jobs, hipStream_t stream) {
+  const size_t slot_bytes = staged_slot_bytes(al);
+  const int nthreads = staged_copy_threads(al);
+  { const int rrc = staged_ring(al); if (rrc != WFA_HIP_OK) return rrc; }
+  const int nslots = (int)al->pin_slot.size();
   struct Piece { void* dst; const uint8_t* src; size_t bytes; const UploadJob* job; size_t off; };
   std::vector<Piece> pieces;
   for (const UploadJob& j : jobs)
@@ -499,6 +514,72 @@ static int staged_upload(wfa_hip_aligner* al, const std::vector<UploadJob>& jobs
   return WFA_HIP_OK;
 }
 
+// Host-packed form of the pipelined upload: the host threads pack the caller's ASCII sequences to
+// 2 bits per base (host_pack.cpp: AVX-512 / AVX2 / plain C) straight into the pinned slots, together with the per-pair
+// metadata, so 76 + 16 B per 150 bp pair cross PCIe instead of 300 + 32 B and the device pack kernel is not run.
+// A piece is a run of whole 64-pair blocks whose words and metadata fit one slot.  Pairs with a letter outside ACGT are
+// listed in `flagged` (ascending); the caller uploads their bytes separately.  Returns after every piece is ENQUEUED:
+// the caller's arrays are not read after that.
+namespace wfa { bool host_pack_seq(const uint8_t* s, int len, uint32_t* out, int form); }
+
+struct PackPiece { int64_t lo, hi; uint64_t wlo; uint64_t nwords; };
+
+static int staged_pack_upload(wfa_hip_aligner* al, wfa_hip_batch* b, const std::vector<PackPiece>& pieces, const uint8_t* seqs,
+                              const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len,
+                              hipStream_t stream, std::vector<uint32_t>* flagged) {
+  { const int rrc = staged_ring(al); if (rrc != WFA_HIP_OK) return rrc; }
+  const int nslots = (int)al->pin_slot.size();
+  const int nthreads = std::min<int>(staged_pack_threads(al), std::max<int>(1, (int)pieces.size()));
+  const long np = (long)pieces.size();
+  std::atomic<long> next(0);
+  std::vector<std::atomic<long>> issued((size_t)nslots);
+  for (auto& x : issued) x.store(-1);
+  std::atomic<int> failed(0);
+  std::vector<std::vector<uint32_t>> bad((size_t)np);
+  const int device = al->device;
+  auto worker = [&]() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      const long i = next.fetch_add(1);
+      if (i >= np || failed.load()) return;
+      const PackPiece& pc = pieces[(size_t)i];
+      const int sl = (int)(i % nslots);
+      if (i >= nslots) while (issued[(size_t)sl].load(std::memory_order_acquire) != i - nslots) std::this_thread::yield();
+      if (al->pin_ev_recorded[(size_t)sl] && hipEventSynchronize(al->pin_ev[(size_t)sl]) != hipSuccess) failed.store(1);
+      uint32_t* words = reinterpret_cast<uint32_t*>(al->pin_slot[(size_t)sl]);
+      const size_t meta_at = ((size_t)pc.nwords * 4 + 15) & ~(size_t)15;
+      WfaPairMeta* meta = reinterpret_cast<WfaPairMeta*>(al->pin_slot[(size_t)sl] + meta_at);
+      uint64_t w = pc.wlo;
+      for (int64_t q = pc.lo; q < pc.hi; ++q) {
+        const int pl = p_len[q], tl = t_len[q];
+        WfaPairMeta& m = meta[q - pc.lo];
+        m.plen = pl; m.tlen = tl;
+        m.p_woff = (uint32_t)w;
+        bool bd = wfa::host_pack_seq(seqs + p_off[q], pl, words + (w - pc.wlo), -1);
+        w += (uint64_t)((pl + 15) >> 4);
+        m.t_woff = (uint32_t)w;
+        bd |= wfa::host_pack_seq(seqs + t_off[q], tl, words + (w - pc.wlo), -1);
+        w += (uint64_t)((tl + 15) >> 4);
+        if (bd) bad[(size_t)i].push_back((uint32_t)q);
+      }
+      bool ok = true;
+      if (pc.nwords) ok = hipMemcpyAsync(b->d_words + pc.wlo, words, (size_t)pc.nwords * 4, hipMemcpyHostToDevice, stream) == hipSuccess;
+      ok = ok && hipMemcpyAsync(b->d_meta + pc.lo, meta, (size_t)(pc.hi - pc.lo) * sizeof(WfaPairMeta), hipMemcpyHostToDevice, stream) == hipSuccess;
+      ok = ok && hipEventRecord(al->pin_ev[(size_t)sl], stream) == hipSuccess;
+      if (!ok) failed.store(1);
+      al->pin_ev_recorded[(size_t)sl] = 1;
+      issued[(size_t)sl].store(i, std::memory_order_release);
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nthreads; ++t) th.emplace_back(worker);
+  worker();
+  for (auto& x : th) x.join();
+  if (failed.load()) { al->err = "pipelined upload failed"; return WFA_HIP_EDEVICE; }
+  for (auto& v : bad) flagged->insert(flagged->end(), v.begin(), v.end());
+  return WFA_HIP_OK;
+}
+
 static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const uint8_t* seqs,
                        const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len) {
   b->cfg = al->cfg; b->dcfg = al->dcfg; b->ncomp = al->ncomp;
@@ -516,12 +597,20 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
   // writes each piece straight into its pinned slot — no host copy of the metadata exists
   const bool pipelined = n >= 262144 && knob(al, K_NO_PIPE, 0) == 0;
   const int64_t piece_pairs = (int64_t)(staged_slot_bytes(al) / sizeof(WfaPairMeta));
-  const int nthr = pipelined ? (int)((n + piece_pairs - 1) / piece_pairs)
+  // (pipelined: a piece of the metadata upload = `sub` parts of pass 1, so that a large team shares pass 1 evenly)
+  const int sub = pipelined ? 8 : 1;
+  const int64_t part_pairs = piece_pairs / sub;   // (a multiple of 64: the slot size is whole megabytes)
+  const int nthr = pipelined ? (int)((n + part_pairs - 1) / part_pairs)
                              : (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, std::thread::hardware_concurrency()), n / 65536));
-  auto part_lo = [&](int t) -> int64_t { return pipelined ? std::min<int64_t>(n, (int64_t)t * piece_pairs) : n * t / nthr; };
+  auto part_lo = [&](int t) -> int64_t { return pipelined ? std::min<int64_t>(n, (int64_t)t * part_pairs) : n * t / nthr; };
   std::unique_ptr<WfaPairMeta[]> meta(pipelined ? nullptr : new WfaPairMeta[(size_t)std::max<int64_t>(n, 1)]);  // not zero-filled: first touched in parallel below
   struct Part { uint64_t words = 0; int64_t packed = 0, ops = 0, blob_end = 0; int max_width = 0, max_len = 0, err = 0; };
   std::vector<Part> parts((size_t)nthr);
+  // host-packed upload: large batches without a wildcard (a wildcard aligns every pair on its bytes).  Pass 1 then also
+  // sums the words of every block of 64 pairs (the parts start on block boundaries), the pieces of the upload are cut
+  // from those below
+  bool host_pack = pipelined && c.wildcard < 0 && knob(al, K_HOST_PACK, 1) != 0;
+  std::vector<uint32_t> blk_words(host_pack ? (size_t)((n + 63) >> 6) : 0, 0u);
   auto pass1 = [&](int t) {
     Part& pt = parts[(size_t)t];
     const int64_t lo = part_lo(t), hi = part_lo(t + 1);
@@ -533,6 +622,7 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
       if (c.span == WFA_SPAN_ENDSFREE &&
           (c.pattern_begin_free > pl || c.pattern_end_free > pl || c.text_begin_free > tl || c.text_end_free > tl)) { pt.err = 3; return; }
       pt.words += (uint64_t)((pl + 15) >> 4) + (uint64_t)((tl + 15) >> 4);
+      if (host_pack) blk_words[(size_t)(i >> 6)] += (uint32_t)((pl + 15) >> 4) + (uint32_t)((tl + 15) >> 4);
       pt.max_width = std::max(pt.max_width, pl + tl + 3);
       pt.max_len = std::max(pt.max_len, std::max(pl, tl));
       pt.packed += (int64_t)((pl + 3) >> 2) + ((tl + 3) >> 2);
@@ -543,7 +633,7 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
   auto run_threads = [&](auto&& fn) {
     if (nthr == 1) { fn(0); return; }
     // (a bounded team: the parts are claimed from a counter)
-    const int team = std::min(nthr, std::max(1, std::min(16, (int)std::thread::hardware_concurrency())));
+    const int team = std::min(nthr, std::max(1, std::min(pipelined ? 32 : 16, (int)std::thread::hardware_concurrency() / (pipelined ? 2 : 1))));
     std::atomic<int> nextp(0);
     auto loop = [&]() { for (int t = nextp.fetch_add(1); t < nthr; t = nextp.fetch_add(1)) fn(t); };
     std::vector<std::thread> th;
@@ -565,9 +655,26 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
     b->packed_bytes += pt.packed; b->ops_bytes += pt.ops; blob_end = std::max(blob_end, pt.blob_end);
   }
   if (woff > 0xFFFFFFF0ull) { al->err = "batch too large: more than 2^32 packed words (split the batch)"; return WFA_HIP_EINVAL; }
-  auto pass2_part = [&](int t, WfaPairMeta* out /* element 0 = pair part_lo(t) */) {
+  std::vector<PackPiece> pack_pieces;
+  if (host_pack) {
+    const size_t slot = staged_slot_bytes(al);
+    PackPiece cur{0, 0, 0, 0};
+    const int64_t nblk = (n + 63) >> 6;
+    for (int64_t bi = 0; bi < nblk && host_pack; ++bi) {
+      const int64_t blo = bi << 6, bhi = std::min<int64_t>(n, blo + 64);
+      const uint64_t bw = blk_words[(size_t)bi];
+      if ((size_t)bw * 4 + 16 + 64 * sizeof(WfaPairMeta) > slot) host_pack = false;   // (very long reads: the plain form)
+      if (cur.hi > cur.lo && (size_t)(cur.nwords + bw) * 4 + 16 + (size_t)(bhi - cur.lo) * sizeof(WfaPairMeta) > slot) {
+        pack_pieces.push_back(cur);
+        cur = PackPiece{blo, blo, cur.wlo + cur.nwords, 0};
+      }
+      cur.hi = bhi; cur.nwords += bw;
+    }
+    if (cur.hi > cur.lo) pack_pieces.push_back(cur);
+  }
+  auto pass2_part = [&](int t, WfaPairMeta* out /* element 0 = pair part_lo(t) */, int nparts = 1) {
     uint64_t w = wbase[(size_t)t];
-    const int64_t lo = part_lo(t), hi = part_lo(t + 1);
+    const int64_t lo = part_lo(t), hi = part_lo(std::min(t + nparts, nthr));
     for (int64_t i = lo; i < hi; ++i) {
       const int pl = p_len[i], tl = t_len[i];
       WfaPairMeta& m = out[i - lo];
@@ -580,7 +687,7 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
   if (timing) { fprintf(stderr, "[wfa_hip] meta pass %.3f ms\n", now_ms() - t0); t0 = now_ms(); }
   const bool full = (c.scope == WFA_SCOPE_FULL);
   const size_t nn = (size_t)std::max<int64_t>(n, 1);
-  HIP_TRY(al, pool_alloc(al, (void**)&b->d_bytes, (size_t)blob_end + 64));
+  if (!host_pack) HIP_TRY(al, pool_alloc(al, (void**)&b->d_bytes, (size_t)blob_end + 64));
   HIP_TRY(al, pool_alloc(al, (void**)&b->d_pboff, nn * sizeof(int64_t)));
   HIP_TRY(al, pool_alloc(al, (void**)&b->d_tboff, nn * sizeof(int64_t)));
   HIP_TRY(al, pool_alloc(al, (void**)&b->d_meta, nn * sizeof(WfaPairMeta)));
@@ -609,12 +716,56 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
     if (n > 256) HIP_TRY(al, hipStreamSynchronize(al->stream)); else b->uploads_pending = true;
   }
   if (timing) { fprintf(stderr, "[wfa_hip] mallocs %.3f ms\n", now_ms() - t0); t0 = now_ms(); }
-  if (n > 0) {
+  if (n > 0 && host_pack) {
+    std::vector<uint32_t> flagged;
+    const int urc = staged_pack_upload(al, b, pack_pieces, seqs, p_off, p_len, t_off, t_len, al->stream, &flagged);
+    if (urc != WFA_HIP_OK) return urc;
+    if (timing) { fprintf(stderr, "[wfa_hip] host pack + H2D enqueue %.3f ms (%.2f GB of ASCII, %.2f GB sent)\n", now_ms() - t0, blob_end / 1e9,
+                          (woff * 4.0 + n * 16.0) / 1e9); t0 = now_ms(); }
+    b->n_bytes = (uint32_t)flagged.size();
+    b->n_packed = (uint32_t)n;
+    if (!flagged.empty()) {
+      // the few pairs with other letters: their bytes in a compact blob, byte offsets and flags scattered to their slots
+      const size_t nb = flagged.size();
+      std::vector<int64_t> fpo(nb), fto(nb);
+      size_t blob = 0;
+      for (size_t j = 0; j < nb; ++j) { fpo[j] = (int64_t)blob; blob += (size_t)p_len[flagged[j]]; fto[j] = (int64_t)blob; blob += (size_t)t_len[flagged[j]]; }
+      std::vector<uint8_t> hb(blob + 1);
+      for (size_t j = 0; j < nb; ++j) {
+        memcpy(hb.data() + fpo[j], seqs + p_off[flagged[j]], (size_t)p_len[flagged[j]]);
+        memcpy(hb.data() + fto[j], seqs + t_off[flagged[j]], (size_t)t_len[flagged[j]]);
+      }
+      int64_t *d_fpo = nullptr, *d_fto = nullptr;
+      HIP_TRY(al, pool_alloc(al, (void**)&b->d_bytes, blob + 64));
+      HIP_TRY(al, pool_alloc(al, (void**)&b->d_list_bytes, nb * sizeof(uint32_t)));
+      HIP_TRY(al, pool_alloc(al, (void**)&d_fpo, nb * sizeof(int64_t)));
+      HIP_TRY(al, pool_alloc(al, (void**)&d_fto, nb * sizeof(int64_t)));
+      HIP_TRY(al, hipMemcpyAsync(b->d_bytes, hb.data(), blob, hipMemcpyHostToDevice, al->stream));
+      HIP_TRY(al, hipMemcpyAsync(b->d_list_bytes, flagged.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice, al->stream));
+      HIP_TRY(al, hipMemcpyAsync(d_fpo, fpo.data(), nb * sizeof(int64_t), hipMemcpyHostToDevice, al->stream));
+      HIP_TRY(al, hipMemcpyAsync(d_fto, fto.data(), nb * sizeof(int64_t), hipMemcpyHostToDevice, al->stream));
+      hipLaunchKernelGGL(wfa::wfa_flag_scatter_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, al->stream,
+                         b->d_list_bytes, d_fpo, d_fto, (uint32_t)nb, b->d_pboff, b->d_tboff, b->d_flags);
+      HIP_TRY(al, hipGetLastError());
+      // the list of the 2-bit pairs = all pairs but the flagged ones (ascending)
+      std::vector<uint32_t> lp;
+      lp.reserve((size_t)n - nb);
+      size_t fj = 0;
+      for (int64_t i = 0; i < n; ++i) { if (fj < nb && flagged[fj] == (uint32_t)i) { ++fj; continue; } lp.push_back((uint32_t)i); }
+      b->n_packed = (uint32_t)lp.size();
+      if (!lp.empty()) {
+        HIP_TRY(al, pool_alloc(al, (void**)&b->d_list_packed, lp.size() * sizeof(uint32_t)));
+        HIP_TRY(al, hipMemcpyAsync(b->d_list_packed, lp.data(), lp.size() * sizeof(uint32_t), hipMemcpyHostToDevice, al->stream));
+      }
+      HIP_TRY(al, hipStreamSynchronize(al->stream));   // (host vectors above go out of scope)
+      pool_release(al, d_fpo); pool_release(al, d_fto);
+    }
+  } else if (n > 0) {
     if (pipelined) {
       // host threads -> pinned ring -> DMA; the metadata pieces are computed into their slots, the caller's arrays copied
       std::vector<UploadJob> jobs;
       jobs.push_back({b->d_meta, nullptr, (size_t)n * sizeof(WfaPairMeta),
-                      [&](uint8_t* out, size_t off, size_t) { pass2_part((int)(off / staged_slot_bytes(al)), reinterpret_cast<WfaPairMeta*>(out)); }});
+                      [&](uint8_t* out, size_t off, size_t) { pass2_part((int)(off / staged_slot_bytes(al)) * sub, reinterpret_cast<WfaPairMeta*>(out), sub); }});
       jobs.push_back({b->d_bytes, seqs, (size_t)blob_end, nullptr});
       jobs.push_back({b->d_pboff, p_off, (size_t)n * sizeof(int64_t), nullptr});
       jobs.push_back({b->d_tboff, t_off, (size_t)n * sizeof(int64_t), nullptr});
@@ -1482,6 +1633,32 @@ extern "C" int wfa_hip_align_batch(wfa_hip_aligner_t* al, int64_t n, const uint8
   if (timing) fprintf(stderr, "[wfa_hip] align_batch: create %.3f ms, enqueue %.3f ms, sync + results %.3f ms, destroy %.3f ms\n",
                       t1 - t0, t2 - t1, t3 - t2, now_ms() - t3);
   return rc;
+}
+
+extern "C" int64_t wfa_hip_batch_extent(int64_t n, const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len) {
+  if (n < 0 || (n > 0 && (!p_off || !p_len || !t_off || !t_len))) return -1;
+  const int team = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, std::thread::hardware_concurrency()), n / 262144));
+  std::vector<int64_t> ends((size_t)team, 0);
+  auto work = [&](int t) {
+    int64_t e = 0;
+    for (int64_t i = n * t / team, hi = n * (t + 1) / team; i < hi; ++i) {
+      if (p_off[i] < 0 || t_off[i] < 0 || p_len[i] < 0 || t_len[i] < 0) { e = -1; break; }
+      e = std::max(e, std::max(p_off[i] + p_len[i], t_off[i] + t_len[i]));
+    }
+    ends[(size_t)t] = e;
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < team; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+  int64_t e = 0;
+  for (int64_t v : ends) { if (v < 0) return -1; e = std::max(e, v); }
+  return e;
+}
+
+extern "C" int wfa_hip_pack_2bit(const uint8_t* seq, int32_t len, uint32_t* words, int form) {
+  if (len < 0 || (len > 0 && (!seq || !words))) return WFA_HIP_EINVAL;
+  return wfa::host_pack_seq(seq, len, words, form) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -64,4 +64,14 @@ wfa_pack_kernel(const uint8_t* __restrict__ bytes, const int64_t* __restrict__ p
   }
 }
 
+// Host-packed upload: byte offsets and flags of the pairs that hold a letter outside ACGT (their bytes sit in a compact blob).
+__global__ void __launch_bounds__(256)
+wfa_flag_scatter_kernel(const uint32_t* __restrict__ ids, const int64_t* __restrict__ pb, const int64_t* __restrict__ tb, uint32_t nb,
+                        int64_t* __restrict__ p_boff, int64_t* __restrict__ t_boff, uint8_t* __restrict__ flags) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nb) return;
+  const uint32_t id = ids[j];
+  p_boff[id] = pb[j]; t_boff[id] = tb[j]; flags[id] = 1;
+}
+
 }  // namespace wfa

@@ -120,3 +120,28 @@ def test_shard_planner_properties():
     import pytest
     with pytest.raises(ValueError):
         _native.plan_shards(np.zeros(3, np.int32), np.zeros(3, np.int32), 0)
+
+
+def test_host_pack_2bit_all_forms():
+    """wfa_hip_pack_2bit (host only): every form (plain C / AVX2 / AVX-512BW, a form the CPU lacks falls back) gives the
+    words of the device layout — base j of word w in bits 2 j, code (c >> 1) & 3, zero beyond the end — and reports
+    letters outside ACGT; every length around the 16 / 32 / 64-base rounds, reads that end at the end of their buffer."""
+    import numpy as np
+    from pywfa_amd import _native
+
+    def ref(s):
+        a = np.frombuffer(s, dtype=np.uint8)
+        n = len(a); nw = (n + 15) // 16
+        c = np.zeros(nw * 16, np.uint64); c[:n] = (a >> 1) & 3
+        w = (c.reshape(nw, 16) << (2 * np.arange(16, dtype=np.uint64))).sum(1).astype(np.uint32) if nw else np.zeros(0, np.uint32)
+        return w, any(ch not in b"ACGT" for ch in s)
+
+    rng = np.random.default_rng(5)
+    for form in (-1, 0, 1, 2):
+        for L in list(range(0, 200)) + [255, 256, 257, 1000, 10007]:
+            s = bytes(rng.choice(list(b"ACGT"), size=L).astype(np.uint8))
+            if L and rng.random() < 0.3:
+                i = int(rng.integers(L)); s = s[:i] + bytes([int(rng.choice(list(b"NacgtRY\x00\xff")))]) + s[i + 1:]
+            w, bad = _native.pack_2bit(s, form)
+            rw, rbad = ref(s)
+            assert bad == rbad and np.array_equal(w, rw), (form, L, s)

@@ -290,3 +290,50 @@ def test_two_devices_parity(gpu):
     m.close()
     s1, st1, _ = common.gpu_run(nc, batch, False, False)
     assert np.array_equal(score, s1) and np.array_equal(status, st1)
+
+
+@pytest.mark.parametrize("scope", ["score", "full"])
+def test_host_packed_upload_matches_the_device_packed_one(gpu, scope, monkeypatch):
+    """Batches of >= 256 k pairs are packed to 2 bits per base by host threads on their way into the pinned upload ring
+    (csrc/host_pack.cpp); WFA_HIP_HOST_PACK=0 keeps the ASCII upload + device pack kernel.  Both give the same results, on
+    a ragged batch with letters outside ACGT sprinkled in (those pairs are aligned on their bytes), and a sample agrees with
+    the oracle."""
+    rng = np.random.default_rng(77)
+    base = datagen.generate(300000, 150, 0.03, 4242)
+    pats, txts = [], []
+    for i in range(2000):   # ragged head: other lengths, N / lower case / empty
+        p, t = datagen.pair_strings(base, i)
+        k = i % 7
+        if k == 0: p = p[:int(rng.integers(0, 150))]
+        if k == 1: t = t[:80] + "N" + t[81:]
+        if k == 2: p = p.lower()
+        if k == 3: p, t = "", t[:33]
+        if k == 4: p = p * 3
+        pats.append(p); txts.append(t)
+    head = datagen.from_strings(pats, txts, upper=False)
+    shift = len(head["seqs"])
+    batch = dict(seqs=np.concatenate([head["seqs"], base["seqs"]]),
+                 p_off=np.concatenate([head["p_off"], base["p_off"][2000:] + shift]), p_len=np.concatenate([head["p_len"], base["p_len"][2000:]]),
+                 t_off=np.concatenate([head["t_off"], base["t_off"][2000:] + shift]), t_len=np.concatenate([head["t_len"], base["t_len"][2000:]]))
+    oc, nc = common.configs_pair(span="end-to-end", scope=scope)
+    full = scope == "full"
+    res = {}
+    for hp in ("1", "0"):
+        monkeypatch.setenv("WFA_HIP_HOST_PACK", hp)
+        al = _native.Aligner(nc)     # (the knobs are read when the aligner is created)
+        res[hp] = al.align_batch(batch, full)
+        al.close()
+    s1, st1, c1 = res["1"]; s0, st0, c0 = res["0"]
+    assert np.array_equal(s1, s0) and np.array_equal(st1, st0)
+    if full:
+        assert np.array_equal(c1[1], c0[1]) and np.array_equal(c1[2], c0[2])
+        sel = np.r_[0:2500, 299000:300000]
+        for i in sel:
+            assert c1[0][c1[1][i]:c1[1][i] + c1[2][i]].tobytes() == c0[0][c0[1][i]:c0[1][i] + c0[2][i]].tobytes()
+    sel = np.r_[0:2500, 299000:300000]
+    sub = datagen.subset(batch, sel)
+    o = loader.run(loader.oracle(), oc, sub, want_cigar=full)
+    assert np.array_equal(s1[sel], o["score"]) and np.array_equal(st1[sel], o["status"])
+    if full:
+        for j, i in enumerate(sel):
+            assert c1[0][c1[1][i]:c1[1][i] + c1[2][i]].tobytes() == o["cigars"][j]
