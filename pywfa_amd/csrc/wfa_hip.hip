@@ -24,6 +24,7 @@
 #include "wfa_common.hpp"
 #include "wfa_pack.hpp"
 #include "wfa_general.hpp"
+#include "wfa_wide.hpp"
 #include "wfa_fast.hpp"
 #include "wfa_seg.hpp"
 #include "wfa_lane.hpp"
@@ -41,7 +42,7 @@ static thread_local std::string g_error;
   F(ARENA_KB) F(BAND_DEBUG) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
-  F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
+  F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_WIDE) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
 enum WfaKnob {
 #define WFA_KNOB_ENUM(n) K_##n,
   WFA_KNOBS(WFA_KNOB_ENUM)
@@ -1042,7 +1043,9 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       const int only = knob(al, K_BAND_NCH, 0);
       if (only) { n_stages = 1; band_nch[0] = only; }
     }
-    const bool any_pre = use_fast || use_segfull || n_stages > 0;
+    const bool wide_ok = !tiny && b->ncomp == 3 && b->dcfg.metric == 3 && b->dcfg.heuristic == WFA_HEUR_NONE && b->dcfg.match == 0 &&
+                         b->max_len > 64 && 2 * (int64_t)b->max_len <= 32000 && b->dcfg.e1 >= 1 && b->dcfg.x >= 1 && knob(al, K_NO_WIDE, 0) == 0;
+    const bool any_pre = use_fast || use_segfull || n_stages > 0 || wide_ok;
     Geometry g = plan_general(al, b, any_pre ? std::min<uint32_t>(in_n, (uint32_t)al->cu_count * 16) : in_n, b->arena_fixed + b->arena_ints);
     size_t need = (size_t)g.grid * g.ws_stride * 4;
     // band history: fixed-stride records per score step, one slice per wave
@@ -1083,6 +1086,42 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         }
       }
       band_grid[i] = grid;
+    }
+    // Wide-wavefront stage (wfa_wide.hpp): exact gap-affine pairs the register windows cannot hold (or never try: reads
+    // over 1.2 kb without a heuristic) — one alignment per workgroup, the wavefront rows in LDS; what it hands on goes to
+    // the general kernel.  Rows as wide as LDS allows, at most the whole diagonal range of the longest pair.
+    wfa::WideArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    bool use_wide = false;
+    int wide_grid = 0, wide_threads = 0;
+    size_t wide_smem = 0;
+    if (wide_ok) {
+      wa.g = wfa::gcd_int(wfa::gcd_int(b->dcfg.x, b->dcfg.o1 + b->dcfg.e1), b->dcfg.e1);
+      wa.X = b->dcfg.x / wa.g; wa.OE = (b->dcfg.o1 + b->dcfg.e1) / wa.g; wa.E = b->dcfg.e1 / wa.g;
+      wa.seq_words = ((b->max_len + 15) >> 4) + 4;
+      const int nrows = std::max(wa.X, wa.OE) + 1 + 2 * (wa.E + 1) + 1;
+      const size_t lds_max = (size_t)std::min(160, std::max(16, knob(al, K_WIDE_LDS_KB, 160))) * 1024;
+      const size_t fixed = wfa::wide_smem_bytes(wa.X, wa.OE, wa.E, 0, wa.seq_words);
+      if (wa.E >= 1 && wa.X >= 1 && fixed + (size_t)nrows * 2 * 512 <= lds_max) {
+        int wcap = (int)((lds_max - fixed) / ((size_t)nrows * 2)) - 4;
+        wcap = std::min(wcap, 2 * b->max_len + 4 + b->dcfg.pbf + b->dcfg.tbf) & ~1;
+        wa.wcap = wcap;
+        wide_smem = wfa::wide_smem_bytes(wa.X, wa.OE, wa.E, wcap, wa.seq_words);
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, ((size_t)160 * 1024) / wide_smem));
+        wide_threads = knob(al, K_WIDE_THREADS, per_cu >= 4 ? 256 : (per_cu >= 2 ? 512 : 1024));
+        wide_grid = (int)std::min<int64_t>((int64_t)al->cu_count * per_cu, in_n);
+        use_wide = true;
+        if (full) {
+          // history: one byte per cell up to the step where a wavefront would outgrow the rows, + directory + events
+          const int64_t tmax = (int64_t)wcap * wa.E / 2 + 64;
+          int64_t bytes = (int64_t)wcap * wcap * wa.E / 4 + 16 * tmax + (1 << 16);
+          const int64_t budget = free_budget(al);
+          while (wide_grid > 1 && (int64_t)wide_grid * bytes > budget) wide_grid = (wide_grid + 1) / 2;
+          bytes = std::min<int64_t>(bytes, budget / std::max(wide_grid, 1));
+          wa.hist_stride = (bytes / 4) & ~15ll;
+          need = std::max(need, (size_t)wide_grid * (size_t)wa.hist_stride * 4);
+        }
+      }
     }
     // The narrowest band that keeps most pairs is the cheapest start; it depends on the divergence of the batch (16
     // lanes up to ~3 %, 32 up to ~6 %, 64 up to ~10 %).  A pilot on the first 8192 pairs (score-only kernels, one-round
@@ -1265,6 +1304,21 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       } else {
         if (wfa::launch_band(ba, band_nch[i], full, adapt, seqlds, band_grid[i], stream) != 0) { al->err = "band kernel launch failed"; return WFA_HIP_EDEVICE; }
       }
+      if (first_stage) b->last_kernel_pairs = in_n;
+      in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
+    }
+    if (use_wide) {
+      uint32_t* out_list = b->d_fb_list2[out_sel];
+      uint32_t* out_count = b->d_counters + 4 + out_sel;
+      if (!first_stage) HIP_TRY(al, hipMemsetAsync(out_count, 0, sizeof(uint32_t), stream));
+      wa.words = b->d_words; wa.meta = b->d_meta; wa.worklist = in_list; wa.nwork_dev = in_count; wa.nwork = in_n;
+      wa.score = b->d_score; wa.status = b->d_status; wa.fb_list = out_list; wa.fb_count = out_count;
+      wa.cigar_ops = b->d_ops; wa.cigar_off = b->d_cigar_off; wa.cigar_begin = b->d_cigar_begin; wa.cigar_len = b->d_cigar_len;
+      wa.hist = al->ws;
+      wa.ef = b->dcfg.endsfree ? 1 : 0;
+      wa.pbf = b->dcfg.pbf; wa.pef = b->dcfg.pef; wa.tbf = b->dcfg.tbf; wa.tef = b->dcfg.tef;
+      wa.max_steps = b->dcfg.max_steps;
+      if (wfa::launch_wide(full, wa, wide_grid, wide_threads, wide_smem, stream) != 0) { al->err = "wide kernel launch failed"; return WFA_HIP_EDEVICE; }
       if (first_stage) b->last_kernel_pairs = in_n;
       in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
     }

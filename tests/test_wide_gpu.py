@@ -1,0 +1,87 @@
+"""The wide-wavefront kernel (csrc/wfa_wide.hpp: exact gap-affine alignment, one pair per workgroup, wavefront rows in LDS)
+against the oracle.  Batches of more than 128 pairs so that the staged path runs (smaller batches go straight to the general
+kernel); reads of 2-3 kb at 10 % without a heuristic outgrow the 256-diagonal register window, so the banded stages hand
+them on (or are skipped: reads over 1.2 kb) and this kernel takes them."""
+import numpy as np
+import pytest
+
+import common
+from oracle import loader
+from pywfa_amd import _native, datagen
+
+pytestmark = pytest.mark.gpu
+
+
+def ragged_batch(n, length, error, seed):
+    """`n` pairs of about `length` bases with length differences, a few short / empty ones mixed in."""
+    rng = np.random.default_rng(seed)
+    b = datagen.generate(n, length, error, seed)
+    pats, txts = [], []
+    for i in range(n):
+        p, t = datagen.pair_strings(b, i)
+        k = i % 9
+        if k == 1: p = p[:len(p) - int(rng.integers(1, 200))]
+        if k == 2: t = t[int(rng.integers(1, 200)):]
+        if k == 3: p = p[:int(rng.integers(0, 40))]
+        if k == 4 and i % 36 == 4: p, t = "", t[:17]
+        pats.append(p); txts.append(t)
+    return datagen.from_strings(pats, txts)
+
+
+CASES = [
+    dict(span="end-to-end", scope="score"),
+    dict(span="end-to-end", scope="full"),
+    dict(span="ends-free", scope="full", pattern_begin_free=30, pattern_end_free=40, text_begin_free=20, text_end_free=10),
+    dict(span="ends-free", scope="score", pattern_begin_free=0, pattern_end_free=0, text_begin_free=50, text_end_free=50),
+    dict(span="end-to-end", scope="full", mismatch=2, gap_opening=3, gap_extension=1),
+    dict(span="end-to-end", scope="full", mismatch=5, gap_opening=0, gap_extension=3),
+    dict(span="end-to-end", scope="score", mismatch=1, gap_opening=1, gap_extension=1),
+    dict(span="end-to-end", scope="full", mismatch=6, gap_opening=5, gap_extension=3, memory_mode="medium"),
+    dict(span="end-to-end", scope="score", max_steps=300),
+    dict(span="end-to-end", scope="full", max_steps=1000),
+]
+
+
+@pytest.mark.parametrize("idx", range(len(CASES)))
+def test_wide_kernel_matches_oracle(gpu, idx):
+    batch = ragged_batch(180, 2500, 0.10, 9100 + idx)
+    kw = common.clamp_free(dict(CASES[idx]), batch)
+    oc, nc = common.configs_pair(**kw)
+    full = oc.scope == 1
+    o = loader.run(loader.oracle(), oc, batch, want_cigar=full)
+    score, status, cigars = common.gpu_run(nc, batch, full, resident=bool(idx % 2))
+    common.assert_same(o, score, status, cigars, batch, f"wide {kw}")
+
+
+@pytest.mark.parametrize("scope", ["score", "full"])
+def test_wide_kernel_rows_too_narrow_hand_on(gpu, scope, monkeypatch):
+    """With 24 KB of LDS the rows hold a few hundred diagonals: most pairs outgrow them and are handed on to the general
+    kernel; the results do not change.  (And with the kernel switched off.)"""
+    batch = ragged_batch(150, 3000, 0.10, 9200)
+    oc, nc = common.configs_pair(span="end-to-end", scope=scope)
+    full = scope == "full"
+    o = loader.run(loader.oracle(), oc, batch, want_cigar=full)
+    for env in ({"WFA_HIP_WIDE_LDS_KB": "24"}, {"WFA_HIP_NO_WIDE": "1"}, {"WFA_HIP_WIDE_THREADS": "256"}):
+        for k_, v_ in env.items(): monkeypatch.setenv(k_, v_)
+        score, status, cigars = common.gpu_run(nc, batch, full, resident=True)
+        for k_ in env: monkeypatch.delenv(k_)
+        common.assert_same(o, score, status, cigars, batch, f"wide {env}")
+
+
+def test_wide_kernel_10kb_exact_sample(gpu):
+    """BASELINE-sized reads: 10 kb at 8 % without a heuristic (wavefronts of ~5 000 diagonals), score and full CIGAR."""
+    batch = datagen.generate(136, 10000, 0.08, datagen.SEEDS["C3"])
+    sel = np.r_[0:6, 130:136]
+    for scope in ("score", "full"):
+        oc, nc = common.configs_pair(span="end-to-end", scope=scope)
+        full = scope == "full"
+        fn = loader.reference() if loader.have_reference() else loader.oracle()
+        o = loader.run(fn, oc, datagen.subset(batch, sel), want_cigar=full)
+        score, status, cigars = common.gpu_run(nc, batch, full, resident=True)
+        assert np.array_equal(score[sel], o["score"]) and np.array_equal(status[sel], o["status"])
+        if full:
+            for j, i in enumerate(sel):
+                assert bytes(cigars[i]) == o["cigars"][j]
+        # every pair: full and score scopes agree (checked through the second pass of the loop)
+        if scope == "score": s_score = score
+        else: assert np.array_equal(s_score, score)
