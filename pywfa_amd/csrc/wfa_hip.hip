@@ -553,6 +553,7 @@ static int staged_pack_upload(wfa_hip_aligner* al, wfa_hip_batch* b, const std::
       uint64_t w = pc.wlo;
       for (int64_t q = pc.lo; q < pc.hi; ++q) {
         const int pl = p_len[q], tl = t_len[q];
+        if (p_off[q] < 0 || t_off[q] < 0) { failed.store(2); break; }
         WfaPairMeta& m = meta[q - pc.lo];
         m.plen = pl; m.tlen = tl;
         m.p_woff = (uint32_t)w;
@@ -576,6 +577,7 @@ static int staged_pack_upload(wfa_hip_aligner* al, wfa_hip_batch* b, const std::
   for (int t = 1; t < nthreads; ++t) th.emplace_back(worker);
   worker();
   for (auto& x : th) x.join();
+  if (failed.load() == 2) { al->err = "negative length or offset"; return WFA_HIP_EINVAL; }
   if (failed.load()) { al->err = "pipelined upload failed"; return WFA_HIP_EDEVICE; }
   for (auto& v : bad) flagged->insert(flagged->end(), v.begin(), v.end());
   return WFA_HIP_OK;
@@ -611,13 +613,15 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
   // sums the words of every block of 64 pairs (the parts start on block boundaries), the pieces of the upload are cut
   // from those below
   bool host_pack = pipelined && c.wildcard < 0 && knob(al, K_HOST_PACK, 1) != 0;
+  const bool light = host_pack;
   std::vector<uint32_t> blk_words(host_pack ? (size_t)((n + 63) >> 6) : 0, 0u);
   auto pass1 = [&](int t) {
     Part& pt = parts[(size_t)t];
     const int64_t lo = part_lo(t), hi = part_lo(t + 1);
     for (int64_t i = lo; i < hi; ++i) {
       const int pl = p_len[i], tl = t_len[i];
-      if (pl < 0 || tl < 0 || p_off[i] < 0 || t_off[i] < 0) { pt.err = 1; return; }
+      // (host-packed upload: the offsets are first read, and checked, by the pack workers; pass 1 reads the lengths only)
+      if (pl < 0 || tl < 0 || (!light && (p_off[i] < 0 || t_off[i] < 0))) { pt.err = 1; return; }
       if ((int64_t)pl + tl > (int64_t)INT_MAX / 2 - 8) { pt.err = 2; return; }
       // wavefront_align.c:86-102: the reference exit(1)s here
       if (c.span == WFA_SPAN_ENDSFREE &&
@@ -628,7 +632,14 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
       pt.max_len = std::max(pt.max_len, std::max(pl, tl));
       pt.packed += (int64_t)((pl + 3) >> 2) + ((tl + 3) >> 2);
       pt.ops += (int64_t)pl + tl;
-      pt.blob_end = std::max(pt.blob_end, std::max(p_off[i] + pl, t_off[i] + tl));
+      if (!light) pt.blob_end = std::max(pt.blob_end, std::max(p_off[i] + pl, t_off[i] + tl));
+    }
+  };
+  auto pass_offsets = [&](int t) {   // what a light pass 1 left out (the host-packed form turned out not to fit)
+    Part& pt = parts[(size_t)t];
+    for (int64_t i = part_lo(t), hi = part_lo(t + 1); i < hi; ++i) {
+      if (p_off[i] < 0 || t_off[i] < 0) { pt.err = 1; return; }
+      pt.blob_end = std::max(pt.blob_end, std::max(p_off[i] + (int64_t)p_len[i], t_off[i] + (int64_t)t_len[i]));
     }
   };
   auto run_threads = [&](auto&& fn) {
@@ -672,6 +683,13 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
       cur.hi = bhi; cur.nwords += bw;
     }
     if (cur.hi > cur.lo) pack_pieces.push_back(cur);
+    if (!host_pack) {
+      run_threads(pass_offsets);
+      for (int t = 0; t < nthr; ++t) {
+        if (parts[(size_t)t].err == 1) { al->err = "negative length or offset"; return WFA_HIP_EINVAL; }
+        blob_end = std::max(blob_end, parts[(size_t)t].blob_end);
+      }
+    }
   }
   auto pass2_part = [&](int t, WfaPairMeta* out /* element 0 = pair part_lo(t) */, int nparts = 1) {
     uint64_t w = wbase[(size_t)t];
@@ -721,7 +739,7 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
     std::vector<uint32_t> flagged;
     const int urc = staged_pack_upload(al, b, pack_pieces, seqs, p_off, p_len, t_off, t_len, al->stream, &flagged);
     if (urc != WFA_HIP_OK) return urc;
-    if (timing) { fprintf(stderr, "[wfa_hip] host pack + H2D enqueue %.3f ms (%.2f GB of ASCII, %.2f GB sent)\n", now_ms() - t0, blob_end / 1e9,
+    if (timing) { fprintf(stderr, "[wfa_hip] host pack + H2D enqueue %.3f ms (%.2f GB of ASCII, %.2f GB sent)\n", now_ms() - t0, b->ops_bytes / 1e9,
                           (woff * 4.0 + n * 16.0) / 1e9); t0 = now_ms(); }
     b->n_bytes = (uint32_t)flagged.size();
     b->n_packed = (uint32_t)n;
