@@ -42,7 +42,7 @@ static thread_local std::string g_error;
   F(ARENA_KB) F(BAND_DEBUG) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
-  F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_WIDE) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
+  F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_DUAL) F(NO_WIDE) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
 enum WfaKnob {
 #define WFA_KNOB_ENUM(n) K_##n,
   WFA_KNOBS(WFA_KNOB_ENUM)
@@ -84,6 +84,10 @@ struct wfa_hip_aligner {
   // one first waits for ws_event (recorded after each run), so runs are stream-ordered whatever streams callers pass
   hipEvent_t ws_event = nullptr;
   hipStream_t ws_last_stream = nullptr;
+  // the walks of a split stage's launch run on this stream, under the alignment kernel of the next launch (which writes
+  // the other half of the workspace); created on first use
+  hipStream_t side_stream = nullptr;
+  hipEvent_t band_event[2] = {nullptr, nullptr}, walk_event[2] = {nullptr, nullptr};
   bool ws_event_recorded = false;
   // pinned staging ring of the pipelined upload (batches of >= 256 k pairs): host threads copy pieces of the caller's
   // pageable arrays into the slots, each slot goes to the device by DMA as soon as it is full
@@ -376,6 +380,8 @@ static void aligner_free(wfa_hip_aligner* al) {
   if (al->tiny_h) (void)hipHostFree(al->tiny_h);
   if (al->tiny_d) (void)hipFree(al->tiny_d);
   for (hipEvent_t e : al->pin_ev) (void)hipEventDestroy(e);
+  if (al->side_stream) (void)hipStreamDestroy(al->side_stream);
+  for (int i = 0; i < 2; ++i) { if (al->band_event[i]) (void)hipEventDestroy(al->band_event[i]); if (al->walk_event[i]) (void)hipEventDestroy(al->walk_event[i]); }
   if (al->stream) (void)hipStreamDestroy(al->stream);
   delete al;
 }
@@ -886,6 +892,55 @@ extern "C" wfa_hip_batch_t* wfa_hip_batch_create(wfa_hip_aligner_t* al, int64_t 
   return b;
 }
 
+// ---- the walks of a split stage on a stream of their own ----------------------------------------------
+// Launch i of a split stage = alignment kernel (history into half i & 1 of the workspace) + the walks of its pairs.  The
+// walks are latency-bound chains with little parallelism (one thread per alignment): they run on the side stream, under the
+// alignment kernel of the next launch, which goes to the other half.  (Alternating whole launches between two streams
+// measured worse: two alignment kernels at once, C4 -35 %.)
+struct DualStream {
+  wfa_hip_aligner* al; hipStream_t main; bool on = false; bool used[2] = {false, false};
+  int begin(bool want) {
+    on = false; used[0] = used[1] = false;
+    if (!want || knob(al, K_NO_DUAL, 0) != 0) return WFA_HIP_OK;
+    if (!al->side_stream) {
+      HIP_TRY(al, hipStreamCreateWithFlags(&al->side_stream, hipStreamNonBlocking));
+      for (int i = 0; i < 2; ++i) {
+        HIP_TRY(al, hipEventCreateWithFlags(&al->band_event[i], hipEventDisableTiming));
+        HIP_TRY(al, hipEventCreateWithFlags(&al->walk_event[i], hipEventDisableTiming));
+      }
+    }
+    on = true;
+    return WFA_HIP_OK;
+  }
+  // before the alignment kernel of `launch` is enqueued on main: its half must be free (the walks of launch - 2 are over)
+  int before_align(int64_t launch) {
+    if (on && used[launch & 1]) HIP_TRY(al, hipStreamWaitEvent(main, al->walk_event[launch & 1], 0));
+    return WFA_HIP_OK;
+  }
+  // the stream for the walks of `launch` (call after its alignment kernel was enqueued on main)
+  int walk_stream(int64_t launch, hipStream_t* out) {
+    *out = main;
+    if (!on) return WFA_HIP_OK;
+    HIP_TRY(al, hipEventRecord(al->band_event[launch & 1], main));
+    HIP_TRY(al, hipStreamWaitEvent(al->side_stream, al->band_event[launch & 1], 0));
+    *out = al->side_stream;
+    return WFA_HIP_OK;
+  }
+  int after_walk(int64_t launch) {
+    if (!on) return WFA_HIP_OK;
+    HIP_TRY(al, hipEventRecord(al->walk_event[launch & 1], al->side_stream));
+    used[launch & 1] = true;
+    return WFA_HIP_OK;
+  }
+  // join: `main` continues after every walk
+  int end() {
+    if (!on) return WFA_HIP_OK;
+    for (int i = 0; i < 2; ++i) if (used[i]) HIP_TRY(al, hipStreamWaitEvent(main, al->walk_event[i], 0));
+    on = false;
+    return WFA_HIP_OK;
+  }
+};
+
 // ---- launch geometry -------------------------------------------------------------------------------
 
 static int ensure_ws(wfa_hip_aligner* al, size_t bytes) {
@@ -1182,7 +1237,8 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         int64_t want = (i == 0) ? std::min<int64_t>((int64_t)knob(al, K_SEGFULL_PAIRS, 2000000), std::max<int64_t>(1, ((int64_t)8 << 30) / slot_bytes))
                                 : std::max<int64_t>(4096, (int64_t)in_n / (i == 1 ? 8 : 32));
         segfull_cap[i] = std::max<int64_t>(1, std::min<int64_t>(in_n, std::min<int64_t>(want, free_budget(al) / slot_bytes)));
-        need = std::max(need, (size_t)(segfull_cap[i] * slot_bytes));
+        // (several launches: two slot arrays, the walks of a launch run under the alignment kernel of the next)
+        need = std::max(need, (size_t)(segfull_cap[i] * slot_bytes) * ((i == 0 && segfull_cap[i] < (int64_t)in_n) ? 2 : 1));
       }
     }
     int rc = ensure_ws(al, need);
@@ -1209,14 +1265,27 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       // (first stage: the host knows the count and walks it in launches of `cap` pairs; later stages: one launch over
       // the device-side list, slots for `cap` of its pairs)
       const int64_t total = (in_count == nullptr) ? (int64_t)in_n : segfull_cap[sf];
-      for (int64_t w0 = 0; w0 < total; w0 += segfull_cap[sf]) {
+      const size_t half_bytes = ((size_t)segfull_cap[sf] * (size_t)(segfull_slot_ints[sf] * 4 + (int64_t)sizeof(int4)) + 255) & ~(size_t)255;
+      DualStream dual{al, stream};
+      { const int drc = dual.begin(sf == 0 && in_count == nullptr && total > segfull_cap[sf] && al->ws_bytes >= 2 * half_bytes); if (drc != WFA_HIP_OK) return drc; }
+      int64_t launch = 0;
+      for (int64_t w0 = 0; w0 < total; w0 += segfull_cap[sf], ++launch) {
         const uint32_t cnt = (uint32_t)std::min<int64_t>(segfull_cap[sf], total - w0);
+        char* base = reinterpret_cast<char*>(al->ws) + ((dual.on && (launch & 1)) ? half_bytes : 0);
+        fa.hist = reinterpret_cast<int32_t*>(base);
+        fa.end_state = reinterpret_cast<int4*>(base + (size_t)segfull_cap[sf] * segfull_slot_ints[sf] * 4);
+        ba.hist = fa.hist; ba.end_state = fa.end_state;
         fa.work_begin = (uint32_t)w0; fa.nwork = cnt;
+        { const int drc = dual.before_align(launch); if (drc != WFA_HIP_OK) return drc; }
         if (in_count != nullptr) HIP_TRY(al, hipMemsetAsync(fa.end_state, 0, (size_t)cnt * sizeof(int4), stream));
         if (wfa::launch_seg_full(b->dcfg, al->cu_count, knob(al, K_FAST_WAVES_PER_CU, 256), stream, fa, segfull_w[sf]) != 0) { al->err = "segmented kernel launch failed"; return WFA_HIP_EDEVICE; }
         ba.work_begin = (uint32_t)w0; ba.nwork = cnt;
-        if (wfa::launch_band_bt(ba, 1, stream) != 0) { al->err = "backtrace launch failed"; return WFA_HIP_EDEVICE; }
+        hipStream_t ws_ = stream;
+        { const int drc = dual.walk_stream(launch, &ws_); if (drc != WFA_HIP_OK) return drc; }
+        if (wfa::launch_band_bt(ba, 1, ws_) != 0) { al->err = "backtrace launch failed"; return WFA_HIP_EDEVICE; }
+        { const int drc = dual.after_walk(launch); if (drc != WFA_HIP_OK) return drc; }
       }
+      { const int drc = dual.end(); if (drc != WFA_HIP_OK) return drc; }
       if (first_stage) b->last_kernel_pairs = in_n;
       in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
     }
@@ -1306,19 +1375,36 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         if (pb_mode && pb_stride) { ba.pb = 1; ba.hist_stride = pb_stride; ba.pb_code_ints = pb_code_ints; ba.pb_event_ints = pb_event_ints; }
         const int64_t slot_bytes = slot_ints * 4 + (int64_t)sizeof(int4);
         int64_t per_launch = (int64_t)(al->ws_bytes / (size_t)slot_bytes);
+        // more than one launch: two halves of the workspace, the walks of a launch run on the side stream under the alignment
+        // kernel of the next launch
+        // (only while a halved launch still fills the chip a few times over: gap-affine-2p at 10 kb runs 2 waves per SIMD and
+        // its launches are small already — halving them measured -35 %)
+        const bool two = per_launch < (int64_t)in_n && per_launch / 2 >= (int64_t)al->cu_count * 32 && knob(al, K_NO_DUAL, 0) == 0;
+        if (two) per_launch /= 2;
         per_launch = std::min<int64_t>(per_launch, in_n);
         const int64_t full_grid = (int64_t)al->cu_count * knob(al, K_BAND_WAVES_PER_CU, 128);
         if (per_launch > full_grid) per_launch = (per_launch / full_grid) * full_grid;  // whole rounds of waves
         if (per_launch < 1) { al->err = "band history does not fit"; return WFA_HIP_EDEVICE; }
         ba.split = 1;
-        ba.end_state = reinterpret_cast<int4*>(reinterpret_cast<char*>(al->ws) + (size_t)per_launch * slot_ints * 4);
-        for (int64_t w0 = 0; w0 < in_n; w0 += per_launch) {
+        const size_t half_bytes = ((size_t)per_launch * (size_t)slot_bytes + 255) & ~(size_t)255;
+        DualStream dual{al, stream};
+        { const int drc = dual.begin(two && al->ws_bytes >= 2 * half_bytes); if (drc != WFA_HIP_OK) return drc; }
+        int64_t launch = 0;
+        for (int64_t w0 = 0; w0 < in_n; w0 += per_launch, ++launch) {
           const uint32_t cnt = (uint32_t)std::min<int64_t>(per_launch, in_n - w0);
+          char* base = reinterpret_cast<char*>(al->ws) + ((dual.on && (launch & 1)) ? half_bytes : 0);
+          ba.hist = reinterpret_cast<int32_t*>(base);
+          ba.end_state = reinterpret_cast<int4*>(base + (size_t)per_launch * slot_ints * 4);
           ba.work_begin = (uint32_t)w0; ba.nwork = cnt;
           const long long grid = std::min<long long>((long long)al->cu_count * knob(al, K_BAND_WAVES_PER_CU, 128), cnt);
+          { const int drc = dual.before_align(launch); if (drc != WFA_HIP_OK) return drc; }
           if (wfa::launch_band(ba, band_nch[i], full, adapt, seqlds, grid, stream) != 0) { al->err = "band kernel launch failed"; return WFA_HIP_EDEVICE; }
-          if (wfa::launch_band_bt(ba, band_nch[i], stream) != 0) { al->err = "band backtrace launch failed"; return WFA_HIP_EDEVICE; }
+          hipStream_t ws_ = stream;
+          { const int drc = dual.walk_stream(launch, &ws_); if (drc != WFA_HIP_OK) return drc; }
+          if (wfa::launch_band_bt(ba, band_nch[i], ws_) != 0) { al->err = "band backtrace launch failed"; return WFA_HIP_EDEVICE; }
+          { const int drc = dual.after_walk(launch); if (drc != WFA_HIP_OK) return drc; }
         }
+        { const int drc = dual.end(); if (drc != WFA_HIP_OK) return drc; }
       } else {
         if (wfa::launch_band(ba, band_nch[i], full, adapt, seqlds, band_grid[i], stream) != 0) { al->err = "band kernel launch failed"; return WFA_HIP_EDEVICE; }
       }
