@@ -134,8 +134,9 @@ def run_resident(al, batch, steps, warmup, want_cigar, barrier=None):
     return out
 
 
-def extra_config(name, n, length, error, seed, cfg_kw, scheme, survey_bytes, trim=0, cpu_pairs=400, cpu_budget=4.0):
-    """One of the other BASELINE configurations on a stated prefix: kernel time, roofline, CPU baseline, parity."""
+def extra_config(name, n, length, error, seed, cfg_kw, scheme, survey_bytes, trim=0, cpu_pairs=400, cpu_budget=4.0, env=None):
+    """One of the other BASELINE configurations on a stated prefix: kernel time, roofline, CPU baseline, parity.
+    env: library knobs for this configuration (read when its aligner is created)."""
     from pywfa_amd import _native, datagen
     from oracle import loader
     batch = datagen.generate(n, length, error, seed)
@@ -146,7 +147,13 @@ def extra_config(name, n, length, error, seed, cfg_kw, scheme, survey_bytes, tri
     for fname, _ in _native.Config._fields_:
         setattr(nc, fname, getattr(oc, fname))
     full = oc.scope == 1
-    al = _native.Aligner(nc, 0)
+    for k_, v_ in (env or {}).items():
+        os.environ[k_] = v_
+    try:
+        al = _native.Aligner(nc, 0)
+    finally:
+        for k_ in (env or {}):
+            del os.environ[k_]
     r = run_resident(al, batch, 3, 1, full)
     al.close()
     wc = work_counts(batch, cfg_kw, 8 if length >= 5000 else 2000)
@@ -371,19 +378,26 @@ def main():
             try:
                 xs.append(extra_config("C1", 1_000_000, 150, 0.02, datagen.SEEDS["C1"], dict(scope="full"), "explicit", 236,
                                        cpu_pairs=200000, cpu_budget=3.0))
+                # (long reads keep the piggy-back history by default; WFA_HIP_BAND_PB=0 = the explicit offsets, for the record)
                 xs.append(extra_config("C3", 100_000, 10000, 0.08, datagen.SEEDS["C3"],
-                                       dict(span="end-to-end", scope="full", heuristic="adaptive"), "explicit", 750e3))
-                xs.append(extra_config("C3-piggyback", 100_000, 10000, 0.08, datagen.SEEDS["C3"],
-                                       dict(span="end-to-end", scope="full", heuristic="adaptive", memory_mode="medium"), "piggyback", 114e3))
+                                       dict(span="end-to-end", scope="full", heuristic="adaptive"), "piggyback", 114e3))
+                xs.append(extra_config("C3-explicit-history", 100_000, 10000, 0.08, datagen.SEEDS["C3"],
+                                       dict(span="end-to-end", scope="full", heuristic="adaptive"), "explicit", 750e3, env={"WFA_HIP_BAND_PB": "0"}))
                 xs.append(extra_config("C4-adaptive", 20_000, 10000, 0.08, datagen.SEEDS["C4"],
                                        dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100,
-                                            scope="full", heuristic="adaptive"), "explicit", 750e3 * 5 / 3, trim=50, cpu_pairs=100))
+                                            scope="full", heuristic="adaptive"), "piggyback", 114e3 * 5 / 3, trim=50, cpu_pairs=100))
+                xs.append(extra_config("C4-adaptive-explicit-history", 20_000, 10000, 0.08, datagen.SEEDS["C4"],
+                                       dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100,
+                                            scope="full", heuristic="adaptive"), "explicit", 750e3 * 5 / 3, trim=50, cpu_pairs=100,
+                                       env={"WFA_HIP_BAND_PB": "0"}))
             except Exception as e:
                 xs.append({"error": repr(e)})
             out["extra"]["configs"] = xs
             out["extra"]["configs_note"] = ("stated prefixes of the BASELINE streams: C1 at 1 M pairs (BASELINE names 1 k), C3 100 k of 1 M, "
                                             "C4 20 k of 1 M with wf-adaptive (stated: the exact form writes ~0.4 GB of history per pair; its "
-                                            "bytes per pair are C3's figure x 5/3 components); C2 above is the full 10 M")
+                                            "bytes per pair are C3's figure x 5/3 components); C2 above is the full 10 M.  Long reads keep the "
+                                            "piggy-back history (one byte of origin codes per cell) in every memory mode; the *-explicit-history "
+                                            "lines are the same configurations with WFA_HIP_BAND_PB=0")
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -1124,10 +1124,12 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     // band history: fixed-stride records per score step, one slice per wave
     long long band_grid[3] = {0, 0, 0};
     int64_t band_stride[3] = {0, 0, 0};
-    // memory_mode medium / low (the reference's piggy-back backtrace, R/wavefront_backtrace_offload.c): the split stage
-    // keeps one byte of origin codes per (step, diagonal) instead of the offsets and re-extends the matches afterwards
+    // The split stage (long reads) keeps the piggy-back history (the reference's R/wavefront_backtrace_offload.c scheme): one
+    // byte of origin codes per (step, diagonal) instead of the offsets, the matches re-extended afterwards.  In EVERY
+    // memory mode: the op strings are the same and it is the faster form (C3 91 vs 97 ms per 100 k pairs, C4 adaptive 57 vs
+    // 77 ms per 10 k: 8-16x less history, so more pairs per launch); WFA_HIP_BAND_PB=0 keeps the explicit offsets.
     const int pb_env = knob(al, K_BAND_PB, -1);
-    const bool pb_mode = full && (pb_env >= 0 ? pb_env != 0 : (b->cfg.memory_mode == WFA_MEM_MED || b->cfg.memory_mode == WFA_MEM_LOW));
+    const bool pb_mode = full && (pb_env >= 0 ? pb_env != 0 : true);
     int64_t pb_code_ints = 0, pb_event_ints = 0, pb_stride = 0;
     for (int i = 0; i < n_stages; ++i) {
       // 4x more waves than a CU holds at once: waves retire one after the other (oldest-first issue) and the

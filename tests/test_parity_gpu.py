@@ -247,10 +247,13 @@ def test_segmented_full_cigar_in_several_launches(gpu, span, monkeypatch):
 @pytest.mark.parametrize("kw", [dict(span="end-to-end", memory_mode="medium"), dict(span="end-to-end", memory_mode="low", heuristic="adaptive"),
                                 dict(memory_mode="medium"), dict(memory_mode="low", span="ends-free", pattern_begin_free=40, pattern_end_free=30,
                                                                  text_begin_free=25, text_end_free=35, heuristic="adaptive")])
-def test_piggyback_history_gives_the_same_cigars(gpu, kw):
-    """memory_mode medium / low: long reads keep one byte of origin codes per (step, diagonal) instead of the offsets and
-    the op string is unpacked by re-extending the matches; the reference returns the same alignments in
-    all its memory modes, and so must this."""
+@pytest.mark.parametrize("band_pb", ["default", "0"])
+def test_piggyback_history_gives_the_same_cigars(gpu, kw, band_pb, monkeypatch):
+    """Long reads keep one byte of origin codes per (step, diagonal) instead of the offsets and the op string is unpacked by
+    re-extending the matches — by default in every memory mode; WFA_HIP_BAND_PB=0 keeps the explicit offsets.
+    The reference returns the same alignments in all its memory modes, and so must both forms."""
+    if band_pb != "default":
+        monkeypatch.setenv("WFA_HIP_BAND_PB", band_pb)
     for i, (n, L, e) in enumerate([(700, 1500, 0.06), (300, 4000, 0.08), (120, 10000, 0.08), (400, 2500, 0.01)]):
         batch = datagen.generate(n, L, e, 8800 + i)
         kw2 = common.clamp_free(dict(kw, scope="full"), batch)
@@ -266,11 +269,15 @@ def test_piggyback_history_gives_the_same_cigars(gpu, kw):
                                 dict(memory_mode="low", span="ends-free", pattern_begin_free=40, pattern_end_free=30, text_begin_free=25,
                                      text_end_free=35, heuristic="adaptive"),
                                 dict(memory_mode="medium", span="end-to-end")])
-def test_piggyback_history_gap_affine_2p(gpu, kw):
-    """The piggy-back history of the banded kernel for gap-affine-2p: seven bits of origin codes per (step,
+@pytest.mark.parametrize("band_pb", ["default", "0"])
+def test_piggyback_history_gap_affine_2p(gpu, kw, band_pb, monkeypatch):
+    """(band_pb = "0": the same inputs with the explicit 16-byte history entries.)
+    The piggy-back history of the banded kernel for gap-affine-2p: seven bits of origin codes per (step,
     diagonal) — which of mismatch / D1 / D2 / I1 / I2 made M, and open-or-extend for each of I1, D1, I2, D2 — walked back
     with the reference's candidate priority (R/wavefront_backtrace.c:49-59).  Inputs with long gaps make the second gap
     piece win; the exact form (last case) runs 2p wavefronts past the 256-diagonal window into the general kernel."""
+    if band_pb != "default":
+        monkeypatch.setenv("WFA_HIP_BAND_PB", band_pb)
     exact = "heuristic" not in kw
     shapes = [(300, 1500, 0.06), (24, 3000, 0.08)] if exact else [(500, 1500, 0.06), (200, 4000, 0.08), (100, 10000, 0.08), (300, 2500, 0.01)]
     for i, (n, L, e) in enumerate(shapes):
