@@ -1124,6 +1124,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     // band history: fixed-stride records per score step, one slice per wave
     long long band_grid[3] = {0, 0, 0};
     int64_t band_stride[3] = {0, 0, 0};
+    size_t split_region = 0, later_need = 0;   // bytes of the split stage's slots; largest history of the band stages behind it
     // The split stage (long reads) keeps the piggy-back history (the reference's R/wavefront_backtrace_offload.c scheme): one
     // byte of origin codes per (step, diagonal) instead of the offsets, the matches re-extended afterwards.  In EVERY
     // memory mode: the op strings are the same and it is the faster form (C3 91 vs 97 ms per 100 k pairs, C4 adaptive 57 vs
@@ -1155,12 +1156,27 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
             pb_stride = pb_code_ints + pb_event_ints + ((2 * (int64_t)records + 8 + 63) & ~63ll);  // + run records
           }
           const int64_t slot_bytes = (pb_mode ? pb_stride : band_stride[i]) * 4 + 16;
-          int64_t pairs = std::min<int64_t>(in_n, (int64_t)al->cu_count * 32 * knob(al, K_BAND_SPLIT_ROUNDS, 4));
-          while (pairs > 1 && pairs * slot_bytes > budget) pairs = (pairs + 1) / 2;
-          need = std::max(need, (size_t)(pairs * slot_bytes));
+          // slots for every pair of the batch when they fit half of the free memory (the compact piggy-back history: C3 0.3 MB
+          // per pair), otherwise for as many pairs as do (explicit history: up to 4 x the resident waves)
+          int64_t pairs = in_n;
+          if (pairs * slot_bytes > budget / 2) {
+            pairs = std::min<int64_t>(in_n, (int64_t)al->cu_count * 32 * knob(al, K_BAND_SPLIT_ROUNDS, 4));
+            while (pairs > 1 && pairs * slot_bytes > budget) pairs = (pairs + 1) / 2;
+          }
+          split_region = ((size_t)(pairs * slot_bytes) + 255) & ~(size_t)255;
+          need = std::max(need, split_region);
+        } else if (i > 0) {
+          later_need = std::max(later_need, (size_t)grid * band_stride[i] * 4);
         }
       }
       band_grid[i] = grid;
+    }
+    // the band stages behind a split stage get a region of their own behind its slots when both fit: the walks of the split
+    // stage's last launch then run under them
+    size_t later_off = 0;
+    if (split_region && later_need && (int64_t)(split_region + later_need) <= free_budget(al)) {
+      later_off = split_region;
+      need = std::max(need, split_region + later_need);
     }
     // Wide-wavefront stage (wfa_wide.hpp): exact gap-affine pairs the register windows cannot hold (or never try: reads
     // over 1.2 kb without a heuristic) — one alignment per workgroup, the wavefront rows in LDS; what it hands on goes to
@@ -1346,6 +1362,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
       }
     }
+    DualStream pending_walks{al, stream};   // walks of a split stage left running under the band stages behind it
     for (int i = 0; i < n_stages; ++i) {
       wfa::BandArgs ba;
       memset(&ba, 0, sizeof(ba));
@@ -1368,7 +1385,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       ba.h16 = (b->max_len < 32000) ? 1 : 0;
       ba.ef = (b->dcfg.endsfree && (b->dcfg.pbf | b->dcfg.pef | b->dcfg.tbf | b->dcfg.tef)) ? 1 : 0;
       ba.pbf = b->dcfg.pbf; ba.pef = b->dcfg.pef; ba.tbf = b->dcfg.tbf; ba.tef = b->dcfg.tef;
-      ba.hist = al->ws; ba.hist_stride = band_stride[i];
+      ba.hist = (i > 0 && later_off) ? al->ws + later_off / 4 : al->ws; ba.hist_stride = band_stride[i];
       const bool split = full && in_count == nullptr && b->max_len > 1000 && knob(al, K_BAND_NO_SPLIT, 0) == 0;
       if (split) {
         // history slot per PAIR: as many pairs per launch as the workspace holds; the walks of a launch run
@@ -1376,43 +1393,60 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         const int64_t slot_ints = (pb_mode && pb_stride) ? pb_stride : band_stride[i];
         if (pb_mode && pb_stride) { ba.pb = 1; ba.hist_stride = pb_stride; ba.pb_code_ints = pb_code_ints; ba.pb_event_ints = pb_event_ints; }
         const int64_t slot_bytes = slot_ints * 4 + (int64_t)sizeof(int4);
-        int64_t per_launch = (int64_t)(al->ws_bytes / (size_t)slot_bytes);
-        // more than one launch: two halves of the workspace, the walks of a launch run on the side stream under the alignment
-        // kernel of the next launch
-        // (only while a halved launch still fills the chip a few times over: gap-affine-2p at 10 kb runs 2 waves per SIMD and
-        // its launches are small already — halving them measured -35 %)
-        const bool two = per_launch < (int64_t)in_n && per_launch / 2 >= (int64_t)al->cu_count * 32 && knob(al, K_NO_DUAL, 0) == 0;
-        if (two) per_launch /= 2;
-        per_launch = std::min<int64_t>(per_launch, in_n);
-        const int64_t full_grid = (int64_t)al->cu_count * knob(al, K_BAND_WAVES_PER_CU, 128);
-        if (per_launch > full_grid) per_launch = (per_launch / full_grid) * full_grid;  // whole rounds of waves
-        if (per_launch < 1) { al->err = "band history does not fit"; return WFA_HIP_EDEVICE; }
+        // Slots: `cap` pairs fit the stage's region.  The launches are balanced (no small last launch) and their walks run on
+        // the side stream under the next alignment kernel: every launch has slots of its own when the whole batch fits
+        // (two launches at least, if each still fills the chip a few times over), otherwise the launches alternate between
+        // two halves of the region (only while a half still fills the chip: gap-affine-2p with explicit history at 10 kb
+        // runs 2 waves per SIMD and its launches are small already — halving them measured -35 %).
+        const size_t region = later_off ? later_off : al->ws_bytes;
+        const int64_t cap = std::min<int64_t>((int64_t)(region / (size_t)slot_bytes), in_n);
+        if (cap < 1) { al->err = "band history does not fit"; return WFA_HIP_EDEVICE; }
+        const int64_t chip = (int64_t)al->cu_count * 32;
+        const bool dual_ok = knob(al, K_NO_DUAL, 0) == 0;
+        const bool all_fit = cap >= (int64_t)in_n;
+        int64_t nl, per_launch;
+        bool halves = false;
+        if (all_fit) {
+          nl = (dual_ok && (int64_t)in_n >= 4 * chip) ? 2 : 1;
+          per_launch = ((int64_t)in_n + nl - 1) / nl;
+        } else {
+          halves = dual_ok && cap / 2 >= chip;
+          const int64_t lmax = halves ? cap / 2 : cap;
+          nl = ((int64_t)in_n + lmax - 1) / lmax;
+          per_launch = std::min<int64_t>(lmax, (((int64_t)in_n + nl - 1) / nl + 63) & ~63ll);
+        }
         ba.split = 1;
-        const size_t half_bytes = ((size_t)per_launch * (size_t)slot_bytes + 255) & ~(size_t)255;
+        char* const es_base = reinterpret_cast<char*>(al->ws) + (size_t)cap * slot_ints * 4;   // end states behind the slots
         DualStream dual{al, stream};
-        { const int drc = dual.begin(two && al->ws_bytes >= 2 * half_bytes); if (drc != WFA_HIP_OK) return drc; }
+        // (one launch: its walks go to the side stream only if a band stage with a region of its own follows)
+        const bool side = (nl > 1 && (all_fit || halves)) || (nl == 1 && later_off != 0 && i + 1 < n_stages);
+        { const int drc = dual.begin(side); if (drc != WFA_HIP_OK) return drc; }
         int64_t launch = 0;
         for (int64_t w0 = 0; w0 < in_n; w0 += per_launch, ++launch) {
           const uint32_t cnt = (uint32_t)std::min<int64_t>(per_launch, in_n - w0);
-          char* base = reinterpret_cast<char*>(al->ws) + ((dual.on && (launch & 1)) ? half_bytes : 0);
-          ba.hist = reinterpret_cast<int32_t*>(base);
-          ba.end_state = reinterpret_cast<int4*>(base + (size_t)per_launch * slot_ints * 4);
+          const int64_t slot0 = all_fit ? w0 : ((halves && (launch & 1)) ? per_launch : 0);
+          ba.hist = al->ws + slot0 * slot_ints;
+          ba.end_state = reinterpret_cast<int4*>(es_base) + slot0;
           ba.work_begin = (uint32_t)w0; ba.nwork = cnt;
           const long long grid = std::min<long long>((long long)al->cu_count * knob(al, K_BAND_WAVES_PER_CU, 128), cnt);
-          { const int drc = dual.before_align(launch); if (drc != WFA_HIP_OK) return drc; }
+          if (!all_fit) { const int drc = dual.before_align(launch); if (drc != WFA_HIP_OK) return drc; }
           if (wfa::launch_band(ba, band_nch[i], full, adapt, seqlds, grid, stream) != 0) { al->err = "band kernel launch failed"; return WFA_HIP_EDEVICE; }
           hipStream_t ws_ = stream;
           { const int drc = dual.walk_stream(launch, &ws_); if (drc != WFA_HIP_OK) return drc; }
           if (wfa::launch_band_bt(ba, band_nch[i], ws_) != 0) { al->err = "band backtrace launch failed"; return WFA_HIP_EDEVICE; }
           { const int drc = dual.after_walk(launch); if (drc != WFA_HIP_OK) return drc; }
         }
-        { const int drc = dual.end(); if (drc != WFA_HIP_OK) return drc; }
+        // the walks still running are joined before anything reuses their slots: at once, unless the next band stage has
+        // its own region
+        if (later_off && i + 1 < n_stages && dual.on) pending_walks = dual;
+        else { const int drc = dual.end(); if (drc != WFA_HIP_OK) return drc; }
       } else {
         if (wfa::launch_band(ba, band_nch[i], full, adapt, seqlds, band_grid[i], stream) != 0) { al->err = "band kernel launch failed"; return WFA_HIP_EDEVICE; }
       }
       if (first_stage) b->last_kernel_pairs = in_n;
       in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
     }
+    { const int drc = pending_walks.end(); if (drc != WFA_HIP_OK) return drc; }   // (the stages below use the workspace from its start)
     if (use_wide) {
       uint32_t* out_list = b->d_fb_list2[out_sel];
       uint32_t* out_count = b->d_counters + 4 + out_sel;
