@@ -1032,7 +1032,7 @@ template <int NCH, bool FULL, bool ADAPT, bool PB, bool SPLIT, int X, int OE, in
 static int launch_band_k(const BandArgs& a, bool seqlds, long long grid, hipStream_t stream) {
   const size_t smem = seqlds ? (size_t)a.lds_words * 2 * sizeof(uint32_t) : 0;
   // (the piggy-back forms need a few more registers: compiled without the occupancy cap rather than with spills)
-  if constexpr (OE2 > 0 && NCH == 3 && !PB) {
+  if constexpr (OE2 > 0 && NCH == 3) {
     if (seqlds) hipLaunchKernelGGL((wfa_band_kernel_w4<NCH, FULL, ADAPT, true, PB, SPLIT, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
     else hipLaunchKernelGGL((wfa_band_kernel_w4<NCH, FULL, ADAPT, false, PB, SPLIT, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), 0, stream, a);
   } else if constexpr (OE2 > 0 && NCH == 4 && !PB) {
