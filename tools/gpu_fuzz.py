@@ -51,6 +51,27 @@ for it in range(rounds):
         batch = datagen.from_strings([pats[i] for i in perm], [txts[i] for i in perm])
     else:
         batch = b  # one large batch as generated (exercises the pilot that picks the first segment width)
+    if it % 9 == 5:
+        # a batch of >= 256 k pairs (the host-packed pipelined upload): a ragged head, some with letters outside ACGT, in
+        # front of a generated body
+        L = int(rng.choice([40, 100, 150, 250])); nb = int(rng.choice([270000, 400000]))
+        body = datagen.generate(nb, L, float(rng.choice([0.01, 0.03, 0.08])), int(rng.integers(1, 1 << 30)))
+        hp, ht = [], []
+        for i in range(3000):
+            p, t = datagen.pair_strings(body, i)
+            k_ = i % 8
+            if k_ == 0: p = p[:int(rng.integers(0, L))]
+            if k_ == 1 and len(t) > 5: t = t[:3] + "N" + t[4:]
+            if k_ == 2: p = p.lower()
+            if k_ == 3: t = t + p[: int(rng.integers(0, 40))]
+            hp.append(p); ht.append(t)
+        head = datagen.from_strings(hp, ht, upper=False)
+        shift = len(head["seqs"])
+        batch = dict(seqs=np.concatenate([head["seqs"], body["seqs"]]),
+                     p_off=np.concatenate([head["p_off"], body["p_off"][3000:] + shift]), p_len=np.concatenate([head["p_len"], body["p_len"][3000:]]),
+                     t_off=np.concatenate([head["t_off"], body["t_off"][3000:] + shift]), t_len=np.concatenate([head["t_len"], body["t_len"][3000:]]))
+        kw.pop("max_steps", None)
+        if kw.get("memory_mode") == "biwfa": kw["memory_mode"] = "high"
     kw = common.clamp_free(kw, batch)
     try:
         oc, nc = common.configs_pair(**kw)
