@@ -643,7 +643,7 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
   // sums the words of every block of 64 pairs (the parts start on block boundaries), the pieces of the upload are cut
   // from those below
   bool host_pack = pipelined && c.wildcard < 0 && knob(al, K_HOST_PACK, 1) != 0;
-  const bool light = host_pack;
+  const bool light = host_pack;   // (pass 1 reads the lengths only; see pass1_light)
   std::vector<uint32_t> blk_words(host_pack ? (size_t)((n + 63) >> 6) : 0, 0u);
   auto pass1 = [&](int t) {
     Part& pt = parts[(size_t)t];
@@ -665,6 +665,39 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
       if (!light) pt.blob_end = std::max(pt.blob_end, std::max(p_off[i] + pl, t_off[i] + tl));
     }
   };
+  // pass 1 of the host-packed form: lengths only, no early exits — a loop the compiler vectorises (10 M pairs: 3.3 -> ~0.5 ms
+  // on 32 threads); negative lengths / free ends larger than a sequence are found from the OR / minima afterwards
+  auto pass1_light = [&](int t) {
+    Part& pt = parts[(size_t)t];
+    const int64_t lo = part_lo(t), hi = part_lo(t + 1);
+    int32_t neg = 0, minp = INT_MAX, mint = INT_MAX, mxl = 0;
+    uint32_t mxw = 0;
+    uint64_t words = 0, packed = 0, ops = 0;
+    for (int64_t b0 = lo; b0 < hi; b0 += 64) {
+      const int64_t b1 = std::min<int64_t>(hi, b0 + 64);
+      uint32_t bw = 0, bp = 0, bo = 0;
+      for (int64_t i = b0; i < b1; ++i) {
+        const int32_t pl = p_len[i], tl = t_len[i];
+        neg |= pl | tl;
+        minp = std::min(minp, pl); mint = std::min(mint, tl);
+        mxl = std::max(mxl, std::max(pl, tl));
+        mxw = std::max(mxw, (uint32_t)pl + (uint32_t)tl);
+        bw += ((uint32_t)(pl + 15) >> 4) + ((uint32_t)(tl + 15) >> 4);
+        bp += ((uint32_t)(pl + 3) >> 2) + ((uint32_t)(tl + 3) >> 2);
+        bo += (uint32_t)pl + (uint32_t)tl;
+      }
+      // (64 pairs: the 32-bit sums cannot overflow before the length check below fails)
+      blk_words[(size_t)(b0 >> 6)] = bw;
+      words += bw; packed += bp; ops += bo;
+    }
+    if (neg < 0) { pt.err = 1; return; }
+    if (mxw > (uint32_t)(INT_MAX / 2 - 8)) { pt.err = 2; return; }
+    if (mxl > (1 << 24)) { pt.err = 4; return; }   // (sequences this long: the plain form and its 64-bit sums)
+    if (hi > lo && c.span == WFA_SPAN_ENDSFREE &&
+        (std::max(c.pattern_begin_free, c.pattern_end_free) > minp || std::max(c.text_begin_free, c.text_end_free) > mint)) { pt.err = 3; return; }
+    pt.words = words; pt.packed = (int64_t)packed; pt.ops = (int64_t)ops;
+    pt.max_width = (int)mxw + 3; pt.max_len = mxl;
+  };
   auto pass_offsets = [&](int t) {   // what a light pass 1 left out (the host-packed form turned out not to fit)
     Part& pt = parts[(size_t)t];
     for (int64_t i = part_lo(t), hi = part_lo(t + 1); i < hi; ++i) {
@@ -683,7 +716,17 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
     loop();
     for (auto& x : th) x.join();
   };
-  run_threads(pass1);
+  if (light) {
+    run_threads(pass1_light);
+    bool too_long = false;
+    for (const Part& pt : parts) too_long |= (pt.err == 4);
+    if (too_long) {
+      host_pack = false;
+      for (Part& pt : parts) pt = Part();
+      run_threads(pass1);
+      run_threads(pass_offsets);
+    }
+  } else run_threads(pass1);
   uint64_t woff = 0;
   int64_t blob_end = 0;
   std::vector<uint64_t> wbase((size_t)nthr);
