@@ -2,12 +2,18 @@
 #include "wfa_wide.hpp"
 
 namespace wfa {
-int launch_wide(bool full, const WideArgs& a, int grid, int threads, size_t smem, hipStream_t stream) {
-  const void* kern = full ? reinterpret_cast<const void*>(&wfa_wide_kernel<true>) : reinterpret_cast<const void*>(&wfa_wide_kernel<false>);
+template <bool FULL, bool TWO, bool GROWS>
+static int launch_wide_t(const WideArgs& a, int grid, int threads, size_t smem, hipStream_t stream) {
   // (more than the default 64 KB of dynamic LDS: a workgroup may take the CU's whole 160 KB)
-  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) { (void)hipGetLastError(); return -1; }
-  if (full) hipLaunchKernelGGL(wfa_wide_kernel<true>, dim3(grid), dim3(threads), smem, stream, a);
-  else hipLaunchKernelGGL(wfa_wide_kernel<false>, dim3(grid), dim3(threads), smem, stream, a);
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wfa_wide_kernel<FULL, TWO, GROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  hipLaunchKernelGGL((wfa_wide_kernel<FULL, TWO, GROWS>), dim3(grid), dim3(threads), smem, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int launch_wide(bool full, bool two, const WideArgs& a, int grid, int threads, size_t smem, hipStream_t stream) {
+  if (two) return full ? launch_wide_t<true, true, true>(a, grid, threads, smem, stream) : launch_wide_t<false, true, true>(a, grid, threads, smem, stream);
+  return full ? launch_wide_t<true, false, false>(a, grid, threads, smem, stream) : launch_wide_t<false, false, false>(a, grid, threads, smem, stream);
 }
 }  // namespace wfa

@@ -1183,7 +1183,8 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       const int only = knob(al, K_BAND_NCH, 0);
       if (only) { n_stages = 1; band_nch[0] = only; }
     }
-    const bool wide_ok = !tiny && b->ncomp == 3 && b->dcfg.metric == 3 && b->dcfg.heuristic == WFA_HEUR_NONE && b->dcfg.match == 0 &&
+    const bool wide_ok = !tiny && ((b->ncomp == 3 && b->dcfg.metric == 3) || (b->ncomp == 5 && b->dcfg.metric == 4 && b->dcfg.e2 >= 1)) &&
+                         b->dcfg.heuristic == WFA_HEUR_NONE && b->dcfg.match == 0 &&
                          b->max_len > 64 && 2 * (int64_t)b->max_len <= 32000 && b->dcfg.e1 >= 1 && b->dcfg.x >= 1 && knob(al, K_NO_WIDE, 0) == 0;
     const bool any_pre = use_fast || use_segfull || n_stages > 0 || wide_ok;
     Geometry g = plan_general(al, b, any_pre ? std::min<uint32_t>(in_n, (uint32_t)al->cu_count * 16) : in_n, b->arena_fixed + b->arena_ints);
@@ -1253,31 +1254,53 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     bool use_wide = false;
     int wide_grid = 0, wide_threads = 0;
     size_t wide_smem = 0;
+    const bool wide_two = (b->ncomp == 5);
+    size_t wide_hist_off = 0;   // bytes: the history slices start behind the row slices (2p)
     if (wide_ok) {
-      wa.g = wfa::gcd_int(wfa::gcd_int(b->dcfg.x, b->dcfg.o1 + b->dcfg.e1), b->dcfg.e1);
+      wa.g = wide_two ? wfa::band_gcd(b->dcfg, true) : wfa::gcd_int(wfa::gcd_int(b->dcfg.x, b->dcfg.o1 + b->dcfg.e1), b->dcfg.e1);
       wa.X = b->dcfg.x / wa.g; wa.OE = (b->dcfg.o1 + b->dcfg.e1) / wa.g; wa.E = b->dcfg.e1 / wa.g;
+      if (wide_two) { wa.OE2 = (b->dcfg.o2 + b->dcfg.e2) / wa.g; wa.E2 = b->dcfg.e2 / wa.g; }
       wa.seq_words = ((b->max_len + 15) >> 4) + 4;
-      const int nrows = std::max(wa.X, wa.OE) + 1 + 2 * (wa.E + 1) + 1;
-      const size_t lds_max = (size_t)std::min(160, std::max(16, knob(al, K_WIDE_LDS_KB, 160))) * 1024;
-      const size_t fixed = wfa::wide_smem_bytes(wa.X, wa.OE, wa.E, 0, wa.seq_words);
-      if (wa.E >= 1 && wa.X >= 1 && fixed + (size_t)nrows * 2 * 512 <= lds_max) {
-        int wcap = (int)((lds_max - fixed) / ((size_t)nrows * 2)) - 4;
-        wcap = std::min(wcap, 2 * b->max_len + 4 + b->dcfg.pbf + b->dcfg.tbf) & ~1;
-        wa.wcap = wcap;
-        wide_smem = wfa::wide_smem_bytes(wa.X, wa.OE, wa.E, wcap, wa.seq_words);
-        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, ((size_t)160 * 1024) / wide_smem));
-        wide_threads = knob(al, K_WIDE_THREADS, per_cu >= 4 ? 256 : (per_cu >= 2 ? 512 : 1024));
-        wide_grid = (int)std::min<int64_t>((int64_t)al->cu_count * per_cu, in_n);
-        use_wide = true;
-        if (full) {
-          // history: one byte per cell up to the step where a wavefront would outgrow the rows, + directory + events
-          const int64_t tmax = (int64_t)wcap * wa.E / 2 + 64;
-          int64_t bytes = (int64_t)wcap * wcap * wa.E / 4 + 16 * tmax + (1 << 16);
-          const int64_t budget = free_budget(al);
-          while (wide_grid > 1 && (int64_t)wide_grid * bytes > budget) wide_grid = (wide_grid + 1) / 2;
-          bytes = std::min<int64_t>(bytes, budget / std::max(wide_grid, 1));
-          wa.hist_stride = (bytes / 4) & ~15ll;
-          need = std::max(need, (size_t)wide_grid * (size_t)wa.hist_stride * 4);
+      const int nrows = wfa::wide_rows(wa.X, wa.OE, wa.E, wa.OE2, wa.E2);
+      const int64_t budget = free_budget(al);
+      if (wide_two) {
+        // gap-affine-2p: the rows (M alone: o2 + e2 + 1 of them) live in the workgroup's slice of the workspace, as wide as the
+        // whole diagonal range of the longest pair (no pair outgrows them); two workgroups of 1 024 threads per CU
+        wa.wcap = (2 * b->max_len + 8 + b->dcfg.pbf + b->dcfg.tbf) & ~1;
+        wa.rows_stride = (int64_t)((nrows * wfa::wide_row_halfs(wa.wcap) + 63) & ~(size_t)63);
+        wide_smem = wfa::wide_smem_bytes(wa.X, wa.OE, wa.E, wa.OE2, wa.E2, wa.wcap, wa.seq_words, false);
+        wide_threads = knob(al, K_WIDE_THREADS, 1024);
+        wide_grid = (int)std::min<int64_t>((int64_t)al->cu_count * std::max(1, 2048 / wide_threads), in_n);
+        int64_t hist_bytes = 0;
+        if (full) hist_bytes = (int64_t)wa.wcap * ((int64_t)(b->max_len * 0.9) / wa.g + 64) / 2 + (1 << 20);   // one byte per cell, + directory + events
+        while (wide_grid > 1 && (int64_t)wide_grid * (wa.rows_stride * 2 + hist_bytes) > budget) wide_grid = (wide_grid + 1) / 2;
+        if ((int64_t)wide_grid * (wa.rows_stride * 2 + hist_bytes) <= budget) {
+          wa.hist_stride = (hist_bytes / 4) & ~15ll;
+          wide_hist_off = ((size_t)wide_grid * (size_t)wa.rows_stride * 2 + 255) & ~(size_t)255;
+          need = std::max(need, wide_hist_off + (size_t)wide_grid * (size_t)wa.hist_stride * 4);
+          use_wide = true;
+        }
+      } else {
+        const size_t lds_max = (size_t)std::min(160, std::max(16, knob(al, K_WIDE_LDS_KB, 160))) * 1024;
+        const size_t fixed = wfa::wide_smem_bytes(wa.X, wa.OE, wa.E, 0, 0, 0, wa.seq_words, true);
+        if (fixed + (size_t)nrows * 2 * 512 <= lds_max) {
+          int wcap = (int)((lds_max - fixed) / ((size_t)nrows * 2)) - 4;
+          wcap = std::min(wcap, 2 * b->max_len + 4 + b->dcfg.pbf + b->dcfg.tbf) & ~1;
+          wa.wcap = wcap;
+          wide_smem = wfa::wide_smem_bytes(wa.X, wa.OE, wa.E, 0, 0, wcap, wa.seq_words, true);
+          const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, ((size_t)160 * 1024) / wide_smem));
+          wide_threads = knob(al, K_WIDE_THREADS, per_cu >= 4 ? 256 : (per_cu >= 2 ? 512 : 1024));
+          wide_grid = (int)std::min<int64_t>((int64_t)al->cu_count * per_cu, in_n);
+          use_wide = true;
+          if (full) {
+            // history: one byte per cell up to the step where a wavefront would outgrow the rows, + directory + events
+            const int64_t tmax = (int64_t)wcap * wa.E / 2 + 64;
+            int64_t bytes = (int64_t)wcap * wcap * wa.E / 4 + 16 * tmax + (1 << 16);
+            while (wide_grid > 1 && (int64_t)wide_grid * bytes > budget) wide_grid = (wide_grid + 1) / 2;
+            bytes = std::min<int64_t>(bytes, budget / std::max(wide_grid, 1));
+            wa.hist_stride = (bytes / 4) & ~15ll;
+            need = std::max(need, (size_t)wide_grid * (size_t)wa.hist_stride * 4);
+          }
         }
       }
     }
@@ -1521,11 +1544,12 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       wa.words = b->d_words; wa.meta = b->d_meta; wa.worklist = in_list; wa.nwork_dev = in_count; wa.nwork = in_n;
       wa.score = b->d_score; wa.status = b->d_status; wa.fb_list = out_list; wa.fb_count = out_count;
       wa.cigar_ops = b->d_ops; wa.cigar_off = b->d_cigar_off; wa.cigar_begin = b->d_cigar_begin; wa.cigar_len = b->d_cigar_len;
-      wa.hist = al->ws;
+      wa.rows = wide_two ? reinterpret_cast<short*>(al->ws) : nullptr;
+      wa.hist = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(al->ws) + wide_hist_off);
       wa.ef = b->dcfg.endsfree ? 1 : 0;
       wa.pbf = b->dcfg.pbf; wa.pef = b->dcfg.pef; wa.tbf = b->dcfg.tbf; wa.tef = b->dcfg.tef;
       wa.max_steps = b->dcfg.max_steps;
-      if (wfa::launch_wide(full, wa, wide_grid, wide_threads, wide_smem, stream) != 0) { al->err = "wide kernel launch failed"; return WFA_HIP_EDEVICE; }
+      if (wfa::launch_wide(full, wide_two, wa, wide_grid, wide_threads, wide_smem, stream) != 0) { al->err = "wide kernel launch failed"; return WFA_HIP_EDEVICE; }
       if (first_stage) b->last_kernel_pairs = in_n;
       in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
     }

@@ -46,7 +46,10 @@ struct WideArgs {
   int32_t* cigar_len;
   int32_t* hist;          // full scope: slice of workgroup b = hist + b * hist_stride (ints)
   long long hist_stride;
+  short* rows;            // rows in the HBM workspace (gap-affine-2p): slice of workgroup b = rows + b * rows_stride (halfs)
+  long long rows_stride;
   int g, X, OE, E;        // score step and the penalties in steps
+  int OE2, E2;            // gap-affine-2p: the second gap piece
   int ef, pbf, pef, tbf, tef;
   int max_steps;
   int wcap;               // diagonals per row
@@ -58,26 +61,39 @@ struct WideArgs {
 
 __device__ __forceinline__ uint32_t wide_ffbl(uint32_t x) { uint32_t r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
 
-static inline size_t wide_smem_bytes(int X, int OE, int E, int wcap, int seq_words) {
-  const int NM = (X > OE ? X : OE) + 1, NG = E + 1, NR = NM + 2 * NG + 1;   // + the always-NULL row
-  const size_t rw = (size_t)((wcap + 2 + 1) & ~1);
-  return (size_t)(WFA_WIDE_CTRL_INTS + 2 * NR) * 4 + (size_t)2 * seq_words * 4 + (size_t)NR * rw * 2;
+// rows of one alignment: M for the last max(x, o+e, o2+e2)/g + 1 steps, I1 / D1 for the last e/g + 1, I2 / D2 for the last
+// e2/g + 1, and one row that is always NULL (inputs before score 0)
+static inline int wide_rows(int X, int OE, int E, int OE2, int E2) {
+  int dm = X > OE ? X : OE;
+  if (OE2 > dm) dm = OE2;
+  return dm + 1 + 2 * (E + 1) + (OE2 > 0 ? 2 * (E2 + 1) : 0) + 1;
+}
+static inline size_t wide_row_halfs(int wcap) { return (size_t)((wcap + 2 + 1) & ~1); }
+// LDS of a workgroup: control words, row limits, the two sequences, and (rows in LDS) the rows
+static inline size_t wide_smem_bytes(int X, int OE, int E, int OE2, int E2, int wcap, int seq_words, bool rows_in_lds) {
+  const int NR = wide_rows(X, OE, E, OE2, E2);
+  return (size_t)(WFA_WIDE_CTRL_INTS + 2 * NR) * 4 + (size_t)2 * seq_words * 4 + (rows_in_lds ? (size_t)NR * wide_row_halfs(wcap) * 2 : 0);
 }
 
-template <bool FULL>
+// FULL: piggy-back history + walk; TWO: gap-affine-2p (components M, I1, D1, I2, D2); GROWS: the rows live in the workgroup's
+// slice of the HBM workspace (L2-resident) instead of LDS — the 2p form: 37 rows x 20 000 diagonals for 10 kb reads
+template <bool FULL, bool TWO, bool GROWS>
 __global__ void __launch_bounds__(1024)
 wfa_wide_kernel(const WideArgs a) {
+  constexpr int NC = TWO ? 5 : 3;
   extern __shared__ int wsm[];
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
-  const int DM = max(a.X, a.OE);
-  const int NM = DM + 1, NG = a.E + 1, NR = NM + 2 * NG + 1;
+  const int DM = TWO ? max(max(a.X, a.OE), a.OE2) : max(a.X, a.OE);
+  const int NM = DM + 1, NG1 = a.E + 1, NG2 = TWO ? a.E2 + 1 : 0, NR = NM + 2 * NG1 + 2 * NG2 + 1;
   const int rw = (a.wcap + 2 + 1) & ~1;            // halfs per row: guard, wcap diagonals, guard (+ pad)
-  int* const ctrl = wsm;                           // [0..5] trim min x3 / max x3 (parity 0), [6..11] parity 1, [12..13] end k
+  int* const ctrl = wsm;                           // [10 par .. 10 par + 9] trim min x NC / max x NC, [20 + par] end k
   int* const rlo = wsm + WFA_WIDE_CTRL_INTS;       // trimmed limits of every row
   int* const rhi = rlo + NR;
   uint32_t* const sP = reinterpret_cast<uint32_t*>(rhi + NR);
   uint32_t* const sT = sP + a.seq_words;
-  short* const rows = reinterpret_cast<short*>(sT + a.seq_words);
+  short* rows;
+  if constexpr (GROWS) rows = a.rows + (long long)blockIdx.x * a.rows_stride;
+  else rows = reinterpret_cast<short*>(sT + a.seq_words);
   const int NULLROW = NR - 1;
   const uint32_t nwork = a.nwork_dev ? *a.nwork_dev : a.nwork;
   int* const hist = FULL ? a.hist + (long long)blockIdx.x * a.hist_stride : nullptr;
@@ -91,7 +107,7 @@ wfa_wide_kernel(const WideArgs a) {
     // rows are centred between the start and the target diagonals
     const int koff = a.wcap / 2 + 1 - (ak + tbf - pbf) / 2;     // row index of diagonal k = k + koff (1 .. wcap)
     const int kmin = 1 - koff, kmax = a.wcap - koff;
-    __syncthreads();   // the previous pair is done with LDS
+    __syncthreads();   // the previous pair is done with LDS and the rows
     // ---- sequences and rows ----
     {
       const int nwp = (plen + 15) >> 4, nwt = (tlen + 15) >> 4;
@@ -102,11 +118,11 @@ wfa_wide_kernel(const WideArgs a) {
       const int n32 = NR * rw / 2;
       for (int i = tid; i < n32; i += T) r32[i] = 0xC000C000u;   // NULL, NULL
       for (int i = tid; i < NR; i += T) { rlo[i] = 1; rhi[i] = -1; }
-      if (tid < 14) ctrl[tid] = (tid >= 12 || (tid % 6) < 3) ? INT_MAX : INT_MIN;
+      if (tid < 22) ctrl[tid] = (tid >= 20 || (tid % 10) < NC) ? INT_MAX : INT_MIN;
     }
     bool hand_on = (plen + tlen > 32000) || (-pbf < kmin) || (tbf > kmax) || (ak < kmin) || (ak > kmax);
     int end_reason = 0;   // 1 reached, 3 handed on, 4 step limit
-    int end_k = 0, end_off = 0, end_t = 0;
+    int end_k = 0, end_t = 0;
     long long pb_used = 0;                                  // FULL: code bytes in use
     uint8_t* const pb_codes = FULL ? reinterpret_cast<uint8_t*>(hist) : nullptr;
     const long long pb_cap = FULL ? a.hist_stride * 4 : 0;  // bytes shared by codes (bottom-up) and directory (top-down)
@@ -116,24 +132,34 @@ wfa_wide_kernel(const WideArgs a) {
     for (int t = 0; !hand_on; ++t) {
       const int s = t * a.g;
       const int par = t & 1;
-      int* const TRmin = ctrl + 6 * par;
-      int* const TRmax = TRmin + 3;
+      int* const TRmin = ctrl + 10 * par;
+      int* const TRmax = TRmin + NC;
       // the limit is tested after compute-next of a score and before its extension (R/wavefront_unialign.c:98-107)
       if (t > 0 && s >= a.max_steps) { end_reason = 4; break; }
       if (t > 16000) { end_reason = 3; break; }
-      // ---- rows of this step and its inputs ----
-      const int rM = t % NM, rI = NM + t % NG, rD = NM + NG + t % NG;
+      // ---- rows of this step (M, I1, D1, I2, D2) and its inputs ----
+      int rW[NC];
+      rW[0] = t % NM; rW[1] = NM + t % NG1; rW[2] = NM + NG1 + t % NG1;
+      if (TWO) { rW[3] = NM + 2 * NG1 + t % NG2; rW[4] = NM + 2 * NG1 + NG2 + t % NG2; }
       const int iX = (t >= a.X) ? (t - a.X) % NM : NULLROW;
       const int iO = (t >= a.OE) ? (t - a.OE) % NM : NULLROW;
-      const int iI = (t >= a.E) ? NM + (t - a.E) % NG : NULLROW;
-      const int iD = (t >= a.E) ? NM + NG + (t - a.E) % NG : NULLROW;
+      const int iI = (t >= a.E) ? NM + (t - a.E) % NG1 : NULLROW;
+      const int iD = (t >= a.E) ? NM + NG1 + (t - a.E) % NG1 : NULLROW;
+      const int iO2 = (TWO && t >= a.OE2) ? (t - a.OE2) % NM : NULLROW;
+      const int iI2 = (TWO && t >= a.E2) ? NM + 2 * NG1 + (t - a.E2) % NG2 : NULLROW;
+      const int iD2 = (TWO && t >= a.E2) ? NM + 2 * NG1 + NG2 + (t - a.E2) % NG2 : NULLROW;
       int lo, hi;
       if (t == 0) { lo = -pbf; hi = tbf; }
       else {
         // R/wavefront_compute.c:40-86 (a null input counts with lo = 1, hi = -1, as there)
         lo = min(min(rlo[iX], rlo[iO] - 1), min(rlo[iI] + 1, rlo[iD] - 1));
         hi = max(max(rhi[iX], rhi[iO] + 1), max(rhi[iI] + 1, rhi[iD] - 1));
-        const bool all_null = rlo[iX] > rhi[iX] && rlo[iO] > rhi[iO] && rlo[iI] > rhi[iI] && rlo[iD] > rhi[iD];
+        bool all_null = rlo[iX] > rhi[iX] && rlo[iO] > rhi[iO] && rlo[iI] > rhi[iI] && rlo[iD] > rhi[iD];
+        if (TWO) {
+          lo = min(lo, min(rlo[iO2] - 1, min(rlo[iI2] + 1, rlo[iD2] - 1)));
+          hi = max(hi, max(rhi[iO2] + 1, max(rhi[iI2] + 1, rhi[iD2] - 1)));
+          all_null = all_null && rlo[iO2] > rhi[iO2] && rlo[iI2] > rhi[iI2] && rlo[iD2] > rhi[iD2];
+        }
         if (all_null) { lo = 1; hi = -1; }
       }
       if (lo <= hi && (lo < kmin || hi > kmax)) { end_reason = 3; break; }
@@ -145,44 +171,63 @@ wfa_wide_kernel(const WideArgs a) {
         code_base = pb_used; pb_used += nb;
         if (tid == 0) { int* d = hist + a.hist_stride - 3ll * (t + 1); d[0] = (lo <= hi) ? lo : 1; d[1] = (lo <= hi) ? hi : 0; d[2] = (int)code_base; }
       }
-      short* const wM = rows + rM * rw + koff;
-      short* const wI = rows + rI * rw + koff;
-      short* const wD = rows + rD * rw + koff;
-      const short* const pX = rows + iX * rw + koff;
-      const short* const pO = rows + iO * rw + koff;
-      const short* const pI = rows + iI * rw + koff;
-      const short* const pD = rows + iD * rw + koff;
-      // stale cells of the rows written now (their previous wavefronts) outside the range written below
-      {
-        const int olo[3] = {rlo[rM], rlo[rI], rlo[rD]}, ohi[3] = {rhi[rM], rhi[rI], rhi[rD]};
-        short* const w3[3] = {wM, wI, wD};
+      short* wR[NC];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          if (olo[c] > ohi[c]) continue;
-          if (lo > hi) { for (int k = olo[c] + tid; k <= ohi[c]; k += T) w3[c][k] = (short)WFA_WIDE_NULL; continue; }
-          for (int k = olo[c] + tid; k <= min(ohi[c], lo - 1); k += T) w3[c][k] = (short)WFA_WIDE_NULL;
-          for (int k = max(olo[c], hi + 1) + tid; k <= ohi[c]; k += T) w3[c][k] = (short)WFA_WIDE_NULL;
-        }
+      for (int c = 0; c < NC; ++c) wR[c] = rows + (long long)rW[c] * rw + koff;
+      const short* const pX = rows + (long long)iX * rw + koff;
+      const short* const pO = rows + (long long)iO * rw + koff;
+      const short* const pI = rows + (long long)iI * rw + koff;
+      const short* const pD = rows + (long long)iD * rw + koff;
+      const short* const pO2 = rows + (long long)iO2 * rw + koff;
+      const short* const pI2 = rows + (long long)iI2 * rw + koff;
+      const short* const pD2 = rows + (long long)iD2 * rw + koff;
+      // stale cells of the rows written now (their previous wavefronts) outside the range written below
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int olo = rlo[rW[c]], ohi = rhi[rW[c]];
+        if (olo > ohi) continue;
+        if (lo > hi) { for (int k = olo + tid; k <= ohi; k += T) wR[c][k] = (short)WFA_WIDE_NULL; continue; }
+        for (int k = olo + tid; k <= min(ohi, lo - 1); k += T) wR[c][k] = (short)WFA_WIDE_NULL;
+        for (int k = max(olo, hi + 1) + tid; k <= ohi; k += T) wR[c][k] = (short)WFA_WIDE_NULL;
       }
       // ---- the pass: compute, clamp, extend, store; trimmed limits by wave ballots ----
-      int wmin[3] = {INT_MAX, INT_MAX, INT_MAX}, wmax[3] = {INT_MIN, INT_MIN, INT_MIN};   // (wave-uniform)
+      int wmin[NC], wmax[NC];   // (wave-uniform)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) { wmin[c] = INT_MAX; wmax[c] = INT_MIN; }
       for (int k0 = lo + (tid & ~63); k0 <= hi; k0 += T) {
         const int k = k0 + lane;
         const bool in = k <= hi;
-        int mv = WFA_WIDE_NULL, iv = WFA_WIDE_NULL, dv = WFA_WIDE_NULL, code = 0;
+        int v5[NC];   // M, I1, D1, I2, D2 of this diagonal
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v5[c] = WFA_WIDE_NULL;
+        int code = 0;
         if (in) {
           if (t == 0) {
-            mv = max(k, 0);   // R/wavefront_aligner.c:251-310: offset 0 on diagonal 0, the free begins on theirs
+            v5[0] = max(k, 0);   // R/wavefront_aligner.c:251-310: offset 0 on diagonal 0, the free begins on theirs
           } else {
             const int mo_lo = pO[k - 1], ie_lo = pI[k - 1], mo_hi = pO[k + 1], de_hi = pD[k + 1];
-            iv = max(mo_lo, ie_lo) + 1;
-            dv = max(mo_hi, de_hi);
+            v5[1] = max(mo_lo, ie_lo) + 1;
+            v5[2] = max(mo_hi, de_hi);
             const int x1 = pX[k] + 1;
-            mv = max(dv, max(x1, iv));
-            if (FULL) {
-              // the backtrace's choice on equal offsets (R/wavefront_backtrace.c:49-59), as wfa_general.hpp PB
-              const int mc = (x1 >= max(dv, iv)) ? 0 : ((dv >= iv) ? 1 : 2);
-              code = mc | ((ie_lo >= mo_lo) ? 4 : 0) | ((de_hi >= mo_hi) ? 8 : 0);
+            if (TWO) {
+              // R/wavefront_compute_affine2p.c:45-106
+              const int mo2_lo = pO2[k - 1], i2e_lo = pI2[k - 1], mo2_hi = pO2[k + 1], d2e_hi = pD2[k + 1];
+              v5[3] = max(mo2_lo, i2e_lo) + 1;
+              v5[4] = max(mo2_hi, d2e_hi);
+              const int best = max(max(v5[2], v5[4]), max(x1, max(v5[1], v5[3])));
+              v5[0] = best;
+              if (FULL) {
+                // the backtrace's choice on equal offsets (R/wavefront_backtrace.c:49-59): mismatch > D2 > D1 > I2 > I1,
+                // extension > opening (as wfa_general.hpp PB)
+                const int mc = (x1 >= best) ? 0 : (v5[4] >= best) ? 2 : (v5[2] >= best) ? 1 : (v5[3] >= best) ? 4 : 3;
+                code = mc | ((ie_lo >= mo_lo) ? 8 : 0) | ((de_hi >= mo_hi) ? 16 : 0) | ((i2e_lo >= mo2_lo) ? 32 : 0) | ((d2e_hi >= mo2_hi) ? 64 : 0);
+              }
+            } else {
+              v5[0] = max(v5[2], max(x1, v5[1]));
+              if (FULL) {
+                const int mc = (x1 >= max(v5[2], v5[1])) ? 0 : ((v5[2] >= v5[1]) ? 1 : 2);
+                code = mc | ((ie_lo >= mo_lo) ? 4 : 0) | ((de_hi >= mo_hi) ? 8 : 0);
+              }
             }
           }
         }
@@ -191,17 +236,21 @@ wfa_wide_kernel(const WideArgs a) {
         const int base = max(k, 0);
         const bool kin = in && limk >= base;    // (a diagonal beyond -plen .. tlen holds no cell)
         const uint32_t span = (uint32_t)(limk - base);
-        const bool m_in = (uint32_t)(mv - base) <= span && kin;
-        const bool i_in = (uint32_t)(iv - base) <= span && kin;
-        const bool d_in = (uint32_t)(dv - base) <= span && kin;
-        if (!m_in) mv = WFA_WIDE_NULL;          // only M is clamped (R/wavefront_compute_affine.c:80-84)
-        const unsigned long long bm = __ballot(m_in), bi = __ballot(i_in), bd = __ballot(d_in);
-        if (bm) { wmin[0] = min(wmin[0], k0 + (int)__builtin_ctzll(bm)); wmax[0] = max(wmax[0], k0 + 63 - (int)__builtin_clzll(bm)); }
-        if (bi) { wmin[1] = min(wmin[1], k0 + (int)__builtin_ctzll(bi)); wmax[1] = max(wmax[1], k0 + 63 - (int)__builtin_clzll(bi)); }
-        if (bd) { wmin[2] = min(wmin[2], k0 + (int)__builtin_ctzll(bd)); wmax[2] = max(wmax[2], k0 + 63 - (int)__builtin_clzll(bd)); }
+        bool inb[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) inb[c] = (uint32_t)(v5[c] - base) <= span && kin;
+        const bool m_in = inb[0];
+        if (!m_in) v5[0] = WFA_WIDE_NULL;       // only M is clamped (R/wavefront_compute_affine.c:80-84)
+        unsigned long long bm = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const unsigned long long bc = __ballot(inb[c]);
+          if (c == 0) bm = bc;
+          if (bc) { wmin[c] = min(wmin[c], k0 + (int)__builtin_ctzll(bc)); wmax[c] = max(wmax[c], k0 + 63 - (int)__builtin_clzll(bc)); }
+        }
         // extend M (R/wavefront_extend_kernels.c:64-88): 32 bases per round, never past either sequence end
         if (bm) {
-          int h = mv, v = mv - k, left = m_in ? limk - mv : 0;
+          int h = v5[0], v = v5[0] - k, left = m_in ? limk - v5[0] : 0;
           bool more = false;
           if (left > 0) {
             // first probe: 16 bases (cells away from the alignment path compare unrelated bases and stop at once)
@@ -224,57 +273,57 @@ wfa_wide_kernel(const WideArgs a) {
             }
           }
           if (m_in) {
-            mv = h;
+            v5[0] = h;
             // termination on the extended offset
             if (a.ef) {
-              if ((h >= tlen && plen - v <= a.pef) || (v >= plen && tlen - h <= a.tef)) atomicMin(&ctrl[12 + par], k);
+              if ((h >= tlen && plen - v <= a.pef) || (v >= plen && tlen - h <= a.tef)) atomicMin(&ctrl[20 + par], k);
             } else if (k == ak && h >= tlen) {
-              ctrl[12 + par] = k;
+              ctrl[20 + par] = k;
             }
           }
         }
         if (in) {
-          // (negative I / D values are stored as they are: they start at NULL and gain at most 1 per step, so they stay
+          // (negative gap values are stored as they are: they start at NULL and gain at most 1 per step, so they stay
           // negative for the 16 000 steps a pair may take here, and a negative offset is never in bounds)
-          wM[k] = (short)mv;
-          wI[k] = (short)iv;
-          wD[k] = (short)dv;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) wR[c][k] = (short)v5[c];
           if (FULL) pb_codes[code_base + (k - lo)] = (uint8_t)code;
         }
       }
       if (lane == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) if (wmin[c] != INT_MAX) { atomicMin(&TRmin[c], wmin[c]); atomicMax(&TRmax[c], wmax[c]); }
+        for (int c = 0; c < NC; ++c) if (wmin[c] != INT_MAX) { atomicMin(&TRmin[c], wmin[c]); atomicMax(&TRmax[c], wmax[c]); }
       }
       __syncthreads();   // rows, trimmed limits and the end flag of this step are visible
       // ---- trimmed limits (R/wavefront_compute.c:571-605): first / last in-bounds cell; none -> null ----
-      int tlo[3], thi[3];
+      int tlo[NC], thi[NC];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
+      for (int c = 0; c < NC; ++c) {
         const int mn = TRmin[c], mx = TRmax[c];
         if (mn != INT_MAX) { tlo[c] = mn; thi[c] = mx; } else { tlo[c] = 1; thi[c] = -1; }
       }
-      const int ek = ctrl[12 + par];
-      if (ek != INT_MAX) { end_reason = 1; end_k = ek; end_off = wM[ek]; end_t = t; }
-      // I / D cells outside their trimmed limits become NULL (M's are NULL already)
+      const int ek = ctrl[20 + par];
+      if (ek != INT_MAX) { end_reason = 1; end_k = ek; end_t = t; }
+      // gap cells outside their trimmed limits become NULL (M's are NULL already)
       if (lo <= hi) {
-        short* const w2[2] = {wI, wD};
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const int l = tlo[c + 1], h2 = thi[c + 1];
-          if (l > h2) { for (int k = lo + tid; k <= hi; k += T) w2[c][k] = (short)WFA_WIDE_NULL; }
+        for (int c = 1; c < NC; ++c) {
+          const int l = tlo[c], h2 = thi[c];
+          if (l > h2) { for (int k = lo + tid; k <= hi; k += T) wR[c][k] = (short)WFA_WIDE_NULL; }
           else {
-            for (int k = lo + tid; k < l; k += T) w2[c][k] = (short)WFA_WIDE_NULL;
-            for (int k = h2 + 1 + tid; k <= hi; k += T) w2[c][k] = (short)WFA_WIDE_NULL;
+            for (int k = lo + tid; k < l; k += T) wR[c][k] = (short)WFA_WIDE_NULL;
+            for (int k = h2 + 1 + tid; k <= hi; k += T) wR[c][k] = (short)WFA_WIDE_NULL;
           }
         }
       }
       if (tid == 0) {
-        rlo[rM] = tlo[0]; rhi[rM] = thi[0]; rlo[rI] = tlo[1]; rhi[rI] = thi[1]; rlo[rD] = tlo[2]; rhi[rD] = thi[2];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { rlo[rW[c]] = tlo[c]; rhi[rW[c]] = thi[c]; }
         // the other parity's scratch for the next step
-        int* o = ctrl + 6 * (par ^ 1);
-        o[0] = INT_MAX; o[1] = INT_MAX; o[2] = INT_MAX; o[3] = INT_MIN; o[4] = INT_MIN; o[5] = INT_MIN;
-        ctrl[12 + (par ^ 1)] = INT_MAX;
+        int* o = ctrl + 10 * (par ^ 1);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { o[c] = INT_MAX; o[NC + c] = INT_MIN; }
+        ctrl[20 + (par ^ 1)] = INT_MAX;
       }
       __syncthreads();
       if (end_reason) break;
@@ -305,10 +354,15 @@ wfa_wide_kernel(const WideArgs a) {
             const int* d = hist + a.hist_stride - 3ll * (tc + 1);
             const int cd = (k >= d[0] && k <= d[1]) ? pb_codes[(long long)d[2] + (k - d[0])] : 0;
             const uint8_t flag = (comp == 0) ? 0x80 : 0;
-            const int src = (comp == 0) ? ((cd & 3) == 0 ? 0 : ((cd & 3) == 1 ? 1 : 3)) : (comp == 1 ? 3 : 1);   // 0 X, 1 D, 3 I
+            int src;   // 0 mismatch, 1 D1, 2 D2, 3 I1, 4 I2
+            if (TWO) src = (comp == 0) ? (cd & 7) : (comp == 1) ? 3 : (comp == 2) ? 1 : (comp == 3) ? 4 : 2;
+            else src = (comp == 0) ? ((cd & 3) == 0 ? 0 : ((cd & 3) == 1 ? 1 : 3)) : (comp == 1 ? 3 : 1);
+            const int bi1 = TWO ? 8 : 4, bd1 = TWO ? 16 : 8;
             if (src == 0) { ev[nev++] = (uint8_t)('X' | 0x80); tc -= a.X; }
-            else if (src == 1) { ev[nev++] = (uint8_t)('D' | flag); ++k; if (cd & 8) { tc -= a.E; comp = 2; } else { tc -= a.OE; comp = 0; } }
-            else { ev[nev++] = (uint8_t)('I' | flag); --k; if (cd & 4) { tc -= a.E; comp = 1; } else { tc -= a.OE; comp = 0; } }
+            else if (src == 1) { ev[nev++] = (uint8_t)('D' | flag); ++k; if (cd & bd1) { tc -= a.E; comp = 2; } else { tc -= a.OE; comp = 0; } }
+            else if (src == 2) { ev[nev++] = (uint8_t)('D' | flag); ++k; if (cd & 64) { tc -= a.E2; comp = 4; } else { tc -= a.OE2; comp = 0; } }
+            else if (src == 3) { ev[nev++] = (uint8_t)('I' | flag); --k; if (cd & bi1) { tc -= a.E; comp = 1; } else { tc -= a.OE; comp = 0; } }
+            else { ev[nev++] = (uint8_t)('I' | flag); --k; if (cd & 32) { tc -= a.E2; comp = 3; } else { tc -= a.OE2; comp = 0; } }
           }
           if (fail || tc < 0) {
             out_status = WFA_INTERNAL_FALLBACK; out_score = 0;
@@ -354,7 +408,7 @@ wfa_wide_kernel(const WideArgs a) {
   }
 }
 
-// host entry point (csrc/k_wide.hip)
-int launch_wide(bool full, const WideArgs& a, int grid, int threads, size_t smem, hipStream_t stream);
+// host entry point (csrc/k_wide.hip): two = gap-affine-2p with the rows in the HBM workspace
+int launch_wide(bool full, bool two, const WideArgs& a, int grid, int threads, size_t smem, hipStream_t stream);
 
 }  // namespace wfa

@@ -39,6 +39,13 @@ CASES = [
     dict(span="end-to-end", scope="full", mismatch=6, gap_opening=5, gap_extension=3, memory_mode="medium"),
     dict(span="end-to-end", scope="score", max_steps=300),
     dict(span="end-to-end", scope="full", max_steps=1000),
+    # gap-affine-2p: the rows live in the HBM workspace (five components, M ring o2 + e2 + 1 deep)
+    dict(distance="affine2p", span="end-to-end", scope="score"),
+    dict(distance="affine2p", span="end-to-end", scope="full"),
+    dict(distance="affine2p", span="ends-free", scope="full", pattern_begin_free=30, pattern_end_free=40, text_begin_free=20, text_end_free=10),
+    dict(distance="affine2p", span="end-to-end", scope="full", mismatch=3, gap_opening=4, gap_extension=2, gap_opening2=12, gap_extension2=1),
+    dict(distance="affine2p", span="end-to-end", scope="full", mismatch=2, gap_opening=2, gap_extension=2, gap_opening2=10, gap_extension2=1, memory_mode="low"),
+    dict(distance="affine2p", span="end-to-end", scope="full", max_steps=700),
 ]
 
 
@@ -66,6 +73,28 @@ def test_wide_kernel_rows_too_narrow_hand_on(gpu, scope, monkeypatch):
         score, status, cigars = common.gpu_run(nc, batch, full, resident=True)
         for k_ in env: monkeypatch.delenv(k_)
         common.assert_same(o, score, status, cigars, batch, f"wide {env}")
+
+
+def test_wide_kernel_c4_as_written_sample(gpu):
+    """BASELINE C4 as it is written — 10 kb, gap-affine-2p, ends-free 100 / 100, the text cut by 50 at both ends, no heuristic,
+    full CIGAR — in a batch large enough for the staged path: wavefronts of ~9 000 diagonals in the 2p form of the wide kernel.
+    A sample against the real library, every pair: scope=score and scope=full agree."""
+    batch = datagen.trim_text(datagen.generate(132, 10000, 0.08, datagen.SEEDS["C4"]), 50)
+    sel = np.r_[0:3, 129:132]
+    kw = dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100)
+    res = {}
+    for scope in ("score", "full"):
+        oc, nc = common.configs_pair(**dict(kw, scope=scope))
+        full = scope == "full"
+        fn = loader.reference() if loader.have_reference() else loader.oracle()
+        o = loader.run(fn, oc, datagen.subset(batch, sel), want_cigar=full)
+        score, status, cigars = common.gpu_run(nc, batch, full, resident=True)
+        assert np.array_equal(score[sel], o["score"]) and np.array_equal(status[sel], o["status"])
+        if full:
+            for j, i in enumerate(sel):
+                assert bytes(cigars[i]) == o["cigars"][j]
+        res[scope] = (score, status)
+    assert np.array_equal(res["score"][0], res["full"][0]) and np.array_equal(res["score"][1], res["full"][1])
 
 
 def test_wide_kernel_10kb_exact_sample(gpu):

@@ -48,8 +48,9 @@ if "C3x" in which: run("10kb exact score", 2000, 10000, 0.08, 1003, dict(span="e
 if "C4a" in which: run("C4 10kb affine2p endsfree adaptive full", 10000, 10000, 0.08, 1004, dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="full", heuristic="adaptive"), cpu_n=200)
 if "C4m" in which: run("C4 10kb affine2p endsfree adaptive full, memory_mode=medium", 10000, 10000, 0.08, 1004, dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="full", heuristic="adaptive", memory_mode="medium"), cpu_n=200)
 if "C4s" in which: run("C4 10kb affine2p endsfree adaptive score", 10000, 10000, 0.08, 1004, dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="score", heuristic="adaptive"), cpu_n=200)
-if "C4x" in which: run("C4 10kb affine2p endsfree EXACT full", 64, 10000, 0.08, 1004, dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="full"), cpu_n=8, reps=1)
-if "C3xf" in which: run("10kb affine EXACT full", 256, 10000, 0.08, 1003, dict(span="end-to-end", scope="full"), cpu_n=16, reps=1)
+if "C4xs" in which: run("C4 10kb affine2p endsfree EXACT score", 1024, 10000, 0.08, 1004, dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="score"), cpu_n=8, reps=1)
+if "C4x" in which: run("C4 10kb affine2p endsfree EXACT full", 1024, 10000, 0.08, 1004, dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="full"), cpu_n=8, reps=1)
+if "C3xf" in which: run("10kb affine EXACT full", 1024, 10000, 0.08, 1003, dict(span="end-to-end", scope="full"), cpu_n=16, reps=1)
 if "C5" in which: run("C5 100kb xdrop", 2000, 100000, 0.08, 1005, dict(span="end-to-end", scope="full", heuristic="X-drop", xdrop=20), cpu_n=100)
 if "X150" in which: run("150bp X-drop(100) score", 2000000, 150, 0.02, 1002, dict(span="end-to-end", scope="score", heuristic="X-drop", xdrop=100), cpu_n=100000)
 if "A150" in which: run("150bp adaptive score", 2000000, 150, 0.02, 1002, dict(span="end-to-end", scope="score", heuristic="adaptive"), cpu_n=100000)
