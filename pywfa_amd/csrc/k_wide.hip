@@ -13,6 +13,7 @@ static int launch_wide_t(const WideArgs& a, int grid, int threads, size_t smem, 
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 int launch_wide(bool full, bool two, const WideArgs& a, int grid, int threads, size_t smem, hipStream_t stream) {
+  if (!two && a.rows) return full ? launch_wide_t<true, false, true>(a, grid, threads, smem, stream) : launch_wide_t<false, false, true>(a, grid, threads, smem, stream);
   if (two) return full ? launch_wide_t<true, true, true>(a, grid, threads, smem, stream) : launch_wide_t<false, true, true>(a, grid, threads, smem, stream);
   return full ? launch_wide_t<true, false, false>(a, grid, threads, smem, stream) : launch_wide_t<false, false, false>(a, grid, threads, smem, stream);
 }

@@ -42,7 +42,7 @@ static thread_local std::string g_error;
   F(ARENA_KB) F(BAND_DEBUG) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
-  F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
+  F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
 enum WfaKnob {
 #define WFA_KNOB_ENUM(n) K_##n,
   WFA_KNOBS(WFA_KNOB_ENUM)
@@ -1249,58 +1249,66 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     // Wide-wavefront stage (wfa_wide.hpp): exact gap-affine pairs the register windows cannot hold (or never try: reads
     // over 1.2 kb without a heuristic) — one alignment per workgroup, the wavefront rows in LDS; what it hands on goes to
     // the general kernel.  Rows as wide as LDS allows, at most the whole diagonal range of the longest pair.
-    wfa::WideArgs wa;
-    memset(&wa, 0, sizeof(wa));
-    bool use_wide = false;
-    int wide_grid = 0, wide_threads = 0;
-    size_t wide_smem = 0;
+    // Up to two such stages: rows in LDS (gap-affine: the faster form, 23.3 vs 21.7 k aln/s at 10 kb, but ~7 900 diagonals at
+    // most), then rows in the workgroup's slice of the HBM workspace (as wide as the whole diagonal range of the longest pair: no
+    // pair outgrows them; gap-affine-2p has only this form: its M ring alone is o2 + e2 + 1 rows).
+    struct WideStage { wfa::WideArgs a; int grid = 0, threads = 0; size_t smem = 0, hist_off = 0; bool grows = false; };
+    WideStage wide_stage[2];
+    int n_wide = 0;
     const bool wide_two = (b->ncomp == 5);
-    size_t wide_hist_off = 0;   // bytes: the history slices start behind the row slices (2p)
     if (wide_ok) {
-      wa.g = wide_two ? wfa::band_gcd(b->dcfg, true) : wfa::gcd_int(wfa::gcd_int(b->dcfg.x, b->dcfg.o1 + b->dcfg.e1), b->dcfg.e1);
-      wa.X = b->dcfg.x / wa.g; wa.OE = (b->dcfg.o1 + b->dcfg.e1) / wa.g; wa.E = b->dcfg.e1 / wa.g;
-      if (wide_two) { wa.OE2 = (b->dcfg.o2 + b->dcfg.e2) / wa.g; wa.E2 = b->dcfg.e2 / wa.g; }
-      wa.seq_words = ((b->max_len + 15) >> 4) + 4;
-      const int nrows = wfa::wide_rows(wa.X, wa.OE, wa.E, wa.OE2, wa.E2);
+      wfa::WideArgs w0;
+      memset(&w0, 0, sizeof(w0));
+      w0.g = wide_two ? wfa::band_gcd(b->dcfg, true) : wfa::gcd_int(wfa::gcd_int(b->dcfg.x, b->dcfg.o1 + b->dcfg.e1), b->dcfg.e1);
+      w0.X = b->dcfg.x / w0.g; w0.OE = (b->dcfg.o1 + b->dcfg.e1) / w0.g; w0.E = b->dcfg.e1 / w0.g;
+      if (wide_two) { w0.OE2 = (b->dcfg.o2 + b->dcfg.e2) / w0.g; w0.E2 = b->dcfg.e2 / w0.g; }
+      w0.seq_words = ((b->max_len + 15) >> 4) + 4;
+      const int nrows = wfa::wide_rows(w0.X, w0.OE, w0.E, w0.OE2, w0.E2);
       const int64_t budget = free_budget(al);
-      if (wide_two) {
-        // gap-affine-2p: the rows (M alone: o2 + e2 + 1 of them) live in the workgroup's slice of the workspace, as wide as the
-        // whole diagonal range of the longest pair (no pair outgrows them); two workgroups of 1 024 threads per CU
-        wa.wcap = (2 * b->max_len + 8 + b->dcfg.pbf + b->dcfg.tbf) & ~1;
-        wa.rows_stride = (int64_t)((nrows * wfa::wide_row_halfs(wa.wcap) + 63) & ~(size_t)63);
-        wide_smem = wfa::wide_smem_bytes(wa.X, wa.OE, wa.E, wa.OE2, wa.E2, wa.wcap, wa.seq_words, false);
-        wide_threads = knob(al, K_WIDE_THREADS, 1024);
-        wide_grid = (int)std::min<int64_t>((int64_t)al->cu_count * std::max(1, 2048 / wide_threads), in_n);
-        int64_t hist_bytes = 0;
-        if (full) hist_bytes = (int64_t)wa.wcap * ((int64_t)(b->max_len * 0.9) / wa.g + 64) / 2 + (1 << 20);   // one byte per cell, + directory + events
-        while (wide_grid > 1 && (int64_t)wide_grid * (wa.rows_stride * 2 + hist_bytes) > budget) wide_grid = (wide_grid + 1) / 2;
-        if ((int64_t)wide_grid * (wa.rows_stride * 2 + hist_bytes) <= budget) {
-          wa.hist_stride = (hist_bytes / 4) & ~15ll;
-          wide_hist_off = ((size_t)wide_grid * (size_t)wa.rows_stride * 2 + 255) & ~(size_t)255;
-          need = std::max(need, wide_hist_off + (size_t)wide_grid * (size_t)wa.hist_stride * 4);
-          use_wide = true;
-        }
-      } else {
+      const int full_range = (2 * b->max_len + 8 + b->dcfg.pbf + b->dcfg.tbf) & ~1;
+      bool lds_covers_all = false;
+      if (!wide_two && knob(al, K_WIDE_GROWS, 0) == 0) {
+        WideStage& st = wide_stage[n_wide];
+        st.a = w0;
         const size_t lds_max = (size_t)std::min(160, std::max(16, knob(al, K_WIDE_LDS_KB, 160))) * 1024;
-        const size_t fixed = wfa::wide_smem_bytes(wa.X, wa.OE, wa.E, 0, 0, 0, wa.seq_words, true);
+        const size_t fixed = wfa::wide_smem_bytes(w0.X, w0.OE, w0.E, 0, 0, 0, w0.seq_words, true);
         if (fixed + (size_t)nrows * 2 * 512 <= lds_max) {
           int wcap = (int)((lds_max - fixed) / ((size_t)nrows * 2)) - 4;
-          wcap = std::min(wcap, 2 * b->max_len + 4 + b->dcfg.pbf + b->dcfg.tbf) & ~1;
-          wa.wcap = wcap;
-          wide_smem = wfa::wide_smem_bytes(wa.X, wa.OE, wa.E, 0, 0, wcap, wa.seq_words, true);
-          const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, ((size_t)160 * 1024) / wide_smem));
-          wide_threads = knob(al, K_WIDE_THREADS, per_cu >= 4 ? 256 : (per_cu >= 2 ? 512 : 1024));
-          wide_grid = (int)std::min<int64_t>((int64_t)al->cu_count * per_cu, in_n);
-          use_wide = true;
+          wcap = std::min(wcap, full_range) & ~1;
+          lds_covers_all = wcap >= full_range;
+          st.a.wcap = wcap;
+          st.smem = wfa::wide_smem_bytes(w0.X, w0.OE, w0.E, 0, 0, wcap, w0.seq_words, true);
+          const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, ((size_t)160 * 1024) / st.smem));
+          st.threads = knob(al, K_WIDE_THREADS, per_cu >= 4 ? 256 : (per_cu >= 2 ? 512 : 1024));
+          st.grid = (int)std::min<int64_t>((int64_t)al->cu_count * per_cu, in_n);
           if (full) {
             // history: one byte per cell up to the step where a wavefront would outgrow the rows, + directory + events
-            const int64_t tmax = (int64_t)wcap * wa.E / 2 + 64;
-            int64_t bytes = (int64_t)wcap * wcap * wa.E / 4 + 16 * tmax + (1 << 16);
-            while (wide_grid > 1 && (int64_t)wide_grid * bytes > budget) wide_grid = (wide_grid + 1) / 2;
-            bytes = std::min<int64_t>(bytes, budget / std::max(wide_grid, 1));
-            wa.hist_stride = (bytes / 4) & ~15ll;
-            need = std::max(need, (size_t)wide_grid * (size_t)wa.hist_stride * 4);
+            const int64_t tmax = (int64_t)wcap * w0.E / 2 + 64;
+            int64_t bytes = (int64_t)wcap * wcap * w0.E / 4 + 16 * tmax + (1 << 16);
+            while (st.grid > 1 && (int64_t)st.grid * bytes > budget) st.grid = (st.grid + 1) / 2;
+            bytes = std::min<int64_t>(bytes, budget / std::max(st.grid, 1));
+            st.a.hist_stride = (bytes / 4) & ~15ll;
+            need = std::max(need, (size_t)st.grid * (size_t)st.a.hist_stride * 4);
           }
+          ++n_wide;
+        }
+      }
+      if (!lds_covers_all) {
+        WideStage& st = wide_stage[n_wide];
+        st.a = w0; st.grows = true;
+        st.a.wcap = full_range;
+        st.a.rows_stride = (int64_t)((nrows * wfa::wide_row_halfs(full_range) + 63) & ~(size_t)63);
+        st.smem = wfa::wide_smem_bytes(w0.X, w0.OE, w0.E, w0.OE2, w0.E2, full_range, w0.seq_words, false);
+        st.threads = knob(al, K_WIDE_THREADS, 1024);
+        st.grid = (int)std::min<int64_t>((int64_t)al->cu_count * std::max(1, 2048 / st.threads), in_n);
+        int64_t hist_bytes = 0;
+        if (full) hist_bytes = (int64_t)full_range * ((int64_t)(b->max_len * 0.9) / w0.g + 64) / 2 + (1 << 20);   // one byte per cell, + directory + events
+        while (st.grid > 1 && (int64_t)st.grid * (st.a.rows_stride * 2 + hist_bytes) > budget) st.grid = (st.grid + 1) / 2;
+        if ((int64_t)st.grid * (st.a.rows_stride * 2 + hist_bytes) <= budget) {
+          st.a.hist_stride = (hist_bytes / 4) & ~15ll;
+          st.hist_off = ((size_t)st.grid * (size_t)st.a.rows_stride * 2 + 255) & ~(size_t)255;
+          need = std::max(need, st.hist_off + (size_t)st.grid * (size_t)st.a.hist_stride * 4);
+          ++n_wide;
         }
       }
     }
@@ -1537,19 +1545,21 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
     }
     { const int drc = pending_walks.end(); if (drc != WFA_HIP_OK) return drc; }   // (the stages below use the workspace from its start)
-    if (use_wide) {
+    for (int ws_i = 0; ws_i < n_wide; ++ws_i) {
+      WideStage& st = wide_stage[ws_i];
+      wfa::WideArgs& wa = st.a;
       uint32_t* out_list = b->d_fb_list2[out_sel];
       uint32_t* out_count = b->d_counters + 4 + out_sel;
       if (!first_stage) HIP_TRY(al, hipMemsetAsync(out_count, 0, sizeof(uint32_t), stream));
       wa.words = b->d_words; wa.meta = b->d_meta; wa.worklist = in_list; wa.nwork_dev = in_count; wa.nwork = in_n;
       wa.score = b->d_score; wa.status = b->d_status; wa.fb_list = out_list; wa.fb_count = out_count;
       wa.cigar_ops = b->d_ops; wa.cigar_off = b->d_cigar_off; wa.cigar_begin = b->d_cigar_begin; wa.cigar_len = b->d_cigar_len;
-      wa.rows = wide_two ? reinterpret_cast<short*>(al->ws) : nullptr;
-      wa.hist = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(al->ws) + wide_hist_off);
+      wa.rows = st.grows ? reinterpret_cast<short*>(al->ws) : nullptr;
+      wa.hist = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(al->ws) + st.hist_off);
       wa.ef = b->dcfg.endsfree ? 1 : 0;
       wa.pbf = b->dcfg.pbf; wa.pef = b->dcfg.pef; wa.tbf = b->dcfg.tbf; wa.tef = b->dcfg.tef;
       wa.max_steps = b->dcfg.max_steps;
-      if (wfa::launch_wide(full, wide_two, wa, wide_grid, wide_threads, wide_smem, stream) != 0) { al->err = "wide kernel launch failed"; return WFA_HIP_EDEVICE; }
+      if (wfa::launch_wide(full, wide_two, wa, st.grid, st.threads, st.smem, stream) != 0) { al->err = "wide kernel launch failed"; return WFA_HIP_EDEVICE; }
       if (first_stage) b->last_kernel_pairs = in_n;
       in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
     }
