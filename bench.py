@@ -386,6 +386,9 @@ def main():
                 xs.append(extra_config("C4-adaptive", 20_000, 10000, 0.08, datagen.SEEDS["C4"],
                                        dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100,
                                             scope="full", heuristic="adaptive"), "piggyback", 114e3 * 5 / 3, trim=50, cpu_pairs=100))
+                xs.append(extra_config("C4-exact", 1024, 10000, 0.08, datagen.SEEDS["C4"],
+                                       dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="full"),
+                                       "piggyback", 54e6, trim=50, cpu_pairs=8, cpu_budget=3.0))
                 xs.append(extra_config("C4-adaptive-explicit-history", 20_000, 10000, 0.08, datagen.SEEDS["C4"],
                                        dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100,
                                             scope="full", heuristic="adaptive"), "explicit", 750e3 * 5 / 3, trim=50, cpu_pairs=100,
@@ -394,8 +397,8 @@ def main():
                 xs.append({"error": repr(e)})
             out["extra"]["configs"] = xs
             out["extra"]["configs_note"] = ("stated prefixes of the BASELINE streams: C1 at 1 M pairs (BASELINE names 1 k), C3 100 k of 1 M, "
-                                            "C4 20 k of 1 M with wf-adaptive (stated: the exact form writes ~0.4 GB of history per pair; its "
-                                            "bytes per pair are C3's figure x 5/3 components); C2 above is the full 10 M.  Long reads keep the "
+                                            "C4 as written (no heuristic) on 1 024 pairs (54 MB per pair: SURVEY's piggy-back figure) and with wf-adaptive on 20 k of "
+                                            "1 M (its bytes per pair are C3's figure x 5/3 components); C2 above is the full 10 M.  Long reads keep the "
                                             "piggy-back history (one byte of origin codes per cell) in every memory mode; the *-explicit-history "
                                             "lines are the same configurations with WFA_HIP_BAND_PB=0")
         print(json.dumps(out), flush=True)
