@@ -1159,9 +1159,11 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     // the general kernel's geometry is fixed first so that one workspace allocation serves every stage
     int n_stages = 0;
     int band_nch[3] = {0, 0, 0};
-    // a handful of pairs: one launch of the general kernel beats six nearly empty stages (single-pair calls of a
-    // pywfa-style loop)
-    const bool tiny = in_n <= (uint32_t)knob(al, K_TINY_BATCH, 128);
+    // a handful of short pairs: one launch of the general kernel beats six nearly empty stages (single-pair calls of a
+    // pywfa-style loop).  Long reads take the stages whatever the count: an alignment of milliseconds dwarfs the launches, and
+    // the banded / wide kernels are several times faster per pair (8 pairs of C4 as written: 57 ms instead of 436 ms; 8 x 10 kb
+    // wf-adaptive with full CIGAR: 3.9 instead of 15.7 ms)
+    const bool tiny = in_n <= (uint32_t)knob(al, K_TINY_BATCH, 128) && b->max_len <= 1000;
     const bool use_fast = !tiny && !full && wfa::seg_supported(b->dcfg, b->ncomp, full) && b->max_len <= WFA_FAST_MAX_LEN &&
                           knob(al, K_NO_FAST, 0) == 0;
     // full CIGARs of short reads: the segmented kernel with a history slot per pair, then the thread-per-alignment walk

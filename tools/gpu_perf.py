@@ -50,6 +50,9 @@ if "C4a" in which: run("C4 10kb affine2p endsfree adaptive full", 10000, 10000, 
 if "C4m" in which: run("C4 10kb affine2p endsfree adaptive full, memory_mode=medium", 10000, 10000, 0.08, 1004, dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="full", heuristic="adaptive", memory_mode="medium"), cpu_n=200)
 if "C4s" in which: run("C4 10kb affine2p endsfree adaptive score", 10000, 10000, 0.08, 1004, dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="score", heuristic="adaptive"), cpu_n=200)
 if "C4xs" in which: run("C4 10kb affine2p endsfree EXACT score", 1024, 10000, 0.08, 1004, dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="score"), cpu_n=8, reps=1)
+if "C4x8" in which: run("C4 exact full, 8 pairs", 8, 10000, 0.08, 1004, dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="full"), cpu_n=2, reps=1)
+if "C3x8" in which: run("10kb exact full, 8 pairs", 8, 10000, 0.08, 1003, dict(span="end-to-end", scope="full"), cpu_n=4, reps=1)
+if "C3a8" in which: run("10kb adaptive full, 8 pairs", 8, 10000, 0.08, 1003, dict(span="end-to-end", scope="full", heuristic="adaptive"), cpu_n=8, reps=1)
 if "C4x" in which: run("C4 10kb affine2p endsfree EXACT full", 1024, 10000, 0.08, 1004, dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="full"), cpu_n=8, reps=1)
 if "C3xf" in which: run("10kb affine EXACT full", 1024, 10000, 0.08, 1003, dict(span="end-to-end", scope="full"), cpu_n=16, reps=1)
 if "C5" in which: run("C5 100kb xdrop", 2000, 100000, 0.08, 1005, dict(span="end-to-end", scope="full", heuristic="X-drop", xdrop=20), cpu_n=100)
