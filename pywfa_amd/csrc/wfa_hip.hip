@@ -1831,6 +1831,7 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
     ops_total += (int64_t)pl + tl;
     max_len = std::max(max_len, std::max(pl, tl)); max_width = std::max(max_width, pl + tl + 3);
   }
+  if (max_len > 1000) return 0;   // long reads: the staged path (banded / wide kernels) is several times faster than this one's general kernel
   // input region: meta, byte offsets, op-region starts, the bytes; output region: results and op bytes
   const size_t o_meta = 0, o_pb = o_meta + (size_t)n * sizeof(WfaPairMeta), o_tb = o_pb + (size_t)n * 8, o_co = o_tb + (size_t)n * 8,
                o_blob = (o_co + (size_t)(n + 1) * 8 + 15) & ~(size_t)15, in_bytes = (o_blob + (size_t)blob + 15) & ~(size_t)15;
