@@ -231,6 +231,39 @@ def _ops_to_string(ops):
     return "".join(f"{int(n)}{chr(int(c))}" for c, n in zip(ch, ln))
 
 
+class _RunSequence:
+    """Read-only sequence over the per-pair CIGAR runs of a batch (run-length encoded on the GPU: ``run_off`` int64[n+1],
+    ``run_code`` uint8 = pywfa's cigartuple codes, ``run_len`` int32).  Items are built on access — a Python str per pair
+    costs ~1 us, the alignment itself ~0.001 us — ``kind``: "str" = CIGAR string, "ops" = uint8 array of op characters."""
+
+    _CHARS = np.frombuffer(_OP_CHARS.encode(), dtype=np.uint8)   # cigartuple code -> op character
+
+    def __init__(self, run_off, run_code, run_len, kind):
+        self._off, self._code, self._len, self._kind = run_off, run_code, run_len, kind
+
+    def __len__(self):
+        return len(self._off) - 1
+
+    def _item(self, i):
+        a, b = int(self._off[i]), int(self._off[i + 1])
+        if self._kind == "str":
+            return "".join(f"{n}{_OP_CHARS[c]}" for c, n in zip(self._code[a:b].tolist(), self._len[a:b].tolist()))
+        return np.repeat(self._CHARS[self._code[a:b]], self._len[a:b])
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._item(j) for j in range(*i.indices(len(self)))]
+        n = len(self)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError(i)
+        return self._item(i)
+
+    def __iter__(self):
+        return (self._item(i) for i in range(len(self)))
+
+
 class BatchResults:
     """Results of a whole batch with the Python-side surface pre-computed on the device: ``score``,
     ``status``, run-length encoded CIGARs (``run_off``, ``run_code``, ``run_len``) and ``locations``
@@ -388,7 +421,8 @@ class WavefrontAligner:
     def wavefront_align_batch(self, texts, patterns=None):
         """Align many pairs on the GPU. ``patterns`` None = the cached pattern for every text.
 
-        Returns dict(score=int32[n], status=int32[n], cigarstrings=list[str] (scope full))."""
+        Returns dict(score=int32[n], status=int32[n], cigarstrings=sequence of str, cigar_ops=sequence of uint8 arrays
+        (scope full; built from the GPU's run-length encoding when an item is read))."""
         texts = list(texts)
         if patterns is None:
             if self._bpattern is None:
@@ -404,6 +438,19 @@ class WavefrontAligner:
     def align_batch(self, batch):
         """Align a prepared batch dict (see ``pywfa_amd.datagen``): ASCII blob + offsets + lengths."""
         full = self._cfg.scope == 1
+        if full and self._multi is None:
+            # one device: the op strings stay on the GPU, their run-length encoding comes back (csrc/wfa_rle.hpp); the Python
+            # strings / op arrays are built when they are read
+            rb = self._native.batch(batch)
+            try:
+                rb.run()
+                rb.sync()
+                score, status, _ = rb.results(False)
+                off, code, rlen, _locs = rb.rle()
+            finally:
+                rb.close()
+            return {"score": score, "status": status, "cigar_ops": _RunSequence(off, code, rlen, "ops"),
+                    "cigarstrings": _RunSequence(off, code, rlen, "str")}
         score, status, cig = (self._multi or self._native).align_batch(batch, full)
         out = {"score": score, "status": status}
         if full:
