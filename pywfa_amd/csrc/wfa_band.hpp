@@ -59,6 +59,8 @@ struct BandArgs {
   int4* end_state;        // split: per slot {end score, end k, end offset, 1 = walk it}
   int ef, pbf, pef, tbf, tef;  // ends-free span with these free ends (R/wavefront_termination.c:115-162)
   int h16;                // FULL: 1 = history entries are 4 x int16 (sequences < 32000 bases) instead of 4 x int32
+  int32_t* done;          // single-call path: per pair, set to 1 (system scope) after everything else of the pair was written:
+                          // the host polls it in the pinned block instead of waiting for the stream
   int debug;              // timing experiments only: 1 = skip the backtrace, 2 = skip the history stores
   long long pb_code_ints; // piggy-back: ints of a slot reserved for the code records; then pb_event_ints of event bytes, then the runs
   long long pb_event_ints;
@@ -764,10 +766,11 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
         a.cigar_len[pair] = (int)((long long)plen + tlen - begin);
       }
     }
+    if (a.done) __threadfence_system();   // the op bytes of every lane before the flag below
     if (lane == 0) {
       if (fallback) {
         a.status[pair] = WFA_INTERNAL_FALLBACK;
-        a.fb_list[atomicAdd(a.fb_count, 1u)] = pair;
+        if (a.fb_list) a.fb_list[atomicAdd(a.fb_count, 1u)] = pair;   // (no list: the single-call path reads the status)
       } else if (stop_status != 0) {
         a.score[pair] = stop_score;
         a.status[pair] = stop_status;
@@ -775,6 +778,7 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
         a.score[pair] = result;
         a.status[pair] = 0;
       }
+      if (a.done) { __threadfence_system(); __hip_atomic_store(&a.done[pair], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
     }
   }
 }

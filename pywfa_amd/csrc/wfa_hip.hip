@@ -42,7 +42,7 @@ static thread_local std::string g_error;
   F(ARENA_KB) F(BAND_DEBUG) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
-  F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
+  F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
 enum WfaKnob {
 #define WFA_KNOB_ENUM(n) K_##n,
   WFA_KNOBS(WFA_KNOB_ENUM)
@@ -1846,6 +1846,106 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
   uint8_t* h = al->tiny_h;
   uint8_t* hd = nullptr;   // the pinned block as the device sees it
   HIP_TRY(al, hipHostGetDevicePointer((void**)&hd, h, 0));
+  // ---- gap-affine / gap-affine-2p with an instantiated penalty shape, pure ACGT: ONE launch of the banded kernel (one wave per
+  // pair, 128 diagonals in registers).  The host packs the sequences to 2 bits into the pinned block; the kernel stages them
+  // in LDS straight from there (no copy kernel), aligns, walks back in-kernel and writes results and op bytes into the pinned
+  // block.  A pair the window cannot hold shows as status WFA_INTERNAL_FALLBACK and the call goes on to the general kernel below.
+  if (wfa::band_supported(al->dcfg, al->ncomp) && c.wildcard < 0 && knob(al, K_NO_TINY_BAND, 0) == 0 && knob(al, K_NO_BAND, 0) == 0) {
+    const size_t b_meta = 0, b_co = b_meta + (size_t)n * sizeof(WfaPairMeta), b_done = b_co + (size_t)(n + 1) * 8,
+                 b_words = (b_done + (size_t)n * 4 + 15) & ~(size_t)15;
+    WfaPairMeta* bm = reinterpret_cast<WfaPairMeta*>(h + b_meta);
+    int64_t* bco = reinterpret_cast<int64_t*>(h + b_co);
+    uint32_t* bw = reinterpret_cast<uint32_t*>(h + b_words);
+    uint32_t w = 0;
+    int64_t oo = 0;
+    bool bad = false;
+    size_t need_bytes = b_words;
+    for (int64_t i = 0; i < n; ++i) need_bytes += (size_t)(((p_len[i] + 15) >> 4) + ((t_len[i] + 15) >> 4)) * 4;
+    if (need_bytes + 64 <= TINY_IN_BYTES) {
+      for (int64_t i = 0; i < n && !bad; ++i) {
+        const int pl = p_len[i], tl = t_len[i];
+        bm[i].plen = pl; bm[i].tlen = tl;
+        bm[i].p_woff = w; bad |= wfa::host_pack_seq(seqs + p_off[i], pl, bw + w, -1); w += (uint32_t)((pl + 15) >> 4);
+        bm[i].t_woff = w; bad |= wfa::host_pack_seq(seqs + t_off[i], tl, bw + w, -1); w += (uint32_t)((tl + 15) >> 4);
+        bco[i] = oo; oo += (int64_t)pl + tl;
+      }
+      bco[n] = oo;
+      for (int j = 0; j < 4; ++j) bw[w + j] = 0;   // (the funnel shift reads one word ahead)
+    } else {
+      bad = true;
+    }
+    if (!bad) {
+      const int nch = 2;
+      wfa::BandArgs ba;
+      memset(&ba, 0, sizeof(ba));
+      ba.words = reinterpret_cast<const uint32_t*>(hd + b_words); ba.meta = reinterpret_cast<const WfaPairMeta*>(hd + b_meta);
+      ba.nwork = (uint32_t)n;
+      ba.score = reinterpret_cast<int32_t*>(hd + o_score); ba.status = reinterpret_cast<int32_t*>(hd + o_status);
+      ba.cigar_ops = hd + o_ops; ba.cigar_off = reinterpret_cast<const int64_t*>(hd + b_co);
+      ba.cigar_begin = reinterpret_cast<int64_t*>(hd + o_cb); ba.cigar_len = reinterpret_cast<int32_t*>(hd + o_cl);
+      ba.g = wfa::band_gcd(al->dcfg, al->ncomp == 5);
+      ba.x = al->dcfg.x; ba.oe = al->dcfg.o1 + al->dcfg.e1; ba.e = al->dcfg.e1;
+      if (al->ncomp == 5) { ba.oe2 = al->dcfg.o2 + al->dcfg.e2; ba.e2 = al->dcfg.e2; }
+      ba.min_wf_len = al->dcfg.min_wf_len; ba.max_dist_thr = al->dcfg.max_dist_thr; ba.steps_between = al->dcfg.steps_between;
+      ba.heur = al->dcfg.heuristic; ba.xdrop = al->dcfg.xdrop; ba.max_steps = al->dcfg.max_steps; ba.scope = al->dcfg.scope;
+      ba.lds_words = ((max_len + 15) >> 4) + 4;
+      ba.h16 = 1;
+      ba.ef = (al->dcfg.endsfree && (al->dcfg.pbf | al->dcfg.pef | al->dcfg.tbf | al->dcfg.tef)) ? 1 : 0;
+      ba.pbf = al->dcfg.pbf; ba.pef = al->dcfg.pef; ba.tbf = al->dcfg.tbf; ba.tef = al->dcfg.tef;
+      if (full) {
+        const int rec = ((al->ncomp != 5) ? 2 : 4) * 64 * nch;
+        const long long records = std::max<long long>(256, (long long)(max_len * 0.9) / ba.g + 64);
+        ba.hist_stride = ((int64_t)records * rec + 63) & ~63ll;
+        const int erc = ensure_ws(al, (size_t)n * (size_t)ba.hist_stride * 4);
+        if (erc != WFA_HIP_OK) return erc;
+        ba.hist = al->ws;
+      }
+      hipStream_t stream = al->stream;
+      if (al->ws_event_recorded && al->ws_last_stream != stream) HIP_TRY(al, hipStreamWaitEvent(stream, al->ws_event, 0));
+      // (a status that is none of the kernel's: a wave that wrote nothing would be seen)
+      int32_t* hst0 = reinterpret_cast<int32_t*>(h + o_status);
+      for (int64_t i = 0; i < n; ++i) hst0[i] = WFA_INTERNAL_FALLBACK;
+      // completion: a flag per pair in the pinned block, stored by the kernel at system scope after the pair's results;
+      // the host polls the flags (a few microseconds after the last store) and only then falls back on the stream wait
+      volatile int32_t* hdone = reinterpret_cast<volatile int32_t*>(h + b_done);
+      const bool poll = knob(al, K_NO_TINY_POLL, 0) == 0;
+      for (int64_t i = 0; i < n; ++i) hdone[i] = 0;
+      ba.done = poll ? reinterpret_cast<int32_t*>(hd + b_done) : nullptr;
+      if (wfa::launch_band(ba, nch, full, al->dcfg.heuristic != WFA_HEUR_NONE, true, (long long)n, stream) != 0) { al->err = "band kernel launch failed"; return WFA_HIP_EDEVICE; }
+      HIP_TRY(al, hipEventRecord(al->ws_event, stream));
+      al->ws_event_recorded = true; al->ws_last_stream = stream;
+      bool seen = false;
+      if (poll) {
+        const double t_poll = now_ms();
+        for (;;) {
+          int64_t got = 0;
+          for (int64_t i = 0; i < n; ++i) got += (hdone[i] != 0);
+          if (got == n) { seen = true; break; }
+          if (now_ms() - t_poll > 20.0) break;   // (something is wrong or slow: the stream wait below decides)
+          __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+      }
+      if (!seen) HIP_TRY(al, hipStreamSynchronize(stream));
+      const int32_t* hs = reinterpret_cast<const int32_t*>(h + o_score);
+      bool handed_on = false;
+      for (int64_t i = 0; i < n; ++i) handed_on |= (hst0[i] == WFA_INTERNAL_FALLBACK);
+      if (!handed_on) {
+        const int64_t* hcb = reinterpret_cast<const int64_t*>(h + o_cb); const int32_t* hcl = reinterpret_cast<const int32_t*>(h + o_cl);
+        for (int64_t i = 0; i < n; ++i) {
+          score[i] = hs[i]; status[i] = hst0[i];
+          if (cigar_len) cigar_len[i] = full ? hcl[i] : 0;
+          if (cigar_begin) cigar_begin[i] = 0;
+          if (full && cigar_ops) {
+            const int64_t rel = hcb[i] - bco[i];
+            if (hcl[i] > 0) memcpy(cigar_ops + cigar_off[i] + rel, h + o_ops + hcb[i], (size_t)hcl[i]);
+            cigar_begin[i] = cigar_off[i] + rel;
+          }
+        }
+        return 1;
+      }
+    }
+  }
   WfaPairMeta* meta = reinterpret_cast<WfaPairMeta*>(h + o_meta);
   int64_t* pb = reinterpret_cast<int64_t*>(h + o_pb); int64_t* tb = reinterpret_cast<int64_t*>(h + o_tb); int64_t* co = reinterpret_cast<int64_t*>(h + o_co);
   int64_t bo = 0, oo = 0;

@@ -352,3 +352,53 @@ def test_pilot_choice_never_changes_results(gpu, scope, order):
             for i in range(0, len(score), 37):
                 assert ops[cb[i]:cb[i] + cl[i]].tobytes() == o["cigars"][i]
     rb.close(); al.close()
+
+
+@pytest.mark.parametrize("kw", [dict(span="end-to-end", scope="score"), dict(scope="full"),
+                                dict(scope="full", span="ends-free", pattern_begin_free=6, pattern_end_free=9, text_begin_free=4, text_end_free=3),
+                                dict(scope="full", heuristic="adaptive"), dict(scope="score", heuristic="X-drop", xdrop=30),
+                                dict(scope="full", distance="affine2p"), dict(scope="full", max_steps=14),
+                                dict(scope="full", mismatch=4, gap_opening=4, gap_extension=2),
+                                dict(scope="full", mismatch=7, gap_opening=3, gap_extension=2),      # no banded shape: the general kernel
+                                dict(scope="full", distance="levenshtein")])
+def test_single_calls_match_oracle(gpu, kw, monkeypatch):
+    """Calls of 1 .. 16 pairs (pywfa's usual loop) take the single-call path: one launch of the banded kernel reading the
+    host-packed pairs from the pinned block, completion polled by the host; pairs it cannot hold (unrelated sequences: the
+    wavefront outgrows 128 diagonals), letters outside ACGT and penalty shapes without a banded instantiation go through the
+    general kernel instead.  Every result against the oracle; the same with the polling and the banded form switched off."""
+    from pywfa_amd import _native
+    rng = np.random.default_rng(4)
+    base = datagen.generate(64, 150, 0.04, 4711)
+    pats, txts = [], []
+    for i in range(64):
+        p, t = datagen.pair_strings(base, i)
+        k = i % 8
+        if k == 1: p = p[:int(rng.integers(0, 150))]
+        if k == 2: t = "".join(rng.choice(list("ACGT"), size=300))          # unrelated: handed on
+        if k == 3: t = t[:50] + "N" + t[51:]
+        if k == 4: p, t = "", t[:9]
+        if k == 5: t = t[:60] + t[90:]                                       # a 30-base gap
+        pats.append(p); txts.append(t)
+    batch = datagen.from_strings(pats, txts)
+    if any(kw.get(f, 0) for f in ("pattern_begin_free", "pattern_end_free", "text_begin_free", "text_end_free")):
+        batch = datagen.subset(batch, np.flatnonzero((batch["p_len"] >= 10) & (batch["t_len"] >= 10)))   # (free ends fit every pair)
+    nb = len(batch["p_len"])
+    oc, nc = common.configs_pair(**kw)
+    full = oc.scope == 1
+    o = loader.run(loader.oracle(), oc, batch, want_cigar=full)
+    for env in ({}, {"WFA_HIP_NO_TINY_POLL": "1"}, {"WFA_HIP_NO_TINY_BAND": "1"}):
+        for k_, v_ in env.items(): monkeypatch.setenv(k_, v_)
+        al = _native.Aligner(nc)
+        lo = 0
+        for size in [1, 1, 2, 3, 7, 16, 1, 16, 5, 12]:
+            idx = np.arange(lo, lo + size) % nb
+            sub = datagen.subset(batch, idx)
+            score, status, cig = al.align_batch(sub, full)
+            assert np.array_equal(score, o["score"][idx]) and np.array_equal(status, o["status"][idx]), (env, size, lo)
+            if full:
+                ops, cbeg, clen = cig
+                for j, i in enumerate(idx):
+                    assert ops[cbeg[j]:cbeg[j] + clen[j]].tobytes() == o["cigars"][i], (env, size, lo, j)
+            lo += size
+        al.close()
+        for k_ in env: monkeypatch.delenv(k_)
