@@ -1803,7 +1803,8 @@ extern "C" int64_t wfa_hip_batch_fallback_pairs(const wfa_hip_batch_t* b) { retu
 // device copy by one small kernel; the general kernel (raw bytes: any alphabet, every configuration) aligns the pairs,
 // writing scores / statuses / op bytes straight into the pinned block; one stream synchronisation; the host copies
 // the results out.  No allocation, no memcpy call, no per-call environment lookup.
-static const int64_t TINY_MAX_PAIRS = 16;
+static const int64_t TINY_MAX_PAIRS = 16;          // general-kernel form (a workspace slice per pair)
+static const int64_t TINY_MAX_PAIRS_BAND = 1024;   // banded form: whatever the pinned block holds (1 024 x 150 bp with op strings)
 static const size_t TINY_IN_BYTES = (size_t)256 << 10, TINY_BLOCK_BYTES = (size_t)1 << 20;
 
 __global__ void __launch_bounds__(256) wfa_tiny_copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, int n16) {
@@ -1816,7 +1817,7 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
                       const int64_t* cigar_off, int64_t* cigar_begin, int32_t* cigar_len) {
   const wfa_hip_config_t& c = al->cfg;
   const bool full = c.scope == WFA_SCOPE_FULL;
-  if (n < 1 || n > TINY_MAX_PAIRS || knob(al, K_NO_TINY, 0)) return 0;
+  if (n < 1 || n > TINY_MAX_PAIRS_BAND || knob(al, K_NO_TINY, 0)) return 0;
   if (full && c.memory_mode == WFA_MEM_BIWFA) return 0;
   if (!score || !status || (full && cigar_ops && (!cigar_off || !cigar_begin || !cigar_len))) return 0;
   int64_t blob = 0, ops_total = 0;
@@ -1837,7 +1838,10 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
                o_blob = (o_co + (size_t)(n + 1) * 8 + 15) & ~(size_t)15, in_bytes = (o_blob + (size_t)blob + 15) & ~(size_t)15;
   const size_t o_score = TINY_IN_BYTES, o_status = o_score + (size_t)n * 4, o_cb = (o_status + (size_t)n * 4 + 7) & ~(size_t)7, o_cl = o_cb + (size_t)n * 8,
                o_ops = (o_cl + (size_t)n * 4 + 15) & ~(size_t)15;
-  if (in_bytes > TINY_IN_BYTES || (full && o_ops + (size_t)ops_total + 16 > TINY_BLOCK_BYTES)) return 0;
+  if (full && o_ops + (size_t)ops_total + 16 > TINY_BLOCK_BYTES) return 0;
+  const bool general_fits = n <= TINY_MAX_PAIRS && in_bytes <= TINY_IN_BYTES;
+  const bool band_form = wfa::band_supported(al->dcfg, al->ncomp) && c.wildcard < 0 && knob(al, K_NO_TINY_BAND, 0) == 0 && knob(al, K_NO_BAND, 0) == 0;
+  if (!general_fits && !band_form) return 0;
   HIP_TRY(al, hipSetDevice(al->device));
   if (!al->tiny_h) {
     HIP_TRY(al, hipHostMalloc((void**)&al->tiny_h, TINY_BLOCK_BYTES, hipHostMallocMapped));
@@ -1850,7 +1854,7 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
   // pair, 128 diagonals in registers).  The host packs the sequences to 2 bits into the pinned block; the kernel stages them
   // in LDS straight from there (no copy kernel), aligns, walks back in-kernel and writes results and op bytes into the pinned
   // block.  A pair the window cannot hold shows as status WFA_INTERNAL_FALLBACK and the call goes on to the general kernel below.
-  if (wfa::band_supported(al->dcfg, al->ncomp) && c.wildcard < 0 && knob(al, K_NO_TINY_BAND, 0) == 0 && knob(al, K_NO_BAND, 0) == 0) {
+  if (band_form) {
     const size_t b_meta = 0, b_co = b_meta + (size_t)n * sizeof(WfaPairMeta), b_done = b_co + (size_t)(n + 1) * 8,
                  b_words = (b_done + (size_t)n * 4 + 15) & ~(size_t)15;
     WfaPairMeta* bm = reinterpret_cast<WfaPairMeta*>(h + b_meta);
@@ -1946,6 +1950,7 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
       }
     }
   }
+  if (!general_fits) return 0;   // (more pairs than the general-kernel form takes: the batch path)
   WfaPairMeta* meta = reinterpret_cast<WfaPairMeta*>(h + o_meta);
   int64_t* pb = reinterpret_cast<int64_t*>(h + o_pb); int64_t* tb = reinterpret_cast<int64_t*>(h + o_tb); int64_t* co = reinterpret_cast<int64_t*>(h + o_co);
   int64_t bo = 0, oo = 0;
@@ -2012,7 +2017,7 @@ extern "C" int wfa_hip_align_batch(wfa_hip_aligner_t* al, int64_t n, const uint8
                                    int32_t* score, int32_t* status, uint8_t* cigar_ops, const int64_t* cigar_off,
                                    int64_t* cigar_begin, int32_t* cigar_len) {
   if (!al) return WFA_HIP_EINVAL;
-  if (n > 0 && n <= TINY_MAX_PAIRS && seqs && p_off && p_len && t_off && t_len) {
+  if (n > 0 && n <= TINY_MAX_PAIRS_BAND && seqs && p_off && p_len && t_off && t_len) {
     const int trc = align_tiny(al, n, seqs, p_off, p_len, t_off, t_len, score, status, cigar_ops, cigar_off, cigar_begin, cigar_len);
     if (trc == 1) return WFA_HIP_OK;
     if (trc < 0) return trc;

@@ -362,7 +362,7 @@ def test_pilot_choice_never_changes_results(gpu, scope, order):
                                 dict(scope="full", mismatch=7, gap_opening=3, gap_extension=2),      # no banded shape: the general kernel
                                 dict(scope="full", distance="levenshtein")])
 def test_single_calls_match_oracle(gpu, kw, monkeypatch):
-    """Calls of 1 .. 16 pairs (pywfa's usual loop) take the single-call path: one launch of the banded kernel reading the
+    """Calls of 1 .. 1 024 short pairs (pywfa's usual loop, and small batches) take the single-call path: one launch of the banded kernel reading the
     host-packed pairs from the pinned block, completion polled by the host; pairs it cannot hold (unrelated sequences: the
     wavefront outgrows 128 diagonals), letters outside ACGT and penalty shapes without a banded instantiation go through the
     general kernel instead.  Every result against the oracle; the same with the polling and the banded form switched off."""
@@ -390,7 +390,7 @@ def test_single_calls_match_oracle(gpu, kw, monkeypatch):
         for k_, v_ in env.items(): monkeypatch.setenv(k_, v_)
         al = _native.Aligner(nc)
         lo = 0
-        for size in [1, 1, 2, 3, 7, 16, 1, 16, 5, 12]:
+        for size in [1, 1, 2, 3, 7, 16, 1, 17, 64, 300, 1024, 5]:   # (17 ..: the banded form only; beyond the pinned block: the batch path)
             idx = np.arange(lo, lo + size) % nb
             sub = datagen.subset(batch, idx)
             score, status, cig = al.align_batch(sub, full)
