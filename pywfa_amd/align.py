@@ -264,6 +264,34 @@ class _RunSequence:
         return (self._item(i) for i in range(len(self)))
 
 
+class _OpsSequence:
+    """Read-only sequence over the per-pair op strings of a small batch (``ops`` uint8, ``begin`` / ``length`` per pair);
+    ``kind``: "str" = CIGAR string (run-length encoded when read), "ops" = uint8 array of op characters."""
+
+    def __init__(self, ops, begin, length, kind):
+        self._ops, self._beg, self._len, self._kind = ops, begin, length, kind
+
+    def __len__(self):
+        return len(self._beg)
+
+    def _item(self, i):
+        o = self._ops[self._beg[i]:self._beg[i] + self._len[i]]
+        return _ops_to_string(o) if self._kind == "str" else o
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._item(j) for j in range(*i.indices(len(self)))]
+        n = len(self)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError(i)
+        return self._item(i)
+
+    def __iter__(self):
+        return (self._item(i) for i in range(len(self)))
+
+
 class BatchResults:
     """Results of a whole batch with the Python-side surface pre-computed on the device: ``score``,
     ``status``, run-length encoded CIGARs (``run_off``, ``run_code``, ``run_len``) and ``locations``
@@ -438,6 +466,12 @@ class WavefrontAligner:
     def align_batch(self, batch):
         """Align a prepared batch dict (see ``pywfa_amd.datagen``): ASCII blob + offsets + lengths."""
         full = self._cfg.scope == 1
+        if full and self._multi is None and len(batch["p_len"]) <= 1024:
+            # a small batch: the single-call form of the library (one launch, results polled in a pinned block); the CIGAR
+            # strings are run-length encoded when they are read
+            score, status, (ops, cbeg, clen) = self._native.align_batch(batch, True)
+            return {"score": score, "status": status, "cigar_ops": _OpsSequence(ops, cbeg, clen, "ops"),
+                    "cigarstrings": _OpsSequence(ops, cbeg, clen, "str")}
         if full and self._multi is None:
             # one device: the op strings stay on the GPU, their run-length encoding comes back (csrc/wfa_rle.hpp); the Python
             # strings / op arrays are built when they are read
