@@ -17,11 +17,16 @@
 // inputs without range tests.  Offsets are < 32 768 (plen + tlen <= 32 000), NULL = -16 384 in a row; a negative value
 // is dead (it never becomes in-bounds, R/wavefront_offset.h:44-57).
 //
-// Scope: gap-affine, match = 0, 2-bit pairs, no heuristic, end-to-end or ends-free, score-only or full CIGAR.  Full CIGAR
-// keeps the piggy-back history of the general kernel (one byte of origin codes per cell + a 12-byte directory record per
-// step in the workgroup's slice of the HBM workspace; wfa_general.hpp PB) and the same walk / forward unpack.
-// A pair whose wavefront leaves the rows, whose history does not fit, or that runs into an all-NULL stretch is handed on
-// (fb_list) to the general kernel.
+// Scope: gap-affine and gap-affine-2p, match = 0, 2-bit pairs, no heuristic, end-to-end or ends-free, score-only or full
+// CIGAR.  Full CIGAR keeps the piggy-back history of the general kernel (one byte of origin codes per cell + a 12-byte
+// directory record per step in the workgroup's slice of the HBM workspace; wfa_general.hpp PB) and the same walk / forward
+// unpack.  A pair whose wavefront leaves the rows, whose history does not fit, or that runs into an all-NULL stretch is
+// handed on (fb_list) to the next stage.
+//
+// Two forms of the rows (template GROWS): in LDS (gap-affine: as above, ~7 900 diagonals at most), or in the workgroup's slice
+// of the HBM workspace, as wide as the whole diagonal range of the longest pair — what outgrew the LDS rows, and gap-affine-2p
+// (TWO: components M, I1, D1, I2, D2, R/wavefront_compute_affine2p.c:45-106; the M ring alone is max(x, o+e, o2+e2)/g + 1
+// rows: 26 for pywfa's defaults, 37 rows x 20 000 diagonals x 2 B = 1.5 MB per workgroup at 10 kb): BASELINE's C4 as written.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <limits.h>
