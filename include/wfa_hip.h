@@ -158,6 +158,37 @@ int wfa_hip_align_batch(wfa_hip_aligner_t* aligner, int64_t n,
                         uint8_t* cigar_ops, const int64_t* cigar_off,
                         int64_t* cigar_begin, int32_t* cigar_len);
 
+/*
+ * The same call for a caller that already holds 2-bit reads (cf. wavefront_align_packed2bits, wfa.h:211-216,
+ * wavefront_sequences.h:115): `packed` holds every sequence in the reference's packed form (wavefront_sequences.c:102-139:
+ * four bases per byte, base j of a byte in bits 2j .. 2j+1, 'A' 0 / 'C' 1 / 'G' 2 / 'T' 3), a sequence of len bases being
+ * (len + 3) / 4 bytes starting at its BYTE offset p_off[i] / t_off[i]; p_len / t_len stay in bases.  The results are those
+ * of wfa_hip_align_batch on the decoded ASCII sequences (that is what the tests pin it against: the reference's own entry
+ * reads only (len + 7) / 8 bytes per sequence, wavefront_sequences.c:112, and aligns uninitialised buffer bytes behind them).
+ * No host packing and a quarter of the bytes over PCIe.  A wildcard letter cannot be expressed: WFA_HIP_ENOTSUP.
+ */
+int wfa_hip_align_batch_packed2bits(wfa_hip_aligner_t* aligner, int64_t n,
+                                    const uint8_t* packed,
+                                    const int64_t* p_off, const int32_t* p_len,
+                                    const int64_t* t_off, const int32_t* t_len,
+                                    int32_t* score, int32_t* status,
+                                    uint8_t* cigar_ops, const int64_t* cigar_off,
+                                    int64_t* cigar_begin, int32_t* cigar_len);
+
+/* ---- host helper: the text of cigar_print_pretty ------------------------------------------------- */
+
+/*
+ * What cigar_print_pretty prints (cigar.h:180-186, cigar.c:778-863; called by align.pyx:445-459) for the op string
+ * ops[0 .. ops_len) (chars M X I D, i.e. cigar->operations[begin_offset .. end_offset)) of `pattern` against `text`: the
+ * ALIGNMENT (runs incl. M), ETRACE (runs without M) and CIGAR (SAM style, X folded into M) lines and the three rows
+ * PATTERN / marks / TEXT.  Written NUL-terminated into out[0 .. cap) (truncated if cap is too small, like snprintf);
+ * returns the length of the whole text without the NUL, or WFA_HIP_EINVAL.  Host only, needs no GPU.
+ */
+int64_t wfa_hip_cigar_sprint_pretty(const uint8_t* ops, int64_t ops_len,
+                                    const uint8_t* pattern, int32_t plen,
+                                    const uint8_t* text, int32_t tlen,
+                                    char* out, int64_t cap);
+
 /* ---- host helper: the 2-bit packing the large-batch upload uses ----------------------------------- */
 
 /*
@@ -210,15 +241,25 @@ int wfa_hip_multi_align_batch(wfa_hip_multi_t* multi, int64_t n,
 
 /* ---- HBM-resident batches (what bench.py times; inputs resident before the clock starts) -- */
 
-/* Upload n pairs (same input arrays as above) and 2-bit pack them on the device.
- * The returned batch keeps sequences, per-pair metadata and result arrays in HBM. */
+/* Upload n pairs (same input arrays as above) as 2-bit codes (packed by host threads on their way into the pinned upload
+ * ring for batches of >= 256 k pairs, by a device kernel otherwise).  The returned batch keeps sequences, per-pair metadata
+ * and result arrays in HBM.  For short-read batches of >= 64 k pairs the call also runs the pilot that picks the first
+ * stage of the cascade (up to three small launches on 8192 pairs sampled across the batch, each waited for).  The input
+ * arrays are not read after the call returns; uploads still in flight then are ordered before any later run by the library
+ * (whatever stream the run is given). */
 wfa_hip_batch_t* wfa_hip_batch_create(wfa_hip_aligner_t* aligner, int64_t n,
                                       const uint8_t* seqs,
                                       const int64_t* p_off, const int32_t* p_len,
                                       const int64_t* t_off, const int32_t* t_len);
+/* The same for 2-bit reads in the reference's packed form (see wfa_hip_align_batch_packed2bits). */
+wfa_hip_batch_t* wfa_hip_batch_create_packed2bits(wfa_hip_aligner_t* aligner, int64_t n,
+                                                  const uint8_t* packed,
+                                                  const int64_t* p_off, const int32_t* p_len,
+                                                  const int64_t* t_off, const int32_t* t_len);
 void wfa_hip_batch_destroy(wfa_hip_batch_t* batch);
 /* Enqueue the alignment kernels for the whole batch on `stream` (hipStream_t passed as
- * void*, NULL = the library's own stream) and return without waiting. */
+ * void*, NULL = the library's own stream) and return without waiting: the call only enqueues (kernels, memsets, event
+ * waits); it never synchronises with the device. */
 int wfa_hip_batch_run(wfa_hip_batch_t* batch, void* stream);
 /* Wait for the last run of this batch. */
 int wfa_hip_batch_sync(wfa_hip_batch_t* batch);

@@ -59,6 +59,7 @@ SYMBOLS = [
     "wfa_hip_batch_rle_counts", "wfa_hip_batch_rle_runs",
     "wfa_hip_plan_shards", "wfa_hip_multi_create", "wfa_hip_multi_destroy", "wfa_hip_multi_set_config",
     "wfa_hip_multi_last_error", "wfa_hip_multi_align_batch", "wfa_hip_pack_2bit", "wfa_hip_batch_extent",
+    "wfa_hip_align_batch_packed2bits", "wfa_hip_batch_create_packed2bits", "wfa_hip_cigar_sprint_pretty",
 ]
 
 
@@ -89,6 +90,11 @@ def lib():
     L.wfa_hip_align_batch.argtypes = [vp, i64] + [vp] * 11
     L.wfa_hip_batch_create.argtypes = [vp, i64] + [vp] * 5
     L.wfa_hip_batch_create.restype = vp
+    L.wfa_hip_align_batch_packed2bits.argtypes = [vp, i64] + [vp] * 11
+    L.wfa_hip_batch_create_packed2bits.argtypes = [vp, i64] + [vp] * 5
+    L.wfa_hip_batch_create_packed2bits.restype = vp
+    L.wfa_hip_cigar_sprint_pretty.argtypes = [vp, i64, vp, i32, vp, i32, vp, i64]
+    L.wfa_hip_cigar_sprint_pretty.restype = i64
     L.wfa_hip_batch_destroy.argtypes = [vp]
     L.wfa_hip_batch_destroy.restype = None
     L.wfa_hip_batch_run.argtypes = [vp, vp]
@@ -138,6 +144,8 @@ def _ptr(a):
 
 
 def _check_batch(batch):
+    if "packed" in batch:
+        return _check_packed(batch)
     seqs = np.ascontiguousarray(batch["seqs"], dtype=np.uint8)
     p_off = np.ascontiguousarray(batch["p_off"], dtype=np.int64)
     t_off = np.ascontiguousarray(batch["t_off"], dtype=np.int64)
@@ -153,6 +161,40 @@ def _check_batch(batch):
         if end > seqs.size:
             raise ValueError("sequence offsets run past the blob")
     return seqs, p_off, p_len, t_off, t_len, n
+
+
+def _check_packed(batch):
+    """A batch of 2-bit reads (datagen.to_packed2bits): byte offsets into ``packed``, lengths in bases."""
+    packed = np.ascontiguousarray(batch["packed"], dtype=np.uint8)
+    p_off = np.ascontiguousarray(batch["p_off"], dtype=np.int64)
+    t_off = np.ascontiguousarray(batch["t_off"], dtype=np.int64)
+    p_len = np.ascontiguousarray(batch["p_len"], dtype=np.int32)
+    t_len = np.ascontiguousarray(batch["t_len"], dtype=np.int32)
+    n = p_len.shape[0]
+    if not (p_off.shape[0] == t_off.shape[0] == t_len.shape[0] == n):
+        raise ValueError("batch arrays differ in length")
+    if n:
+        if min(p_off.min(), t_off.min(), p_len.min(), t_len.min()) < 0:
+            raise ValueError("negative length or offset")
+        end = max(int((p_off + ((p_len.astype(np.int64) + 3) >> 2)).max()), int((t_off + ((t_len.astype(np.int64) + 3) >> 2)).max()))
+        if end > packed.size:
+            raise ValueError("sequence offsets run past the blob")
+    return packed, p_off, p_len, t_off, t_len, n
+
+
+def cigar_sprint_pretty(ops, pattern, text):
+    """wfa_hip_cigar_sprint_pretty (host only): the text WFA2-lib's cigar_print_pretty prints for this op string."""
+    ops = np.ascontiguousarray(ops, dtype=np.uint8)
+    pattern, text = bytes(pattern), bytes(text)
+    fn = lib().wfa_hip_cigar_sprint_pretty
+    pb = ctypes.c_char_p(pattern) if pattern else None
+    tb = ctypes.c_char_p(text) if text else None
+    need = fn(_ptr(ops) if ops.size else None, ops.size, pb, len(pattern), tb, len(text), None, 0)
+    if need < 0:
+        raise ValueError("wfa_hip_cigar_sprint_pretty: invalid arguments")
+    buf = ctypes.create_string_buffer(int(need) + 1)
+    fn(_ptr(ops) if ops.size else None, ops.size, pb, len(pattern), tb, len(text), buf, need + 1)
+    return buf.value.decode("ascii", "replace")
 
 
 class Aligner:
@@ -229,9 +271,10 @@ class Aligner:
             clen = np.zeros(n, np.int32)
         else:
             cigar_off = ops = cbeg = clen = None
-        rc = lib().wfa_hip_align_batch(self._h, n, _ptr(seqs), _ptr(p_off), _ptr(p_len), _ptr(t_off),
-                                       _ptr(t_len), _ptr(score), _ptr(status), _ptr(ops),
-                                       _ptr(cigar_off), _ptr(cbeg), _ptr(clen))
+        entry = lib().wfa_hip_align_batch_packed2bits if "packed" in batch else lib().wfa_hip_align_batch
+        rc = entry(self._h, n, _ptr(seqs), _ptr(p_off), _ptr(p_len), _ptr(t_off),
+                   _ptr(t_len), _ptr(score), _ptr(status), _ptr(ops),
+                   _ptr(cigar_off), _ptr(cbeg), _ptr(clen))
         if rc != OK:
             self._raise(rc, "wfa_hip_align_batch")
         return score, status, ((ops, cbeg, clen) if want_cigar else None)
@@ -330,8 +373,8 @@ class ResidentBatch:
         self.aligner = aligner
         self.n = n
         self._p_len, self._t_len = p_len, t_len
-        self._h = lib().wfa_hip_batch_create(aligner._h, n, _ptr(seqs), _ptr(p_off), _ptr(p_len),
-                                             _ptr(t_off), _ptr(t_len))
+        create = lib().wfa_hip_batch_create_packed2bits if "packed" in batch else lib().wfa_hip_batch_create
+        self._h = create(aligner._h, n, _ptr(seqs), _ptr(p_off), _ptr(p_len), _ptr(t_off), _ptr(t_len))
         if not self._h:
             msg = aligner.error()
             if "failed:" in msg:

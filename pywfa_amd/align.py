@@ -9,9 +9,10 @@ and constructing an aligner fails loudly when the library or a HIP device is mis
 Deliberate deviations from the reference (DESIGN.md §"Deviations"):
   * invalid penalties / ends-free sizes raise ``ValueError`` where WFA2-lib calls ``exit(1)``
     (wavefront_penalties.c:101-112, wavefront_align.c:95-101);
-  * ``memory_mode="biwfa"`` is built for ``scope="score"`` without heuristic, free ends or ``max_steps`` (the
-    reference returns the same scores there as in its other memory modes); its other forms raise
-    ``NotImplementedError`` (SURVEY.md §8 f4);
+  * ``memory_mode="biwfa"``: ``scope="score"`` runs the ordinary score-only kernels (the reference returns the same
+    scores there as in its other memory modes), ``scope="full"`` runs the breakpoint recursion on the device
+    (csrc/wfa_biwfa.hpp); BiWFA with free ends raises ``NotImplementedError`` (the reference itself
+    ``exit(1)``s, wavefront_align.c:60-75);
   * property setters re-derive the whole native configuration (the reference pokes single C fields
     and leaves derived state stale).
 """
@@ -70,20 +71,22 @@ class AlignmentResult:
 
     @staticmethod
     def _aligned(sequence, tuples, begin, end, gap_type):
-        # The reference unpacks (op, length) tuples as (length, mid) and compares mid with "D"/"I"
-        # (align.pyx:168-180): the gap branch never fires and slices are
-        # taken with the op code as length.  Reproduced as is.
-        seq = sequence[begin:end]
-        parts = []
-        index = 0
-        for length, mid in tuples:
-            if mid == gap_type:
-                parts.append("-" * length)
-            else:
-                parts.append(seq[index:index + length])
-                index += length
-        parts.append(seq[index:end - begin])
-        return "".join(parts)
+        """``aligned_pattern`` / ``aligned_text``.  The reference reads every
+        ``(code, run)`` tuple as ``(width, kind)`` and inserts a gap only where ``kind`` equals the gap letter; a run
+        length is never a letter, so for tuples the aligner produced no gap is inserted, the pieces tile the window
+        ``sequence[begin:end]`` and the result is that window.  Hand-made tuples whose second field IS the gap letter
+        still get their dashes."""
+        window = sequence[begin:end]
+        if all(kind != gap_type for _, kind in tuples):
+            return window
+        pieces, at = [], 0
+        for width, kind in tuples:
+            if kind == gap_type:
+                pieces.append("-" * width)
+                continue
+            pieces.append(window[at:at + width])
+            at += width
+        return "".join(pieces) + window[at:end - begin]
 
     @property
     def aligned_pattern(self):
@@ -101,34 +104,30 @@ class AlignmentResult:
     def cigarstring(self):
         return cigartuples_to_str(self.cigartuples)
 
+    # rows of the three-line view per cigartuple code: (takes pattern bases, takes text bases, glyph of the middle row);
+    # M / = are joined by '|', X by '*', gaps and clips by blanks, anything else is refused
+    _PRETTY_ROWS = {0: (True, True, "|"), 7: (True, True, "|"), 8: (True, True, "*"),
+                    1: (False, True, " "), 4: (False, True, " "), 5: (False, True, " "),
+                    2: (True, False, " ")}
+
     @property
     def pretty(self):
-        """Three-row view of the alignment (align.pyx:122-165)."""
-        compact = [i for i in self.cigartuples if i[0] != 0 and i[0] != [8]]
-        out = f"{self.cigarstring}      ALIGNMENT\n"
-        out += f"{cigartuples_to_str(compact)}      ALIGNMENT.COMPACT\n"
-        p, g, t = ["      PATTERN    "], ["                 "], ["      TEXT       "]
-        pat, txt = self.pattern, self.text
-        pi = ti = 0
-        for op, n in self.cigartuples:
-            if op in (1, 4, 5):
-                t.append(txt[ti:ti + n]); ti += n
-                p.append("-" * n); g.append(" " * n)
-            elif op in (0, 7):
-                t.append(txt[ti:ti + n]); ti += n
-                p.append(pat[pi:pi + n]); pi += n
-                g.append("|" * n)
-            elif op == 2:
-                t.append("-" * n)
-                p.append(pat[pi:pi + n]); pi += n
-                g.append(" " * n)
-            elif op == 8:
-                t.append(txt[ti:ti + n]); ti += n
-                p.append(pat[pi:pi + n]); pi += n
-                g.append("*" * n)
-            else:
-                raise ValueError(f"Cigar operation not available for pretty print - {op}")
-        return out + "".join(p) + "\n" + "".join(g) + "\n" + "".join(t) + "\n"
+        """The CIGAR, the CIGAR without its match runs, and the PATTERN / marks / TEXT rows."""
+        rows = {"p": "      PATTERN    ", "g": "                 ", "t": "      TEXT       "}
+        used_p = used_t = 0
+        for code, run in self.cigartuples:
+            if code not in self._PRETTY_ROWS:
+                raise ValueError(f"Cigar operation not available for pretty print - {code}")
+            on_p, on_t, glyph = self._PRETTY_ROWS[code]
+            rows["p"] += self.pattern[used_p:used_p + run] if on_p else "-" * run
+            rows["t"] += self.text[used_t:used_t + run] if on_t else "-" * run
+            rows["g"] += glyph * run
+            used_p += run if on_p else 0
+            used_t += run if on_t else 0
+        # (the compact form drops the match runs only: the reference's second filter compares an int with a list)
+        compact = cigartuples_to_str([ct for ct in self.cigartuples if ct[0] != 0])
+        head = f"{self.cigarstring}      ALIGNMENT\n{compact}      ALIGNMENT.COMPACT\n"
+        return head + rows["p"] + "\n" + rows["g"] + "\n" + rows["t"] + "\n"
 
 
 def _flank_scan(ct, threshold_left, threshold_right, text_len, pattern_len):
@@ -541,35 +540,9 @@ class WavefrontAligner:
         return ps, pe, ts, te
 
     def cigar_print_pretty(self, file_name=None):
-        """ALIGNMENT / ETRACE / CIGAR + three alignment rows, like cigar_print_pretty
-        (WFA2_lib/alignment/cigar.c:778-863) called by align.pyx:445-459."""
-        pattern = self._bpattern.decode("ascii")
-        text = self._text
-        ch, ln = _rle(self._ops)
-        alignment = "".join(f"{int(n)}{chr(int(c))}" for c, n in zip(ch, ln))
-        etrace = "".join(f"{int(n)}{chr(int(c))}" for c, n in zip(ch, ln) if chr(int(c)) != "M")
-        folded = np.where(self._ops == ord("X"), ord("M"), self._ops).astype(np.uint8)
-        sam = _ops_to_string(folded)
-        pa, oa, ta = [], [], []
-        pp = tp = 0
-        for c in self._ops.tobytes().decode("ascii"):
-            if c == "M":
-                pa.append(pattern[pp]); ta.append(text[tp])
-                oa.append("|" if pattern[pp] == text[tp] else "X")
-                pp += 1; tp += 1
-            elif c == "X":
-                pa.append(pattern[pp]); ta.append(text[tp])
-                oa.append(" " if pattern[pp] != text[tp] else "X")
-                pp += 1; tp += 1
-            elif c == "I":
-                pa.append("-"); oa.append(" "); ta.append(text[tp]); tp += 1
-            elif c == "D":
-                pa.append(pattern[pp]); oa.append(" "); ta.append("-"); pp += 1
-        rest_p, rest_t = pattern[pp:], text[tp:]
-        pa.append(rest_p); ta.append(rest_t)
-        oa.append("?" * max(len(rest_p), len(rest_t)))
-        out = (f"      ALIGNMENT {alignment}\n      ETRACE    {etrace}\n      CIGAR     {sam}\n"
-               f"      PATTERN    {''.join(pa)}\n                 {''.join(oa)}\n      TEXT       {''.join(ta)}\n")
+        """ALIGNMENT / ETRACE / CIGAR + three alignment rows: the text of cigar_print_pretty
+        (WFA2_lib/alignment/cigar.c:778-863, called by align.pyx:445-459) from the C ABI's wfa_hip_cigar_sprint_pretty."""
+        out = _native.cigar_sprint_pretty(self._ops, self._bpattern, self._text.encode("ascii"))
         if file_name:
             with open(file_name, "w") as f:
                 f.write(out)

@@ -28,6 +28,7 @@ for f in k_*.hip; do
 done
 run $HIPCC $FLAGS -c wfa_hip.hip -o $OBJ/wfa_hip.o
 run g++ -O3 -std=c++17 -fPIC -c host_pack.cpp -o $OBJ/host_pack.o   # host code only (AVX-512 / AVX2 / plain C, chosen at run time)
+run g++ -O3 -std=c++17 -fPIC -I../../include -c host_cigar.cpp -o $OBJ/host_cigar.o   # host code only (text helpers)
 fail=0
 for p in "${pids[@]}"; do wait $p || fail=1; done
 [ $fail -eq 0 ] || { echo "build failed"; exit 1; }

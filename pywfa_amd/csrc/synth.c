@@ -79,3 +79,29 @@ void wfa_synth_fill(uint64_t seed, int64_t first, int64_t n, int32_t length, dou
     }
   }
 }
+
+/* The batch as a caller of wavefront_align_packed2bits would hold it (wavefront_sequences.c:102-139): four bases per byte,
+ * base j of a byte in bits 2j..2j+1, A 0 / C 1 / G 2 / T 3; sequence i = (len[i] + 3) / 4 bytes at out + out_off[i].
+ * Letters outside ACGT are not representable: returns the number of such letters (their codes are written as 0). */
+int64_t wfa_synth_pack2bits(const uint8_t* seqs, const int64_t* off, const int32_t* len, int64_t n, uint8_t* out, const int64_t* out_off) {
+  int64_t i, bad = 0;
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+  for (i = 0; i < n; ++i) {
+    const uint8_t* s = seqs + off[i];
+    uint8_t* o = out + out_off[i];
+    const int32_t L = len[i];
+    int32_t j;
+    for (j = 0; j < L; j += 4) {
+      uint8_t b = 0;
+      int32_t q;
+      for (q = 0; q < 4 && j + q < L; ++q) {
+        const uint8_t c = s[j + q];
+        uint8_t code = 0;
+        if (c == 'C') code = 1; else if (c == 'G') code = 2; else if (c == 'T') code = 3; else if (c != 'A') ++bad;
+        b |= (uint8_t)(code << (2 * q));
+      }
+      o[j >> 2] = b;
+    }
+  }
+  return bad;
+}

@@ -124,6 +124,12 @@ static inline int knob(const wfa_hip_aligner* al, WfaKnob k, int dflt) {
 // nothing: hipFree of a 10 M-pair batch's arrays alone was 23 ms of a 133 ms call).  At most 8 GB stay cached.
 static const size_t POOL_MAX_BLOCK = (size_t)4 << 30, POOL_MAX_CACHED = (size_t)8 << 30;
 
+// frees the cached (idle) blocks only; blocks in use by live batches keep their entries in pool_size
+static void pool_drain_cached(wfa_hip_aligner* al) {
+  for (auto& kv : al->pool_free) { al->pool_size.erase(kv.second); (void)hipFree(kv.second); }
+  al->pool_free.clear(); al->pool_cached = 0;
+}
+
 static hipError_t pool_alloc(wfa_hip_aligner* al, void** p, size_t bytes) {
   size_t want = 256;
   if (bytes > POOL_MAX_BLOCK) want = (bytes + 255) & ~(size_t)255;
@@ -135,7 +141,13 @@ static hipError_t pool_alloc(wfa_hip_aligner* al, void** p, size_t bytes) {
       return hipSuccess;
     }
   }
-  const hipError_t e = hipMalloc(p, want);
+  hipError_t e = hipMalloc(p, want);
+  if (e == hipErrorOutOfMemory && al->pool_cached > 0) {
+    // the cache holds idle blocks of other sizes: give them back and try once more
+    (void)hipGetLastError();
+    pool_drain_cached(al);
+    e = hipMalloc(p, want);
+  }
   if (e == hipSuccess) al->pool_size[*p] = want;
   return e;
 }
@@ -201,6 +213,9 @@ struct wfa_hip_batch {
   int64_t last_fallback = 0;
   hipStream_t last_stream = nullptr;
   bool uploads_pending = false;
+  // recorded on the aligner's stream after the last upload / memset / pack kernel of batch_build: a run on another stream
+  // waits for it (the host-packed upload returns with its DMAs still in flight)
+  hipEvent_t upload_event = nullptr;
   int stage_pick = 0;  // first register-kernel stage chosen by the pilot of the first run (0 = not yet): 16, 32 or 64 lanes
   int64_t arena_ints = 0;  // FULL: arena size used by the last launch (the part that grows 8x when a pair overflows it)
   int64_t arena_fixed = 0; // FULL, piggy-back history of the general kernel: the score-only ring in front of the growing part
@@ -436,6 +451,7 @@ static void batch_free(wfa_hip_batch* b) {
   const double t1 = timing ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
   for (void* p : ptrs) pool_release(b->al, p);
   for (hipEvent_t e : b->ev) (void)hipEventDestroy(e);
+  if (b->upload_event) (void)hipEventDestroy(b->upload_event);
   const double t2 = timing ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
   wfa_hip_aligner* al = b->al;
   delete b;
@@ -509,7 +525,8 @@ static int staged_upload(wfa_hip_aligner* al, const std::vector<UploadJob>& jobs
       const int sl = (int)(i % nslots);
       // the slot's previous piece (of this call, or of an earlier one): wait until its DMA was enqueued (by whichever
       // thread had it), then until it is over
-      if (i >= nslots) while (issued[(size_t)sl].load(std::memory_order_acquire) != i - nslots) std::this_thread::yield();
+      // (a worker that saw `failed` leaves without publishing its piece: whoever waits for that piece must leave too)
+      if (i >= nslots) while (issued[(size_t)sl].load(std::memory_order_acquire) != i - nslots) { if (failed.load()) return; std::this_thread::yield(); }
       if (al->pin_ev_recorded[(size_t)sl] && hipEventSynchronize(al->pin_ev[(size_t)sl]) != hipSuccess) failed.store(1);
       if (pieces[(size_t)i].src) memcpy(al->pin_slot[(size_t)sl], pieces[(size_t)i].src, pieces[(size_t)i].bytes);
       else pieces[(size_t)i].job->gen(al->pin_slot[(size_t)sl], pieces[(size_t)i].off, pieces[(size_t)i].bytes);
@@ -571,7 +588,7 @@ static int staged_pack_upload(wfa_hip_aligner* al, wfa_hip_batch* b, const std::
       const PackPiece& pc = pieces[(size_t)i];
       hipStream_t stream = (two_up && (i & 1)) ? al->up_stream : main_stream;   // (shadows the parameter: this piece's stream)
       const int sl = (int)(i % nslots);
-      if (i >= nslots) while (issued[(size_t)sl].load(std::memory_order_acquire) != i - nslots) std::this_thread::yield();
+      if (i >= nslots) while (issued[(size_t)sl].load(std::memory_order_acquire) != i - nslots) { if (failed.load()) return; std::this_thread::yield(); }
       if (al->pin_ev_recorded[(size_t)sl] && hipEventSynchronize(al->pin_ev[(size_t)sl]) != hipSuccess) failed.store(1);
       uint32_t* words = reinterpret_cast<uint32_t*>(al->pin_slot[(size_t)sl]);
       const size_t meta_at = ((size_t)pc.nwords * 4 + 15) & ~(size_t)15;
@@ -579,7 +596,7 @@ static int staged_pack_upload(wfa_hip_aligner* al, wfa_hip_batch* b, const std::
       uint64_t w = pc.wlo;
       for (int64_t q = pc.lo; q < pc.hi; ++q) {
         const int pl = p_len[q], tl = t_len[q];
-        if (p_off[q] < 0 || t_off[q] < 0) { failed.store(2); break; }
+        if (p_off[q] < 0 || t_off[q] < 0) { failed.store(2); return; }
         WfaPairMeta& m = meta[q - pc.lo];
         m.plen = pl; m.tlen = tl;
         m.p_woff = (uint32_t)w;
@@ -613,8 +630,12 @@ static int staged_pack_upload(wfa_hip_aligner* al, wfa_hip_batch* b, const std::
   return WFA_HIP_OK;
 }
 
+static int pilot_first_width(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream);
+
+// in2bit: `seqs` holds 2-bit reads in the reference's packed form (wavefront_sequences.c:102-139: four bases per byte, base j
+// of a byte in bits 2j..2j+1, A 0 / C 1 / G 2 / T 3), a sequence of len bases = (len + 3) / 4 bytes at its BYTE offset
 static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const uint8_t* seqs,
-                       const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len) {
+                       const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len, bool in2bit = false) {
   b->cfg = al->cfg; b->dcfg = al->dcfg; b->ncomp = al->ncomp;
   const wfa_hip_config_t& c = b->cfg;
   const bool timing = al->knobs.set[K_TIMING];
@@ -642,7 +663,7 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
   // host-packed upload: large batches without a wildcard (a wildcard aligns every pair on its bytes).  Pass 1 then also
   // sums the words of every block of 64 pairs (the parts start on block boundaries), the pieces of the upload are cut
   // from those below
-  bool host_pack = pipelined && c.wildcard < 0 && knob(al, K_HOST_PACK, 1) != 0;
+  bool host_pack = pipelined && !in2bit && c.wildcard < 0 && knob(al, K_HOST_PACK, 1) != 0;
   const bool light = host_pack;   // (pass 1 reads the lengths only; see pass1_light)
   std::vector<uint32_t> blk_words(host_pack ? (size_t)((n + 63) >> 6) : 0, 0u);
   auto pass1 = [&](int t) {
@@ -662,7 +683,8 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
       pt.max_len = std::max(pt.max_len, std::max(pl, tl));
       pt.packed += (int64_t)((pl + 3) >> 2) + ((tl + 3) >> 2);
       pt.ops += (int64_t)pl + tl;
-      if (!light) pt.blob_end = std::max(pt.blob_end, std::max(p_off[i] + pl, t_off[i] + tl));
+      if (!light) pt.blob_end = in2bit ? std::max(pt.blob_end, std::max(p_off[i] + ((pl + 3) >> 2), t_off[i] + ((tl + 3) >> 2)))
+                                       : std::max(pt.blob_end, std::max(p_off[i] + pl, t_off[i] + tl));
     }
   };
   // pass 1 of the host-packed form: lengths only, no early exits — a loop the compiler vectorises (10 M pairs: 3.3 -> ~0.5 ms
@@ -869,6 +891,23 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
       HIP_TRY(al, hipMemcpyAsync(b->d_tboff, t_off, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, al->stream));
       HIP_TRY(al, hipMemcpyAsync(b->d_meta, meta.get(), (size_t)n * sizeof(WfaPairMeta), hipMemcpyHostToDevice, al->stream));
     }
+    if (in2bit) {
+      // 2-bit input: re-based to whole words and re-coded by one small kernel; no letter can be outside ACGT
+      const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, (int64_t)al->cu_count * 64));
+      hipLaunchKernelGGL(wfa::wfa_repack2_kernel, dim3(grid), dim3(256), 0, al->stream, b->d_bytes, b->d_pboff, b->d_tboff, b->d_meta, n, b->d_words);
+      HIP_TRY(al, hipGetLastError());
+      b->n_bytes = 0; b->n_packed = (uint32_t)n;
+      if (n <= 256) b->uploads_pending = true;
+      else if (!pipelined) {   // (the caller's arrays are still being read by the plain copies)
+        HIP_TRY(al, hipStreamSynchronize(al->stream));
+        pool_release(al, b->d_bytes); b->d_bytes = nullptr;
+      }
+      b->h_meta = std::move(meta);
+      { const int prc = pilot_first_width(al, b, al->stream); if (prc != WFA_HIP_OK) return prc; }
+      HIP_TRY(al, hipEventCreateWithFlags(&b->upload_event, hipEventDisableTiming));
+      HIP_TRY(al, hipEventRecord(b->upload_event, al->stream));
+      return WFA_HIP_OK;
+    }
     const int threads = 256;
     // lanes per pair: the words of the longest pair, rounded up to a power of two (at most a whole wave)
     int log2slots = 1;
@@ -931,12 +970,50 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
     if (timing) { fprintf(stderr, "[wfa_hip] work lists + free %.3f ms\n", now_ms() - t0); t0 = now_ms(); }
   }
   b->h_meta = std::move(meta);
+  { const int prc = pilot_first_width(al, b, al->stream); if (prc != WFA_HIP_OK) return prc; }
+  HIP_TRY(al, hipEventCreateWithFlags(&b->upload_event, hipEventDisableTiming));
+  HIP_TRY(al, hipEventRecord(b->upload_event, al->stream));
+  return WFA_HIP_OK;
+}
+
+// The narrowest band that keeps most pairs is the cheapest first stage of the short-read cascade; it depends on the divergence
+// of the batch (16 lanes up to ~3 %, 32 up to ~6 %, 64 up to ~10 %).  A pilot on 8192 pairs sampled at a fixed stride across
+// the batch (score-only kernels, one-round form: a name of its own in a profile) decides once per batch, when the batch is
+// created: b->stage_pick = 16 / 32 / 64, or 128 = none of them.  (Up to three small launches, each waited for: it runs where
+// the upload is waited for anyway, so that wfa_hip_batch_run only enqueues.)
+__global__ void __launch_bounds__(256) wfa_pilot_sample_kernel(const uint32_t* __restrict__ list, uint32_t stride, uint32_t np, uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < np) out[i] = list ? list[i * stride] : i * stride;
+}
+
+static int pilot_first_width(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream) {
+  const bool full = (b->cfg.scope == WFA_SCOPE_FULL);
+  if (b->stage_pick != 0 || b->n_packed < 65536u) return WFA_HIP_OK;
+  if (!wfa::seg_supported(b->dcfg, b->ncomp, false) || b->max_len > WFA_FAST_MAX_LEN || knob(al, K_NO_FAST, 0) != 0) return WFA_HIP_OK;
+  if (full ? (knob(al, K_NO_SEGFULL, 0) != 0 || al->knobs.set[K_SEGFULL_STAGES]) : !al->knobs.fast_stages.empty()) return WFA_HIP_OK;
+  const uint32_t np = 8192u, stride = b->n_packed / np;
+  uint32_t* plist = b->d_fb_list2[0];
+  uint32_t* psample = b->d_fb_list2[1];
+  uint32_t* pcount = b->d_counters + 4;
+  hipLaunchKernelGGL(wfa_pilot_sample_kernel, dim3((np + 255u) / 256u), dim3(256), 0, stream, b->d_list_packed, stride, np, psample);
+  HIP_TRY(al, hipGetLastError());
+  b->stage_pick = 128;
+  for (int w = 16; w <= 64; w *= 2) {
+    HIP_TRY(al, hipMemsetAsync(pcount, 0, sizeof(uint32_t), stream));
+    if (wfa::launch_seg(b->dcfg, al->cu_count, knob(al, K_FAST_WAVES_PER_CU, 256), stream, b->d_words, b->d_meta, psample, nullptr, np, b->d_score, b->d_status,
+                        plist, pcount, w == 16 ? 2 : (w == 32 ? 4 : 5)) != 0) { al->err = "pilot launch failed"; return WFA_HIP_EDEVICE; }
+    uint32_t handed = 0;
+    HIP_TRY(al, hipMemcpyAsync(&handed, pcount, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(al, hipStreamSynchronize(stream));
+    if (handed * 5u <= np * 2u) { b->stage_pick = w; break; }  // at most 40 % handed on
+  }
+  HIP_TRY(al, hipMemsetAsync(pcount, 0, sizeof(uint32_t), stream));
   return WFA_HIP_OK;
 }
 
 static wfa_hip_batch* batch_create_nosync(wfa_hip_aligner_t* al, int64_t n, const uint8_t* seqs,
                                           const int64_t* p_off, const int32_t* p_len,
-                                          const int64_t* t_off, const int32_t* t_len) {
+                                          const int64_t* t_off, const int32_t* t_len, bool in2bit = false) {
   if (!al) { g_error = "null aligner"; return nullptr; }
   if (n < 0 || n > 0x7FFFFFF0ll || (n > 0 && (!seqs || !p_off || !p_len || !t_off || !t_len))) {
     al->err = "invalid batch arguments"; g_error = al->err; return nullptr;
@@ -945,7 +1022,8 @@ static wfa_hip_batch* batch_create_nosync(wfa_hip_aligner_t* al, int64_t n, cons
   wfa_hip_batch* b = new wfa_hip_batch();
   b->al = al;
   al->live_batches += 1;
-  const int rc = batch_build(al, b, n, seqs, p_off, p_len, t_off, t_len);
+  if (in2bit && al->cfg.wildcard >= 0) { al->err = "2-bit reads cannot hold a wildcard letter"; g_error = al->err; batch_free(b); return nullptr; }
+  const int rc = batch_build(al, b, n, seqs, p_off, p_len, t_off, t_len, in2bit);
   if (rc != WFA_HIP_OK) { g_error = al->err; batch_free(b); return nullptr; }
   return b;
 }
@@ -957,6 +1035,28 @@ extern "C" wfa_hip_batch_t* wfa_hip_batch_create(wfa_hip_aligner_t* al, int64_t 
   // inputs are borrowed for the call only: their upload must be over before it returns
   if (b && b->uploads_pending) { (void)hipStreamSynchronize(al->stream); b->uploads_pending = false; }
   return b;
+}
+
+extern "C" wfa_hip_batch_t* wfa_hip_batch_create_packed2bits(wfa_hip_aligner_t* al, int64_t n, const uint8_t* packed,
+                                                             const int64_t* p_off, const int32_t* p_len,
+                                                             const int64_t* t_off, const int32_t* t_len) {
+  wfa_hip_batch* b = batch_create_nosync(al, n, packed, p_off, p_len, t_off, t_len, true);
+  if (b && b->uploads_pending) { (void)hipStreamSynchronize(al->stream); b->uploads_pending = false; }
+  return b;
+}
+
+extern "C" int wfa_hip_align_batch_packed2bits(wfa_hip_aligner_t* al, int64_t n, const uint8_t* packed,
+                                               const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len,
+                                               int32_t* score, int32_t* status, uint8_t* cigar_ops, const int64_t* cigar_off,
+                                               int64_t* cigar_begin, int32_t* cigar_len) {
+  if (!al) return WFA_HIP_EINVAL;
+  if (al->cfg.wildcard >= 0) { al->err = "2-bit reads cannot hold a wildcard letter"; return WFA_HIP_ENOTSUP; }
+  wfa_hip_batch_t* b = batch_create_nosync(al, n, packed, p_off, p_len, t_off, t_len, true);
+  if (!b) return (al->err.find("failed:") != std::string::npos) ? WFA_HIP_EDEVICE : WFA_HIP_EINVAL;
+  int rc = wfa_hip_batch_run(b, nullptr);
+  if (rc == WFA_HIP_OK) rc = wfa_hip_batch_results(b, score, status, cigar_ops, cigar_off, cigar_begin, cigar_len);
+  wfa_hip_batch_destroy(b);
+  return rc;
 }
 
 // ---- the walks of a split stage on a stream of their own ----------------------------------------------
@@ -1013,7 +1113,13 @@ struct DualStream {
 static int ensure_ws(wfa_hip_aligner* al, size_t bytes) {
   if (bytes <= al->ws_bytes) return WFA_HIP_OK;
   if (al->ws) { (void)hipFree(al->ws); al->ws = nullptr; al->ws_bytes = 0; }
-  HIP_TRY(al, hipMalloc((void**)&al->ws, bytes));
+  hipError_t e = hipMalloc((void**)&al->ws, bytes);
+  if (e == hipErrorOutOfMemory && al->pool_cached > 0) {   // idle blocks of finished batches: give them back and try once more
+    (void)hipGetLastError();
+    pool_drain_cached(al);
+    e = hipMalloc((void**)&al->ws, bytes);
+  }
+  HIP_TRY(al, e);
   al->ws_bytes = bytes;
   return WFA_HIP_OK;
 }
@@ -1051,8 +1157,8 @@ struct Geometry { int threads; int grid; int64_t ws_stride; };
 static int64_t free_budget(wfa_hip_aligner* al) {
   size_t fr = 0, tot = 0;
   if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = al->total_mem / 2;
-  // what we already hold as workspace can be re-used
-  return (int64_t)((double)(fr + al->ws_bytes) * 0.8);
+  // what we already hold as workspace can be re-used, and so can the idle blocks of the pool (drained on demand)
+  return (int64_t)((double)(fr + al->ws_bytes + al->pool_cached) * 0.8);
 }
 
 static Geometry plan_general(wfa_hip_aligner* al, const wfa_hip_batch* b, uint32_t nwork, int64_t arena_ints) {
@@ -1098,6 +1204,8 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
   // every run of this aligner uses the one workspace (al->ws): order this run after the previous one when it was
   // enqueued on another stream
   if (al->ws_event_recorded && al->ws_last_stream != stream) HIP_TRY(al, hipStreamWaitEvent(stream, al->ws_event, 0));
+  // the batch's uploads were enqueued on the aligner's stream (and may still be in flight): a run elsewhere waits for them
+  if (stream != al->stream && b->upload_event) HIP_TRY(al, hipStreamWaitEvent(stream, b->upload_event, 0));
   b->last_stream = stream;
   b->ran = true; b->synced = false;
   b->last_fallback = 0;
@@ -1314,35 +1422,12 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         }
       }
     }
-    // The narrowest band that keeps most pairs is the cheapest start; it depends on the divergence of the batch (16
-    // lanes up to ~3 %, 32 up to ~6 %, 64 up to ~10 %).  A pilot on the first 8192 pairs (score-only kernels, one-round
-    // form: a name of its own in a profile) decides once per batch: b->stage_pick = 16 / 32 / 64, or 128 = none of them.
-    auto pick_first_width = [&]() -> int {
-      if (b->stage_pick != 0) return WFA_HIP_OK;
-      const uint32_t np = std::min<uint32_t>(8192u, in_n);
-      uint32_t* plist = b->d_fb_list2[0];
-      uint32_t* pcount = b->d_counters + 4;
-      b->stage_pick = 128;
-      for (int w = 16; w <= 64; w *= 2) {
-        HIP_TRY(al, hipMemsetAsync(pcount, 0, sizeof(uint32_t), stream));
-        if (wfa::launch_seg(b->dcfg, al->cu_count, knob(al, K_FAST_WAVES_PER_CU, 256), stream, b->d_words, b->d_meta, in_list, nullptr, np, b->d_score, b->d_status,
-                            plist, pcount, w == 16 ? 2 : (w == 32 ? 4 : 5)) != 0) { al->err = "pilot launch failed"; return WFA_HIP_EDEVICE; }
-        uint32_t handed = 0;
-        HIP_TRY(al, hipMemcpyAsync(&handed, pcount, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(al, hipStreamSynchronize(stream));
-        if (handed * 5u <= np * 2u) { b->stage_pick = w; break; }  // at most 40 % handed on
-      }
-      HIP_TRY(al, hipMemsetAsync(pcount, 0, sizeof(uint32_t), stream));
-      return WFA_HIP_OK;
-    };
     // full CIGARs of short reads: 16-lane segments over the whole batch (history slot per pair, several launches), then
     // 32- and 64-lane segments over what was handed on (device-side counts: slots for 1/8 resp. 1/32 of the batch)
     int64_t segfull_slot_ints[3] = {0, 0, 0}, segfull_cap[3] = {0, 0, 0};
     int segfull_w[3] = {16, 32, 64};
     int n_segfull = use_segfull ? 3 : 0;
-    if (use_segfull && in_n >= 65536u && !al->knobs.set[K_SEGFULL_STAGES]) {
-      const int prc = pick_first_width();
-      if (prc != WFA_HIP_OK) return prc;
+    if (use_segfull && b->stage_pick != 0 && !al->knobs.set[K_SEGFULL_STAGES]) {   // (the pilot of batch_build chose the first width)
       n_segfull = 0;
       for (int w = 16; w <= 64; w *= 2) if (w >= b->stage_pick) segfull_w[n_segfull++] = w;
     } else if (use_segfull) {
@@ -1413,8 +1498,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       // of 8/16/32/64 lanes with the two-round (lazy) extension, 3/2/4/5 = the same widths extending every cell at once
       const char* stages_env = al->knobs.fast_stages.empty() ? nullptr : al->knobs.fast_stages.c_str();
       const char* stages = stages_env ? stages_env : "189";
-      if (!stages_env && in_n >= 65536u && in_count == nullptr) {
-        { const int prc = pick_first_width(); if (prc != WFA_HIP_OK) return prc; }
+      if (!stages_env && b->stage_pick != 0 && in_count == nullptr) {   // (the pilot of batch_build chose the first width)
         stages = (b->stage_pick == 16) ? "189" : (b->stage_pick == 32) ? "89" : "9";  // (128: 64 lanes still take the pairs that fit)
       }
       int variants[6] = {-1, -1, -1, -1, -1, -1};

@@ -64,6 +64,37 @@ wfa_pack_kernel(const uint8_t* __restrict__ bytes, const int64_t* __restrict__ p
   }
 }
 
+// 2-bit input (wfa_hip_*_packed2bits): the caller's reads are already 2 bits per base in the reference's packed form
+// (R/wavefront_sequences.c:102-139: four bases per byte, base j of a byte in bits 2j..2j+1, A 0 / C 1 / G 2 / T 3), a
+// sequence at any byte offset.  The kernels read whole words that start a sequence and the code (c >> 1) & 3 of the ASCII
+// letter (A 0 / C 1 / T 2 / G 3), so every word is re-based and re-coded: code' = code ^ (code >> 1) swaps 2 and 3.
+// 16 lanes per pair, four pairs per wave.
+__global__ void __launch_bounds__(256)
+wfa_repack2_kernel(const uint8_t* __restrict__ bytes, const int64_t* __restrict__ p_boff, const int64_t* __restrict__ t_boff,
+                   const WfaPairMeta* __restrict__ meta, int64_t n, uint32_t* __restrict__ words) {
+  const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  const int wl = threadIdx.x & 15;
+  for (int64_t pair = group; pair < n; pair += ngroups) {
+    const WfaPairMeta pm = meta[pair];
+    const int nwp = (pm.plen + 15) >> 4, ntot = nwp + ((pm.tlen + 15) >> 4);
+    const int64_t pb = p_boff[pair], tb = t_boff[pair];
+    for (int w = wl; w < ntot; w += 16) {
+      const bool is_text = w >= nwp;
+      const int ws = is_text ? w - nwp : w;
+      const int len = is_text ? pm.tlen : pm.plen;
+      const int nbases = min(16, len - ws * 16);            // bases of this word
+      const int nbytes = (nbases + 3) >> 2;                 // bytes of the caller's sequence that hold them
+      const uint8_t* src = bytes + (is_text ? tb : pb) + (int64_t)ws * 4;
+      uint32_t v = 0;
+      for (int j = 0; j < nbytes; ++j) v |= (uint32_t)src[j] << (8 * j);
+      v ^= (v >> 1) & 0x55555555u;
+      if (nbases < 16) v &= (1u << (2 * nbases)) - 1u;      // zero beyond the end, like the other packers
+      words[pm.p_woff + w] = v;
+    }
+  }
+}
+
 // Host-packed upload: byte offsets and flags of the pairs that hold a letter outside ACGT (their bytes sit in a compact blob).
 __global__ void __launch_bounds__(256)
 wfa_flag_scatter_kernel(const uint32_t* __restrict__ ids, const int64_t* __restrict__ pb, const int64_t* __restrict__ tb, uint32_t nb,

@@ -145,3 +145,63 @@ def test_host_pack_2bit_all_forms():
             w, bad = _native.pack_2bit(s, form)
             rw, rbad = ref(s)
             assert bad == rbad and np.array_equal(w, rw), (form, L, s)
+
+
+def _expand_cigar(cigarstring):
+    ops = bytearray()
+    for n, c in re.findall(r"(\d+)([MXID])", cigarstring):
+        ops += c.encode() * int(n)
+    return bytes(ops)
+
+
+def test_cigar_sprint_pretty_matches_the_reference_text():
+    """wfa_hip_cigar_sprint_pretty (host only) against every cigar_print_pretty text recorded from the reference
+    (tests/golden/python_surface.json, written by tools/make_golden.py)."""
+    import json
+    import numpy as np
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "python_surface.json")))
+    seen = 0
+    for rec in cases:
+        pattern = (rec["case"]["ctor"].get("pattern") or "").upper()
+        text, cigar = None, None
+        for st, out in zip(rec["case"]["steps"], rec["expected"]):
+            if st["op"] == "align" and "aligner" in out:
+                text, cigar = st["text"], out["aligner"]["cigarstring"]
+                if st.get("pattern") is not None:
+                    pattern = st["pattern"].upper()
+            elif st["op"] == "pretty_print" and "text" in out and text is not None:
+                ops = np.frombuffer(_expand_cigar(cigar), dtype=np.uint8)
+                got = _native.cigar_sprint_pretty(ops, pattern.encode(), text.encode())
+                assert got == out["text"], rec["case"]["name"]
+                seen += 1
+    assert seen >= 1
+    # truncation like snprintf, and the unaligned tails marked '?'
+    L = _native.lib()
+    buf = ctypes.create_string_buffer(8)
+    need = L.wfa_hip_cigar_sprint_pretty(None, 0, ctypes.c_char_p(b"AC"), 2, ctypes.c_char_p(b"ACG"), 3, buf, 8)
+    assert need > 8 and buf.value == b"      A"
+    assert _native.cigar_sprint_pretty(np.zeros(0, np.uint8), b"AC", b"ACG").endswith(
+        "      PATTERN    AC\n                 ???\n      TEXT       ACG\n")
+
+
+def test_packed2bits_helper_layout():
+    """datagen.to_packed2bits writes the reference's packed form (wavefront_sequences.c:102-139): four bases per byte,
+    base j in bits 2j..2j+1, A 0 / C 1 / G 2 / T 3; the C helper and the NumPy form agree."""
+    import numpy as np
+    from pywfa_amd import datagen
+    b = datagen.from_strings(["ACGTA", "", "TTTTGGGGC"], ["GATTACA", "C", ""])
+    pk = datagen.to_packed2bits(b)
+    lut = "ACGT"
+    for i in range(3):
+        for off, ln, src in ((pk["p_off"][i], pk["p_len"][i], b["p_off"][i]), (pk["t_off"][i], pk["t_len"][i], b["t_off"][i])):
+            dec = "".join(lut[(pk["packed"][off + j // 4] >> (2 * (j % 4))) & 3] for j in range(ln))
+            assert dec == b["seqs"][src:src + ln].tobytes().decode()
+    saved = datagen._synth
+    try:
+        datagen._synth = False
+        pk2 = datagen.to_packed2bits(b)
+    finally:
+        datagen._synth = saved
+    assert np.array_equal(pk2["packed"], pk["packed"]) and np.array_equal(pk2["t_off"], pk["t_off"])
+    with pytest.raises(ValueError):
+        datagen.to_packed2bits(datagen.from_strings(["ACGN"], ["ACGT"]))

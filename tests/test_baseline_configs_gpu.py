@@ -337,3 +337,71 @@ def test_host_packed_upload_matches_the_device_packed_one(gpu, scope, monkeypatc
     if full:
         for j, i in enumerate(sel):
             assert c1[0][c1[1][i]:c1[1][i] + c1[2][i]].tobytes() == o["cigars"][j]
+
+
+def test_large_batch_runs_on_a_caller_stream_right_after_create(gpu):
+    """Batches of >= 256 k pairs come back from wfa_hip_batch_create with the DMAs of the host-packed upload still in
+    flight on the library's stream; a run on a caller-created stream is ordered after them by the library."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    s = ctypes.c_void_p()
+    assert hip.hipStreamCreateWithFlags(ctypes.byref(s), 1) == 0   # hipStreamNonBlocking
+    batch = datagen.generate(400000, 150, 0.02, 919)
+    oc, nc = common.configs_pair(span="end-to-end", scope="score")
+    o = loader.run(loader.reference() if loader.have_reference() else loader.oracle(), oc, batch, want_cigar=False)
+    al = _native.Aligner(nc)
+    for _ in range(3):
+        rb = al.batch(batch)
+        rb.run(s)
+        rb.sync()
+        score, status, _ = rb.results(False)
+        rb.close()
+        assert np.array_equal(score, o["score"]) and np.array_equal(status, o["status"])
+    al.close()
+    hip.hipStreamDestroy(s)
+
+
+@pytest.mark.parametrize("n,length,kw", [(3000, 150, dict(span="end-to-end", scope="score")), (3000, 150, dict(scope="full")),
+                                         (300000, 150, dict(span="end-to-end", scope="score")),
+                                         (40, 3000, dict(scope="full", heuristic="adaptive")),
+                                         (5, 100, dict(distance="affine2p", scope="full"))])
+def test_packed2bits_entry_equals_the_ascii_entry(gpu, n, length, kw):
+    """wfa_hip_align_batch_packed2bits / wfa_hip_batch_create_packed2bits (cf. wavefront_align_packed2bits, wfa.h:211): 2-bit
+    reads in the reference's packed form give the results of the ASCII entry on the decoded sequences, and those of the oracle."""
+    batch = datagen.generate(n, length, 0.04, 5150 + n)
+    if n == 3000:   # ragged: other lengths, empty sequences
+        pats, txts = [], []
+        for i in range(n):
+            p, t = datagen.pair_strings(batch, i)
+            if i % 11 == 0: p = p[:i % 150]
+            if i % 13 == 0: t = ""
+            pats.append(p); txts.append(t)
+        batch = datagen.from_strings(pats, txts)
+    pk = datagen.to_packed2bits(batch)
+    oc, nc = common.configs_pair(**kw)
+    full = oc.scope == 1
+    o = loader.run(loader.oracle(), oc, datagen.subset(batch, np.arange(min(n, 3000))), want_cigar=full)
+    al = _native.Aligner(nc)
+    ref = al.align_batch(batch, full)
+    got = al.align_batch(pk, full)
+    rb = al.batch(pk); rb.run(); rb.sync()
+    res = rb.results(full)
+    rb.close(); al.close()
+    for s, st, cig in (got, res):
+        assert np.array_equal(s, ref[0]) and np.array_equal(st, ref[1])
+        m = min(n, 3000)
+        cigars = None
+        if full:
+            ops, cb, cl = cig
+            cigars = [ops[cb[i]:cb[i] + cl[i]].tobytes() for i in range(m)]
+            rops, rcb, rcl = ref[2]
+            assert all(cigars[i] == rops[rcb[i]:rcb[i] + rcl[i]].tobytes() for i in range(m))
+        common.assert_same(o, s[:m], st[:m], cigars, batch, f"packed2bits {kw}")
+
+
+def test_packed2bits_refuses_a_wildcard(gpu):
+    oc, nc = common.configs_pair(wildcard="N")
+    al = _native.Aligner(nc)
+    with pytest.raises(NotImplementedError):
+        al.align_batch(datagen.to_packed2bits(datagen.from_strings(["ACGT"], ["ACGA"])), True)
+    al.close()
