@@ -134,9 +134,28 @@ def run_resident(al, batch, steps, warmup, want_cigar, barrier=None):
     return out
 
 
-def extra_config(name, n, length, error, seed, cfg_kw, scheme, survey_bytes, trim=0, cpu_pairs=400, cpu_budget=4.0, env=None):
+def counter_file(name, src_hash):
+    """profiles/traffic_<name>.json (tools/make_profiles.py): HBM bytes per run and the dominant kernel's on-chip counters,
+    used only when collected on this kernel source.  Returns (traffic bytes per run or None, secondary or None, provenance)."""
+    path = os.path.join(ROOT, "profiles", f"traffic_{name}.json")
+    try:
+        with open(path) as f:
+            tj = json.load(f)
+    except (OSError, ValueError):
+        return None, None, None
+    same = tj.get("kernel_source_hash") == src_hash
+    prov = {"file": f"profiles/traffic_{name}.json", "collected_on_kernel_source": tj.get("kernel_source_hash"),
+            "same_kernel_source": same, "pairs_profiled": tj.get("pairs"), "counter_files": tj.get("source")}
+    if not same:
+        return None, None, prov
+    return tj.get("hbm_bytes_per_pair"), tj.get("secondary"), prov
+
+
+def extra_config(name, n, length, error, seed, cfg_kw, scheme, survey_bytes, trim=0, cpu_pairs=400, cpu_budget=4.0, env=None,
+                 mt_parity_pairs=0, steps=3):
     """One of the other BASELINE configurations on a stated prefix: kernel time, roofline, CPU baseline, parity.
-    env: library knobs for this configuration (read when its aligner is created)."""
+    env: library knobs for this configuration (read when its aligner is created); mt_parity_pairs: check that many pairs
+    (scores, statuses, op strings) against the reference run on all host threads, beyond the 1-thread timing sample."""
     from pywfa_amd import _native, datagen
     from oracle import loader
     batch = datagen.generate(n, length, error, seed)
@@ -154,7 +173,7 @@ def extra_config(name, n, length, error, seed, cfg_kw, scheme, survey_bytes, tri
     finally:
         for k_ in (env or {}):
             del os.environ[k_]
-    r = run_resident(al, batch, 3, 1, full)
+    r = run_resident(al, batch, steps, 1, full)
     al.close()
     wc = work_counts(batch, cfg_kw, 8 if length >= 5000 else 2000)
     # algorithmic HBM bytes per pair: SURVEY.md §8(d)'s per-unit figure for this configuration and history scheme
@@ -162,17 +181,26 @@ def extra_config(name, n, length, error, seed, cfg_kw, scheme, survey_bytes, tri
     bytes_pair = float(survey_bytes)
     achieved = bytes_pair * n / (r["kernel_ms"] * 1e-3) / 1e9
     cpu, n_cpu, res = cpu_reference(batch, cfg_kw, cpu_pairs, cpu_budget, full)
-    rate = n / (r["elapsed"] / 3)
+    n_bad = parity(res, n_cpu, r["score"], r["status"], r["cig"])
+    if mt_parity_pairs > n_cpu and loader.have_reference():
+        n_mt = int(min(n, mt_parity_pairs))
+        res_mt = loader.reference_mt_full(oc, datagen.subset(batch, np.arange(n_mt)), os.cpu_count() or 1, want_cigar=full)
+        n_bad = parity(res_mt, n_mt, r["score"], r["status"], r["cig"])
+        n_cpu = n_mt
+    rate = n / (r["elapsed"] / steps)
+    traffic_pair, secondary, prov = counter_file(name, kernel_source_hash())
     return {"name": name, "pairs": n, "read_length": length, "error": error, "seed": seed, "config": cfg_kw,
             "history_scheme": scheme if (full and length > 1000) else None,
-            "kernel_ms": r["kernel_ms"], "ms_per_step": r["elapsed"] / 3 * 1e3, "alignments_per_s": rate,
+            "kernel_ms": r["kernel_ms"], "ms_per_step": r["elapsed"] / steps * 1e3, "alignments_per_s": rate,
             "offsets_per_s": rate * wc["offsets_per_pair"], "work": wc,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "bytes_per_pair": bytes_pair, "bytes_per_pair_source": "SURVEY.md §8(d)",
-                         "io_bytes_per_pair_measured": r["io_bytes"] / n},
+                         "io_bytes_per_pair_measured": r["io_bytes"] / n,
+                         "traffic": None if traffic_pair is None else traffic_pair * n, "traffic_bytes_per_pair": traffic_pair,
+                         "traffic_provenance": prov, "secondary": secondary},
             "completed": int((r["status"] == 0).sum()), "handed_to_general_kernel": int(r["fallback"]),
             "cpu_baseline": cpu, "speedup_vs_1_thread": rate / cpu["value"],
-            "parity_checked_pairs": n_cpu, "parity_mismatches": parity(res, n_cpu, r["score"], r["status"], r["cig"])}
+            "parity_checked_pairs": n_cpu, "parity_mismatches": n_bad}
 
 
 def shard_first(rank, pairs_per_gpu):
@@ -270,7 +298,20 @@ def main():
             best = dt if best is None else min(best, dt)
         assert np.array_equal(s2, score) and np.array_equal(st2, status)
         return best
-    t_e2e = time_e2e(al, 3)
+    dist_barrier(dist, backend)
+    t_e2e = dist_max(dist, backend, time_e2e(al, 3))   # (N > 1: every rank's call at once, the host cores shared: the slowest rank counts)
+    # a caller that holds 2-bit reads already (wfa_hip_align_batch_packed2bits): no host packing, a quarter of the bytes
+    t_e2e_2bit = None
+    if rank == 0 and n_gpus == 1:
+        pk = datagen.to_packed2bits(batch)
+        outs2 = (np.zeros(args.pairs, np.int32), np.zeros(args.pairs, np.int32))
+        for _ in range(3):
+            t0 = time.perf_counter()
+            s2, st2, _ = al.align_batch(pk, False, out=outs2)
+            dt = time.perf_counter() - t0
+            t_e2e_2bit = dt if t_e2e_2bit is None else min(t_e2e_2bit, dt)
+        assert np.array_equal(s2, score) and np.array_equal(st2, status)
+        del pk
     al.close()
     # the same call with the host packer off (ASCII over PCIe + device pack kernel), for the record
     t_e2e_ascii = None
@@ -326,10 +367,17 @@ def main():
             "config": {"workload": f"C2: {args.pairs} x {args.length}bp pairs per GPU, {args.error * 100:g}% error (seed 1002), "
                                    "gap-affine 0/4/6/2, end-to-end, scope=score, 2-bit packed sequences resident in HBM; the first "
                                    "stage's width was chosen by a pilot on 8192 pairs during warm-up (once per resident batch)",
-                       "pairs_per_gpu": args.pairs, "read_length": args.length, "parallelism": f"pairs sharded over {n_gpus} GPU(s), no collective"},
+                       "pairs_per_gpu": args.pairs, "read_length": args.length, "parallelism": f"pairs sharded over {n_gpus} GPU(s), no collective",
+                       # `value` is the HBM-resident rate; the PCIe-inclusive rate of the same batch (host ASCII in -> host results out, every
+                       # rank's call at once, the slowest rank counted) is never `value` but belongs beside it (full detail: "end_to_end")
+                       "end_to_end_alignments_per_s": e2e_rate * n_gpus, "end_to_end_seconds_per_batch": t_e2e,
+                       "end_to_end_pcie_frac": e2e_rate * sent_bytes / 1e9 / PCIE_PEAK_GBS,
+                       "end_to_end_2bit_input_alignments_per_s": None if t_e2e_2bit is None else args.pairs / t_e2e_2bit},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_provenance": provenance,
                          "secondary": secondary,
+                         "secondary_bound": None if not secondary else secondary.get("bound"),
+                         "secondary_frac": None if not secondary else secondary.get("frac"),
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_pair": alg_bytes / max(args.pairs, 1),
                          "kernel_ms": kernel_ms, "kernel": "wfa alignment kernels of one step (HIP events on the launch stream)"},
             "offsets_per_s": value * wc["offsets_per_pair"],
@@ -339,6 +387,10 @@ def main():
                            "ascii_bytes_per_pair": ascii_bytes, "ascii_gb_s_consumed": e2e_rate * ascii_bytes / 1e9,
                            "pcie_bytes_per_pair": sent_bytes, "pcie_gb_s": e2e_rate * sent_bytes / 1e9,
                            "pcie_frac": e2e_rate * sent_bytes / 1e9 / PCIE_PEAK_GBS,
+                           "packed2bits_input": None if t_e2e_2bit is None else {
+                               "value": args.pairs / t_e2e_2bit, "seconds_per_batch": t_e2e_2bit,
+                               "what": "wfa_hip_align_batch_packed2bits: the caller holds 2-bit reads (4 bases per byte): no host packing",
+                               "pcie_bytes_per_pair": float(((batch["p_len"].astype(np.int64) + 3) >> 2).sum() + ((batch["t_len"].astype(np.int64) + 3) >> 2).sum()) / args.pairs + 32 + 8},
                            "ascii_upload": None if t_e2e_ascii is None else {
                                "value": args.pairs / t_e2e_ascii, "seconds_per_batch": t_e2e_ascii,
                                "what": "WFA_HIP_HOST_PACK=0: the ASCII blob crosses PCIe, the device packs it",
@@ -356,51 +408,78 @@ def main():
             if cpu["kind"] == "reference":
                 # context only: the same library on every host thread (one aligner object per thread); its scores are
                 # checked too
+                # (steady state: every thread walks its slice of the batch `repeat` times with one aligner, the repeat count
+                # chosen so that the run lasts >= 5 s; nothing is subtracted: thread start, the aligners' set-up and the
+                # first-touch faults are inside the time, they just no longer dominate it)
                 try:
                     nt = os.cpu_count() or 1
                     ocfg = loader.make_config(**cfg_kw)
-                    n_probe = min(args.pairs, max(nt * 2000, 500000))
                     t0 = time.perf_counter()
-                    loader.reference_mt(ocfg, datagen.subset(batch, np.arange(n_probe)), nt, 1)
-                    dt_p = max(time.perf_counter() - t0, 1e-6)
-                    n_mt = int(min(args.pairs, max(n_probe, 8.0 * n_probe / dt_p)))
+                    loader.reference_mt(ocfg, batch, nt, 1)
+                    t_1 = time.perf_counter() - t0
                     t0 = time.perf_counter()
-                    rmt = loader.reference_mt(ocfg, datagen.subset(batch, np.arange(n_mt)), nt, 1)
+                    loader.reference_mt(ocfg, batch, nt, 4)
+                    t_4 = time.perf_counter() - t0
+                    per_pass = max((t_4 - t_1) / 3.0, 1e-4)
+                    repeat = int(min(2000, max(4, np.ceil(6.0 / per_pass))))
+                    t0 = time.perf_counter()
+                    rmt = loader.reference_mt(ocfg, batch, nt, repeat)
                     dt_mt = time.perf_counter() - t0
-                    cpu["all_threads"] = {"value": n_mt / dt_mt, "threads": nt,
-                                          "sample": f"first {n_mt} pairs, one aligner per thread, {dt_mt:.1f} s",
-                                          "parity_checked_pairs": n_mt, "parity_mismatches": parity(rmt, n_mt, score, status, None)}
+                    cpu["all_threads"] = {"value": args.pairs * repeat / dt_mt, "threads": nt, "repeat": repeat, "seconds": dt_mt,
+                                          "one_pass_seconds": t_1, "four_pass_seconds": t_4,
+                                          "sample": f"all {args.pairs} pairs x {repeat} passes, one aligner per thread, {dt_mt:.1f} s (a single pass "
+                                                    f"takes {t_1:.2f} s, set-up dominated: {args.pairs / t_1 / 1e6:.1f} M/s)",
+                                          "parity_checked_pairs": args.pairs, "parity_mismatches": parity(rmt, args.pairs, score, status, None)}
+                    cpu["all_threads_value"] = cpu["all_threads"]["value"]
+                    cpu["all_threads_threads"] = nt
                 except Exception as e:  # the single-thread figure above is the reported baseline
                     cpu["all_threads"] = {"error": str(e)}
             out["cpu_baseline"] = cpu
         if n_gpus == 1 and not args.no_extra_configs:
+            C4 = dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="full")
             xs = []
-            try:
-                xs.append(extra_config("C1", 1_000_000, 150, 0.02, datagen.SEEDS["C1"], dict(scope="full"), "explicit", 236,
-                                       cpu_pairs=200000, cpu_budget=3.0))
+            plan = [
+                dict(name="C1", n=1_000_000, length=150, error=0.02, seed=datagen.SEEDS["C1"], cfg_kw=dict(scope="full"), scheme="explicit",
+                     survey_bytes=236, cpu_pairs=200000, cpu_budget=3.0),
                 # (long reads keep the piggy-back history by default; WFA_HIP_BAND_PB=0 = the explicit offsets, for the record)
-                xs.append(extra_config("C3", 100_000, 10000, 0.08, datagen.SEEDS["C3"],
-                                       dict(span="end-to-end", scope="full", heuristic="adaptive"), "piggyback", 114e3))
-                xs.append(extra_config("C3-explicit-history", 100_000, 10000, 0.08, datagen.SEEDS["C3"],
-                                       dict(span="end-to-end", scope="full", heuristic="adaptive"), "explicit", 750e3, env={"WFA_HIP_BAND_PB": "0"}))
-                xs.append(extra_config("C4-adaptive", 20_000, 10000, 0.08, datagen.SEEDS["C4"],
-                                       dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100,
-                                            scope="full", heuristic="adaptive"), "piggyback", 114e3 * 5 / 3, trim=50, cpu_pairs=100))
-                xs.append(extra_config("C4-exact", 1024, 10000, 0.08, datagen.SEEDS["C4"],
-                                       dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="full"),
-                                       "piggyback", 54e6, trim=50, cpu_pairs=8, cpu_budget=3.0))
-                xs.append(extra_config("C4-adaptive-explicit-history", 20_000, 10000, 0.08, datagen.SEEDS["C4"],
-                                       dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100,
-                                            scope="full", heuristic="adaptive"), "explicit", 750e3 * 5 / 3, trim=50, cpu_pairs=100,
-                                       env={"WFA_HIP_BAND_PB": "0"}))
-            except Exception as e:
-                xs.append({"error": repr(e)})
+                dict(name="C3", n=100_000, length=10000, error=0.08, seed=datagen.SEEDS["C3"],
+                     cfg_kw=dict(span="end-to-end", scope="full", heuristic="adaptive"), scheme="piggyback", survey_bytes=114e3),
+                dict(name="C4-adaptive", n=20_000, length=10000, error=0.08, seed=datagen.SEEDS["C4"], cfg_kw=dict(C4, heuristic="adaptive"),
+                     scheme="piggyback", survey_bytes=114e3 * 5 / 3, trim=50, cpu_pairs=100),
+                dict(name="C4-exact", n=1024, length=10000, error=0.08, seed=datagen.SEEDS["C4"], cfg_kw=C4, scheme="piggyback", survey_bytes=54e6,
+                     trim=50, cpu_pairs=8, cpu_budget=3.0, mt_parity_pairs=64),
+                dict(name="exact-10kb-score", n=2048, length=10000, error=0.08, seed=datagen.SEEDS["C3"], cfg_kw=dict(span="end-to-end", scope="score"),
+                     scheme="none", survey_bytes=2 * 2500 + 8, cpu_pairs=40, cpu_budget=3.0, mt_parity_pairs=256),
+                dict(name="exact-10kb-full", n=2048, length=10000, error=0.08, seed=datagen.SEEDS["C3"], cfg_kw=dict(span="end-to-end", scope="full"),
+                     scheme="piggyback", survey_bytes=5.1e6 + 2 * 2500 + 10_800, cpu_pairs=20, cpu_budget=3.0, mt_parity_pairs=128),
+                dict(name="C5-adaptive", n=8192, length=100000, error=0.08, seed=datagen.SEEDS["C5"],
+                     cfg_kw=dict(span="end-to-end", scope="full", heuristic="adaptive"), scheme="piggyback", survey_bytes=1.14e6, cpu_pairs=4,
+                     cpu_budget=2.0, mt_parity_pairs=32, steps=2),
+                dict(name="C3-explicit-history", n=100_000, length=10000, error=0.08, seed=datagen.SEEDS["C3"],
+                     cfg_kw=dict(span="end-to-end", scope="full", heuristic="adaptive"), scheme="explicit", survey_bytes=750e3, env={"WFA_HIP_BAND_PB": "0"}),
+                dict(name="C4-adaptive-explicit-history", n=20_000, length=10000, error=0.08, seed=datagen.SEEDS["C4"], cfg_kw=dict(C4, heuristic="adaptive"),
+                     scheme="explicit", survey_bytes=750e3 * 5 / 3, trim=50, cpu_pairs=100, env={"WFA_HIP_BAND_PB": "0"}),
+            ]
+            for kw_ in plan:
+                try:
+                    xs.append(extra_config(**kw_))
+                except Exception as e:
+                    xs.append({"name": kw_["name"], "error": repr(e)})
             out["extra"]["configs"] = xs
             out["extra"]["configs_note"] = ("stated prefixes of the BASELINE streams: C1 at 1 M pairs (BASELINE names 1 k), C3 100 k of 1 M, "
                                             "C4 as written (no heuristic) on 1 024 pairs (54 MB per pair: SURVEY's piggy-back figure) and with wf-adaptive on 20 k of "
-                                            "1 M (its bytes per pair are C3's figure x 5/3 components); C2 above is the full 10 M.  Long reads keep the "
+                                            "1 M (its bytes per pair are C3's figure x 5/3 components); exact (no heuristic) gap-affine 10 kb, score and full CIGAR "
+                                            "(5.1 M M-offsets per pair: one history byte each); C5 with wf-adaptive on 8 192 of 100 k pairs (X-drop(20) / match = 0 as "
+                                            "BASELINE writes C5 drops every pair after a few steps, SURVEY Q2); C2 above is the full 10 M.  Long reads keep the "
                                             "piggy-back history (one byte of origin codes per cell) in every memory mode; the *-explicit-history "
                                             "lines are the same configurations with WFA_HIP_BAND_PB=0")
+            # the other half of the metric where a record that keeps only the scalars of `config` still shows it
+            for x in xs:
+                if "alignments_per_s" in x:
+                    key = x["name"].lower().replace("-", "_")
+                    out["config"][f"{key}_alignments_per_s"] = x["alignments_per_s"]
+                    out["config"][f"{key}_hbm_frac"] = x["roofline"]["frac"]
+                    out["config"][f"{key}_parity_mismatches"] = x["parity_mismatches"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -200,6 +200,38 @@ def reference_mt(cfg, batch, nthreads, repeat=1):
     return {"score": score, "status": status, "cigars": None}
 
 
+def reference_mt_full(cfg, batch, nthreads=None, want_cigar=None):
+    """`run(reference(), ...)` on several host threads (pairs handed out one at a time, one aligner per thread): scores,
+    statuses and op strings of the real reference for the expensive configurations."""
+    reference()
+    lib = ctypes.CDLL(reference_path())
+    fn = lib.ref_align_batch_mt_full
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.POINTER(Config), ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 11
+    nthreads = int(nthreads or os.cpu_count() or 1)
+    n = len(batch["p_len"])
+    seqs = np.ascontiguousarray(batch["seqs"], dtype=np.uint8)
+    p_off = np.ascontiguousarray(batch["p_off"], np.int64); p_len = np.ascontiguousarray(batch["p_len"], np.int32)
+    t_off = np.ascontiguousarray(batch["t_off"], np.int64); t_len = np.ascontiguousarray(batch["t_len"], np.int32)
+    score = np.zeros(n, np.int32)
+    status = np.zeros(n, np.int32)
+    if want_cigar is None:
+        want_cigar = cfg.scope == 1
+    cigar_off = ops = cbeg = clen = None
+    if want_cigar:
+        cigar_off = np.zeros(n + 1, np.int64)
+        np.cumsum(p_len.astype(np.int64) + t_len.astype(np.int64), out=cigar_off[1:])
+        ops = np.zeros(max(int(cigar_off[-1]), 1), np.uint8)
+        cbeg = np.zeros(n, np.int64)
+        clen = np.zeros(n, np.int32)
+    rc = fn(ctypes.byref(cfg), min(nthreads, max(n, 1)), n, _ptr(seqs), _ptr(p_off), _ptr(p_len), _ptr(t_off), _ptr(t_len),
+            _ptr(score), _ptr(status), _ptr(ops), _ptr(cigar_off), _ptr(cbeg), _ptr(clen))
+    if rc != 0:
+        raise RuntimeError(f"reference returned {rc}")
+    cigars = [ops[cbeg[i]:cbeg[i] + clen[i]].tobytes() for i in range(n)] if want_cigar else None
+    return {"score": score, "status": status, "cigars": cigars}
+
+
 def oracle_counters(reset=False):
     """(M offsets, offsets of all components, bases compared) the oracle has processed since the last reset
     (bench.py's "offsets/s" figure)."""

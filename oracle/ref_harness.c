@@ -162,4 +162,39 @@ int ref_align_batch_mt(const wfa_hip_config_t* cfg, int nthreads, int repeat, in
   return rc;
 }
 
+/* ref_align_batch on `nthreads` host threads, op strings included: the pairs are handed out one at a time (long reads differ
+ * a lot in cost), one aligner object per thread, created on the thread's first pair.  For the parity checks of the expensive
+ * configurations (exact gap-affine-2p at 10 kb: ~0.1 s and ~0.4 GB per pair on one core). */
+int ref_align_batch_mt_full(const wfa_hip_config_t* cfg, int nthreads, int64_t n, const uint8_t* seqs,
+                            const int64_t* p_off, const int32_t* p_len,
+                            const int64_t* t_off, const int32_t* t_len,
+                            int32_t* score, int32_t* status,
+                            uint8_t* cigar_ops, const int64_t* cigar_off,
+                            int64_t* cigar_begin, int32_t* cigar_len) {
+  int rc = 0;
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+  {
+    wavefront_aligner_t* aligner = NULL;
+#pragma omp for schedule(dynamic, 1)
+    for (int64_t i = 0; i < n; ++i) {
+      if (aligner == NULL) aligner = ref_new_aligner(cfg);
+      if (aligner == NULL) { rc = -1; continue; }
+      wavefront_align(aligner, (const char*)(seqs + p_off[i]), p_len[i], (const char*)(seqs + t_off[i]), t_len[i]);
+      score[i] = aligner->cigar->score;
+      status[i] = aligner->align_status.status;
+      if (cigar_len) {
+        const cigar_t* const cigar = aligner->cigar;
+        int len = cigar->end_offset - cigar->begin_offset;
+        if (len < 0) len = 0;
+        cigar_len[i] = len;
+        if (cigar_begin) cigar_begin[i] = cigar_off ? cigar_off[i] : 0;
+        if (cigar_ops && cigar_off && len > 0) memcpy(cigar_ops + cigar_off[i], cigar->operations + cigar->begin_offset, (size_t)len);
+      }
+    }
+    if (aligner != NULL) wavefront_aligner_delete(aligner);
+  }
+  return rc;
+}
+
 const char* ref_version(void) { return "WFA2-lib v2.3 (pywfa 0.5.1 vendored copy)"; }

@@ -22,6 +22,9 @@ def run(label, n, L, e, seed, kw, cpu_n=None, reps=2, check=True):
     score, status, cig = rb.results(full)
     fb = rb.fallback_pairs(); alg = rb.algorithmic_bytes(); rb.close(); al.close()
     cpu_n = min(n, cpu_n or n)
+    if os.environ.get("NO_CPU"):   # profile passes: the device work only
+        print(f"{label:42s} kernel_ms={ms:9.3f} aln/s={n / wall:.4g} handed_to_general={fb} pairs={n} runs={reps + 1}", flush=True)
+        return None
     sub = datagen.subset(batch, np.arange(cpu_n))
     fn = loader.reference() if loader.have_reference() else loader.oracle()
     t0 = time.time(); o = loader.run(fn, oc, sub); t_cpu = time.time() - t0
@@ -63,4 +66,9 @@ if "B10k" in which: run("10kb BiWFA full", 2000, 10000, 0.08, 1003, dict(span="e
 if "B1k" in which: run("1kb BiWFA full", 50000, 1000, 0.08, 1003, dict(span="end-to-end", scope="full", memory_mode="biwfa"), cpu_n=2000)
 if "C5a8k" in which: run("100kb adaptive full, 8192 pairs", 8192, 100000, 0.08, 1005, dict(span="end-to-end", scope="full", heuristic="adaptive"), cpu_n=4, reps=1)
 if "C5as8k" in which: run("100kb adaptive score, 8192 pairs", 8192, 100000, 0.08, 1005, dict(span="end-to-end", scope="score", heuristic="adaptive"), cpu_n=4, reps=1)
+if "X100k" in which: run("100kb exact score", 64, 100000, 0.08, 1005, dict(span="end-to-end", scope="score"), cpu_n=1, reps=1)
+if "X100kf" in which: run("100kb exact full", 64, 100000, 0.08, 1005, dict(span="end-to-end", scope="full"), cpu_n=1, reps=1)
+if "X30k" in which: run("30kb exact score", 512, 30000, 0.08, 1005, dict(span="end-to-end", scope="score"), cpu_n=2, reps=1)
+if "X30kf" in which: run("30kb exact full", 512, 30000, 0.08, 1005, dict(span="end-to-end", scope="full"), cpu_n=2, reps=1)
+if "EF150" in which: run("150bp ends-free(8,7,3,2) score", 2000000, 150, 0.02, 1002, dict(span="ends-free", pattern_begin_free=8, pattern_end_free=7, text_begin_free=3, text_end_free=2, scope="score"), cpu_n=100000)
 if "C5a" in which: run("100kb adaptive full", 500, 100000, 0.08, 1005, dict(span="end-to-end", scope="full", heuristic="adaptive"), cpu_n=10)

@@ -6,7 +6,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     seen = set()
     for r in csv.DictReader(open(f)):
-        kn = r["Kernel_Name"].split("(")[0][:60]
+        kn = r["Kernel_Name"].split("(")[0][:120]
         acc[kn][r["Counter_Name"]] += float(r["Counter_Value"])
         key = (kn, r["Dispatch_Id"])
         if key not in seen: seen.add(key); cnt[kn] += 1

@@ -1,6 +1,6 @@
 """Development aid: wall time of wfa_hip_align_batch (host ASCII in -> host results out) on the C2 batch."""
 import sys, time, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 from pywfa_amd import _native, datagen
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000000

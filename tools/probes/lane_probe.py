@@ -2,7 +2,7 @@
 """Development aid: C2 kernel time under different stage orders (WFA_HIP_FAST_STAGES) + a parity check of a sample."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import loader
 from pywfa_amd import datagen, _native

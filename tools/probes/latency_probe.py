@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Latency of single-pair calls through the Python surface and through the C ABI (development aid)."""
 import time, sys, os, random
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
 import numpy as np
 from pywfa_amd import WavefrontAligner, _native, datagen
 import common

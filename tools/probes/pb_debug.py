@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Compare the piggy-back and the explicit history of the banded kernel on a few long pairs (development aid)."""
 import os, sys
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from oracle import loader

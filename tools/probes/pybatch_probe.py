@@ -1,6 +1,6 @@
 """Development aid: what a Python caller of wavefront_align_batch(list of str) pays per pair."""
 import sys, time, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from pywfa_amd import WavefrontAligner, datagen
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 b = datagen.generate(n, 150, 0.02, 1001)

@@ -1,6 +1,6 @@
 """Development aid: wavefront_align_batch(list of str) for small lists."""
 import sys, time, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from pywfa_amd import WavefrontAligner, datagen
 b = datagen.generate(2048, 150, 0.02, 1001)
 P, T = [], []

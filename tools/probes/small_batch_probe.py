@@ -1,6 +1,6 @@
 """Development aid: wall time of wfa_hip_align_batch for small batches of 150 bp pairs."""
 import sys, time, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 from pywfa_amd import _native, datagen
 b = datagen.generate(4096, 150, 0.02, 1002)

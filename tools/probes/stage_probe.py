@@ -2,7 +2,7 @@
 """Per-stage kernel times of the register-kernel cascade on C2-shaped data (development aid, no torch):
    python tools/stage_probe.py 245 24 3245      (N=pairs, default 10M; prints the library's stage lines)"""
 import os, sys, time
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from pywfa_amd import datagen, _native
