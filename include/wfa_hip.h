@@ -209,6 +209,8 @@ int wfa_hip_pack_2bit(const uint8_t* seq, int32_t len, uint32_t* words, int form
  * (pywfa_amd/_native.py does; pywfa itself passes one str per call, align.pyx:432-437).
  */
 int64_t wfa_hip_batch_extent(int64_t n, const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len);
+/* The same for a batch of 2-bit reads (wfa_hip_align_batch_packed2bits): a sequence of len bases reaches (len + 3) / 4 bytes. */
+int64_t wfa_hip_batch_extent_packed2bits(int64_t n, const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len);
 
 /* ---- several devices of one node ------------------------------------------------ */
 

@@ -232,6 +232,17 @@ def reference_mt_full(cfg, batch, nthreads=None, want_cigar=None):
     return {"score": score, "status": status, "cigars": cigars}
 
 
+def oracle_undefined_reads(reset=False):
+    """How often the oracle met the one undefined branch of the reference's ends-free re-seeding (match < 0 with free begins,
+    wavefront_compute.c:229-251: offsets[0] is read without ever being written) since the last reset.  The oracle reads NULL
+    there; parity against the real library is only claimed where this stays 0."""
+    oracle()
+    lib = ctypes.CDLL(os.path.join(HERE, "liboracle.so"))
+    lib.wfa_oracle_undefined_reads.argtypes = [ctypes.c_int]
+    lib.wfa_oracle_undefined_reads.restype = ctypes.c_int64
+    return int(lib.wfa_oracle_undefined_reads(1 if reset else 0))
+
+
 def oracle_counters(reset=False):
     """(M offsets, offsets of all components, bases compared) the oracle has processed since the last reset
     (bench.py's "offsets/s" figure)."""

@@ -44,6 +44,8 @@ typedef struct {
   int ncomp; /* 1 indel/edit/linear, 3 affine, 5 affine2p */
   int metric; /* WFA_DIST_* */
   int scope; /* max_score_scope (R/wavefront_components.c:81-124) */
+  /* match < 0 with free begins: the begin cells are (re)seeded score by score (R/wavefront_compute.c:124-254) */
+  int ef_seed, ef_pbf, ef_tbf;
   /* history: comp-major tables indexed by score (full) or score % scope (score-only) */
   wf_t* wf[5]; /* 0=M 1=I1 2=D1 3=I2 4=D2 */
   int64_t wf_cap;
@@ -90,11 +92,13 @@ static int ws_reserve_arena(oracle_ws_t* ws, int64_t n) {
   return 0;
 }
 
-/* storage for wavefront (comp c, score s) covering k in [lo,hi] */
-static int wf_alloc(oracle_ws_t* ws, int c, int s, int lo, int hi) {
+/* storage for wavefront (comp c, score s) covering k in [alo,ahi], valid range [lo,hi] */
+static int wf_alloc_range(oracle_ws_t* ws, int c, int s, int alo, int ahi, int lo, int hi);
+static int wf_alloc(oracle_ws_t* ws, int c, int s, int lo, int hi) { return wf_alloc_range(ws, c, s, lo, hi, lo, hi); }
+static int wf_alloc_range(oracle_ws_t* ws, int c, int s, int alo, int ahi, int lo, int hi) {
   const int64_t slot = ws->modular ? (s % ws->scope) : s;
   wf_t* w = &ws->wf[c][slot];
-  const int64_t n = (int64_t)hi - lo + 1;
+  const int64_t n = (int64_t)ahi - alo + 1;
   if (ws->modular) {
     w->idx = (slot * 5 + c) * ws->slot_stride;
     if (n > ws->slot_stride) return -1;
@@ -106,7 +110,7 @@ static int wf_alloc(oracle_ws_t* ws, int c, int s, int lo, int hi) {
   w->exists = 1;
   w->lo = lo;
   w->hi = hi;
-  w->base = lo;
+  w->base = alo;
   return 0;
 }
 
@@ -178,6 +182,70 @@ static void wf_trim(oracle_ws_t* ws, wf_t* w, int plen, int tlen) {
 }
 
 /*
+ * match < 0 with free begins (R/wavefront_compute.c:124-254).  With a match score the begin-free cells are not all worth the
+ * same, so wavefront 0 holds diagonal 0 only and the cell that skips j text (pattern) bases enters the M wavefront of score
+ * j * (-match): (k = j, offset j) resp. (k = -j, offset 0), if it beats what compute-next put there.
+ *   required   :124-139     limits :140-153     re-seeding a computed wavefront :171-213     a null step :214-254
+ * One branch of the reference is undefined: a null step at a required score whose j exceeds both free begins gets lo = hi = 0
+ * with offsets[0] never written (:229-251).  Here that offset is NULL (the wavefront is null) and the event is counted
+ * (wfa_oracle_undefined_reads): parity against the real library is claimed only where the count stays 0.
+ */
+static int64_t g_undefined_reads;
+int64_t wfa_oracle_undefined_reads(int reset) { const int64_t v = g_undefined_reads; if (reset) g_undefined_reads = 0; return v; }
+
+static inline int ef_required(const oracle_ws_t* ws, int s) {
+  return ws->ef_seed && (s % (-ws->match)) == 0;
+}
+/* a null step at a required score (wavefront_compute_endsfree_allocate_null); returns -1 when out of memory */
+static int ef_seed_null_step(oracle_ws_t* ws, int s) {
+  const int ek = s / (-ws->match);
+  const int tb = ws->ef_tbf >= ek, pb = ws->ef_pbf >= ek;
+  int lo = 0, hi = 0;
+  if (tb && pb) { lo = -ek; hi = ek; } else if (tb) { lo = hi = ek; } else if (pb) { lo = hi = -ek; }
+  if (!tb && !pb) { ++g_undefined_reads; return 0; }   /* the reference: lo = hi = 0, offsets[0] unset; here: null */
+  if (wf_alloc(ws, 0, s, lo, hi)) return -1;
+  wf_t* w = wf_slot(ws, 0, s);
+  int32_t* o = ws->arena + w->idx;
+  int k;
+  for (k = lo; k <= hi; ++k) o[k - w->base] = OFFSET_NULL;
+  if (tb) o[ek - w->base] = ek;
+  if (pb) o[-ek - w->base] = 0;
+  return 0;
+}
+/* storage range of a computed wavefront at a required score (wavefront_compute_endsfree_limits) */
+static void ef_limits(const oracle_ws_t* ws, int s, int* alo, int* ahi) {
+  const int ek = s / (-ws->match);
+  if (ws->ef_tbf >= ek && ek > *ahi) *ahi = ek;
+  if (ws->ef_pbf >= ek && -ek < *alo) *alo = -ek;
+}
+/* re-seeding of the computed M wavefront before its ends are trimmed (wavefront_compute_endsfree_init) */
+static void ef_seed_computed(oracle_ws_t* ws, wf_t* w, int s) {
+  const int ek = s / (-ws->match);
+  const int lo = w->lo, hi = w->hi;
+  int32_t* o = ws->arena + w->idx;
+  int k;
+  if (ws->ef_tbf >= ek) {
+    if (hi >= ek) {
+      /* (ek < lo: the reference compares with a cell outside the wavefront and may write it; it stays outside, unobservable) */
+      if (ek >= lo && o[ek - w->base] <= ek) o[ek - w->base] = ek;
+    } else {
+      for (k = hi + 1; k < ek; ++k) o[k - w->base] = OFFSET_NULL;
+      o[ek - w->base] = ek;
+      w->hi = ek;
+    }
+  }
+  if (ws->ef_pbf >= ek) {
+    if (lo <= -ek) {
+      if (-ek <= hi && o[-ek - w->base] <= 0) o[-ek - w->base] = 0;
+    } else {
+      o[-ek - w->base] = 0;
+      for (k = -ek + 1; k < lo; ++k) o[k - w->base] = OFFSET_NULL;
+      w->lo = -ek;
+    }
+  }
+}
+
+/*
  * Compute-next for score s (R/wavefront_compute_affine.c:44-86,229-260;
  * R/wavefront_compute_affine2p.c:45-106,286-368; limits R/wavefront_compute.c:40-86;
  * which outputs exist R/wavefront_compute.c:440-485).  Returns 1 for a null step.
@@ -192,13 +260,20 @@ static int compute_next_linear(oracle_ws_t* ws, int s, int plen, int tlen, int* 
   wf_in_t mx = wf_fetch(ws, 0, indel ? -1 : s - ws->x);
   wf_in_t mo = wf_fetch(ws, 0, s - ws->o1);
   wf_slot(ws, 0, s)->exists = 0;
-  if (mx.null && mo.null) return 1;
+  if (mx.null && mo.null) {
+    if (ef_required(ws, s) && ef_seed_null_step(ws, s)) *err = 1;
+    return 1;
+  }
   int lo = mo.lo - 1, hi = mo.hi + 1;
   if (!indel) { lo = MIN2(mx.lo, lo); hi = MAX2(mx.hi, hi); }
-  if (wf_alloc(ws, 0, s, lo, hi)) { *err = 1; return 0; }
+  {
+    int alo = lo, ahi = hi;
+    if (ef_required(ws, s)) ef_limits(ws, s, &alo, &ahi);
+    if (wf_alloc_range(ws, 0, s, alo, ahi, lo, hi)) { *err = 1; return 0; }
+  }
   mx = wf_fetch(ws, 0, indel ? -1 : s - ws->x);
   mo = wf_fetch(ws, 0, s - ws->o1);
-  int32_t* om = ws->arena + wf_slot(ws, 0, s)->idx;
+  int32_t* om = ws->arena + wf_slot(ws, 0, s)->idx + (lo - wf_slot(ws, 0, s)->base);
   int k;
   g_m_offsets += (int64_t)hi - lo + 1; g_all_offsets += (int64_t)hi - lo + 1;
   for (k = lo; k <= hi; ++k) {
@@ -210,6 +285,7 @@ static int compute_next_linear(oracle_ws_t* ws, int s, int plen, int tlen, int* 
     if (v > (uint32_t)plen) mv = OFFSET_NULL;
     om[k - lo] = mv;
   }
+  if (ef_required(ws, s)) ef_seed_computed(ws, wf_slot(ws, 0, s), s);
   wf_trim(ws, wf_slot(ws, 0, s), plen, tlen);
   return 0;
 }
@@ -231,6 +307,7 @@ static int compute_next(oracle_ws_t* ws, int s, int plen, int tlen, int* err) {
   /* the slot is being overwritten (modular) or is fresh (full) */
   for (c = 0; c < ws->ncomp; ++c) wf_slot(ws, c, s)->exists = 0;
   if (mx.null && mo1.null && i1e.null && d1e.null && (!two || (mo2.null && i2e.null && d2e.null))) {
+    if (ef_required(ws, s) && ef_seed_null_step(ws, s)) *err = 1;
     return 1;
   }
   int lo = mx.lo, hi = mx.hi;
@@ -248,7 +325,11 @@ static int compute_next(oracle_ws_t* ws, int s, int plen, int tlen, int* err) {
   const int has_d2 = two && (!mo2.null || !d2e.null);
   /* the reference delegates to the 1-piece kernel when all *2 inputs are null; the values
    * it would have produced for I2/D2 are then never stored, so the result is identical */
-  if (wf_alloc(ws, 0, s, lo, hi)) { *err = 1; return 0; }
+  {
+    int alo = lo, ahi = hi;
+    if (ef_required(ws, s)) ef_limits(ws, s, &alo, &ahi);
+    if (wf_alloc_range(ws, 0, s, alo, ahi, lo, hi)) { *err = 1; return 0; }
+  }
   if (has_i1 && wf_alloc(ws, 1, s, lo, hi)) { *err = 1; return 0; }
   if (has_d1 && wf_alloc(ws, 2, s, lo, hi)) { *err = 1; return 0; }
   if (has_i2 && wf_alloc(ws, 3, s, lo, hi)) { *err = 1; return 0; }
@@ -263,7 +344,7 @@ static int compute_next(oracle_ws_t* ws, int s, int plen, int tlen, int* err) {
     i2e = wf_fetch(ws, 3, s - ws->e2);
     d2e = wf_fetch(ws, 4, s - ws->e2);
   }
-  int32_t* om = ws->arena + wf_slot(ws, 0, s)->idx;
+  int32_t* om = ws->arena + wf_slot(ws, 0, s)->idx + (lo - wf_slot(ws, 0, s)->base);
   int32_t* oi1 = has_i1 ? ws->arena + wf_slot(ws, 1, s)->idx : NULL;
   int32_t* od1 = has_d1 ? ws->arena + wf_slot(ws, 2, s)->idx : NULL;
   int32_t* oi2 = has_i2 ? ws->arena + wf_slot(ws, 3, s)->idx : NULL;
@@ -294,6 +375,7 @@ static int compute_next(oracle_ws_t* ws, int s, int plen, int tlen, int* err) {
     if (v > (uint32_t)plen) mv = OFFSET_NULL;
     om[k - lo] = mv;
   }
+  if (ef_required(ws, s)) ef_seed_computed(ws, wf_slot(ws, 0, s), s);
   for (c = 0; c < ws->ncomp; ++c) {
     wf_t* w = wf_slot(ws, c, s);
     if (w->exists) wf_trim(ws, w, plen, tlen);
@@ -575,6 +657,9 @@ static int align_one(oracle_ws_t* ws, const wfa_hip_config_t* cfg, const uint8_t
   const int64_t max_steps = (cfg->max_steps <= 0) ? INT_MAX : cfg->max_steps;
   const int wc = cfg->wildcard;
   int err = 0;
+  /* R/wavefront_compute.c:124-139 (wavefront_compute_endsfree_required, without its per-score test) */
+  ws->ef_pbf = cfg->pattern_begin_free; ws->ef_tbf = cfg->text_begin_free;
+  ws->ef_seed = (ws->match != 0 && endsfree && (ws->ef_pbf != 0 || ws->ef_tbf != 0));
   ws->modular = !full;
   ws->arena_used = 0;
   if (ws->modular) {
@@ -743,6 +828,7 @@ static int bi_uni_init(bi_uni_t* u, const bi_view_t* view, int comp_begin, int c
   u->null_steps = 0; u->status = BI_OK; u->status_score = 0; u->end_k = 0; u->end_off = OFFSET_NULL;
   ws->modular = modular;
   ws->arena_used = 0;
+  ws->ef_seed = 0;   /* (BiWFA has no free ends: R/wavefront_align.c:60-75) */
   if (modular) {
     ws->slot_stride = (int64_t)u->plen + u->tlen + 8;
     if (ws_reserve_scores(ws, ws->scope)) return -1;
@@ -1110,10 +1196,11 @@ int wfa_oracle_align_batch(const wfa_hip_config_t* cfg, int64_t n, const uint8_t
   oracle_ws_t ws;
   memset(&ws, 0, sizeof(ws));
   if (ws_set_penalties(&ws, cfg)) return -1;
-  /* match<0 with free begins needs the ends-free re-seeding of R/wavefront_compute.c:124-254
-   * ("next"): not restated here */
-  if (cfg->match < 0 && cfg->span == WFA_SPAN_ENDSFREE &&
-      (cfg->pattern_begin_free > 0 || cfg->text_begin_free > 0)) return -1;
+  /* match<0 with free begins (the ends-free re-seeding of R/wavefront_compute.c:124-254): score scope only.  With a backtrace
+   * the reference itself fails on ordinary inputs — exit(-1) "I?/D?-Beginning backtrace error" in memory mode high, an endless
+   * loop in medium / low (tests/test_oracle_vs_ref.py keeps the reproducers) — so there is nothing to restate. */
+  if (cfg->distance >= WFA_DIST_LINEAR && cfg->match < 0 && cfg->span == WFA_SPAN_ENDSFREE &&
+      (cfg->pattern_begin_free > 0 || cfg->text_begin_free > 0) && cfg->scope == WFA_SCOPE_FULL) return -1;
   /* BiWFA (R/wavefront_bialign.c): without heuristic, free ends (the reference exit(1)s, R/wavefront_align.c:60-75) or a
    * step limit.  scope=score: wavefront_bialign_compute_score (:662-702) returns what the other memory modes return
    * (pinned by tests/test_oracle_vs_ref.py); scope=full: the breakpoint recursion restated above. */

@@ -60,6 +60,7 @@ SYMBOLS = [
     "wfa_hip_plan_shards", "wfa_hip_multi_create", "wfa_hip_multi_destroy", "wfa_hip_multi_set_config",
     "wfa_hip_multi_last_error", "wfa_hip_multi_align_batch", "wfa_hip_pack_2bit", "wfa_hip_batch_extent",
     "wfa_hip_align_batch_packed2bits", "wfa_hip_batch_create_packed2bits", "wfa_hip_cigar_sprint_pretty",
+    "wfa_hip_batch_extent_packed2bits",
 ]
 
 
@@ -112,6 +113,8 @@ def lib():
     L.wfa_hip_pack_2bit.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_int]
     L.wfa_hip_batch_extent.argtypes = [i64, vp, vp, vp, vp]
     L.wfa_hip_batch_extent.restype = i64
+    L.wfa_hip_batch_extent_packed2bits.argtypes = [i64, vp, vp, vp, vp]
+    L.wfa_hip_batch_extent_packed2bits.restype = i64
     L.wfa_hip_multi_create.argtypes = [cfgp, vp, ctypes.c_int]
     L.wfa_hip_multi_create.restype = vp
     L.wfa_hip_multi_destroy.argtypes = [vp]
@@ -174,9 +177,9 @@ def _check_packed(batch):
     if not (p_off.shape[0] == t_off.shape[0] == t_len.shape[0] == n):
         raise ValueError("batch arrays differ in length")
     if n:
-        if min(p_off.min(), t_off.min(), p_len.min(), t_len.min()) < 0:
+        end = lib().wfa_hip_batch_extent_packed2bits(n, _ptr(p_off), _ptr(p_len), _ptr(t_off), _ptr(t_len))
+        if end < 0:
             raise ValueError("negative length or offset")
-        end = max(int((p_off + ((p_len.astype(np.int64) + 3) >> 2)).max()), int((t_off + ((t_len.astype(np.int64) + 3) >> 2)).max()))
         if end > packed.size:
             raise ValueError("sequence offsets run past the blob")
     return packed, p_off, p_len, t_off, t_len, n

@@ -331,6 +331,9 @@ wfa_general_kernel(const WfaKernelArgs a) {
     }
 
     int s = 0, null_steps = 0;
+    // match < 0 with free begins: the begin-free cells enter the M wavefront of score j * (-match) (R/wavefront_compute.c:124-254);
+    // score scope only (with a backtrace the reference fails on ordinary inputs: refused by wfa_hip_config_validate)
+    const bool ef_seed = !FULL && cfg.match != 0 && cfg.endsfree && (cfg.pbf != 0 || cfg.tbf != 0);
     int steps_wait = cfg.steps_between, have_max_sw = 0, max_sw = 0;
     int end_reason = overflow ? 3 : 0;  // 1 reached, 2 unreachable, 3 overflow, 4 max steps
     int end_k = 0, end_off = WFA_OFFSET_NULL;
@@ -471,9 +474,27 @@ wfa_general_kernel(const WfaKernelArgs a) {
           if (pb_used + (long long)(s + 2) * 12 > pb_cap) { end_reason = 3; break; }
           if (tid == 0) { int* d = ws + ws_stride - 3ll * (s + 1); d[0] = 1; d[1] = 0; d[2] = 0; }
         }
+        // a null step at a score that re-seeds the free begins (wavefront_compute_endsfree_allocate_null): M exists and holds
+        // the cell(s) (k = j, offset j) / (k = -j, offset 0), NULL in between.  (j beyond both free begins: the reference leaves
+        // lo = hi = 0 with offsets[0] unset, R/wavefront_compute.c:229-251; here the wavefront stays null)
+        int seed_lo = 1, seed_hi = -1;
+        if (!FULL && ef_seed && s % (-cfg.match) == 0) {
+          const int ek = s / (-cfg.match);
+          const bool tb = cfg.tbf >= ek, pb = cfg.pbf >= ek;
+          if (tb && pb) { seed_lo = -ek; seed_hi = ek; } else if (tb) { seed_lo = seed_hi = ek; } else if (pb) { seed_lo = seed_hi = -ek; }
+          if (seed_lo <= seed_hi) {
+            const int data = (s % scope) * NCOMP * rstride;
+            cur_exists = 1; cur_lo = seed_lo; cur_hi = seed_hi; cur_idx0 = data - rbase;
+            for (int k = seed_lo + tid; k <= seed_hi; k += T) ws[cur_idx0 + k] = (k == ek && tb) ? ek : ((k == -ek && pb) ? 0 : WFA_OFFSET_NULL);
+          }
+        }
         if (tid == 0) {
           for (int c = 0; c < NCOMP; ++c) { mslot[MT::LO + c] = 1; mslot[MT::HI + c] = -1; }
           mslot[MT::BASE] = 0; mslot[MT::WIDTH] = 0; mslot[MT::DATA] = 0; mslot[MT::EXISTS] = 0;
+          if (seed_lo <= seed_hi) {
+            mslot[MT::LO] = seed_lo; mslot[MT::HI] = seed_hi;
+            mslot[MT::BASE] = rbase; mslot[MT::WIDTH] = rstride; mslot[MT::DATA] = (s % scope) * NCOMP * rstride; mslot[MT::EXISTS] = 1;
+          }
         }
       } else {
         null_steps = 0;
@@ -581,6 +602,30 @@ wfa_general_kernel(const WfaKernelArgs a) {
           const bool has = (c == 0) || (c == 1 && has_i1) || (c == 2 && has_d1) ||
                            (NCOMP == 5 && c == 3 && has_i2) || (NCOMP == 5 && c == 4 && has_d2);
           if (has && mn != INT_MAX) { tlo[c] = mn; thi[c] = mxk; } else { tlo[c] = 1; thi[c] = -1; }
+        }
+        if (!FULL && ef_seed && s % (-cfg.match) == 0) {
+          // wavefront_compute_endsfree_init (R/wavefront_compute.c:171-213) on the computed range [lo, hi], before the trim: a
+          // begin-free cell replaces what compute-next put on its diagonal unless that is further along; a cell beyond the range
+          // extends it (NULL in between).  The cells are in bounds, so the trimmed range grows to hold them.
+          const int ek = s / (-cfg.match);
+          auto grow = [&](int k) { if (tlo[0] > thi[0]) { tlo[0] = k; thi[0] = k; } else { tlo[0] = min(tlo[0], k); thi[0] = max(thi[0], k); } };
+          if (cfg.tbf >= ek) {
+            if (hi >= ek) {
+              // (ek < lo: the reference compares with a cell outside the wavefront; whatever it writes stays outside)
+              if (ek >= lo && ws[o_m + ek] <= ek) { if (tid == 0) ws[o_m + ek] = ek; grow(ek); }
+            } else {
+              for (int k = hi + 1 + tid; k <= ek; k += T) ws[o_m + k] = (k == ek) ? ek : WFA_OFFSET_NULL;
+              grow(ek);
+            }
+          }
+          if (cfg.pbf >= ek) {
+            if (lo <= -ek) {
+              if (-ek <= hi && ws[o_m - ek] <= 0) { if (tid == 0) ws[o_m - ek] = 0; grow(-ek); }
+            } else {
+              for (int k = -ek + tid; k < lo; k += T) ws[o_m + k] = (k == -ek) ? 0 : WFA_OFFSET_NULL;
+              grow(-ek);
+            }
+          }
         }
         cur_exists = 1; cur_lo = tlo[0]; cur_hi = thi[0]; cur_idx0 = o_m;
         if (tid == 0) {

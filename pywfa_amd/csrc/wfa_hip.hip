@@ -308,8 +308,12 @@ extern "C" int wfa_hip_config_validate(const wfa_hip_config_t* c, char* err, siz
   }
   if (c->pattern_begin_free < 0 || c->pattern_end_free < 0 || c->text_begin_free < 0 || c->text_end_free < 0)
     return fail_cfg(err, errlen, WFA_HIP_EINVAL, "ends-free sizes must be >= 0");
-  if (c->distance >= WFA_DIST_LINEAR && c->match < 0 && c->span == WFA_SPAN_ENDSFREE && (c->pattern_begin_free > 0 || c->text_begin_free > 0))
-    return fail_cfg(err, errlen, WFA_HIP_ENOTSUP, "match<0 with free begins (ends-free re-seeding) is not on the accelerated path");
+  // match < 0 with free begins (the ends-free re-seeding of R/wavefront_compute.c:124-254): score scope.  With a backtrace the
+  // reference itself fails on ordinary inputs (exit(-1) "I?/D?-Beginning backtrace error" in memory mode high, an endless loop
+  // in medium / low; reproducers among the CPU tests), so scope=full has nothing to be equal to
+  if (c->distance >= WFA_DIST_LINEAR && c->match < 0 && c->span == WFA_SPAN_ENDSFREE && (c->pattern_begin_free > 0 || c->text_begin_free > 0) &&
+      c->scope == WFA_SCOPE_FULL)
+    return fail_cfg(err, errlen, WFA_HIP_ENOTSUP, "match<0 with free begins is built for scope=score (with a backtrace the reference itself exits or hangs)");
   if (c->wildcard < -1 || c->wildcard > 255) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "wildcard must be -1 or a byte");
   if (c->reserved != 0) return fail_cfg(err, errlen, WFA_HIP_EINVAL, "reserved must be 0");
   return WFA_HIP_OK;
@@ -2122,7 +2126,14 @@ extern "C" int wfa_hip_align_batch(wfa_hip_aligner_t* al, int64_t n, const uint8
   return rc;
 }
 
+static int64_t batch_extent(int64_t n, const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len, bool in2bit);
 extern "C" int64_t wfa_hip_batch_extent(int64_t n, const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len) {
+  return batch_extent(n, p_off, p_len, t_off, t_len, false);
+}
+extern "C" int64_t wfa_hip_batch_extent_packed2bits(int64_t n, const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len) {
+  return batch_extent(n, p_off, p_len, t_off, t_len, true);
+}
+static int64_t batch_extent(int64_t n, const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len, bool in2bit) {
   if (n < 0 || (n > 0 && (!p_off || !p_len || !t_off || !t_len))) return -1;
   const int team = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, std::thread::hardware_concurrency()), n / 262144));
   std::vector<int64_t> ends((size_t)team, 0);
@@ -2130,7 +2141,8 @@ extern "C" int64_t wfa_hip_batch_extent(int64_t n, const int64_t* p_off, const i
     int64_t e = 0;
     for (int64_t i = n * t / team, hi = n * (t + 1) / team; i < hi; ++i) {
       if (p_off[i] < 0 || t_off[i] < 0 || p_len[i] < 0 || t_len[i] < 0) { e = -1; break; }
-      e = std::max(e, std::max(p_off[i] + p_len[i], t_off[i] + t_len[i]));
+      e = in2bit ? std::max(e, std::max(p_off[i] + ((p_len[i] + 3) >> 2), t_off[i] + ((t_len[i] + 3) >> 2)))
+                 : std::max(e, std::max(p_off[i] + p_len[i], t_off[i] + t_len[i]));
     }
     ends[(size_t)t] = e;
   };

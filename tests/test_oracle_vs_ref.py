@@ -90,3 +90,58 @@ def test_biwfa_outside_the_built_subset_is_refused():
                dict(scope="score", span="ends-free", text_end_free=5), dict(scope="full", span="ends-free", pattern_begin_free=3)):
         with pytest.raises(Exception):
             loader.run(loader.oracle(), loader.make_config(**dict(kw, memory_mode="biwfa")), batch, want_cigar=False)
+
+
+# ---- match < 0 with free begins: the ends-free re-seeding (R/wavefront_compute.c:124-254), SURVEY §8 f3 --------------------
+# What can be pinned.  The reference leaves parts of a re-seeded wavefront unwritten: a null step whose begin-free cell exists
+# on one side only gets lo = hi = +-j with wf_elements_init_min = init_max = 0 (R/wavefront.c:107-108), so later reads of the
+# diagonals between 0 and j take whatever the slab held before — its scores then depend on the alignments the process ran
+# earlier (tools/ref_endsfree_repro.py shows one pair scoring 72 alone and 73 after other pairs).  With pattern_begin_free ==
+# text_begin_free both cells exist at every re-seeded null step, everything in between is written, and the library is
+# deterministic: those rows are pinned here, in score scope (with a backtrace it exits or hangs, below).
+EF_SEED = [dict(distance=d, match=m, mismatch=x, gap_opening=o, gap_extension=e, pattern_begin_free=f, text_begin_free=f,
+                pattern_end_free=pe, text_end_free=te, heuristic=h)
+           for d in ("affine", "affine2p", "linear")
+           for (m, x, o, e) in ((-1, 3, 6, 2), (-2, 4, 6, 2), (-1, 4, 6, 2), (-3, 2, 1, 1))
+           for (f, pe, te) in ((9, 7, 2), (12, 0, 0), (30, 5, 5))
+           for h in (None, "adaptive")]
+
+
+@pytest.mark.parametrize("cfg_idx", range(len(EF_SEED)))
+def test_endsfree_reseeding_equals_reference_where_it_is_defined(cfg_idx):
+    import validate_oracle as vo
+    kw = dict(EF_SEED[cfg_idx], span="ends-free", scope="score")
+    for batch in (datagen.generate(300, 150, 0.06, 4100 + cfg_idx), datagen.generate(12, 1000, 0.08, 4200 + cfg_idx), vo.corpus_special(seed=40 + cfg_idx)):
+        kw2 = common.clamp_free(kw, batch)
+        if kw2["pattern_begin_free"] != kw2["text_begin_free"]:
+            kw2["pattern_begin_free"] = kw2["text_begin_free"] = min(kw2["pattern_begin_free"], kw2["text_begin_free"])
+        cfg = loader.make_config(**kw2)
+        loader.oracle_undefined_reads(True)
+        o = loader.run(loader.oracle(), cfg, batch, want_cigar=False)
+        if loader.oracle_undefined_reads():
+            continue   # (free begins shorter than the first mismatch score: the reference's unset offsets[0], see the oracle)
+        r = loader.run(loader.reference(), cfg, batch, want_cigar=False)
+        assert np.array_equal(r["score"], o["score"]) and np.array_equal(r["status"], o["status"]), kw2
+
+
+def test_reference_fails_with_a_backtrace_under_match_lt_0_and_free_begins():
+    """Why scope=full is refused for match < 0 with free begins: on an ordinary 150 bp batch the real library exit(-1)s with
+    "I?/D?-Beginning backtrace error" in memory mode high and does not return in memory mode medium (run in a child)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, {root!r})\n"
+            "from oracle import loader\nfrom pywfa_amd import datagen\n"
+            "cfg = loader.make_config(distance='affine', match=-1, mismatch=3, span='ends-free', pattern_begin_free=8, pattern_end_free=7,"
+            " text_begin_free=3, text_end_free=2, scope='full', memory_mode={mem!r})\n"
+            "loader.run(loader.reference(), cfg, datagen.generate(1500, 150, 0.06, 77))\nprint('survived')\n")
+    import os
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    p = subprocess.run([sys.executable, "-c", code.format(root=root, mem="high")], capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "backtrace error" in p.stderr and "survived" not in p.stdout
+    try:
+        p = subprocess.run([sys.executable, "-c", code.format(root=root, mem="medium")], capture_output=True, text=True, timeout=20)
+        assert "survived" not in p.stdout   # (should it ever return, it has not produced a usable result)
+    except subprocess.TimeoutExpired:
+        pass
+    with pytest.raises(Exception):   # the oracle refuses the configuration instead
+        loader.run(loader.oracle(), loader.make_config(match=-1, pattern_begin_free=3, scope="full"), datagen.generate(2, 50, 0.05, 1))

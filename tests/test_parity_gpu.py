@@ -59,6 +59,14 @@ GRID += [
     dict(distance="linear"), dict(distance="linear", mismatch=3, gap_extension=5, span="end-to-end"),
     dict(distance="linear", heuristic="X-drop", xdrop=100), dict(distance="linear", match=-1, span="end-to-end"),
     dict(distance="linear", max_steps=12, scope="score"), dict(distance="indel", heuristic="adaptive", scope="score"),
+    # match < 0 with free begins: the ends-free re-seeding (R/wavefront_compute.c:124-254), score scope.  Equal free begins: the
+    # rows the oracle is pinned on against the real library (tests/test_oracle_vs_ref.py); unequal: the reference reads cells it
+    # never wrote there (tools/ref_endsfree_repro.py), the oracle's NULL reading is what is compared
+    dict(distance="affine", match=-1, mismatch=3, span="ends-free", pattern_begin_free=9, pattern_end_free=7, text_begin_free=9, text_end_free=2, scope="score"),
+    dict(distance="affine2p", match=-2, span="ends-free", pattern_begin_free=12, text_begin_free=12, scope="score", heuristic="adaptive"),
+    dict(distance="linear", match=-1, mismatch=3, gap_extension=2, span="ends-free", pattern_begin_free=9, text_begin_free=9, pattern_end_free=3, scope="score"),
+    dict(distance="affine", match=-1, span="ends-free", pattern_begin_free=8, pattern_end_free=7, text_begin_free=3, text_end_free=2, scope="score"),
+    dict(distance="affine2p", match=-1, mismatch=3, span="ends-free", pattern_begin_free=20, text_end_free=9, scope="score", heuristic="X-drop", xdrop=100),
 ]
 
 SHAPES = {"150bp_2pct": (1500, 150, 0.02), "150bp_15pct": (400, 150, 0.15), "1kb_8pct": (60, 1000, 0.08)}
@@ -120,6 +128,24 @@ def test_ragged_and_empty_batches(gpu):
     common.assert_same(o, score, status, cigars, ragged, "ragged")
     assert common.rle(cigars[0]) == "4I" and score[0] == -14   # empty pattern
     al.close()
+
+
+def test_match_lt_0_with_free_begins_and_a_backtrace_is_refused(gpu):
+    """With a backtrace the reference itself exits or hangs on this configuration (tests/test_oracle_vs_ref.py): NotImplementedError."""
+    from pywfa_amd import _native
+    c = _native.default_config()
+    c.match, c.pattern_begin_free = -1, 4
+    assert _native.validate(c)[0] == _native.ENOTSUP
+    c.scope = 0
+    assert _native.validate(c)[0] == _native.OK
+    import pywfa_amd
+    with pytest.raises(NotImplementedError):
+        pywfa_amd.WavefrontAligner("ACGT", match=-1, pattern_begin_free=2)
+    a = pywfa_amd.WavefrontAligner("ACGTTTGACA", match=-1, mismatch=3, pattern_begin_free=3, text_begin_free=3, scope="score")
+    cfg = loader.make_config(match=-1, mismatch=3, pattern_begin_free=3, text_begin_free=3, scope="score")
+    o = loader.run(loader.oracle(), cfg, datagen.from_strings(["ACGTTTGACA"], ["TTACGTTAGACA"]), want_cigar=False)
+    assert a.wavefront_align("TTACGTTAGACA") == int(o["score"][0])
+    a.close()
 
 
 def test_ends_free_larger_than_sequence_is_an_error(gpu):
