@@ -55,7 +55,7 @@ extern "C" {
 #define WFA_MEM_HIGH       0   /* wavefront_memory_high (explicit wavefront history)  */
 #define WFA_MEM_MED        1   /* wavefront_memory_med  (same results as high)        */
 #define WFA_MEM_LOW        2   /* wavefront_memory_low  (same results as high)        */
-#define WFA_MEM_BIWFA      3   /* wavefront_memory_ultralow (BiWFA, wavefront_bialign.c) — without heuristic / free ends / max_steps */
+#define WFA_MEM_BIWFA      3   /* wavefront_memory_ultralow (BiWFA, wavefront_bialign.c) — without heuristic / free ends */
 
 /* per-pair status codes, identical to the reference (wfa.h:46-51) */
 #define WFA_STATUS_COMPLETED          0

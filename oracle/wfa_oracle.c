@@ -1134,6 +1134,25 @@ static int bi_align_one(bi_ctx_t* cx, const wfa_hip_config_t* cfg, const uint8_t
 }
 
 /* R/wavefront_penalties.c:95-173 */
+/* R/wavefront_bialign.c:662-702 (wavefront_bialign_compute_score) + the status translation of :703-730: the top-level
+ * breakpoint search alone.  OK or END_REACHED (one direction crossed the whole matrix before any overlap): completed with
+ * the breakpoint's / the reached score; anything else leaves the score at cigar_clear's INT32_MIN. */
+static int bi_score_one(bi_ctx_t* cx, const uint8_t* P, int plen, const uint8_t* T, int tlen, int32_t* out_score, int32_t* out_status) {
+  cx->P = P; cx->T = T;
+  bi_breakpoint_t bp;
+  const int st = bi_find_breakpoint(cx, 0, plen, 0, tlen, 0, 0, &bp);
+  if (st == WFA_STATUS_OOM) return -1;
+  if (st == BI_OK || st == BI_END_REACHED) {
+    const int sc = (st == BI_OK) ? bp.score : ((cx->fwd.status == BI_END_REACHED) ? cx->fwd.status_score : cx->rev.status_score);
+    *out_score = classic_score(&cx->fwd.ws, plen, tlen, sc);
+    *out_status = WFA_STATUS_COMPLETED;
+  } else {
+    *out_score = INT32_MIN;
+    *out_status = (st == WFA_STATUS_MAX_STEPS_REACHED) ? WFA_STATUS_MAX_STEPS_REACHED : -300;
+  }
+  return 0;
+}
+
 static int ws_set_penalties(oracle_ws_t* ws, const wfa_hip_config_t* cfg) {
   ws->metric = cfg->distance;
   if (cfg->distance == WFA_DIST_INDEL || cfg->distance == WFA_DIST_EDIT) {
@@ -1204,19 +1223,22 @@ int wfa_oracle_align_batch(const wfa_hip_config_t* cfg, int64_t n, const uint8_t
   /* BiWFA (R/wavefront_bialign.c): without heuristic, free ends (the reference exit(1)s, R/wavefront_align.c:60-75) or a
    * step limit.  scope=score: wavefront_bialign_compute_score (:662-702) returns what the other memory modes return
    * (pinned by tests/test_oracle_vs_ref.py); scope=full: the breakpoint recursion restated above. */
-  int biwfa_full = 0;
+  int biwfa_full = 0, biwfa_score = 0;
   bi_ctx_t* bcx = NULL;
   if (cfg->memory_mode == WFA_MEM_BIWFA) {
     const int free_ends = cfg->span == WFA_SPAN_ENDSFREE &&
         (cfg->pattern_begin_free | cfg->pattern_end_free | cfg->text_begin_free | cfg->text_end_free) != 0;
-    if (cfg->heuristic != WFA_HEUR_NONE || free_ends || cfg->max_steps > 0) return -1;
-    if (cfg->scope == WFA_SCOPE_FULL) {
-      biwfa_full = 1;
+    if (cfg->heuristic != WFA_HEUR_NONE || free_ends) return -1;
+    /* scope=score with a step limit: the limit counts the forward + reverse scores (R/wavefront_bialign.c:475,513), which is
+     * not what the ordinary algorithm counts: the top-level breakpoint search is run as it is (:662-702) */
+    if (cfg->scope == WFA_SCOPE_FULL || cfg->max_steps > 0) {
+      biwfa_full = (cfg->scope == WFA_SCOPE_FULL);
+      biwfa_score = !biwfa_full;
       bcx = (bi_ctx_t*)calloc(1, sizeof(bi_ctx_t));
       if (!bcx) return -2;
       if (ws_set_penalties(&bcx->fwd.ws, cfg) || ws_set_penalties(&bcx->rev.ws, cfg) || ws_set_penalties(&bcx->base.ws, cfg)) { free(bcx); return -1; }
       bcx->wc = cfg->wildcard;
-      bcx->max_steps = INT_MAX;
+      bcx->max_steps = (cfg->max_steps <= 0) ? INT_MAX : cfg->max_steps;   /* align.pyx:415-417 -> R/wavefront_bialigner.c:168-174 */
     }
   }
   const int full = (cfg->scope == WFA_SCOPE_FULL);
@@ -1233,6 +1255,8 @@ int wfa_oracle_align_batch(const wfa_hip_config_t* cfg, int64_t n, const uint8_t
     int32_t sc = 0, st = 0;
     if (biwfa_full) {
       if (bi_align_one(bcx, cfg, seqs + p_off[i], plen, seqs + t_off[i], tlen, &sc, &st, cigar_ops + cigar_off[i], &ob, &ol)) { rc = -2; break; }
+    } else if (biwfa_score) {
+      if (bi_score_one(bcx, seqs + p_off[i], plen, seqs + t_off[i], tlen, &sc, &st)) { rc = -2; break; }
     } else if (align_one(&ws, cfg, seqs + p_off[i], plen, seqs + t_off[i], tlen, &sc, &st,
                          full ? cigar_ops + cigar_off[i] : NULL, &ob, &ol)) { rc = -2; break; }
     score[i] = sc;

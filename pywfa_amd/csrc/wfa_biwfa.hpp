@@ -45,6 +45,7 @@ struct BiwfaArgs {
   int64_t base_ints;   // ints of the base-case history
   int ring_stride;     // plen + tlen + 3 of the longest pair of the launch
   int base_stride;     // diagonals a base-case wavefront can span (2 x 501 + 3, or less for short reads)
+  int score_only;      // scope=score with a step limit: the top-level breakpoint search alone (R/wavefront_bialign.c:662-702)
 };
 
 // a window of the two sequences, read forwards or backwards (R/wavefront_sequences.c:275-310)
@@ -455,9 +456,10 @@ wfa_biwfa_kernel(const BiwfaArgs a) {
     view.wildcard = cfg.wildcard;
     if (PACKED) { view.pw = a.k.words + pm.p_woff; view.tw = a.k.words + pm.t_woff; view.pb = nullptr; view.tb = nullptr; }
     else { view.pb = a.k.bytes + a.k.p_boff[pair]; view.tb = a.k.bytes + a.k.t_boff[pair]; view.pw = nullptr; view.tw = nullptr; }
-    uint8_t* const out = a.k.cigar_ops + a.k.cigar_off[pair];
+    uint8_t* const out = a.score_only ? nullptr : a.k.cigar_ops + a.k.cigar_off[pair];
     long long out_len = 0;
     int status = 0, top_score = INT_MIN;   // INT_MIN: no top-level split (the score stays unset, Q6)
+    bool hand_on = false;                  // the top-level base case outgrew its history: the general kernel takes the pair
     BiSide<NCOMP> F, R, B;
     F.ring = ring_f; F.ws = wsb; F.dir = nullptr; F.stride = a.ring_stride; F.slots = scope;
     R.ring = ring_r; R.ws = wsb + a.ring_ints; R.dir = nullptr; R.stride = a.ring_stride; R.slots = scope;
@@ -471,7 +473,7 @@ wfa_biwfa_kernel(const BiwfaArgs a) {
       int* w = stack;
       w[0] = 0; w[1] = pm.plen; w[2] = 0; w[3] = pm.tlen;
       w[4] = 0 | (0 << 4) | (1 << 8) | ((cfg.endsfree ? 1 : 0) << 9);
-      w[5] = (max(pm.plen, pm.tlen) <= WFA_BI_FALLBACK_MIN_LENGTH) ? 0 : INT_MAX;
+      w[5] = (!a.score_only && max(pm.plen, pm.tlen) <= WFA_BI_FALLBACK_MIN_LENGTH) ? 0 : INT_MAX;
     }
     sp = 1;
     __syncthreads();
@@ -483,8 +485,10 @@ wfa_biwfa_kernel(const BiwfaArgs a) {
       const bool level0 = (flags >> 8) & 1, ef_form = (flags >> 9) & 1;
       const int plen = pend - pbeg, tlen = tend - tbeg;
       __syncthreads();   // the window has been read: its stack slot may be reused
-      if (tlen == 0) { for (int i = lane; i < plen; i += 64) out[out_len + i] = 'D'; out_len += plen; continue; }
-      if (plen == 0) { for (int i = lane; i < tlen; i += 64) out[out_len + i] = 'I'; out_len += tlen; continue; }
+      if (!a.score_only) {   // (the score-only form runs the breakpoint search whatever the lengths, :662-702)
+        if (tlen == 0) { for (int i = lane; i < plen; i += 64) out[out_len + i] = 'D'; out_len += plen; continue; }
+        if (plen == 0) { for (int i = lane; i < tlen; i += 64) out[out_len + i] = 'I'; out_len += tlen; continue; }
+      }
       view.pbeg = pbeg; view.pend = pend; view.tbeg = tbeg; view.tend = tend;
       bool do_base = score_remaining <= WFA_BI_FALLBACK_MIN_SCORE;
       BiBreakpoint bp;
@@ -553,6 +557,14 @@ wfa_biwfa_kernel(const BiwfaArgs a) {
             last_forward = true;
           }
         }
+        if (a.score_only) {
+          // R/wavefront_bialign.c:683-701: a breakpoint, or an end reached before any overlap, is a completed alignment with
+          // that score; anything else leaves the score unset
+          if (!quit) top_score = bp.score;
+          else if (st == WFA_BI_END_REACHED) top_score = reached;
+          else status = (st == WFA_STATUS_MAX_STEPS_REACHED) ? WFA_STATUS_MAX_STEPS_REACHED : WFA_STATUS_UNATTAINABLE;
+          break;
+        }
         if (quit) {
           // R/wavefront_bialign.c:520-548 (wavefront_bialign_find_breakpoint_exception)
           if (st == WFA_BI_END_REACHED && reached <= WFA_BI_RECOVERY_MIN_SCORE) do_base = true;
@@ -580,9 +592,13 @@ wfa_biwfa_kernel(const BiwfaArgs a) {
             if (bi_side_terminated<NCOMP>(B, scope, s, comp_end, plen, tlen)) { reached_end = true; end_k = tlen - plen; end_off = tlen; break; }
           }
           ++s;
-          if (s >= WFA_BI_BASE_SLOTS - 1 || s >= max_steps) { fail = true; break; }
-          if (!bi_side_compute<NCOMP>(B, cfg, scope, s, plen, tlen, lane)) { fail = true; break; }
+          if (s >= max_steps) { fail = true; break; }   // the base aligner's own limit: not "completed" (R/wavefront_bialign.c:182-187)
+          // A window handed to the base case scores <= 250 (or <= 500 after an early end): only the top-level base case of
+          // reads <= 100 bases has no bound (divergent pairs under large penalties).  Such a pair goes to the general kernel.
+          if (s >= WFA_BI_BASE_SLOTS - 1) { hand_on = true; break; }
+          if (!bi_side_compute<NCOMP>(B, cfg, scope, s, plen, tlen, lane)) { hand_on = true; break; }
         }
+        if (hand_on) break;
         if (fail || !reached_end) { status = WFA_STATUS_UNATTAINABLE; break; }
         // backtrace right to left into the free tail of the pair's region, then move it down to out_len
         __syncthreads();
@@ -621,15 +637,22 @@ wfa_biwfa_kernel(const BiwfaArgs a) {
     }
     if (lane == 0) {
       int out_score = INT_MIN, out_status = status;
-      if (status == 0) {
+      if (hand_on && a.k.fb_list) {
+        out_status = WFA_INTERNAL_FALLBACK; out_len = 0;
+        a.k.fb_list[atomicAdd(a.k.fb_count, 1u)] = pair;
+      } else if (hand_on) {
+        out_status = WFA_STATUS_UNATTAINABLE; out_len = 0;
+      } else if (status == 0) {
         if (top_score != INT_MIN) out_score = classic_score(cfg, pm.plen, pm.tlen, top_score);
-      } else {
+      } else if (status == WFA_STATUS_OOM) {
         out_len = 0;
-      }
+      }   // (step limit / unattainable: the ops appended so far stay, as in the reference's cigar)
       a.k.score[pair] = out_score;
       a.k.status[pair] = out_status;
-      a.k.cigar_begin[pair] = a.k.cigar_off[pair];
-      a.k.cigar_len[pair] = (int)out_len;
+      if (!a.score_only) {
+        a.k.cigar_begin[pair] = a.k.cigar_off[pair];
+        a.k.cigar_len[pair] = (int)out_len;
+      }
     }
     __syncthreads();
   }

@@ -34,6 +34,9 @@ struct WfaDevConfig {
   int32_t min_wf_len, max_dist_thr, steps_between, xdrop;
   int32_t max_steps;           // INT32_MAX = unlimited
   int32_t wildcard;            // -1 none
+  int32_t biwfa_top;           // 1: the general kernel stands in for the top-level base case of BiWFA (reads of <= 100 bases whose
+                               // score outgrows the BiWFA kernel's base-case history): a completed pair keeps the unset score
+                               // (SURVEY Q6), every other ending is "unattainable" (R/wavefront_bialign.c:182-187,725-729)
 };
 
 // Arguments of the alignment kernels (passed by value).

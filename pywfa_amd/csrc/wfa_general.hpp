@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include "wfa_common.hpp"
+#include "wfa_hip.h"
 
 namespace wfa {
 
@@ -725,6 +726,12 @@ wfa_general_kernel(const WfaKernelArgs a) {
         } else {
           out_score = INT_MIN; out_status = 1;  // empty CIGAR after maxtrim (R/alignment/cigar.c:473-613)
         }
+      }
+      if (FULL && cfg.biwfa_top && out_status != WFA_INTERNAL_OVERFLOW) {
+        // standing in for BiWFA's top-level base case: the score is never written there, and whatever is not a completed
+        // alignment (step limit, unreachable) comes back as "unattainable" with no ops
+        out_score = INT_MIN;
+        if (out_status != 0) { out_status = WFA_STATUS_UNATTAINABLE; cbeg = a.cigar_off[pair]; clen = 0; }
       }
       a.score[pair] = out_score;
       a.status[pair] = out_status;

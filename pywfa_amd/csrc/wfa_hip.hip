@@ -298,13 +298,14 @@ extern "C" int wfa_hip_config_validate(const wfa_hip_config_t* c, char* err, siz
   if (c->memory_mode == WFA_MEM_BIWFA) {
     // BiWFA (R/wavefront_bialign.c).  scope=score: wavefront_bialign_compute_score (:662-702) returns the score of the optimal
     // alignment, which is what the other memory modes return (checked on every metric against the real library,
-    // the CPU checkers under tests/), and the score-only kernels hold O(s) state already.  scope=full: the breakpoint
-    // recursion on the device (csrc/wfa_biwfa.hpp).  Not built: BiWFA with a heuristic or a step limit (the reference runs
+    // the CPU checkers under tests/), and the score-only kernels hold O(s) state already; with a step limit (counted over the
+    // forward + reverse scores, :475,513) the top-level breakpoint search itself runs on the device.  scope=full: the breakpoint
+    // recursion on the device (csrc/wfa_biwfa.hpp), step limit included.  Not built: BiWFA with a heuristic (the reference runs
     // the cut-off inside both directions), and with free ends (the reference itself exit(1)s, R/wavefront_align.c:60-75).
     const bool free_ends = c->span == WFA_SPAN_ENDSFREE &&
                            (c->pattern_begin_free | c->pattern_end_free | c->text_begin_free | c->text_end_free) != 0;
-    if (c->heuristic != WFA_HEUR_NONE || free_ends || c->max_steps > 0)
-      return fail_cfg(err, errlen, WFA_HIP_ENOTSUP, "memory_mode biwfa is on the accelerated path without heuristic, free ends or max_steps only");
+    if (c->heuristic != WFA_HEUR_NONE || free_ends)
+      return fail_cfg(err, errlen, WFA_HIP_ENOTSUP, "memory_mode biwfa is on the accelerated path without heuristic or free ends only");
   }
   if (c->pattern_begin_free < 0 || c->pattern_end_free < 0 || c->text_begin_free < 0 || c->text_end_free < 0)
     return fail_cfg(err, errlen, WFA_HIP_EINVAL, "ends-free sizes must be >= 0");
@@ -339,6 +340,7 @@ static void derive_dev_config(const wfa_hip_config_t& c, WfaDevConfig* d, int* n
     d->steps_between = c.steps_between_cutoffs; d->xdrop = c.xdrop;
     d->max_steps = (c.max_steps <= 0) ? INT_MAX : c.max_steps;
     d->wildcard = c.wildcard;
+    d->biwfa_top = 0;
     return;
   }
   *ncomp = two ? 5 : 3;
@@ -366,6 +368,7 @@ static void derive_dev_config(const wfa_hip_config_t& c, WfaDevConfig* d, int* n
   d->steps_between = c.steps_between_cutoffs; d->xdrop = c.xdrop;
   d->max_steps = (c.max_steps <= 0) ? INT_MAX : c.max_steps;  // align.pyx:415-417
   d->wildcard = c.wildcard;
+  d->biwfa_top = 0;
 }
 
 extern "C" wfa_hip_aligner_t* wfa_hip_create(const wfa_hip_config_t* cfg, int device) {
@@ -1228,32 +1231,46 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
   hipEvent_t ev0 = b->ev[b->ev_used], ev1 = b->ev[b->ev_used + 1];
   b->ev_used += 2; b->runs_pending += 1;
   HIP_TRY(al, hipEventRecord(ev0, stream));
-  if (full && b->cfg.memory_mode == WFA_MEM_BIWFA) {
-    // BiWFA: one wave per alignment; a workgroup's slice of the workspace = forward ring + reverse ring + base-case history
+  const bool biwfa_score = !full && b->cfg.memory_mode == WFA_MEM_BIWFA && b->cfg.max_steps > 0;
+  if ((full && b->cfg.memory_mode == WFA_MEM_BIWFA) || biwfa_score) {
+    // BiWFA: one wave per alignment; a workgroup's slice of the workspace = forward ring + reverse ring + base-case history.
+    // (scope=score with a step limit: the top-level breakpoint search alone, no base-case history)
     wfa::BiwfaArgs ba;
     memset(&ba, 0, sizeof(ba));
+    ba.score_only = biwfa_score ? 1 : 0;
     ba.ring_stride = b->max_width;
     ba.ring_ints = ((int64_t)b->dcfg.scope * b->ncomp * ba.ring_stride + 63) & ~63ll;
     ba.base_stride = wfa::biwfa_base_stride(b->max_width);
-    ba.base_ints = (wfa::biwfa_base_ints(b->ncomp, ba.base_stride) + 63) & ~63ll;
+    ba.base_ints = biwfa_score ? 0 : ((wfa::biwfa_base_ints(b->ncomp, ba.base_stride) + 63) & ~63ll);
     const int64_t stride = 2 * ba.ring_ints + ba.base_ints;
     int64_t grid = std::min<int64_t>((int64_t)al->cu_count * knob(al, K_WAVES_PER_CU, 32), std::max<int64_t>(b->n, 1));
     const int64_t budget = free_budget(al);
     while (grid > 1 && grid * stride * 4 > budget) grid = (grid + 1) / 2;
-    int rc = ensure_ws(al, (size_t)grid * stride * 4);
+    // the general kernel behind it (full scope): pairs whose top-level base case outgrew the BiWFA kernel's history
+    // (reads of <= 100 bases under large penalties) are aligned by the ordinary algorithm, which is what that base case is
+    b->dcfg.biwfa_top = full ? 1 : 0;
+    Geometry g = plan_general(al, b, (uint32_t)std::min<int64_t>(b->n, (int64_t)al->cu_count * 16), b->arena_fixed + b->arena_ints);
+    int rc = ensure_ws(al, std::max((size_t)grid * stride * 4, full ? (size_t)g.grid * g.ws_stride * 4 : (size_t)0));
     if (rc != WFA_HIP_OK) return rc;
     WfaKernelArgs& a = ba.k;
     a.words = b->d_words; a.bytes = b->d_bytes; a.meta = b->d_meta; a.p_boff = b->d_pboff; a.t_boff = b->d_tboff;
     a.score = b->d_score; a.status = b->d_status;
     a.cigar_ops = b->d_ops; a.cigar_off = b->d_cigar_off; a.cigar_begin = b->d_cigar_begin; a.cigar_len = b->d_cigar_len;
     a.ws = al->ws; a.ws_stride = stride; a.cfg = b->dcfg;
-    if (b->n_packed > 0) {
-      a.worklist = b->d_list_packed; a.nwork_dev = nullptr; a.nwork = b->n_packed;
-      if (wfa::launch_biwfa_any(b->ncomp, true, ba, (int)std::min<int64_t>(grid, b->n_packed), stream) != 0) { al->err = "BiWFA kernel launch failed"; return WFA_HIP_EDEVICE; }
+    for (int kind = 0; kind < 2; ++kind) {   // 2-bit pairs, then the pairs aligned on their bytes
+      const uint32_t cnt = kind ? b->n_bytes : b->n_packed;
+      if (cnt == 0) continue;
+      a.worklist = kind ? b->d_list_bytes : b->d_list_packed; a.nwork_dev = nullptr; a.nwork = cnt;
+      a.fb_list = full ? b->d_fb_list2[kind] : nullptr; a.fb_count = b->d_counters + 4 + kind;
+      if (wfa::launch_biwfa_any(b->ncomp, kind == 0, ba, (int)std::min<int64_t>(grid, cnt), stream) != 0) { al->err = "BiWFA kernel launch failed"; return WFA_HIP_EDEVICE; }
     }
-    if (b->n_bytes > 0) {
-      a.worklist = b->d_list_bytes; a.nwork_dev = nullptr; a.nwork = b->n_bytes;
-      if (wfa::launch_biwfa_any(b->ncomp, false, ba, (int)std::min<int64_t>(grid, b->n_bytes), stream) != 0) { al->err = "BiWFA kernel launch failed"; return WFA_HIP_EDEVICE; }
+    if (full) {
+      for (int kind = 0; kind < 2; ++kind) {
+        if ((kind ? b->n_bytes : b->n_packed) == 0) continue;
+        rc = launch_general_dyn(al, b, stream, kind == 0, b->d_fb_list2[kind], b->d_counters + 4 + kind, 0u, g.ws_stride, g.grid, g.threads,
+                                b->d_ovf_list[0], b->d_counters + 1);
+        if (rc != WFA_HIP_OK) return rc;
+      }
     }
     b->last_kernel_pairs = b->n;
     HIP_TRY(al, hipEventRecord(ev1, stream));
@@ -1906,7 +1923,7 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
   const wfa_hip_config_t& c = al->cfg;
   const bool full = c.scope == WFA_SCOPE_FULL;
   if (n < 1 || n > TINY_MAX_PAIRS_BAND || knob(al, K_NO_TINY, 0)) return 0;
-  if (full && c.memory_mode == WFA_MEM_BIWFA) return 0;
+  if (c.memory_mode == WFA_MEM_BIWFA && (full || c.max_steps > 0)) return 0;   // (the BiWFA kernel: the batch path)
   if (!score || !status || (full && cigar_ops && (!cigar_off || !cigar_begin || !cigar_len))) return 0;
   int64_t blob = 0, ops_total = 0;
   int max_len = 0, max_width = 0;

@@ -52,12 +52,16 @@ def test_validate_rejects(field, value, code):
 
 
 def test_validate_biwfa():
-    """memory_mode biwfa (full CIGAR included) is on the accelerated path without heuristic, free ends or max_steps; the
-    rest is refused with ENOTSUP (the reference itself exit(1)s on free ends, wavefront_align.c:60-75)."""
+    """memory_mode biwfa (full CIGAR and step limit included) is on the accelerated path without heuristic or free ends; those
+    are refused with ENOTSUP (the reference itself exit(1)s on free ends, wavefront_align.c:60-75)."""
     c = _native.default_config()
     c.memory_mode = 3
     assert _native.validate(c)[0] == _native.OK
-    for field, value in (("heuristic", 1), ("max_steps", 50), ("text_end_free", 4)):
+    c.max_steps = 50
+    assert _native.validate(c)[0] == _native.OK
+    c.scope = 0
+    assert _native.validate(c)[0] == _native.OK
+    for field, value in (("heuristic", 1), ("text_end_free", 4)):
         c = _native.default_config()
         c.memory_mode = 3
         setattr(c, field, value)

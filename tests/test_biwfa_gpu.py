@@ -60,9 +60,14 @@ def test_biwfa_python_surface(gpu):
     h = pywfa_amd.WavefrontAligner(p, span="end-to-end")
     assert a.wavefront_align(t) == h.wavefront_align(t)
     assert a.status == 0 and a.cigarstring == h.cigarstring or len(a.cigarstring) > 0
-    for kw in (dict(heuristic="adaptive"), dict(max_steps=100), dict(span="ends-free", text_end_free=3)):
+    for kw in (dict(heuristic="adaptive"), dict(span="ends-free", text_end_free=3)):
         with pytest.raises(NotImplementedError):
             pywfa_amd.WavefrontAligner(p, memory_mode="biwfa", **kw)
+    # a step limit below the score: -100 and the unset score, in both scopes (R/wavefront_bialign.c:475,513,725)
+    for scope in ("full", "score"):
+        b = pywfa_amd.WavefrontAligner(p, memory_mode="biwfa", span="end-to-end", max_steps=30, scope=scope)
+        assert b.wavefront_align(t) == -2147483648 and b.status == -100 and b.cigarstring == ""
+        b.close()
 
 
 BIWFA_GOLD = common.load_golden("biwfa.json")
@@ -75,7 +80,40 @@ def test_biwfa_matches_golden_vectors(gpu, run_idx):
     pairs = BIWFA_GOLD["corpora"][run["corpus"]]
     batch = datagen.from_strings([p for p, _ in pairs], [t for _, t in pairs])
     _, nc = common.configs_pair(**run["config"])
-    score, status, cigars = common.gpu_run(nc, batch, True, resident=(run_idx % 2 == 0))
+    full = run["config"]["scope"] == "full"
+    score, status, cigars = common.gpu_run(nc, batch, full, resident=(run_idx % 2 == 0))
     assert score.tolist() == run["score"]
     assert status.tolist() == run["status"]
-    assert [common.rle(c) for c in cigars] == run["cigar"]
+    if full:
+        assert [common.rle(c) for c in cigars] == run["cigar"]
+
+
+@pytest.mark.parametrize("kw", [dict(match=-1, span="end-to-end"), dict(mismatch=6, gap_opening=2, gap_extension=3), dict(distance="affine2p", match=-2),
+                                dict(match=-1, max_steps=600), dict(distance="linear", match=-1, mismatch=5, gap_extension=4)])
+def test_biwfa_short_divergent_reads_under_large_penalties(gpu, kw):
+    """the top-level base case of reads <= 100 bases has no score bound (two unrelated 100-mers under match=-1 score
+    ~1000): what outgrows the BiWFA kernel's base-case history is aligned by the general kernel — same op strings, the unset
+    score, and "unattainable" where the base aligner's own step limit strikes."""
+    rng = np.random.default_rng(5)
+    pats = ["".join(rng.choice(list("ACGT"), size=int(rng.integers(40, 101)))) for _ in range(400)]
+    txts = ["".join(rng.choice(list("ACGT"), size=int(rng.integers(40, 101)))) for _ in range(400)]
+    batch = datagen.from_strings(pats + ["ACGT" * 20, ""], txts + ["ACGT" * 20, "ACGTACGT"])
+    oc, nc = common.configs_pair(**dict(kw, scope="full", memory_mode="biwfa"))
+    o = loader.run(loader.oracle(), oc, batch)
+    for resident in (True, False):
+        score, status, cigars = common.gpu_run(nc, batch, True, resident=resident)
+        common.assert_same(o, score, status, cigars, batch, f"biwfa short divergent {kw}")
+
+
+@pytest.mark.parametrize("kw0", [dict(span="end-to-end"), dict(distance="affine2p"), dict(distance="levenshtein", span="end-to-end"), dict(match=-1, span="end-to-end")])
+@pytest.mark.parametrize("scope", ["full", "score"])
+def test_biwfa_step_limit_matches_oracle(gpu, kw0, scope):
+    import validate_oracle as vo
+    corpora = [datagen.generate(500, 150, 0.05, 21), datagen.generate(200, 150, 0.2, 22), datagen.generate(300, 60, 0.1, 23),
+               datagen.generate(40, 1500, 0.08, 24), datagen.generate(6, 10000, 0.08, 25), vo.corpus_special(seed=6)]
+    for ms in (5, 60, 300, 1200):
+        oc, nc = common.configs_pair(**dict(kw0, scope=scope, memory_mode="biwfa", max_steps=ms))
+        for i, batch in enumerate(corpora):
+            o = loader.run(loader.oracle(), oc, batch)
+            score, status, cigars = common.gpu_run(nc, batch, scope == "full", resident=(i % 2 == 0))
+            common.assert_same(o, score, status, cigars, batch, f"biwfa max_steps={ms} {scope} {kw0} corpus {i}")

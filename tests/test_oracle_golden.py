@@ -37,7 +37,8 @@ def test_oracle_matches_reference_biwfa_vectors(run_idx):
     o = loader.run(loader.oracle(), loader.make_config(**run["config"]), batch)
     assert o["score"].tolist() == run["score"]
     assert o["status"].tolist() == run["status"]
-    assert [common.rle(c) for c in o["cigars"]] == run["cigar"]
+    if run["cigar"] is not None:
+        assert [common.rle(c) for c in o["cigars"]] == run["cigar"]
 
 
 def _surface_alignments():

@@ -84,9 +84,27 @@ def test_biwfa_full_cigar_equals_reference(cfg_idx):
         assert np.array_equal(o["score"][have], h["score"][have]), kw
 
 
+@pytest.mark.parametrize("kw0", [dict(span="end-to-end"), dict(), dict(distance="affine2p"), dict(distance="levenshtein", span="end-to-end"),
+                                 dict(distance="linear", mismatch=3, gap_extension=5), dict(match=-1, span="end-to-end"), dict(distance="indel")])
+def test_biwfa_step_limit_equals_reference(kw0):
+    """max_steps in BiWFA: the limit counts forward + reverse scores in the breakpoint search
+    (R/wavefront_bialign.c:475,513 -> status -100, score unset) and the base cases carry it too (R/wavefront_bialigner.c:168-174:
+    a base case that hits it is not "completed" -> -300); both scopes; status, score and the op string appended so far."""
+    import validate_oracle as vo
+    corpora = [datagen.generate(300, 150, 0.05, 11), datagen.generate(150, 150, 0.2, 12), datagen.generate(200, 60, 0.1, 13),
+               datagen.generate(20, 1500, 0.08, 14), vo.corpus_special(seed=5)]
+    for ms in (5, 60, 300, 3000):
+        for scope in ("full", "score"):
+            cfg = loader.make_config(**dict(kw0, scope=scope, memory_mode="biwfa", max_steps=ms))
+            for batch in corpora:
+                r = loader.run(loader.reference(), cfg, batch)
+                o = loader.run(loader.oracle(), cfg, batch)
+                common.assert_same(r, o["score"], o["status"], o["cigars"], batch, f"biwfa max_steps={ms} {scope} {kw0}")
+
+
 def test_biwfa_outside_the_built_subset_is_refused():
     batch = datagen.generate(4, 50, 0.05, 1)
-    for kw in (dict(scope="full", heuristic="adaptive"), dict(scope="score", heuristic="adaptive"), dict(scope="score", max_steps=50),
+    for kw in (dict(scope="full", heuristic="adaptive"), dict(scope="score", heuristic="adaptive"),
                dict(scope="score", span="ends-free", text_end_free=5), dict(scope="full", span="ends-free", pattern_begin_free=3)):
         with pytest.raises(Exception):
             loader.run(loader.oracle(), loader.make_config(**dict(kw, memory_mode="biwfa")), batch, want_cigar=False)

@@ -269,6 +269,33 @@ def biwfa_vectors():
                 continue
             out["runs"].append({"corpus": name, "config": kw, "score": [int(x) for x in r["score"]],
                                 "status": [int(x) for x in r["status"]], "cigar": [rle(c) for c in r["cigars"]]})
+    # round 3: a step limit (counted over the forward + reverse scores, wavefront_bialign.c:475,513; the base cases carry it too,
+    # wavefront_bialigner.c:168-174), both scopes; reads of <= 100 bases under large penalties (the top-level base case has no
+    # score bound)
+    limited = [dict(span="end-to-end"), dict(distance="affine2p"), dict(distance="levenshtein", span="end-to-end"), dict(match=-1, span="end-to-end")]
+    for name in ("special", "L60_e0.1", "L150_e0.2", "L1500_e0.1"):
+        pairs = out["corpora"][name]
+        b = datagen.from_strings([p for p, _ in pairs], [t for _, t in pairs])
+        for kw in limited:
+            for ms in (20, 150, 700):
+                for scope in ("full", "score"):
+                    kw2 = dict(kw, scope=scope, memory_mode="biwfa", max_steps=ms)
+                    r = vo.run_reference(kw2, b)
+                    if r is None:
+                        continue
+                    out["runs"].append({"corpus": name, "config": kw2, "score": [int(x) for x in r["score"]], "status": [int(x) for x in r["status"]],
+                                        "cigar": [rle(c) for c in r["cigars"]] if r["cigars"] is not None else None})
+    rng = np.random.default_rng(77)
+    unrelated = [["".join(rng.choice(list("ACGT"), size=int(rng.integers(60, 101)))), "".join(rng.choice(list("ACGT"), size=int(rng.integers(60, 101))))]
+                 for _ in range(24)]
+    out["corpora"]["unrelated_le100"] = unrelated
+    b = datagen.from_strings([p for p, _ in unrelated], [t for _, t in unrelated])
+    for kw in (dict(match=-1, span="end-to-end"), dict(mismatch=6, gap_opening=2, gap_extension=3), dict(distance="affine2p", match=-2), dict(match=-1, max_steps=600)):
+        kw2 = dict(kw, scope="full", memory_mode="biwfa")
+        r = vo.run_reference(kw2, b)
+        if r is not None:
+            out["runs"].append({"corpus": "unrelated_le100", "config": kw2, "score": [int(x) for x in r["score"]], "status": [int(x) for x in r["status"]],
+                                "cigar": [rle(c) for c in r["cigars"]]})
     return out
 
 
