@@ -1012,6 +1012,59 @@ wfa_seg_expand_kernel(const BandArgs a) {
   }
 }
 
+// Short reads, history of wfa_lane_kernel<.., FULL> (wfa_lane.hpp): the walk ran in the alignment kernel; a slot holds the run
+// records {length << 8 | op} in forward order from its first int.  Four alignments per wave, 16 lanes each.
+__global__ void __launch_bounds__(256)
+wfa_lane_expand_kernel(const BandArgs a) {
+  const int lane = threadIdx.x & 63, sub = lane >> 4, l = lane & 15;
+  const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+  const uint32_t t = wave * 4u + (uint32_t)sub;
+  int4 es = make_int4(0, 0, 0, 0);
+  if (t < a.nwork) es = a.end_state[t];
+  const bool live = es.w == 2;
+  uint32_t pair = 0;
+  WfaPairMeta pm; pm.p_woff = 0; pm.t_woff = 0; pm.plen = 0; pm.tlen = 0;
+  if (live) {
+    const uint32_t wi = a.work_begin + t;
+    pair = a.worklist ? a.worklist[wi] : wi;
+    pm = a.meta[pair];
+  }
+  const uint32_t* runs = reinterpret_cast<const uint32_t*>(a.hist + (long long)t * a.hist_stride);
+  uint8_t* buf = live ? a.cigar_ops + a.cigar_off[pair] : nullptr;
+  const int nruns = live ? es.y : 0;
+  int start = es.x;
+  int maxruns = nruns;  // the four alignments of the wave loop together
+#pragma unroll
+  for (int d = 16; d < 64; d <<= 1) maxruns = max(maxruns, __shfl_xor(maxruns, d, 64));
+  for (int r0 = 0; r0 < maxruns; r0 += 16) {
+    const int r = r0 + l;
+    const uint32_t rec = (r < nruns) ? runs[r] : 0u;
+    const int len = (int)(rec >> 8);
+    const int op = (int)(rec & 0xFFu);
+    int cum = len;  // inclusive prefix sum over the 16 lanes of the alignment
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) { const int o = __shfl_up(cum, d, 16); if (l >= d) cum += o; }
+    const int pos = start + cum - len;  // first byte of this lane's run
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+      const int src = (lane & 48) + j;
+      const int jpos = __shfl(pos, src, 64), jlen = __shfl(len, src, 64), jop = __shfl(op, src, 64);
+      for (int i = l; i < jlen; i += 16) buf[jpos + i] = (uint8_t)jop;
+    }
+    start += __shfl(cum, (lane & 48) + 15, 64);
+  }
+  if (live && l == 0) {
+    a.cigar_begin[pair] = a.cigar_off[pair] + es.x;
+    a.cigar_len[pair] = pm.plen + pm.tlen - es.x;
+  }
+}
+
+inline int launch_lane_expand_impl(const BandArgs& a, hipStream_t stream) {
+  if (a.nwork == 0) return 0;
+  hipLaunchKernelGGL(wfa_lane_expand_kernel, dim3((a.nwork + 15u) / 16u), dim3(256), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 inline int launch_band_bt_impl(const BandArgs& a, int nch, hipStream_t stream) {
   const unsigned grid = (a.nwork + 63u) / 64u;
   if (grid == 0) return 0;
@@ -1078,6 +1131,7 @@ static int launch_band_shape(const BandArgs& a, int nch, bool full, bool adapt, 
 // ---- host entry points.  Every penalty shape is compiled in its own translation unit (csrc/k_band.hip, once per
 // index; index 4 = gap-affine-2p, index 5 = the walks / expansion kernels) so that the library builds in parallel.
 int launch_band_bt(const BandArgs& a, int nch, hipStream_t stream);
+int launch_lane_expand(const BandArgs& a, hipStream_t stream);   // op bytes from the run records of wfa_lane_kernel<.., FULL>
 #define WFA_BAND_DECL(i, x, oe, e) int launch_band_s##i(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds, long long grid, hipStream_t stream);
 WFA_BAND_SHAPES(WFA_BAND_DECL)
 #undef WFA_BAND_DECL

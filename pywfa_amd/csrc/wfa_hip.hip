@@ -42,7 +42,7 @@ static thread_local std::string g_error;
   F(ARENA_KB) F(BAND_DEBUG) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
-  F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
+  F(LANE_FULL) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
 enum WfaKnob {
 #define WFA_KNOB_ENUM(n) K_##n,
   WFA_KNOBS(WFA_KNOB_ENUM)
@@ -1454,20 +1454,61 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     } else if (use_segfull) {
       n_segfull = std::max(0, std::min(3, knob(al, K_SEGFULL_STAGES, 3)));
     }
+    // Round 3: the 16-diagonal stage of that cascade is the lane-per-pair kernel with origin codes (wfa_lane_kernel<.., FULL>):
+    // it walks in-kernel and leaves only run records in HBM (WFA_LANE_RUN_SLOT ints + an end state per pair), so the whole batch
+    // is one launch; WFA_HIP_LANE_FULL=0 keeps round 2's 16-lane segments with explicit offset records
+    const bool use_lanefull = use_segfull && n_segfull >= 1 && segfull_w[0] == 16 && knob(al, K_LANE_FULL, 1) != 0;
+    if (use_lanefull) { for (int i = 1; i < n_segfull; ++i) segfull_w[i - 1] = segfull_w[i]; --n_segfull; }
+    const int64_t lanefull_slot_bytes = (int64_t)WFA_LANE_RUN_SLOT * 4 + (int64_t)sizeof(int4);
+    int64_t lanefull_cap = 0;
+    if (use_lanefull) {
+      lanefull_cap = std::max<int64_t>(1, std::min<int64_t>(in_n, free_budget(al) / lanefull_slot_bytes));
+      need = std::max(need, (size_t)(lanefull_cap * lanefull_slot_bytes));
+    }
     if (use_segfull) {
       for (int i = 0; i < n_segfull; ++i) {
+        const int rank = i + (use_lanefull ? 1 : 0);   // position in the cascade: 0 = takes the whole batch
         segfull_slot_ints[i] = (int64_t)wfa::seg_full_records(b->dcfg, segfull_w[i]) * segfull_w[i] * 2;  // records of w entries x 8 bytes
         const int64_t slot_bytes = segfull_slot_ints[i] * 4 + (int64_t)sizeof(int4);
-        int64_t want = (i == 0) ? std::min<int64_t>((int64_t)knob(al, K_SEGFULL_PAIRS, 2000000), std::max<int64_t>(1, ((int64_t)8 << 30) / slot_bytes))
-                                : std::max<int64_t>(4096, (int64_t)in_n / (i == 1 ? 8 : 32));
+        int64_t want = (rank == 0) ? std::min<int64_t>((int64_t)knob(al, K_SEGFULL_PAIRS, 2000000), std::max<int64_t>(1, ((int64_t)8 << 30) / slot_bytes))
+                                   : std::max<int64_t>(4096, (int64_t)in_n / (rank == 1 ? 8 : 32));
         segfull_cap[i] = std::max<int64_t>(1, std::min<int64_t>(in_n, std::min<int64_t>(want, free_budget(al) / slot_bytes)));
         // (several launches: two slot arrays, the walks of a launch run under the alignment kernel of the next)
-        need = std::max(need, (size_t)(segfull_cap[i] * slot_bytes) * ((i == 0 && segfull_cap[i] < (int64_t)in_n) ? 2 : 1));
+        need = std::max(need, (size_t)(segfull_cap[i] * slot_bytes) * ((rank == 0 && segfull_cap[i] < (int64_t)in_n) ? 2 : 1));
       }
     }
     int rc = ensure_ws(al, need);
     if (rc != WFA_HIP_OK) return rc;
 
+    if (use_lanefull) {
+      uint32_t* out_list = b->d_fb_list2[out_sel];
+      uint32_t* out_count = b->d_counters + 4 + out_sel;
+      int X, OE, E;
+      const int shape = wfa::seg_shape(b->dcfg, &X, &OE, &E);
+      wfa::FastArgs fa;
+      memset(&fa, 0, sizeof(fa));
+      fa.words = b->d_words; fa.meta = b->d_meta; fa.worklist = in_list; fa.nwork_dev = nullptr;
+      fa.score = b->d_score; fa.status = b->d_status; fa.fb_list = out_list; fa.fb_count = out_count;
+      fa.g = wfa::gcd_int(wfa::gcd_int(b->dcfg.x, b->dcfg.o1 + b->dcfg.e1), b->dcfg.e1);
+      fa.hist = al->ws; fa.hist_stride = WFA_LANE_RUN_SLOT;
+      fa.end_state = reinterpret_cast<int4*>(reinterpret_cast<char*>(al->ws) + (size_t)lanefull_cap * WFA_LANE_RUN_SLOT * 4);
+      wfa::BandArgs ba;
+      memset(&ba, 0, sizeof(ba));
+      ba.meta = b->d_meta; ba.worklist = in_list; ba.words = b->d_words;
+      ba.cigar_ops = b->d_ops; ba.cigar_off = b->d_cigar_off; ba.cigar_begin = b->d_cigar_begin; ba.cigar_len = b->d_cigar_len;
+      ba.hist = fa.hist; ba.hist_stride = fa.hist_stride; ba.end_state = fa.end_state;
+      for (int64_t w0 = 0; w0 < (int64_t)in_n; w0 += lanefull_cap) {
+        const uint32_t cnt = (uint32_t)std::min<int64_t>(lanefull_cap, (int64_t)in_n - w0);
+        fa.work_begin = (uint32_t)w0; fa.nwork = cnt;
+        if (wfa::launch_lane_args(shape, OE, E, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, fa, true) != 0) {
+          al->err = "lane kernel launch failed"; return WFA_HIP_EDEVICE;
+        }
+        ba.work_begin = (uint32_t)w0; ba.nwork = cnt;
+        if (wfa::launch_lane_expand(ba, stream) != 0) { al->err = "expand launch failed"; return WFA_HIP_EDEVICE; }
+      }
+      if (first_stage) b->last_kernel_pairs = in_n;
+      in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
+    }
     for (int sf = 0; sf < n_segfull; ++sf) {
       uint32_t* out_list = b->d_fb_list2[out_sel];
       uint32_t* out_count = b->d_counters + 4 + out_sel;

@@ -21,6 +21,17 @@
 // Exactness is the band argument of wfa_seg.hpp, unchanged: band k in [c - 8, c + 8), c = ceil((tlen - plen) / 2);
 // a score is kept only if S' <= Bmin = min(2o + e(2c + 16 - ak), 2o + e(18 - 2c + ak)), otherwise the pair is handed
 // to the next stage (32- / 64-lane segments, banded, general kernel) — every stage computes the same wavefronts.
+//
+// FULL (round 3): full CIGARs of short reads in the same layout, with the piggy-back history of the long-read kernels
+// (R/wavefront_backtrace_offload.c:39-73, R/wavefront_pcigar.c:204-266): compute-next also records, per cell, which
+// candidate the backtrace would take (R/wavefront_backtrace.c:49-59: mismatch > deletion > insertion on equal offsets, extension
+// > opening) as four comparison bits — 8 bytes per step for the 16 diagonals, kept in the lane's own LDS behind its packed
+// words.  Lanes that finish keep their slot until the wave's next refill; there they walk their codes back from the end cell
+// (one LDS read per edit), unpack forwards re-extending the matches on the LDS words (a wavefront cell is always extended to
+// its end), and leave a handful of run records {length, op} per pair in HBM, written 64 lanes wide; wfa_lane_expand_kernel
+// turns the runs into op bytes.  Nothing else of the history ever reaches HBM (round 2's form stored 8-byte offset records:
+// 1.7 GB per million pairs).  The bound is applied strictly (S' < Bmin) as in wfa_seg_kernel<.., FULL>, so that every
+// candidate the reference's backtrace compares lies inside the band with its true value.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <limits.h>
@@ -76,13 +87,19 @@ __device__ __forceinline__ uint32_t pk_clamp(uint32_t nm, uint32_t lim) {
 #define WFA_LANE_OCCUPANCY
 #endif
 
-template <int X, int OE, int E>
+// records of origin codes a lane can need: steps 0 .. Bmin / g - 1 (wfa_seg.hpp: Bmin / g <= 2 (OE - E) + E (2 H + 1))
+template <int OE, int E>
+struct LaneFull { static constexpr int NREC = 2 * (OE - E) + E * 17 + 1; };
+
+template <int X, int OE, int E, bool FULL>
 __global__ void __launch_bounds__(64) WFA_LANE_OCCUPANCY
-wfa_lane_kernel(const FastArgs a, const int slot_words, const int refill_min) {
+wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_min) {
   constexpr int W = 16, H = 8, NR = 8;            // band of 16 diagonals = 8 packed registers
   constexpr int DM = (X > OE) ? X : OE;           // depth of the M ring
   constexpr int NEVER = 0x7fffffff;
+  constexpr int NREC = LaneFull<OE, E>::NREC;     // FULL: records of 2 words behind the lane's packed words
   extern __shared__ uint32_t lds[];               // [4 guard words][64 slots x slot_words][4 guard words]
+  const int slot_words = FULL ? ((slot_words_seq + 2 * NREC) | 1) : slot_words_seq;   // (odd: lanes hit different banks)
   const int lane = threadIdx.x;
   uint32_t nwork = __builtin_amdgcn_readfirstlane(a.nwork_dev ? *a.nwork_dev : a.nwork);
   const uint32_t per = __builtin_amdgcn_readfirstlane((nwork + gridDim.x - 1) / gridDim.x);
@@ -125,11 +142,122 @@ wfa_lane_kernel(const FastArgs a, const int slot_words, const int refill_min) {
   uint32_t mypid = 0;
   unsigned long long idle = ~0ull;  // lanes without a pair
   int gstep = 0;
+  // FULL: my history slot (work item index of this launch), my lengths, and the end of a finished alignment waiting for its walk
+  const int cbase = 4 + lane * slot_words + slot_words_seq;   // first word of my code records
+  uint32_t myslot = 0;
+  int mypl = 0, fin_t = -1, fin_j = 0;
+  unsigned long long pending = 0ull;   // lanes with a finished alignment not yet walked
+
+  // ---- FULL: walk + unpack of the lanes in `pending` (their LDS slots are untouched since they finished)
+  auto flush_walks = [&]() {
+    if constexpr (FULL) {
+      if (!pending) return;
+      const bool mine = __builtin_amdgcn_inverse_ballot_w64(pending);
+      int nruns = 0, total = 0;
+      bool over = false;
+      if (mine) {
+        // walk the comparison bits back from the end cell (R/wavefront_backtrace.c:320-529 with the choices made at compute
+        // time): bit 3: the mismatch candidate is below the best gap candidate; bit 2: deletion below insertion; bit 1 / 0: the
+        // gap extension of I / D is below its opening.  Events go to the top of my records, downwards (a record is read
+        // before an event can reach it: every hop goes back at least one step).
+        int t = fin_t, j = fin_j, comp = 0, nev = 0;
+        while (t > 0 && nev < 2 * NREC) {
+          const uint32_t dw = lds[cbase + 2 * t + (j >> 3)];
+          const uint32_t nib = (dw >> (4 * (j & 7))) & 0xFu;
+          uint32_t ev;
+          if (comp == 0) {
+            if (!(nib & 8u)) { ev = 'X' | 0x80u; t -= X; }
+            else if (!(nib & 4u)) { ev = 'D' | 0x80u; ++j; if (!(nib & 1u)) { t -= E; comp = 2; } else t -= OE; }
+            else { ev = 'I' | 0x80u; --j; if (!(nib & 2u)) { t -= E; comp = 1; } else t -= OE; }
+          } else if (comp == 1) {
+            ev = 'I'; --j;
+            if (!(nib & 2u)) t -= E; else { t -= OE; comp = 0; }
+          } else {
+            ev = 'D'; ++j;
+            if (!(nib & 1u)) t -= E; else { t -= OE; comp = 0; }
+          }
+          lds[cbase + 2 * NREC - 1 - nev] = ev;
+          ++nev;
+        }
+        // runs grow upwards from my first record, events are consumed downwards from the top: they must not meet
+        over = (t != 0) || (3 * nev + 2 > 2 * NREC) || (2 * nev + 3 > (int)a.hist_stride);
+        if (!over) {
+          // unpack forwards from the cell (score 0, offset 0): after every event that lands in M the run of matches is the
+          // whole common prefix of what is left of the two sequences
+          const int pl = mypl, tl = (int)tend;
+          int v = 0, h = 0;
+          uint32_t cur_op = 'M';
+          int cur_len = 0;
+          auto emit = [&](uint32_t op, int n) {
+            if (n <= 0) return;
+            total += n;
+            if (op == cur_op) { cur_len += n; return; }
+            if (cur_len > 0) { lds[cbase + nruns] = ((uint32_t)cur_len << 8) | cur_op; ++nruns; }
+            cur_op = op; cur_len = n;
+          };
+          auto lcp = [&]() -> int {
+            const int maxn = min(pl - v, tl - h);
+            int n = 0;
+            while (n < maxn) {
+              const int pv = pbase + v + n, th = tb + h + n;
+              const uint32_t pa = ((uint32_t)pv >> 2) & ~3u, ta = ((uint32_t)th >> 2) & ~3u;
+              const uint32_t* pp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds) + pa);
+              const uint32_t* tp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds) + ta);
+              const uint32_t p0 = pp[0], p1 = pp[1], p2 = pp[2], t0 = tp[0], t1 = tp[1], t2 = tp[2];
+              const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)pv << 1) ^ __builtin_amdgcn_alignbit(t1, t0, (uint32_t)th << 1);
+              const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, (uint32_t)pv << 1) ^ __builtin_amdgcn_alignbit(t2, t1, (uint32_t)th << 1);
+              const uint32_t fb = min(lane_ffbl(xl), lane_ffbl(xh) | 32u);
+              const int m = min((int)(fb >> 1), 32);
+              n += m;
+              if (m < 32) break;
+            }
+            return min(n, maxn);
+          };
+          { const int n = lcp(); emit('M', n); v += n; h += n; }
+          for (int e = nev - 1; e >= 0; --e) {
+            const uint32_t ev = lds[cbase + 2 * NREC - 1 - e];
+            const uint32_t op = ev & 0x7Fu;
+            if (op == 'X') { emit('X', 1); ++v; ++h; }
+            else if (op == 'I') { emit('I', 1); ++h; }
+            else { emit('D', 1); ++v; }
+            if (ev & 0x80u) { const int n = lcp(); emit('M', n); v += n; h += n; }
+          }
+          emit('I', tl - h); emit('D', pl - v);
+          if (cur_len > 0) { lds[cbase + nruns] = ((uint32_t)cur_len << 8) | cur_op; ++nruns; }
+          a.end_state[myslot] = make_int4(pl + tl - total, nruns, 1, 2);   // {first op, runs, forward order, ready}
+        }
+      }
+      // a walk that does not fit its records (many one-step hops): the pair goes to the next stage like a rejected one
+      const unsigned long long bover = __ballot(mine && over);
+      if (bover) {
+        uint32_t slot = 0;
+        if (lane == 0) slot = atomicAdd(a.fb_count, (uint32_t)__builtin_popcountll(bover));
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (mine && over) {
+          a.fb_list[slot + __builtin_amdgcn_mbcnt_hi((uint32_t)(bover >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bover, 0u))] = mypid;
+          a.status[mypid] = WFA_INTERNAL_FALLBACK;
+          a.end_state[myslot] = make_int4(0, 0, 0, 0);
+        }
+      }
+      // the run records of every walked lane, 64 lanes wide
+      unsigned long long lm = pending & ~bover;
+      while (lm) {
+        const int L = __builtin_ctzll(lm);
+        lm &= lm - 1ull;
+        const int nr = __builtin_amdgcn_readlane(nruns, L);
+        const uint32_t sl = __builtin_amdgcn_readlane(myslot, L);
+        if (lane < nr) reinterpret_cast<uint32_t*>(a.hist)[(unsigned long long)sl * (unsigned long long)a.hist_stride + lane] = lds[4 + L * slot_words + slot_words_seq + lane];
+      }
+      fin_t = mine ? -1 : fin_t;
+      pending = 0ull;
+    }
+  };
 
   while (true) {
     // =================== take pairs ===================
     const int nidle = __builtin_popcountll(idle);
     if (next_i < end && (nidle >= refill_min || idle == ~0ull)) {
+      flush_walks();   // (FULL: the finished lanes' slots are about to be overwritten)
       const bool is_idle = __builtin_amdgcn_inverse_ballot_w64(idle);
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
       const uint32_t navail = end - next_i;
@@ -163,12 +291,14 @@ wfa_lane_kernel(const FastArgs a, const int slot_words, const int refill_min) {
         const int c = bad ? 0 : ((ak + 1) >> 1);      // band centre: k in [c - H, c + H)
         const int k0 = c - H;                         // diagonal of slot 0
         mypid = n_pid; s0 = gstep;
+        if (FULL) { myslot = next_i + rank; mypl = pl; }   // (slot = index of the work item in this launch)
         kb0 = pbase - k0; tb = pbase + nwp * 16;
         jt = bad ? 0 : ak - k0;
         tend = bad ? 0xffffu : (uint32_t)tl;
         // Bmin / g in units of g (o / g = OE - E, e / g = E), see wfa_seg.hpp
         deadline = bad ? gstep - 1
-                       : gstep + min(2 * (OE - E) + E * (2 * c + 2 * H - ak), 2 * (OE - E) + E * (2 * H + 2 - 2 * c + ak));
+                       : gstep + min(2 * (OE - E) + E * (2 * c + 2 * H - ak), 2 * (OE - E) + E * (2 * H + 2 - 2 * c + ak))
+                               - (FULL ? 1 : 0);   // FULL: S' < Bmin strictly, so that no co-optimal alignment leaves the band
         const int j0 = -k0;                           // slot of diagonal 0: the cell (score 0, offset 0)
         // lim of slot j = min(tlen, plen + k0 + j), two per register (a pair this stage cannot take: NULL, nothing lives)
         const uint32_t lb2 = ((uint32_t)(pl + k0) & 0xffffu) | ((uint32_t)(pl + k0 + 1) << 16);
@@ -195,6 +325,7 @@ wfa_lane_kernel(const FastArgs a, const int slot_words, const int refill_min) {
         load_window(wbase + 64u, pid1, pw1, ln1);
       }
     } else if (idle == ~0ull) {
+      flush_walks();
       break;                                 // nothing left
     }
 
@@ -312,7 +443,9 @@ wfa_lane_kernel(const FastArgs a, const int slot_words, const int refill_min) {
         if (__builtin_amdgcn_inverse_ballot_w64(ba)) {
           a.score[mypid] = -__mul24(gstep - s0, a.g);
           a.status[mypid] = 0;
+          if (FULL) { fin_t = gstep - s0; fin_j = jt; }
         }
+        if (FULL) pending |= ba;
         if (brej) {
           uint32_t slot = 0;
           if (lane == 0) slot = atomicAdd(a.fb_count, (uint32_t)__builtin_popcountll(brej));
@@ -320,6 +453,7 @@ wfa_lane_kernel(const FastArgs a, const int slot_words, const int refill_min) {
           if (__builtin_amdgcn_inverse_ballot_w64(brej)) {
             a.fb_list[slot + __builtin_amdgcn_mbcnt_hi((uint32_t)(brej >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)brej, 0u))] = mypid;
             a.status[mypid] = WFA_INTERNAL_FALLBACK;
+            if (FULL) a.end_state[myslot] = make_int4(0, 0, 0, 0);
           }
         }
         if (__builtin_amdgcn_inverse_ballot_w64(bd)) {
@@ -329,7 +463,7 @@ wfa_lane_kernel(const FastArgs a, const int slot_words, const int refill_min) {
           deadline = NEVER; jt = 0; tend = 0xffffu;
         }
         idle |= bd;
-        if (idle == ~0ull && next_i >= end) break;
+        if (idle == ~0ull && next_i >= end) { flush_walks(); break; }
       }
     }
 
@@ -344,6 +478,16 @@ wfa_lane_kernel(const FastArgs a, const int slot_words, const int refill_min) {
       }
       uint32_t nm[NR], ni[NR], nd[NR];
       const uint32_t one2 = 0x00010001u;
+      // FULL: per slot, is the extension of I / D below its opening?  (the sign of I_e - M_oe / D_e - M_oe, read by the neighbour slot)
+      uint32_t cmp_i[FULL ? NR : 1], cmp_d[FULL ? NR : 1], cbyte[FULL ? NR : 1];
+      if constexpr (FULL) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const uint32_t mo = (OE == 1) ? cur[r] : Mh[OE - 2][r];
+          cmp_i[r] = pk_sub(Ih[E - 1][r], mo);
+          cmp_d[r] = pk_sub(Dh[E - 1][r], mo);
+        }
+      }
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         // I(k) = max(M_oe, I_e)(k - 1) + 1: the value of slot j - 1; D(k) = max(M_oe, D_e)(k + 1): slot j + 1
@@ -352,7 +496,26 @@ wfa_lane_kernel(const FastArgs a, const int slot_words, const int refill_min) {
         ni[r] = pk_add(below, one2);
         nd[r] = above;
         const uint32_t mx = (X == 1) ? cur[r] : Mh[X - 2][r];
-        nm[r] = pk_clamp(pk_max(pk_max(nd[r], ni[r]), pk_add(mx, one2)), lim[r]);
+        const uint32_t gap = pk_max(nd[r], ni[r]), x1 = pk_add(mx, one2);
+        nm[r] = pk_clamp(pk_max(gap, x1), lim[r]);
+        if constexpr (FULL) {
+          // the four comparison bits of each of the two slots (sign bits 15 / 31 of the packed differences): 8: mismatch below the
+          // best gap, 4: deletion below insertion, 2: I extension below opening (slot j - 1), 1: D extension below opening (slot j + 1)
+          const uint32_t ca = pk_sub(x1, gap), cb = pk_sub(nd[r], ni[r]);
+          const uint32_t cc = __builtin_amdgcn_alignbit(cmp_i[r], (r > 0) ? cmp_i[r - 1] : 0u, 16);
+          const uint32_t cd = __builtin_amdgcn_alignbit((r < NR - 1) ? cmp_d[r + 1] : 0u, cmp_d[r], 16);
+          uint32_t t4 = (cc >> 2 & 0x20002000u) | (cd >> 3 & 0x10001000u);
+          t4 = (cb >> 1 & 0x40004000u) | t4;
+          t4 = (ca & 0x80008000u) | t4;
+          cbyte[r] = ((t4 >> 12) & 0xFu) | ((t4 >> 24) & 0xF0u);
+        }
+      }
+      if constexpr (FULL) {
+        // record of the step being made (index gstep + 1 - s0): bytes 0..3 = registers 0..3, 4..7 = registers 4..7
+        const uint32_t c0 = cbyte[0] | (cbyte[1] << 8) | (cbyte[2] << 16) | (cbyte[3] << 24);
+        const uint32_t c1 = cbyte[4] | (cbyte[5] << 8) | (cbyte[6] << 16) | (cbyte[7] << 24);
+        const int trec = gstep + 1 - s0;
+        if (!__builtin_amdgcn_inverse_ballot_w64(idle) && trec < NREC) { lds[cbase + 2 * trec] = c0; lds[cbase + 2 * trec + 1] = c1; }
       }
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
@@ -372,15 +535,16 @@ wfa_lane_kernel(const FastArgs a, const int slot_words, const int refill_min) {
 
 // per-shape entry points (csrc/k_lane.hip compiled once per shape index of WFA_SEG_SHAPES)
 #define WFA_LANE_DECL(i, x, oe, e) \
-  int launch_lane_s##i(unsigned grid, size_t smem, hipStream_t stream, const FastArgs& a, int slot_words, int refill_min);
+  int launch_lane_s##i(unsigned grid, size_t smem, hipStream_t stream, const FastArgs& a, int slot_words, int refill_min, bool full);
 // (the shape list is wfa_seg.hpp's; declared here without including it)
 WFA_LANE_DECL(0, 2, 4, 1) WFA_LANE_DECL(1, 2, 3, 1) WFA_LANE_DECL(2, 4, 7, 1) WFA_LANE_DECL(3, 3, 5, 1)
 WFA_LANE_DECL(4, 6, 8, 3) WFA_LANE_DECL(5, 5, 3, 3) WFA_LANE_DECL(6, 1, 2, 1)
 #undef WFA_LANE_DECL
 
 template <int X, int OE, int E>
-inline int launch_lane_shape(unsigned grid, size_t smem, hipStream_t stream, const FastArgs& a, int slot_words, int refill_min) {
-  hipLaunchKernelGGL((wfa_lane_kernel<X, OE, E>), dim3(grid), dim3(64), smem, stream, a, slot_words, refill_min);
+inline int launch_lane_shape(unsigned grid, size_t smem, hipStream_t stream, const FastArgs& a, int slot_words, int refill_min, bool full) {
+  if (full) hipLaunchKernelGGL((wfa_lane_kernel<X, OE, E, true>), dim3(grid), dim3(64), smem, stream, a, slot_words, refill_min);
+  else hipLaunchKernelGGL((wfa_lane_kernel<X, OE, E, false>), dim3(grid), dim3(64), smem, stream, a, slot_words, refill_min);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -392,6 +556,14 @@ inline int lane_slot_words(int max_len) {
 }
 
 // shape_idx: index in WFA_SEG_SHAPES (seg_shape()); per_cu: slices of the work list (waves) per CU
+// records of origin codes per lane of the FULL form for a penalty shape (LaneFull<OE, E>::NREC)
+inline int lane_full_records(int OE, int E) { return 2 * (OE - E) + E * 17 + 1; }
+// run records per pair of the FULL form (ints of a slot): an alignment inside the band has at most Bmin / g edits
+#define WFA_LANE_RUN_SLOT 32
+
+// full = the FULL form: a.hist = run-record slots (a.hist_stride ints each, slot = work item - a.work_begin), a.end_state per slot
+inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full);
+
 inline int launch_lane(int shape_idx, int g, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, const uint32_t* words,
                        const WfaPairMeta* meta, const uint32_t* worklist, const uint32_t* nwork_dev, uint32_t nwork,
                        int32_t* score, int32_t* status, uint32_t* fb_list, uint32_t* fb_count, int32_t* debug_counters = nullptr) {
@@ -400,21 +572,28 @@ inline int launch_lane(int shape_idx, int g, int cu_count, int per_cu, int refil
   a.score = score; a.status = status; a.fb_list = fb_list; a.fb_count = fb_count;
   a.g = g;
   a.hist = debug_counters; a.hist_stride = 0; a.end_state = nullptr; a.work_begin = 0;
+  return launch_lane_args(shape_idx, 0, 0, cu_count, per_cu, refill_min, max_len, stream, a, false);
+}
+
+inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full) {
+  const uint32_t nwork = a.nwork;
+  const uint32_t* nwork_dev = a.nwork_dev;
   const int slot_words = lane_slot_words(std::min(max_len, WFA_FAST_MAX_LEN));
-  const size_t smem = ((size_t)64 * slot_words + 8) * sizeof(uint32_t);
+  const int lane_words = full ? ((slot_words + 2 * lane_full_records(OE, E)) | 1) : slot_words;   // (as the kernel computes it)
+  const size_t smem = ((size_t)64 * lane_words + 8) * sizeof(uint32_t);
   // every wave should see several hundred pairs (64 lanes x a few refills), and there should be several waves per SIMD
   long long grid = (long long)cu_count * per_cu;
   const long long max_grid = ((long long)nwork + 255) / 256;
   if (!nwork_dev && grid > max_grid) grid = max_grid;
   if (grid < 1) grid = 1;
   switch (shape_idx) {
-    case 0: return launch_lane_s0((unsigned)grid, smem, stream, a, slot_words, refill_min);
-    case 1: return launch_lane_s1((unsigned)grid, smem, stream, a, slot_words, refill_min);
-    case 2: return launch_lane_s2((unsigned)grid, smem, stream, a, slot_words, refill_min);
-    case 3: return launch_lane_s3((unsigned)grid, smem, stream, a, slot_words, refill_min);
-    case 4: return launch_lane_s4((unsigned)grid, smem, stream, a, slot_words, refill_min);
-    case 5: return launch_lane_s5((unsigned)grid, smem, stream, a, slot_words, refill_min);
-    case 6: return launch_lane_s6((unsigned)grid, smem, stream, a, slot_words, refill_min);
+    case 0: return launch_lane_s0((unsigned)grid, smem, stream, a, slot_words, refill_min, full);
+    case 1: return launch_lane_s1((unsigned)grid, smem, stream, a, slot_words, refill_min, full);
+    case 2: return launch_lane_s2((unsigned)grid, smem, stream, a, slot_words, refill_min, full);
+    case 3: return launch_lane_s3((unsigned)grid, smem, stream, a, slot_words, refill_min, full);
+    case 4: return launch_lane_s4((unsigned)grid, smem, stream, a, slot_words, refill_min, full);
+    case 5: return launch_lane_s5((unsigned)grid, smem, stream, a, slot_words, refill_min, full);
+    case 6: return launch_lane_s6((unsigned)grid, smem, stream, a, slot_words, refill_min, full);
     default: return -1;
   }
 }
