@@ -42,7 +42,7 @@ static thread_local std::string g_error;
   F(ARENA_KB) F(BAND_DEBUG) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
-  F(LANE_FULL) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
+  F(LANE_FULL) F(LANE_LDS_PAD_KB) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
 enum WfaKnob {
 #define WFA_KNOB_ENUM(n) K_##n,
   WFA_KNOBS(WFA_KNOB_ENUM)
@@ -1316,7 +1316,9 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     }
     const bool wide_ok = !tiny && ((b->ncomp == 3 && b->dcfg.metric == 3) || (b->ncomp == 5 && b->dcfg.metric == 4 && b->dcfg.e2 >= 1)) &&
                          b->dcfg.heuristic == WFA_HEUR_NONE && b->dcfg.match == 0 &&
-                         b->max_len > 64 && 2 * (int64_t)b->max_len <= 32000 && b->dcfg.e1 >= 1 && b->dcfg.x >= 1 && knob(al, K_NO_WIDE, 0) == 0;
+                         b->max_len > 64 && 2 * (int64_t)b->max_len <= 0x3fffff00ll && b->dcfg.e1 >= 1 && b->dcfg.x >= 1 && knob(al, K_NO_WIDE, 0) == 0;
+    // reads beyond 16 kb (plen + tlen > 32 000 does not fit int16 offsets): the workspace-row form with int32 rows (round 3)
+    const bool wide32 = 2 * (int64_t)b->max_len > 32000;
     const bool any_pre = use_fast || use_segfull || n_stages > 0 || wide_ok;
     Geometry g = plan_general(al, b, any_pre ? std::min<uint32_t>(in_n, (uint32_t)al->cu_count * 16) : in_n, b->arena_fixed + b->arena_ints);
     size_t need = (size_t)g.grid * g.ws_stride * 4;
@@ -1383,7 +1385,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     // Up to two such stages: rows in LDS (gap-affine: the faster form, 23.3 vs 21.7 k aln/s at 10 kb, but ~7 900 diagonals at
     // most), then rows in the workgroup's slice of the HBM workspace (as wide as the whole diagonal range of the longest pair: no
     // pair outgrows them; gap-affine-2p has only this form: its M ring alone is o2 + e2 + 1 rows).
-    struct WideStage { wfa::WideArgs a; int grid = 0, threads = 0; size_t smem = 0, hist_off = 0; bool grows = false; };
+    struct WideStage { wfa::WideArgs a; int grid = 0, threads = 0; size_t smem = 0, hist_off = 0; bool grows = false, w32 = false; };
     WideStage wide_stage[2];
     int n_wide = 0;
     const bool wide_two = (b->ncomp == 5);
@@ -1398,7 +1400,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       const int64_t budget = free_budget(al);
       const int full_range = (2 * b->max_len + 8 + b->dcfg.pbf + b->dcfg.tbf) & ~1;
       bool lds_covers_all = false;
-      if (!wide_two && knob(al, K_WIDE_GROWS, 0) == 0) {
+      if (!wide_two && !wide32 && knob(al, K_WIDE_GROWS, 0) == 0) {
         WideStage& st = wide_stage[n_wide];
         st.a = w0;
         const size_t lds_max = (size_t)std::min(160, std::max(16, knob(al, K_WIDE_LDS_KB, 160))) * 1024;
@@ -1426,18 +1428,20 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       }
       if (!lds_covers_all) {
         WideStage& st = wide_stage[n_wide];
-        st.a = w0; st.grows = true;
+        st.a = w0; st.grows = true; st.w32 = wide32;
         st.a.wcap = full_range;
         st.a.rows_stride = (int64_t)((nrows * wfa::wide_row_halfs(full_range) + 63) & ~(size_t)63);
+        const int64_t row_bytes = wide32 ? 4 : 2;   // bytes per offset
         st.smem = wfa::wide_smem_bytes(w0.X, w0.OE, w0.E, w0.OE2, w0.E2, full_range, w0.seq_words, false);
+        const bool seqs_fit_lds = st.smem <= (size_t)160 * 1024;   // (both packed sequences are staged in LDS: reads up to ~300 kb)
         st.threads = knob(al, K_WIDE_THREADS, 1024);
-        st.grid = (int)std::min<int64_t>((int64_t)al->cu_count * std::max(1, 2048 / st.threads), in_n);
+        st.grid = (int)std::min<int64_t>((int64_t)al->cu_count * std::max<int64_t>(1, std::min<int64_t>(2048 / st.threads, (160 * 1024) / std::max<size_t>(st.smem, 1))), in_n);
         int64_t hist_bytes = 0;
         if (full) hist_bytes = (int64_t)full_range * ((int64_t)(b->max_len * 0.9) / w0.g + 64) / 2 + (1 << 20);   // one byte per cell, + directory + events
-        while (st.grid > 1 && (int64_t)st.grid * (st.a.rows_stride * 2 + hist_bytes) > budget) st.grid = (st.grid + 1) / 2;
-        if ((int64_t)st.grid * (st.a.rows_stride * 2 + hist_bytes) <= budget) {
+        while (st.grid > 1 && (int64_t)st.grid * (st.a.rows_stride * row_bytes + hist_bytes) > budget) st.grid = (st.grid + 1) / 2;
+        if (seqs_fit_lds && (int64_t)st.grid * (st.a.rows_stride * row_bytes + hist_bytes) <= budget) {
           st.a.hist_stride = (hist_bytes / 4) & ~15ll;
-          st.hist_off = ((size_t)st.grid * (size_t)st.a.rows_stride * 2 + 255) & ~(size_t)255;
+          st.hist_off = ((size_t)st.grid * (size_t)st.a.rows_stride * (size_t)row_bytes + 255) & ~(size_t)255;
           need = std::max(need, st.hist_off + (size_t)st.grid * (size_t)st.a.hist_stride * 4);
           ++n_wide;
         }
@@ -1500,7 +1504,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       for (int64_t w0 = 0; w0 < (int64_t)in_n; w0 += lanefull_cap) {
         const uint32_t cnt = (uint32_t)std::min<int64_t>(lanefull_cap, (int64_t)in_n - w0);
         fa.work_begin = (uint32_t)w0; fa.nwork = cnt;
-        if (wfa::launch_lane_args(shape, OE, E, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, fa, true) != 0) {
+        if (wfa::launch_lane_args(shape, OE, E, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8) | ((knob(al, K_LANE_DEBUG, 0) >> 4) << 8), b->max_len, stream, fa, true) != 0) {
           al->err = "lane kernel launch failed"; return WFA_HIP_EDEVICE;
         }
         ba.work_begin = (uint32_t)w0; ba.nwork = cnt;
@@ -1586,11 +1590,12 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
           lrc = wfa::launch_lane(shape, wfa::gcd_int(wfa::gcd_int(b->dcfg.x, b->dcfg.o1 + b->dcfg.e1), b->dcfg.e1), al->cu_count,
                                  knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, b->d_words, b->d_meta,
                                  in_list, in_count, in_n, b->d_score, b->d_status, out_list, out_count,
-                                 (knob(al, K_LANE_DEBUG, 0) && al->ws) ? al->ws : nullptr);
+                                 (knob(al, K_LANE_DEBUG, 0) && al->ws) ? al->ws : nullptr, knob(al, K_LANE_LDS_PAD_KB, 0));
           if (knob(al, K_LANE_DEBUG, 0) && al->ws) {  // development aid (build with -DWFA_LANE_DEBUG_COUNTERS=1)
-            unsigned long long c[4] = {0, 0, 0, 0};
+            unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             hipStreamSynchronize(stream); hipMemcpy(c, al->ws, sizeof(c), hipMemcpyDeviceToHost); hipMemset(al->ws, 0, sizeof(c));
-            fprintf(stderr, "[wfa_hip] lane kernel: %llu wave-steps, %llu refills, %llu long runs, %llu 32-base rounds\n", c[0], c[1], c[2], c[3]);
+            fprintf(stderr, "[wfa_hip] lane kernel: %llu wave-steps, %llu refills, %llu parked runs, %llu parked rounds, %llu probe blocks, %llu second-run rounds, "
+                            "%llu hand-over blocks, %llu second runs\n", c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
           }
         } else {
           lrc = wfa::launch_seg(b->dcfg, al->cu_count, knob(al, K_FAST_WAVES_PER_CU, 256), stream, b->d_words, b->d_meta, in_list, in_count,
@@ -1707,7 +1712,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       wa.ef = b->dcfg.endsfree ? 1 : 0;
       wa.pbf = b->dcfg.pbf; wa.pef = b->dcfg.pef; wa.tbf = b->dcfg.tbf; wa.tef = b->dcfg.tef;
       wa.max_steps = b->dcfg.max_steps;
-      if (wfa::launch_wide(full, wide_two, wa, st.grid, st.threads, st.smem, stream) != 0) { al->err = "wide kernel launch failed"; return WFA_HIP_EDEVICE; }
+      if (wfa::launch_wide(full, wide_two, wa, st.grid, st.threads, st.smem, stream, st.w32) != 0) { al->err = "wide kernel launch failed"; return WFA_HIP_EDEVICE; }
       if (first_stage) b->last_kernel_pairs = in_n;
       in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
     }

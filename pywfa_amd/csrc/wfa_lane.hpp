@@ -46,8 +46,19 @@ typedef short lane_s2 __attribute__((ext_vector_type(2)));
 #define WFA_LANE_NULL16 (-16384)
 #define WFA_LANE_NULL2 0xC000C000u
 #ifndef WFA_LANE_DEBUG_COUNTERS
-#define WFA_LANE_DEBUG_COUNTERS 0  // 1: a.hist (if set) receives {wave-steps, refills, long runs, 32-base rounds} as four uint64
+#define WFA_LANE_DEBUG_COUNTERS 0  // 1: a.hist (if set) receives eight uint64: {wave-steps, refills, parked runs, parked 32-base rounds,
+#endif                             //    first-probe blocks, rounds of second runs, hand-over blocks, second runs} (score-only form)
+// Analysis builds (tools/lane_mix.py): region marks as comments in the assembly, so that the instructions of each region of the
+// step can be counted by class and weighted with the counters above (the dynamic instruction mix of the kernel)
+#ifndef WFA_LANE_REGION_MARKS
+#define WFA_LANE_REGION_MARKS 0
 #endif
+#if WFA_LANE_REGION_MARKS
+#define WFA_LANE_MARK(name) asm volatile("; WFA_MARK " name ::: "memory")
+#else
+#define WFA_LANE_MARK(name)
+#endif
+#define WFA_LANE_COUNT(i) do { if (WFA_LANE_DEBUG_COUNTERS && !FULL && a.hist) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.hist) + (i), 1ull); } } while (0)
 
 __device__ __forceinline__ uint32_t lane_ffbl(uint32_t x) {  // index of the lowest set bit, ~0u for 0
   uint32_t r;
@@ -93,7 +104,9 @@ struct LaneFull { static constexpr int NREC = 2 * (OE - E) + E * 17 + 1; };
 
 template <int X, int OE, int E, bool FULL>
 __global__ void __launch_bounds__(64) WFA_LANE_OCCUPANCY
-wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_min) {
+wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg) {
+  const int refill_min = refill_arg & 0xff;
+  const int dbg_flags = refill_arg >> 8;   // timing experiments only (WFA_HIP_LANE_DEBUG >> 4): 1 = skip the walks, 2 = skip the code stores
   constexpr int W = 16, H = 8, NR = 8;            // band of 16 diagonals = 8 packed registers
   constexpr int DM = (X > OE) ? X : OE;           // depth of the M ring
   constexpr int NEVER = 0x7fffffff;
@@ -145,13 +158,17 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_min
   // FULL: my history slot (work item index of this launch), my lengths, and the end of a finished alignment waiting for its walk
   const int cbase = 4 + lane * slot_words + slot_words_seq;   // first word of my code records
   uint32_t myslot = 0;
-  int mypl = 0, fin_t = -1, fin_j = 0;
+  int mypl = 0, fin_t = -1, fin_j = 0, fin_tl = 0;
   unsigned long long pending = 0ull;   // lanes with a finished alignment not yet walked
 
   // ---- FULL: walk + unpack of the lanes in `pending` (their LDS slots are untouched since they finished)
   auto flush_walks = [&]() {
     if constexpr (FULL) {
       if (!pending) return;
+      if (dbg_flags & 1) {
+        if (__builtin_amdgcn_inverse_ballot_w64(pending)) a.end_state[myslot] = make_int4(0, 0, 0, 0);
+        pending = 0ull; fin_t = -1; return;
+      }
       const bool mine = __builtin_amdgcn_inverse_ballot_w64(pending);
       int nruns = 0, total = 0;
       bool over = false;
@@ -184,7 +201,7 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_min
         if (!over) {
           // unpack forwards from the cell (score 0, offset 0): after every event that lands in M the run of matches is the
           // whole common prefix of what is left of the two sequences
-          const int pl = mypl, tl = (int)tend;
+          const int pl = mypl, tl = fin_tl;
           int v = 0, h = 0;
           uint32_t cur_op = 'M';
           int cur_len = 0;
@@ -254,10 +271,13 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_min
   };
 
   while (true) {
+    WFA_LANE_MARK("looptop_begin");   // (analysis builds: what precedes the first of these is the prologue)
     // =================== take pairs ===================
     const int nidle = __builtin_popcountll(idle);
     if (next_i < end && (nidle >= refill_min || idle == ~0ull)) {
       flush_walks();   // (FULL: the finished lanes' slots are about to be overwritten)
+      WFA_LANE_MARK("refill_begin");
+      WFA_LANE_COUNT(1);
       const bool is_idle = __builtin_amdgcn_inverse_ballot_w64(idle);
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
       const uint32_t navail = end - next_i;
@@ -273,7 +293,7 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_min
       const int ak = tl - pl;
       // a pair this stage cannot take (too long for the slot, |tlen - plen| outside the band) gets an expired deadline:
       // the hand-over path below passes it on at once
-      const bool bad = n_ln == 0xffffffffu || ntot + 1 > slot_words || ak < 1 - 2 * H || ak > 2 * H - 1;
+      const bool bad = n_ln == 0xffffffffu || ntot + 1 > slot_words_seq || ak < 1 - 2 * H || ak > 2 * H - 1;
       const unsigned long long tmask = __ballot(take);
       // packed words of every taken pair: one direct-to-LDS load each (lane j -> word j of the pair -> slot word j;
       // the text words of a pair follow its pattern words, csrc/wfa_hip.hip batch_build)
@@ -324,6 +344,7 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_min
         pid0 = pid1; pw0 = pw1; ln0 = ln1; wbase += 64u;
         load_window(wbase + 64u, pid1, pw1, ln1);
       }
+      WFA_LANE_MARK("refill_end");
     } else if (idle == ~0ull) {
       flush_walks();
       break;                                 // nothing left
@@ -342,6 +363,8 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_min
       // some slot of this register holds a cell (offset >= 0) that can still run (offset < lim): per half min(cur, lim - 1 - cur) >= 0
       const uint32_t ua = pk_min(cur[r], pk_add(pk_sub(lim[r], cur[r]), 0xffffffffu));
       if (__any((ua & 0x80008000u) != 0x80008000u)) {
+        WFA_LANE_MARK("probe_begin");
+        WFA_LANE_COUNT(4);
         int off[2], left[2], x[2];
         bool valid[2], more[2];
 #pragma unroll
@@ -373,10 +396,14 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_min
           const bool now = more[q] && !park;
           hot_x = park ? x[q] : hot_x; hot_left = park ? left[q] : hot_left; hot_j = park ? j : hot_j;
           if (__any(now)) {
+            WFA_LANE_MARK("nowfix_begin");
+            WFA_LANE_COUNT(7);
             bool mo = now;
             int lf = mo ? left[q] : 0;       // other lanes advance by 0
             int xx = x[q];
             do {
+              WFA_LANE_MARK("now_begin");
+              WFA_LANE_COUNT(5);
               const int v = xx + kb0 - j, h = xx + tb;
               const uint32_t pa = ((uint32_t)v >> 2) & ~3u, ta = ((uint32_t)h >> 2) & ~3u;
               const uint32_t* pp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds) + pa);
@@ -388,12 +415,15 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_min
               const int m = min((int)(fb >> 1), min(32, lf));
               xx += m; lf -= m;
               mo = (m == 32) && (lf > 0);
+              WFA_LANE_MARK("now_end");
             } while (__any(mo));
             x[q] = xx;
+            WFA_LANE_MARK("nowfix_end");
           }
         }
         x[0] = valid[0] ? x[0] : off[0]; x[1] = valid[1] ? x[1] : off[1];
         cur[r] = ((uint32_t)x[0] & 0xffffu) | ((uint32_t)x[1] << 16);
+        WFA_LANE_MARK("probe_end");
       }
     }
     if (__any(hot_j >= 0)) {
@@ -401,8 +431,10 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_min
       bool mo = hot_j >= 0;
       int lf = mo ? hot_left : 0;
       const int kbj = kb0 - hot_j;
-      if (WFA_LANE_DEBUG_COUNTERS && a.hist) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.hist) + 2, 1ull); }
+      WFA_LANE_COUNT(2);
+      WFA_LANE_MARK("parkfix_begin");
       do {
+        WFA_LANE_MARK("parked_begin");
         const int v = hot_x + kbj, h = hot_x + tb;
         const uint32_t pa = ((uint32_t)v >> 2) & ~3u, ta = ((uint32_t)h >> 2) & ~3u;
         const uint32_t* pp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds) + pa);
@@ -414,7 +446,8 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_min
         const int m = min((int)(fb >> 1), min(32, lf));
         hot_x += m; lf -= m;
         mo = (m == 32) && (lf > 0);
-        if (WFA_LANE_DEBUG_COUNTERS && a.hist) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.hist) + 3, 1ull); }
+        WFA_LANE_COUNT(3);
+        WFA_LANE_MARK("parked_end");
       } while (__any(mo));
       // back into its half register (lanes without a parked run: hot_j = -1 matches no register)
       const int hr = hot_j >> 1;
@@ -425,6 +458,7 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_min
         const uint32_t mk = (hr == r) ? hmask : 0u;
         cur[r] = (cur[r] & ~mk) | (hval & mk);
       }
+      WFA_LANE_MARK("parkfix_end");
     }
 
     // =================== termination / hand-over ===================
@@ -439,11 +473,13 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_min
       const unsigned long long brej = __ballot(gstep > deadline) & active;
       const unsigned long long bd = bfin | brej;
       if (bd) {
+        WFA_LANE_MARK("bd_begin");
+        WFA_LANE_COUNT(6);
         const unsigned long long ba = bfin & ~brej;
         if (__builtin_amdgcn_inverse_ballot_w64(ba)) {
           a.score[mypid] = -__mul24(gstep - s0, a.g);
           a.status[mypid] = 0;
-          if (FULL) { fin_t = gstep - s0; fin_j = jt; }
+          if (FULL) { fin_t = gstep - s0; fin_j = jt; fin_tl = (int)tend; }
         }
         if (FULL) pending |= ba;
         if (brej) {
@@ -463,6 +499,7 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_min
           deadline = NEVER; jt = 0; tend = 0xffffu;
         }
         idle |= bd;
+        WFA_LANE_MARK("bd_end");
         if (idle == ~0ull && next_i >= end) { flush_walks(); break; }
       }
     }
@@ -515,7 +552,7 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_min
         const uint32_t c0 = cbyte[0] | (cbyte[1] << 8) | (cbyte[2] << 16) | (cbyte[3] << 24);
         const uint32_t c1 = cbyte[4] | (cbyte[5] << 8) | (cbyte[6] << 16) | (cbyte[7] << 24);
         const int trec = gstep + 1 - s0;
-        if (!__builtin_amdgcn_inverse_ballot_w64(idle) && trec < NREC) { lds[cbase + 2 * trec] = c0; lds[cbase + 2 * trec + 1] = c1; }
+        if (!__builtin_amdgcn_inverse_ballot_w64(idle) && trec < NREC && !(dbg_flags & 2)) { lds[cbase + 2 * trec] = c0; lds[cbase + 2 * trec + 1] = c1; }
       }
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
@@ -530,7 +567,7 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_min
     }
     ++gstep;
   }
-  if (WFA_LANE_DEBUG_COUNTERS && a.hist) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.hist), (unsigned long long)gstep); }
+  if (WFA_LANE_DEBUG_COUNTERS && !FULL && a.hist) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.hist), (unsigned long long)gstep); }
 }
 
 // per-shape entry points (csrc/k_lane.hip compiled once per shape index of WFA_SEG_SHAPES)
@@ -562,25 +599,25 @@ inline int lane_full_records(int OE, int E) { return 2 * (OE - E) + E * 17 + 1; 
 #define WFA_LANE_RUN_SLOT 32
 
 // full = the FULL form: a.hist = run-record slots (a.hist_stride ints each, slot = work item - a.work_begin), a.end_state per slot
-inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full);
+inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full, int lds_pad_kb = 0);
 
 inline int launch_lane(int shape_idx, int g, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, const uint32_t* words,
                        const WfaPairMeta* meta, const uint32_t* worklist, const uint32_t* nwork_dev, uint32_t nwork,
-                       int32_t* score, int32_t* status, uint32_t* fb_list, uint32_t* fb_count, int32_t* debug_counters = nullptr) {
+                       int32_t* score, int32_t* status, uint32_t* fb_list, uint32_t* fb_count, int32_t* debug_counters = nullptr, int lds_pad_kb = 0) {
   FastArgs a;
   a.words = words; a.meta = meta; a.worklist = worklist; a.nwork_dev = nwork_dev; a.nwork = nwork;
   a.score = score; a.status = status; a.fb_list = fb_list; a.fb_count = fb_count;
   a.g = g;
   a.hist = debug_counters; a.hist_stride = 0; a.end_state = nullptr; a.work_begin = 0;
-  return launch_lane_args(shape_idx, 0, 0, cu_count, per_cu, refill_min, max_len, stream, a, false);
+  return launch_lane_args(shape_idx, 0, 0, cu_count, per_cu, refill_min, max_len, stream, a, false, lds_pad_kb);
 }
 
-inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full) {
+inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full, int lds_pad_kb) {
   const uint32_t nwork = a.nwork;
   const uint32_t* nwork_dev = a.nwork_dev;
   const int slot_words = lane_slot_words(std::min(max_len, WFA_FAST_MAX_LEN));
   const int lane_words = full ? ((slot_words + 2 * lane_full_records(OE, E)) | 1) : slot_words;   // (as the kernel computes it)
-  const size_t smem = ((size_t)64 * lane_words + 8) * sizeof(uint32_t);
+  const size_t smem = ((size_t)64 * lane_words + 8) * sizeof(uint32_t) + (size_t)lds_pad_kb * 1024;   // (lds_pad_kb: occupancy experiments)
   // every wave should see several hundred pairs (64 lanes x a few refills), and there should be several waves per SIMD
   long long grid = (long long)cu_count * per_cu;
   const long long max_grid = ((long long)nwork + 255) / 256;

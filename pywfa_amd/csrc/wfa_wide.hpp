@@ -30,6 +30,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <limits.h>
+#include <type_traits>
 #include "wfa_common.hpp"
 #include "wfa_hip.h"
 
@@ -51,7 +52,7 @@ struct WideArgs {
   int32_t* cigar_len;
   int32_t* hist;          // full scope: slice of workgroup b = hist + b * hist_stride (ints)
   long long hist_stride;
-  short* rows;            // rows in the HBM workspace (gap-affine-2p): slice of workgroup b = rows + b * rows_stride (halfs)
+  short* rows;            // rows in the HBM workspace: slice of workgroup b = rows + b * rows_stride (elements: int16, or int32 in the W32 form)
   long long rows_stride;
   int g, X, OE, E;        // score step and the penalties in steps
   int OE2, E2;            // gap-affine-2p: the second gap piece
@@ -82,9 +83,13 @@ static inline size_t wide_smem_bytes(int X, int OE, int E, int OE2, int E2, int 
 
 // FULL: piggy-back history + walk; TWO: gap-affine-2p (components M, I1, D1, I2, D2); GROWS: the rows live in the workgroup's
 // slice of the HBM workspace (L2-resident) instead of LDS — the 2p form: 37 rows x 20 000 diagonals for 10 kb reads
-template <bool FULL, bool TWO, bool GROWS>
+// W32: rows of int32 offsets (GROWS only): reads beyond 16 kb (plen + tlen > 32 000), any number of steps
+template <bool FULL, bool TWO, bool GROWS, bool W32 = false>
 __global__ void __launch_bounds__(1024)
 wfa_wide_kernel(const WideArgs a) {
+  static_assert(!W32 || GROWS, "int32 rows live in the workspace");
+  typedef typename std::conditional<W32, int, short>::type row_t;
+  constexpr int RNULL = W32 ? WFA_OFFSET_NULL : WFA_WIDE_NULL;
   constexpr int NC = TWO ? 5 : 3;
   extern __shared__ int wsm[];
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
@@ -96,9 +101,9 @@ wfa_wide_kernel(const WideArgs a) {
   int* const rhi = rlo + NR;
   uint32_t* const sP = reinterpret_cast<uint32_t*>(rhi + NR);
   uint32_t* const sT = sP + a.seq_words;
-  short* rows;
-  if constexpr (GROWS) rows = a.rows + (long long)blockIdx.x * a.rows_stride;
-  else rows = reinterpret_cast<short*>(sT + a.seq_words);
+  row_t* rows;
+  if constexpr (GROWS) rows = reinterpret_cast<row_t*>(a.rows) + (long long)blockIdx.x * a.rows_stride;   // (rows_stride in elements)
+  else rows = reinterpret_cast<row_t*>(sT + a.seq_words);
   const int NULLROW = NR - 1;
   const uint32_t nwork = a.nwork_dev ? *a.nwork_dev : a.nwork;
   int* const hist = FULL ? a.hist + (long long)blockIdx.x * a.hist_stride : nullptr;
@@ -120,12 +125,12 @@ wfa_wide_kernel(const WideArgs a) {
       const uint32_t* gt = a.words + pm.t_woff;
       for (int i = tid; i < a.seq_words; i += T) { sP[i] = (i < nwp) ? gp[i] : 0u; sT[i] = (i < nwt) ? gt[i] : 0u; }
       uint32_t* r32 = reinterpret_cast<uint32_t*>(rows);
-      const int n32 = NR * rw / 2;
-      for (int i = tid; i < n32; i += T) r32[i] = 0xC000C000u;   // NULL, NULL
+      const int n32 = W32 ? NR * rw : NR * rw / 2;
+      for (int i = tid; i < n32; i += T) r32[i] = W32 ? (uint32_t)WFA_OFFSET_NULL : 0xC000C000u;   // NULL (, NULL)
       for (int i = tid; i < NR; i += T) { rlo[i] = 1; rhi[i] = -1; }
       if (tid < 22) ctrl[tid] = (tid >= 20 || (tid % 10) < NC) ? INT_MAX : INT_MIN;
     }
-    bool hand_on = (plen + tlen > 32000) || (-pbf < kmin) || (tbf > kmax) || (ak < kmin) || (ak > kmax);
+    bool hand_on = (!W32 && plen + tlen > 32000) || (-pbf < kmin) || (tbf > kmax) || (ak < kmin) || (ak > kmax);
     int end_reason = 0;   // 1 reached, 3 handed on, 4 step limit
     int end_k = 0, end_t = 0;
     long long pb_used = 0;                                  // FULL: code bytes in use
@@ -141,7 +146,7 @@ wfa_wide_kernel(const WideArgs a) {
       int* const TRmax = TRmin + NC;
       // the limit is tested after compute-next of a score and before its extension (R/wavefront_unialign.c:98-107)
       if (t > 0 && s >= a.max_steps) { end_reason = 4; break; }
-      if (t > 16000) { end_reason = 3; break; }
+      if (!W32 && t > 16000) { end_reason = 3; break; }   // (int16 rows: a NULL gains at most 1 per step and must stay negative)
       // ---- rows of this step (M, I1, D1, I2, D2) and its inputs ----
       int rW[NC];
       rW[0] = t % NM; rW[1] = NM + t % NG1; rW[2] = NM + NG1 + t % NG1;
@@ -176,24 +181,24 @@ wfa_wide_kernel(const WideArgs a) {
         code_base = pb_used; pb_used += nb;
         if (tid == 0) { int* d = hist + a.hist_stride - 3ll * (t + 1); d[0] = (lo <= hi) ? lo : 1; d[1] = (lo <= hi) ? hi : 0; d[2] = (int)code_base; }
       }
-      short* wR[NC];
+      row_t* wR[NC];
 #pragma unroll
       for (int c = 0; c < NC; ++c) wR[c] = rows + (long long)rW[c] * rw + koff;
-      const short* const pX = rows + (long long)iX * rw + koff;
-      const short* const pO = rows + (long long)iO * rw + koff;
-      const short* const pI = rows + (long long)iI * rw + koff;
-      const short* const pD = rows + (long long)iD * rw + koff;
-      const short* const pO2 = rows + (long long)iO2 * rw + koff;
-      const short* const pI2 = rows + (long long)iI2 * rw + koff;
-      const short* const pD2 = rows + (long long)iD2 * rw + koff;
+      const row_t* const pX = rows + (long long)iX * rw + koff;
+      const row_t* const pO = rows + (long long)iO * rw + koff;
+      const row_t* const pI = rows + (long long)iI * rw + koff;
+      const row_t* const pD = rows + (long long)iD * rw + koff;
+      const row_t* const pO2 = rows + (long long)iO2 * rw + koff;
+      const row_t* const pI2 = rows + (long long)iI2 * rw + koff;
+      const row_t* const pD2 = rows + (long long)iD2 * rw + koff;
       // stale cells of the rows written now (their previous wavefronts) outside the range written below
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int olo = rlo[rW[c]], ohi = rhi[rW[c]];
         if (olo > ohi) continue;
-        if (lo > hi) { for (int k = olo + tid; k <= ohi; k += T) wR[c][k] = (short)WFA_WIDE_NULL; continue; }
-        for (int k = olo + tid; k <= min(ohi, lo - 1); k += T) wR[c][k] = (short)WFA_WIDE_NULL;
-        for (int k = max(olo, hi + 1) + tid; k <= ohi; k += T) wR[c][k] = (short)WFA_WIDE_NULL;
+        if (lo > hi) { for (int k = olo + tid; k <= ohi; k += T) wR[c][k] = (row_t)RNULL; continue; }
+        for (int k = olo + tid; k <= min(ohi, lo - 1); k += T) wR[c][k] = (row_t)RNULL;
+        for (int k = max(olo, hi + 1) + tid; k <= ohi; k += T) wR[c][k] = (row_t)RNULL;
       }
       // ---- the pass: compute, clamp, extend, store; trimmed limits by wave ballots ----
       int wmin[NC], wmax[NC];   // (wave-uniform)
@@ -204,7 +209,7 @@ wfa_wide_kernel(const WideArgs a) {
         const bool in = k <= hi;
         int v5[NC];   // M, I1, D1, I2, D2 of this diagonal
 #pragma unroll
-        for (int c = 0; c < NC; ++c) v5[c] = WFA_WIDE_NULL;
+        for (int c = 0; c < NC; ++c) v5[c] = RNULL;
         int code = 0;
         if (in) {
           if (t == 0) {
@@ -245,7 +250,7 @@ wfa_wide_kernel(const WideArgs a) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) inb[c] = (uint32_t)(v5[c] - base) <= span && kin;
         const bool m_in = inb[0];
-        if (!m_in) v5[0] = WFA_WIDE_NULL;       // only M is clamped (R/wavefront_compute_affine.c:80-84)
+        if (!m_in) v5[0] = RNULL;               // only M is clamped (R/wavefront_compute_affine.c:80-84)
         unsigned long long bm = 0;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -291,7 +296,7 @@ wfa_wide_kernel(const WideArgs a) {
           // (negative gap values are stored as they are: they start at NULL and gain at most 1 per step, so they stay
           // negative for the 16 000 steps a pair may take here, and a negative offset is never in bounds)
 #pragma unroll
-          for (int c = 0; c < NC; ++c) wR[c][k] = (short)v5[c];
+          for (int c = 0; c < NC; ++c) wR[c][k] = (row_t)v5[c];
           if (FULL) pb_codes[code_base + (k - lo)] = (uint8_t)code;
         }
       }
@@ -314,10 +319,10 @@ wfa_wide_kernel(const WideArgs a) {
 #pragma unroll
         for (int c = 1; c < NC; ++c) {
           const int l = tlo[c], h2 = thi[c];
-          if (l > h2) { for (int k = lo + tid; k <= hi; k += T) wR[c][k] = (short)WFA_WIDE_NULL; }
+          if (l > h2) { for (int k = lo + tid; k <= hi; k += T) wR[c][k] = (row_t)RNULL; }
           else {
-            for (int k = lo + tid; k < l; k += T) wR[c][k] = (short)WFA_WIDE_NULL;
-            for (int k = h2 + 1 + tid; k <= hi; k += T) wR[c][k] = (short)WFA_WIDE_NULL;
+            for (int k = lo + tid; k < l; k += T) wR[c][k] = (row_t)RNULL;
+            for (int k = h2 + 1 + tid; k <= hi; k += T) wR[c][k] = (row_t)RNULL;
           }
         }
       }
@@ -414,6 +419,6 @@ wfa_wide_kernel(const WideArgs a) {
 }
 
 // host entry point (csrc/k_wide.hip): two = gap-affine-2p with the rows in the HBM workspace
-int launch_wide(bool full, bool two, const WideArgs& a, int grid, int threads, size_t smem, hipStream_t stream);
+int launch_wide(bool full, bool two, const WideArgs& a, int grid, int threads, size_t smem, hipStream_t stream, bool w32 = false);
 
 }  // namespace wfa

@@ -114,3 +114,26 @@ def test_wide_kernel_10kb_exact_sample(gpu):
         # every pair: full and score scopes agree (checked through the second pass of the loop)
         if scope == "score": s_score = score
         else: assert np.array_equal(s_score, score)
+
+
+@pytest.mark.parametrize("kw", [dict(span="end-to-end", scope="score"), dict(span="end-to-end", scope="full"),
+                                dict(distance="affine2p", span="ends-free", pattern_end_free=50, text_end_free=50, scope="score")])
+def test_exact_reads_beyond_16kb_take_the_int32_rows(gpu, kw):
+    """Exact (no heuristic) alignment of reads beyond 16 kb (plen + tlen > 32 000 does not fit int16 rows): the workspace-row
+    form of the wide-wavefront kernel with int32 offsets against the oracle, score and full CIGAR; nothing
+    is left to the general kernel."""
+    batch = datagen.generate(5, 30000, 0.06, 8801)
+    oc, nc = common.configs_pair(**kw)
+    o = loader.run(loader.oracle(), oc, batch)
+    al = _native.Aligner(nc)
+    rb = al.batch(batch)
+    rb.run(); rb.sync()
+    full = oc.scope == 1
+    score, status, cig = rb.results(full)
+    assert rb.fallback_pairs() == 0
+    rb.close(); al.close()
+    cigars = None
+    if full:
+        ops, cb, cl = cig
+        cigars = [ops[cb[i]:cb[i] + cl[i]].tobytes() for i in range(len(score))]
+    common.assert_same(o, score, status, cigars, batch, f"30 kb exact {kw}")

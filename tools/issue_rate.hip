@@ -41,6 +41,8 @@ __global__ void __launch_bounds__(1024) k_issue(int* sink) {
   if (KIND == 9) { BODY("v_lshlrev_b32 %0, 1, %0", "v_lshrrev_b32 %1, 1, %1", "v_ashrrev_i32 %2, 1, %2", "v_lshlrev_b32 %3, 3, %3") }
   if (KIND == 10) { BODY("v_sub_u32 %0, %0, %4", "v_sub_u32 %1, %1, %4", "v_add3_u32 %2, %2, %4, %5", "v_lshl_add_u32 %3, %3, 2, %4") }
   if (KIND == 11) { BODY("v_cmp_gt_i32 vcc, %0, %4", "v_cndmask_b32 %1, %1, %5, vcc", "v_cmp_lt_i32 vcc, %2, %4", "v_cndmask_b32 %3, %3, %5, vcc") }
+  if (KIND == 12) { BODY("v_mov_b32 %0, %1", "v_mov_b32 %1, %2", "v_mov_b32 %2, %3", "v_mov_b32 %3, %0") }
+  if (KIND == 13) { BODY("v_bfe_u32 %0, %0, 1, 31", "v_bfi_b32 %1, %4, %1, %5", "v_and_or_b32 %2, %2, %4, %5", "v_perm_b32 %3, %3, %5, %4") }
   if ((a0 ^ a1 ^ a2 ^ a3) == 0x12345) *sink = 1;
 }
 
@@ -65,20 +67,21 @@ int main() {
   hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
   const int cus = p.multiProcessorCount;
   printf("device %s, %d CUs; %d x 32 wave-instructions per wave; per SIMD = w waves\n", p.gcnArchName, cus, ITERS);
-  const char* names[12] = {"v_fma_f32", "v_max_i32", "v_alignbit_b32", "v_add_u32", "v_pk_max/add_i16", "v_cndmask_b32(sgpr mask)", "v_mov_b32_dpp", "ffbl/xor/min mix", "v_and/or/xor_b32", "v_lsh*_b32", "v_sub/add3/lshl_add", "v_cmp + v_cndmask(vcc)"};
-  double ms[12][4];
+  const char* names[14] = {"v_fma_f32", "v_max_i32", "v_alignbit_b32", "v_add_u32", "v_pk_max/add_i16", "v_cndmask_b32(sgpr mask)", "v_mov_b32_dpp", "ffbl/xor/min mix", "v_and/or/xor_b32", "v_lsh*_b32", "v_sub/add3/lshl_add", "v_cmp + v_cndmask(vcc)", "v_mov_b32", "v_bfe/bfi/and_or/perm"};
+  double ms[14][4];
   const int ws[4] = {1, 2, 4, 8};
   for (int wi = 0; wi < 4; ++wi) {
     const int w = ws[wi];
     ms[0][wi] = run_kind<0>(cus, w); ms[1][wi] = run_kind<1>(cus, w); ms[2][wi] = run_kind<2>(cus, w); ms[3][wi] = run_kind<3>(cus, w);
     ms[4][wi] = run_kind<4>(cus, w); ms[5][wi] = run_kind<5>(cus, w); ms[6][wi] = run_kind<6>(cus, w); ms[7][wi] = run_kind<7>(cus, w);
     ms[8][wi] = run_kind<8>(cus, w); ms[9][wi] = run_kind<9>(cus, w); ms[10][wi] = run_kind<10>(cus, w); ms[11][wi] = run_kind<11>(cus, w);
+    ms[12][wi] = run_kind<12>(cus, w); ms[13][wi] = run_kind<13>(cus, w);
   }
   // yardstick: v_fma_f32 at 4 waves per SIMD = 2 cycles per wave-instruction per SIMD
   const double insts4 = (double)ITERS * 32 * 4;
   const double clock_ghz = insts4 * 2.0 / (ms[0][2] * 1e6);
   printf("implied shader clock from v_fma_f32 @ 4 waves/SIMD = 2 cycles: %.3f GHz\n", clock_ghz);
-  for (int k = 0; k < 12; ++k) {
+  for (int k = 0; k < 14; ++k) {
     printf("%-26s", names[k]);
     for (int wi = 0; wi < 4; ++wi) {
       const double insts = (double)ITERS * 32 * ws[wi];
