@@ -42,7 +42,7 @@ static thread_local std::string g_error;
   F(ARENA_KB) F(BAND_DEBUG) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
-  F(LANE_FULL) F(LANE_LDS_PAD_KB) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
+  F(LANE_FULL) F(LANE_LDS_PAD_KB) F(WIDE2) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
 enum WfaKnob {
 #define WFA_KNOB_ENUM(n) K_##n,
   WFA_KNOBS(WFA_KNOB_ENUM)
@@ -1712,7 +1712,11 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       wa.ef = b->dcfg.endsfree ? 1 : 0;
       wa.pbf = b->dcfg.pbf; wa.pef = b->dcfg.pef; wa.tbf = b->dcfg.tbf; wa.tef = b->dcfg.tef;
       wa.max_steps = b->dcfg.max_steps;
-      if (wfa::launch_wide(full, wide_two, wa, st.grid, st.threads, st.smem, stream, st.w32) != 0) { al->err = "wide kernel launch failed"; return WFA_HIP_EDEVICE; }
+      // gap-affine with int16 rows: the packed form (two diagonals per lane, one barrier per step; WFA_HIP_WIDE2=0: round 2's form)
+      const bool wide2 = !wide_two && !st.w32 && knob(al, K_WIDE2, 1) != 0;
+      const int wrc = wide2 ? wfa::launch_wide2(full, wa, st.grid, st.threads, st.smem, stream)
+                            : wfa::launch_wide(full, wide_two, wa, st.grid, st.threads, st.smem, stream, st.w32);
+      if (wrc != 0) { al->err = "wide kernel launch failed"; return WFA_HIP_EDEVICE; }
       if (first_stage) b->last_kernel_pairs = in_n;
       in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
     }
