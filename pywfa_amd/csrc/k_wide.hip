@@ -1,6 +1,5 @@
 // k_wide.hip — translation unit of the wide-wavefront kernel (wfa_wide.hpp).
 #include "wfa_wide.hpp"
-#include "wfa_wide2.hpp"
 
 namespace wfa {
 template <bool FULL, bool TWO, bool GROWS, bool W32 = false>
@@ -12,20 +11,6 @@ static int launch_wide_t(const WideArgs& a, int grid, int threads, size_t smem, 
   }
   hipLaunchKernelGGL((wfa_wide_kernel<FULL, TWO, GROWS, W32>), dim3(grid), dim3(threads), smem, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
-}
-template <bool FULL, bool GROWS>
-static int launch_wide2_t(const WideArgs& a, int grid, int threads, size_t smem, hipStream_t stream) {
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wfa_wide2_kernel<FULL, GROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
-    (void)hipGetLastError();
-    return -1;
-  }
-  hipLaunchKernelGGL((wfa_wide2_kernel<FULL, GROWS>), dim3(grid), dim3(threads), smem, stream, a);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
-}
-// the packed form (wfa_wide2.hpp): gap-affine, int16 rows in LDS (a.rows == nullptr) or in the workspace
-int launch_wide2(bool full, const WideArgs& a, int grid, int threads, size_t smem, hipStream_t stream) {
-  if (a.rows) return full ? launch_wide2_t<true, true>(a, grid, threads, smem, stream) : launch_wide2_t<false, true>(a, grid, threads, smem, stream);
-  return full ? launch_wide2_t<true, false>(a, grid, threads, smem, stream) : launch_wide2_t<false, false>(a, grid, threads, smem, stream);
 }
 int launch_wide(bool full, bool two, const WideArgs& a, int grid, int threads, size_t smem, hipStream_t stream, bool w32) {
   if (w32) {   // int32 rows in the workspace: reads beyond 16 kb

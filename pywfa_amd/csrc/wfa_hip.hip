@@ -42,7 +42,7 @@ static thread_local std::string g_error;
   F(ARENA_KB) F(BAND_DEBUG) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
-  F(LANE_FULL) F(LANE_LDS_PAD_KB) F(WIDE2) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
+  F(LANE_FULL) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
 enum WfaKnob {
 #define WFA_KNOB_ENUM(n) K_##n,
   WFA_KNOBS(WFA_KNOB_ENUM)
@@ -1400,7 +1400,19 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       const int64_t budget = free_budget(al);
       const int full_range = (2 * b->max_len + 8 + b->dcfg.pbf + b->dcfg.tbf) & ~1;
       bool lds_covers_all = false;
-      if (!wide_two && !wide32 && knob(al, K_WIDE_GROWS, 0) == 0) {
+      // Round 3: the pass of a step is a short dependent chain (row reads -> recurrences -> sequence reads -> stores -> barrier),
+      // so a CU is kept busy by MANY pairs in flight, not by many threads on one pair: with rows in the workspace (L2) a workgroup
+      // needs only its sequences in LDS, and 8 workgroups of 256 threads per CU align 10 kb reads 1.6x faster than one workgroup
+      // of 1 024 threads with its rows in LDS (36.8 k vs 23.3 k aln/s; gap-affine-2p: 4 x 512 threads, +25 %).  The LDS form
+      // (north_star's layout) remains what a small batch gets: all of a CU's threads on one pair is the shortest latency.
+      // WFA_HIP_WIDE_GROWS: 1 = workspace rows always, 0 = LDS rows first always
+      const int grows_knob = knob(al, K_WIDE_GROWS, -1);
+      const bool many_pairs = (int64_t)in_n >= (int64_t)al->cu_count * 4;
+      const bool prefer_ws = grows_knob >= 0 ? grows_knob != 0 : many_pairs;
+      int ws_threads = 1024;   // the largest workgroup that still leaves no workgroup slot of the chip empty
+      for (int tcand = wide_two ? 512 : 256; tcand < 1024; tcand *= 2)
+        if ((int64_t)al->cu_count * (2048 / tcand) <= (int64_t)in_n) { ws_threads = tcand; break; }
+      if (!wide_two && !wide32 && !prefer_ws) {
         WideStage& st = wide_stage[n_wide];
         st.a = w0;
         const size_t lds_max = (size_t)std::min(160, std::max(16, knob(al, K_WIDE_LDS_KB, 160))) * 1024;
@@ -1434,7 +1446,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         const int64_t row_bytes = wide32 ? 4 : 2;   // bytes per offset
         st.smem = wfa::wide_smem_bytes(w0.X, w0.OE, w0.E, w0.OE2, w0.E2, full_range, w0.seq_words, false);
         const bool seqs_fit_lds = st.smem <= (size_t)160 * 1024;   // (both packed sequences are staged in LDS: reads up to ~300 kb)
-        st.threads = knob(al, K_WIDE_THREADS, 1024);
+        st.threads = knob(al, K_WIDE_THREADS, ws_threads);
         st.grid = (int)std::min<int64_t>((int64_t)al->cu_count * std::max<int64_t>(1, std::min<int64_t>(2048 / st.threads, (160 * 1024) / std::max<size_t>(st.smem, 1))), in_n);
         int64_t hist_bytes = 0;
         if (full) hist_bytes = (int64_t)full_range * ((int64_t)(b->max_len * 0.9) / w0.g + 64) / 2 + (1 << 20);   // one byte per cell, + directory + events
@@ -1504,7 +1516,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       for (int64_t w0 = 0; w0 < (int64_t)in_n; w0 += lanefull_cap) {
         const uint32_t cnt = (uint32_t)std::min<int64_t>(lanefull_cap, (int64_t)in_n - w0);
         fa.work_begin = (uint32_t)w0; fa.nwork = cnt;
-        if (wfa::launch_lane_args(shape, OE, E, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8) | ((knob(al, K_LANE_DEBUG, 0) >> 4) << 8), b->max_len, stream, fa, true) != 0) {
+        if (wfa::launch_lane_args(shape, OE, E, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8) | ((knob(al, K_LANE_DEBUG, 0) >> 4) << 8), b->max_len, stream, fa, true, 0, knob(al, K_LANE_MIN_PAIRS, 0)) != 0) {
           al->err = "lane kernel launch failed"; return WFA_HIP_EDEVICE;
         }
         ba.work_begin = (uint32_t)w0; ba.nwork = cnt;
@@ -1712,11 +1724,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       wa.ef = b->dcfg.endsfree ? 1 : 0;
       wa.pbf = b->dcfg.pbf; wa.pef = b->dcfg.pef; wa.tbf = b->dcfg.tbf; wa.tef = b->dcfg.tef;
       wa.max_steps = b->dcfg.max_steps;
-      // gap-affine with int16 rows: the packed form (two diagonals per lane, one barrier per step; WFA_HIP_WIDE2=0: round 2's form)
-      const bool wide2 = !wide_two && !st.w32 && knob(al, K_WIDE2, 1) != 0;
-      const int wrc = wide2 ? wfa::launch_wide2(full, wa, st.grid, st.threads, st.smem, stream)
-                            : wfa::launch_wide(full, wide_two, wa, st.grid, st.threads, st.smem, stream, st.w32);
-      if (wrc != 0) { al->err = "wide kernel launch failed"; return WFA_HIP_EDEVICE; }
+      if (wfa::launch_wide(full, wide_two, wa, st.grid, st.threads, st.smem, stream, st.w32) != 0) { al->err = "wide kernel launch failed"; return WFA_HIP_EDEVICE; }
       if (first_stage) b->last_kernel_pairs = in_n;
       in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
     }

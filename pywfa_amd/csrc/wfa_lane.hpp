@@ -599,7 +599,7 @@ inline int lane_full_records(int OE, int E) { return 2 * (OE - E) + E * 17 + 1; 
 #define WFA_LANE_RUN_SLOT 32
 
 // full = the FULL form: a.hist = run-record slots (a.hist_stride ints each, slot = work item - a.work_begin), a.end_state per slot
-inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full, int lds_pad_kb = 0);
+inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full, int lds_pad_kb = 0, int min_pairs = 0);
 
 inline int launch_lane(int shape_idx, int g, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, const uint32_t* words,
                        const WfaPairMeta* meta, const uint32_t* worklist, const uint32_t* nwork_dev, uint32_t nwork,
@@ -612,7 +612,7 @@ inline int launch_lane(int shape_idx, int g, int cu_count, int per_cu, int refil
   return launch_lane_args(shape_idx, 0, 0, cu_count, per_cu, refill_min, max_len, stream, a, false, lds_pad_kb);
 }
 
-inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full, int lds_pad_kb) {
+inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full, int lds_pad_kb, int min_pairs) {
   const uint32_t nwork = a.nwork;
   const uint32_t* nwork_dev = a.nwork_dev;
   const int slot_words = lane_slot_words(std::min(max_len, WFA_FAST_MAX_LEN));
@@ -620,7 +620,10 @@ inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_
   const size_t smem = ((size_t)64 * lane_words + 8) * sizeof(uint32_t) + (size_t)lds_pad_kb * 1024;   // (lds_pad_kb: occupancy experiments)
   // every wave should see several hundred pairs (64 lanes x a few refills), and there should be several waves per SIMD
   long long grid = (long long)cu_count * per_cu;
-  const long long max_grid = ((long long)nwork + 255) / 256;
+  // a wave should see a few refills' worth of pairs: 256 in the score-only form; the FULL form holds fewer waves per CU (its
+  // records live in LDS), so shorter slices balance better there (1 M pairs: 64 per wave -7 %)
+  if (min_pairs <= 0) min_pairs = full ? 64 : 256;
+  const long long max_grid = ((long long)nwork + min_pairs - 1) / std::max(min_pairs, 64);
   if (!nwork_dev && grid > max_grid) grid = max_grid;
   if (grid < 1) grid = 1;
   switch (shape_idx) {

@@ -420,6 +420,5 @@ wfa_wide_kernel(const WideArgs a) {
 
 // host entry point (csrc/k_wide.hip): two = gap-affine-2p with the rows in the HBM workspace
 int launch_wide(bool full, bool two, const WideArgs& a, int grid, int threads, size_t smem, hipStream_t stream, bool w32 = false);
-int launch_wide2(bool full, const WideArgs& a, int grid, int threads, size_t smem, hipStream_t stream);   // the packed form (wfa_wide2.hpp)
 
 }  // namespace wfa

@@ -38,6 +38,27 @@ def test_c4_as_written_exact_full_cigar(gpu):
         common.assert_same(o, score, status, cigars, batch, f"C4 exact resident={resident}")
 
 
+def test_c4_as_written_64_pairs_vs_the_real_library(gpu):
+    """the newest path (gap-affine-2p wide kernel: workspace rows, seven-bit origin codes, five-component
+    walk) on 64 pairs of C4 as BASELINE writes it, against the real WFA2-lib run on every host thread (scores, statuses and op
+    strings); falls back on the oracle where the reference build did not travel."""
+    batch = c4_batch(64)
+    oc, nc = common.configs_pair(**C4_KW)
+    if loader.have_reference():
+        o = loader.reference_mt_full(oc, batch)
+    else:
+        o = loader.run(loader.oracle(), oc, batch)
+    al = _native.Aligner(nc)
+    rb = al.batch(batch)
+    rb.run(); rb.sync()
+    score, status, (ops, cbeg, clen) = rb.results(True)
+    assert rb.fallback_pairs() == 0
+    rb.close(); al.close()
+    cigars = [ops[cbeg[i]:cbeg[i] + clen[i]].tobytes() for i in range(len(score))]
+    common.assert_same(o, score, status, cigars, batch, "C4 as written, 64 pairs")
+    assert (status == 0).all()
+
+
 @pytest.mark.parametrize("memory_mode", ["medium", "low"])
 def test_c4_exact_low_memory_modes(gpu, memory_mode):
     """memory_mode medium / low (piggy-back history) returns the same alignments for gap-affine-2p."""

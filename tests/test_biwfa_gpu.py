@@ -52,6 +52,17 @@ def test_biwfa_long_reads_and_memory(gpu):
     assert np.array_equal(score_h, score)
 
 
+def test_biwfa_100kb_vs_the_real_library(gpu):
+    """SURVEY §8 f4 names BiWFA "for 100 kb+": four 100 kb pairs at 8 % (scores ~ 45 k, the recursion splits nine levels deep)
+    against the real library in its ultralow mode (all host threads; the oracle where the reference build did not travel)."""
+    batch = datagen.generate(4, 100000, 0.08, 1005)
+    oc, nc = common.configs_pair(span="end-to-end", scope="full", memory_mode="biwfa")
+    o = loader.reference_mt_full(oc, batch) if loader.have_reference() else loader.run(loader.oracle(), oc, batch)
+    score, status, cigars = common.gpu_run(nc, batch, True, resident=True)
+    common.assert_same(o, score, status, cigars, batch, "biwfa 100 kb")
+    assert (status == 0).all()
+
+
 def test_biwfa_python_surface(gpu):
     import pywfa_amd
     p = "TCTTTACTCGCGCGTTGGAGAAATACAATAGT" * 8

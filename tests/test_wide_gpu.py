@@ -137,3 +137,21 @@ def test_exact_reads_beyond_16kb_take_the_int32_rows(gpu, kw):
         ops, cb, cl = cig
         cigars = [ops[cb[i]:cb[i] + cl[i]].tobytes() for i in range(len(score))]
     common.assert_same(o, score, status, cigars, batch, f"30 kb exact {kw}")
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 8, 9, 10, 12, 15])
+def test_wide_kernel_many_pairs_take_the_workspace_rows(gpu, idx, monkeypatch):
+    """Batches with pairs enough to fill every workgroup slot of the chip (>= 4 per CU) run the workspace-row form with small
+    workgroups (8 x 256 threads per CU for gap-affine, 4 x 512 for gap-affine-2p: many pairs in flight per CU) instead of one
+    1 024-thread workgroup with its rows in LDS; same results, nothing left to the general kernel; and the LDS form on the same
+    batch when it is forced."""
+    batch = ragged_batch(1100, 1800, 0.10, 9500 + idx)
+    kw = common.clamp_free(dict(CASES[idx]), batch)
+    oc, nc = common.configs_pair(**kw)
+    full = oc.scope == 1
+    o = loader.run(loader.oracle(), oc, batch, want_cigar=full)
+    for env in ({}, {"WFA_HIP_WIDE_GROWS": "0"}):
+        for k_, v_ in env.items(): monkeypatch.setenv(k_, v_)
+        score, status, cigars = common.gpu_run(nc, batch, full, resident=True)
+        for k_ in env: monkeypatch.delenv(k_)
+        common.assert_same(o, score, status, cigars, batch, f"wide, many pairs {kw} {env}")

@@ -1,18 +1,13 @@
 export NO_CPU=1 BRIEF=1 TMPDIR=/tmp
-O=gpurun_out/r3f
+O=gpurun_out/r3i
 run() { echo "== $*" >> $O.log; env "$@" python tools/gpu_perf.py $CFG >> $O.log 2>&1; }
 rm -f $O.log
-CFG=N150
-run A=1
-run WFA_HIP_LANE_LDS_PAD_KB=5
-run WFA_HIP_LANE_LDS_PAD_KB=8
-run WFA_HIP_LANE_LDS_PAD_KB=12
-run WFA_HIP_LANE_LDS_PAD_KB=20
-CFG=C1
-run A=1
-run WFA_HIP_LANE_DEBUG=16
-run WFA_HIP_LANE_DEBUG=32
-run WFA_HIP_LANE_DEBUG=48
+CFG=C3x
+for w2 in 0 1; do for th in 128 256 384 512; do run WFA_HIP_WIDE2=$w2 WFA_HIP_WIDE_GROWS=1 WFA_HIP_WIDE_THREADS=$th; done; done
+CFG=C3xf
+for w2 in 0 1; do for th in 256 512; do run WFA_HIP_WIDE2=$w2 WFA_HIP_WIDE_GROWS=1 WFA_HIP_WIDE_THREADS=$th; done; done
+CFG=C4xs
+for th in 256 512 1024; do run WFA_HIP_WIDE_THREADS=$th; done
+CFG=C4x
+for th in 512 1024; do run WFA_HIP_WIDE_THREADS=$th; done
 cat $O.log
-timeout 600 python -m pytest tests/test_wide_gpu.py -m gpu -x -q -k "beyond_16kb" 2>&1 | tail -5
-BRIEF=1 NO_CPU= timeout 900 python tools/gpu_perf.py X30k X30kf X100k 2>&1 | tail -5
