@@ -36,6 +36,10 @@ struct FastArgs {
   long long hist_stride;  // ints per slot
   int4* end_state;        // per slot {end score, end k, end offset, 1 = walk it}
   uint32_t work_begin;    // first work item of this launch (slot = item - work_begin)
+  // the general score-only form of the lane kernel (wfa_lane_kernel<.., HEUR>): free ends, wf-adaptive, step limit
+  int ef, pbf, pef, tbf, tef;                                // ends-free span with these free ends (R/wavefront_termination.c:115-162)
+  int heur, min_wf_len, max_dist_thr, steps_between;         // 1 = wf-adaptive (R/wavefront_heuristic.c:257-293)
+  int max_steps;                                             // INT_MAX = unlimited (R/wavefront_unialign.c:98-107)
 };
 
 // neighbour diagonals inside a segment of W lanes (wfa_seg.hpp): lanes at a segment border receive NULL

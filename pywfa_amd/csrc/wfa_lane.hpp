@@ -22,6 +22,14 @@
 // a score is kept only if S' <= Bmin = min(2o + e(2c + 16 - ak), 2o + e(18 - 2c + ak)), otherwise the pair is handed
 // to the next stage (32- / 64-lane segments, banded, general kernel) — every stage computes the same wavefronts.
 //
+// HEUR (round 3; score only): the same layout for what the band bound cannot prove — wf-adaptive (R/wavefront_heuristic.c:257-293),
+// ends-free spans with free ends (R/wavefront_aligner.c:259-302, R/wavefront_termination.c:115-162) and a step limit
+// (R/wavefront_unialign.c:98-107).  A heuristic result is not the optimum, so "S' <= Bmin" proves nothing; instead the band must
+// hold the WHOLE wavefront: the pair is handed on the moment a cell of its outermost slots (0 or 15) comes alive — until then no
+// cell outside the band can exist, and everything computed equals the unbanded computation, cut-offs included.  The cut-off per
+// pair: live slots by sign bits, distances max(plen - v, tlen - h) on packed halves, first / last slot within max_distance of the
+// best, the dropped slots set to NULL in M, I and D (the equate, :161-172).
+//
 // FULL (round 3): full CIGARs of short reads in the same layout, with the piggy-back history of the long-read kernels
 // (R/wavefront_backtrace_offload.c:39-73, R/wavefront_pcigar.c:204-266): compute-next also records, per cell, which
 // candidate the backtrace would take (R/wavefront_backtrace.c:49-59: mismatch > deletion > insertion on equal offsets, extension
@@ -102,9 +110,10 @@ __device__ __forceinline__ uint32_t pk_clamp(uint32_t nm, uint32_t lim) {
 template <int OE, int E>
 struct LaneFull { static constexpr int NREC = 2 * (OE - E) + E * 17 + 1; };
 
-template <int X, int OE, int E, bool FULL>
+template <int X, int OE, int E, bool FULL, bool HEUR = false>
 __global__ void __launch_bounds__(64) WFA_LANE_OCCUPANCY
 wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg) {
+  static_assert(!(FULL && HEUR), "the general form is score only");
   const int refill_min = refill_arg & 0xff;
   const int dbg_flags = refill_arg >> 8;   // timing experiments only (WFA_HIP_LANE_DEBUG >> 4): 1 = skip the walks, 2 = skip the code stores
   constexpr int W = 16, H = 8, NR = 8;            // band of 16 diagonals = 8 packed registers
@@ -152,6 +161,10 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
   int jt = 0;                    // slot of the end diagonal tlen - plen
   uint32_t tend = 0xffffu;       // tlen: the offset that ends the alignment on slot jt (0xffff: no pair)
   int s0 = 0, deadline = NEVER;
+  // HEUR: termination thresholds per slot (an offset >= thr ends the alignment; 0x3fff: never), the packed plen + k and tlen
+  // of my pair, the cut-off countdown
+  uint32_t thr[HEUR ? NR : 1], my_lb2 = 0, my_tl2 = 0;
+  int steps_wait = 0, my_dinit = 0;
   uint32_t mypid = 0;
   unsigned long long idle = ~0ull;  // lanes without a pair
   int gstep = 0;
@@ -293,7 +306,12 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
       const int ak = tl - pl;
       // a pair this stage cannot take (too long for the slot, |tlen - plen| outside the band) gets an expired deadline:
       // the hand-over path below passes it on at once
-      const bool bad = n_ln == 0xffffffffu || ntot + 1 > slot_words_seq || ak < 1 - 2 * H || ak > 2 * H - 1;
+      // HEUR: the band is centred on the span from the lowest to the highest diagonal the alignment must touch (the free begins
+      // and the end diagonal), all of them at least one slot away from the edges
+      const int pbf_ = (HEUR && a.ef) ? a.pbf : 0, tbf_ = (HEUR && a.ef) ? a.tbf : 0;
+      const int dlo = min(-pbf_, ak), dhi = max(tbf_, ak);
+      const bool bad = n_ln == 0xffffffffu || ntot + 1 > slot_words_seq ||
+                       (HEUR ? (dhi - dlo > 2 * H - 3) : (ak < 1 - 2 * H || ak > 2 * H - 1));
       const unsigned long long tmask = __ballot(take);
       // packed words of every taken pair: one direct-to-LDS load each (lane j -> word j of the pair -> slot word j;
       // the text words of a pair follow its pattern words, csrc/wfa_hip.hip batch_build)
@@ -308,7 +326,7 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
         }
       }
       if (take) {
-        const int c = bad ? 0 : ((ak + 1) >> 1);      // band centre: k in [c - H, c + H)
+        const int c = bad ? 0 : (HEUR ? ((dlo + dhi + 1) >> 1) : ((ak + 1) >> 1));      // band centre: k in [c - H, c + H)
         const int k0 = c - H;                         // diagonal of slot 0
         mypid = n_pid; s0 = gstep;
         if (FULL) { myslot = next_i + rank; mypl = pl; }   // (slot = index of the work item in this launch)
@@ -317,6 +335,7 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
         tend = bad ? 0xffffu : (uint32_t)tl;
         // Bmin / g in units of g (o / g = OE - E, e / g = E), see wfa_seg.hpp
         deadline = bad ? gstep - 1
+                       : HEUR ? gstep + 4 * (pl + tl) + 64   // (no bound to prove: only a cap on the steps a pair may take here)
                        : gstep + min(2 * (OE - E) + E * (2 * c + 2 * H - ak), 2 * (OE - E) + E * (2 * H + 2 - 2 * c + ak))
                                - (FULL ? 1 : 0);   // FULL: S' < Bmin strictly, so that no co-optimal alignment leaves the band
         const int j0 = -k0;                           // slot of diagonal 0: the cell (score 0, offset 0)
@@ -326,9 +345,30 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
         const int j0r = bad ? -1 : (j0 >> 1);
         const uint32_t c0 = (j0 & 1) ? ((uint32_t)WFA_LANE_NULL16 & 0xffffu) : (WFA_LANE_NULL2 & 0xffff0000u);  // offset 0 in half j0 & 1
 #pragma unroll
+        if (HEUR) { my_lb2 = lb2; my_tl2 = tl2; steps_wait = a.steps_between; my_dinit = max(pl, tl); }
+#pragma unroll
         for (int r = 0; r < NR; ++r) {
           lim[r] = bad ? WFA_LANE_NULL2 : pk_min(tl2, pk_add(lb2, (uint32_t)(2 * r) * 0x00010001u));
           cur[r] = (j0r == r) ? c0 : WFA_LANE_NULL2;
+          if (HEUR) {
+            // wavefront 0 over the free begins (offset max(k, 0) on diagonals -pbf .. tbf) and the thresholds that end the alignment:
+            // end-to-end: offset tlen on the end diagonal; ends-free: h >= tlen with plen - v <= pef, or v >= plen with tlen - h <= tef,
+            // i.e. offset >= min(max(tlen, plen + k - pef), max(plen + k, tlen - tef))
+            uint32_t c2 = 0, t2 = 0;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const int k = k0 + 2 * r + q;
+              int w0v = (k == 0) ? 0 : WFA_LANE_NULL16;
+              if (a.ef && k >= -pbf_ && k <= tbf_) w0v = max(k, 0);
+              int th = (k == ak) ? tl : 0x3fff;
+              if (a.ef) th = min(max(tl, pl + k - a.pef), max(pl + k, tl - a.tef));
+              if (bad) { w0v = WFA_LANE_NULL16; th = 0x3fff; }
+              th = max(0, min(th, 0x3fff));
+              c2 |= ((uint32_t)w0v & 0xffffu) << (16 * q);
+              t2 |= ((uint32_t)th & 0xffffu) << (16 * q);
+            }
+            cur[r] = c2; thr[r] = t2;
+          }
 #pragma unroll
           for (int d = 0; d < DM; ++d) Mh[d][r] = WFA_LANE_NULL2;
 #pragma unroll
