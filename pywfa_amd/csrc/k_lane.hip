@@ -4,8 +4,8 @@
 
 namespace wfa {
 #define WFA_LANE_DEFINE(i, x, oe, e)                                                                                        \
-  int launch_lane_s##i(unsigned grid, size_t smem, hipStream_t stream, const FastArgs& a, int slot_words, int refill_min, bool full) { \
-    return launch_lane_shape<x, oe, e>(grid, smem, stream, a, slot_words, refill_min, full);                                          \
+  int launch_lane_s##i(unsigned grid, size_t smem, hipStream_t stream, const FastArgs& a, int slot_words, int refill_min, bool full, bool heur) { \
+    return launch_lane_shape<x, oe, e>(grid, smem, stream, a, slot_words, refill_min, full, heur);                                               \
   }
 #if WFA_TU_INDEX == 0
 WFA_LANE_DEFINE(0, 2, 4, 1)

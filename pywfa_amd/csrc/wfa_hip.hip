@@ -42,7 +42,7 @@ static thread_local std::string g_error;
   F(ARENA_KB) F(BAND_DEBUG) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
-  F(LANE_FULL) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
+  F(LANE_FULL) F(LANE_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
 enum WfaKnob {
 #define WFA_KNOB_ENUM(n) K_##n,
   WFA_KNOBS(WFA_KNOB_ENUM)
@@ -1298,6 +1298,12 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     // full CIGARs of short reads: the segmented kernel with a history slot per pair, then the thread-per-alignment walk
     const bool use_segfull = !tiny && full && wfa::seg_supported(b->dcfg, b->ncomp, false) && b->max_len <= WFA_FAST_MAX_LEN &&
                              knob(al, K_NO_FAST, 0) == 0 && knob(al, K_NO_SEGFULL, 0) == 0;
+    // Round 3: score-only short reads with wf-adaptive, free ends or a step limit — what the bound of the register kernels cannot
+    // prove — start in the general form of the lane kernel (wfa_lane_kernel<.., HEUR>: the pair is handed on the moment its
+    // wavefront touches the band's outermost slots); the banded stages take what it hands on
+    int lh_x, lh_oe, lh_e;
+    const bool use_laneh = !tiny && !full && !use_fast && wfa::lane_heur_config(b->dcfg, b->ncomp) && wfa::seg_shape(b->dcfg, &lh_x, &lh_oe, &lh_e) >= 0 &&
+                           b->max_len <= WFA_FAST_MAX_LEN && knob(al, K_NO_FAST, 0) == 0 && knob(al, K_LANE_HEUR, 1) != 0;
     if (!tiny && wfa::band_supported(b->dcfg, b->ncomp) && (b->ncomp != 5 || b->max_len < 32000) && knob(al, K_NO_BAND, 0) == 0) {
       if (b->ncomp == 5) {
         // gap-affine-2p wavefronts are wide (C4: 99 % need more than 108 diagonals, 2.6 % more than 172)
@@ -1319,7 +1325,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
                          b->max_len > 64 && 2 * (int64_t)b->max_len <= 0x3fffff00ll && b->dcfg.e1 >= 1 && b->dcfg.x >= 1 && knob(al, K_NO_WIDE, 0) == 0;
     // reads beyond 16 kb (plen + tlen > 32 000 does not fit int16 offsets): the workspace-row form with int32 rows (round 3)
     const bool wide32 = 2 * (int64_t)b->max_len > 32000;
-    const bool any_pre = use_fast || use_segfull || n_stages > 0 || wide_ok;
+    const bool any_pre = use_fast || use_laneh || use_segfull || n_stages > 0 || wide_ok;
     Geometry g = plan_general(al, b, any_pre ? std::min<uint32_t>(in_n, (uint32_t)al->cu_count * 16) : in_n, b->arena_fixed + b->arena_ints);
     size_t need = (size_t)g.grid * g.ws_stride * 4;
     // band history: fixed-stride records per score step, one slice per wave
@@ -1338,7 +1344,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       // dispatcher refills the CU, instead of a tail of lone waves (C1 +20 %, C3 +13 %)
       long long grid = (long long)al->cu_count * knob(al, K_BAND_WAVES_PER_CU, 128);
       grid = std::min<long long>(grid, in_n);
-      if (i > 0 || use_fast || use_segfull) grid = std::min<long long>(grid, (long long)al->cu_count * knob(al, K_BAND_LEFTOVER_WAVES_PER_CU, 64));
+      if (i > 0 || use_fast || use_laneh || use_segfull) grid = std::min<long long>(grid, (long long)al->cu_count * knob(al, K_BAND_LEFTOVER_WAVES_PER_CU, 64));
       if (full) {
         const bool h16 = b->max_len < 32000;
         const int rec = ((h16 && b->ncomp != 5) ? 2 : 4) * (band_nch[i] == 3 ? 256 : 64 * band_nch[i]);  // ints per record (2p: 16-byte entries)
@@ -1626,6 +1632,26 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         if (first_stage) b->last_kernel_pairs = in_n;
         in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
       }
+    }
+    if (use_laneh) {
+      uint32_t* out_list = b->d_fb_list2[out_sel];
+      uint32_t* out_count = b->d_counters + 4 + out_sel;
+      if (!first_stage) HIP_TRY(al, hipMemsetAsync(out_count, 0, sizeof(uint32_t), stream));
+      wfa::FastArgs fa;
+      memset(&fa, 0, sizeof(fa));
+      fa.words = b->d_words; fa.meta = b->d_meta; fa.worklist = in_list; fa.nwork_dev = in_count; fa.nwork = in_n;
+      fa.score = b->d_score; fa.status = b->d_status; fa.fb_list = out_list; fa.fb_count = out_count;
+      fa.g = wfa::gcd_int(wfa::gcd_int(b->dcfg.x, b->dcfg.o1 + b->dcfg.e1), b->dcfg.e1);
+      fa.ef = (b->dcfg.endsfree && (b->dcfg.pbf | b->dcfg.pef | b->dcfg.tbf | b->dcfg.tef)) ? 1 : 0;
+      fa.pbf = b->dcfg.pbf; fa.pef = b->dcfg.pef; fa.tbf = b->dcfg.tbf; fa.tef = b->dcfg.tef;
+      fa.heur = b->dcfg.heuristic; fa.min_wf_len = b->dcfg.min_wf_len; fa.max_dist_thr = b->dcfg.max_dist_thr;
+      fa.steps_between = b->dcfg.steps_between; fa.max_steps = b->dcfg.max_steps;
+      const int shape = wfa::seg_shape(b->dcfg, &lh_x, &lh_oe, &lh_e);
+      if (wfa::launch_lane_args(shape, lh_oe, lh_e, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, fa, false, 0, 256, true) != 0) {
+        al->err = "lane kernel launch failed"; return WFA_HIP_EDEVICE;
+      }
+      if (first_stage) b->last_kernel_pairs = in_n;
+      in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
     }
     DualStream pending_walks{al, stream};   // walks of a split stage left running under the band stages behind it
     for (int i = 0; i < n_stages; ++i) {

@@ -45,6 +45,7 @@
 #include <limits.h>
 #include <algorithm>
 #include "wfa_common.hpp"
+#include "wfa_hip.h"
 #include "wfa_fast.hpp"
 
 namespace wfa {
@@ -149,9 +150,11 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
   // ---- per-lane state
   const int pbase = (4 + lane * slot_words) * 16;  // base coordinate (in bases) of my LDS slot
   uint32_t cur[NR], lim[NR], Mh[DM][NR], Ih[E][NR], Dh[E][NR];
+  uint32_t thr[HEUR ? NR : 1];   // HEUR: termination thresholds per slot, two per register
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     cur[r] = WFA_LANE_NULL2; lim[r] = WFA_LANE_NULL2;
+    if (HEUR) thr[r] = 0x3fff3fffu;
 #pragma unroll
     for (int d = 0; d < DM; ++d) Mh[d][r] = WFA_LANE_NULL2;
 #pragma unroll
@@ -163,8 +166,9 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
   int s0 = 0, deadline = NEVER;
   // HEUR: termination thresholds per slot (an offset >= thr ends the alignment; 0x3fff: never), the packed plen + k and tlen
   // of my pair, the cut-off countdown
-  uint32_t thr[HEUR ? NR : 1], my_lb2 = 0, my_tl2 = 0;
+  uint32_t my_lb2 = 0, my_tl2 = 0;
   int steps_wait = 0, my_dinit = 0;
+  bool edge_live = false;
   uint32_t mypid = 0;
   unsigned long long idle = ~0ull;  // lanes without a pair
   int gstep = 0;
@@ -344,7 +348,6 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
         const uint32_t tl2 = (uint32_t)tl | ((uint32_t)tl << 16);
         const int j0r = bad ? -1 : (j0 >> 1);
         const uint32_t c0 = (j0 & 1) ? ((uint32_t)WFA_LANE_NULL16 & 0xffffu) : (WFA_LANE_NULL2 & 0xffff0000u);  // offset 0 in half j0 & 1
-#pragma unroll
         if (HEUR) { my_lb2 = lb2; my_tl2 = tl2; steps_wait = a.steps_between; my_dinit = max(pl, tl); }
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -504,14 +507,28 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
     // =================== termination / hand-over ===================
     {
       // R/wavefront_termination.c:37-61: the cell of the end diagonal (slot jt) has reached offset tlen
-      uint32_t sel = cur[0];
+      uint32_t endv = 0;
+      bool hit = false;
+      if constexpr (HEUR) {
+        // some slot has reached its threshold (ends-free: R/wavefront_termination.c:115-162; the score does not depend on which)
+        uint32_t acc = 0;
 #pragma unroll
-      for (int r = 1; r < NR; ++r) sel = ((jt >> 1) == r) ? cur[r] : sel;
-      const uint32_t endv = (jt & 1) ? (sel >> 16) : (sel & 0xffffu);
+        for (int r = 0; r < NR; ++r) acc |= ~pk_sub(cur[r], thr[r]);   // sign clear: offset >= threshold
+        hit = (acc & 0x80008000u) != 0u;
+      } else {
+        uint32_t sel = cur[0];
+#pragma unroll
+        for (int r = 1; r < NR; ++r) sel = ((jt >> 1) == r) ? cur[r] : sel;
+        endv = (jt & 1) ? (sel >> 16) : (sel & 0xffffu);
+      }
       const unsigned long long active = ~idle;
-      const unsigned long long bfin = __ballot(endv == tend) & active;
-      const unsigned long long brej = __ballot(gstep > deadline) & active;
-      const unsigned long long bd = bfin | brej;
+      const unsigned long long bfin = __ballot(HEUR ? hit : (endv == tend)) & active;
+      // HEUR: also the step limit (tested after compute-next of a score, before its extension: the first score >= max_steps lies
+      // at or before the next step's, R/wavefront_unialign.c:98-107) and a pair whose band no longer holds its wavefront
+      unsigned long long blimit = 0ull;
+      if constexpr (HEUR) blimit = __ballot(a.max_steps != NEVER && __mul24(gstep - s0 + 1, a.g) >= a.max_steps) & active & ~bfin;
+      const unsigned long long brej = __ballot(gstep > deadline || (HEUR && edge_live)) & active & ~blimit;
+      const unsigned long long bd = bfin | brej | blimit;
       if (bd) {
         WFA_LANE_MARK("bd_begin");
         WFA_LANE_COUNT(6);
@@ -520,6 +537,10 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
           a.score[mypid] = -__mul24(gstep - s0, a.g);
           a.status[mypid] = 0;
           if (FULL) { fin_t = gstep - s0; fin_j = jt; fin_tl = (int)tend; }
+        }
+        if (HEUR && __builtin_amdgcn_inverse_ballot_w64(blimit)) {
+          a.score[mypid] = -a.max_steps;
+          a.status[mypid] = WFA_STATUS_MAX_STEPS_REACHED;
         }
         if (FULL) pending |= ba;
         if (brej) {
@@ -535,12 +556,73 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
         if (__builtin_amdgcn_inverse_ballot_w64(bd)) {
           // an idle lane computes nothing that lives: every new cell is clamped away
 #pragma unroll
-          for (int r = 0; r < NR; ++r) { cur[r] = WFA_LANE_NULL2; lim[r] = WFA_LANE_NULL2; }
-          deadline = NEVER; jt = 0; tend = 0xffffu;
+          for (int r = 0; r < NR; ++r) { cur[r] = WFA_LANE_NULL2; lim[r] = WFA_LANE_NULL2; if (HEUR) thr[r] = 0x3fff3fffu; }
+          deadline = NEVER; jt = 0; tend = 0xffffu; edge_live = false;
         }
         idle |= bd;
         WFA_LANE_MARK("bd_end");
         if (idle == ~0ull && next_i >= end) { flush_walks(); break; }
+      }
+    }
+
+    // =================== wf-adaptive cut-off (R/wavefront_heuristic.c:257-293, dispatcher :509-567) ===================
+    if constexpr (HEUR) {
+      if (a.heur == 1) {
+        // live slots of M as a 16-bit mask per pair (bit j: slot j holds an offset)
+        auto mask16 = [&](const uint32_t (&x)[NR]) -> uint32_t {   // bit 2 r + q = sign bit of half q of x[r] is CLEAR
+          uint32_t m = 0;
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            const uint32_t nx = ~x[r];
+            m |= (((nx >> 15) & 1u) | ((nx >> 30) & 2u)) << (2 * r);
+          }
+          return m;
+        };
+        const uint32_t live = mask16(cur);
+        if (live != 0u) --steps_wait;   // (the cut-off is looked at only when the wavefront exists)
+        const int lo = (int)lane_ffbl(live), hi = 31 - (int)__builtin_clz(live | 1u);   // (live == 0: lo = -1 as unsigned: width test fails)
+        const bool consider = live != 0u && steps_wait <= 0 && (hi - lo + 1) >= a.min_wf_len && !__builtin_amdgcn_inverse_ballot_w64(idle);
+        if (__any(consider)) {
+          // d = max(plen - v, tlen - h) = max(tlen, plen + k) - offset; dead slots: far away
+          uint32_t d2[NR];
+          uint32_t dm = 0x3fff3fffu;
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            const uint32_t dl = pk_max(my_tl2, pk_add(my_lb2, (uint32_t)(2 * r) * 0x00010001u));
+            const uint32_t dv = pk_sub(dl, cur[r]);
+            const uint32_t dead = __builtin_bit_cast(uint32_t, __builtin_bit_cast(lane_s2, cur[r]) >> (short)15);   // 0xffff per dead half
+            d2[r] = (dv & ~dead) | (0x3fff3fffu & dead);
+            dm = pk_min(dm, d2[r]);
+          }
+          const int dmin = min(my_dinit, min((int)(dm & 0xffffu), (int)(dm >> 16)));
+          const uint32_t lim2 = (uint32_t)min(dmin + min(a.max_dist_thr, 0x3ffe), 0x3ffe) * 0x00010001u;   // (< 0x3fff: dead slots never qualify)
+          uint32_t okx[NR];
+#pragma unroll
+          for (int r = 0; r < NR; ++r) okx[r] = pk_sub(lim2, d2[r]);   // sign clear: d - dmin <= threshold
+          const uint32_t okm = mask16(okx);
+          const int lc = okm ? (int)lane_ffbl(okm) : 0x7fffffff, hc = okm ? 31 - (int)__builtin_clz(okm) : -0x7fffffff;
+          const int akj = jt;   // slot of the end diagonal tlen - plen
+          int new_lo = lo, new_hi = hi;
+          const int top_limit = min(akj, hi);
+          if (top_limit > lo) new_lo = min(lc, top_limit);
+          const int bottom_limit = max(akj, new_lo);
+          if (bottom_limit < hi) new_hi = max(hc, bottom_limit);
+          if (consider) steps_wait = a.steps_between;
+          const bool cut = consider && (new_lo != lo || new_hi != hi);
+          if (__any(cut)) {
+            // the dropped slots read NULL in M, I and D from now on
+            const uint32_t keep = cut ? (((2u << new_hi) - 1u) & ~((1u << new_lo) - 1u)) : 0xffffu;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+              const uint32_t ka = (uint32_t)__builtin_amdgcn_sbfe((int)keep, 2 * r, 1) & 0xffffu;        // 0xffff if slot 2 r stays
+              const uint32_t kb = (uint32_t)__builtin_amdgcn_sbfe((int)keep, 2 * r + 1, 1) << 16;       // 0xffff0000 if slot 2 r + 1 stays
+              const uint32_t km = ka | kb;
+              cur[r] = (cur[r] & km) | (WFA_LANE_NULL2 & ~km);
+              Ih[0][r] = (Ih[0][r] & km) | (WFA_LANE_NULL2 & ~km);
+              Dh[0][r] = (Dh[0][r] & km) | (WFA_LANE_NULL2 & ~km);
+            }
+          }
+        }
       }
     }
 
@@ -604,6 +686,10 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
         Ih[0][r] = ni[r]; Dh[0][r] = nd[r];
         cur[r] = nm[r];
       }
+      if constexpr (HEUR) {
+        // a cell of an outermost slot is alive (an offset or a gap value >= 0): the next steps could reach beyond the band
+        edge_live = (((nm[0] & ni[0] & nd[0]) & 0x00008000u) == 0u) || (((nm[NR - 1] & ni[NR - 1] & nd[NR - 1]) & 0x80000000u) == 0u);
+      }
     }
     ++gstep;
   }
@@ -612,17 +698,24 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
 
 // per-shape entry points (csrc/k_lane.hip compiled once per shape index of WFA_SEG_SHAPES)
 #define WFA_LANE_DECL(i, x, oe, e) \
-  int launch_lane_s##i(unsigned grid, size_t smem, hipStream_t stream, const FastArgs& a, int slot_words, int refill_min, bool full);
+  int launch_lane_s##i(unsigned grid, size_t smem, hipStream_t stream, const FastArgs& a, int slot_words, int refill_min, bool full, bool heur);
 // (the shape list is wfa_seg.hpp's; declared here without including it)
 WFA_LANE_DECL(0, 2, 4, 1) WFA_LANE_DECL(1, 2, 3, 1) WFA_LANE_DECL(2, 4, 7, 1) WFA_LANE_DECL(3, 3, 5, 1)
 WFA_LANE_DECL(4, 6, 8, 3) WFA_LANE_DECL(5, 5, 3, 3) WFA_LANE_DECL(6, 1, 2, 1)
 #undef WFA_LANE_DECL
 
 template <int X, int OE, int E>
-inline int launch_lane_shape(unsigned grid, size_t smem, hipStream_t stream, const FastArgs& a, int slot_words, int refill_min, bool full) {
-  if (full) hipLaunchKernelGGL((wfa_lane_kernel<X, OE, E, true>), dim3(grid), dim3(64), smem, stream, a, slot_words, refill_min);
+inline int launch_lane_shape(unsigned grid, size_t smem, hipStream_t stream, const FastArgs& a, int slot_words, int refill_min, bool full, bool heur) {
+  if (heur) hipLaunchKernelGGL((wfa_lane_kernel<X, OE, E, false, true>), dim3(grid), dim3(64), smem, stream, a, slot_words, refill_min);
+  else if (full) hipLaunchKernelGGL((wfa_lane_kernel<X, OE, E, true>), dim3(grid), dim3(64), smem, stream, a, slot_words, refill_min);
   else hipLaunchKernelGGL((wfa_lane_kernel<X, OE, E, false>), dim3(grid), dim3(64), smem, stream, a, slot_words, refill_min);
   return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// configurations of the general score-only form (HEUR): gap-affine with an instantiated shape, match 0, no wildcard; no heuristic or
+// wf-adaptive (X-drop stays in the banded kernel), any free ends, any step limit (the shape list is wfa_seg.hpp's: seg_shape())
+inline bool lane_heur_config(const WfaDevConfig& c, int ncomp) {
+  return ncomp == 3 && c.match == 0 && c.wildcard < 0 && (c.heuristic == 0 || c.heuristic == 1);
 }
 
 // LDS words of a pair's slot for reads up to max_len bases: both sequences + one spare word, odd (lane slots then
@@ -639,7 +732,7 @@ inline int lane_full_records(int OE, int E) { return 2 * (OE - E) + E * 17 + 1; 
 #define WFA_LANE_RUN_SLOT 32
 
 // full = the FULL form: a.hist = run-record slots (a.hist_stride ints each, slot = work item - a.work_begin), a.end_state per slot
-inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full, int lds_pad_kb = 0, int min_pairs = 0);
+inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full, int lds_pad_kb = 0, int min_pairs = 0, bool heur = false);
 
 inline int launch_lane(int shape_idx, int g, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, const uint32_t* words,
                        const WfaPairMeta* meta, const uint32_t* worklist, const uint32_t* nwork_dev, uint32_t nwork,
@@ -649,10 +742,11 @@ inline int launch_lane(int shape_idx, int g, int cu_count, int per_cu, int refil
   a.score = score; a.status = status; a.fb_list = fb_list; a.fb_count = fb_count;
   a.g = g;
   a.hist = debug_counters; a.hist_stride = 0; a.end_state = nullptr; a.work_begin = 0;
+  a.ef = a.pbf = a.pef = a.tbf = a.tef = 0; a.heur = 0; a.min_wf_len = a.max_dist_thr = a.steps_between = 0; a.max_steps = INT_MAX;
   return launch_lane_args(shape_idx, 0, 0, cu_count, per_cu, refill_min, max_len, stream, a, false, lds_pad_kb);
 }
 
-inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full, int lds_pad_kb, int min_pairs) {
+inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full, int lds_pad_kb, int min_pairs, bool heur) {
   const uint32_t nwork = a.nwork;
   const uint32_t* nwork_dev = a.nwork_dev;
   const int slot_words = lane_slot_words(std::min(max_len, WFA_FAST_MAX_LEN));
@@ -667,13 +761,13 @@ inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_
   if (!nwork_dev && grid > max_grid) grid = max_grid;
   if (grid < 1) grid = 1;
   switch (shape_idx) {
-    case 0: return launch_lane_s0((unsigned)grid, smem, stream, a, slot_words, refill_min, full);
-    case 1: return launch_lane_s1((unsigned)grid, smem, stream, a, slot_words, refill_min, full);
-    case 2: return launch_lane_s2((unsigned)grid, smem, stream, a, slot_words, refill_min, full);
-    case 3: return launch_lane_s3((unsigned)grid, smem, stream, a, slot_words, refill_min, full);
-    case 4: return launch_lane_s4((unsigned)grid, smem, stream, a, slot_words, refill_min, full);
-    case 5: return launch_lane_s5((unsigned)grid, smem, stream, a, slot_words, refill_min, full);
-    case 6: return launch_lane_s6((unsigned)grid, smem, stream, a, slot_words, refill_min, full);
+    case 0: return launch_lane_s0((unsigned)grid, smem, stream, a, slot_words, refill_min, full, heur);
+    case 1: return launch_lane_s1((unsigned)grid, smem, stream, a, slot_words, refill_min, full, heur);
+    case 2: return launch_lane_s2((unsigned)grid, smem, stream, a, slot_words, refill_min, full, heur);
+    case 3: return launch_lane_s3((unsigned)grid, smem, stream, a, slot_words, refill_min, full, heur);
+    case 4: return launch_lane_s4((unsigned)grid, smem, stream, a, slot_words, refill_min, full, heur);
+    case 5: return launch_lane_s5((unsigned)grid, smem, stream, a, slot_words, refill_min, full, heur);
+    case 6: return launch_lane_s6((unsigned)grid, smem, stream, a, slot_words, refill_min, full, heur);
     default: return -1;
   }
 }
