@@ -446,11 +446,11 @@ def main():
                      cfg_kw=dict(span="end-to-end", scope="full", heuristic="adaptive"), scheme="piggyback", survey_bytes=114e3),
                 dict(name="C4-adaptive", n=20_000, length=10000, error=0.08, seed=datagen.SEEDS["C4"], cfg_kw=dict(C4, heuristic="adaptive"),
                      scheme="piggyback", survey_bytes=114e3 * 5 / 3, trim=50, cpu_pairs=100),
-                dict(name="C4-exact", n=1024, length=10000, error=0.08, seed=datagen.SEEDS["C4"], cfg_kw=C4, scheme="piggyback", survey_bytes=54e6,
+                dict(name="C4-exact", n=4096, length=10000, error=0.08, seed=datagen.SEEDS["C4"], cfg_kw=C4, scheme="piggyback", survey_bytes=54e6,
                      trim=50, cpu_pairs=8, cpu_budget=3.0, mt_parity_pairs=64),
-                dict(name="exact-10kb-score", n=2048, length=10000, error=0.08, seed=datagen.SEEDS["C3"], cfg_kw=dict(span="end-to-end", scope="score"),
+                dict(name="exact-10kb-score", n=8192, length=10000, error=0.08, seed=datagen.SEEDS["C3"], cfg_kw=dict(span="end-to-end", scope="score"),
                      scheme="none", survey_bytes=2 * 2500 + 8, cpu_pairs=40, cpu_budget=3.0, mt_parity_pairs=256),
-                dict(name="exact-10kb-full", n=2048, length=10000, error=0.08, seed=datagen.SEEDS["C3"], cfg_kw=dict(span="end-to-end", scope="full"),
+                dict(name="exact-10kb-full", n=8192, length=10000, error=0.08, seed=datagen.SEEDS["C3"], cfg_kw=dict(span="end-to-end", scope="full"),
                      scheme="piggyback", survey_bytes=5.1e6 + 2 * 2500 + 10_800, cpu_pairs=20, cpu_budget=3.0, mt_parity_pairs=128),
                 dict(name="C5-adaptive", n=8192, length=100000, error=0.08, seed=datagen.SEEDS["C5"],
                      cfg_kw=dict(span="end-to-end", scope="full", heuristic="adaptive"), scheme="piggyback", survey_bytes=1.14e6, cpu_pairs=4,
@@ -467,8 +467,8 @@ def main():
                     xs.append({"name": kw_["name"], "error": repr(e)})
             out["extra"]["configs"] = xs
             out["extra"]["configs_note"] = ("stated prefixes of the BASELINE streams: C1 at 1 M pairs (BASELINE names 1 k), C3 100 k of 1 M, "
-                                            "C4 as written (no heuristic) on 1 024 pairs (54 MB per pair: SURVEY's piggy-back figure) and with wf-adaptive on 20 k of "
-                                            "1 M (its bytes per pair are C3's figure x 5/3 components); exact (no heuristic) gap-affine 10 kb, score and full CIGAR "
+                                            "C4 as written (no heuristic) on 4 096 pairs (54 MB per pair: SURVEY's piggy-back figure) and with wf-adaptive on 20 k of "
+                                            "1 M (its bytes per pair are C3's figure x 5/3 components); exact (no heuristic) gap-affine 10 kb on 8 192 pairs, score and full CIGAR "
                                             "(5.1 M M-offsets per pair: one history byte each); C5 with wf-adaptive on 8 192 of 100 k pairs (X-drop(20) / match = 0 as "
                                             "BASELINE writes C5 drops every pair after a few steps, SURVEY Q2); C2 above is the full 10 M.  Long reads keep the "
                                             "piggy-back history (one byte of origin codes per cell) in every memory mode; the *-explicit-history "

@@ -217,6 +217,7 @@ struct wfa_hip_batch {
   // waits for it (the host-packed upload returns with its DMAs still in flight)
   hipEvent_t upload_event = nullptr;
   int stage_pick = 0;  // first register-kernel stage chosen by the pilot of the first run (0 = not yet): 16, 32 or 64 lanes
+  int laneh_pick = 0;  // general score-only form of the lane kernel first (wf-adaptive / free ends / step limit): 1 yes, 2 no (its pilot), 0 undecided
   int64_t arena_ints = 0;  // FULL: arena size used by the last launch (the part that grows 8x when a pair overflows it)
   int64_t arena_fixed = 0; // FULL, piggy-back history of the general kernel: the score-only ring in front of the growing part
   // device-side result surface (RLE)
@@ -638,6 +639,7 @@ static int staged_pack_upload(wfa_hip_aligner* al, wfa_hip_batch* b, const std::
 }
 
 static int pilot_first_width(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream);
+static int pilot_lane_heur(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream);
 
 // in2bit: `seqs` holds 2-bit reads in the reference's packed form (wavefront_sequences.c:102-139: four bases per byte, base j
 // of a byte in bits 2j..2j+1, A 0 / C 1 / G 2 / T 3), a sequence of len bases = (len + 3) / 4 bytes at its BYTE offset
@@ -911,6 +913,7 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
       }
       b->h_meta = std::move(meta);
       { const int prc = pilot_first_width(al, b, al->stream); if (prc != WFA_HIP_OK) return prc; }
+      { const int prc = pilot_lane_heur(al, b, al->stream); if (prc != WFA_HIP_OK) return prc; }
       HIP_TRY(al, hipEventCreateWithFlags(&b->upload_event, hipEventDisableTiming));
       HIP_TRY(al, hipEventRecord(b->upload_event, al->stream));
       return WFA_HIP_OK;
@@ -978,6 +981,7 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
   }
   b->h_meta = std::move(meta);
   { const int prc = pilot_first_width(al, b, al->stream); if (prc != WFA_HIP_OK) return prc; }
+  { const int prc = pilot_lane_heur(al, b, al->stream); if (prc != WFA_HIP_OK) return prc; }
   HIP_TRY(al, hipEventCreateWithFlags(&b->upload_event, hipEventDisableTiming));
   HIP_TRY(al, hipEventRecord(b->upload_event, al->stream));
   return WFA_HIP_OK;
@@ -1015,6 +1019,45 @@ static int pilot_first_width(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t 
     if (handed * 5u <= np * 2u) { b->stage_pick = w; break; }  // at most 40 % handed on
   }
   HIP_TRY(al, hipMemsetAsync(pcount, 0, sizeof(uint32_t), stream));
+  return WFA_HIP_OK;
+}
+
+// The general score-only form of the lane kernel (wfa_lane_kernel<.., HEUR>) keeps a pair only while its wavefront stays clear of the
+// band's outermost slots; what it hands on has cost its work for nothing.  At 2 % divergence about half of the 150 bp pairs outgrow the
+// 16 slots (and the cascade is faster without the stage), at <= 1 % few do (and it is ~2x faster with it): a pilot on 8192 sampled pairs
+// decides once per batch, when the batch is created (b->laneh_pick: 1 = first stage, 2 = not used).
+static int pilot_lane_heur(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream) {
+  if (b->laneh_pick != 0 || b->cfg.scope == WFA_SCOPE_FULL) return WFA_HIP_OK;
+  b->laneh_pick = 2;
+  int X, OE, E;
+  if (!wfa::lane_heur_config(b->dcfg, b->ncomp) || wfa::seg_supported(b->dcfg, b->ncomp, false) ||
+      wfa::seg_shape(b->dcfg, &X, &OE, &E) < 0 || b->max_len > WFA_FAST_MAX_LEN || knob(al, K_NO_FAST, 0) != 0) return WFA_HIP_OK;
+  const int forced = knob(al, K_LANE_HEUR, -1);   // (WFA_HIP_LANE_HEUR = 1 / 0: always / never, whatever the batch)
+  if (forced >= 0) { b->laneh_pick = forced ? 1 : 2; return WFA_HIP_OK; }
+  if (b->n_packed < 65536u) return WFA_HIP_OK;
+  const uint32_t np = 8192u, stride = b->n_packed / np;
+  uint32_t* plist = b->d_fb_list2[0];
+  uint32_t* psample = b->d_fb_list2[1];
+  uint32_t* pcount = b->d_counters + 4;
+  hipLaunchKernelGGL(wfa_pilot_sample_kernel, dim3((np + 255u) / 256u), dim3(256), 0, stream, b->d_list_packed, stride, np, psample);
+  HIP_TRY(al, hipGetLastError());
+  HIP_TRY(al, hipMemsetAsync(pcount, 0, sizeof(uint32_t), stream));
+  wfa::FastArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.words = b->d_words; fa.meta = b->d_meta; fa.worklist = psample; fa.nwork = np;
+  fa.score = b->d_score; fa.status = b->d_status; fa.fb_list = plist; fa.fb_count = pcount;
+  fa.g = wfa::gcd_int(wfa::gcd_int(b->dcfg.x, b->dcfg.o1 + b->dcfg.e1), b->dcfg.e1);
+  fa.ef = (b->dcfg.endsfree && (b->dcfg.pbf | b->dcfg.pef | b->dcfg.tbf | b->dcfg.tef)) ? 1 : 0;
+  fa.pbf = b->dcfg.pbf; fa.pef = b->dcfg.pef; fa.tbf = b->dcfg.tbf; fa.tef = b->dcfg.tef;
+  fa.heur = b->dcfg.heuristic; fa.min_wf_len = b->dcfg.min_wf_len; fa.max_dist_thr = b->dcfg.max_dist_thr;
+  fa.steps_between = b->dcfg.steps_between; fa.max_steps = b->dcfg.max_steps;
+  if (wfa::launch_lane_args(wfa::seg_shape(b->dcfg, &X, &OE, &E), OE, E, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8),
+                            b->max_len, stream, fa, false, 0, 256, true) != 0) { al->err = "pilot launch failed"; return WFA_HIP_EDEVICE; }
+  uint32_t handed = 0;
+  HIP_TRY(al, hipMemcpyAsync(&handed, pcount, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(al, hipStreamSynchronize(stream));
+  HIP_TRY(al, hipMemsetAsync(pcount, 0, sizeof(uint32_t), stream));
+  if (handed * 4u <= np) b->laneh_pick = 1;   // at most a quarter handed on
   return WFA_HIP_OK;
 }
 
@@ -1303,7 +1346,8 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     // wavefront touches the band's outermost slots); the banded stages take what it hands on
     int lh_x, lh_oe, lh_e;
     const bool use_laneh = !tiny && !full && !use_fast && wfa::lane_heur_config(b->dcfg, b->ncomp) && wfa::seg_shape(b->dcfg, &lh_x, &lh_oe, &lh_e) >= 0 &&
-                           b->max_len <= WFA_FAST_MAX_LEN && knob(al, K_NO_FAST, 0) == 0 && knob(al, K_LANE_HEUR, 1) != 0;
+                           b->max_len <= WFA_FAST_MAX_LEN && knob(al, K_NO_FAST, 0) == 0 &&
+                           (b->laneh_pick == 1 || (b->laneh_pick == 0 && knob(al, K_LANE_HEUR, 0) != 0));   // (the pilot of batch_build, or WFA_HIP_LANE_HEUR=1)
     if (!tiny && wfa::band_supported(b->dcfg, b->ncomp) && (b->ncomp != 5 || b->max_len < 32000) && knob(al, K_NO_BAND, 0) == 0) {
       if (b->ncomp == 5) {
         // gap-affine-2p wavefronts are wide (C4: 99 % need more than 108 diagonals, 2.6 % more than 172)

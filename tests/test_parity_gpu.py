@@ -130,6 +130,41 @@ def test_ragged_and_empty_batches(gpu):
     al.close()
 
 
+LANE_GENERAL = [dict(span="end-to-end", heuristic="adaptive"), dict(span="ends-free", heuristic="adaptive"),
+                dict(span="ends-free", pattern_begin_free=8, pattern_end_free=7, text_begin_free=3, text_end_free=2),
+                dict(span="ends-free", pattern_begin_free=4, pattern_end_free=0, text_begin_free=2, text_end_free=9, heuristic="adaptive"),
+                dict(span="ends-free", pattern_begin_free=20, text_end_free=9), dict(span="end-to-end", max_steps=10), dict(max_steps=24, heuristic="adaptive"),
+                dict(span="end-to-end", heuristic="adaptive", min_wavefront_length=5, max_distance_threshold=10, steps_between_cutoffs=3),
+                dict(span="end-to-end", heuristic="adaptive", mismatch=2, gap_opening=3, gap_extension=1),
+                dict(span="ends-free", text_begin_free=5, pattern_end_free=5, mismatch=3, gap_opening=3, gap_extension=1, heuristic="adaptive", min_wavefront_length=3)]
+
+
+@pytest.mark.parametrize("cfg_idx", range(len(LANE_GENERAL)))
+def test_lane_kernel_general_form(gpu, corpora, cfg_idx, monkeypatch):
+    """The general score-only form of the lane kernel (wfa_lane_kernel<.., HEUR>, round 3: wf-adaptive, free ends and the step limit
+    under the no-clipping rule) forced on (WFA_HIP_LANE_HEUR=1: small batches skip its pilot), over every corpus: what it keeps and
+    what it hands on to the banded stages must equal the oracle."""
+    monkeypatch.setenv("WFA_HIP_LANE_HEUR", "1")
+    for name in ("150bp_2pct", "150bp_15pct", "special"):
+        batch = corpora[name]
+        kw = common.clamp_free(dict(LANE_GENERAL[cfg_idx], scope="score"), batch)
+        oc, nc = common.configs_pair(**kw)
+        o = loader.run(loader.oracle(), oc, batch, want_cigar=False)
+        score, status, _ = common.gpu_run(nc, batch, False, resident=(cfg_idx % 2 == 1))
+        common.assert_same(o, score, status, None, batch, f"lane general form {name} {kw}")
+
+
+@pytest.mark.parametrize("error", [0.005, 0.03])
+def test_lane_kernel_general_form_pilot(gpu, error):
+    """Batches of >= 64 k pairs let a pilot decide whether the general form goes first (few pairs outgrow its 16 slots at 0.5 %
+    divergence, about half at 3 %); either way the results are the oracle's."""
+    batch = datagen.generate(70000, 150, error, 4455)
+    oc, nc = common.configs_pair(span="end-to-end", scope="score", heuristic="adaptive")
+    o = loader.run(loader.reference() if loader.have_reference() else loader.oracle(), oc, batch, want_cigar=False)
+    score, status, _ = common.gpu_run(nc, batch, False, resident=True)
+    common.assert_same(o, score, status, None, batch, f"lane general form pilot {error}")
+
+
 def test_match_lt_0_with_free_begins_and_a_backtrace_is_refused(gpu):
     """With a backtrace the reference itself exits or hangs on this configuration (tests/test_oracle_vs_ref.py): NotImplementedError."""
     from pywfa_amd import _native
