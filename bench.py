@@ -455,6 +455,12 @@ def main():
                 dict(name="C5-adaptive", n=8192, length=100000, error=0.08, seed=datagen.SEEDS["C5"],
                      cfg_kw=dict(span="end-to-end", scope="full", heuristic="adaptive"), scheme="piggyback", survey_bytes=1.14e6, cpu_pairs=4,
                      cpu_budget=2.0, mt_parity_pairs=32, steps=2),
+                # wf-adaptive on short reads: the general form of the lane kernel goes first where its pilot finds that
+                # few pairs outgrow its 16 slots (0.5 % divergence), the banded kernel takes the batch otherwise (2 %)
+                dict(name="150bp-adaptive-2pct", n=2_000_000, length=150, error=0.02, seed=datagen.SEEDS["C2"],
+                     cfg_kw=dict(span="end-to-end", scope="score", heuristic="adaptive"), scheme="none", survey_bytes=84, cpu_pairs=200000, cpu_budget=2.0),
+                dict(name="150bp-adaptive-0.5pct", n=2_000_000, length=150, error=0.005, seed=datagen.SEEDS["C2"],
+                     cfg_kw=dict(span="end-to-end", scope="score", heuristic="adaptive"), scheme="none", survey_bytes=84, cpu_pairs=200000, cpu_budget=2.0),
                 dict(name="C3-explicit-history", n=100_000, length=10000, error=0.08, seed=datagen.SEEDS["C3"],
                      cfg_kw=dict(span="end-to-end", scope="full", heuristic="adaptive"), scheme="explicit", survey_bytes=750e3, env={"WFA_HIP_BAND_PB": "0"}),
                 dict(name="C4-adaptive-explicit-history", n=20_000, length=10000, error=0.08, seed=datagen.SEEDS["C4"], cfg_kw=dict(C4, heuristic="adaptive"),
@@ -476,7 +482,7 @@ def main():
             # the other half of the metric where a record that keeps only the scalars of `config` still shows it
             for x in xs:
                 if "alignments_per_s" in x:
-                    key = x["name"].lower().replace("-", "_")
+                    key = x["name"].lower().replace("-", "_").replace(".", "")
                     out["config"][f"{key}_alignments_per_s"] = x["alignments_per_s"]
                     out["config"][f"{key}_hbm_frac"] = x["roofline"]["frac"]
                     out["config"][f"{key}_parity_mismatches"] = x["parity_mismatches"]

@@ -66,6 +66,7 @@ struct BandArgs {
   long long pb_event_ints;
   int pb;                 // FULL + split: 1 = piggy-back history: one byte of origin codes per (step, diagonal)
                           // instead of the offsets; the walk follows the codes and the matches are re-extended afterwards
+  const uint2* lane_codes; // wfa_lane_kernel<.., FULL>: the comparison bits of every wave-step (64 lanes x 8 bytes per record)
   int seg_w;              // > 0: the history was written by wfa_seg_kernel<.., FULL>: records of seg_w entries {M, I, D, -} x
                           // int16, entry k - klo, klo = ceil((tlen - plen) / 2) - seg_w / 2
 };
@@ -1012,8 +1013,86 @@ wfa_seg_expand_kernel(const BandArgs a) {
   }
 }
 
-// Short reads, history of wfa_lane_kernel<.., FULL> (wfa_lane.hpp): the walk ran in the alignment kernel; a slot holds the run
-// records {length << 8 | op} in forward order from its first int.  Four alignments per wave, 16 lanes each.
+// Short reads, history of wfa_lane_kernel<.., FULL> (wfa_lane.hpp): one THREAD per alignment walks the comparison bits back from
+// the end cell (R/wavefront_backtrace.c:320-529 with the choices made at compute time: bit 3 of a slot's nibble: the mismatch
+// candidate is below the best gap candidate; bit 2: deletion below insertion; bit 1 / 0: the extension of I / D is below its
+// opening), then unpacks forwards from the cell (score 0, offset 0), re-extending the matches on the packed words, into run
+// records {length << 8 | op} at the start of the alignment's slot.  An alignment whose edits do not fit (more than 31 runs) is
+// handed on to the next stage.
+__global__ void __launch_bounds__(64)
+wfa_lane_walk_kernel(const BandArgs a) {
+  const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+  if (t >= a.nwork) return;
+  const int4 es = a.end_state[t];
+  if (es.w != 1) return;
+  const uint32_t wi = a.work_begin + t;
+  const uint32_t pair = a.worklist ? a.worklist[wi] : wi;
+  const WfaPairMeta pm = a.meta[pair];
+  const int plen = pm.plen, tlen = pm.tlen;
+  const int dx = a.x / a.g, doe = a.oe / a.g, de = a.e / a.g;
+  const int ln = es.y & 0xff, t_end = es.z;
+  const uint2* const rec_end = a.lane_codes + (unsigned long long)(unsigned)es.x * 64ull + (unsigned)ln;
+  // events, last edit first: 4 bits each (op: 1 X, 2 I, 3 D; bit 3: lands in M) in two 64-bit words
+  unsigned long long ev_lo = 0ull, ev_hi = 0ull;
+  int tt = t_end, j = es.y >> 8, comp = 0, nev = 0;
+  while (tt > 0 && nev < 32) {
+    const uint2 c = rec_end[-(long long)(t_end - tt) * 64ll];
+    const uint32_t nib = (((j < 8) ? c.x : c.y) >> (4 * (j & 7))) & 0xFu;
+    uint32_t ev;
+    if (comp == 0) {
+      if (!(nib & 8u)) { ev = 1u | 8u; tt -= dx; }
+      else if (!(nib & 4u)) { ev = 3u | 8u; ++j; if (!(nib & 1u)) { tt -= de; comp = 2; } else tt -= doe; }
+      else { ev = 2u | 8u; --j; if (!(nib & 2u)) { tt -= de; comp = 1; } else tt -= doe; }
+    } else if (comp == 1) {
+      ev = 2u; --j;
+      if (!(nib & 2u)) tt -= de; else { tt -= doe; comp = 0; }
+    } else {
+      ev = 3u; ++j;
+      if (!(nib & 1u)) tt -= de; else { tt -= doe; comp = 0; }
+    }
+    if (nev < 16) ev_lo |= (unsigned long long)ev << (4 * nev); else ev_hi |= (unsigned long long)ev << (4 * (nev - 16));
+    ++nev;
+  }
+  uint32_t* const runs = reinterpret_cast<uint32_t*>(a.hist + (long long)t * a.hist_stride);
+  const int max_runs = (int)a.hist_stride;
+  bool over = (tt != 0);
+  int nruns = 0, total = 0;
+  if (!over) {
+    const uint32_t* P = a.words + pm.p_woff;
+    const uint32_t* T = a.words + pm.t_woff;
+    int v = 0, h = 0;
+    uint32_t cur_op = 'M';
+    int cur_len = 0;
+    auto emit = [&](uint32_t op, int n) {
+      if (n <= 0) return;
+      total += n;
+      if (op == cur_op) { cur_len += n; return; }
+      if (cur_len > 0) { if (nruns < max_runs) runs[nruns] = ((uint32_t)cur_len << 8) | cur_op; ++nruns; }
+      cur_op = op; cur_len = n;
+    };
+    { const int n = pb_lcp(P, T, v, h, min(plen - v, tlen - h)); emit('M', n); v += n; h += n; }
+    for (int e = nev - 1; e >= 0; --e) {
+      const uint32_t ev = (uint32_t)(((e < 16) ? (ev_lo >> (4 * e)) : (ev_hi >> (4 * (e - 16)))) & 0xFull);
+      const uint32_t op = ev & 7u;
+      if (op == 1u) { emit('X', 1); ++v; ++h; }
+      else if (op == 2u) { emit('I', 1); ++h; }
+      else { emit('D', 1); ++v; }
+      if (ev & 8u) { const int n = pb_lcp(P, T, v, h, min(plen - v, tlen - h)); emit('M', n); v += n; h += n; }
+    }
+    emit('I', tlen - h); emit('D', plen - v);
+    if (cur_len > 0) { if (nruns < max_runs) runs[nruns] = ((uint32_t)cur_len << 8) | cur_op; ++nruns; }
+    over = nruns > max_runs;
+  }
+  if (over) {
+    a.end_state[t] = make_int4(0, 0, 0, 0);
+    a.status[pair] = WFA_INTERNAL_FALLBACK;
+    a.fb_list[atomicAdd(a.fb_count, 1u)] = pair;
+  } else {
+    a.end_state[t] = make_int4(plen + tlen - total, nruns, 1, 2);   // {first op, runs, forward order, ready}
+  }
+}
+
+// The op bytes from the run records of wfa_lane_walk_kernel.  Four alignments per wave, 16 lanes each.
 __global__ void __launch_bounds__(256)
 wfa_lane_expand_kernel(const BandArgs a) {
   const int lane = threadIdx.x & 63, sub = lane >> 4, l = lane & 15;
@@ -1061,6 +1140,8 @@ wfa_lane_expand_kernel(const BandArgs a) {
 
 inline int launch_lane_expand_impl(const BandArgs& a, hipStream_t stream) {
   if (a.nwork == 0) return 0;
+  hipLaunchKernelGGL(wfa_lane_walk_kernel, dim3((a.nwork + 63u) / 64u), dim3(64), 0, stream, a);
+  if (hipGetLastError() != hipSuccess) return -1;
   hipLaunchKernelGGL(wfa_lane_expand_kernel, dim3((a.nwork + 15u) / 16u), dim3(256), 0, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

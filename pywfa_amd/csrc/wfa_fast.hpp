@@ -36,6 +36,9 @@ struct FastArgs {
   long long hist_stride;  // ints per slot
   int4* end_state;        // per slot {end score, end k, end offset, 1 = walk it}
   uint32_t work_begin;    // first work item of this launch (slot = item - work_begin)
+  // full-CIGAR form of the lane kernel (wfa_lane_kernel<.., FULL>): the origin codes of every wave-step, 64 lanes x 8 bytes per record
+  uint2* codes;           // wave w owns the records [w * codes_cap, (w + 1) * codes_cap)
+  int codes_cap;          // records per wave
   // the general score-only form of the lane kernel (wfa_lane_kernel<.., HEUR>): free ends, wf-adaptive, step limit
   int ef, pbf, pef, tbf, tef;                                // ends-free span with these free ends (R/wavefront_termination.c:115-162)
   int heur, min_wf_len, max_dist_thr, steps_between;         // 1 = wf-adaptive (R/wavefront_heuristic.c:257-293)

@@ -1529,9 +1529,17 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     if (use_lanefull) { for (int i = 1; i < n_segfull; ++i) segfull_w[i - 1] = segfull_w[i]; --n_segfull; }
     const int64_t lanefull_slot_bytes = (int64_t)WFA_LANE_RUN_SLOT * 4 + (int64_t)sizeof(int4);
     int64_t lanefull_cap = 0;
+    long long lanefull_grid = 0;
+    int lanefull_recs = 0, lf_x = 0, lf_oe = 0, lf_e = 0;
+    size_t lanefull_codes_off = 0;
     if (use_lanefull) {
-      lanefull_cap = std::max<int64_t>(1, std::min<int64_t>(in_n, free_budget(al) / lanefull_slot_bytes));
-      need = std::max(need, (size_t)(lanefull_cap * lanefull_slot_bytes));
+      (void)wfa::seg_shape(b->dcfg, &lf_x, &lf_oe, &lf_e);
+      // per launch: run records + end state per pair, and the waves' record lists of comparison bits (512 bytes per wave-step)
+      lanefull_cap = std::max<int64_t>(1, std::min<int64_t>(in_n, free_budget(al) / (lanefull_slot_bytes + 256)));
+      wfa::lane_full_geometry((uint32_t)lanefull_cap, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_MIN_PAIRS, 0), lf_oe, lf_e,
+                              &lanefull_grid, &lanefull_recs);
+      lanefull_codes_off = ((size_t)(lanefull_cap * lanefull_slot_bytes) + 255) & ~(size_t)255;
+      need = std::max(need, lanefull_codes_off + (size_t)lanefull_grid * (size_t)lanefull_recs * 512);
     }
     if (use_segfull) {
       for (int i = 0; i < n_segfull; ++i) {
@@ -1560,15 +1568,19 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       fa.g = wfa::gcd_int(wfa::gcd_int(b->dcfg.x, b->dcfg.o1 + b->dcfg.e1), b->dcfg.e1);
       fa.hist = al->ws; fa.hist_stride = WFA_LANE_RUN_SLOT;
       fa.end_state = reinterpret_cast<int4*>(reinterpret_cast<char*>(al->ws) + (size_t)lanefull_cap * WFA_LANE_RUN_SLOT * 4);
+      fa.codes = reinterpret_cast<uint2*>(reinterpret_cast<char*>(al->ws) + lanefull_codes_off); fa.codes_cap = lanefull_recs;
       wfa::BandArgs ba;
       memset(&ba, 0, sizeof(ba));
       ba.meta = b->d_meta; ba.worklist = in_list; ba.words = b->d_words;
       ba.cigar_ops = b->d_ops; ba.cigar_off = b->d_cigar_off; ba.cigar_begin = b->d_cigar_begin; ba.cigar_len = b->d_cigar_len;
       ba.hist = fa.hist; ba.hist_stride = fa.hist_stride; ba.end_state = fa.end_state;
+      ba.lane_codes = fa.codes; ba.status = b->d_status; ba.fb_list = out_list; ba.fb_count = out_count;
+      ba.g = fa.g; ba.x = b->dcfg.x; ba.oe = b->dcfg.o1 + b->dcfg.e1; ba.e = b->dcfg.e1;
       for (int64_t w0 = 0; w0 < (int64_t)in_n; w0 += lanefull_cap) {
         const uint32_t cnt = (uint32_t)std::min<int64_t>(lanefull_cap, (int64_t)in_n - w0);
         fa.work_begin = (uint32_t)w0; fa.nwork = cnt;
-        if (wfa::launch_lane_args(shape, OE, E, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8) | ((knob(al, K_LANE_DEBUG, 0) >> 4) << 8), b->max_len, stream, fa, true, 0, knob(al, K_LANE_MIN_PAIRS, 0)) != 0) {
+        // (a shorter last launch has fewer waves and needs fewer records than the lists were sized for)
+        if (wfa::launch_lane_args(shape, OE, E, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, fa, true, 0, knob(al, K_LANE_MIN_PAIRS, 0)) != 0) {
           al->err = "lane kernel launch failed"; return WFA_HIP_EDEVICE;
         }
         ba.work_begin = (uint32_t)w0; ba.nwork = cnt;

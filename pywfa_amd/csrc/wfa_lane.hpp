@@ -33,13 +33,15 @@
 // FULL (round 3): full CIGARs of short reads in the same layout, with the piggy-back history of the long-read kernels
 // (R/wavefront_backtrace_offload.c:39-73, R/wavefront_pcigar.c:204-266): compute-next also records, per cell, which
 // candidate the backtrace would take (R/wavefront_backtrace.c:49-59: mismatch > deletion > insertion on equal offsets, extension
-// > opening) as four comparison bits — 8 bytes per step for the 16 diagonals, kept in the lane's own LDS behind its packed
-// words.  Lanes that finish keep their slot until the wave's next refill; there they walk their codes back from the end cell
-// (one LDS read per edit), unpack forwards re-extending the matches on the LDS words (a wavefront cell is always extended to
-// its end), and leave a handful of run records {length, op} per pair in HBM, written 64 lanes wide; wfa_lane_expand_kernel
-// turns the runs into op bytes.  Nothing else of the history ever reaches HBM (round 2's form stored 8-byte offset records:
-// 1.7 GB per million pairs).  The bound is applied strictly (S' < Bmin) as in wfa_seg_kernel<.., FULL>, so that every
-// candidate the reference's backtrace compares lies inside the band with its true value.
+// > opening) as four comparison bits — 8 bytes per lane and step for the 16 diagonals, and a wave-step's 64 x 8 bytes leave
+// as ONE coalesced 512-byte store into the wave's record list in HBM.  A pair that ends leaves {record of its end step, lane, end
+// slot, steps}; wfa_lane_walk_kernel (wfa_band.hpp; one thread per alignment, every lane busy) follows the bits back — one 8-byte
+// load per edit —, unpacks forwards re-extending the matches on the packed words (a wavefront cell is always extended to its end)
+// and leaves a handful of run records {length, op}; wfa_lane_expand_kernel turns the runs into op bytes.  96 MB of codes per
+// million pairs instead of round 2's 1.7 GB of 8-byte offset records.  The bound is applied strictly (S' < Bmin) as in
+// wfa_seg_kernel<.., FULL>, so that every candidate the reference's backtrace compares lies inside the band with its true value.
+// (First form of this round: records in LDS and the walk inside this kernel at every refill — 12 of 64 lanes busy in the walk,
+// 2.25 waves per SIMD: 0.80 ms per million pairs against 0.30 for the score alone; dropped.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <limits.h>
@@ -116,13 +118,12 @@ __global__ void __launch_bounds__(64) WFA_LANE_OCCUPANCY
 wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg) {
   static_assert(!(FULL && HEUR), "the general form is score only");
   const int refill_min = refill_arg & 0xff;
-  const int dbg_flags = refill_arg >> 8;   // timing experiments only (WFA_HIP_LANE_DEBUG >> 4): 1 = skip the walks, 2 = skip the code stores
   constexpr int W = 16, H = 8, NR = 8;            // band of 16 diagonals = 8 packed registers
   constexpr int DM = (X > OE) ? X : OE;           // depth of the M ring
   constexpr int NEVER = 0x7fffffff;
-  constexpr int NREC = LaneFull<OE, E>::NREC;     // FULL: records of 2 words behind the lane's packed words
+  constexpr int NREC = LaneFull<OE, E>::NREC;     // FULL: steps a pair can take here (bounds the walk)
   extern __shared__ uint32_t lds[];               // [4 guard words][64 slots x slot_words][4 guard words]
-  const int slot_words = FULL ? ((slot_words_seq + 2 * NREC) | 1) : slot_words_seq;   // (odd: lanes hit different banks)
+  const int slot_words = slot_words_seq;
   const int lane = threadIdx.x;
   uint32_t nwork = __builtin_amdgcn_readfirstlane(a.nwork_dev ? *a.nwork_dev : a.nwork);
   const uint32_t per = __builtin_amdgcn_readfirstlane((nwork + gridDim.x - 1) / gridDim.x);
@@ -172,127 +173,17 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
   uint32_t mypid = 0;
   unsigned long long idle = ~0ull;  // lanes without a pair
   int gstep = 0;
-  // FULL: my history slot (work item index of this launch), my lengths, and the end of a finished alignment waiting for its walk
-  const int cbase = 4 + lane * slot_words + slot_words_seq;   // first word of my code records
+  // FULL: my history slot (work item index of this launch); the wave's record list; once it is full the wave records nothing
+  // more and hands on what finishes afterwards
   uint32_t myslot = 0;
-  int mypl = 0, fin_t = -1, fin_j = 0, fin_tl = 0;
-  unsigned long long pending = 0ull;   // lanes with a finished alignment not yet walked
-
-  // ---- FULL: walk + unpack of the lanes in `pending` (their LDS slots are untouched since they finished)
-  auto flush_walks = [&]() {
-    if constexpr (FULL) {
-      if (!pending) return;
-      if (dbg_flags & 1) {
-        if (__builtin_amdgcn_inverse_ballot_w64(pending)) a.end_state[myslot] = make_int4(0, 0, 0, 0);
-        pending = 0ull; fin_t = -1; return;
-      }
-      const bool mine = __builtin_amdgcn_inverse_ballot_w64(pending);
-      int nruns = 0, total = 0;
-      bool over = false;
-      if (mine) {
-        // walk the comparison bits back from the end cell (R/wavefront_backtrace.c:320-529 with the choices made at compute
-        // time): bit 3: the mismatch candidate is below the best gap candidate; bit 2: deletion below insertion; bit 1 / 0: the
-        // gap extension of I / D is below its opening.  Events go to the top of my records, downwards (a record is read
-        // before an event can reach it: every hop goes back at least one step).
-        int t = fin_t, j = fin_j, comp = 0, nev = 0;
-        while (t > 0 && nev < 2 * NREC) {
-          const uint32_t dw = lds[cbase + 2 * t + (j >> 3)];
-          const uint32_t nib = (dw >> (4 * (j & 7))) & 0xFu;
-          uint32_t ev;
-          if (comp == 0) {
-            if (!(nib & 8u)) { ev = 'X' | 0x80u; t -= X; }
-            else if (!(nib & 4u)) { ev = 'D' | 0x80u; ++j; if (!(nib & 1u)) { t -= E; comp = 2; } else t -= OE; }
-            else { ev = 'I' | 0x80u; --j; if (!(nib & 2u)) { t -= E; comp = 1; } else t -= OE; }
-          } else if (comp == 1) {
-            ev = 'I'; --j;
-            if (!(nib & 2u)) t -= E; else { t -= OE; comp = 0; }
-          } else {
-            ev = 'D'; ++j;
-            if (!(nib & 1u)) t -= E; else { t -= OE; comp = 0; }
-          }
-          lds[cbase + 2 * NREC - 1 - nev] = ev;
-          ++nev;
-        }
-        // runs grow upwards from my first record, events are consumed downwards from the top: they must not meet
-        over = (t != 0) || (3 * nev + 2 > 2 * NREC) || (2 * nev + 3 > (int)a.hist_stride);
-        if (!over) {
-          // unpack forwards from the cell (score 0, offset 0): after every event that lands in M the run of matches is the
-          // whole common prefix of what is left of the two sequences
-          const int pl = mypl, tl = fin_tl;
-          int v = 0, h = 0;
-          uint32_t cur_op = 'M';
-          int cur_len = 0;
-          auto emit = [&](uint32_t op, int n) {
-            if (n <= 0) return;
-            total += n;
-            if (op == cur_op) { cur_len += n; return; }
-            if (cur_len > 0) { lds[cbase + nruns] = ((uint32_t)cur_len << 8) | cur_op; ++nruns; }
-            cur_op = op; cur_len = n;
-          };
-          auto lcp = [&]() -> int {
-            const int maxn = min(pl - v, tl - h);
-            int n = 0;
-            while (n < maxn) {
-              const int pv = pbase + v + n, th = tb + h + n;
-              const uint32_t pa = ((uint32_t)pv >> 2) & ~3u, ta = ((uint32_t)th >> 2) & ~3u;
-              const uint32_t* pp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds) + pa);
-              const uint32_t* tp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds) + ta);
-              const uint32_t p0 = pp[0], p1 = pp[1], p2 = pp[2], t0 = tp[0], t1 = tp[1], t2 = tp[2];
-              const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)pv << 1) ^ __builtin_amdgcn_alignbit(t1, t0, (uint32_t)th << 1);
-              const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, (uint32_t)pv << 1) ^ __builtin_amdgcn_alignbit(t2, t1, (uint32_t)th << 1);
-              const uint32_t fb = min(lane_ffbl(xl), lane_ffbl(xh) | 32u);
-              const int m = min((int)(fb >> 1), 32);
-              n += m;
-              if (m < 32) break;
-            }
-            return min(n, maxn);
-          };
-          { const int n = lcp(); emit('M', n); v += n; h += n; }
-          for (int e = nev - 1; e >= 0; --e) {
-            const uint32_t ev = lds[cbase + 2 * NREC - 1 - e];
-            const uint32_t op = ev & 0x7Fu;
-            if (op == 'X') { emit('X', 1); ++v; ++h; }
-            else if (op == 'I') { emit('I', 1); ++h; }
-            else { emit('D', 1); ++v; }
-            if (ev & 0x80u) { const int n = lcp(); emit('M', n); v += n; h += n; }
-          }
-          emit('I', tl - h); emit('D', pl - v);
-          if (cur_len > 0) { lds[cbase + nruns] = ((uint32_t)cur_len << 8) | cur_op; ++nruns; }
-          a.end_state[myslot] = make_int4(pl + tl - total, nruns, 1, 2);   // {first op, runs, forward order, ready}
-        }
-      }
-      // a walk that does not fit its records (many one-step hops): the pair goes to the next stage like a rejected one
-      const unsigned long long bover = __ballot(mine && over);
-      if (bover) {
-        uint32_t slot = 0;
-        if (lane == 0) slot = atomicAdd(a.fb_count, (uint32_t)__builtin_popcountll(bover));
-        slot = __builtin_amdgcn_readfirstlane(slot);
-        if (mine && over) {
-          a.fb_list[slot + __builtin_amdgcn_mbcnt_hi((uint32_t)(bover >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bover, 0u))] = mypid;
-          a.status[mypid] = WFA_INTERNAL_FALLBACK;
-          a.end_state[myslot] = make_int4(0, 0, 0, 0);
-        }
-      }
-      // the run records of every walked lane, 64 lanes wide
-      unsigned long long lm = pending & ~bover;
-      while (lm) {
-        const int L = __builtin_ctzll(lm);
-        lm &= lm - 1ull;
-        const int nr = __builtin_amdgcn_readlane(nruns, L);
-        const uint32_t sl = __builtin_amdgcn_readlane(myslot, L);
-        if (lane < nr) reinterpret_cast<uint32_t*>(a.hist)[(unsigned long long)sl * (unsigned long long)a.hist_stride + lane] = lds[4 + L * slot_words + slot_words_seq + lane];
-      }
-      fin_t = mine ? -1 : fin_t;
-      pending = 0ull;
-    }
-  };
+  uint2* const wave_codes = FULL ? a.codes + (unsigned long long)blockIdx.x * (unsigned long long)a.codes_cap * 64ull : nullptr;
+  bool codes_full = false;
 
   while (true) {
     WFA_LANE_MARK("looptop_begin");   // (analysis builds: what precedes the first of these is the prologue)
     // =================== take pairs ===================
     const int nidle = __builtin_popcountll(idle);
     if (next_i < end && (nidle >= refill_min || idle == ~0ull)) {
-      flush_walks();   // (FULL: the finished lanes' slots are about to be overwritten)
       WFA_LANE_MARK("refill_begin");
       WFA_LANE_COUNT(1);
       const bool is_idle = __builtin_amdgcn_inverse_ballot_w64(idle);
@@ -333,7 +224,7 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
         const int c = bad ? 0 : (HEUR ? ((dlo + dhi + 1) >> 1) : ((ak + 1) >> 1));      // band centre: k in [c - H, c + H)
         const int k0 = c - H;                         // diagonal of slot 0
         mypid = n_pid; s0 = gstep;
-        if (FULL) { myslot = next_i + rank; mypl = pl; }   // (slot = index of the work item in this launch)
+        if (FULL) myslot = next_i + rank;   // (slot = index of the work item in this launch)
         kb0 = pbase - k0; tb = pbase + nwp * 16;
         jt = bad ? 0 : ak - k0;
         tend = bad ? 0xffffu : (uint32_t)tl;
@@ -389,7 +280,6 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
       }
       WFA_LANE_MARK("refill_end");
     } else if (idle == ~0ull) {
-      flush_walks();
       break;                                 // nothing left
     }
 
@@ -527,7 +417,7 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
       // at or before the next step's, R/wavefront_unialign.c:98-107) and a pair whose band no longer holds its wavefront
       unsigned long long blimit = 0ull;
       if constexpr (HEUR) blimit = __ballot(a.max_steps != NEVER && __mul24(gstep - s0 + 1, a.g) >= a.max_steps) & active & ~bfin;
-      const unsigned long long brej = __ballot(gstep > deadline || (HEUR && edge_live)) & active & ~blimit;
+      const unsigned long long brej = __ballot(gstep > deadline || (HEUR && edge_live) || (FULL && codes_full)) & active & ~blimit;
       const unsigned long long bd = bfin | brej | blimit;
       if (bd) {
         WFA_LANE_MARK("bd_begin");
@@ -536,13 +426,13 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
         if (__builtin_amdgcn_inverse_ballot_w64(ba)) {
           a.score[mypid] = -__mul24(gstep - s0, a.g);
           a.status[mypid] = 0;
-          if (FULL) { fin_t = gstep - s0; fin_j = jt; fin_tl = (int)tend; }
+          // FULL: where the walk starts: the record of this step in the wave's list, my lane and end slot, the steps taken
+          if (FULL) a.end_state[myslot] = make_int4((int)(blockIdx.x * (unsigned)a.codes_cap + (unsigned)gstep), lane | (jt << 8), gstep - s0, 1);
         }
         if (HEUR && __builtin_amdgcn_inverse_ballot_w64(blimit)) {
           a.score[mypid] = -a.max_steps;
           a.status[mypid] = WFA_STATUS_MAX_STEPS_REACHED;
         }
-        if (FULL) pending |= ba;
         if (brej) {
           uint32_t slot = 0;
           if (lane == 0) slot = atomicAdd(a.fb_count, (uint32_t)__builtin_popcountll(brej));
@@ -561,7 +451,7 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
         }
         idle |= bd;
         WFA_LANE_MARK("bd_end");
-        if (idle == ~0ull && next_i >= end) { flush_walks(); break; }
+        if (idle == ~0ull && next_i >= end) break;
       }
     }
 
@@ -670,11 +560,12 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
         }
       }
       if constexpr (FULL) {
-        // record of the step being made (index gstep + 1 - s0): bytes 0..3 = registers 0..3, 4..7 = registers 4..7
+        // bytes 0..3 = registers 0..3, 4..7 = registers 4..7
         const uint32_t c0 = cbyte[0] | (cbyte[1] << 8) | (cbyte[2] << 16) | (cbyte[3] << 24);
         const uint32_t c1 = cbyte[4] | (cbyte[5] << 8) | (cbyte[6] << 16) | (cbyte[7] << 24);
-        const int trec = gstep + 1 - s0;
-        if (!__builtin_amdgcn_inverse_ballot_w64(idle) && trec < NREC && !(dbg_flags & 2)) { lds[cbase + 2 * trec] = c0; lds[cbase + 2 * trec + 1] = c1; }
+        // the record of the step being made: one 512-byte store of the wave (idle lanes write along: nobody reads theirs)
+        if (gstep + 1 < a.codes_cap) wave_codes[(unsigned)(gstep + 1) * 64u + (unsigned)lane] = make_uint2(c0, c1);
+        else codes_full = true;
       }
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
@@ -728,6 +619,21 @@ inline int lane_slot_words(int max_len) {
 // shape_idx: index in WFA_SEG_SHAPES (seg_shape()); per_cu: slices of the work list (waves) per CU
 // records of origin codes per lane of the FULL form for a penalty shape (LaneFull<OE, E>::NREC)
 inline int lane_full_records(int OE, int E) { return 2 * (OE - E) + E * 17 + 1; }
+// FULL form: waves of a launch over `nwork` pairs and the records a wave's list needs.  A wave of `per` pairs makes at most
+// per x NREC lane-steps with >= 64 - refill_min - (a burst) lanes busy: per x NREC / 32 + 2 NREC records are never reached in
+// practice, and a wave that does fill its list hands the rest of its pairs on.
+inline void lane_full_geometry(uint32_t nwork, int cu_count, int per_cu, int min_pairs, int OE, int E, long long* grid_out, int* cap_out) {
+  if (min_pairs <= 0) min_pairs = 256;
+  long long grid = (long long)cu_count * per_cu;
+  const long long max_grid = ((long long)nwork + min_pairs - 1) / std::max(min_pairs, 64);
+  if (grid > max_grid) grid = max_grid;
+  if (grid < 1) grid = 1;
+  const long long per = ((long long)nwork + grid - 1) / grid;
+  const int nrec = lane_full_records(OE, E);
+  *grid_out = grid;
+  *cap_out = (int)(per * nrec / 32 + 2 * nrec + 8);
+}
+
 // run records per pair of the FULL form (ints of a slot): an alignment inside the band has at most Bmin / g edits
 #define WFA_LANE_RUN_SLOT 32
 
@@ -750,16 +656,15 @@ inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_
   const uint32_t nwork = a.nwork;
   const uint32_t* nwork_dev = a.nwork_dev;
   const int slot_words = lane_slot_words(std::min(max_len, WFA_FAST_MAX_LEN));
-  const int lane_words = full ? ((slot_words + 2 * lane_full_records(OE, E)) | 1) : slot_words;   // (as the kernel computes it)
-  const size_t smem = ((size_t)64 * lane_words + 8) * sizeof(uint32_t) + (size_t)lds_pad_kb * 1024;   // (lds_pad_kb: occupancy experiments)
+  const size_t smem = ((size_t)64 * slot_words + 8) * sizeof(uint32_t) + (size_t)lds_pad_kb * 1024;   // (lds_pad_kb: occupancy experiments)
   // every wave should see several hundred pairs (64 lanes x a few refills), and there should be several waves per SIMD
   long long grid = (long long)cu_count * per_cu;
-  // a wave should see a few refills' worth of pairs: 256 in the score-only form; the FULL form holds fewer waves per CU (its
-  // records live in LDS), so shorter slices balance better there (1 M pairs: 64 per wave -7 %)
-  if (min_pairs <= 0) min_pairs = full ? 64 : 256;
+  // a wave should see a few refills' worth of pairs
+  if (min_pairs <= 0) min_pairs = 256;
   const long long max_grid = ((long long)nwork + min_pairs - 1) / std::max(min_pairs, 64);
   if (!nwork_dev && grid > max_grid) grid = max_grid;
   if (grid < 1) grid = 1;
+  if (full && a.codes_cap <= 0) return -1;   // (the caller sizes the record lists with lane_full_geometry)
   switch (shape_idx) {
     case 0: return launch_lane_s0((unsigned)grid, smem, stream, a, slot_words, refill_min, full, heur);
     case 1: return launch_lane_s1((unsigned)grid, smem, stream, a, slot_words, refill_min, full, heur);
