@@ -1526,7 +1526,9 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     // it walks in-kernel and leaves only run records in HBM (WFA_LANE_RUN_SLOT ints + an end state per pair), so the whole batch
     // is one launch; WFA_HIP_LANE_FULL=0 keeps round 2's 16-lane segments with explicit offset records
     const bool use_lanefull = use_segfull && n_segfull >= 1 && segfull_w[0] == 16 && knob(al, K_LANE_FULL, 1) != 0;
-    if (use_lanefull) { for (int i = 1; i < n_segfull; ++i) segfull_w[i - 1] = segfull_w[i]; --n_segfull; }
+    // (behind it one segment stage, 32 lanes, then the banded kernel: the 64-lane stage cost more in launches than its ~300 pairs per
+    // million are worth)
+    if (use_lanefull) { for (int i = 1; i < n_segfull; ++i) segfull_w[i - 1] = segfull_w[i]; --n_segfull; if (!al->knobs.set[K_SEGFULL_STAGES]) n_segfull = std::min(n_segfull, 1); }
     const int64_t lanefull_slot_bytes = (int64_t)WFA_LANE_RUN_SLOT * 4 + (int64_t)sizeof(int4);
     int64_t lanefull_cap = 0;
     long long lanefull_grid = 0;
