@@ -23,7 +23,7 @@ WFA_BAND_DEFINE(3, 3, 5, 1, 0, 0)
 WFA_BAND_DEFINE(4, 4, 8, 2, 25, 1)
 #elif WFA_TU_INDEX == 5
 int launch_band_bt(const BandArgs& a, int nch, hipStream_t stream) { return launch_band_bt_impl(a, nch, stream); }
-int launch_lane_expand(const BandArgs& a, hipStream_t stream) { return launch_lane_expand_impl(a, stream); }
+int launch_lane_expand(const BandArgs& a, hipStream_t walk_stream, hipStream_t expand_stream) { return launch_lane_expand_impl(a, walk_stream, expand_stream); }
 #else
 #error "WFA_TU_INDEX: 0..3 gap-affine shapes, 4 gap-affine-2p, 5 walks"
 #endif

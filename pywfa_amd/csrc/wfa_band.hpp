@@ -1138,12 +1138,19 @@ wfa_lane_expand_kernel(const BandArgs a) {
   }
 }
 
-inline int launch_lane_expand_impl(const BandArgs& a, hipStream_t stream) {
+// (the walk can hand a pair on, so it runs before the next stage; the expand only reads run records and writes op bytes, so
+// the host may put it on a side stream under the stages behind the lane kernel)
+inline int launch_lane_expand_impl(const BandArgs& a, hipStream_t walk_stream, hipStream_t expand_stream) {
   if (a.nwork == 0) return 0;
-  hipLaunchKernelGGL(wfa_lane_walk_kernel, dim3((a.nwork + 63u) / 64u), dim3(64), 0, stream, a);
-  if (hipGetLastError() != hipSuccess) return -1;
-  hipLaunchKernelGGL(wfa_lane_expand_kernel, dim3((a.nwork + 15u) / 16u), dim3(256), 0, stream, a);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  if (walk_stream) {
+    hipLaunchKernelGGL(wfa_lane_walk_kernel, dim3((a.nwork + 63u) / 64u), dim3(64), 0, walk_stream, a);
+    if (hipGetLastError() != hipSuccess) return -1;
+  }
+  if (expand_stream) {
+    hipLaunchKernelGGL(wfa_lane_expand_kernel, dim3((a.nwork + 15u) / 16u), dim3(256), 0, expand_stream, a);
+    if (hipGetLastError() != hipSuccess) return -1;
+  }
+  return 0;
 }
 
 inline int launch_band_bt_impl(const BandArgs& a, int nch, hipStream_t stream) {
@@ -1212,7 +1219,7 @@ static int launch_band_shape(const BandArgs& a, int nch, bool full, bool adapt, 
 // ---- host entry points.  Every penalty shape is compiled in its own translation unit (csrc/k_band.hip, once per
 // index; index 4 = gap-affine-2p, index 5 = the walks / expansion kernels) so that the library builds in parallel.
 int launch_band_bt(const BandArgs& a, int nch, hipStream_t stream);
-int launch_lane_expand(const BandArgs& a, hipStream_t stream);   // op bytes from the run records of wfa_lane_kernel<.., FULL>
+int launch_lane_expand(const BandArgs& a, hipStream_t walk_stream, hipStream_t expand_stream);   // walk the codes of wfa_lane_kernel<.., FULL> into run records / run records into op bytes (either stream may be null: that half is skipped)
 #define WFA_BAND_DECL(i, x, oe, e) int launch_band_s##i(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds, long long grid, hipStream_t stream);
 WFA_BAND_SHAPES(WFA_BAND_DECL)
 #undef WFA_BAND_DECL

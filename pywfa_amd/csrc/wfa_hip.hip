@@ -42,7 +42,7 @@ static thread_local std::string g_error;
   F(ARENA_KB) F(BAND_DEBUG) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
-  F(LANE_FULL) F(LANE_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
+  F(LANE_FULL) F(LANE_FULL_SPLIT) F(LANE_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
 enum WfaKnob {
 #define WFA_KNOB_ENUM(n) K_##n,
   WFA_KNOBS(WFA_KNOB_ENUM)
@@ -1529,20 +1529,6 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     // (behind it one segment stage, 32 lanes, then the banded kernel: the 64-lane stage cost more in launches than its ~300 pairs per
     // million are worth)
     if (use_lanefull) { for (int i = 1; i < n_segfull; ++i) segfull_w[i - 1] = segfull_w[i]; --n_segfull; if (!al->knobs.set[K_SEGFULL_STAGES]) n_segfull = std::min(n_segfull, 1); }
-    const int64_t lanefull_slot_bytes = (int64_t)WFA_LANE_RUN_SLOT * 4 + (int64_t)sizeof(int4);
-    int64_t lanefull_cap = 0;
-    long long lanefull_grid = 0;
-    int lanefull_recs = 0, lf_x = 0, lf_oe = 0, lf_e = 0;
-    size_t lanefull_codes_off = 0;
-    if (use_lanefull) {
-      (void)wfa::seg_shape(b->dcfg, &lf_x, &lf_oe, &lf_e);
-      // per launch: run records + end state per pair, and the waves' record lists of comparison bits (512 bytes per wave-step)
-      lanefull_cap = std::max<int64_t>(1, std::min<int64_t>(in_n, free_budget(al) / (lanefull_slot_bytes + 256)));
-      wfa::lane_full_geometry((uint32_t)lanefull_cap, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_MIN_PAIRS, 0), lf_oe, lf_e,
-                              &lanefull_grid, &lanefull_recs);
-      lanefull_codes_off = ((size_t)(lanefull_cap * lanefull_slot_bytes) + 255) & ~(size_t)255;
-      need = std::max(need, lanefull_codes_off + (size_t)lanefull_grid * (size_t)lanefull_recs * 512);
-    }
     if (use_segfull) {
       for (int i = 0; i < n_segfull; ++i) {
         const int rank = i + (use_lanefull ? 1 : 0);   // position in the cascade: 0 = takes the whole batch
@@ -1555,9 +1541,36 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         need = std::max(need, (size_t)(segfull_cap[i] * slot_bytes) * ((rank == 0 && segfull_cap[i] < (int64_t)in_n) ? 2 : 1));
       }
     }
+    // the lane-full stage's region lies BEHIND everything the later stages use (its expand runs on the side stream under them)
+    const int64_t lanefull_slot_bytes = (int64_t)WFA_LANE_RUN_SLOT * 4 + (int64_t)sizeof(int4);
+    int64_t lanefull_cap = 0;
+    long long lanefull_grid = 0;
+    int lanefull_recs = 0, lf_x = 0, lf_oe = 0, lf_e = 0;
+    size_t lanefull_off = 0, lanefull_codes_off = 0, lanefull_codes_bytes = 0, lanefull_list_off = 0;
+    int lanefull_split = 1;   // > 1: every launch has slots and code lists of its own
+    if (use_lanefull) {
+      (void)wfa::seg_shape(b->dcfg, &lf_x, &lf_oe, &lf_e);
+      lanefull_off = (need + 255) & ~(size_t)255;
+      // per launch: run records + end state per pair, and the waves' record lists of comparison bits (512 bytes per wave-step)
+      const int64_t lf_budget = std::max<int64_t>((int64_t)free_budget(al) - (int64_t)lanefull_off, (int64_t)1 << 20);
+      lanefull_cap = std::max<int64_t>(1, std::min<int64_t>(in_n, lf_budget / (lanefull_slot_bytes + 256)));
+      // When the whole batch fits (the usual case) it is cut into balanced launches with code lists of their own: walk + expand of a
+      // launch (latency- and memory-bound) run on the side stream under the lane kernel (issue-bound) of the next
+      if (lanefull_cap >= (int64_t)in_n) {
+        lanefull_split = std::max(1, std::min(8, knob(al, K_LANE_FULL_SPLIT, (int64_t)in_n >= 524288 ? 2 : 1)));
+        lanefull_cap = ((((int64_t)in_n + lanefull_split - 1) / lanefull_split) + 63) & ~63ll;
+      }
+      wfa::lane_full_geometry((uint32_t)lanefull_cap, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_MIN_PAIRS, 0), lf_oe, lf_e,
+                              &lanefull_grid, &lanefull_recs);
+      lanefull_codes_off = lanefull_off + (((size_t)(lanefull_cap * lanefull_split * lanefull_slot_bytes) + 255) & ~(size_t)255);
+      lanefull_codes_bytes = ((size_t)lanefull_grid * (size_t)lanefull_recs * 512 + 255) & ~(size_t)255;
+      lanefull_list_off = lanefull_codes_off + lanefull_codes_bytes * (size_t)lanefull_split;
+      need = std::max(need, lanefull_list_off + (size_t)in_n * sizeof(uint32_t));
+    }
     int rc = ensure_ws(al, need);
     if (rc != WFA_HIP_OK) return rc;
 
+    DualStream lane_expands{al, stream};   // the expand of the lane-full stage, left running under the stages behind it
     if (use_lanefull) {
       uint32_t* out_list = b->d_fb_list2[out_sel];
       uint32_t* out_count = b->d_counters + 4 + out_sel;
@@ -1568,25 +1581,41 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       fa.words = b->d_words; fa.meta = b->d_meta; fa.worklist = in_list; fa.nwork_dev = nullptr;
       fa.score = b->d_score; fa.status = b->d_status; fa.fb_list = out_list; fa.fb_count = out_count;
       fa.g = wfa::gcd_int(wfa::gcd_int(b->dcfg.x, b->dcfg.o1 + b->dcfg.e1), b->dcfg.e1);
-      fa.hist = al->ws; fa.hist_stride = WFA_LANE_RUN_SLOT;
-      fa.end_state = reinterpret_cast<int4*>(reinterpret_cast<char*>(al->ws) + (size_t)lanefull_cap * WFA_LANE_RUN_SLOT * 4);
+      const int64_t lf_slots = lanefull_cap * lanefull_split;   // slots in the region (split: slot = work item; otherwise one launch's worth, reused)
+      int32_t* const lf_runs = al->ws + lanefull_off / 4;
+      int4* const lf_ends = reinterpret_cast<int4*>(reinterpret_cast<char*>(al->ws) + lanefull_off + (size_t)lf_slots * WFA_LANE_RUN_SLOT * 4);
+      fa.hist = lf_runs; fa.hist_stride = WFA_LANE_RUN_SLOT; fa.end_state = lf_ends;
       fa.codes = reinterpret_cast<uint2*>(reinterpret_cast<char*>(al->ws) + lanefull_codes_off); fa.codes_cap = lanefull_recs;
       wfa::BandArgs ba;
       memset(&ba, 0, sizeof(ba));
       ba.meta = b->d_meta; ba.worklist = in_list; ba.words = b->d_words;
       ba.cigar_ops = b->d_ops; ba.cigar_off = b->d_cigar_off; ba.cigar_begin = b->d_cigar_begin; ba.cigar_len = b->d_cigar_len;
       ba.hist = fa.hist; ba.hist_stride = fa.hist_stride; ba.end_state = fa.end_state;
-      ba.lane_codes = fa.codes; ba.status = b->d_status; ba.fb_list = out_list; ba.fb_count = out_count;
+      // (the walk hands a pair with more runs than its slot holds to a list of its own, taken by the general kernel after the join:
+      // walk and expand both run beside the later stages)
+      uint32_t* const walk_list = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(al->ws) + lanefull_list_off);
+      ba.lane_codes = fa.codes; ba.status = b->d_status; ba.fb_list = walk_list; ba.fb_count = b->d_counters + 8;
       ba.g = fa.g; ba.x = b->dcfg.x; ba.oe = b->dcfg.o1 + b->dcfg.e1; ba.e = b->dcfg.e1;
-      for (int64_t w0 = 0; w0 < (int64_t)in_n; w0 += lanefull_cap) {
+      // one launch (the usual case): the op bytes are written on the side stream while the main stream goes on with what was handed on
+      { const int drc = lane_expands.begin(lf_slots >= (int64_t)in_n); if (drc != WFA_HIP_OK) return drc; }
+      int64_t launch = 0;
+      for (int64_t w0 = 0; w0 < (int64_t)in_n; w0 += lanefull_cap, ++launch) {
         const uint32_t cnt = (uint32_t)std::min<int64_t>(lanefull_cap, (int64_t)in_n - w0);
         fa.work_begin = (uint32_t)w0; fa.nwork = cnt;
+        if (lf_slots >= (int64_t)in_n) {   // slots and code lists of this launch
+          fa.hist = lf_runs + w0 * WFA_LANE_RUN_SLOT; fa.end_state = lf_ends + w0;
+          fa.codes = reinterpret_cast<uint2*>(reinterpret_cast<char*>(al->ws) + lanefull_codes_off + (size_t)launch * lanefull_codes_bytes);
+          ba.hist = fa.hist; ba.end_state = fa.end_state; ba.lane_codes = fa.codes;
+        }
         // (a shorter last launch has fewer waves and needs fewer records than the lists were sized for)
         if (wfa::launch_lane_args(shape, OE, E, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, fa, true, 0, knob(al, K_LANE_MIN_PAIRS, 0)) != 0) {
           al->err = "lane kernel launch failed"; return WFA_HIP_EDEVICE;
         }
         ba.work_begin = (uint32_t)w0; ba.nwork = cnt;
-        if (wfa::launch_lane_expand(ba, stream) != 0) { al->err = "expand launch failed"; return WFA_HIP_EDEVICE; }
+        hipStream_t es_ = stream;
+        { const int drc = lane_expands.walk_stream(launch, &es_); if (drc != WFA_HIP_OK) return drc; }
+        if (wfa::launch_lane_expand(ba, es_, es_) != 0) { al->err = "walk / expand launch failed"; return WFA_HIP_EDEVICE; }
+        { const int drc = lane_expands.after_walk(launch); if (drc != WFA_HIP_OK) return drc; }
       }
       if (first_stage) b->last_kernel_pairs = in_n;
       in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
@@ -1819,6 +1848,12 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
                             b->d_ovf_list[0], b->d_counters + 1);
     if (rc != WFA_HIP_OK) return rc;
     if (first_stage) b->last_kernel_pairs = in_n;
+    { const int drc = lane_expands.end(); if (drc != WFA_HIP_OK) return drc; }
+    if (use_lanefull) {   // what the walks of the lane-full stage handed on (nothing, as a rule)
+      rc = launch_general_dyn(al, b, stream, true, reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(al->ws) + lanefull_list_off), b->d_counters + 8,
+                              (uint32_t)b->n_packed, g.ws_stride, g.grid, g.threads, b->d_ovf_list[0], b->d_counters + 1);
+      if (rc != WFA_HIP_OK) return rc;
+    }
   }
   HIP_TRY(al, hipEventRecord(ev1, stream));
   // 3) 8-bit pairs (non-ACGT letters, wildcard matching)

@@ -6,6 +6,7 @@ TAG=${1:-r02}
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
+python3 -c "import bench; print(bench.kernel_source_hash())" > $OUT/${TAG}_kernel_source_hash.txt
 hipcc --offload-arch=gfx950 -O3 tools/issue_rate.hip -o /tmp/issue_rate && timeout 120 /tmp/issue_rate > $OUT/${TAG}_issue_rate.txt 2>&1
 rocprofv3 -L > $OUT/${TAG}_counters_list.txt 2>&1
 ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-configs"

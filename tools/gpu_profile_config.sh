@@ -8,6 +8,7 @@ OUT=gpurun_out
 P=$OUT/${TAG}_${CFG}
 mkdir -p $OUT
 export TMPDIR=/tmp NO_CPU=1 BRIEF=1
+python3 -c "import bench; print(bench.kernel_source_hash())" > $OUT/${TAG}_kernel_source_hash.txt
 pass() {  # name, counters...
   local name=$1; shift
   timeout 900 rocprofv3 --kernel-trace --pmc "$@" -d ${P}_pmc_$name -o pmc --output-format csv -- python3 tools/gpu_perf.py $CFG > ${P}_pmc_$name.log 2>&1

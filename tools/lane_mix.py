@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Dynamic instruction mix of wfa_lane_kernel<2,4,1,false> (the C2 hot loop): which share of its vector instructions runs at
+"""Dynamic instruction mix of wfa_lane_kernel<2,4,1,false,false> (the C2 hot loop): which share of its vector instructions runs at
 the full issue rate (development aid).
 
     python tools/lane_mix.py [counts-file]
@@ -19,7 +19,7 @@ import json, os, re, subprocess, sys, collections
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 CSRC = os.path.join(ROOT, "pywfa_amd", "csrc")
 ASM = "/tmp/k_lane_marks.s"
-KERNEL = "_ZN3wfa15wfa_lane_kernelILi2ELi4ELi1ELb0EEEvNS_8FastArgsEii"
+KERNEL = "_ZN3wfa15wfa_lane_kernelILi2ELi4ELi1ELb0ELb0EEEvNS_8FastArgsEii"
 FULL_RATE = ("v_add_u32", "v_add_co_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_and_or_b32", "v_or3_b32", "v_not_b32")
 
 

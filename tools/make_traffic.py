@@ -12,6 +12,10 @@ sys.path.insert(0, ROOT)
 import bench
 
 root, tag = sys.argv[1], sys.argv[2]
+def measured_hash():
+    """the hash the measured build printed on the GPU box (tools/gpu_counters.sh); this tree's if that file is absent"""
+    f = os.path.join(root, f"{tag}_kernel_source_hash.txt")
+    return open(f).read().strip() if os.path.exists(f) else bench.kernel_source_hash()
 def per_dispatch(name):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(set)
     for f in glob.glob(os.path.join(root, f"{tag}_pmc_{name}", "**", "*counter_collection.csv"), recursive=True):
@@ -83,9 +87,13 @@ out = {
     "hbm_bytes_per_launch": int(fetch_kb * 1024 * 2 + write_kb * 1024),
     "correction": "gfx950: FETCH_SIZE tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE taken as is",
     "secondary": sec,
-    "kernel_source_hash": bench.kernel_source_hash(), "git_head": head,
+    "kernel_source_hash": measured_hash(), "git_head": head,
     "source": f"rocprofv3 --pmc, separate passes (tools/gpu_counters.sh {tag}): profiles/{tag}_pmc_*.txt; python3 bench.py --steps 2 --warmup 1",
 }
+import shutil
+for part in ("kernel_stats.csv", "pmc_sq1.txt", "pmc_sq2.txt", "pmc_fetch.txt", "pmc_write.txt", "issue_rate.txt", "lane_regions.txt"):
+    if os.path.exists(os.path.join(root, f"{tag}_{part}")):
+        shutil.copy(os.path.join(root, f"{tag}_{part}"), os.path.join(ROOT, "profiles", f"{tag}_{part}"))
 with open(os.path.join(ROOT, "profiles", "traffic_c2.json"), "w") as f:
     json.dump(out, f, indent=1)
 print(json.dumps(out, indent=1))
