@@ -444,7 +444,11 @@ def main():
                 # (long reads keep the piggy-back history by default; WFA_HIP_BAND_PB=0 = the explicit offsets, for the record)
                 dict(name="C3", n=100_000, length=10000, error=0.08, seed=datagen.SEEDS["C3"],
                      cfg_kw=dict(span="end-to-end", scope="full", heuristic="adaptive"), scheme="piggyback", survey_bytes=114e3),
-                dict(name="C4-adaptive", n=20_000, length=10000, error=0.08, seed=datagen.SEEDS["C4"], cfg_kw=dict(C4, heuristic="adaptive"),
+                # (the same path on a batch that fills the chip: a 1 M-pair launch of the lane kernel is 3 900 waves)
+                dict(name="C1-10M-pairs", n=10_000_000, length=150, error=0.02, seed=datagen.SEEDS["C1"], cfg_kw=dict(scope="full"), scheme="explicit",
+                     survey_bytes=236, cpu_pairs=100000, cpu_budget=2.0),
+                # (100 k pairs: the last stage of this cascade is one alignment's latency long whatever the batch size)
+                dict(name="C4-adaptive", n=100_000, length=10000, error=0.08, seed=datagen.SEEDS["C4"], cfg_kw=dict(C4, heuristic="adaptive"),
                      scheme="piggyback", survey_bytes=114e3 * 5 / 3, trim=50, cpu_pairs=100),
                 dict(name="C4-exact", n=4096, length=10000, error=0.08, seed=datagen.SEEDS["C4"], cfg_kw=C4, scheme="piggyback", survey_bytes=54e6,
                      trim=50, cpu_pairs=8, cpu_budget=3.0, mt_parity_pairs=64),
@@ -472,8 +476,8 @@ def main():
                 except Exception as e:
                     xs.append({"name": kw_["name"], "error": repr(e)})
             out["extra"]["configs"] = xs
-            out["extra"]["configs_note"] = ("stated prefixes of the BASELINE streams: C1 at 1 M pairs (BASELINE names 1 k), C3 100 k of 1 M, "
-                                            "C4 as written (no heuristic) on 4 096 pairs (54 MB per pair: SURVEY's piggy-back figure) and with wf-adaptive on 20 k of "
+            out["extra"]["configs_note"] = ("stated prefixes of the BASELINE streams: C1 at 1 M pairs (BASELINE names 1 k; and at 10 M, a batch that fills the chip), C3 100 k of 1 M, "
+                                            "C4 as written (no heuristic) on 4 096 pairs (54 MB per pair: SURVEY's piggy-back figure) and with wf-adaptive on 100 k of "
                                             "1 M (its bytes per pair are C3's figure x 5/3 components); exact (no heuristic) gap-affine 10 kb on 8 192 pairs, score and full CIGAR "
                                             "(5.1 M M-offsets per pair: one history byte each); C5 with wf-adaptive on 8 192 of 100 k pairs (X-drop(20) / match = 0 as "
                                             "BASELINE writes C5 drops every pair after a few steps, SURVEY Q2); C2 above is the full 10 M.  Long reads keep the "

@@ -9,6 +9,9 @@ namespace wfa {
   }                                                                                                              \
   int launch_seg_full_s##i(int w, unsigned grid, hipStream_t stream, const FastArgs& a) {                        \
     return launch_seg_full_shape<x, oe, e>(w, grid, stream, a);                                                  \
+  }                                                                                                              \
+  int launch_seg_heur_s##i(unsigned grid, hipStream_t stream, const FastArgs& a) {                               \
+    return launch_seg_heur_shape<x, oe, e>(grid, stream, a);                                                     \
   }
 #if WFA_TU_INDEX == 0
 WFA_SEG_DEFINE(0, 2, 4, 1)

@@ -42,7 +42,7 @@ static thread_local std::string g_error;
   F(ARENA_KB) F(BAND_DEBUG) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
-  F(LANE_FULL) F(LANE_FULL_SPLIT) F(LANE_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
+  F(LANE_FULL) F(LANE_FULL_SPLIT) F(LANE_HEUR) F(SEG_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
 enum WfaKnob {
 #define WFA_KNOB_ENUM(n) K_##n,
   WFA_KNOBS(WFA_KNOB_ENUM)
@@ -217,6 +217,7 @@ struct wfa_hip_batch {
   // waits for it (the host-packed upload returns with its DMAs still in flight)
   hipEvent_t upload_event = nullptr;
   int stage_pick = 0;  // first register-kernel stage chosen by the pilot of the first run (0 = not yet): 16, 32 or 64 lanes
+  int segh_pick = 0;   // the same for the general form of the 32-lane segments (wfa_seg_kernel<.., HEUR>)
   int laneh_pick = 0;  // general score-only form of the lane kernel first (wf-adaptive / free ends / step limit): 1 yes, 2 no (its pilot), 0 undecided
   int64_t arena_ints = 0;  // FULL: arena size used by the last launch (the part that grows 8x when a pair overflows it)
   int64_t arena_fixed = 0; // FULL, piggy-back history of the general kernel: the score-only ring in front of the growing part
@@ -1028,20 +1029,25 @@ static int pilot_first_width(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t 
 // decides once per batch, when the batch is created (b->laneh_pick: 1 = first stage, 2 = not used).
 static int pilot_lane_heur(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream) {
   if (b->laneh_pick != 0 || b->cfg.scope == WFA_SCOPE_FULL) return WFA_HIP_OK;
-  b->laneh_pick = 2;
+  b->laneh_pick = 2; b->segh_pick = 2;
   int X, OE, E;
   if (!wfa::lane_heur_config(b->dcfg, b->ncomp) || wfa::seg_supported(b->dcfg, b->ncomp, false) ||
       wfa::seg_shape(b->dcfg, &X, &OE, &E) < 0 || b->max_len > WFA_FAST_MAX_LEN || knob(al, K_NO_FAST, 0) != 0) return WFA_HIP_OK;
-  const int forced = knob(al, K_LANE_HEUR, -1);   // (WFA_HIP_LANE_HEUR = 1 / 0: always / never, whatever the batch)
-  if (forced >= 0) { b->laneh_pick = forced ? 1 : 2; return WFA_HIP_OK; }
-  if (b->n_packed < 65536u) return WFA_HIP_OK;
+  const bool free_begins = b->dcfg.endsfree && (b->dcfg.pbf | b->dcfg.tbf) != 0;
+  const bool seg_ok = wfa::seg_heur_config(b->dcfg, b->ncomp);
+  const int forced = knob(al, K_LANE_HEUR, -1);       // (WFA_HIP_LANE_HEUR = 1 / 0: always / never, whatever the batch)
+  const int forced_seg = knob(al, K_SEG_HEUR, -1);    // (WFA_HIP_SEG_HEUR likewise)
+  if (forced >= 0) b->laneh_pick = forced ? 1 : 2;
+  if (forced_seg >= 0) b->segh_pick = (forced_seg && seg_ok) ? 1 : 2;
+  else if (seg_ok && !free_begins) b->segh_pick = 1;  // (small batches: on, unless wavefront 0 already spans many diagonals)
+  if ((forced >= 0 && (forced_seg >= 0 || !seg_ok)) || b->n_packed < 65536u) return WFA_HIP_OK;
   const uint32_t np = 8192u, stride = b->n_packed / np;
   uint32_t* plist = b->d_fb_list2[0];
   uint32_t* psample = b->d_fb_list2[1];
   uint32_t* pcount = b->d_counters + 4;
   hipLaunchKernelGGL(wfa_pilot_sample_kernel, dim3((np + 255u) / 256u), dim3(256), 0, stream, b->d_list_packed, stride, np, psample);
   HIP_TRY(al, hipGetLastError());
-  HIP_TRY(al, hipMemsetAsync(pcount, 0, sizeof(uint32_t), stream));
+  HIP_TRY(al, hipMemsetAsync(pcount, 0, 2 * sizeof(uint32_t), stream));
   wfa::FastArgs fa;
   memset(&fa, 0, sizeof(fa));
   fa.words = b->d_words; fa.meta = b->d_meta; fa.worklist = psample; fa.nwork = np;
@@ -1051,13 +1057,19 @@ static int pilot_lane_heur(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t st
   fa.pbf = b->dcfg.pbf; fa.pef = b->dcfg.pef; fa.tbf = b->dcfg.tbf; fa.tef = b->dcfg.tef;
   fa.heur = b->dcfg.heuristic; fa.min_wf_len = b->dcfg.min_wf_len; fa.max_dist_thr = b->dcfg.max_dist_thr;
   fa.steps_between = b->dcfg.steps_between; fa.max_steps = b->dcfg.max_steps;
-  if (wfa::launch_lane_args(wfa::seg_shape(b->dcfg, &X, &OE, &E), OE, E, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8),
+  if (forced < 0 &&
+      wfa::launch_lane_args(wfa::seg_shape(b->dcfg, &X, &OE, &E), OE, E, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8),
                             b->max_len, stream, fa, false, 0, 256, true) != 0) { al->err = "pilot launch failed"; return WFA_HIP_EDEVICE; }
-  uint32_t handed = 0;
-  HIP_TRY(al, hipMemcpyAsync(&handed, pcount, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  if (forced_seg < 0 && seg_ok) {   // (the same sample through the 32-lane form; its list is not read, only its count)
+    fa.fb_count = pcount + 1;
+    if (wfa::launch_seg_heur(b->dcfg, al->cu_count, knob(al, K_FAST_WAVES_PER_CU, 256), stream, fa) != 0) { al->err = "pilot launch failed"; return WFA_HIP_EDEVICE; }
+  }
+  uint32_t handed[2] = {0, 0};
+  HIP_TRY(al, hipMemcpyAsync(handed, pcount, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   HIP_TRY(al, hipStreamSynchronize(stream));
-  HIP_TRY(al, hipMemsetAsync(pcount, 0, sizeof(uint32_t), stream));
-  if (handed * 4u <= np) b->laneh_pick = 1;   // at most a quarter handed on
+  HIP_TRY(al, hipMemsetAsync(pcount, 0, 2 * sizeof(uint32_t), stream));
+  if (forced < 0) b->laneh_pick = (handed[0] * 4u <= np) ? 1 : 2;                  // at most a quarter handed on
+  if (forced_seg < 0 && seg_ok) b->segh_pick = (handed[1] * 4u <= np) ? 1 : 2;
   return WFA_HIP_OK;
 }
 
@@ -1348,6 +1360,11 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     const bool use_laneh = !tiny && !full && !use_fast && wfa::lane_heur_config(b->dcfg, b->ncomp) && wfa::seg_shape(b->dcfg, &lh_x, &lh_oe, &lh_e) >= 0 &&
                            b->max_len <= WFA_FAST_MAX_LEN && knob(al, K_NO_FAST, 0) == 0 &&
                            (b->laneh_pick == 1 || (b->laneh_pick == 0 && knob(al, K_LANE_HEUR, 0) != 0));   // (the pilot of batch_build, or WFA_HIP_LANE_HEUR=1)
+    // ... and then (or first, when the lane form's pilot said no) the same form of the 32-lane segments: two pairs per wave, a band twice
+    // as wide (WFA_HIP_SEG_HEUR=0: off)
+    const bool use_segh = !tiny && !full && !use_fast && wfa::seg_heur_config(b->dcfg, b->ncomp) && b->max_len <= WFA_FAST_MAX_LEN &&
+                          knob(al, K_NO_FAST, 0) == 0 && !wfa::seg_supported(b->dcfg, b->ncomp, false) &&
+                          (b->segh_pick == 1 || (b->segh_pick == 0 && knob(al, K_SEG_HEUR, 0) != 0));   // (the pilot of batch_build, or WFA_HIP_SEG_HEUR=1)
     if (!tiny && wfa::band_supported(b->dcfg, b->ncomp) && (b->ncomp != 5 || b->max_len < 32000) && knob(al, K_NO_BAND, 0) == 0) {
       if (b->ncomp == 5) {
         // gap-affine-2p wavefronts are wide (C4: 99 % need more than 108 diagonals, 2.6 % more than 172)
@@ -1369,7 +1386,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
                          b->max_len > 64 && 2 * (int64_t)b->max_len <= 0x3fffff00ll && b->dcfg.e1 >= 1 && b->dcfg.x >= 1 && knob(al, K_NO_WIDE, 0) == 0;
     // reads beyond 16 kb (plen + tlen > 32 000 does not fit int16 offsets): the workspace-row form with int32 rows (round 3)
     const bool wide32 = 2 * (int64_t)b->max_len > 32000;
-    const bool any_pre = use_fast || use_laneh || use_segfull || n_stages > 0 || wide_ok;
+    const bool any_pre = use_fast || use_laneh || use_segh || use_segfull || n_stages > 0 || wide_ok;
     Geometry g = plan_general(al, b, any_pre ? std::min<uint32_t>(in_n, (uint32_t)al->cu_count * 16) : in_n, b->arena_fixed + b->arena_ints);
     size_t need = (size_t)g.grid * g.ws_stride * 4;
     // band history: fixed-stride records per score step, one slice per wave
@@ -1388,7 +1405,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       // dispatcher refills the CU, instead of a tail of lone waves (C1 +20 %, C3 +13 %)
       long long grid = (long long)al->cu_count * knob(al, K_BAND_WAVES_PER_CU, 128);
       grid = std::min<long long>(grid, in_n);
-      if (i > 0 || use_fast || use_laneh || use_segfull) grid = std::min<long long>(grid, (long long)al->cu_count * knob(al, K_BAND_LEFTOVER_WAVES_PER_CU, 64));
+      if (i > 0 || use_fast || use_laneh || use_segh || use_segfull) grid = std::min<long long>(grid, (long long)al->cu_count * knob(al, K_BAND_LEFTOVER_WAVES_PER_CU, 64));
       if (full) {
         const bool h16 = b->max_len < 32000;
         const int rec = ((h16 && b->ncomp != 5) ? 2 : 4) * (band_nch[i] == 3 ? 256 : 64 * band_nch[i]);  // ints per record (2p: 16-byte entries)
@@ -1736,6 +1753,24 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       const int shape = wfa::seg_shape(b->dcfg, &lh_x, &lh_oe, &lh_e);
       if (wfa::launch_lane_args(shape, lh_oe, lh_e, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, fa, false, 0, 256, true) != 0) {
         al->err = "lane kernel launch failed"; return WFA_HIP_EDEVICE;
+      }
+      if (first_stage) b->last_kernel_pairs = in_n;
+      in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
+    }
+    if (use_segh) {
+      uint32_t* out_list = b->d_fb_list2[out_sel];
+      uint32_t* out_count = b->d_counters + 4 + out_sel;
+      if (!first_stage) HIP_TRY(al, hipMemsetAsync(out_count, 0, sizeof(uint32_t), stream));
+      wfa::FastArgs fa;
+      memset(&fa, 0, sizeof(fa));
+      fa.words = b->d_words; fa.meta = b->d_meta; fa.worklist = in_list; fa.nwork_dev = in_count; fa.nwork = in_n;
+      fa.score = b->d_score; fa.status = b->d_status; fa.fb_list = out_list; fa.fb_count = out_count;
+      fa.ef = (b->dcfg.endsfree && (b->dcfg.pbf | b->dcfg.pef | b->dcfg.tbf | b->dcfg.tef)) ? 1 : 0;
+      fa.pbf = b->dcfg.pbf; fa.pef = b->dcfg.pef; fa.tbf = b->dcfg.tbf; fa.tef = b->dcfg.tef;
+      fa.heur = b->dcfg.heuristic; fa.min_wf_len = b->dcfg.min_wf_len; fa.max_dist_thr = b->dcfg.max_dist_thr;
+      fa.steps_between = b->dcfg.steps_between; fa.max_steps = b->dcfg.max_steps;
+      if (wfa::launch_seg_heur(b->dcfg, al->cu_count, knob(al, K_FAST_WAVES_PER_CU, 256), stream, fa) != 0) {
+        al->err = "segmented kernel launch failed"; return WFA_HIP_EDEVICE;
       }
       if (first_stage) b->last_kernel_pairs = in_n;
       in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;

@@ -45,10 +45,15 @@ __device__ __forceinline__ uint32_t ffbl_u32(uint32_t x) {
   return r;
 }
 
-template <int X, int OE, int E, int W, bool LAZY, bool FULL>
+// HEUR (round 3; score only, W <= 32, one-round extension): the general form for what the band bound cannot prove — wf-adaptive
+// (R/wavefront_heuristic.c:257-293), free ends (R/wavefront_termination.c:115-162, wavefront 0 over the free begins).  The rule that
+// keeps it exact is the lane kernel's (wfa_lane.hpp, HEUR): NO CLIPPING — a segment hands its pair on as soon as a cell of one of
+// its two outermost lanes is alive, i.e. before the band has dropped anything the unbanded run would have kept.
+template <int X, int OE, int E, int W, bool LAZY, bool FULL, bool HEUR = false>
 __global__ void __launch_bounds__(64)
 wfa_seg_kernel(const FastArgs a) {
   static_assert(!(LAZY && FULL), "the history of a step is stored in the step itself");
+  static_assert(!HEUR || (!LAZY && !FULL && W <= 32), "the general form: score only, every cell extended in its own step");
   static_assert(!LAZY || X >= 2, "the lazy extension needs a wavefront to be consumed two steps after it is made");
   static_assert(W == 8 || W == 16 || W == 32 || W == 64, "segment width");
   constexpr int DM = (X > OE) ? X : OE;
@@ -167,6 +172,10 @@ wfa_seg_kernel(const FastArgs a) {
   for (int d = 0; d < DM; ++d) Mh[d] = WFA_OFFSET_NULL;
 #pragma unroll
   for (int d = 0; d < E; ++d) { Ih[d] = WFA_OFFSET_NULL; Dh[d] = WFA_OFFSET_NULL; }
+  // HEUR: max(tlen, plen + k) of my diagonal (distance to the end = hdl - offset), lane of the end diagonal in my segment, the
+  // distance of an empty wavefront, steps until the cut-off is looked at again, "a cell of an outermost lane is alive"
+  int hdl = 0, hjt = 0, hdinit = 0, steps_wait = 0;
+  bool edge = false;
   uint32_t want = (1u << NS) - 1u;  // segments waiting for a pair
   uint32_t busy = 0;                // segments aligning
   int gstep = 0;
@@ -196,9 +205,14 @@ wfa_seg_kernel(const FastArgs a) {
           // a pair this stage cannot take (too long, |tlen - plen| outside the band) is given an expired deadline:
           // the hand-over path below passes it on at once
           // The band is centred between diagonal 0 and diagonal ak = tlen - plen: c = ceil(ak / 2), k in [c - H, c + H).
-          const bool bad = pl > WFA_FAST_MAX_LEN || tl > WFA_FAST_MAX_LEN || tl - pl < 1 - 2 * H || tl - pl > 2 * H - 1;
+          // HEUR: the band is centred on the span from the lowest to the highest diagonal the alignment must touch (the free begins and
+          // the end diagonal), all of them at least one lane away from the segment's edges
+          const int pbf_ = (HEUR && a.ef) ? a.pbf : 0, tbf_ = (HEUR && a.ef) ? a.tbf : 0;
+          const int dlo = min(-pbf_, tl - pl), dhi = max(tbf_, tl - pl);
+          const bool bad = pl > WFA_FAST_MAX_LEN || tl > WFA_FAST_MAX_LEN ||
+                           (HEUR ? (dhi - dlo > W - 3 || pbf_ > pl || tbf_ > tl) : (tl - pl < 1 - 2 * H || tl - pl > 2 * H - 1));
           const int akk = bad ? 0x7fff : tl - pl;
-          const int c = bad ? 0 : ((tl - pl + 1) >> 1);
+          const int c = bad ? 0 : (HEUR ? ((dlo + dhi + 1) >> 1) : ((tl - pl + 1) >> 1));
           const int nwp = (pl + 15) >> 4, ntot = nwp + ((tl + 15) >> 4);
           // loads complete in order: only the load of pair i + 1 (the other slot), if there is one, may still be in flight
           if (i + 1u < end) __builtin_amdgcn_s_waitcnt(0xF71);  // vmcnt(1)
@@ -218,10 +232,19 @@ wfa_seg_kernel(const FastArgs a) {
             // c + H and the way back to ak, downwards from 0 to c - H - 1 and back (LAZY: wavefront s is judged one
             // round later)
             deadline = bad ? gstep - 1
+                           : HEUR ? gstep + 4 * (pl + tl) + 64   // (no bound to prove: only a cap on the steps a pair may take here)
                            : gstep + min(2 * (OE - E) + E * (2 * c + 2 * H - akk), 2 * (OE - E) + E * (2 * H + 2 - 2 * c + akk)) + (LAZY ? 1 : 0)
                                    - (FULL ? 1 : 0);  // FULL: S' < Bmin strictly, so that no co-optimal alignment leaves the band
             if (FULL) { tslot = i; hp = reinterpret_cast<int2*>(a.hist + (long long)i * a.hist_stride) + l; }
             cur = (bad || k != 0) ? WFA_OFFSET_NULL : 0;
+            if (HEUR) {
+              // wavefront 0 over the free begins (offset max(k, 0) on diagonals -pbf .. tbf); the threshold that ends the alignment on
+              // my diagonal: end-to-end: offset tlen on the end diagonal; ends-free: h >= tlen with plen - v <= pef, or v >= plen with
+              // tlen - h <= tef, i.e. offset >= min(max(tlen, plen + k - pef), max(plen + k, tlen - tef))
+              if (!bad && a.ef && k >= -pbf_ && k <= tbf_) cur = max(k, 0);
+              if (a.ef) target = bad ? NEVER : min(max(tl, pl + k - a.pef), max(pl + k, tl - a.tef));
+              hdl = max(tl, pl + k); hjt = akk - (c - H); hdinit = max(pl, tl); steps_wait = a.steps_between; edge = false;
+            }
 #pragma unroll
             for (int d = 0; d < DM; ++d) Mh[d] = WFA_OFFSET_NULL;
 #pragma unroll
@@ -298,9 +321,17 @@ wfa_seg_kernel(const FastArgs a) {
     }
     // ---------------- termination / hand-over ----------------
     {
-      const bool rej = gstep > deadline;  // segment-uniform
-      const bool fin = (LAZY ? Mh[0] : cur) >= target;  // possible on the lane of the end diagonal only
-      const unsigned long long bfin = __ballot(fin), brej = __ballot(rej);
+      const bool rej = gstep > deadline || (HEUR && edge);  // segment-uniform
+      const bool fin = (LAZY ? Mh[0] : cur) >= target;  // possible on the lane of the end diagonal only (HEUR, free ends: on any lane)
+      unsigned long long bfin = __ballot(fin);
+      const unsigned long long brej = __ballot(rej);
+      if (HEUR) {
+        // one lane per segment reports (the score does not depend on which cell ended the alignment)
+        unsigned long long one = 0ull;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { const unsigned long long f = bfin & (FIELD << (s * W)); one |= f & (0ull - f); }
+        bfin = one;
+      }
       const unsigned long long bd = bfin | brej;
       if (bd) {
         const unsigned long long ba = bfin & ~brej;
@@ -332,8 +363,37 @@ wfa_seg_kernel(const FastArgs a) {
             want |= 1u << s; busy &= ~(1u << s);
             if (LAZY) { mcur &= ~(FIELD << (s * W)); mold &= ~(FIELD << (s * W)); }
           }
-        if (((bd >> (seg * W)) & FIELD) != 0ull) { target = NEVER; deadline = NEVER; lim = WFA_OFFSET_NULL; cur = WFA_OFFSET_NULL; }
+        if (((bd >> (seg * W)) & FIELD) != 0ull) { target = NEVER; deadline = NEVER; lim = WFA_OFFSET_NULL; cur = WFA_OFFSET_NULL; edge = false; }
         if (!busy && next_i >= end) break;
+      }
+    }
+    // ---------------- wf-adaptive cut-off (R/wavefront_heuristic.c:257-293, dispatcher :509-567) ----------------
+    if constexpr (HEUR) {
+      if (a.heur == 1) {
+        const uint32_t f = (uint32_t)((__ballot(cur >= 0) >> (seg * W)) & FIELD);   // live lanes of my segment's M wavefront
+        if (f != 0u) --steps_wait;   // (the cut-off is looked at only when the wavefront exists)
+        const int lo = (int)__builtin_ctz(f | 0x80000000u), hi = 31 - (int)__builtin_clz(f | 1u);
+        const bool consider = f != 0u && steps_wait <= 0 && (hi - lo + 1) >= a.min_wf_len && deadline != NEVER;
+        if (__any(consider)) {
+          // d = max(plen - v, tlen - h) = max(tlen, plen + k) - offset; dead lanes: far away
+          const int d = (cur >= 0) ? hdl - cur : 0x3fffffff;
+          int dmin = d;
+#pragma unroll
+          for (int m = 1; m < W; m <<= 1) dmin = min(dmin, __shfl_xor(dmin, m, 64));
+          dmin = min(dmin, hdinit);
+          const uint32_t okf = (uint32_t)((__ballot(cur >= 0 && d - dmin <= a.max_dist_thr) >> (seg * W)) & FIELD);
+          const int lc = okf ? (int)__builtin_ctz(okf) : 0x7fffffff, hc = okf ? 31 - (int)__builtin_clz(okf) : -0x7fffffff;
+          int new_lo = lo, new_hi = hi;
+          const int top_limit = min(hjt, hi);
+          if (top_limit > lo) new_lo = min(lc, top_limit);
+          const int bottom_limit = max(hjt, new_lo);
+          if (bottom_limit < hi) new_hi = max(hc, bottom_limit);
+          if (consider) {
+            steps_wait = a.steps_between;
+            // the dropped lanes read NULL in M, I and D from now on
+            if ((new_lo != lo || new_hi != hi) && (l < new_lo || l > new_hi)) { cur = WFA_OFFSET_NULL; Ih[0] = WFA_OFFSET_NULL; Dh[0] = WFA_OFFSET_NULL; }
+          }
+        }
       }
     }
     // ---------------- compute-next ----------------
@@ -352,6 +412,11 @@ wfa_seg_kernel(const FastArgs a) {
       Ih[0] = ni; Dh[0] = nd;
       cur = nm;
       if (LAZY) { mold = mcur; mcur = __ballot(nm >= 0); }
+      if (HEUR) {
+        // a cell of an outermost lane is alive (an offset or a gap value >= 0): the next steps could reach beyond the band
+        const unsigned long long eb = __ballot((l == 0 || l == W - 1) && (nm & ni & nd) >= 0);
+        edge = ((eb >> (seg * W)) & FIELD) != 0ull;
+      }
     }
     ++gstep;
     // window 0 used up: window 1 moves down and the one after is requested (its use is >= 50 pairs away)
@@ -372,7 +437,8 @@ wfa_seg_kernel(const FastArgs a) {
 
 #define WFA_SEG_DECL(i, x, oe, e)                                                                        \
   int launch_seg_s##i(int w, bool lazy, unsigned grid, hipStream_t stream, const FastArgs& a);           \
-  int launch_seg_full_s##i(int w, unsigned grid, hipStream_t stream, const FastArgs& a);
+  int launch_seg_full_s##i(int w, unsigned grid, hipStream_t stream, const FastArgs& a);                 \
+  int launch_seg_heur_s##i(unsigned grid, hipStream_t stream, const FastArgs& a);
 WFA_SEG_SHAPES(WFA_SEG_DECL)
 #undef WFA_SEG_DECL
 
@@ -414,6 +480,13 @@ inline int launch_seg_shape(int w, bool lazy, unsigned grid, hipStream_t stream,
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// the general score-only form (HEUR), segments of 32 lanes
+template <int X, int OE, int E>
+inline int launch_seg_heur_shape(unsigned grid, hipStream_t stream, const FastArgs& a) {
+  hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 32, false, false, true>), dim3(grid), dim3(64), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // full-CIGAR launch with segments of `w` lanes: items [work_begin, work_begin + nwork) of the work list, one history slot
 // each (a.nwork_dev set: the list is a previous stage's, a.nwork slots were reserved)
 template <int X, int OE, int E>
@@ -438,6 +511,29 @@ inline int launch_seg_full(const WfaDevConfig& c, int cu_count, int per_cu, hipS
 #define WFA_SEG_LAUNCH_FULL(i, x, oe, e) if (idx == i) return launch_seg_full_s##i(w, (unsigned)grid, stream, a);
   WFA_SEG_SHAPES(WFA_SEG_LAUNCH_FULL)
 #undef WFA_SEG_LAUNCH_FULL
+  return -1;
+}
+
+// configurations of the general form of the 32-lane segments: what the lane kernel's general form takes (wfa_lane.hpp,
+// lane_heur_config), without a step limit (the banded kernel reports the limit's status)
+inline bool seg_heur_config(const WfaDevConfig& c, int ncomp) {
+  int X, OE, E;
+  return ncomp == 3 && c.match == 0 && c.wildcard < 0 && (c.heuristic == 0 || c.heuristic == 1) && c.max_steps == INT_MAX &&
+         seg_shape(c, &X, &OE, &E) >= 0;
+}
+// a.ef / a.pbf .. / a.heur .. set by the caller (wfa_fast.hpp); the work list is a.worklist / a.nwork_dev / a.nwork
+inline int launch_seg_heur(const WfaDevConfig& c, int cu_count, int per_cu, hipStream_t stream, FastArgs a) {
+  int X, OE, E;
+  const int idx = seg_shape(c, &X, &OE, &E);
+  if (idx < 0) return -1;
+  a.g = gcd_int(gcd_int(c.x, c.o1 + c.e1), c.e1);
+  a.hist = nullptr; a.hist_stride = 0; a.end_state = nullptr; a.work_begin = 0;
+  long long grid = (long long)cu_count * per_cu;
+  if (!a.nwork_dev && grid > (long long)a.nwork) grid = a.nwork;
+  if (grid < 1) grid = 1;
+#define WFA_SEG_LAUNCH_HEUR(i, x, oe, e) if (idx == i) return launch_seg_heur_s##i((unsigned)grid, stream, a);
+  WFA_SEG_SHAPES(WFA_SEG_LAUNCH_HEUR)
+#undef WFA_SEG_LAUNCH_HEUR
   return -1;
 }
 

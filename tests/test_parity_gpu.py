@@ -154,6 +154,22 @@ def test_lane_kernel_general_form(gpu, corpora, cfg_idx, monkeypatch):
         common.assert_same(o, score, status, None, batch, f"lane general form {name} {kw}")
 
 
+@pytest.mark.parametrize("lane_first", [0, 1])
+@pytest.mark.parametrize("cfg_idx", [i for i, c in enumerate(LANE_GENERAL) if "max_steps" not in c])
+def test_segmented_kernel_general_form(gpu, corpora, cfg_idx, lane_first, monkeypatch):
+    """The same form of the 32-lane segments (wfa_seg_kernel<.., 32, .., HEUR>: two pairs per wave, a band of 32 diagonals) forced on
+    (WFA_HIP_SEG_HEUR=1), alone and behind the lane form: what it keeps and what it hands on must equal the oracle."""
+    monkeypatch.setenv("WFA_HIP_SEG_HEUR", "1")
+    monkeypatch.setenv("WFA_HIP_LANE_HEUR", str(lane_first))
+    for name in ("150bp_2pct", "150bp_15pct", "special"):
+        batch = corpora[name]
+        kw = common.clamp_free(dict(LANE_GENERAL[cfg_idx], scope="score"), batch)
+        oc, nc = common.configs_pair(**kw)
+        o = loader.run(loader.oracle(), oc, batch, want_cigar=False)
+        score, status, _ = common.gpu_run(nc, batch, False, resident=(cfg_idx % 2 == 0))
+        common.assert_same(o, score, status, None, batch, f"segment general form {name} {kw}")
+
+
 @pytest.mark.parametrize("error", [0.005, 0.03])
 def test_lane_kernel_general_form_pilot(gpu, error):
     """Batches of >= 64 k pairs let a pilot decide whether the general form goes first (few pairs outgrow its 16 slots at 0.5 %
