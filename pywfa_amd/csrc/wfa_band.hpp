@@ -1035,23 +1035,38 @@ wfa_lane_walk_kernel(const BandArgs a) {
   // events, last edit first: 4 bits each (op: 1 X, 2 I, 3 D; bit 3: lands in M) in two 64-bit words
   unsigned long long ev_lo = 0ull, ev_hi = 0ull;
   int tt = t_end, j = es.y >> 8, comp = 0, nev = 0;
+  // (the records of the next CH steps down are requested together — independent loads, one round trip — and the hops that land on
+  // them are taken from registers: 2-4 round trips per alignment instead of one per edit)
+  constexpr int CH = 8;
   while (tt > 0 && nev < 32) {
-    const uint2 c = rec_end[-(long long)(t_end - tt) * 64ll];
-    const uint32_t nib = (((j < 8) ? c.x : c.y) >> (4 * (j & 7))) & 0xFu;
-    uint32_t ev;
-    if (comp == 0) {
-      if (!(nib & 8u)) { ev = 1u | 8u; tt -= dx; }
-      else if (!(nib & 4u)) { ev = 3u | 8u; ++j; if (!(nib & 1u)) { tt -= de; comp = 2; } else tt -= doe; }
-      else { ev = 2u | 8u; --j; if (!(nib & 2u)) { tt -= de; comp = 1; } else tt -= doe; }
-    } else if (comp == 1) {
-      ev = 2u; --j;
-      if (!(nib & 2u)) tt -= de; else { tt -= doe; comp = 0; }
-    } else {
-      ev = 3u; ++j;
-      if (!(nib & 1u)) tt -= de; else { tt -= doe; comp = 0; }
+    const int top = tt;
+    uint2 cc[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int st = top - i;
+      cc[i] = (st > 0) ? rec_end[-(long long)(t_end - st) * 64ll] : make_uint2(0u, 0u);
     }
-    if (nev < 16) ev_lo |= (unsigned long long)ev << (4 * nev); else ev_hi |= (unsigned long long)ev << (4 * (nev - 16));
-    ++nev;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      if (tt == top - i && tt > 0 && nev < 32) {
+        const uint2 c = cc[i];
+        const uint32_t nib = (((j < 8) ? c.x : c.y) >> (4 * (j & 7))) & 0xFu;
+        uint32_t ev;
+        if (comp == 0) {
+          if (!(nib & 8u)) { ev = 1u | 8u; tt -= dx; }
+          else if (!(nib & 4u)) { ev = 3u | 8u; ++j; if (!(nib & 1u)) { tt -= de; comp = 2; } else tt -= doe; }
+          else { ev = 2u | 8u; --j; if (!(nib & 2u)) { tt -= de; comp = 1; } else tt -= doe; }
+        } else if (comp == 1) {
+          ev = 2u; --j;
+          if (!(nib & 2u)) tt -= de; else { tt -= doe; comp = 0; }
+        } else {
+          ev = 3u; ++j;
+          if (!(nib & 1u)) tt -= de; else { tt -= doe; comp = 0; }
+        }
+        if (nev < 16) ev_lo |= (unsigned long long)ev << (4 * nev); else ev_hi |= (unsigned long long)ev << (4 * (nev - 16));
+        ++nev;
+      }
+    }
   }
   uint32_t* const runs = reinterpret_cast<uint32_t*>(a.hist + (long long)t * a.hist_stride);
   const int max_runs = (int)a.hist_stride;

@@ -27,8 +27,8 @@ for it in range(rounds):
     if rng.random() < 0.2: kw["distance"] = "affine2p"
     if rng.random() < 0.3: kw["memory_mode"] = str(rng.choice(["medium", "low"]))
     if rng.random() < 0.1: kw["max_steps"] = int(rng.choice([6, 20, 60, 400]))
-    if rng.random() < 0.12:   # BiWFA: without heuristic, free ends or a step limit
-        for k_ in ("heuristic", "xdrop", "max_steps", "pattern_begin_free", "pattern_end_free", "text_begin_free", "text_end_free"): kw.pop(k_, None)
+    if rng.random() < 0.12:   # BiWFA: without heuristic or free ends (a step limit is honoured, round 3)
+        for k_ in ("heuristic", "xdrop", "pattern_begin_free", "pattern_end_free", "text_begin_free", "text_end_free"): kw.pop(k_, None)
         kw["memory_mode"] = "biwfa"
     # a batch of mixed lengths and divergences, with length differences (end-to-end gaps)
     pats, txts = [], []
