@@ -1571,6 +1571,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       // per launch: run records + end state per pair, and the waves' record lists of comparison bits (512 bytes per wave-step)
       const int64_t lf_budget = std::max<int64_t>((int64_t)free_budget(al) - (int64_t)lanefull_off, (int64_t)1 << 20);
       lanefull_cap = std::max<int64_t>(1, std::min<int64_t>(in_n, lf_budget / (lanefull_slot_bytes + 256)));
+      if (al->knobs.set[K_SEGFULL_PAIRS]) lanefull_cap = std::min<int64_t>(lanefull_cap, std::max<int64_t>(64, knob(al, K_SEGFULL_PAIRS, 2000000)));   // (tests: several launches over one region)
       // When the whole batch fits (the usual case) it is cut into balanced launches with code lists of their own: walk + expand of a
       // launch (latency- and memory-bound) run on the side stream under the lane kernel (issue-bound) of the next
       if (lanefull_cap >= (int64_t)in_n) {

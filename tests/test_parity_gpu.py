@@ -299,9 +299,10 @@ def test_segmented_kernel_penalty_shapes(gpu, pen):
 
 @pytest.mark.parametrize("span", ["ends-free", "end-to-end"])
 def test_segmented_full_cigar_in_several_launches(gpu, span, monkeypatch):
-    """Full CIGARs of short reads come from the segmented kernel with a history slot per pair; with a small slot budget the
-    batch takes several launches (work_begin > 0), some pairs exceed the band's bound and are finished by the banded
-    kernel, and a re-run of the resident batch gives the same op strings."""
+    """Full CIGARs of short reads come from the lane kernel's full-CIGAR form (round 3; WFA_HIP_LANE_FULL=0: from the 16-lane segments
+    with a history slot per pair); with a small slot budget the batch takes several launches over one region (work_begin > 0), some
+    pairs exceed the band's bound and are finished by the stages behind, and a re-run of the resident batch gives the same op
+    strings.  Also: the batch cut into launches with regions of their own (walks and expands on the side stream), and the default."""
     monkeypatch.setenv("WFA_HIP_SEGFULL_PAIRS", "1500")
     parts = [datagen.generate(4000, 150, 0.02, 9100), datagen.generate(1200, 150, 0.12, 9101), datagen.generate(1000, 400, 0.02, 9102),
              datagen.generate(700, 33, 0.06, 9103)]
@@ -311,8 +312,14 @@ def test_segmented_full_cigar_in_several_launches(gpu, span, monkeypatch):
         for resident in (False, True):
             score, status, cigars = common.gpu_run(nc, batch, True, resident)
             common.assert_same(o, score, status, cigars, batch, f"segmented full {span}")
-    # the same through the default budget and without the segmented stage
-    for env in ({}, {"WFA_HIP_NO_SEGFULL": "1"}):
+    monkeypatch.setenv("WFA_HIP_LANE_FULL", "0")
+    for batch in parts[:2]:
+        o = loader.run(loader.oracle(), oc, batch)
+        score, status, cigars = common.gpu_run(nc, batch, True, True)
+        common.assert_same(o, score, status, cigars, batch, f"segmented full {span}, 16-lane segments first")
+    monkeypatch.delenv("WFA_HIP_LANE_FULL", raising=False)
+    # the same through the default budget, in three launches with regions of their own, and without the stage
+    for env in ({}, {"WFA_HIP_LANE_FULL_SPLIT": "3"}, {"WFA_HIP_NO_SEGFULL": "1"}):
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
         monkeypatch.delenv("WFA_HIP_SEGFULL_PAIRS", raising=False)
