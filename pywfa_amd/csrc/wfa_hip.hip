@@ -1478,8 +1478,13 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       const bool prefer_ws = grows_knob >= 0 ? grows_knob != 0 : many_pairs;
       // threads per workgroup of the workspace form: 256 (gap-affine-2p: 512) once the batch has a pair for every CU's four
       // workgroup slots of that size — measured on 2 000 x 10 kb: 128 threads 35.1 k, 256: 36.8 k, 384: 31.0 k, 512: 32.6 k, 1 024: 21.6 k aln/s
+      // (8 192 x 10 kb: 128 threads 200 / 231 ms score / full, 256: 207 / 241; C4 as written, 4 096 pairs: 256 threads 705 ms, 512: 740,
+      // 384: 925, 128: 719; the 2p form compiled for six waves per SIMD — three 512-thread workgroups per CU instead of two — 1 047 ms:
+      // more workgroups in flight than the rows' L2 footprint allows cost more than the latency they hide)
       int ws_threads = 1024;
-      if ((int64_t)in_n >= (int64_t)al->cu_count * 4) ws_threads = wide_two ? 512 : 256;
+      if (!wide_two && (int64_t)in_n >= (int64_t)al->cu_count * 16) ws_threads = 128;
+      else if ((int64_t)in_n >= (int64_t)al->cu_count * 8) ws_threads = 256;
+      else if ((int64_t)in_n >= (int64_t)al->cu_count * 4) ws_threads = wide_two ? 512 : 256;
       else if ((int64_t)in_n >= (int64_t)al->cu_count * 2) ws_threads = 512;
       if (!wide_two && !wide32 && !prefer_ws) {
         WideStage& st = wide_stage[n_wide];
