@@ -109,14 +109,21 @@ def work_counts(batch, cfg_kw, n):
     return {"m_offsets_per_pair": m / n, "offsets_per_pair": allc / n, "bases_compared_per_pair": bases / n, "sample_pairs": n}
 
 
-def run_resident(al, batch, steps, warmup, want_cigar, barrier=None):
-    """Warm-up, then `steps` timed passes over the resident batch.  Returns timings and results."""
+def run_resident(al, batch, steps, warmup, want_cigar, barrier=None, min_seconds=0.0):
+    """Warm-up, then `steps` timed passes over the resident batch.  Returns timings and results.
+    min_seconds (extra configurations only): short steps are repeated until the timed region lasts about that long (<= 50 steps),
+    so that one slow enqueue on a busy host does not decide a 3-step measurement."""
     t0 = time.perf_counter()
     rb = al.batch(batch)
     t_upload = time.perf_counter() - t0
     for _ in range(warmup):
         rb.run()
     rb.sync()
+    if min_seconds > 0.0:
+        t0 = time.perf_counter()
+        rb.run(); rb.sync()
+        est = max(time.perf_counter() - t0, 1e-5)
+        steps = max(steps, min(50, int(min_seconds / est) + 1))
     if barrier:
         barrier()
     t0 = time.perf_counter()
@@ -129,7 +136,7 @@ def run_resident(al, batch, steps, warmup, want_cigar, barrier=None):
     kernel_ms, kernel_pairs = rb.last_kernel()  # mean HIP-event time per step over the timed steps
     score, status, cig = rb.results(want_cigar)
     out = {"elapsed": elapsed, "kernel_ms": kernel_ms, "upload_s": t_upload, "score": score, "status": status, "cig": cig,
-           "fallback": rb.fallback_pairs(), "io_bytes": rb.algorithmic_bytes()}
+           "fallback": rb.fallback_pairs(), "io_bytes": rb.algorithmic_bytes(), "steps": steps}
     rb.close()
     return out
 
@@ -173,7 +180,8 @@ def extra_config(name, n, length, error, seed, cfg_kw, scheme, survey_bytes, tri
     finally:
         for k_ in (env or {}):
             del os.environ[k_]
-    r = run_resident(al, batch, steps, 1, full)
+    r = run_resident(al, batch, steps, 1, full, min_seconds=0.1)
+    steps = r["steps"]
     al.close()
     wc = work_counts(batch, cfg_kw, 8 if length >= 5000 else 2000)
     # algorithmic HBM bytes per pair: SURVEY.md §8(d)'s per-unit figure for this configuration and history scheme
@@ -191,7 +199,7 @@ def extra_config(name, n, length, error, seed, cfg_kw, scheme, survey_bytes, tri
     traffic_pair, secondary, prov = counter_file(name, kernel_source_hash())
     return {"name": name, "pairs": n, "read_length": length, "error": error, "seed": seed, "config": cfg_kw,
             "history_scheme": scheme if (full and length > 1000) else None,
-            "kernel_ms": r["kernel_ms"], "ms_per_step": r["elapsed"] / steps * 1e3, "alignments_per_s": rate,
+            "kernel_ms": r["kernel_ms"], "ms_per_step": r["elapsed"] / steps * 1e3, "steps": steps, "alignments_per_s": rate,
             "offsets_per_s": rate * wc["offsets_per_pair"], "work": wc,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "bytes_per_pair": bytes_pair, "bytes_per_pair_source": "SURVEY.md §8(d)",
