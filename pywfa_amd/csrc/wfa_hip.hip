@@ -1188,10 +1188,16 @@ static int ensure_ws(wfa_hip_aligner* al, size_t bytes) {
 
 // memory_mode medium / low: the general kernel keeps the piggy-back history (one byte of origin codes per cell) instead of the
 // explicit arena (full scope, gap-affine / gap-affine-2p; WFA_HIP_GENERAL_PB = 0 / 1 overrides)
-static bool general_pb(const wfa_hip_aligner* al, const wfa_hip_config_t& c, int ncomp) {
+// history of the general kernel: one byte of origin codes per cell (PB) instead of the offsets — memory modes medium / low, and, like
+// the banded kernel's split stage, long reads in every mode (round 3: the explicit arena of a 100 kb pair overflows and is re-run 8x
+// larger, with a host round trip each time: C5-shaped wf-adaptive 10.8 k -> 16 k aln/s); WFA_HIP_BAND_PB=0 / WFA_HIP_GENERAL_PB=0 keep
+// the explicit offsets
+static bool general_pb(const wfa_hip_aligner* al, const wfa_hip_config_t& c, int ncomp, int max_len) {
   if (c.scope != WFA_SCOPE_FULL || ncomp < 3) return false;
   const int e = knob(al, K_GENERAL_PB, -1);
-  return e >= 0 ? e != 0 : (c.memory_mode == WFA_MEM_MED || c.memory_mode == WFA_MEM_LOW);
+  if (e >= 0) return e != 0;
+  if (c.memory_mode == WFA_MEM_MED || c.memory_mode == WFA_MEM_LOW) return true;
+  return max_len > 1000 && knob(al, K_BAND_PB, 1) != 0;
 }
 
 static int launch_general_dyn(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream, bool packed,
@@ -1206,7 +1212,7 @@ static int launch_general_dyn(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t
   a.ws = al->ws; a.ws_stride = ws_stride;
   a.fb_list = ovf_list; a.fb_count = ovf_count;
   a.cfg = b->dcfg;
-  if (wfa::launch_general_any(b->ncomp, packed, b->cfg.scope == WFA_SCOPE_FULL, general_pb(al, b->cfg, b->ncomp), a, grid, threads, stream) != 0) {
+  if (wfa::launch_general_any(b->ncomp, packed, b->cfg.scope == WFA_SCOPE_FULL, general_pb(al, b->cfg, b->ncomp, b->max_len), a, grid, threads, stream) != 0) {
     al->err = std::string("general kernel launch failed: ") + hipGetErrorString(hipGetLastError());
     return WFA_HIP_EDEVICE;
   }
@@ -1251,7 +1257,7 @@ static int64_t initial_arena_ints(const wfa_hip_aligner* al, const wfa_hip_batch
   // less than what wavefront 0 and a few hundred scores need; overflowing pairs are re-run larger
   ll ints = (ll)b->max_len * (b->ncomp * 64 + mi) / 4 + (ll)b->max_width * b->ncomp * 4 + 4096 * mi;
   // piggy-back history: one byte per cell + 12 bytes per score (the ring of offsets is b->arena_fixed)
-  if (general_pb(al, b->cfg, b->ncomp)) ints = (ll)b->max_len * (64 + 12) / 4 + 4096;
+  if (general_pb(al, b->cfg, b->ncomp, b->max_len)) ints = (ll)b->max_len * (64 + 12) / 4 + 4096;
   ints = std::max<ll>(ints, 1 << 14);
   const int e = knob(al, K_ARENA_KB, 0);
   if (e > 0) ints = (ll)e * 256;
@@ -1276,7 +1282,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
   const bool full = (b->cfg.scope == WFA_SCOPE_FULL);
   HIP_TRY(al, hipMemsetAsync(b->d_counters, 0, 16 * sizeof(uint32_t), stream));
   b->arena_ints = full ? initial_arena_ints(al, b) : 0;
-  b->arena_fixed = general_pb(al, b->cfg, b->ncomp) ? (((int64_t)b->dcfg.scope * b->ncomp * b->max_width + 64 + 63) & ~63ll) : 0;
+  b->arena_fixed = general_pb(al, b->cfg, b->ncomp, b->max_len) ? (((int64_t)b->dcfg.scope * b->ncomp * b->max_width + 64 + 63) & ~63ll) : 0;
 
   // A cascade of kernels over the 2-bit pairs: each stage aligns what fits it and appends the rest to
   // a leftover list (pair ids + a device-side count) that the next stage consumes on the same stream;
