@@ -42,7 +42,7 @@ static thread_local std::string g_error;
   F(ARENA_KB) F(BAND_DEBUG) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
-  F(LANE_FULL) F(LANE_FULL_SPLIT) F(LANE_HEUR) F(SEG_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
+  F(LANE_FULL) F(LANE_FULL_SPLIT) F(LANE_HEUR) F(SEG_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_ADAPT) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
 enum WfaKnob {
 #define WFA_KNOB_ENUM(n) K_##n,
   WFA_KNOBS(WFA_KNOB_ENUM)
@@ -1376,8 +1376,12 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         // gap-affine-2p wavefronts are wide (C4: 99 % need more than 108 diagonals, 2.6 % more than 172)
         band_nch[n_stages++] = 3; band_nch[n_stages++] = 4;
       } else if (adapt) {
+        // (the wavefront a cut-off keeps grows with the read: at 10 kb 3 % of the pairs outgrow the 128-diagonal window, at 100 kb 46 % —
+        // and a second stage of few, lone waves runs at its pairs' latency: reads over 20 kb start in the 256-diagonal window.
+        // 8 192 x 100 kb wf-adaptive: 509 -> 359 ms)
         if (b->max_len <= 300) { band_nch[n_stages++] = 1; }
-        band_nch[n_stages++] = 2; band_nch[n_stages++] = 4;
+        if (b->max_len <= 20000) band_nch[n_stages++] = 2;
+        band_nch[n_stages++] = 4;
       } else if (b->max_len <= 300) {
         if (!use_fast && !use_segfull) band_nch[n_stages++] = 1;
         band_nch[n_stages++] = 2; band_nch[n_stages++] = 4;
@@ -1387,8 +1391,12 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       const int only = knob(al, K_BAND_NCH, 0);
       if (only) { n_stages = 1; band_nch[0] = only; }
     }
+    // (round 3) wf-adaptive: the wide kernel takes what the banded stages hand on — the few pairs whose wavefront outgrows 256 diagonals
+    // (47 of 8 192 at 100 kb) — instead of the general kernel: rows in the workspace, its cut-off in-kernel (WFA_HIP_WIDE_ADAPT=0: off)
+    const bool wide_adapt = b->dcfg.heuristic == WFA_HEUR_ADAPTIVE && b->max_len > 1000 &&
+                            (knob(al, K_WIDE_ADAPT, 1) == 2 || (n_stages > 0 && knob(al, K_WIDE_ADAPT, 1) != 0));   // (2: also without banded stages in front: tests)
     const bool wide_ok = !tiny && ((b->ncomp == 3 && b->dcfg.metric == 3) || (b->ncomp == 5 && b->dcfg.metric == 4 && b->dcfg.e2 >= 1)) &&
-                         b->dcfg.heuristic == WFA_HEUR_NONE && b->dcfg.match == 0 &&
+                         (b->dcfg.heuristic == WFA_HEUR_NONE || wide_adapt) && b->dcfg.match == 0 &&
                          b->max_len > 64 && 2 * (int64_t)b->max_len <= 0x3fffff00ll && b->dcfg.e1 >= 1 && b->dcfg.x >= 1 && knob(al, K_NO_WIDE, 0) == 0;
     // reads beyond 16 kb (plen + tlen > 32 000 does not fit int16 offsets): the workspace-row form with int32 rows (round 3)
     const bool wide32 = 2 * (int64_t)b->max_len > 32000;
@@ -1492,7 +1500,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       else if ((int64_t)in_n >= (int64_t)al->cu_count * 8) ws_threads = 256;
       else if ((int64_t)in_n >= (int64_t)al->cu_count * 4) ws_threads = wide_two ? 512 : 256;
       else if ((int64_t)in_n >= (int64_t)al->cu_count * 2) ws_threads = 512;
-      if (!wide_two && !wide32 && !prefer_ws) {
+      if (!wide_two && !wide32 && !prefer_ws && !wide_adapt) {
         WideStage& st = wide_stage[n_wide];
         st.a = w0;
         const size_t lds_max = (size_t)std::min(160, std::max(16, knob(al, K_WIDE_LDS_KB, 160))) * 1024;
@@ -1526,10 +1534,13 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         const int64_t row_bytes = wide32 ? 4 : 2;   // bytes per offset
         st.smem = wfa::wide_smem_bytes(w0.X, w0.OE, w0.E, w0.OE2, w0.E2, full_range, w0.seq_words, false);
         const bool seqs_fit_lds = st.smem <= (size_t)160 * 1024;   // (both packed sequences are staged in LDS: reads up to ~300 kb)
-        st.threads = knob(al, K_WIDE_THREADS, ws_threads);
+        st.threads = knob(al, K_WIDE_THREADS, wide_adapt ? 256 : ws_threads);
         st.grid = (int)std::min<int64_t>((int64_t)al->cu_count * std::max<int64_t>(1, std::min<int64_t>(2048 / st.threads, (160 * 1024) / std::max<size_t>(st.smem, 1))), in_n);
+        if (wide_adapt) st.grid = std::min(st.grid, al->cu_count);   // (leftovers: one workgroup per CU is plenty)
         int64_t hist_bytes = 0;
         if (full) hist_bytes = (int64_t)full_range * ((int64_t)(b->max_len * 0.9) / w0.g + 64) / 2 + (1 << 20);   // one byte per cell, + directory + events
+        // (wf-adaptive: the cut-off keeps the wavefronts narrow: ~2 KB of codes per step; a pair that needs more is handed on)
+        if (full && wide_adapt) hist_bytes = std::min<int64_t>(hist_bytes, ((int64_t)(b->max_len * 1.2) / w0.g + 64) * 2048 + (1 << 20));
         while (st.grid > 1 && (int64_t)st.grid * (st.a.rows_stride * row_bytes + hist_bytes) > budget) st.grid = (st.grid + 1) / 2;
         if (seqs_fit_lds && (int64_t)st.grid * (st.a.rows_stride * row_bytes + hist_bytes) <= budget) {
           st.a.hist_stride = (hist_bytes / 4) & ~15ll;
@@ -1886,6 +1897,8 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       wa.ef = b->dcfg.endsfree ? 1 : 0;
       wa.pbf = b->dcfg.pbf; wa.pef = b->dcfg.pef; wa.tbf = b->dcfg.tbf; wa.tef = b->dcfg.tef;
       wa.max_steps = b->dcfg.max_steps;
+      wa.heur = (b->dcfg.heuristic == WFA_HEUR_ADAPTIVE) ? 1 : 0; wa.min_wf_len = b->dcfg.min_wf_len; wa.max_dist_thr = b->dcfg.max_dist_thr;
+      wa.steps_between = b->dcfg.steps_between;
       if (wfa::launch_wide(full, wide_two, wa, st.grid, st.threads, st.smem, stream, st.w32) != 0) { al->err = "wide kernel launch failed"; return WFA_HIP_EDEVICE; }
       if (first_stage) b->last_kernel_pairs = in_n;
       in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;

@@ -60,6 +60,7 @@ struct WideArgs {
   int max_steps;
   int wcap;               // diagonals per row
   int seq_words;          // LDS words per sequence (>= words of the longest sequence + 3)
+  int heur, min_wf_len, max_dist_thr, steps_between;   // heur = 1: wf-adaptive (R/wavefront_heuristic.c:257-293), what the banded stages handed on
 };
 
 #define WFA_WIDE_NULL (-16384)
@@ -129,6 +130,7 @@ wfa_wide_kernel(const WideArgs a) {
       for (int i = tid; i < n32; i += T) r32[i] = W32 ? (uint32_t)WFA_OFFSET_NULL : 0xC000C000u;   // NULL (, NULL)
       for (int i = tid; i < NR; i += T) { rlo[i] = 1; rhi[i] = -1; }
       if (tid < 22) ctrl[tid] = (tid >= 20 || (tid % 10) < NC) ? INT_MAX : INT_MIN;
+      if (tid >= 22 && tid < 28) ctrl[tid] = ((tid - 22) % 3 == 2) ? INT_MIN : INT_MAX;   // cut-off scratch per parity: min distance, first / last kept diagonal
     }
     bool hand_on = (!W32 && plen + tlen > 32000) || (-pbf < kmin) || (tbf > kmax) || (ak < kmin) || (ak > kmax);
     int end_reason = 0;   // 1 reached, 3 handed on, 4 step limit
@@ -137,6 +139,7 @@ wfa_wide_kernel(const WideArgs a) {
     uint8_t* const pb_codes = FULL ? reinterpret_cast<uint8_t*>(hist) : nullptr;
     const long long pb_cap = FULL ? a.hist_stride * 4 : 0;  // bytes shared by codes (bottom-up) and directory (top-down)
     int null_run = 0;
+    int steps_wait = a.steps_between;   // wf-adaptive: steps until the cut-off is looked at again
     __syncthreads();
 
     for (int t = 0; !hand_on; ++t) {
@@ -314,6 +317,51 @@ wfa_wide_kernel(const WideArgs a) {
       }
       const int ek = ctrl[20 + par];
       if (ek != INT_MAX) { end_reason = 1; end_k = ek; end_t = t; }
+      // ---- wf-adaptive cut-off on the extended M wavefront (R/wavefront_heuristic.c:257-293, dispatcher :509-567): the diagonals whose
+      // distance to the end exceeds the smallest by more than the threshold are dropped from both ends, never past the end diagonal;
+      // the gap wavefronts are cut to the same limits (the equate) ----
+      if (a.heur == 1 && !end_reason && tlo[0] <= thi[0]) {
+        --steps_wait;
+        const int mlo = tlo[0], mhi = thi[0];
+        if (steps_wait <= 0 && mhi - mlo + 1 >= a.min_wf_len) {   // (uniform: every thread read the same limits)
+          int* const cut = ctrl + 22 + 3 * par;
+          int dloc = INT_MAX;
+          for (int k = mlo + tid; k <= mhi; k += T) {
+            const int off = wR[0][k];
+            if (off >= 0) dloc = min(dloc, max(tlen, plen + k) - off);   // max(plen - v, tlen - h)
+          }
+#pragma unroll
+          for (int m = 32; m >= 1; m >>= 1) dloc = min(dloc, __shfl_xor(dloc, m, 64));
+          if (lane == 0 && dloc != INT_MAX) atomicMin(&cut[0], dloc);
+          __syncthreads();
+          const int dmin = min(cut[0], max(plen, tlen));
+          int fk = INT_MAX, lk = INT_MIN;
+          for (int k = mlo + tid; k <= mhi; k += T) {
+            const int off = wR[0][k];
+            if (off >= 0 && max(tlen, plen + k) - off - dmin <= a.max_dist_thr) { fk = min(fk, k); lk = max(lk, k); }
+          }
+#pragma unroll
+          for (int m = 32; m >= 1; m >>= 1) { fk = min(fk, __shfl_xor(fk, m, 64)); lk = max(lk, __shfl_xor(lk, m, 64)); }
+          if (lane == 0 && fk != INT_MAX) { atomicMin(&cut[1], fk); atomicMax(&cut[2], lk); }
+          __syncthreads();
+          const int lc = cut[1], hc = cut[2];   // (INT_MAX / INT_MIN: no diagonal qualifies)
+          int new_lo = mlo, new_hi = mhi;
+          const int top_limit = min(ak, mhi);
+          if (top_limit > mlo) new_lo = min(lc, top_limit);
+          const int bottom_limit = max(ak, new_lo);
+          if (bottom_limit < mhi) new_hi = max(hc, bottom_limit);
+          steps_wait = a.steps_between;
+          if (new_lo != mlo || new_hi != mhi) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              for (int k = lo + tid; k < new_lo; k += T) wR[c][k] = (row_t)RNULL;
+              for (int k = max(new_hi + 1, lo) + tid; k <= hi; k += T) wR[c][k] = (row_t)RNULL;
+              tlo[c] = max(tlo[c], new_lo); thi[c] = min(thi[c], new_hi);
+              if (tlo[c] > thi[c]) { tlo[c] = 1; thi[c] = -1; }
+            }
+          }
+        }
+      }
       // gap cells outside their trimmed limits become NULL (M's are NULL already)
       if (lo <= hi) {
 #pragma unroll
@@ -334,6 +382,8 @@ wfa_wide_kernel(const WideArgs a) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) { o[c] = INT_MAX; o[NC + c] = INT_MIN; }
         ctrl[20 + (par ^ 1)] = INT_MAX;
+        o = ctrl + 22 + 3 * (par ^ 1);
+        o[0] = INT_MAX; o[1] = INT_MAX; o[2] = INT_MIN;
       }
       __syncthreads();
       if (end_reason) break;

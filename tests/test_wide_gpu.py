@@ -155,3 +155,43 @@ def test_wide_kernel_many_pairs_take_the_workspace_rows(gpu, idx, monkeypatch):
         score, status, cigars = common.gpu_run(nc, batch, full, resident=True)
         for k_ in env: monkeypatch.delenv(k_)
         common.assert_same(o, score, status, cigars, batch, f"wide, many pairs {kw} {env}")
+
+
+ADAPT_CASES = [
+    dict(span="end-to-end", scope="score", heuristic="adaptive"),
+    dict(span="end-to-end", scope="full", heuristic="adaptive"),
+    dict(span="end-to-end", scope="full", heuristic="adaptive", min_wavefront_length=5, max_distance_threshold=20, steps_between_cutoffs=3),
+    dict(span="ends-free", scope="full", heuristic="adaptive", pattern_begin_free=30, pattern_end_free=40, text_begin_free=20, text_end_free=10),
+    dict(span="end-to-end", scope="full", heuristic="adaptive", mismatch=2, gap_opening=3, gap_extension=1, max_distance_threshold=200),
+    dict(distance="affine2p", span="end-to-end", scope="full", heuristic="adaptive"),
+    dict(distance="affine2p", span="ends-free", scope="score", heuristic="adaptive", pattern_end_free=100, text_end_free=100, min_wavefront_length=20),
+    dict(span="end-to-end", scope="full", heuristic="adaptive", max_steps=1500),
+]
+
+
+@pytest.mark.parametrize("idx", range(len(ADAPT_CASES)))
+def test_wide_kernel_wf_adaptive(gpu, idx, monkeypatch):
+    """Round 3: the wide kernel evaluates the wf-adaptive cut-off itself (R/wavefront_heuristic.c:257-293) and takes what the banded
+    stages hand on.  Here the banded stages are off and the form is forced (WFA_HIP_WIDE_ADAPT=2), so every pair runs through it:
+    results must equal the oracle's, which prunes the same diagonals."""
+    monkeypatch.setenv("WFA_HIP_NO_BAND", "1")
+    monkeypatch.setenv("WFA_HIP_WIDE_ADAPT", "2")
+    batch = ragged_batch(180, 2500, 0.10, 9300 + idx)
+    kw = common.clamp_free(dict(ADAPT_CASES[idx]), batch)
+    oc, nc = common.configs_pair(**kw)
+    full = oc.scope == 1
+    o = loader.run(loader.oracle(), oc, batch, want_cigar=full)
+    score, status, cigars = common.gpu_run(nc, batch, full, resident=bool(idx % 2))
+    common.assert_same(o, score, status, cigars, batch, f"wide wf-adaptive {kw}")
+
+
+def test_wide_kernel_takes_wf_adaptive_leftovers_of_the_banded_stages(gpu):
+    """Default cascade, 30 kb reads at 12 % with a generous cut-off: some wavefronts outgrow the 256-diagonal window and the wide kernel
+    (not the general kernel) finishes them; compared with the real library when it is there."""
+    batch = datagen.generate(160, 30000, 0.12, 9400)
+    kw = dict(span="end-to-end", scope="full", heuristic="adaptive", max_distance_threshold=400)
+    oc, nc = common.configs_pair(**kw)
+    fn = loader.reference() if loader.have_reference() else loader.oracle()
+    o = loader.run(fn, oc, batch)
+    score, status, cigars = common.gpu_run(nc, batch, True, resident=True)
+    common.assert_same(o, score, status, cigars, batch, "wide takes the banded stages' wf-adaptive leftovers")

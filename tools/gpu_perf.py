@@ -71,6 +71,7 @@ if "A150" in which: run("150bp adaptive score", 2000000, 150, 0.02, 1002, dict(s
 if "N150" in which: run("150bp no heuristic score", 2000000, 150, 0.02, 1002, dict(span="end-to-end", scope="score"), cpu_n=100000)
 if "B10k" in which: run("10kb BiWFA full", 2000, 10000, 0.08, 1003, dict(span="end-to-end", scope="full", memory_mode="biwfa"), cpu_n=40)
 if "B1k" in which: run("1kb BiWFA full", 50000, 1000, 0.08, 1003, dict(span="end-to-end", scope="full", memory_mode="biwfa"), cpu_n=2000)
+if "A30k" in which: run("30kb adaptive full", 4096, 30000, 0.08, 1005, dict(span="end-to-end", scope="full", heuristic="adaptive"), cpu_n=8, reps=1)
 if "C5a8k" in which: run("100kb adaptive full, 8192 pairs", 8192, 100000, 0.08, 1005, dict(span="end-to-end", scope="full", heuristic="adaptive"), cpu_n=4, reps=1)
 if "C5as8k" in which: run("100kb adaptive score, 8192 pairs", 8192, 100000, 0.08, 1005, dict(span="end-to-end", scope="score", heuristic="adaptive"), cpu_n=4, reps=1)
 if "X100k" in which: run("100kb exact score", 64, 100000, 0.08, 1005, dict(span="end-to-end", scope="score"), cpu_n=1, reps=1)
