@@ -1189,7 +1189,7 @@ static int ensure_ws(wfa_hip_aligner* al, size_t bytes) {
 // memory_mode medium / low: the general kernel keeps the piggy-back history (one byte of origin codes per cell) instead of the
 // explicit arena (full scope, gap-affine / gap-affine-2p; WFA_HIP_GENERAL_PB = 0 / 1 overrides)
 // history of the general kernel: one byte of origin codes per cell (PB) instead of the offsets — memory modes medium / low, and, like
-// the banded kernel's split stage, long reads in every mode (round 3: the explicit arena of a 100 kb pair overflows and is re-run 8x
+// the banded kernel's split stage, reads over 20 kb in every mode (round 3: the explicit arena of a 100 kb pair overflows and is re-run 8x
 // larger, with a host round trip each time: C5-shaped wf-adaptive 10.8 k -> 16 k aln/s); WFA_HIP_BAND_PB=0 / WFA_HIP_GENERAL_PB=0 keep
 // the explicit offsets
 static bool general_pb(const wfa_hip_aligner* al, const wfa_hip_config_t& c, int ncomp, int max_len) {
@@ -1197,7 +1197,7 @@ static bool general_pb(const wfa_hip_aligner* al, const wfa_hip_config_t& c, int
   const int e = knob(al, K_GENERAL_PB, -1);
   if (e >= 0) return e != 0;
   if (c.memory_mode == WFA_MEM_MED || c.memory_mode == WFA_MEM_LOW) return true;
-  return max_len > 1000 && knob(al, K_BAND_PB, 1) != 0;
+  return max_len > 20000 && knob(al, K_BAND_PB, 1) != 0;   // (at 10 kb the explicit arena fits and its walk is quicker: a lone leftover pair of C4-adaptive 30 ms sooner)
 }
 
 static int launch_general_dyn(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream, bool packed,
@@ -1393,8 +1393,10 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     }
     // (round 3) wf-adaptive: the wide kernel takes what the banded stages hand on — the few pairs whose wavefront outgrows 256 diagonals
     // (47 of 8 192 at 100 kb) — instead of the general kernel: rows in the workspace, its cut-off in-kernel (WFA_HIP_WIDE_ADAPT=0: off)
+    // (reads over 20 kb: at 10 kb the general kernel is as quick for the odd pair, and the 2p rows of the wide kernel are slower)
+    const int wide_adapt_knob = knob(al, K_WIDE_ADAPT, 1);
     const bool wide_adapt = b->dcfg.heuristic == WFA_HEUR_ADAPTIVE && b->max_len > 1000 &&
-                            (knob(al, K_WIDE_ADAPT, 1) == 2 || (n_stages > 0 && knob(al, K_WIDE_ADAPT, 1) != 0));   // (2: also without banded stages in front: tests)
+                            (wide_adapt_knob == 2 || (n_stages > 0 && wide_adapt_knob != 0 && b->max_len > 20000));   // (2: any length, also without banded stages in front: tests)
     const bool wide_ok = !tiny && ((b->ncomp == 3 && b->dcfg.metric == 3) || (b->ncomp == 5 && b->dcfg.metric == 4 && b->dcfg.e2 >= 1)) &&
                          (b->dcfg.heuristic == WFA_HEUR_NONE || wide_adapt) && b->dcfg.match == 0 &&
                          b->max_len > 64 && 2 * (int64_t)b->max_len <= 0x3fffff00ll && b->dcfg.e1 >= 1 && b->dcfg.x >= 1 && knob(al, K_NO_WIDE, 0) == 0;
