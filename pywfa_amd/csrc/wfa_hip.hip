@@ -1536,7 +1536,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         const int64_t row_bytes = wide32 ? 4 : 2;   // bytes per offset
         st.smem = wfa::wide_smem_bytes(w0.X, w0.OE, w0.E, w0.OE2, w0.E2, full_range, w0.seq_words, false);
         const bool seqs_fit_lds = st.smem <= (size_t)160 * 1024;   // (both packed sequences are staged in LDS: reads up to ~300 kb)
-        st.threads = knob(al, K_WIDE_THREADS, wide_adapt ? 256 : ws_threads);
+        st.threads = knob(al, K_WIDE_THREADS, wide_adapt ? 512 : ws_threads);   // (wf-adaptive: a cut wavefront is a few hundred diagonals: one cell per thread)
         st.grid = (int)std::min<int64_t>((int64_t)al->cu_count * std::max<int64_t>(1, std::min<int64_t>(2048 / st.threads, (160 * 1024) / std::max<size_t>(st.smem, 1))), in_n);
         if (wide_adapt) st.grid = std::min(st.grid, al->cu_count);   // (leftovers: one workgroup per CU is plenty)
         int64_t hist_bytes = 0;

@@ -207,6 +207,8 @@ wfa_wide_kernel(const WideArgs a) {
       int wmin[NC], wmax[NC];   // (wave-uniform)
 #pragma unroll
       for (int c = 0; c < NC; ++c) { wmin[c] = INT_MAX; wmax[c] = INT_MIN; }
+      // wf-adaptive: the smallest distance to the end over the extended M cells, and this thread's cell if it had just one
+      int dloc = INT_MAX, my_cells = 0, my_off = RNULL, my_k = 0;
       for (int k0 = lo + (tid & ~63); k0 <= hi; k0 += T) {
         const int k = k0 + lane;
         const bool in = k <= hi;
@@ -295,6 +297,10 @@ wfa_wide_kernel(const WideArgs a) {
             }
           }
         }
+        if (a.heur == 1 && in) {
+          if (v5[0] >= 0) dloc = min(dloc, max(tlen, plen + k) - v5[0]);   // max(plen - v, tlen - h)
+          my_off = v5[0]; my_k = k; ++my_cells;
+        }
         if (in) {
           // (negative gap values are stored as they are: they start at NULL and gain at most 1 per step, so they stay
           // negative for the 16 000 steps a pair may take here, and a negative offset is never in bounds)
@@ -303,11 +309,16 @@ wfa_wide_kernel(const WideArgs a) {
           if (FULL) pb_codes[code_base + (k - lo)] = (uint8_t)code;
         }
       }
+      if (a.heur == 1) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) dloc = min(dloc, __shfl_xor(dloc, m, 64));
+      }
       if (lane == 0) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) if (wmin[c] != INT_MAX) { atomicMin(&TRmin[c], wmin[c]); atomicMax(&TRmax[c], wmax[c]); }
+        if (a.heur == 1 && dloc != INT_MAX) atomicMin(&ctrl[22 + 3 * par], dloc);
       }
-      __syncthreads();   // rows, trimmed limits and the end flag of this step are visible
+      __syncthreads();   // rows, trimmed limits, the end flag and the smallest distance of this step are visible
       // ---- trimmed limits (R/wavefront_compute.c:571-605): first / last in-bounds cell; none -> null ----
       int tlo[NC], thi[NC];
 #pragma unroll
@@ -325,20 +336,15 @@ wfa_wide_kernel(const WideArgs a) {
         const int mlo = tlo[0], mhi = thi[0];
         if (steps_wait <= 0 && mhi - mlo + 1 >= a.min_wf_len) {   // (uniform: every thread read the same limits)
           int* const cut = ctrl + 22 + 3 * par;
-          int dloc = INT_MAX;
-          for (int k = mlo + tid; k <= mhi; k += T) {
-            const int off = wR[0][k];
-            if (off >= 0) dloc = min(dloc, max(tlen, plen + k) - off);   // max(plen - v, tlen - h)
-          }
-#pragma unroll
-          for (int m = 32; m >= 1; m >>= 1) dloc = min(dloc, __shfl_xor(dloc, m, 64));
-          if (lane == 0 && dloc != INT_MAX) atomicMin(&cut[0], dloc);
-          __syncthreads();
-          const int dmin = min(cut[0], max(plen, tlen));
+          const int dmin = min(cut[0], max(plen, tlen));   // (collected in the pass above)
           int fk = INT_MAX, lk = INT_MIN;
-          for (int k = mlo + tid; k <= mhi; k += T) {
-            const int off = wR[0][k];
-            if (off >= 0 && max(tlen, plen + k) - off - dmin <= a.max_dist_thr) { fk = min(fk, k); lk = max(lk, k); }
+          if (my_cells <= 1) {   // the usual case: this thread's one cell is still in registers
+            if (my_cells == 1 && my_off >= 0 && max(tlen, plen + my_k) - my_off - dmin <= a.max_dist_thr) fk = lk = my_k;
+          } else {
+            for (int k = mlo + tid; k <= mhi; k += T) {
+              const int off = wR[0][k];
+              if (off >= 0 && max(tlen, plen + k) - off - dmin <= a.max_dist_thr) { fk = min(fk, k); lk = max(lk, k); }
+            }
           }
 #pragma unroll
           for (int m = 32; m >= 1; m >>= 1) { fk = min(fk, __shfl_xor(fk, m, 64)); lk = max(lk, __shfl_xor(lk, m, 64)); }
