@@ -38,6 +38,7 @@ for it in range(rounds):
         err = float(rng.choice([0.0, 0.01, 0.02, 0.02, 0.05, 0.1, 0.25]))
         n = int(rng.choice([300, 2000, 9000, 9000, 70000])) if L <= 250 else int(rng.choice([100, 700]))
         if it % 7 == 3 and part == 0: L, n = int(rng.choice([1500, 3000, 6000])), int(rng.choice([60, 160, 300]))  # long reads: banded kernel, split launches, wide-wavefront kernel
+        if it % 21 == 10 and part == 0: L, n = int(rng.choice([22000, 30000])), int(rng.choice([40, 140]))  # reads over 20 kb: 256-diagonal first window, the wide kernel's cut-off, piggy-back arena of the general kernel
         b = datagen.generate(n, L, err, int(rng.integers(1, 1 << 30)))
         cut = rng.integers(0, 20, size=n) * (rng.random(n) < 0.3)
         for i in (range(n) if n <= 9000 else range(0)):
