@@ -146,7 +146,7 @@ const char* wfa_hip_last_error(const wfa_hip_aligner_t* aligner);
  *                   the op string cigar->operations[begin_offset:end_offset) of pair i is
  *                   cigar_ops[cigar_begin[i] .. +cigar_len[i])  (chars M X I D)
  * All buffers are borrowed for the call; outputs are caller-owned.
- * Inside: up to 1 024 short pairs take one launch on a pinned block (single calls of a pywfa-style loop: ~30 us); batches of
+ * Inside: up to 4 096 short pairs take one launch on a pinned block (single calls of a pywfa-style loop: ~30 us); batches of
  * >= 256 k pairs are packed to 2 bits per base by host threads on their way into a pinned upload ring; everything else is
  * uploaded as it is and packed on the device.  The results are the same whichever way.
  */

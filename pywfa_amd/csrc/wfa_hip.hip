@@ -2150,8 +2150,11 @@ extern "C" int64_t wfa_hip_batch_fallback_pairs(const wfa_hip_batch_t* b) { retu
 // writing scores / statuses / op bytes straight into the pinned block; one stream synchronisation; the host copies
 // the results out.  No allocation, no memcpy call, no per-call environment lookup.
 static const int64_t TINY_MAX_PAIRS = 16;          // general-kernel form (a workspace slice per pair)
-static const int64_t TINY_MAX_PAIRS_BAND = 1024;   // banded form: whatever the pinned block holds (1 024 x 150 bp with op strings)
-static const size_t TINY_IN_BYTES = (size_t)256 << 10, TINY_BLOCK_BYTES = (size_t)1 << 20;
+// banded form: up to 4 096 pairs, whatever the pinned block holds (4 096 x 150 bp with op strings).  Round 3 (was 1 024): the host packs the
+// pairs on one thread (~70 ns per pair), so the path scales linearly and meets the batch machinery's fixed ~0.5 ms at ~8 k pairs:
+// 2 048 pairs 160 us (score) / 320 us (op strings) against 482 / 730 us, 4 096 pairs 319 / 589 against 534 / 1 001 us
+static const int64_t TINY_MAX_PAIRS_BAND = 4096;
+static const size_t TINY_IN_BYTES = (size_t)1 << 20, TINY_BLOCK_BYTES = (size_t)4 << 20;
 
 __global__ void __launch_bounds__(256) wfa_tiny_copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, int n16) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];

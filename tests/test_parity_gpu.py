@@ -82,7 +82,11 @@ def corpora():
 
 @pytest.mark.parametrize("cfg_idx", range(len(GRID)))
 @pytest.mark.parametrize("corpus", list(SHAPES) + ["special"])
-def test_hip_matches_oracle(gpu, corpora, corpus, cfg_idx):
+def test_hip_matches_oracle(gpu, corpora, corpus, cfg_idx, monkeypatch):
+    # (non-resident calls of <= 4 096 short pairs take the single-launch path; every fourth configuration keeps the batch machinery —
+    # pageable upload, device pack, the kernel cascade — covered at these sizes)
+    if cfg_idx % 4 == 0:
+        monkeypatch.setenv("WFA_HIP_NO_TINY", "1")
     batch = corpora[corpus]
     kw = common.clamp_free(GRID[cfg_idx], batch)
     oc, nc = common.configs_pair(**kw)
@@ -446,7 +450,7 @@ def test_pilot_choice_never_changes_results(gpu, scope, order):
                                 dict(scope="full", mismatch=7, gap_opening=3, gap_extension=2),      # no banded shape: the general kernel
                                 dict(scope="full", distance="levenshtein")])
 def test_single_calls_match_oracle(gpu, kw, monkeypatch):
-    """Calls of 1 .. 1 024 short pairs (pywfa's usual loop, and small batches) take the single-call path: one launch of the banded kernel reading the
+    """Calls of 1 .. 4 096 short pairs (pywfa's usual loop, and small batches) take the single-call path: one launch of the banded kernel reading the
     host-packed pairs from the pinned block, completion polled by the host; pairs it cannot hold (unrelated sequences: the
     wavefront outgrows 128 diagonals), letters outside ACGT and penalty shapes without a banded instantiation go through the
     general kernel instead.  Every result against the oracle; the same with the polling and the banded form switched off."""
@@ -474,7 +478,7 @@ def test_single_calls_match_oracle(gpu, kw, monkeypatch):
         for k_, v_ in env.items(): monkeypatch.setenv(k_, v_)
         al = _native.Aligner(nc)
         lo = 0
-        for size in [1, 1, 2, 3, 7, 16, 1, 17, 64, 300, 1024, 5]:   # (17 ..: the banded form only; beyond the pinned block: the batch path)
+        for size in [1, 1, 2, 3, 7, 16, 1, 17, 64, 300, 1024, 5, 4096, 4097]:   # (17 ..: the banded form only; beyond 4 096 pairs / the pinned block: the batch path)
             idx = np.arange(lo, lo + size) % nb
             sub = datagen.subset(batch, idx)
             score, status, cig = al.align_batch(sub, full)

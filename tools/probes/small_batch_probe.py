@@ -3,11 +3,11 @@ import sys, time, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 from pywfa_amd import _native, datagen
-b = datagen.generate(4096, 150, 0.02, 1002)
+b = datagen.generate(16384, 150, 0.02, 1002)
 for scope in (0, 1):
     cfg = _native.default_config(); cfg.span = 0; cfg.scope = scope
     al = _native.Aligner(cfg)
-    for n in (1, 16, 17, 64, 128, 129, 512, 4096):
+    for n in (1, 16, 128, 512, 1024, 2048, 4096, 8192, 8193, 16384):
         sub = datagen.subset(b, np.arange(n))
         al.align_batch(sub, bool(scope))
         t0 = time.time()
