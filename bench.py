@@ -211,6 +211,159 @@ def extra_config(name, n, length, error, seed, cfg_kw, scheme, survey_bytes, tri
             "parity_checked_pairs": n_cpu, "parity_mismatches": n_bad}
 
 
+LINE_LIMIT = 6000   # bytes of the final stdout line (the driver keeps an 8 KB tail; round 3's 30 KB line was not parsed)
+WORKLOAD_LIMIT = 120
+
+
+def _num(v):
+    """Finite, short numbers: 6 significant digits are enough for a rate, and NaN / Infinity are not JSON."""
+    if isinstance(v, (bool, type(None), str)):
+        return v
+    if isinstance(v, (int, np.integer)):
+        return int(v)
+    if isinstance(v, (float, np.floating)):
+        v = float(v)
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float(f"{v:.6g}")
+    return v
+
+
+def _scalars(d, keys=None):
+    """The scalar entries of a dict (optionally only `keys`), numbers shortened; nested objects are dropped."""
+    out = {}
+    for k, v in d.items():
+        if keys is not None and k not in keys:
+            continue
+        if isinstance(v, (dict, list, tuple)):
+            continue
+        out[k] = _num(v)
+    return out
+
+
+def compact_record(full):
+    """The record of the final stdout line: the contract keys, `config` (workload <= 120 chars + one scalar triple per
+    extra configuration), `roofline`, `cpu_baseline`, `end_to_end` — scalars only.  Everything else (per-configuration
+    rooflines, counters' provenance, prose) stays in the detail file."""
+    rec = {k: _num(full.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                          "scaling", "vs_baseline", "dtype", "data")}
+    cfg = _scalars(full.get("config", {}))
+    if isinstance(cfg.get("workload"), str):
+        cfg["workload"] = cfg["workload"][:WORKLOAD_LIMIT]
+    rec["config"] = cfg
+    roof = full.get("roofline") or {}
+    rec["roofline"] = _scalars(roof, ("bound", "achieved", "peak", "unit", "frac", "traffic", "secondary_bound", "secondary_frac",
+                                      "algorithmic_bytes_per_launch", "bytes_per_pair", "kernel_ms", "kernel"))
+    rec["roofline"].setdefault("traffic", None)
+    if "cpu_baseline" in full:
+        cb = _scalars(full["cpu_baseline"], ("value", "unit", "cores", "kind", "sample", "library", "parity_checked_pairs",
+                                             "parity_mismatches", "all_threads_value", "all_threads_threads"))
+        if isinstance(cb.get("sample"), str):
+            cb["sample"] = cb["sample"][:160]
+        rec["cpu_baseline"] = cb
+    if "end_to_end" in full:
+        rec["end_to_end"] = _scalars(full["end_to_end"], ("value", "unit", "seconds_per_batch", "pcie_gb_s", "pcie_frac",
+                                                          "ascii_gb_s_consumed", "includes_pilot"))
+    if "offsets_per_s" in full:
+        rec["offsets_per_s"] = _num(full["offsets_per_s"])
+    rec["errors"] = [str(e)[:200] for e in full.get("errors", [])][:8]
+    rec["detail"] = full.get("detail_file")
+    rec["kernel_source_hash"] = (full.get("extra") or {}).get("kernel_source_hash")
+    return rec
+
+
+def format_line(rec, limit=LINE_LIMIT):
+    """One strict-JSON line of at most `limit` bytes.  If the record is too long the per-configuration scalars of `config`
+    go first (longest names first) — the contract keys, `roofline` and `cpu_baseline` always stay."""
+    def dump(r):
+        return json.dumps(r, allow_nan=False, separators=(", ", ": "))
+    line = dump(rec)
+    if len(line.encode()) > limit:
+        rec = json.loads(line)
+        core = ("workload", "pairs_per_gpu", "read_length", "parallelism")
+        extras = sorted((k for k in rec["config"] if k not in core), key=lambda k: (-len(k), k))
+        rec["config"]["truncated"] = True
+        for k in extras:
+            del rec["config"][k]
+            line = dump(rec)
+            if len(line.encode()) <= limit:
+                break
+    if len(line.encode()) > limit:
+        raise ValueError(f"bench line is {len(line.encode())} bytes, limit {limit}")
+    return line
+
+
+def write_detail(full):
+    """The fat record (every configuration's roofline, counters' provenance, CPU samples) goes to a side file, and to
+    gpurun_out/ when that exists so that it travels back from the GPU box; never to stdout."""
+    name = "bench_detail.json"
+    text = json.dumps(full, default=lambda o: _num(o) if isinstance(o, (np.integer, np.floating)) else str(o))
+    written = None
+    for d in (os.path.join(ROOT, "gpurun_out"), ROOT):
+        try:
+            if d.endswith("gpurun_out"):
+                os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, name), "w") as f:
+                f.write(text + "\n")
+            written = written or os.path.relpath(os.path.join(d, name), ROOT)
+        except OSError:
+            pass
+    return written
+
+
+def native_config(**kw):
+    """pywfa's constructor kwargs -> wfa_hip_config_t (defaults = wfa_hip_config_default = align.pyx:309-334)."""
+    from pywfa_amd import _native
+    c = _native.default_config()
+    for k, v in kw.items():
+        if k == "distance":
+            c.distance = _native.DIST[v]
+        elif k == "scope":
+            c.scope = _native.SCOPE[v]
+        elif k == "span":
+            c.span = _native.SPAN[v]
+        elif k == "heuristic":
+            c.heuristic = _native.HEUR[v]
+        elif k == "memory_mode":
+            c.memory_mode = _native.MEM[v]
+        elif k == "wildcard":
+            c.wildcard = -1 if v is None else ord(v.upper())
+        else:
+            setattr(c, k, int(v))
+    return c
+
+
+def transcripts_valid(batch, score, status, cig, cfg_kw, sample=2000):
+    """Size-independent check of a full-CIGAR run without a CPU reference (N > 1 legs): every completed pair's op string
+    consumes exactly plen / tlen bases (inside the free ends), M only over equal bases, and — match = 0 — its gap-affine
+    penalty equals -score.  Checked on an evenly spaced sample; returns the number of violations."""
+    ops, cbeg, clen = cig
+    n = len(score)
+    x, o, e = cfg_kw.get("mismatch", 4), cfg_kw.get("gap_opening", 6), cfg_kw.get("gap_extension", 2)
+    bad = 0
+    for i in np.linspace(0, n - 1, min(sample, n)).astype(np.int64):
+        if status[i] != 0:
+            bad += 1
+            continue
+        s = ops[cbeg[i]:cbeg[i] + clen[i]]
+        nm, nx, ni, nd = (int((s == c).sum()) for c in (77, 88, 73, 68))
+        if nm + nx + nd != int(batch["p_len"][i]) or nm + nx + ni != int(batch["t_len"][i]):
+            bad += 1
+            continue
+        pi = np.cumsum(s != 73) - 1 + int(batch["p_off"][i])   # pattern base under each op (I consumes none)
+        ti = np.cumsum(s != 68) - 1 + int(batch["t_off"][i])
+        m, xm = s == 77, s == 88
+        if (batch["seqs"][pi[m]] != batch["seqs"][ti[m]]).any() or (batch["seqs"][pi[xm]] == batch["seqs"][ti[xm]]).any():
+            bad += 1
+            continue
+        if cfg_kw.get("distance", "affine") == "affine" and cfg_kw.get("span", "ends-free") == "end-to-end":
+            g = (s == 73) | (s == 68)
+            opens = int((g & ~np.concatenate(([False], s[:-1] == s[1:]))).sum())
+            if nx * x + opens * o + (ni + nd) * e != -int(score[i]):
+                bad += 1
+    return bad
+
+
 def shard_first(rank, pairs_per_gpu):
     """Weak scaling: rank r owns pairs [r*P, (r+1)*P) of the one seeded stream (no overlap, no gaps)."""
     return rank * pairs_per_gpu
@@ -247,6 +400,70 @@ def dist_max(dist, backend, value):
     return float(t.item())
 
 
+def dist_sum(dist, backend, value):
+    """SUM over ranks of a host number (pairs completed, violations)."""
+    if dist is None:
+        return value
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+C3_KW = dict(distance="affine", span="end-to-end", scope="full", heuristic="adaptive")
+C5_XDROP_KW = dict(distance="affine", span="end-to-end", scope="full", heuristic="X-drop", xdrop=20)   # C5 as BASELINE writes it (SURVEY Q2)
+C5_ADAPT_KW = dict(distance="affine", span="end-to-end", scope="full", heuristic="adaptive")
+
+
+def c3_leg(rank, world, local_rank, pairs, steps, dist, backend):
+    """The 10 kb half of the metric at any N: every rank aligns its own `pairs` of the C3 stream (10 kb, 8 %, wf-adaptive,
+    full CIGAR on the device), barrier on both sides, MAX time over ranks, pairs summed.  No CPU reference here: the op strings
+    are checked through their invariants (transcripts_valid)."""
+    from pywfa_amd import _native, datagen
+    batch = datagen.generate(pairs, 10000, 0.08, datagen.SEEDS["C3"], first=shard_first(rank, pairs))
+    al = _native.Aligner(native_config(**C3_KW), device=local_rank)
+    r = run_resident(al, batch, steps, 1, True, barrier=lambda: dist_barrier(dist, backend))
+    al.close()
+    elapsed = dist_max(dist, backend, r["elapsed"])
+    bad = transcripts_valid(batch, r["score"], r["status"], r["cig"], C3_KW, sample=500)
+    bad = dist_sum(dist, backend, bad)
+    done = dist_sum(dist, backend, int((r["status"] == 0).sum()))
+    rate = pairs * world * steps / elapsed
+    bytes_pair = 114e3   # SURVEY §8(d), piggy-back history
+    return {"pairs_per_gpu": pairs, "steps": steps, "ms_per_step": elapsed / steps * 1e3, "alignments_per_s": rate,
+            "kernel_ms_rank0": r["kernel_ms"], "hbm_frac": bytes_pair * pairs / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "completed": int(done), "invalid_transcripts": int(bad), "checked_per_rank": min(500, pairs)}
+
+
+def multi_leg(pairs_per_device, length=100000, calls=2):
+    """C5 through ONE process's wfa_hip_multi_align_batch over every visible device (the product's own sharding):
+    host ASCII in -> host results out, so this rate includes PCIe.  X-drop(20) as BASELINE writes C5 (every pair is dropped
+    after a few steps, SURVEY Q2: status 1, INT32_MIN, empty CIGAR) and wf-adaptive (completes)."""
+    from pywfa_amd import _native, datagen
+    ndev = _native.lib().wfa_hip_device_count()
+    devices = list(range(ndev))
+    n = pairs_per_device * ndev
+    batch = datagen.generate(n, length, 0.08, datagen.SEEDS["C5"])
+    out = {"devices": ndev, "pairs": n, "read_length": length}
+    for name, kw in (("xdrop", C5_XDROP_KW), ("adaptive", C5_ADAPT_KW)):
+        ma = _native.MultiAligner(native_config(**kw), devices)
+        best = None
+        for _ in range(calls):
+            t0 = time.perf_counter()
+            score, status, cig = ma.align_batch(batch, True)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        ma.close()
+        ops, cbeg, clen = cig
+        if name == "xdrop":
+            bad = int(((status != 1) | (score != -2**31) | (clen != 0)).sum())
+        else:
+            bad = transcripts_valid(batch, score, status, cig, kw, sample=64)
+        out[name] = {"alignments_per_s": n / best, "seconds_per_call": best, "completed": int((status == 0).sum()),
+                     "dropped": int((status == 1).sum()), "violations": bad}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -257,7 +474,31 @@ def main():
     ap.add_argument("--error", type=float, default=0.02)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
+    ap.add_argument("--c3-pairs", type=int, default=100_000, help="N > 1: 10 kb pairs per GPU of the C3 leg")
+    ap.add_argument("--multi", action="store_true",
+                    help="only the C5 leg: one process, wfa_hip_multi_align_batch over every visible device")
+    ap.add_argument("--multi-pairs", type=int, default=1024, help="100 kb pairs per device of the C5 leg")
     args = ap.parse_args()
+
+    if args.multi:
+        m = multi_leg(args.multi_pairs)
+        full = {"metric": "pairwise alignments/sec", "value": m["adaptive"]["alignments_per_s"], "unit": "alignments/s",
+                "n_gpus": m["devices"], "steps": 1, "warmup": 1, "ms_per_step": m["adaptive"]["seconds_per_call"] * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+                "config": {"workload": f"C5: {m['pairs']} x 100kb pairs, 8% error, wf-adaptive, full CIGAR, one process, "
+                                       f"wfa_hip_multi_align_batch over {m['devices']} device(s), host in -> host out",
+                           "pairs_per_gpu": args.multi_pairs, "read_length": 100000,
+                           "parallelism": f"contiguous shards over {m['devices']} device(s), no collective",
+                           "c5_multi_adaptive_alignments_per_s": m["adaptive"]["alignments_per_s"],
+                           "c5_multi_adaptive_violations": m["adaptive"]["violations"],
+                           "c5_multi_xdrop_alignments_per_s": m["xdrop"]["alignments_per_s"],
+                           "c5_multi_xdrop_violations": m["xdrop"]["violations"]},
+                "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None},
+                "extra": {"multi": m, "kernel_source_hash": kernel_source_hash()},
+                "errors": [f"{k}: {m[k]['violations']} violations" for k in ("xdrop", "adaptive") if m[k]["violations"]]}
+        full["detail_file"] = write_detail(full)
+        print(format_line(compact_record(full)), flush=True)
+        sys.exit(1 if full["errors"] else 0)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` by hand: start one rank per GPU as a child (nothing has touched the GPU yet) and
@@ -330,7 +571,12 @@ def main():
         t_e2e_ascii = time_e2e(al0, 2)
         al0.close()
 
+    c3 = None
+    if n_gpus > 1 and not args.no_extra_configs:
+        c3 = c3_leg(rank, world, local_rank, args.c3_pairs, 3, dist, backend)
+
     if rank == 0:
+        errors = []
         src_hash = kernel_source_hash()
         # HBM traffic of one launch and the on-chip counters, from the PMC passes committed under profiles/ (bench.py
         # cannot collect counters itself): used only when they were collected on this workload AND this kernel source
@@ -372,9 +618,11 @@ def main():
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
-            "config": {"workload": f"C2: {args.pairs} x {args.length}bp pairs per GPU, {args.error * 100:g}% error (seed 1002), "
-                                   "gap-affine 0/4/6/2, end-to-end, scope=score, 2-bit packed sequences resident in HBM; the first "
-                                   "stage's width was chosen by a pilot on 8192 pairs during warm-up (once per resident batch)",
+            "config": {"workload": f"C2: {args.pairs} x {args.length}bp pairs/GPU, {args.error * 100:g}% error, gap-affine 0/4/6/2, "
+                                   "end-to-end, scope=score, 2-bit reads resident in HBM",
+                       # (the first stage's width is chosen by a pilot on 8192 pairs once per resident batch, outside the timed steps;
+                       #  wfa_hip_align_batch pays it on every call: the end_to_end figures below include it)
+                       "pilot_in_timed_region": False, "end_to_end_includes_pilot": True,
                        "pairs_per_gpu": args.pairs, "read_length": args.length, "parallelism": f"pairs sharded over {n_gpus} GPU(s), no collective",
                        # `value` is the HBM-resident rate; the PCIe-inclusive rate of the same batch (host ASCII in -> host results out, every
                        # rank's call at once, the slowest rank counted) is never `value` but belongs beside it (full detail: "end_to_end")
@@ -392,7 +640,7 @@ def main():
             "end_to_end": {"value": e2e_rate * n_gpus, "unit": "alignments/s", "seconds_per_batch": t_e2e,
                            "what": "wfa_hip_align_batch: host ASCII in -> host scores/status out (host threads pack to 2 bits into the pinned "
                                    "upload ring, DMA, align, download); results into caller-owned arrays",
-                           "ascii_bytes_per_pair": ascii_bytes, "ascii_gb_s_consumed": e2e_rate * ascii_bytes / 1e9,
+                           "includes_pilot": True, "ascii_bytes_per_pair": ascii_bytes, "ascii_gb_s_consumed": e2e_rate * ascii_bytes / 1e9,
                            "pcie_bytes_per_pair": sent_bytes, "pcie_gb_s": e2e_rate * sent_bytes / 1e9,
                            "pcie_frac": e2e_rate * sent_bytes / 1e9 / PCIE_PEAK_GBS,
                            "packed2bits_input": None if t_e2e_2bit is None else {
@@ -481,8 +729,9 @@ def main():
             for kw_ in plan:
                 try:
                     xs.append(extra_config(**kw_))
-                except Exception as e:
+                except Exception as e:   # the headline line is still printed, but the run ends non-zero (below)
                     xs.append({"name": kw_["name"], "error": repr(e)})
+                    errors.append(f"{kw_['name']}: {e!r}")
             out["extra"]["configs"] = xs
             out["extra"]["configs_note"] = ("stated prefixes of the BASELINE streams: C1 at 1 M pairs (BASELINE names 1 k; and at 10 M, a batch that fills the chip), C3 100 k of 1 M, "
                                             "C4 as written (no heuristic) on 4 096 pairs (54 MB per pair: SURVEY's piggy-back figure) and with wf-adaptive on 100 k of "
@@ -498,10 +747,42 @@ def main():
                     out["config"][f"{key}_alignments_per_s"] = x["alignments_per_s"]
                     out["config"][f"{key}_hbm_frac"] = x["roofline"]["frac"]
                     out["config"][f"{key}_parity_mismatches"] = x["parity_mismatches"]
-        print(json.dumps(out), flush=True)
+                    if x["parity_mismatches"]:
+                        errors.append(f"{x['name']}: {x['parity_mismatches']} parity mismatches of {x['parity_checked_pairs']}")
+            try:   # C5 through the product's own multi-device entry (one process, every visible device)
+                m = multi_leg(args.multi_pairs)
+                out["extra"]["multi"] = m
+                out["config"]["c5_multi_devices"] = m["devices"]
+                for k in ("xdrop", "adaptive"):
+                    out["config"][f"c5_multi_{k}_alignments_per_s"] = m[k]["alignments_per_s"]
+                    if m[k]["violations"]:
+                        errors.append(f"C5 multi {k}: {m[k]['violations']} violations")
+            except Exception as e:
+                errors.append(f"C5 multi leg: {e!r}")
+        if c3 is not None:
+            out["extra"]["c3_leg"] = c3
+            out["config"]["c3_pairs_per_gpu"] = c3["pairs_per_gpu"]
+            out["config"]["c3_alignments_per_s"] = c3["alignments_per_s"]
+            out["config"]["c3_hbm_frac"] = c3["hbm_frac"]
+            out["config"]["c3_invalid_transcripts"] = c3["invalid_transcripts"]
+            if c3["invalid_transcripts"] or c3["completed"] != c3["pairs_per_gpu"] * n_gpus:
+                errors.append(f"C3 leg: {c3['invalid_transcripts']} invalid transcripts, {c3['completed']} completed")
+        cb = out.get("cpu_baseline") or {}
+        if cb.get("parity_mismatches"):
+            errors.append(f"C2: {cb['parity_mismatches']} parity mismatches of {cb['parity_checked_pairs']}")
+        if (cb.get("all_threads") or {}).get("parity_mismatches"):
+            errors.append(f"C2 (all threads): {cb['all_threads']['parity_mismatches']} parity mismatches")
+        out["errors"] = errors
+        out["detail_file"] = write_detail(out)
+        # the LAST stdout line: one strict-JSON object well under the driver's 8 KB (tests/test_bench_line.py)
+        print(format_line(compact_record(out)), flush=True)
+    failed = bool(rank == 0 and out["errors"])
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        print("bench.py: " + "; ".join(out["errors"]), file=sys.stderr)
+        sys.exit(1)
 
 
 if __name__ == "__main__":
