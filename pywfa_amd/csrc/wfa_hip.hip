@@ -25,6 +25,7 @@
 #include "wfa_pack.hpp"
 #include "wfa_general.hpp"
 #include "wfa_wide.hpp"
+#include "wfa_tile.hpp"
 #include "wfa_fast.hpp"
 #include "wfa_seg.hpp"
 #include "wfa_lane.hpp"
@@ -42,7 +43,7 @@ static thread_local std::string g_error;
   F(ARENA_KB) F(BAND_DEBUG) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
-  F(LANE_FULL) F(LANE_FULL_SPLIT) F(LANE_HEUR) F(SEG_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_ADAPT) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
+  F(LANE_FULL) F(LANE_FULL_SPLIT) F(LANE_HEUR) F(SEG_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_ADAPT) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(TILE) F(TILE_T) F(TILE_WT) F(TILE_THREADS) F(TILE_PER_CU) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
 enum WfaKnob {
 #define WFA_KNOB_ENUM(n) K_##n,
   WFA_KNOBS(WFA_KNOB_ENUM)
@@ -1471,6 +1472,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     struct WideStage { wfa::WideArgs a; int grid = 0, threads = 0; size_t smem = 0, hist_off = 0; bool grows = false, w32 = false; };
     WideStage wide_stage[2];
     int n_wide = 0;
+    struct TileStage { wfa::TileArgs a; int grid = 0, threads = 0; size_t smem = 0, hist_off = 0; bool on = false; } tile_stage;
     const bool wide_two = (b->ncomp == 5);
     if (wide_ok) {
       wfa::WideArgs w0;
@@ -1502,6 +1504,44 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       else if ((int64_t)in_n >= (int64_t)al->cu_count * 8) ws_threads = 256;
       else if ((int64_t)in_n >= (int64_t)al->cu_count * 4) ws_threads = wide_two ? 512 : 256;
       else if ((int64_t)in_n >= (int64_t)al->cu_count * 2) ws_threads = 512;
+      // Round 4: the temporally blocked form (wfa_tile.hpp) goes first for exact alignments with int16 rows: a wave advances a
+      // block of diagonals by T steps inside an LDS tile, the rows in the workspace are read and written once per T steps.  What it
+      // hands on (pairs where the reference's per-step trimming would change a value, a history that does not fit) goes to the
+      // step-by-step forms below.  WFA_HIP_TILE=0: off; WFA_HIP_TILE_T / _WT / _THREADS / _PER_CU: geometry
+      if (b->dcfg.heuristic == WFA_HEUR_NONE && !wide32 && knob(al, K_TILE, 1) != 0) {
+        wfa::TileArgs& ta = tile_stage.a;
+        memset(&ta, 0, sizeof(ta));
+        wfa::TileGeom& tg = ta.g;
+        tg.X = w0.X; tg.OE = w0.OE; tg.E = w0.E; tg.OE2 = w0.OE2; tg.E2 = w0.E2;
+        tg.DM = std::max(std::max(tg.X, tg.OE), tg.OE2);
+        tg.T = knob(al, K_TILE_T, wide_two ? 8 : 16) & ~1;
+        tg.Wt = knob(al, K_TILE_WT, wide_two ? 128 : 256);
+        const int bw = tg.Wt - 2 * tg.T;
+        const int tthreads = std::max(64, std::min(512, knob(al, K_TILE_THREADS, 256) & ~63));
+        if (tg.T >= 2 && tg.T <= WFA_TILE_MAX_T && tg.Wt >= 64 && tg.Wt % 64 == 0 && tg.Wt <= 256 && bw >= 16 &&
+            wfa::tile_cand_count(tg) <= WFA_TILE_MAX_ROWS) {
+          ta.gs = w0.g; ta.seq_words = w0.seq_words;
+          const int nbmax = (2 * b->max_len + 1 + bw - 1) / bw;
+          ta.rwh = (nbmax * bw + 2 * tg.T + 1) & ~1;
+          ta.rows_stride = ((int64_t)wfa::tile_hbm_rows(tg) * ta.rwh + 63) & ~63ll;
+          tile_stage.threads = tthreads;
+          tile_stage.smem = wfa::tile_smem_bytes(tg, ta.seq_words, tthreads / 64);
+          if (tile_stage.smem <= (size_t)160 * 1024) {
+            int per_cu = wfa::tile_occupancy(full, wide_two, tg.Wt / 64, tthreads, tile_stage.smem);
+            per_cu = std::max(1, std::min(per_cu, knob(al, K_TILE_PER_CU, 16)));
+            tile_stage.grid = (int)std::min<int64_t>((int64_t)al->cu_count * per_cu, in_n);
+            int64_t hist_bytes = 0;
+            if (full) hist_bytes = (int64_t)full_range * ((int64_t)(b->max_len * 0.9) / w0.g + 64 + tg.T) / 2 + (1 << 20);
+            while (tile_stage.grid > 1 && (int64_t)tile_stage.grid * (ta.rows_stride * 2 + hist_bytes) > budget) tile_stage.grid = (tile_stage.grid + 1) / 2;
+            if ((int64_t)tile_stage.grid * (ta.rows_stride * 2 + hist_bytes) <= budget) {
+              ta.hist_stride = (hist_bytes / 4) & ~15ll;
+              tile_stage.hist_off = ((size_t)tile_stage.grid * (size_t)ta.rows_stride * 2 + 255) & ~(size_t)255;
+              need = std::max(need, tile_stage.hist_off + (size_t)tile_stage.grid * (size_t)ta.hist_stride * 4);
+              tile_stage.on = true;
+            }
+          }
+        }
+      }
       if (!wide_two && !wide32 && !prefer_ws && !wide_adapt) {
         WideStage& st = wide_stage[n_wide];
         st.a = w0;
@@ -1885,6 +1925,38 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
     }
     { const int drc = pending_walks.end(); if (drc != WFA_HIP_OK) return drc; }   // (the stages below use the workspace from its start)
+    if (tile_stage.on) {
+      wfa::TileArgs& ta = tile_stage.a;
+      uint32_t* out_list = b->d_fb_list2[out_sel];
+      uint32_t* out_count = b->d_counters + 4 + out_sel;
+      if (!first_stage) HIP_TRY(al, hipMemsetAsync(out_count, 0, sizeof(uint32_t), stream));
+      ta.words = b->d_words; ta.meta = b->d_meta; ta.worklist = in_list; ta.nwork_dev = in_count; ta.nwork = in_n;
+      ta.score = b->d_score; ta.status = b->d_status; ta.fb_list = out_list; ta.fb_count = out_count;
+      ta.cigar_ops = b->d_ops; ta.cigar_off = b->d_cigar_off; ta.cigar_begin = b->d_cigar_begin; ta.cigar_len = b->d_cigar_len;
+      ta.rows = reinterpret_cast<short*>(al->ws);
+      ta.hist = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(al->ws) + tile_stage.hist_off);
+      ta.ef = b->dcfg.endsfree ? 1 : 0;
+      ta.pbf = b->dcfg.pbf; ta.pef = b->dcfg.pef; ta.tbf = b->dcfg.tbf; ta.tef = b->dcfg.tef;
+      ta.max_steps = b->dcfg.max_steps;
+      hipEvent_t se0 = nullptr, se1 = nullptr;
+      const bool stage_timing = knob(al, K_STAGE_TIMING, 0) != 0;
+      if (stage_timing) { (void)hipEventCreate(&se0); (void)hipEventCreate(&se1); (void)hipEventRecord(se0, stream); }
+      ta.dbg = stage_timing ? b->d_counters + 8 : nullptr;   // ([8] is the lane-full stage's list count: short reads only)
+      if (stage_timing) (void)hipMemsetAsync(b->d_counters + 8, 0, 8 * sizeof(uint32_t), stream);
+      if (wfa::launch_tile(full, wide_two, ta, tile_stage.grid, tile_stage.threads, tile_stage.smem, stream) != 0) { al->err = "tile kernel launch failed"; return WFA_HIP_EDEVICE; }
+      if (stage_timing) {  // development aid: synchronises
+        (void)hipEventRecord(se1, stream); (void)hipEventSynchronize(se1);
+        float ms = 0.f; (void)hipEventElapsedTime(&ms, se0, se1);
+        uint32_t handed = 0; (void)hipMemcpy(&handed, out_count, sizeof(uint32_t), hipMemcpyDeviceToHost);
+        uint32_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpy(dbg, b->d_counters + 8, sizeof(dbg), hipMemcpyDeviceToHost);
+        if (dbg[3] | dbg[4]) fprintf(stderr, "[wfa_hip] tile profile (k-cycles of s_memtime, summed over waves): load %u, steps %u, write-back %u; steps that entered the end test %u, the long-match loop %u\n", dbg[3], dbg[4], dbg[5], dbg[6], dbg[7]);
+        fprintf(stderr, "[wfa_hip] tile stage (T %d, Wt %d, %d x %d threads, %zu B LDS): %.3f ms, handed on %u pairs; %u super-steps, %u repeated with statistics, %u tiles\n",
+                ta.g.T, ta.g.Wt, tile_stage.grid, tile_stage.threads, tile_stage.smem, ms, handed, dbg[0], dbg[1], dbg[2]);
+        (void)hipEventDestroy(se0); (void)hipEventDestroy(se1);
+      }
+      if (first_stage) b->last_kernel_pairs = in_n;
+      in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
+    }
     for (int ws_i = 0; ws_i < n_wide; ++ws_i) {
       WideStage& st = wide_stage[ws_i];
       wfa::WideArgs& wa = st.a;
@@ -1901,7 +1973,17 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       wa.max_steps = b->dcfg.max_steps;
       wa.heur = (b->dcfg.heuristic == WFA_HEUR_ADAPTIVE) ? 1 : 0; wa.min_wf_len = b->dcfg.min_wf_len; wa.max_dist_thr = b->dcfg.max_dist_thr;
       wa.steps_between = b->dcfg.steps_between;
+      hipEvent_t se0 = nullptr, se1 = nullptr;
+      const bool stage_timing = knob(al, K_STAGE_TIMING, 0) != 0;
+      if (stage_timing) { (void)hipEventCreate(&se0); (void)hipEventCreate(&se1); (void)hipEventRecord(se0, stream); }
       if (wfa::launch_wide(full, wide_two, wa, st.grid, st.threads, st.smem, stream, st.w32) != 0) { al->err = "wide kernel launch failed"; return WFA_HIP_EDEVICE; }
+      if (stage_timing) {  // development aid: synchronises
+        (void)hipEventRecord(se1, stream); (void)hipEventSynchronize(se1);
+        float ms = 0.f; (void)hipEventElapsedTime(&ms, se0, se1);
+        uint32_t handed = 0; (void)hipMemcpy(&handed, out_count, sizeof(uint32_t), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[wfa_hip] wide stage %d (%d x %d threads): %.3f ms, handed on %u pairs\n", ws_i, st.grid, st.threads, ms, handed);
+        (void)hipEventDestroy(se0); (void)hipEventDestroy(se1);
+      }
       if (first_stage) b->last_kernel_pairs = in_n;
       in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
     }

@@ -82,6 +82,63 @@ static inline size_t wide_smem_bytes(int X, int OE, int E, int OE2, int E2, int 
   return (size_t)(WFA_WIDE_CTRL_INTS + 2 * NR) * 4 + (size_t)2 * seq_words * 4 + (rows_in_lds ? (size_t)NR * wide_row_halfs(wcap) * 2 : 0);
 }
 
+// Full CIGAR of the wide-wavefront kernels (this file and wfa_tile.hpp): one lane walks the origin codes back from the end cell
+// (R/wavefront_backtrace.c:320-529's choices, decided at compute time), keeping one event byte per edit, then unpacks forwards
+// from the start cell re-extending the matches on the LDS copies of the packed sequences.  Directory record of step t:
+// hist[hist_stride - 3 (t + 1)] = {lo, hi, first code byte}.  Returns the number of ops written to `out`, or -1 when the
+// events do not fit `ev_cap` or the walk leaves score 0 below.
+template <bool TWO>
+__device__ inline long long wide_walk_unpack(const int* hist, long long hist_stride, const uint8_t* pb_codes, uint8_t* ev, long long ev_cap,
+                                             int end_t, int end_k, int X, int OE, int E, int OE2, int E2,
+                                             const uint32_t* sP, const uint32_t* sT, int plen, int tlen, uint8_t* out) {
+  int tc = end_t, k = end_k, comp = 0;
+  long long nev = 0;
+  while (tc > 0) {
+    if (nev >= ev_cap) return -1;
+    const int* d = hist + hist_stride - 3ll * (tc + 1);
+    const int cd = (k >= d[0] && k <= d[1]) ? pb_codes[(long long)d[2] + (k - d[0])] : 0;
+    const uint8_t flag = (comp == 0) ? 0x80 : 0;
+    int src;   // 0 mismatch, 1 D1, 2 D2, 3 I1, 4 I2
+    if (TWO) src = (comp == 0) ? (cd & 7) : (comp == 1) ? 3 : (comp == 2) ? 1 : (comp == 3) ? 4 : 2;
+    else src = (comp == 0) ? ((cd & 3) == 0 ? 0 : ((cd & 3) == 1 ? 1 : 3)) : (comp == 1 ? 3 : 1);
+    const int bi1 = TWO ? 8 : 4, bd1 = TWO ? 16 : 8;
+    if (src == 0) { ev[nev++] = (uint8_t)('X' | 0x80); tc -= X; }
+    else if (src == 1) { ev[nev++] = (uint8_t)('D' | flag); ++k; if (cd & bd1) { tc -= E; comp = 2; } else { tc -= OE; comp = 0; } }
+    else if (src == 2) { ev[nev++] = (uint8_t)('D' | flag); ++k; if (cd & 64) { tc -= E2; comp = 4; } else { tc -= OE2; comp = 0; } }
+    else if (src == 3) { ev[nev++] = (uint8_t)('I' | flag); --k; if (cd & bi1) { tc -= E; comp = 1; } else { tc -= OE; comp = 0; } }
+    else { ev[nev++] = (uint8_t)('I' | flag); --k; if (cd & 32) { tc -= E2; comp = 3; } else { tc -= OE2; comp = 0; } }
+  }
+  if (tc < 0) return -1;
+  long long n = 0;
+  auto emit = [&](char c, int cnt) { for (int i = 0; i < cnt; ++i) out[n++] = (uint8_t)c; };
+  auto lcp = [&](int v, int h) {   // common prefix of pattern[v..] and text[h..] on the LDS copies
+    const int maxrun = min(plen - v, tlen - h);
+    int run = 0;
+    while (run < maxrun) {
+      const int pv = v + run, th = h + run;
+      const uint32_t xp = __builtin_amdgcn_alignbit(sP[(pv >> 4) + 1], sP[pv >> 4], (uint32_t)(pv & 15) << 1);
+      const uint32_t xt = __builtin_amdgcn_alignbit(sT[(th >> 4) + 1], sT[th >> 4], (uint32_t)(th & 15) << 1);
+      const uint32_t x = xp ^ xt;
+      const int m = x ? (__builtin_ctz(x) >> 1) : 16;
+      run += m;
+      if (m < 16) break;
+    }
+    return min(run, maxrun);
+  };
+  int h = max(k, 0), v = h - k;
+  emit('I', h); emit('D', v);
+  { const int e = lcp(v, h); emit('M', e); v += e; h += e; }
+  for (long long e_ = nev - 1; e_ >= 0; --e_) {
+    const int op = ev[e_] & 0x7F;
+    if (op == 'X') { emit('X', 1); ++v; ++h; }
+    else if (op == 'I') { emit('I', 1); ++h; }
+    else { emit('D', 1); ++v; }
+    if (ev[e_] & 0x80) { const int e = lcp(v, h); emit('M', e); v += e; h += e; }
+  }
+  emit('I', tlen - h); emit('D', plen - v);
+  return n;
+}
+
 // FULL: piggy-back history + walk; TWO: gap-affine-2p (components M, I1, D1, I2, D2); GROWS: the rows live in the workgroup's
 // slice of the HBM workspace (L2-resident) instead of LDS — the 2p form: 37 rows x 20 000 diagonals for 10 kb reads
 // W32: rows of int32 offsets (GROWS only): reads beyond 16 kb (plen + tlen > 32 000), any number of steps
@@ -410,58 +467,12 @@ wfa_wide_kernel(const WideArgs a) {
         out_score = -(end_t * a.g);
         if (FULL) {
           // walk the origin codes back from the end cell, then unpack forwards re-extending the matches (wfa_general.hpp PB)
-          uint8_t* const ev = pb_codes + pb_used;
-          const long long ev_cap = pb_cap - pb_used - (long long)(end_t + 2) * 12;
-          int tc = end_t, k = end_k, comp = 0;
-          long long nev = 0;
-          bool fail = false;
-          while (tc > 0) {
-            if (nev >= ev_cap) { fail = true; break; }
-            const int* d = hist + a.hist_stride - 3ll * (tc + 1);
-            const int cd = (k >= d[0] && k <= d[1]) ? pb_codes[(long long)d[2] + (k - d[0])] : 0;
-            const uint8_t flag = (comp == 0) ? 0x80 : 0;
-            int src;   // 0 mismatch, 1 D1, 2 D2, 3 I1, 4 I2
-            if (TWO) src = (comp == 0) ? (cd & 7) : (comp == 1) ? 3 : (comp == 2) ? 1 : (comp == 3) ? 4 : 2;
-            else src = (comp == 0) ? ((cd & 3) == 0 ? 0 : ((cd & 3) == 1 ? 1 : 3)) : (comp == 1 ? 3 : 1);
-            const int bi1 = TWO ? 8 : 4, bd1 = TWO ? 16 : 8;
-            if (src == 0) { ev[nev++] = (uint8_t)('X' | 0x80); tc -= a.X; }
-            else if (src == 1) { ev[nev++] = (uint8_t)('D' | flag); ++k; if (cd & bd1) { tc -= a.E; comp = 2; } else { tc -= a.OE; comp = 0; } }
-            else if (src == 2) { ev[nev++] = (uint8_t)('D' | flag); ++k; if (cd & 64) { tc -= a.E2; comp = 4; } else { tc -= a.OE2; comp = 0; } }
-            else if (src == 3) { ev[nev++] = (uint8_t)('I' | flag); --k; if (cd & bi1) { tc -= a.E; comp = 1; } else { tc -= a.OE; comp = 0; } }
-            else { ev[nev++] = (uint8_t)('I' | flag); --k; if (cd & 32) { tc -= a.E2; comp = 3; } else { tc -= a.OE2; comp = 0; } }
-          }
-          if (fail || tc < 0) {
+          const long long n = wide_walk_unpack<TWO>(hist, a.hist_stride, pb_codes, pb_codes + pb_used, pb_cap - pb_used - (long long)(end_t + 2) * 12,
+                                                    end_t, end_k, a.X, a.OE, a.E, a.OE2, a.E2, sP, sT, plen, tlen, a.cigar_ops + a.cigar_off[pair]);
+          if (n < 0) {
             out_status = WFA_INTERNAL_FALLBACK; out_score = 0;
             a.fb_list[atomicAdd(a.fb_count, 1u)] = pair;
           } else {
-            uint8_t* const out = a.cigar_ops + a.cigar_off[pair];
-            long long n = 0;
-            auto emit = [&](char c, int cnt) { for (int i = 0; i < cnt; ++i) out[n++] = (uint8_t)c; };
-            auto lcp = [&](int v, int h) {   // common prefix of pattern[v..] and text[h..] on the LDS copies
-              const int maxrun = min(plen - v, tlen - h);
-              int run = 0;
-              while (run < maxrun) {
-                const int pv = v + run, th = h + run;
-                const uint32_t xp = __builtin_amdgcn_alignbit(sP[(pv >> 4) + 1], sP[pv >> 4], (uint32_t)(pv & 15) << 1);
-                const uint32_t xt = __builtin_amdgcn_alignbit(sT[(th >> 4) + 1], sT[th >> 4], (uint32_t)(th & 15) << 1);
-                const uint32_t x = xp ^ xt;
-                const int m = x ? (__builtin_ctz(x) >> 1) : 16;
-                run += m;
-                if (m < 16) break;
-              }
-              return min(run, maxrun);
-            };
-            int h = max(k, 0), v = h - k;
-            emit('I', h); emit('D', v);
-            { const int e = lcp(v, h); emit('M', e); v += e; h += e; }
-            for (long long e_ = nev - 1; e_ >= 0; --e_) {
-              const int op = ev[e_] & 0x7F;
-              if (op == 'X') { emit('X', 1); ++v; ++h; }
-              else if (op == 'I') { emit('I', 1); ++h; }
-              else { emit('D', 1); ++v; }
-              if (ev[e_] & 0x80) { const int e = lcp(v, h); emit('M', e); v += e; h += e; }
-            }
-            emit('I', tlen - h); emit('D', plen - v);
             cbeg = a.cigar_off[pair];
             clen = (int)n;
           }

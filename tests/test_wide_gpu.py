@@ -49,21 +49,84 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("tile", ["1", "0"])
 @pytest.mark.parametrize("idx", range(len(CASES)))
-def test_wide_kernel_matches_oracle(gpu, idx):
+def test_wide_kernel_matches_oracle(gpu, idx, tile, monkeypatch):
+    """tile = 1: the temporally blocked form (csrc/wfa_tile.hpp, round 4) takes the batch first, the step-by-step form what it
+    hands on; tile = 0: the step-by-step form alone (what it was before, and still is for wf-adaptive and reads over 16 kb)."""
+    monkeypatch.setenv("WFA_HIP_TILE", tile)
     batch = ragged_batch(180, 2500, 0.10, 9100 + idx)
     kw = common.clamp_free(dict(CASES[idx]), batch)
     oc, nc = common.configs_pair(**kw)
     full = oc.scope == 1
     o = loader.run(loader.oracle(), oc, batch, want_cigar=full)
     score, status, cigars = common.gpu_run(nc, batch, full, resident=bool(idx % 2))
-    common.assert_same(o, score, status, cigars, batch, f"wide {kw}")
+    common.assert_same(o, score, status, cigars, batch, f"wide {kw} tile={tile}")
+
+
+TILE_GEOMETRIES = [dict(WFA_HIP_TILE_T="4", WFA_HIP_TILE_WT="64"), dict(WFA_HIP_TILE_T="16", WFA_HIP_TILE_WT="128"),
+                   dict(WFA_HIP_TILE_T="8", WFA_HIP_TILE_WT="256", WFA_HIP_TILE_THREADS="128"),
+                   dict(WFA_HIP_TILE_T="2", WFA_HIP_TILE_WT="64", WFA_HIP_TILE_THREADS="512"),
+                   dict(WFA_HIP_TILE_T="32", WFA_HIP_TILE_WT="192", WFA_HIP_TILE_THREADS="192")]
+
+
+@pytest.mark.parametrize("geo", range(len(TILE_GEOMETRIES)))
+@pytest.mark.parametrize("idx", [1, 2, 4, 7, 11, 12, 13, 14])
+def test_tile_kernel_geometries(gpu, idx, geo, monkeypatch):
+    """The blocked form under other geometries than the defaults (steps per super-step, tile width, waves per workgroup): ring
+    slots, halo widths, the far form of the M rows (gap-affine-2p with T <= 8) and the classic one, run-time penalties."""
+    for k_, v_ in TILE_GEOMETRIES[geo].items():
+        monkeypatch.setenv(k_, v_)
+    batch = ragged_batch(150, 2200, 0.10, 9600 + idx)
+    kw = common.clamp_free(dict(CASES[idx]), batch)
+    oc, nc = common.configs_pair(**kw)
+    full = oc.scope == 1
+    o = loader.run(loader.oracle(), oc, batch, want_cigar=full)
+    score, status, cigars = common.gpu_run(nc, batch, full, resident=True)
+    common.assert_same(o, score, status, cigars, batch, f"tile {kw} {TILE_GEOMETRIES[geo]}")
+
+
+@pytest.mark.parametrize("kw", [dict(span="end-to-end", scope="full"), dict(span="end-to-end", scope="score", mismatch=1, gap_opening=1, gap_extension=1),
+                                dict(distance="affine2p", span="end-to-end", scope="full"),
+                                dict(span="ends-free", scope="full", pattern_begin_free=20, pattern_end_free=20, text_begin_free=10, text_end_free=10)])
+def test_tile_kernel_hands_on_what_trimming_would_change(gpu, kw, monkeypatch):
+    """Unrelated sequences, prefixes and overhangs of 65-260 bases: wavefronts run into the ends of the diagonal range and gap cells
+    past a sequence end lie outside their row's in-bounds cells — where the reference's per-step trimming changes values.  The
+    blocked form must notice (tests/test_tile_model.py shows on the CPU that it does in most of these pairs) and hand such pairs to
+    the step-by-step form: results equal the oracle's for every pair."""
+    monkeypatch.setenv("WFA_HIP_NO_FAST", "1")   # (short reads: keep the register kernels out of the way, the wide-wavefront stages take the batch)
+    monkeypatch.setenv("WFA_HIP_NO_BAND", "1")
+    rng = np.random.default_rng(4242)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    pats, txts = [], []
+    for i in range(400):
+        pl = int(rng.integers(65, 260))
+        p = alpha[rng.integers(0, 4, pl)]
+        mode = i % 4
+        if mode == 0:
+            t = alpha[rng.integers(0, 4, int(rng.integers(65, 260)))]
+        elif mode == 1:
+            t = p[:int(rng.integers(40, pl + 1))]
+        elif mode == 2:
+            t = np.concatenate([alpha[rng.integers(0, 4, int(rng.integers(0, 40)))], p])
+        else:
+            t = p.copy()
+            t[rng.integers(0, len(t), 12)] = alpha[rng.integers(0, 4, 12)]
+        pats.append(p.tobytes().decode()); txts.append(t.tobytes().decode())
+    batch = datagen.from_strings(pats, txts)
+    kw = common.clamp_free(dict(kw), batch)
+    oc, nc = common.configs_pair(**kw)
+    full = oc.scope == 1
+    o = loader.run(loader.oracle(), oc, batch, want_cigar=full)
+    score, status, cigars = common.gpu_run(nc, batch, full, resident=True)
+    common.assert_same(o, score, status, cigars, batch, f"tile, short unrelated pairs {kw}")
 
 
 @pytest.mark.parametrize("scope", ["score", "full"])
 def test_wide_kernel_rows_too_narrow_hand_on(gpu, scope, monkeypatch):
     """With 24 KB of LDS the rows hold a few hundred diagonals: most pairs outgrow them and are handed on to the general
     kernel; the results do not change.  (And with the kernel switched off.)"""
+    monkeypatch.setenv("WFA_HIP_TILE", "0")   # (the step-by-step kernel's own forms)
     batch = ragged_batch(150, 3000, 0.10, 9200)
     oc, nc = common.configs_pair(span="end-to-end", scope=scope)
     full = scope == "full"
@@ -145,6 +208,7 @@ def test_wide_kernel_many_pairs_take_the_workspace_rows(gpu, idx, monkeypatch):
     workgroups (8 x 256 threads per CU for gap-affine, 4 x 512 for gap-affine-2p: many pairs in flight per CU) instead of one
     1 024-thread workgroup with its rows in LDS; same results, nothing left to the general kernel; and the LDS form on the same
     batch when it is forced."""
+    monkeypatch.setenv("WFA_HIP_TILE", "0")   # (the step-by-step kernel's own forms)
     batch = ragged_batch(1100, 1800, 0.10, 9500 + idx)
     kw = common.clamp_free(dict(CASES[idx]), batch)
     oc, nc = common.configs_pair(**kw)
