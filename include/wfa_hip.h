@@ -28,8 +28,10 @@
 #ifndef WFA_HIP_H_
 #define WFA_HIP_H_
 
+#ifndef __HIPCC_RTC__   /* (the kernel headers include this file for the status codes, also when compiled by hipRTC) */
 #include <stdint.h>
 #include <stddef.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {

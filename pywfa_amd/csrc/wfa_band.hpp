@@ -15,15 +15,19 @@
 // Whatever does not fit (window, history capacity, dead wavefront) is appended to the fallback list and
 // finished by the general kernel with identical results.
 #pragma once
-#include <hip/hip_runtime.h>
-#include <limits.h>
-#include <type_traits>
+#include "wfa_rtc_compat.hpp"
+#ifndef __HIPCC_RTC__
+#include <string>
+#include "wfa_rtc.hpp"
+#endif
 #include "wfa_hip.h"
 #include "wfa_common.hpp"
 #include "wfa_fast.hpp"
 #include "wfa_general.hpp"
 
 namespace wfa {
+
+template <int N> struct band_int { static constexpr int value = N; };   // (a compile-time chunk count passed to the step lambdas)
 
 // penalty shapes (x, o + e, e) / gcd the banded kernel is instantiated for: pywfa's 4/6/2 and the presets 4/4/2, 4/6/1, 3/4/1
 #define WFA_BAND_SHAPES(F) F(0, 2, 4, 1) F(1, 2, 3, 1) F(2, 4, 7, 1) F(3, 3, 5, 1)
@@ -417,8 +421,8 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
                 for (int c = 0; c < ACT; ++c) if (cur[c] >= 0) cur[c] = h[c];
               }
             };
-            if (ACT_SMALL < NCH && !big) extend_chunks(std::integral_constant<int, ACT_SMALL>{});
-            else extend_chunks(std::integral_constant<int, NCH>{});
+            if (ACT_SMALL < NCH && !big) extend_chunks(band_int<ACT_SMALL>{});
+            else extend_chunks(band_int<NCH>{});
           }
           // ---------------- termination ----------------
           if (a.ef) {
@@ -730,8 +734,8 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
             for (int c = 0; c < ACT; ++c) { I2h[0][c] = ni2[c]; D2h[0][c] = nd2[c]; }
           }
         };
-        if (ACT_SMALL < NCH && !big) compute_next(std::integral_constant<int, ACT_SMALL>{});
-        else compute_next(std::integral_constant<int, NCH>{});
+        if (ACT_SMALL < NCH && !big) compute_next(band_int<ACT_SMALL>{});
+        else compute_next(band_int<NCH>{});
         // ---------------- limits (R/wavefront_unialign.c:98-107, R/wavefront_extend.c:97-104) ----------------
         // The reference walks every integer score; here only multiples of g exist, the scores in between are null steps.
         // A run of more than `scope` null scores after the last non-null one ends the alignment "unreachable" at score
@@ -1188,6 +1192,7 @@ inline int launch_band_bt_impl(const BandArgs& a, int nch, hipStream_t stream) {
 
 #endif  // WFA_BAND_WALK_KERNELS
 
+#ifndef __HIPCC_RTC__   // ---- host side (launch code, shape tables) ----
 template <int NCH, bool FULL, bool ADAPT, bool PB, bool SPLIT, int X, int OE, int E, int OE2, int E2>
 static int launch_band_k(const BandArgs& a, bool seqlds, long long grid, hipStream_t stream) {
   const size_t smem = seqlds ? (size_t)a.lds_words * 2 * sizeof(uint32_t) : 0;
@@ -1260,21 +1265,44 @@ inline bool band_supported(const WfaDevConfig& c, int ncomp) {
 #define WFA_BAND_MATCH2(x, oe, e, oe2, e2) if (X == x && OE == oe && E == e && OE2 == oe2 && E2 == e2) return true;
     WFA_BAND_SHAPES_2P(WFA_BAND_MATCH2)
 #undef WFA_BAND_MATCH2
-    return false;
+    return c.rtc && rtc_shape_ok(X, OE, E, OE2, E2);
   }
 #define WFA_BAND_MATCH(i, x, oe, e) if (X == x && OE == oe && E == e) return true;
   WFA_BAND_SHAPES(WFA_BAND_MATCH)
 #undef WFA_BAND_MATCH
-  return false;
+  return c.rtc && rtc_shape_ok(X, OE, E);
+}
+
+// the banded kernel of a shape without an instantiation, compiled at run time (csrc/wfa_rtc.cpp): the same choice of kernel and
+// template arguments launch_band_shape / _t / _k make at compile time
+inline int launch_band_rtc(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds, long long grid, hipStream_t stream) {
+  const int g = a.g, X = a.x / g, OE = a.oe / g, E = a.e / g, OE2 = a.oe2 > 0 ? a.oe2 / g : 0, E2 = a.oe2 > 0 ? a.e2 / g : 0;
+  if (!(nch == 1 || nch == 2 || nch == 4 || (nch == 3 && OE2 > 0))) return -1;
+  const bool split = full && a.split, pb = split && a.pb;
+  const char* kernel = (OE2 > 0 && nch == 3) ? "wfa_band_kernel_w4" : (OE2 > 0 && nch == 4 && !pb) ? "wfa_band_kernel_w3" : "wfa_band_kernel";
+  const std::string name = std::string("wfa::") + kernel + "<" + std::to_string(nch) + ", " + rtc_bool(full) + ", " + rtc_bool(adapt) + ", " + rtc_bool(seqlds) + ", " +
+                           rtc_bool(pb) + ", " + rtc_bool(split) + ", " + std::to_string(X) + ", " + std::to_string(OE) + ", " + std::to_string(E) + ", " +
+                           std::to_string(OE2) + ", " + std::to_string(E2) + ">";
+  const size_t smem = seqlds ? (size_t)a.lds_words * 2 * sizeof(uint32_t) : 0;
+  return rtc_launch("wfa_band.hpp", name, (unsigned)grid, 64, smem, stream, &a, sizeof(a));
 }
 
 inline int launch_band(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds, long long grid, hipStream_t stream) {
   const int g = a.g, X = a.x / g, OE = a.oe / g, E = a.e / g;
-  if (a.oe2 > 0) return launch_band_s4(a, nch, full, adapt, seqlds, grid, stream);
+  if (rtc_force_all() && rtc_available()) return launch_band_rtc(a, nch, full, adapt, seqlds, grid, stream);
+  if (a.oe2 > 0) {
+    const int OE2 = a.oe2 / g, E2 = a.e2 / g;
+#define WFA_BAND_LAUNCH2(x_, oe_, e_, oe2_, e2_) if (X == x_ && OE == oe_ && E == e_ && OE2 == oe2_ && E2 == e2_) return launch_band_s4(a, nch, full, adapt, seqlds, grid, stream);
+    WFA_BAND_SHAPES_2P(WFA_BAND_LAUNCH2)
+#undef WFA_BAND_LAUNCH2
+    return launch_band_rtc(a, nch, full, adapt, seqlds, grid, stream);
+  }
 #define WFA_BAND_LAUNCH(i, x, oe, e) if (X == x && OE == oe && E == e) return launch_band_s##i(a, nch, full, adapt, seqlds, grid, stream);
   WFA_BAND_SHAPES(WFA_BAND_LAUNCH)
 #undef WFA_BAND_LAUNCH
-  return -1;
+  return launch_band_rtc(a, nch, full, adapt, seqlds, grid, stream);
 }
+
+#endif  // __HIPCC_RTC__
 
 }  // namespace wfa

@@ -5,7 +5,7 @@
 //   a wavefront = {lo, hi, offsets[k]} per score and component M / I1 / D1 / I2 / D2
 //   (wavefront.h:56-77); NULL offset = INT32_MIN/2 (wavefront_offset.h:44).
 #pragma once
-#include <stdint.h>
+#include "wfa_rtc_compat.hpp"
 
 #define WFA_OFFSET_NULL (-1073741824)  // INT32_MIN/2
 
@@ -34,6 +34,10 @@ struct WfaDevConfig {
   int32_t min_wf_len, max_dist_thr, steps_between, xdrop;
   int32_t max_steps;           // INT32_MAX = unlimited
   int32_t wildcard;            // -1 none
+  int32_t score_mode;          // how a completed pair's score is reported from the kernels' -s (csrc/wfa_hip.hip derive_dev_config):
+                               // 0 as it is; 1 (sw_match (plen + tlen) - s) / 2 (match < 0, R/wavefront_penalties.h:73); 2 +s (indel / edit)
+  int32_t sw_match;            // -match of the original configuration (score_mode 1)
+  int32_t rtc;                 // 1: penalty shapes without an instantiation are compiled at run time (csrc/wfa_rtc.cpp)
   int32_t biwfa_top;           // 1: the general kernel stands in for the top-level base case of BiWFA (reads of <= 100 bases whose
                                // score outgrows the BiWFA kernel's base-case history): a completed pair keeps the unset score
                                // (SURVEY Q6), every other ending is "unattainable" (R/wavefront_bialign.c:182-187,725-729)

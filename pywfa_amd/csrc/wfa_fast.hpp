@@ -3,8 +3,7 @@
 // diagonal from the adjacent lane.  (Round 1's one- and two-alignments-per-wave kernels lived here; the segmented
 // kernels superseded them and they were removed in round 2.)
 #pragma once
-#include <hip/hip_runtime.h>
-#include <limits.h>
+#include "wfa_rtc_compat.hpp"
 #include "wfa_common.hpp"
 
 namespace wfa {

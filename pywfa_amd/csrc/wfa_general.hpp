@@ -22,8 +22,7 @@
 // wavefront outside its [lo,hi] yields NULL exactly like the reference's lazily padded arrays
 // (R/wavefront_compute.c:490-567).  Integer arithmetic only.
 #pragma once
-#include <hip/hip_runtime.h>
-#include <limits.h>
+#include "wfa_rtc_compat.hpp"
 #include "wfa_common.hpp"
 #include "wfa_hip.h"
 
@@ -742,6 +741,7 @@ wfa_general_kernel(const WfaKernelArgs a) {
 
 // host entry points, one translation unit per component count (csrc/k_general.hip, -DWFA_TU_INDEX = 0 / 1 / 2 for
 // NCOMP = 1 / 3 / 5)
+#ifndef __HIPCC_RTC__   // ---- host side ----
 int launch_general_c1(bool packed, bool full, bool pb, const WfaKernelArgs& a, int grid, int threads, hipStream_t stream);
 int launch_general_c3(bool packed, bool full, bool pb, const WfaKernelArgs& a, int grid, int threads, hipStream_t stream);
 int launch_general_c5(bool packed, bool full, bool pb, const WfaKernelArgs& a, int grid, int threads, hipStream_t stream);
@@ -773,5 +773,7 @@ inline int launch_general_any(int ncomp, bool packed, bool full, bool pb, const 
   if (ncomp == 3) return launch_general_c3(packed, full, pb, a, grid, threads, stream);
   return launch_general_c5(packed, full, pb, a, grid, threads, stream);
 }
+
+#endif  // __HIPCC_RTC__
 
 }  // namespace wfa

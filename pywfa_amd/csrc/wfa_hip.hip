@@ -26,6 +26,7 @@
 #include "wfa_general.hpp"
 #include "wfa_wide.hpp"
 #include "wfa_tile.hpp"
+#include "wfa_rtc.hpp"
 #include "wfa_fast.hpp"
 #include "wfa_seg.hpp"
 #include "wfa_lane.hpp"
@@ -323,6 +324,42 @@ extern "C" int wfa_hip_config_validate(const wfa_hip_config_t* c, char* err, siz
   return WFA_HIP_OK;
 }
 
+// Configurations that are ordinary gap-affine alignments in disguise run on the fast kernels, with the score translated afterwards
+// (VERDICT r03 item 7):
+//  * match < 0: the reference aligns with the Eizenga-rescaled penalties and reports (-match (plen + tlen) - s) / 2
+//    (R/wavefront_penalties.c:95-173, R/wavefront_penalties.h:73, R/wavefront_compute.c:108-120): here match = 0 + the rescaled
+//    penalties + score_mode 1;
+//  * indel / levenshtein / gap-linear in SCORE scope: a gap-linear recurrence (R/wavefront_compute_linear.c:44-74,
+//    R/wavefront_compute_edit.c:44-100) gives the same scores as gap-affine with o = 0 (I[s][k] = max(M, I)[s-e][k-1] + 1 = M[s-e][k-1] + 1
+//    because M >= I), and the indel distance the same as mismatch = 2 (a mismatch is an insertion + a deletion): gap-affine
+//    (x, 0, indel) + score_mode 2 for the two distances reported as +s.  Op strings can differ where the backtraces break ties
+//    differently (R/wavefront_backtrace.c:223-319 vs :320-529), so scope = full keeps the one-component kernel.
+// Only where nothing else reads the original form: no free ends (the reference re-seeds free begins under match < 0,
+// R/wavefront_compute.c:124-254; its partial-alignment score uses the end position), no X-drop (its score uses match), no step
+// limit (-max_steps is reported in the original scale), no wildcard, not BiWFA.  WFA_HIP_NO_SCORE_MAP=1: off.
+static void map_to_gap_affine(const wfa_hip_config_t& c, WfaDevConfig* d, int* ncomp) {
+  d->score_mode = 0; d->sw_match = 0;
+  static const bool off = getenv("WFA_HIP_NO_SCORE_MAP") && *getenv("WFA_HIP_NO_SCORE_MAP") == '1';
+  if (off) return;
+  const bool free_ends = c.span == WFA_SPAN_ENDSFREE && (c.pattern_begin_free | c.pattern_end_free | c.text_begin_free | c.text_end_free) != 0;
+  if (free_ends || c.max_steps > 0 || c.wildcard >= 0 || c.memory_mode == WFA_MEM_BIWFA) return;
+  if (c.heuristic != WFA_HEUR_NONE && !(c.heuristic == WFA_HEUR_ADAPTIVE && *ncomp != 1)) return;
+  if (*ncomp == 1) {
+    if (c.scope != WFA_SCOPE_SCORE) return;
+    const int indel = d->o1;   // (derive_dev_config keeps the indel penalty there)
+    if (c.distance == WFA_DIST_INDEL) d->x = 2;
+    d->o1 = 0; d->e1 = indel; d->o2 = 0; d->e2 = indel;
+    d->metric = WFA_DIST_AFFINE;
+    *ncomp = 3;
+    d->scope = std::max(d->o1 + d->e1, d->x) + 1;
+    d->score_mode = (c.distance == WFA_DIST_LINEAR) ? (d->match < 0 ? 1 : 0) : 2;
+  } else {
+    if (d->match == 0) return;
+    d->score_mode = 1;
+  }
+  if (d->match < 0) { d->sw_match = -d->match; d->match = 0; }
+}
+
 static void derive_dev_config(const wfa_hip_config_t& c, WfaDevConfig* d, int* ncomp) {
   const bool two = (c.distance == WFA_DIST_AFFINE2P);
   d->metric = c.distance;
@@ -344,6 +381,8 @@ static void derive_dev_config(const wfa_hip_config_t& c, WfaDevConfig* d, int* n
     d->max_steps = (c.max_steps <= 0) ? INT_MAX : c.max_steps;
     d->wildcard = c.wildcard;
     d->biwfa_top = 0;
+    d->rtc = wfa::rtc_available() ? 1 : 0;
+    map_to_gap_affine(c, d, ncomp);
     return;
   }
   *ncomp = two ? 5 : 3;
@@ -372,6 +411,9 @@ static void derive_dev_config(const wfa_hip_config_t& c, WfaDevConfig* d, int* n
   d->max_steps = (c.max_steps <= 0) ? INT_MAX : c.max_steps;  // align.pyx:415-417
   d->wildcard = c.wildcard;
   d->biwfa_top = 0;
+  // penalty shapes without an instantiation: the register kernels are compiled for them at run time where hipRTC works
+  d->rtc = wfa::rtc_available() ? 1 : 0;
+  map_to_gap_affine(c, d, ncomp);
 }
 
 extern "C" wfa_hip_aligner_t* wfa_hip_create(const wfa_hip_config_t* cfg, int device) {
@@ -994,6 +1036,16 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
 // the batch (score-only kernels, one-round form: a name of its own in a profile) decides once per batch, when the batch is
 // created: b->stage_pick = 16 / 32 / 64, or 128 = none of them.  (Up to three small launches, each waited for: it runs where
 // the upload is waited for anyway, so that wfa_hip_batch_run only enqueues.)
+// score_mode (csrc/wfa_common.hpp): the kernels leave -s; completed pairs get the score of the original configuration
+__global__ void __launch_bounds__(256) wfa_score_translate_kernel(int32_t* __restrict__ score, const int32_t* __restrict__ status,
+                                                                  const WfaPairMeta* __restrict__ meta, long long n, int mode, int sw_match) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || status[i] != 0) return;
+  const int raw = score[i];   // -s
+  if (mode == 2) score[i] = -raw;
+  else score[i] = (int)(((long long)sw_match * ((long long)meta[i].plen + meta[i].tlen) + raw) / 2);
+}
+
 __global__ void __launch_bounds__(256) wfa_pilot_sample_kernel(const uint32_t* __restrict__ list, uint32_t stride, uint32_t np, uint32_t* __restrict__ out) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i < np) out[i] = list ? list[i * stride] : i * stride;
@@ -1036,7 +1088,8 @@ static int pilot_lane_heur(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t st
       wfa::seg_shape(b->dcfg, &X, &OE, &E) < 0 || b->max_len > WFA_FAST_MAX_LEN || knob(al, K_NO_FAST, 0) != 0) return WFA_HIP_OK;
   const bool free_begins = b->dcfg.endsfree && (b->dcfg.pbf | b->dcfg.tbf) != 0;
   const bool seg_ok = wfa::seg_heur_config(b->dcfg, b->ncomp);
-  const int forced = knob(al, K_LANE_HEUR, -1);       // (WFA_HIP_LANE_HEUR = 1 / 0: always / never, whatever the batch)
+  int forced = knob(al, K_LANE_HEUR, -1);       // (WFA_HIP_LANE_HEUR = 1 / 0: always / never, whatever the batch)
+  if (wfa::seg_shape(b->dcfg, &X, &OE, &E) == WFA_SHAPE_RTC && !wfa::rtc_lane_shape_ok(X, OE, E)) forced = 0;   // (a run-time shape whose rings outgrow the lane kernel's registers)
   const int forced_seg = knob(al, K_SEG_HEUR, -1);    // (WFA_HIP_SEG_HEUR likewise)
   if (forced >= 0) b->laneh_pick = forced ? 1 : 2;
   if (forced_seg >= 0) b->segh_pick = (forced_seg && seg_ok) ? 1 : 2;
@@ -1060,7 +1113,7 @@ static int pilot_lane_heur(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t st
   fa.steps_between = b->dcfg.steps_between; fa.max_steps = b->dcfg.max_steps;
   if (forced < 0 &&
       wfa::launch_lane_args(wfa::seg_shape(b->dcfg, &X, &OE, &E), OE, E, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8),
-                            b->max_len, stream, fa, false, 0, 256, true) != 0) { al->err = "pilot launch failed"; return WFA_HIP_EDEVICE; }
+                            b->max_len, stream, fa, false, 0, 256, true, X) != 0) { al->err = "pilot launch failed"; return WFA_HIP_EDEVICE; }
   if (forced_seg < 0 && seg_ok) {   // (the same sample through the 32-lane form; its list is not read, only its count)
     fa.fb_count = pcount + 1;
     if (wfa::launch_seg_heur(b->dcfg, al->cu_count, knob(al, K_FAST_WAVES_PER_CU, 256), stream, fa) != 0) { al->err = "pilot launch failed"; return WFA_HIP_EDEVICE; }
@@ -1230,6 +1283,12 @@ static int64_t free_budget(wfa_hip_aligner* al) {
   return (int64_t)((double)(fr + al->ws_bytes + al->pool_cached) * 0.8);
 }
 
+// The history of a full-CIGAR run is sized for scores up to 0.9 x the read length under pywfa's default penalties (4/6/2: about 15 %
+// divergence); other penalties (also the rescaled ones of match < 0) scale the score a divergence costs
+static double penalty_scale(const WfaDevConfig& d) {
+  return std::max(1.0, std::max(d.x / 4.0, std::max((d.o1 + d.e1) / 8.0, d.e1 / 2.0)));
+}
+
 static Geometry plan_general(wfa_hip_aligner* al, const wfa_hip_batch* b, uint32_t nwork, int64_t arena_ints) {
   Geometry g;
   const bool full = (b->cfg.scope == WFA_SCOPE_FULL);
@@ -1365,6 +1424,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     // wavefront touches the band's outermost slots); the banded stages take what it hands on
     int lh_x, lh_oe, lh_e;
     const bool use_laneh = !tiny && !full && !use_fast && wfa::lane_heur_config(b->dcfg, b->ncomp) && wfa::seg_shape(b->dcfg, &lh_x, &lh_oe, &lh_e) >= 0 &&
+                           (wfa::seg_shape(b->dcfg, &lh_x, &lh_oe, &lh_e) != WFA_SHAPE_RTC || wfa::rtc_lane_shape_ok(lh_x, lh_oe, lh_e)) &&
                            b->max_len <= WFA_FAST_MAX_LEN && knob(al, K_NO_FAST, 0) == 0 &&
                            (b->laneh_pick == 1 || (b->laneh_pick == 0 && knob(al, K_LANE_HEUR, 0) != 0));   // (the pilot of batch_build, or WFA_HIP_LANE_HEUR=1)
     // ... and then (or first, when the lane form's pilot said no) the same form of the 32-lane segments: two pairs per wave, a band twice
@@ -1427,7 +1487,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         const bool h16 = b->max_len < 32000;
         const int rec = ((h16 && b->ncomp != 5) ? 2 : 4) * (band_nch[i] == 3 ? 256 : 64 * band_nch[i]);  // ints per record (2p: 16-byte entries)
         // steps of an alignment = score / g; sized for scores up to 0.9 x the read length (about 15 % divergence)
-        long long records = std::max<long long>(256, (long long)(b->max_len * 0.9) / wfa::band_gcd(b->dcfg, b->ncomp == 5) + 64);
+        long long records = std::max<long long>(256, (long long)(b->max_len * 0.9 * penalty_scale(b->dcfg)) / wfa::band_gcd(b->dcfg, b->ncomp == 5) + 64);
         records = knob(al, K_BAND_RECORDS, (int)records);
         band_stride[i] = ((int64_t)records * rec + 63) & ~63ll;
         const int64_t budget = free_budget(al);
@@ -1531,7 +1591,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
             per_cu = std::max(1, std::min(per_cu, knob(al, K_TILE_PER_CU, 16)));
             tile_stage.grid = (int)std::min<int64_t>((int64_t)al->cu_count * per_cu, in_n);
             int64_t hist_bytes = 0;
-            if (full) hist_bytes = (int64_t)full_range * ((int64_t)(b->max_len * 0.9) / w0.g + 64 + tg.T) / 2 + (1 << 20);
+            if (full) hist_bytes = (int64_t)full_range * ((int64_t)(b->max_len * 0.9 * penalty_scale(b->dcfg)) / w0.g + 64 + tg.T) / 2 + (1 << 20);
             while (tile_stage.grid > 1 && (int64_t)tile_stage.grid * (ta.rows_stride * 2 + hist_bytes) > budget) tile_stage.grid = (tile_stage.grid + 1) / 2;
             if ((int64_t)tile_stage.grid * (ta.rows_stride * 2 + hist_bytes) <= budget) {
               ta.hist_stride = (hist_bytes / 4) & ~15ll;
@@ -1580,7 +1640,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         st.grid = (int)std::min<int64_t>((int64_t)al->cu_count * std::max<int64_t>(1, std::min<int64_t>(2048 / st.threads, (160 * 1024) / std::max<size_t>(st.smem, 1))), in_n);
         if (wide_adapt) st.grid = std::min(st.grid, al->cu_count);   // (leftovers: one workgroup per CU is plenty)
         int64_t hist_bytes = 0;
-        if (full) hist_bytes = (int64_t)full_range * ((int64_t)(b->max_len * 0.9) / w0.g + 64) / 2 + (1 << 20);   // one byte per cell, + directory + events
+        if (full) hist_bytes = (int64_t)full_range * ((int64_t)(b->max_len * 0.9 * penalty_scale(b->dcfg)) / w0.g + 64) / 2 + (1 << 20);   // one byte per cell, + directory + events
         // (wf-adaptive: the cut-off keeps the wavefronts narrow: ~2 KB of codes per step; a pair that needs more is handed on)
         if (full && wide_adapt) hist_bytes = std::min<int64_t>(hist_bytes, ((int64_t)(b->max_len * 1.2) / w0.g + 64) * 2048 + (1 << 20));
         while (st.grid > 1 && (int64_t)st.grid * (st.a.rows_stride * row_bytes + hist_bytes) > budget) st.grid = (st.grid + 1) / 2;
@@ -1606,7 +1666,9 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     // Round 3: the 16-diagonal stage of that cascade is the lane-per-pair kernel with origin codes (wfa_lane_kernel<.., FULL>):
     // it walks in-kernel and leaves only run records in HBM (WFA_LANE_RUN_SLOT ints + an end state per pair), so the whole batch
     // is one launch; WFA_HIP_LANE_FULL=0 keeps round 2's 16-lane segments with explicit offset records
-    const bool use_lanefull = use_segfull && n_segfull >= 1 && segfull_w[0] == 16 && knob(al, K_LANE_FULL, 1) != 0;
+    int lfs_x = 0, lfs_oe = 0, lfs_e = 0;
+    const bool lane_shape_fits = wfa::seg_shape(b->dcfg, &lfs_x, &lfs_oe, &lfs_e) != WFA_SHAPE_RTC || wfa::rtc_lane_shape_ok(lfs_x, lfs_oe, lfs_e);
+    const bool use_lanefull = use_segfull && n_segfull >= 1 && segfull_w[0] == 16 && knob(al, K_LANE_FULL, 1) != 0 && lane_shape_fits;
     // (behind it one segment stage, 32 lanes, then the banded kernel: the 64-lane stage cost more in launches than its ~300 pairs per
     // million are worth)
     if (use_lanefull) { for (int i = 1; i < n_segfull; ++i) segfull_w[i - 1] = segfull_w[i]; --n_segfull; if (!al->knobs.set[K_SEGFULL_STAGES]) n_segfull = std::min(n_segfull, 1); }
@@ -1690,7 +1752,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
           ba.hist = fa.hist; ba.end_state = fa.end_state; ba.lane_codes = fa.codes;
         }
         // (a shorter last launch has fewer waves and needs fewer records than the lists were sized for)
-        if (wfa::launch_lane_args(shape, OE, E, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, fa, true, 0, knob(al, K_LANE_MIN_PAIRS, 0)) != 0) {
+        if (wfa::launch_lane_args(shape, OE, E, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, fa, true, 0, knob(al, K_LANE_MIN_PAIRS, 0), false, X) != 0) {
           al->err = "lane kernel launch failed"; return WFA_HIP_EDEVICE;
         }
         ba.work_begin = (uint32_t)w0; ba.nwork = cnt;
@@ -1762,6 +1824,10 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         const int v = *c - '0';
         if (v < 0 || v > 9) continue;
         if (v < 1) continue;
+        if (v == 1) {   // (the lane kernel of a run-time shape: only while its rings fit the register file)
+          int X_, OE_, E_;
+          if (wfa::seg_shape(b->dcfg, &X_, &OE_, &E_) == WFA_SHAPE_RTC && !wfa::rtc_lane_shape_ok(X_, OE_, E_)) continue;
+        }
         variants[nv++] = v;
       }
       if (nv == 0) variants[nv++] = 6;
@@ -1779,7 +1845,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
           lrc = wfa::launch_lane(shape, wfa::gcd_int(wfa::gcd_int(b->dcfg.x, b->dcfg.o1 + b->dcfg.e1), b->dcfg.e1), al->cu_count,
                                  knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, b->d_words, b->d_meta,
                                  in_list, in_count, in_n, b->d_score, b->d_status, out_list, out_count,
-                                 (knob(al, K_LANE_DEBUG, 0) && al->ws) ? al->ws : nullptr, knob(al, K_LANE_LDS_PAD_KB, 0));
+                                 (knob(al, K_LANE_DEBUG, 0) && al->ws) ? al->ws : nullptr, knob(al, K_LANE_LDS_PAD_KB, 0), X, OE, E);
           if (knob(al, K_LANE_DEBUG, 0) && al->ws) {  // development aid (build with -DWFA_LANE_DEBUG_COUNTERS=1)
             unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             hipStreamSynchronize(stream); hipMemcpy(c, al->ws, sizeof(c), hipMemcpyDeviceToHost); hipMemset(al->ws, 0, sizeof(c));
@@ -1816,7 +1882,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       fa.heur = b->dcfg.heuristic; fa.min_wf_len = b->dcfg.min_wf_len; fa.max_dist_thr = b->dcfg.max_dist_thr;
       fa.steps_between = b->dcfg.steps_between; fa.max_steps = b->dcfg.max_steps;
       const int shape = wfa::seg_shape(b->dcfg, &lh_x, &lh_oe, &lh_e);
-      if (wfa::launch_lane_args(shape, lh_oe, lh_e, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, fa, false, 0, 256, true) != 0) {
+      if (wfa::launch_lane_args(shape, lh_oe, lh_e, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, fa, false, 0, 256, true, lh_x) != 0) {
         al->err = "lane kernel launch failed"; return WFA_HIP_EDEVICE;
       }
       if (first_stage) b->last_kernel_pairs = in_n;
@@ -2009,6 +2075,10 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
                             b->d_ovf_list[0], b->d_counters + 1);
     if (rc != WFA_HIP_OK) return rc;
   }
+  // score scope: translate in-stream (full scope: after the arena re-runs, wfa_hip_batch_sync)
+  if (b->dcfg.score_mode != 0 && !full)
+    hipLaunchKernelGGL(wfa_score_translate_kernel, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, stream, b->d_score, b->d_status, b->d_meta,
+                       (long long)b->n, b->dcfg.score_mode, b->dcfg.sw_match);
   HIP_TRY(al, hipEventRecord(al->ws_event, stream));
   al->ws_event_recorded = true; al->ws_last_stream = stream;
   return WFA_HIP_OK;
@@ -2085,6 +2155,11 @@ extern "C" int wfa_hip_batch_sync(wfa_hip_batch_t* b) {
     if (b->cfg.scope == WFA_SCOPE_FULL) {
       const int rc = retry_overflows(b);
       if (rc != WFA_HIP_OK) return rc;
+      if (b->dcfg.score_mode != 0) {   // (every run rewrites the raw scores: once per synchronisation)
+        hipLaunchKernelGGL(wfa_score_translate_kernel, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, b->last_stream, b->d_score, b->d_status,
+                           b->d_meta, (long long)b->n, b->dcfg.score_mode, b->dcfg.sw_match);
+        HIP_TRY(al, hipStreamSynchronize(b->last_stream));
+      }
     }
   }
   b->synced = true;
@@ -2243,6 +2318,13 @@ __global__ void __launch_bounds__(256) wfa_tiny_copy_kernel(uint4* __restrict__ 
 }
 
 // returns 1 when the call was served, 0 when it does not fit this path (the caller takes the batch path), < 0 on error
+// (score_mode: the kernels leave -s, as wfa_score_translate_kernel)
+static inline int32_t tiny_score(const WfaDevConfig& d, int32_t raw, int32_t status, int plen, int tlen) {
+  if (d.score_mode == 0 || status != 0) return raw;
+  if (d.score_mode == 2) return -raw;
+  return (int32_t)(((long long)d.sw_match * ((long long)plen + tlen) + raw) / 2);
+}
+
 static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const int64_t* p_off, const int32_t* p_len,
                       const int64_t* t_off, const int32_t* t_len, int32_t* score, int32_t* status, uint8_t* cigar_ops,
                       const int64_t* cigar_off, int64_t* cigar_begin, int32_t* cigar_len) {
@@ -2329,7 +2411,7 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
       ba.pbf = al->dcfg.pbf; ba.pef = al->dcfg.pef; ba.tbf = al->dcfg.tbf; ba.tef = al->dcfg.tef;
       if (full) {
         const int rec = ((al->ncomp != 5) ? 2 : 4) * 64 * nch;
-        const long long records = std::max<long long>(256, (long long)(max_len * 0.9) / ba.g + 64);
+        const long long records = std::max<long long>(256, (long long)(max_len * 0.9 * penalty_scale(al->dcfg)) / ba.g + 64);
         ba.hist_stride = ((int64_t)records * rec + 63) & ~63ll;
         const int erc = ensure_ws(al, (size_t)n * (size_t)ba.hist_stride * 4);
         if (erc != WFA_HIP_OK) return erc;
@@ -2368,7 +2450,7 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
       if (!handed_on) {
         const int64_t* hcb = reinterpret_cast<const int64_t*>(h + o_cb); const int32_t* hcl = reinterpret_cast<const int32_t*>(h + o_cl);
         for (int64_t i = 0; i < n; ++i) {
-          score[i] = hs[i]; status[i] = hst0[i];
+          score[i] = tiny_score(al->dcfg, hs[i], hst0[i], p_len[i], t_len[i]); status[i] = hst0[i];
           if (cigar_len) cigar_len[i] = full ? hcl[i] : 0;
           if (cigar_begin) cigar_begin[i] = 0;
           if (full && cigar_ops) {
@@ -2431,7 +2513,7 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
   for (int64_t i = 0; i < n; ++i) if (hst[i] == WFA_STATUS_OOM && full) return 0;   // arena too small for this pair: the batch path grows it
   const int64_t* hcb = reinterpret_cast<const int64_t*>(h + o_cb); const int32_t* hcl = reinterpret_cast<const int32_t*>(h + o_cl);
   for (int64_t i = 0; i < n; ++i) {
-    score[i] = hs[i]; status[i] = hst[i];
+    score[i] = tiny_score(al->dcfg, hs[i], hst[i], p_len[i], t_len[i]); status[i] = hst[i];
     if (cigar_len) cigar_len[i] = full ? hcl[i] : 0;
     if (cigar_begin) cigar_begin[i] = 0;
     if (full && cigar_ops) {

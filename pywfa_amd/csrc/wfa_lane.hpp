@@ -43,12 +43,13 @@
 // (First form of this round: records in LDS and the walk inside this kernel at every refill — 12 of 64 lanes busy in the walk,
 // 2.25 waves per SIMD: 0.80 ms per million pairs against 0.30 for the score alone; dropped.)
 #pragma once
-#include <hip/hip_runtime.h>
-#include <limits.h>
-#include <algorithm>
+#include "wfa_rtc_compat.hpp"
 #include "wfa_common.hpp"
 #include "wfa_hip.h"
 #include "wfa_fast.hpp"
+#ifndef __HIPCC_RTC__
+#include "wfa_rtc.hpp"
+#endif
 
 namespace wfa {
 
@@ -587,6 +588,7 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
   if (WFA_LANE_DEBUG_COUNTERS && !FULL && a.hist) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.hist), (unsigned long long)gstep); }
 }
 
+#ifndef __HIPCC_RTC__   // ---- host side (launch code) ----
 // per-shape entry points (csrc/k_lane.hip compiled once per shape index of WFA_SEG_SHAPES)
 #define WFA_LANE_DECL(i, x, oe, e) \
   int launch_lane_s##i(unsigned grid, size_t smem, hipStream_t stream, const FastArgs& a, int slot_words, int refill_min, bool full, bool heur);
@@ -638,21 +640,23 @@ inline void lane_full_geometry(uint32_t nwork, int cu_count, int per_cu, int min
 #define WFA_LANE_RUN_SLOT 32
 
 // full = the FULL form: a.hist = run-record slots (a.hist_stride ints each, slot = work item - a.work_begin), a.end_state per slot
-inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full, int lds_pad_kb = 0, int min_pairs = 0, bool heur = false);
+// (shape_idx WFA_SHAPE_RTC: no instantiation in the library — the kernel of (X, OE, E) is compiled at run time, csrc/wfa_rtc.cpp)
+inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full, int lds_pad_kb = 0, int min_pairs = 0, bool heur = false, int X = 0);
 
 inline int launch_lane(int shape_idx, int g, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, const uint32_t* words,
                        const WfaPairMeta* meta, const uint32_t* worklist, const uint32_t* nwork_dev, uint32_t nwork,
-                       int32_t* score, int32_t* status, uint32_t* fb_list, uint32_t* fb_count, int32_t* debug_counters = nullptr, int lds_pad_kb = 0) {
+                       int32_t* score, int32_t* status, uint32_t* fb_list, uint32_t* fb_count, int32_t* debug_counters = nullptr, int lds_pad_kb = 0,
+                       int X = 0, int OE = 0, int E = 0) {
   FastArgs a;
   a.words = words; a.meta = meta; a.worklist = worklist; a.nwork_dev = nwork_dev; a.nwork = nwork;
   a.score = score; a.status = status; a.fb_list = fb_list; a.fb_count = fb_count;
   a.g = g;
   a.hist = debug_counters; a.hist_stride = 0; a.end_state = nullptr; a.work_begin = 0;
   a.ef = a.pbf = a.pef = a.tbf = a.tef = 0; a.heur = 0; a.min_wf_len = a.max_dist_thr = a.steps_between = 0; a.max_steps = INT_MAX;
-  return launch_lane_args(shape_idx, 0, 0, cu_count, per_cu, refill_min, max_len, stream, a, false, lds_pad_kb);
+  return launch_lane_args(shape_idx, OE, E, cu_count, per_cu, refill_min, max_len, stream, a, false, lds_pad_kb, 0, false, X);
 }
 
-inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full, int lds_pad_kb, int min_pairs, bool heur) {
+inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full, int lds_pad_kb, int min_pairs, bool heur, int X) {
   const uint32_t nwork = a.nwork;
   const uint32_t* nwork_dev = a.nwork_dev;
   const int slot_words = lane_slot_words(std::min(max_len, WFA_FAST_MAX_LEN));
@@ -673,8 +677,16 @@ inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_
     case 4: return launch_lane_s4((unsigned)grid, smem, stream, a, slot_words, refill_min, full, heur);
     case 5: return launch_lane_s5((unsigned)grid, smem, stream, a, slot_words, refill_min, full, heur);
     case 6: return launch_lane_s6((unsigned)grid, smem, stream, a, slot_words, refill_min, full, heur);
+    case WFA_SHAPE_RTC: {
+      struct { FastArgs a; int slot_words; int refill_min; } args = {a, slot_words, refill_min};   // (the kernel's argument list)
+      const std::string name = "wfa::wfa_lane_kernel<" + std::to_string(X) + ", " + std::to_string(OE) + ", " + std::to_string(E) + ", " +
+                               rtc_bool(full && !heur) + ", " + rtc_bool(heur) + ">";
+      return rtc_launch("wfa_lane.hpp", name, (unsigned)grid, 64, smem, stream, &args, sizeof(args));
+    }
     default: return -1;
   }
 }
+
+#endif  // __HIPCC_RTC__
 
 }  // namespace wfa

@@ -1,0 +1,213 @@
+// wfa_rtc.cpp — kernels for penalty shapes the library has no instantiation of, compiled at run time with hipRTC.
+//
+// The register kernels (wfa_lane.hpp, wfa_seg.hpp, wfa_band.hpp) take the penalties (x, o + e, e [, o2 + e2, e2]) / gcd as template
+// parameters: their wavefront rings are registers, unrolled over the penalties.  The library instantiates pywfa's default and a
+// few presets; any other penalties the reference accepts (pywfa/align.pyx:313-318, R/wavefront_penalties.c:95-173) used to
+// fall to the general kernel, 39x slower on short reads.  Here the SAME kernel templates are instantiated
+// for the caller's penalties at run time: the kernel headers are embedded in the library as text (csrc/build.sh generates
+// rtc_sources.inc), hipRTC compiles the one kernel a launch site names (0.5 s; gfx950 code object), the code object is kept in
+// ~/.cache/pywfa_amd (keyed by the sources, the kernel name and the hipRTC version) and loaded as a module per device.
+// No CUDA-style shim: hiprtc + the HIP module API, gfx950 only.
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "wfa_rtc.hpp"
+
+namespace wfa {
+
+struct RtcSource { const char* name; const char* text; };
+#include "rtc_sources.inc"   // static const RtcSource rtc_sources[]; static const int rtc_source_count;
+
+namespace {
+
+std::mutex g_mu;
+std::map<std::string, hipFunction_t> g_functions;   // "device|name expression" -> function
+std::string g_error;
+
+uint64_t fnv1a(const void* p, size_t n, uint64_t h) {
+  const unsigned char* c = static_cast<const unsigned char*>(p);
+  for (size_t i = 0; i < n; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+std::string cache_dir() {
+  const char* e = getenv("WFA_HIP_RTC_CACHE");
+  std::string d;
+  if (e && *e) d = e;
+  else {
+    const char* home = getenv("HOME");
+    d = std::string((home && *home) ? home : "/tmp") + "/.cache/pywfa_amd";
+  }
+  return d;
+}
+
+void mkdirs(const std::string& d) {
+  std::string cur;
+  for (size_t i = 0; i < d.size(); ++i) {
+    cur += d[i];
+    if (d[i] == '/' && cur.size() > 1) mkdir(cur.c_str(), 0755);
+  }
+  mkdir(d.c_str(), 0755);
+}
+
+bool read_file(const std::string& path, std::vector<char>* out) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  const long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  if (n <= 0) { fclose(f); return false; }
+  out->resize((size_t)n);
+  const bool ok = fread(out->data(), 1, (size_t)n, f) == (size_t)n;
+  fclose(f);
+  return ok;
+}
+
+void write_file_atomic(const std::string& path, const std::vector<char>& data) {
+  const std::string tmp = path + "." + std::to_string((long)getpid()) + ".tmp";
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) return;
+  const bool ok = fwrite(data.data(), 1, data.size(), f) == data.size();
+  fclose(f);
+  if (ok) rename(tmp.c_str(), path.c_str()); else unlink(tmp.c_str());
+}
+
+// the code object of `name_expr` (a kernel of `header`) and its lowered (mangled) name; from the cache or compiled now
+bool code_object(const char* header, const std::string& name_expr, std::vector<char>* code, std::string* lowered) {
+  uint64_t h = 14695981039346656037ull;
+  for (int i = 0; i < rtc_source_count; ++i) h = fnv1a(rtc_sources[i].text, strlen(rtc_sources[i].text), h);
+  h = fnv1a(header, strlen(header), h);
+  h = fnv1a(name_expr.data(), name_expr.size(), h);
+  int maj = 0, min = 0;
+  hiprtcVersion(&maj, &min);
+  h = fnv1a(&maj, sizeof(maj), h); h = fnv1a(&min, sizeof(min), h);
+  char key[32];
+  snprintf(key, sizeof(key), "%016llx", (unsigned long long)h);
+  const std::string dir = cache_dir(), path = dir + "/rtc_" + key + ".co";
+  const bool use_cache = !(getenv("WFA_HIP_RTC_NO_CACHE") && *getenv("WFA_HIP_RTC_NO_CACHE") == '1');
+  std::vector<char> blob;
+  if (use_cache && read_file(path, &blob) && blob.size() > 8) {
+    // file = u32 length of the lowered name, the name, the code object
+    uint32_t ln = 0;
+    memcpy(&ln, blob.data(), 4);
+    if (ln > 0 && ln < 4096 && blob.size() > 4 + (size_t)ln) {
+      lowered->assign(blob.data() + 4, ln);
+      code->assign(blob.begin() + 4 + ln, blob.end());
+      return true;
+    }
+  }
+  std::vector<const char*> texts, names;
+  for (int i = 0; i < rtc_source_count; ++i) { texts.push_back(rtc_sources[i].text); names.push_back(rtc_sources[i].name); }
+  const std::string main_src = std::string("#include \"") + header + "\"\n";
+  hiprtcProgram prog;
+  if (hiprtcCreateProgram(&prog, main_src.c_str(), "wfa_rtc_main.hip", rtc_source_count, texts.data(), names.data()) != HIPRTC_SUCCESS) {
+    g_error = "hiprtcCreateProgram failed";
+    return false;
+  }
+  hiprtcAddNameExpression(prog, name_expr.c_str());
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+  const hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
+  if (r != HIPRTC_SUCCESS) {
+    size_t ls = 0;
+    hiprtcGetProgramLogSize(prog, &ls);
+    std::string log(ls, 0);
+    if (ls) hiprtcGetProgramLog(prog, &log[0]);
+    g_error = "hipRTC could not compile " + name_expr + ": " + log.substr(0, 1500);
+    hiprtcDestroyProgram(&prog);
+    return false;
+  }
+  const char* low = nullptr;
+  size_t cs = 0;
+  if (hiprtcGetLoweredName(prog, name_expr.c_str(), &low) != HIPRTC_SUCCESS || !low || hiprtcGetCodeSize(prog, &cs) != HIPRTC_SUCCESS || cs == 0) {
+    g_error = "hipRTC produced no code for " + name_expr;
+    hiprtcDestroyProgram(&prog);
+    return false;
+  }
+  *lowered = low;
+  code->resize(cs);
+  hiprtcGetCode(prog, code->data());
+  hiprtcDestroyProgram(&prog);
+  if (use_cache) {
+    mkdirs(dir);
+    std::vector<char> out(4 + lowered->size() + code->size());
+    const uint32_t ln = (uint32_t)lowered->size();
+    memcpy(out.data(), &ln, 4);
+    memcpy(out.data() + 4, lowered->data(), ln);
+    memcpy(out.data() + 4 + ln, code->data(), code->size());
+    write_file_atomic(path, out);
+  }
+  return true;
+}
+
+}  // namespace
+
+const char* rtc_last_error() { return g_error.c_str(); }
+
+bool rtc_force_all() {
+  static const bool on = getenv("WFA_HIP_RTC_ALL") && *getenv("WFA_HIP_RTC_ALL") == '1';
+  return on;
+}
+
+hipFunction_t rtc_kernel(const char* header, const std::string& name_expr) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { g_error = "hipGetDevice failed"; return nullptr; }
+  const std::string key = std::to_string(dev) + "|" + name_expr;
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_functions.find(key);
+  if (it != g_functions.end()) return it->second;
+  std::vector<char> code;
+  std::string lowered;
+  if (!code_object(header, name_expr, &code, &lowered)) { g_functions[key] = nullptr; return nullptr; }
+  hipModule_t mod;
+  hipFunction_t fn = nullptr;
+  if (hipModuleLoadData(&mod, code.data()) != hipSuccess || hipModuleGetFunction(&fn, mod, lowered.c_str()) != hipSuccess) {
+    (void)hipGetLastError();
+    g_error = "could not load the hipRTC code object of " + name_expr;
+    fn = nullptr;
+  }
+  g_functions[key] = fn;   // (a failure is remembered too: the launch sites fall back once, not on every call)
+  return fn;
+}
+
+int rtc_launch(const char* header, const std::string& name_expr, unsigned grid, unsigned block, size_t smem, hipStream_t stream,
+               const void* args, size_t args_bytes) {
+  hipFunction_t fn = rtc_kernel(header, name_expr);
+  if (!fn) return -1;
+  size_t size = args_bytes;
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void*>(args), HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  if (hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, (unsigned)smem, stream, nullptr, config) != hipSuccess) {
+    (void)hipGetLastError();
+    g_error = "launch of " + name_expr + " failed";
+    return -1;
+  }
+  return 0;
+}
+
+// can hipRTC compile at all here (libhiprtc / comgr present and working)?  Checked once per process on a trivial kernel.
+bool rtc_available() {
+  static int state = -1;
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (state >= 0) return state == 1;
+  if (getenv("WFA_HIP_NO_RTC") && *getenv("WFA_HIP_NO_RTC") == '1') { state = 0; return false; }
+  hiprtcProgram prog;
+  state = 0;
+  if (hiprtcCreateProgram(&prog, "extern \"C\" __global__ void wfa_rtc_probe(int* p) { if (p) *p = 1; }\n", "probe.hip", 0, nullptr, nullptr) == HIPRTC_SUCCESS) {
+    const char* opts[] = {"--offload-arch=gfx950"};
+    if (hiprtcCompileProgram(prog, 1, opts) == HIPRTC_SUCCESS) state = 1;
+    hiprtcDestroyProgram(&prog);
+  }
+  if (state == 0) g_error = "hipRTC is not usable on this system";
+  return state == 1;
+}
+
+}  // namespace wfa

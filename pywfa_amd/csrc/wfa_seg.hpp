@@ -30,11 +30,13 @@
 // trailing zeros), rounds repeated while any lane of the wave is still running.  (A variant in which a whole
 // segment compares 16 W bases for its one long-running diagonal measured no faster and was dropped.)
 #pragma once
-#include <hip/hip_runtime.h>
-#include <limits.h>
-#include <algorithm>
+#include "wfa_rtc_compat.hpp"
 #include "wfa_common.hpp"
 #include "wfa_fast.hpp"
+#ifndef __HIPCC_RTC__
+#include <string>
+#include "wfa_rtc.hpp"
+#endif
 
 namespace wfa {
 
@@ -429,6 +431,7 @@ wfa_seg_kernel(const FastArgs a) {
   fb_flush();
 }
 
+#ifndef __HIPCC_RTC__   // ---- host side (shape table, launch code) ----
 // Penalty shapes (index, x, o + e, e) / gcd with an instantiation of the segmented kernel.  The first is pywfa's default
 // 4/6/2 (also 2/3/1, 8/12/4, ...); the others are the usual short-read / long-read presets: 4/4/2, 4/6/1, 3/4/1,
 // 6/5/3, 5/0/3 and unit costs 1/1/1.  Each shape is compiled in its own translation unit (csrc/k_seg.hip, once per
@@ -442,14 +445,23 @@ wfa_seg_kernel(const FastArgs a) {
 WFA_SEG_SHAPES(WFA_SEG_DECL)
 #undef WFA_SEG_DECL
 
-// index of the instantiated shape of these penalties, -1 if none
+// index of the instantiated shape of these penalties; WFA_SHAPE_RTC for a shape the run-time path takes (c.rtc: hipRTC works here,
+// csrc/wfa_rtc.cpp); -1 if none
 inline int seg_shape(const WfaDevConfig& c, int* X, int* OE, int* E) {
   const int g = gcd_int(gcd_int(c.x, c.o1 + c.e1), c.e1);
   *X = c.x / g; *OE = (c.o1 + c.e1) / g; *E = c.e1 / g;
-#define WFA_SEG_MATCH(i, x, oe, e) if (*X == x && *OE == oe && *E == e) return i;
+#define WFA_SEG_MATCH(i, x, oe, e) if (*X == x && *OE == oe && *E == e && !(c.rtc && rtc_force_all())) return i;
   WFA_SEG_SHAPES(WFA_SEG_MATCH)
 #undef WFA_SEG_MATCH
+  if (c.rtc && rtc_shape_ok(*X, *OE, *E)) return WFA_SHAPE_RTC;
   return -1;
+}
+// the segmented kernel of a run-time shape: wfa_seg_kernel<X, OE, E, W, LAZY, FULL, HEUR>
+inline int launch_seg_rtc(int X, int OE, int E, int w, bool lazy, bool full, bool heur, unsigned grid, hipStream_t stream, const FastArgs& a) {
+  if (lazy && X < 2) lazy = false;   // (the two-round extension needs x / g >= 2)
+  const std::string name = "wfa::wfa_seg_kernel<" + std::to_string(X) + ", " + std::to_string(OE) + ", " + std::to_string(E) + ", " + std::to_string(w) + ", " +
+                           rtc_bool(lazy) + ", " + rtc_bool(full) + ", " + rtc_bool(heur) + ">";
+  return rtc_launch("wfa_seg.hpp", name, grid, 64, 0, stream, &a, sizeof(a));
 }
 
 // which configurations the segmented kernels cover (score only, gap-affine, end-to-end or ends-free without free ends)
@@ -511,6 +523,7 @@ inline int launch_seg_full(const WfaDevConfig& c, int cu_count, int per_cu, hipS
 #define WFA_SEG_LAUNCH_FULL(i, x, oe, e) if (idx == i) return launch_seg_full_s##i(w, (unsigned)grid, stream, a);
   WFA_SEG_SHAPES(WFA_SEG_LAUNCH_FULL)
 #undef WFA_SEG_LAUNCH_FULL
+  if (idx == WFA_SHAPE_RTC) return launch_seg_rtc(X, OE, E, (w == 32 || w == 64) ? w : 16, false, true, false, (unsigned)grid, stream, a);
   return -1;
 }
 
@@ -534,6 +547,7 @@ inline int launch_seg_heur(const WfaDevConfig& c, int cu_count, int per_cu, hipS
 #define WFA_SEG_LAUNCH_HEUR(i, x, oe, e) if (idx == i) return launch_seg_heur_s##i((unsigned)grid, stream, a);
   WFA_SEG_SHAPES(WFA_SEG_LAUNCH_HEUR)
 #undef WFA_SEG_LAUNCH_HEUR
+  if (idx == WFA_SHAPE_RTC) return launch_seg_rtc(X, OE, E, 32, false, false, true, (unsigned)grid, stream, a);
   return -1;
 }
 
@@ -565,7 +579,10 @@ inline int launch_seg(const WfaDevConfig& c, int cu_count, int per_cu, hipStream
 #define WFA_SEG_LAUNCH(i, x, oe, e) if (idx == i) return launch_seg_s##i(w, lazy, (unsigned)grid, stream, a);
   WFA_SEG_SHAPES(WFA_SEG_LAUNCH)
 #undef WFA_SEG_LAUNCH
+  if (idx == WFA_SHAPE_RTC) return launch_seg_rtc(X, OE, E, w, lazy, false, false, (unsigned)grid, stream, a);
   return -1;
 }
+
+#endif  // __HIPCC_RTC__
 
 }  // namespace wfa
