@@ -707,20 +707,33 @@ def main():
                 dict(name="C4-adaptive", n=100_000, length=10000, error=0.08, seed=datagen.SEEDS["C4"], cfg_kw=dict(C4, heuristic="adaptive"),
                      scheme="piggyback", survey_bytes=114e3 * 5 / 3, trim=50, cpu_pairs=100),
                 dict(name="C4-exact", n=4096, length=10000, error=0.08, seed=datagen.SEEDS["C4"], cfg_kw=C4, scheme="piggyback", survey_bytes=54e6,
-                     trim=50, cpu_pairs=8, cpu_budget=3.0, mt_parity_pairs=64),
+                     trim=50, cpu_pairs=8, cpu_budget=3.0, mt_parity_pairs=128),
                 dict(name="exact-10kb-score", n=8192, length=10000, error=0.08, seed=datagen.SEEDS["C3"], cfg_kw=dict(span="end-to-end", scope="score"),
                      scheme="none", survey_bytes=2 * 2500 + 8, cpu_pairs=40, cpu_budget=3.0, mt_parity_pairs=256),
                 dict(name="exact-10kb-full", n=8192, length=10000, error=0.08, seed=datagen.SEEDS["C3"], cfg_kw=dict(span="end-to-end", scope="full"),
                      scheme="piggyback", survey_bytes=5.1e6 + 2 * 2500 + 10_800, cpu_pairs=20, cpu_budget=3.0, mt_parity_pairs=128),
                 dict(name="C5-adaptive", n=8192, length=100000, error=0.08, seed=datagen.SEEDS["C5"],
                      cfg_kw=dict(span="end-to-end", scope="full", heuristic="adaptive"), scheme="piggyback", survey_bytes=1.14e6, cpu_pairs=4,
-                     cpu_budget=2.0, mt_parity_pairs=32, steps=2),
+                     cpu_budget=2.0, mt_parity_pairs=128, steps=2),
                 # wf-adaptive on short reads: the general form of the lane kernel goes first where its pilot finds that
                 # few pairs outgrow its 16 slots (0.5 % divergence), the banded kernel takes the batch otherwise (2 %)
                 dict(name="150bp-adaptive-2pct", n=2_000_000, length=150, error=0.02, seed=datagen.SEEDS["C2"],
                      cfg_kw=dict(span="end-to-end", scope="score", heuristic="adaptive"), scheme="none", survey_bytes=84, cpu_pairs=200000, cpu_budget=2.0),
                 dict(name="150bp-adaptive-0.5pct", n=2_000_000, length=150, error=0.005, seed=datagen.SEEDS["C2"],
                      cfg_kw=dict(span="end-to-end", scope="score", heuristic="adaptive"), scheme="none", survey_bytes=84, cpu_pairs=200000, cpu_budget=2.0),
+                # penalties the library has no instantiation of (round 4: the register kernels are compiled for them at run time, csrc/wfa_rtc.cpp;
+                # mismatch=5 is the reference's own test's, pywfa/tests/test.py:229), and configurations mapped to gap-affine with a translated
+                # score (match < 0: Eizenga-rescaled 10/12/5; levenshtein / gap-linear in score scope)
+                dict(name="C2-mismatch5", n=2_000_000, length=150, error=0.02, seed=datagen.SEEDS["C2"],
+                     cfg_kw=dict(span="end-to-end", scope="score", mismatch=5), scheme="none", survey_bytes=84, cpu_pairs=200000, cpu_budget=2.0),
+                dict(name="C2-match-1", n=2_000_000, length=150, error=0.02, seed=datagen.SEEDS["C2"],
+                     cfg_kw=dict(span="end-to-end", scope="score", match=-1), scheme="none", survey_bytes=84, cpu_pairs=200000, cpu_budget=2.0),
+                dict(name="150bp-levenshtein", n=2_000_000, length=150, error=0.02, seed=datagen.SEEDS["C2"],
+                     cfg_kw=dict(distance="levenshtein", span="end-to-end", scope="score"), scheme="none", survey_bytes=84, cpu_pairs=200000, cpu_budget=2.0),
+                dict(name="150bp-linear", n=2_000_000, length=150, error=0.02, seed=datagen.SEEDS["C2"],
+                     cfg_kw=dict(distance="linear", span="end-to-end", scope="score"), scheme="none", survey_bytes=84, cpu_pairs=200000, cpu_budget=2.0),
+                dict(name="C4-adaptive-mismatch5", n=20_000, length=10000, error=0.08, seed=datagen.SEEDS["C4"], cfg_kw=dict(C4, heuristic="adaptive", mismatch=5),
+                     scheme="piggyback", survey_bytes=114e3 * 5 / 3, trim=50, cpu_pairs=60),
                 dict(name="C3-explicit-history", n=100_000, length=10000, error=0.08, seed=datagen.SEEDS["C3"],
                      cfg_kw=dict(span="end-to-end", scope="full", heuristic="adaptive"), scheme="explicit", survey_bytes=750e3, env={"WFA_HIP_BAND_PB": "0"}),
                 dict(name="C4-adaptive-explicit-history", n=20_000, length=10000, error=0.08, seed=datagen.SEEDS["C4"], cfg_kw=dict(C4, heuristic="adaptive"),

@@ -262,8 +262,11 @@ wfa_hip_batch_t* wfa_hip_batch_create_packed2bits(wfa_hip_aligner_t* aligner, in
                                                   const int64_t* t_off, const int32_t* t_len);
 void wfa_hip_batch_destroy(wfa_hip_batch_t* batch);
 /* Enqueue the alignment kernels for the whole batch on `stream` (hipStream_t passed as
- * void*, NULL = the library's own stream) and return without waiting: the call only enqueues (kernels, memsets, event
- * waits); it never synchronises with the device. */
+ * void*, NULL = the library's own stream) and return without waiting: in the steady state the call only enqueues (kernels,
+ * memsets, event waits).  Exceptions, all one-off: the FIRST run of an aligner and any run that has to grow its workspace
+ * allocate device memory (hipFree / hipMalloc synchronise the device, and may drain the aligner's block pool), and the first
+ * run under penalties the library has no built-in kernels for compiles them (hipRTC, about a second per kernel; cached on
+ * disk under ~/.cache/pywfa_amd or $WFA_HIP_RTC_CACHE). */
 int wfa_hip_batch_run(wfa_hip_batch_t* batch, void* stream);
 /* Wait for the last run of this batch. */
 int wfa_hip_batch_sync(wfa_hip_batch_t* batch);

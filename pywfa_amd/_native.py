@@ -279,7 +279,7 @@ class Aligner:
                    _ptr(t_len), _ptr(score), _ptr(status), _ptr(ops),
                    _ptr(cigar_off), _ptr(cbeg), _ptr(clen))
         if rc != OK:
-            self._raise(rc, "wfa_hip_align_batch")
+            self._raise(rc, "wfa_hip_align_batch_packed2bits" if "packed" in batch else "wfa_hip_align_batch")
         return score, status, ((ops, cbeg, clen) if want_cigar else None)
 
     def batch(self, batch):
@@ -350,6 +350,8 @@ class MultiAligner:
             self._raise(rc, "wfa_hip_multi_set_config")
 
     def align_batch(self, batch, want_cigar):
+        if "packed" in batch:   # (the multi-device entry takes ASCII; 2-bit bytes would be read as letters outside ACGT)
+            raise NotImplementedError("wfa_hip_multi_align_batch takes ASCII reads: 2-bit batches go through Aligner.align_batch per device")
         seqs, p_off, p_len, t_off, t_len, n = _check_batch(batch)
         score = np.zeros(n, np.int32)
         status = np.zeros(n, np.int32)

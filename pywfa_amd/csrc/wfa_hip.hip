@@ -89,7 +89,7 @@ struct wfa_hip_aligner {
   // the walks of a split stage's launch run on this stream, under the alignment kernel of the next launch (which writes
   // the other half of the workspace); created on first use
   hipStream_t side_stream = nullptr;
-  hipEvent_t band_event[2] = {nullptr, nullptr}, walk_event[2] = {nullptr, nullptr};
+  hipEvent_t band_event[4] = {nullptr, nullptr, nullptr, nullptr}, walk_event[4] = {nullptr, nullptr, nullptr, nullptr};   // [0..1] the band stages' walks, [2..3] the lane-full stage's expands
   // second upload stream of the host-packed upload (every other slot's DMAs: two copy engines)
   hipStream_t up_stream = nullptr;
   hipEvent_t up_fork = nullptr, up_join = nullptr;
@@ -454,7 +454,7 @@ static void aligner_free(wfa_hip_aligner* al) {
   if (al->up_fork) (void)hipEventDestroy(al->up_fork);
   if (al->up_join) (void)hipEventDestroy(al->up_join);
   if (al->side_stream) (void)hipStreamDestroy(al->side_stream);
-  for (int i = 0; i < 2; ++i) { if (al->band_event[i]) (void)hipEventDestroy(al->band_event[i]); if (al->walk_event[i]) (void)hipEventDestroy(al->walk_event[i]); }
+  for (int i = 0; i < 4; ++i) { if (al->band_event[i]) (void)hipEventDestroy(al->band_event[i]); if (al->walk_event[i]) (void)hipEventDestroy(al->walk_event[i]); }
   if (al->stream) (void)hipStreamDestroy(al->stream);
   delete al;
 }
@@ -951,7 +951,8 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
       HIP_TRY(al, hipGetLastError());
       b->n_bytes = 0; b->n_packed = (uint32_t)n;
       if (n <= 256) b->uploads_pending = true;
-      else if (!pipelined) {   // (the caller's arrays are still being read by the plain copies)
+      else {   // (plain copies: the caller's arrays are still being read; either way nothing reads the 2-bit blob after the repack kernel —
+               // it used to stay in HBM for the batch's lifetime on the pipelined path)
         HIP_TRY(al, hipStreamSynchronize(al->stream));
         pool_release(al, b->d_bytes); b->d_bytes = nullptr;
       }
@@ -1181,13 +1182,14 @@ extern "C" int wfa_hip_align_batch_packed2bits(wfa_hip_aligner_t* al, int64_t n,
 // alignment kernel of the next launch, which goes to the other half.  (Alternating whole launches between two streams
 // measured worse: two alignment kernels at once, C4 -35 %.)
 struct DualStream {
-  wfa_hip_aligner* al; hipStream_t main; bool on = false; bool used[2] = {false, false};
+  wfa_hip_aligner* al; hipStream_t main; int eb = 0;   // eb: this user's pair of events (the band stages' walks and the lane-full stage's expands no longer share them)
+  bool on = false; bool used[2] = {false, false};
   int begin(bool want) {
     on = false; used[0] = used[1] = false;
     if (!want || knob(al, K_NO_DUAL, 0) != 0) return WFA_HIP_OK;
     if (!al->side_stream) {
       HIP_TRY(al, hipStreamCreateWithFlags(&al->side_stream, hipStreamNonBlocking));
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < 4; ++i) {
         HIP_TRY(al, hipEventCreateWithFlags(&al->band_event[i], hipEventDisableTiming));
         HIP_TRY(al, hipEventCreateWithFlags(&al->walk_event[i], hipEventDisableTiming));
       }
@@ -1197,28 +1199,28 @@ struct DualStream {
   }
   // before the alignment kernel of `launch` is enqueued on main: its half must be free (the walks of launch - 2 are over)
   int before_align(int64_t launch) {
-    if (on && used[launch & 1]) HIP_TRY(al, hipStreamWaitEvent(main, al->walk_event[launch & 1], 0));
+    if (on && used[launch & 1]) HIP_TRY(al, hipStreamWaitEvent(main, al->walk_event[eb + (launch & 1)], 0));
     return WFA_HIP_OK;
   }
   // the stream for the walks of `launch` (call after its alignment kernel was enqueued on main)
   int walk_stream(int64_t launch, hipStream_t* out) {
     *out = main;
     if (!on) return WFA_HIP_OK;
-    HIP_TRY(al, hipEventRecord(al->band_event[launch & 1], main));
-    HIP_TRY(al, hipStreamWaitEvent(al->side_stream, al->band_event[launch & 1], 0));
+    HIP_TRY(al, hipEventRecord(al->band_event[eb + (launch & 1)], main));
+    HIP_TRY(al, hipStreamWaitEvent(al->side_stream, al->band_event[eb + (launch & 1)], 0));
     *out = al->side_stream;
     return WFA_HIP_OK;
   }
   int after_walk(int64_t launch) {
     if (!on) return WFA_HIP_OK;
-    HIP_TRY(al, hipEventRecord(al->walk_event[launch & 1], al->side_stream));
+    HIP_TRY(al, hipEventRecord(al->walk_event[eb + (launch & 1)], al->side_stream));
     used[launch & 1] = true;
     return WFA_HIP_OK;
   }
   // join: `main` continues after every walk
   int end() {
     if (!on) return WFA_HIP_OK;
-    for (int i = 0; i < 2; ++i) if (used[i]) HIP_TRY(al, hipStreamWaitEvent(main, al->walk_event[i], 0));
+    for (int i = 0; i < 2; ++i) if (used[i]) HIP_TRY(al, hipStreamWaitEvent(main, al->walk_event[eb + i], 0));
     on = false;
     return WFA_HIP_OK;
   }
@@ -1334,11 +1336,17 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
   if (al->ws_event_recorded && al->ws_last_stream != stream) HIP_TRY(al, hipStreamWaitEvent(stream, al->ws_event, 0));
   // the batch's uploads were enqueued on the aligner's stream (and may still be in flight): a run elsewhere waits for them
   if (stream != al->stream && b->upload_event) HIP_TRY(al, hipStreamWaitEvent(stream, b->upload_event, 0));
+  // an early return (an error) must not leave walks / expands running on the side stream: they write blocks the caller may
+  // destroy next
+  struct SideGuard {
+    wfa_hip_aligner* al; bool ok = false;
+    ~SideGuard() { if (!ok && al->side_stream) (void)hipStreamSynchronize(al->side_stream); }
+  } side_guard{al};
   b->last_stream = stream;
   b->ran = true; b->synced = false;
   b->last_fallback = 0;
   b->last_kernel_pairs = 0;
-  if (b->n == 0) { b->synced = true; return WFA_HIP_OK; }
+  if (b->n == 0) { b->synced = true; side_guard.ok = true; return WFA_HIP_OK; }
   const bool full = (b->cfg.scope == WFA_SCOPE_FULL);
   HIP_TRY(al, hipMemsetAsync(b->d_counters, 0, 16 * sizeof(uint32_t), stream));
   b->arena_ints = full ? initial_arena_ints(al, b) : 0;
@@ -1397,6 +1405,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     HIP_TRY(al, hipEventRecord(ev1, stream));
     HIP_TRY(al, hipEventRecord(al->ws_event, stream));
     al->ws_event_recorded = true; al->ws_last_stream = stream;
+    side_guard.ok = true;
     return WFA_HIP_OK;
   }
   if (b->n_packed > 0) {
@@ -1714,7 +1723,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     int rc = ensure_ws(al, need);
     if (rc != WFA_HIP_OK) return rc;
 
-    DualStream lane_expands{al, stream};   // the expand of the lane-full stage, left running under the stages behind it
+    DualStream lane_expands{al, stream, 2};   // the expand of the lane-full stage, left running under the stages behind it
     if (use_lanefull) {
       uint32_t* out_list = b->d_fb_list2[out_sel];
       uint32_t* out_count = b->d_counters + 4 + out_sel;
@@ -2081,6 +2090,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
                        (long long)b->n, b->dcfg.score_mode, b->dcfg.sw_match);
   HIP_TRY(al, hipEventRecord(al->ws_event, stream));
   al->ws_event_recorded = true; al->ws_last_stream = stream;
+  side_guard.ok = true;
   return WFA_HIP_OK;
 }
 
@@ -2413,8 +2423,11 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
         const int rec = ((al->ncomp != 5) ? 2 : 4) * 64 * nch;
         const long long records = std::max<long long>(256, (long long)(max_len * 0.9 * penalty_scale(al->dcfg)) / ba.g + 64);
         ba.hist_stride = ((int64_t)records * rec + 63) & ~63ll;
-        const int erc = ensure_ws(al, (size_t)n * (size_t)ba.hist_stride * 4);
-        if (erc != WFA_HIP_OK) return erc;
+        // (one history slice per pair — 256 KB for 150 bp gap-affine — stays allocated for the aligner's lifetime: calls
+        // whose slices exceed 256 MB or the free memory take the batch path, and so does a call whose workspace cannot be had)
+        const size_t hist_bytes = (size_t)n * (size_t)ba.hist_stride * 4;
+        if (hist_bytes > ((size_t)256 << 20) || (int64_t)hist_bytes > free_budget(al)) return 0;
+        if (ensure_ws(al, hist_bytes) != WFA_HIP_OK) return 0;
         ba.hist = al->ws;
       }
       hipStream_t stream = al->stream;

@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(64)
 wfa_seg_kernel(const FastArgs a) {
   static_assert(!(LAZY && FULL), "the history of a step is stored in the step itself");
   static_assert(!HEUR || (!LAZY && !FULL && W <= 32), "the general form: score only, every cell extended in its own step");
-  static_assert(!LAZY || X >= 2, "the lazy extension needs a wavefront to be consumed two steps after it is made");
+  static_assert(!LAZY || (X >= 2 && OE >= 2), "the lazy extension needs a wavefront to be consumed two steps after it is made (M is read at lags X and OE)");
   static_assert(W == 8 || W == 16 || W == 32 || W == 64, "segment width");
   constexpr int DM = (X > OE) ? X : OE;
   constexpr int NS = 64 / W, H = W / 2, LW = (W == 64) ? 6 : (W == 32) ? 5 : (W == 16) ? 4 : 3;
@@ -458,7 +458,7 @@ inline int seg_shape(const WfaDevConfig& c, int* X, int* OE, int* E) {
 }
 // the segmented kernel of a run-time shape: wfa_seg_kernel<X, OE, E, W, LAZY, FULL, HEUR>
 inline int launch_seg_rtc(int X, int OE, int E, int w, bool lazy, bool full, bool heur, unsigned grid, hipStream_t stream, const FastArgs& a) {
-  if (lazy && X < 2) lazy = false;   // (the two-round extension needs x / g >= 2)
+  if (lazy && (X < 2 || OE < 2)) lazy = false;   // (the two-round extension: M must not be read one step after it is made)
   const std::string name = "wfa::wfa_seg_kernel<" + std::to_string(X) + ", " + std::to_string(OE) + ", " + std::to_string(E) + ", " + std::to_string(w) + ", " +
                            rtc_bool(lazy) + ", " + rtc_bool(full) + ", " + rtc_bool(heur) + ">";
   return rtc_launch("wfa_seg.hpp", name, grid, 64, 0, stream, &a, sizeof(a));
@@ -476,7 +476,7 @@ inline bool seg_supported(const WfaDevConfig& c, int ncomp, bool full) {
 template <int X, int OE, int E>
 inline int launch_seg_shape(int w, bool lazy, unsigned grid, hipStream_t stream, const FastArgs& a) {
   const dim3 blk(64), g(grid);
-  if constexpr (X >= 2) {
+  if constexpr (X >= 2 && OE >= 2) {
     if (lazy) {
       if (w == 8) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 8, true, false>), g, blk, 0, stream, a);
       else if (w == 32) hipLaunchKernelGGL((wfa_seg_kernel<X, OE, E, 32, true, false>), g, blk, 0, stream, a);

@@ -12,7 +12,8 @@ import common
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
-PEN = [(4, 6, 2), (4, 6, 2), (4, 6, 2), (4, 4, 2), (4, 6, 1), (3, 4, 1), (6, 5, 3), (5, 0, 3), (1, 1, 1), (2, 3, 1), (7, 3, 2)]
+PEN = [(4, 6, 2), (4, 6, 2), (4, 6, 2), (4, 4, 2), (4, 6, 1), (3, 4, 1), (6, 5, 3), (5, 0, 3), (1, 1, 1), (2, 3, 1), (7, 3, 2),
+       (5, 6, 2), (3, 5, 1), (2, 8, 1), (7, 11, 3), (9, 2, 4)]   # (round 4: shapes without an instantiation: compiled at run time)
 bad_total = 0
 for it in range(rounds):
     x, o, e = PEN[int(rng.integers(len(PEN)))]
@@ -27,6 +28,13 @@ for it in range(rounds):
     if rng.random() < 0.2: kw["distance"] = "affine2p"
     if rng.random() < 0.3: kw["memory_mode"] = str(rng.choice(["medium", "low"]))
     if rng.random() < 0.1: kw["max_steps"] = int(rng.choice([6, 20, 60, 400]))
+    if rng.random() < 0.12:   # round 4: match < 0 (mapped to the rescaled gap-affine form where nothing else reads the original; free begins + CIGAR are refused)
+        kw["match"] = int(rng.choice([-1, -2, -3]))
+        if kw["scope"] == "full":
+            for k_ in ("pattern_begin_free", "pattern_end_free", "text_begin_free", "text_end_free"): kw.pop(k_, None)
+    if rng.random() < 0.1:    # round 4: one-component distances (score scope runs on the gap-affine kernels)
+        kw["distance"] = str(rng.choice(["indel", "levenshtein", "linear"]))
+        for k_ in ("heuristic", "xdrop", "match"): kw.pop(k_, None)
     if rng.random() < 0.12:   # BiWFA: without heuristic or free ends (a step limit is honoured, round 3)
         for k_ in ("heuristic", "xdrop", "pattern_begin_free", "pattern_end_free", "text_begin_free", "text_end_free"): kw.pop(k_, None)
         kw["memory_mode"] = "biwfa"
