@@ -702,7 +702,15 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
   // per-pair metadata on several host threads: pass 1 validates and sums each slice of the batch, pass 2 writes the word
   // offsets from the slice prefix.  Large batches (pipelined upload): the slices are the pieces of the upload ring and pass 2
   // writes each piece straight into its pinned slot — no host copy of the metadata exists
-  const bool pipelined = n >= 262144 && knob(al, K_NO_PIPE, 0) == 0;
+  // (round 4: also few pairs of long reads — C5's 100 kb reads are 200 KB of ASCII per pair: a plain copy from pageable memory moved
+  // them at 3.6 GB/s, the pinned ring with host-side packing at the link's rate)
+  bool many_bases = false;
+  if (n < 262144 && n >= 64) {
+    int64_t bases = 0;
+    for (int64_t i = 0; i < n; ++i) bases += (int64_t)std::max(p_len[i], 0) + std::max(t_len[i], 0);
+    many_bases = bases >= ((int64_t)32 << 20);
+  }
+  const bool pipelined = (n >= 262144 || many_bases) && knob(al, K_NO_PIPE, 0) == 0;
   const int64_t piece_pairs = (int64_t)(staged_slot_bytes(al) / sizeof(WfaPairMeta));
   // (pipelined: a piece of the metadata upload = `sub` parts of pass 1, so that a large team shares pass 1 evenly)
   const int sub = pipelined ? 8 : 1;

@@ -426,3 +426,36 @@ def test_packed2bits_refuses_a_wildcard(gpu):
     with pytest.raises(NotImplementedError):
         al.align_batch(datagen.to_packed2bits(datagen.from_strings(["ACGT"], ["ACGA"])), True)
     al.close()
+
+
+def test_few_long_reads_take_the_pinned_host_packed_upload(gpu, monkeypatch):
+    """Round 4: batches of few pairs but many bases (C5: 200 KB of ASCII per pair) take the pinned, host-packed upload ring too
+    (it used to start at 256 k pairs; a plain copy from pageable memory moved C5's reads at 3.6 GB/s).  600 x 30 kb reads, some with
+    a letter outside ACGT, wf-adaptive: the same results with the ring (default), without it (WFA_HIP_NO_PIPE=1) and with the
+    ASCII ring + device pack (WFA_HIP_HOST_PACK=0); a sample against the oracle; and through the multi-device entry."""
+    base = datagen.generate(600, 30000, 0.05, 4343)
+    pats, txts = [], []
+    for i in range(600):
+        p, t = datagen.pair_strings(base, i)
+        if i % 97 == 5: t = t[:1000] + "N" + t[1001:]
+        if i % 211 == 7: p = p[:12345]
+        pats.append(p); txts.append(t)
+    batch = datagen.from_strings(pats, txts, upper=False)
+    assert int(batch["p_len"].sum() + batch["t_len"].sum()) >= (32 << 20)
+    oc, nc = common.configs_pair(span="end-to-end", scope="score", heuristic="adaptive")
+    res = {}
+    for name, env in (("ring", {}), ("plain", {"WFA_HIP_NO_PIPE": "1"}), ("ascii-ring", {"WFA_HIP_HOST_PACK": "0"})):
+        for k_, v_ in env.items(): monkeypatch.setenv(k_, v_)
+        al = _native.Aligner(nc)
+        res[name] = al.align_batch(batch, False)
+        al.close()
+        for k_ in env: monkeypatch.delenv(k_)
+    for name in ("plain", "ascii-ring"):
+        assert np.array_equal(res["ring"][0], res[name][0]) and np.array_equal(res["ring"][1], res[name][1]), name
+    sel = np.r_[0:12, 95:110, 205:215]
+    o = loader.run(loader.oracle(), oc, datagen.subset(batch, sel), want_cigar=False)
+    assert np.array_equal(res["ring"][0][sel], o["score"]) and np.array_equal(res["ring"][1][sel], o["status"])
+    ma = _native.MultiAligner(nc, [0])
+    s, st, _ = ma.align_batch(batch, False)
+    ma.close()
+    assert np.array_equal(s, res["ring"][0]) and np.array_equal(st, res["ring"][1])
