@@ -161,6 +161,18 @@ int wfa_hip_align_batch(wfa_hip_aligner_t* aligner, int64_t n,
                         int64_t* cigar_begin, int32_t* cigar_len);
 
 /*
+ * One pair per call — pywfa's own usage pattern: wavefront_align(text) against the cached pattern (align.pyx:421-443, one
+ * wavefront_align / wavefront_align_lambda per call, wfa.h:199-210).  The result of wfa_hip_align_batch with n = 1 without its
+ * arrays: `pattern` / `text` are the two ASCII sequences; `cigar_ops` (NULL for scope = score) receives plen + tlen bytes of which
+ * [*cigar_begin, *cigar_begin + *cigar_len) are the alignment's ops.  Served by the single-launch path (host packs the pair into a
+ * pinned block, one wave aligns it, the host polls a completion flag): about 14 us per 150 bp call from C, 19 us with the op
+ * string (tools/probes/latency_c.c on MI355X) against 1-2 us for the reference on a host core — the library is batch-oriented,
+ * and a loop of single calls, while exact, is what wfa_hip_align_batch with many pairs replaces.
+ */
+int wfa_hip_align_pair(wfa_hip_aligner_t* aligner, const uint8_t* pattern, int32_t plen, const uint8_t* text, int32_t tlen,
+                       int32_t* score, int32_t* status, uint8_t* cigar_ops, int64_t* cigar_begin, int32_t* cigar_len);
+
+/*
  * The same call for a caller that already holds 2-bit reads (cf. wavefront_align_packed2bits, wfa.h:211-216,
  * wavefront_sequences.h:115): `packed` holds every sequence in the reference's packed form (wavefront_sequences.c:102-139:
  * four bases per byte, base j of a byte in bits 2j .. 2j+1, 'A' 0 / 'C' 1 / 'G' 2 / 'T' 3), a sequence of len bases being

