@@ -816,6 +816,7 @@ typedef struct {
   int status;       /* BI_OK while running, BI_END_REACHED, BI_END_UNREACHABLE */
   int status_score; /* align_status.score */
   int end_k; int32_t end_off;
+  heur_t hs;        /* the forward / reverse aligners inherit the heuristic (R/wavefront_bialigner.c:53,161-166); the base aligner does not */
 } bi_uni_t;
 
 /* R/wavefront_aligner.c:251-417 with a begin component (:329-390): wavefront 0 is the cell (k=0, offset 0) of that component */
@@ -826,6 +827,7 @@ static int bi_uni_init(bi_uni_t* u, const bi_view_t* view, int comp_begin, int c
   u->tlen = view->tend - view->tbeg;
   u->comp_begin = comp_begin; u->comp_end = comp_end;
   u->null_steps = 0; u->status = BI_OK; u->status_score = 0; u->end_k = 0; u->end_off = OFFSET_NULL;
+  u->hs.steps_wait = 0; u->hs.have_max_sw = 0; u->hs.max_sw = 0;   /* (set by the breakpoint search: R/wavefront_heuristic.c:114-121 at every init) */
   ws->modular = modular;
   ws->arena_used = 0;
   ws->ef_seed = 0;   /* (BiWFA has no free ends: R/wavefront_align.c:60-75) */
@@ -856,9 +858,10 @@ static int bi_terminated(bi_uni_t* u, int s) {
   return 1;
 }
 
-/* R/wavefront_extend.c:90-125 / :178-214 (wavefront_extend_end2end[_max]): extend M[s], test the end, no heuristic here.
+/* R/wavefront_extend.c:90-125 / :178-214 (wavefront_extend_end2end[_max]): extend M[s], test the end, then the heuristic cut-off
+ * of the forward / reverse aligners (hcfg != NULL: R/wavefront_extend.c:117-123,206-212 -> R/wavefront_heuristic.c:509-567).
  * Returns 1 when the aligner is done (status set).  *max_ak (nullable) = largest antidiagonal 2*offset - k reached. */
-static int bi_extend(bi_uni_t* u, int s, int* max_ak) {
+static int bi_extend(bi_uni_t* u, int s, int* max_ak, const wfa_hip_config_t* hcfg) {
   oracle_ws_t* ws = &u->ws;
   wf_t* m = wf_slot(ws, 0, s);
   if (max_ak) *max_ak = 0;
@@ -878,6 +881,9 @@ static int bi_extend(bi_uni_t* u, int s, int* max_ak) {
     if (best < ad) best = ad;
   }
   if (bi_terminated(u, s)) { u->status = BI_END_REACHED; u->status_score = s; return 1; }
+  if (hcfg && hcfg->heuristic != WFA_HEUR_NONE) {
+    if (heur_cutoff(ws, hcfg, &u->hs, s, u->plen, u->tlen)) { u->status = BI_END_UNREACHABLE; u->status_score = s; return 1; }   /* (allocation failure only) */
+  }
   if (max_ak) *max_ak = best;
   return 0;
 }
@@ -968,6 +974,7 @@ typedef struct {
   const uint8_t* P; const uint8_t* T;
   int wc;
   int64_t max_steps;
+  const wfa_hip_config_t* cfg; /* heuristic of the forward / reverse aligners */
   uint8_t* ops; /* appended forwards (R/alignment/cigar.c:125-136) */
   int64_t ops_len;
 } bi_ctx_t;
@@ -986,21 +993,22 @@ static int bi_find_breakpoint(bi_ctx_t* cx, int pbeg, int pend, int tbeg, int te
   const int max_antidiagonal = plen + tlen - 1;
   int score_f = 0, score_r = 0, f_max_ak = 0, r_max_ak = 0, max_ak = 0;
   bp->score = INT_MAX;
-  if (bi_extend(f, 0, &f_max_ak)) return f->status;
-  if (bi_extend(r, 0, &r_max_ak)) return r->status;
+  f->hs.steps_wait = r->hs.steps_wait = cx->cfg->steps_between_cutoffs;   /* R/wavefront_heuristic.c:114-121 (wavefront_heuristic_clear at every unialign init) */
+  if (bi_extend(f, 0, &f_max_ak, cx->cfg)) return f->status;
+  if (bi_extend(r, 0, &r_max_ak, cx->cfg)) return r->status;
   int last_forward = 0;
   for (;;) {
     if (f_max_ak + r_max_ak >= max_antidiagonal) break;
     ++score_f;
     if (bi_compute(f, score_f)) return WFA_STATUS_OOM;
-    const int qf = bi_extend(f, score_f, &max_ak);
+    const int qf = bi_extend(f, score_f, &max_ak, cx->cfg);
     if (f_max_ak < max_ak) f_max_ak = max_ak;
     last_forward = 1;
     if (qf) return f->status;
     if (f_max_ak + r_max_ak >= max_antidiagonal) break;
     ++score_r;
     if (bi_compute(r, score_r)) return WFA_STATUS_OOM;
-    const int qr = bi_extend(r, score_r, &max_ak);
+    const int qr = bi_extend(r, score_r, &max_ak, cx->cfg);
     if (r_max_ak < max_ak) r_max_ak = max_ak;
     last_forward = 0;
     if (qr) return r->status;
@@ -1015,14 +1023,14 @@ static int bi_find_breakpoint(bi_ctx_t* cx, int pbeg, int pend, int tbeg, int te
       bi_overlap(f, r, score_f, score_r, 1, bp);
       ++score_r;
       if (bi_compute(r, score_r)) return WFA_STATUS_OOM;
-      if (bi_extend(r, score_r, NULL)) return r->status;
+      if (bi_extend(r, score_r, NULL, cx->cfg)) return r->status;
     }
     const int min_score_forward = (score_f > scope - 1) ? score_f - (scope - 1) : 0;
     if (min_score_forward + score_r - gap_opening >= bp->score) break;
     bi_overlap(r, f, score_r, score_f, 0, bp);
     ++score_f;
     if (bi_compute(f, score_f)) return WFA_STATUS_OOM;
-    if (bi_extend(f, score_f, NULL)) return f->status;
+    if (bi_extend(f, score_f, NULL, cx->cfg)) return f->status;
     if ((int64_t)score_r + score_f >= cx->max_steps) return WFA_STATUS_MAX_STEPS_REACHED;
     last_forward = 1;
   }
@@ -1058,7 +1066,7 @@ static int bi_base(bi_ctx_t* cx, int pbeg, int pend, int tbeg, int tend, int com
         }
       }
     } else {
-      finished = bi_extend(u, s, NULL);
+      finished = bi_extend(u, s, NULL, NULL);   /* the base aligner has no heuristic (R/wavefront_bialigner.c:66-68) */
     }
     if (finished) break;
     ++s;
@@ -1228,16 +1236,18 @@ int wfa_oracle_align_batch(const wfa_hip_config_t* cfg, int64_t n, const uint8_t
   if (cfg->memory_mode == WFA_MEM_BIWFA) {
     const int free_ends = cfg->span == WFA_SPAN_ENDSFREE &&
         (cfg->pattern_begin_free | cfg->pattern_end_free | cfg->text_begin_free | cfg->text_end_free) != 0;
-    if (cfg->heuristic != WFA_HEUR_NONE || free_ends) return -1;
+    if (free_ends) return -1;
     /* scope=score with a step limit: the limit counts the forward + reverse scores (R/wavefront_bialign.c:475,513), which is
-     * not what the ordinary algorithm counts: the top-level breakpoint search is run as it is (:662-702) */
-    if (cfg->scope == WFA_SCOPE_FULL || cfg->max_steps > 0) {
+     * not what the ordinary algorithm counts: the top-level breakpoint search is run as it is (:662-702).  With a heuristic
+     * likewise: both directions cut their wavefronts off (round 4) */
+    if (cfg->scope == WFA_SCOPE_FULL || cfg->max_steps > 0 || cfg->heuristic != WFA_HEUR_NONE) {
       biwfa_full = (cfg->scope == WFA_SCOPE_FULL);
       biwfa_score = !biwfa_full;
       bcx = (bi_ctx_t*)calloc(1, sizeof(bi_ctx_t));
       if (!bcx) return -2;
       if (ws_set_penalties(&bcx->fwd.ws, cfg) || ws_set_penalties(&bcx->rev.ws, cfg) || ws_set_penalties(&bcx->base.ws, cfg)) { free(bcx); return -1; }
       bcx->wc = cfg->wildcard;
+      bcx->cfg = cfg;
       bcx->max_steps = (cfg->max_steps <= 0) ? INT_MAX : cfg->max_steps;   /* align.pyx:415-417 -> R/wavefront_bialigner.c:168-174 */
     }
   }

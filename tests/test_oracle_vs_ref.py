@@ -102,10 +102,34 @@ def test_biwfa_step_limit_equals_reference(kw0):
                 common.assert_same(r, o["score"], o["status"], o["cigars"], batch, f"biwfa max_steps={ms} {scope} {kw0}")
 
 
+BIWFA_HEUR = [dict(heuristic="adaptive"), dict(heuristic="adaptive", min_wavefront_length=5, max_distance_threshold=15, steps_between_cutoffs=3),
+              dict(heuristic="X-drop", xdrop=400), dict(heuristic="X-drop", xdrop=100, match=-1), dict(heuristic="X-drop", xdrop=20),
+              dict(heuristic="adaptive", distance="affine2p"), dict(heuristic="adaptive", distance="levenshtein"),
+              dict(heuristic="adaptive", distance="linear", mismatch=3, gap_extension=5), dict(heuristic="adaptive", max_steps=400)]
+
+
+@pytest.mark.parametrize("cfg_idx", range(len(BIWFA_HEUR)))
+@pytest.mark.parametrize("scope", ["full", "score"])
+def test_biwfa_with_a_heuristic_equals_reference(cfg_idx, scope):
+    """Round 4: memory_mode="biwfa" with a heuristic.  The forward and the reverse aligner of every breakpoint search inherit it
+    (R/wavefront_bialigner.c:53,161-166) and cut their wavefronts off after every extension (R/wavefront_extend.c:117-123,206-212),
+    each with its own state, re-set at every search (R/wavefront_heuristic.c:114-121); the base cases run without
+    (R/wavefront_bialigner.c:66-68).  The oracle's restatement against the real library in its ultralow mode: status, score, op string."""
+    import validate_oracle as vo
+    kw = dict(BIWFA_HEUR[cfg_idx], scope=scope, memory_mode="biwfa", span="end-to-end")
+    corpora = [datagen.generate(n, L, e, 3900 + 7 * cfg_idx + i)
+               for i, (n, L, e) in enumerate([(300, 150, 0.02), (150, 150, 0.2), (150, 60, 0.1), (30, 1500, 0.08), (10, 4000, 0.15), (4, 10000, 0.08)])]
+    corpora.append(vo.corpus_special(seed=15 + cfg_idx))
+    for batch in corpora:
+        cfg = loader.make_config(**kw)
+        r = loader.run(loader.reference(), cfg, batch)
+        o = loader.run(loader.oracle(), cfg, batch)
+        common.assert_same(r, o["score"], o["status"], o["cigars"], batch, f"biwfa + heuristic {kw}")
+
+
 def test_biwfa_outside_the_built_subset_is_refused():
     batch = datagen.generate(4, 50, 0.05, 1)
-    for kw in (dict(scope="full", heuristic="adaptive"), dict(scope="score", heuristic="adaptive"),
-               dict(scope="score", span="ends-free", text_end_free=5), dict(scope="full", span="ends-free", pattern_begin_free=3)):
+    for kw in (dict(scope="score", span="ends-free", text_end_free=5), dict(scope="full", span="ends-free", pattern_begin_free=3)):
         with pytest.raises(Exception):
             loader.run(loader.oracle(), loader.make_config(**dict(kw, memory_mode="biwfa")), batch, want_cigar=False)
 
