@@ -285,6 +285,21 @@ def biwfa_vectors():
                         continue
                     out["runs"].append({"corpus": name, "config": kw2, "score": [int(x) for x in r["score"]], "status": [int(x) for x in r["status"]],
                                         "cigar": [rle(c) for c in r["cigars"]] if r["cigars"] is not None else None})
+    # round 4: a heuristic, inherited by the forward / reverse aligner of every breakpoint search (wavefront_bialigner.c:53,161-166), both scopes
+    heur = [dict(heuristic="adaptive"), dict(heuristic="adaptive", min_wavefront_length=5, max_distance_threshold=15, steps_between_cutoffs=3),
+            dict(heuristic="X-drop", xdrop=400), dict(heuristic="X-drop", xdrop=100, match=-1), dict(heuristic="adaptive", distance="affine2p"),
+            dict(heuristic="adaptive", distance="levenshtein")]
+    for name in ("special", "L150_e0.2", "L1500_e0.1", "L5000_e0.12"):
+        pairs = out["corpora"][name]
+        b = datagen.from_strings([p for p, _ in pairs], [t for _, t in pairs])
+        for kw in heur:
+            for scope in ("full", "score"):
+                kw2 = dict(kw, scope=scope, memory_mode="biwfa", span="end-to-end")
+                r = vo.run_reference(kw2, b)
+                if r is None:
+                    continue
+                out["runs"].append({"corpus": name, "config": kw2, "score": [int(x) for x in r["score"]], "status": [int(x) for x in r["status"]],
+                                    "cigar": [rle(c) for c in r["cigars"]] if r["cigars"] is not None else None})
     rng = np.random.default_rng(77)
     unrelated = [["".join(rng.choice(list("ACGT"), size=int(rng.integers(60, 101)))), "".join(rng.choice(list("ACGT"), size=int(rng.integers(60, 101))))]
                  for _ in range(24)]
