@@ -12,7 +12,13 @@ WORLD_SIZE spawns it itself); every rank aligns its own P pairs (weak scaling, p
 collective on the data path); barrier + device sync on both sides of the timed region, MAX over ranks, rank 0
 prints ONE JSON line.
 
-Besides the contract keys the line carries (rank 0, N = 1):
+The LAST stdout line is one compact strict-JSON record (about 5 KB; tests/test_bench_line.py): the contract keys, `config` (workload + one
+scalar triple per extra configuration), `roofline`, `cpu_baseline`, `end_to_end` as scalars.  The fat record described below goes to
+bench_detail.json (and gpurun_out/bench_detail.json); a failed configuration, a parity mismatch or an invalid transcript ends the run non-zero.
+N > 1: every rank also times a C3 leg (10 kb, wf-adaptive, full CIGAR; `config.c3_alignments_per_s`).  --multi: only the C5 leg through ONE
+process's wfa_hip_multi_align_batch over every visible device.
+
+Besides the contract keys the detail record carries (rank 0, N = 1):
   roofline      HBM roofline of the C2 step (HIP events on the launch stream), + "secondary": the on-chip bound
                 from the committed counter passes (profiles/), + "traffic" with its provenance
   end_to_end    the PCIe-inclusive rate of the same batch: host ASCII in -> host results out (wfa_hip_align_batch)
