@@ -79,4 +79,15 @@ if "X100kf" in which: run("100kb exact full", 64, 100000, 0.08, 1005, dict(span=
 if "X30k" in which: run("30kb exact score", 512, 30000, 0.08, 1005, dict(span="end-to-end", scope="score"), cpu_n=2, reps=1)
 if "X30kf" in which: run("30kb exact full", 512, 30000, 0.08, 1005, dict(span="end-to-end", scope="full"), cpu_n=2, reps=1)
 if "EF150" in which: run("150bp ends-free(8,7,3,2) score", 2000000, 150, 0.02, 1002, dict(span="ends-free", pattern_begin_free=8, pattern_end_free=7, text_begin_free=3, text_end_free=2, scope="score"), cpu_n=100000)
+# round 4: penalties without an instantiation (run-time compiled kernels), configurations mapped to gap-affine + score translation
+if "M5" in which: run("150bp mismatch=5 score", 2000000, 150, 0.02, 1002, dict(span="end-to-end", scope="score", mismatch=5), cpu_n=100000)
+if "M5f" in which: run("150bp mismatch=5 full", 1000000, 150, 0.02, 1002, dict(scope="full", mismatch=5), cpu_n=50000)
+if "LEV" in which: run("150bp levenshtein score", 2000000, 150, 0.02, 1002, dict(distance="levenshtein", span="end-to-end", scope="score"), cpu_n=100000)
+if "LIN" in which: run("150bp gap-linear score", 2000000, 150, 0.02, 1002, dict(distance="linear", span="end-to-end", scope="score"), cpu_n=100000)
+if "MN1" in which: run("150bp match=-1 score", 2000000, 150, 0.02, 1002, dict(span="end-to-end", scope="score", match=-1), cpu_n=100000)
+if "MN1f" in which: run("150bp match=-1 full", 1000000, 150, 0.02, 1002, dict(scope="full", match=-1), cpu_n=50000)
+if "C4am5" in which: run("C4 adaptive mismatch=5 full", 20000, 10000, 0.08, 1004, dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="full", heuristic="adaptive", mismatch=5), cpu_n=50)
+if "C3m5" in which: run("10kb adaptive mismatch=5 full", 50000, 10000, 0.08, 1003, dict(span="end-to-end", scope="full", heuristic="adaptive", mismatch=5), cpu_n=100)
+if "C3xm5" in which: run("10kb exact mismatch=5 score (tile kernel)", 4096, 10000, 0.08, 1003, dict(span="end-to-end", scope="score", mismatch=5), cpu_n=16, reps=1)
+if "BH10k" in which: run("10kb BiWFA wf-adaptive full", 2000, 10000, 0.08, 1003, dict(span="end-to-end", scope="full", memory_mode="biwfa", heuristic="adaptive"), cpu_n=40)
 if "C5a" in which: run("100kb adaptive full", 500, 100000, 0.08, 1005, dict(span="end-to-end", scope="full", heuristic="adaptive"), cpu_n=10)
