@@ -481,6 +481,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
     ap.add_argument("--c3-pairs", type=int, default=100_000, help="N > 1: 10 kb pairs per GPU of the C3 leg")
+    ap.add_argument("--c3-leg", action="store_true", help="run the C3 leg of the N > 1 runs at N = 1 too (it has no CPU reference: transcripts are validated)")
     ap.add_argument("--multi", action="store_true",
                     help="only the C5 leg: one process, wfa_hip_multi_align_batch over every visible device")
     ap.add_argument("--multi-pairs", type=int, default=1024, help="100 kb pairs per device of the C5 leg")
@@ -578,7 +579,7 @@ def main():
         al0.close()
 
     c3 = None
-    if n_gpus > 1 and not args.no_extra_configs:
+    if args.c3_leg or (n_gpus > 1 and not args.no_extra_configs):
         c3 = c3_leg(rank, world, local_rank, args.c3_pairs, 3, dist, backend)
 
     if rank == 0:
@@ -781,8 +782,8 @@ def main():
         if c3 is not None:
             out["extra"]["c3_leg"] = c3
             out["config"]["c3_pairs_per_gpu"] = c3["pairs_per_gpu"]
-            out["config"]["c3_alignments_per_s"] = c3["alignments_per_s"]
-            out["config"]["c3_hbm_frac"] = c3["hbm_frac"]
+            out["config"]["c3_leg_alignments_per_s" if n_gpus == 1 else "c3_alignments_per_s"] = c3["alignments_per_s"]
+            out["config"]["c3_leg_hbm_frac" if n_gpus == 1 else "c3_hbm_frac"] = c3["hbm_frac"]
             out["config"]["c3_invalid_transcripts"] = c3["invalid_transcripts"]
             if c3["invalid_transcripts"] or c3["completed"] != c3["pairs_per_gpu"] * n_gpus:
                 errors.append(f"C3 leg: {c3['invalid_transcripts']} invalid transcripts, {c3['completed']} completed")

@@ -236,11 +236,7 @@ wfa_tile_kernel(const TileArgs a) {
             const uint32_t* const src = rows32 + ((uint32_t)__builtin_amdgcn_readlane(my_ld_hbm, i) + vcol);
 #pragma unroll
             for (int c0 = 0; c0 < 32 * NCH; c0 += 64)
-#ifndef WFA_TILE_EXPERIMENT_NO_LOAD
               if (c0 + lane < 32 * NCH) __builtin_amdgcn_global_load_lds(src + c0, dst + c0, 4, 0, 0);
-#else
-              if (c0 + lane < 32 * NCH) dst[c0 + lane] = 0xC000C000u + (src == nullptr);
-#endif
           }
           for (unsigned long long m = null_mask; m; m &= m - 1) {   // rows before score 0 (the first super-steps only)
             uint32_t* const dst = tile32 + __builtin_amdgcn_readlane(my_ld_lds, (int)__builtin_ctzll(m));
@@ -429,12 +425,8 @@ wfa_tile_kernel(const TileArgs a) {
               for (int c0 = 0; c0 < 32 * NCH; c0 += 64) {
                 if (c0 + lane < Bw / 2) {
                   const uint32_t v0 = s0[c0 + lane], v1 = s1[c0 + lane];
-#ifndef WFA_TILE_EXPERIMENT_NO_WB
                   d0[c0] = v0;
                   if (two_rows) d1[c0] = v1;
-#else
-                  if (v0 == 0x12345678u && v1 == 0x9abcdef0u) d0[c0] = v0;
-#endif
                 }
               }
             }
