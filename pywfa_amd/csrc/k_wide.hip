@@ -12,13 +12,14 @@ static int launch_wide_t(const WideArgs& a, int grid, int threads, size_t smem, 
   hipLaunchKernelGGL((wfa_wide_kernel<FULL, TWO, GROWS, W32>), dim3(grid), dim3(threads), smem, stream, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-int launch_wide(bool full, bool two, const WideArgs& a, int grid, int threads, size_t smem, hipStream_t stream, bool w32) {
-  if (w32) {   // int32 rows in the workspace: reads beyond 16 kb
-    if (two) return full ? launch_wide_t<true, true, true, true>(a, grid, threads, smem, stream) : launch_wide_t<false, true, true, true>(a, grid, threads, smem, stream);
-    return full ? launch_wide_t<true, false, true, true>(a, grid, threads, smem, stream) : launch_wide_t<false, false, true, true>(a, grid, threads, smem, stream);
-  }
-  if (!two && a.rows) return full ? launch_wide_t<true, false, true>(a, grid, threads, smem, stream) : launch_wide_t<false, false, true>(a, grid, threads, smem, stream);
-  if (two) return full ? launch_wide_t<true, true, true>(a, grid, threads, smem, stream) : launch_wide_t<false, true, true>(a, grid, threads, smem, stream);
-  return full ? launch_wide_t<true, false, false>(a, grid, threads, smem, stream) : launch_wide_t<false, false, false>(a, grid, threads, smem, stream);
+template <bool FULL, bool TWO>
+static int launch_wide_ft(bool grows, bool w32, const WideArgs& a, int grid, int threads, size_t smem, hipStream_t stream) {
+  if (grows) return w32 ? launch_wide_t<FULL, TWO, true, true>(a, grid, threads, smem, stream) : launch_wide_t<FULL, TWO, true, false>(a, grid, threads, smem, stream);
+  return w32 ? launch_wide_t<FULL, TWO, false, true>(a, grid, threads, smem, stream) : launch_wide_t<FULL, TWO, false, false>(a, grid, threads, smem, stream);
+}
+// grows: the rows live in the workgroup's slice of the workspace (a.rows), otherwise in LDS; w32: int32 offsets (reads beyond 16 kb)
+int launch_wide(bool full, bool two, bool grows, const WideArgs& a, int grid, int threads, size_t smem, hipStream_t stream, bool w32) {
+  if (two) return full ? launch_wide_ft<true, true>(grows, w32, a, grid, threads, smem, stream) : launch_wide_ft<false, true>(grows, w32, a, grid, threads, smem, stream);
+  return full ? launch_wide_ft<true, false>(grows, w32, a, grid, threads, smem, stream) : launch_wide_ft<false, false>(grows, w32, a, grid, threads, smem, stream);
 }
 }  // namespace wfa

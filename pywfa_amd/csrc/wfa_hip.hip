@@ -44,7 +44,7 @@ static thread_local std::string g_error;
   F(ARENA_KB) F(BAND_DEBUG) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
-  F(LANE_FULL) F(LANE_FULL_SPLIT) F(LANE_HEUR) F(SEG_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_ADAPT) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(TILE) F(TILE_T) F(TILE_WT) F(TILE_THREADS) F(TILE_PER_CU) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY)
+  F(LANE_FULL) F(LANE_FULL_SPLIT) F(LANE_HEUR) F(SEG_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_ADAPT) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(TILE) F(TILE_T) F(TILE_WT) F(TILE_THREADS) F(TILE_PER_CU) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY) F(PILOT_PCT) F(WIDE_ADAPT_LDS)
 enum WfaKnob {
 #define WFA_KNOB_ENUM(n) K_##n,
   WFA_KNOBS(WFA_KNOB_ENUM)
@@ -1082,7 +1082,12 @@ static int pilot_first_width(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t 
     uint32_t handed = 0;
     HIP_TRY(al, hipMemcpyAsync(&handed, pcount, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY(al, hipStreamSynchronize(stream));
-    if (handed * 5u <= np * 2u) { b->stage_pick = w; break; }  // at most 40 % handed on
+    // (16 diagonals as the first stage pay while they hand on < ~8 % of the pairs score-only (5 %: 1.37 G against 1.21 G aln/s from 32
+    // diagonals; 11 %: 0.87 against 1.10), < ~15 % with the CIGAR (11 %: 0.49 against 0.41; 19 %: 0.30 against 0.37): measured per
+    // divergence, tools/probes/pilot_probe.py, profiles/r04_pilot_probe.txt.  At the 40 % of round 3 the 4 % batches ran 1.8x slower.)
+    const uint32_t pct = (w == 16) ? (uint32_t)knob(al, K_PILOT_PCT, full ? 15 : 8) : 40u;
+    if (knob(al, K_STAGE_TIMING, 0)) fprintf(stderr, "[wfa_hip] pilot: %d diagonals hand on %u of %u\n", w, handed, np);
+    if (handed * 100u <= np * pct) { b->stage_pick = w; break; }
   }
   HIP_TRY(al, hipMemsetAsync(pcount, 0, sizeof(uint32_t), stream));
   return WFA_HIP_OK;
@@ -1551,7 +1556,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     // most), then rows in the workgroup's slice of the HBM workspace (as wide as the whole diagonal range of the longest pair: no
     // pair outgrows them; gap-affine-2p has only this form: its M ring alone is o2 + e2 + 1 rows).
     struct WideStage { wfa::WideArgs a; int grid = 0, threads = 0; size_t smem = 0, hist_off = 0; bool grows = false, w32 = false; };
-    WideStage wide_stage[2];
+    WideStage wide_stage[3];
     int n_wide = 0;
     struct TileStage { wfa::TileArgs a; int grid = 0, threads = 0; size_t smem = 0, hist_off = 0; bool on = false; } tile_stage;
     const bool wide_two = (b->ncomp == 5);
@@ -1647,6 +1652,36 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
             need = std::max(need, (size_t)st.grid * (size_t)st.a.hist_stride * 4);
           }
           ++n_wide;
+        }
+      }
+      // Round 4: what the banded stages hand on under wf-adaptive (47 of 8 192 pairs of 100 kb: a wavefront beyond their 256 diagonals)
+      // is a few hundred diagonals wide and a handful of pairs — one alignment's latency is all that counts.  Rows in LDS (int32 beyond
+      // 16 kb), as many diagonals as fit beside the sequences, one workgroup per CU: a step costs LDS round trips instead of L2 ones
+      // (100 kb: 5.2 us per step there).  A wavefront that leaves the rows goes on to the workspace form below.
+      if (wide_adapt && knob(al, K_WIDE_ADAPT_LDS, 1) != 0) {
+        WideStage& st = wide_stage[n_wide];
+        st.a = w0; st.grows = false; st.w32 = wide32;
+        const int ob = wide32 ? 4 : 2;
+        const size_t lds_max = (size_t)std::min(160, std::max(16, knob(al, K_WIDE_LDS_KB, 160))) * 1024;
+        const size_t fixed = wfa::wide_smem_bytes(w0.X, w0.OE, w0.E, w0.OE2, w0.E2, 0, w0.seq_words, true, ob);
+        if (fixed + (size_t)nrows * ob * 516 <= lds_max) {
+          int wcap = (int)((lds_max - fixed) / ((size_t)nrows * ob)) - 4;
+          wcap = std::min(std::min(wcap, 4096), full_range) & ~1;
+          if (knob(al, K_WIDE_ADAPT_LDS, 1) > 1) wcap = std::min(wcap, knob(al, K_WIDE_ADAPT_LDS, 1) & ~1);   // (tests: rows so narrow that pairs go on to the workspace form)
+          st.a.wcap = wcap;
+          st.smem = wfa::wide_smem_bytes(w0.X, w0.OE, w0.E, w0.OE2, w0.E2, wcap, w0.seq_words, true, ob);
+          st.threads = knob(al, K_WIDE_THREADS, 512);
+          st.grid = (int)std::min<int64_t>((int64_t)al->cu_count, in_n);
+          bool fits = true;
+          if (full) {
+            int64_t hist_bytes = std::min<int64_t>((int64_t)full_range * ((int64_t)(b->max_len * 0.9 * penalty_scale(b->dcfg)) / w0.g + 64) / 2 + (1 << 20),
+                                                   ((int64_t)(b->max_len * 1.2) / w0.g + 64) * 2048 + (1 << 20));
+            while (st.grid > 1 && (int64_t)st.grid * hist_bytes > budget) st.grid = (st.grid + 1) / 2;
+            fits = (int64_t)st.grid * hist_bytes <= budget;
+            st.a.hist_stride = (hist_bytes / 4) & ~15ll;
+            if (fits) need = std::max(need, (size_t)st.grid * (size_t)st.a.hist_stride * 4);
+          }
+          if (fits) ++n_wide;
         }
       }
       if (!lds_covers_all) {
@@ -1928,6 +1963,8 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
     }
     DualStream pending_walks{al, stream};   // walks of a split stage left running under the band stages behind it
+    std::chrono::steady_clock::time_point band_prev;
+    if (knob(al, K_STAGE_TIMING, 0) != 0) { (void)hipStreamSynchronize(stream); band_prev = std::chrono::steady_clock::now(); }
     for (int i = 0; i < n_stages; ++i) {
       wfa::BandArgs ba;
       memset(&ba, 0, sizeof(ba));
@@ -2008,6 +2045,15 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       } else {
         if (wfa::launch_band(ba, band_nch[i], full, adapt, seqlds, band_grid[i], stream) != 0) { al->err = "band kernel launch failed"; return WFA_HIP_EDEVICE; }
       }
+      if (knob(al, K_STAGE_TIMING, 0) != 0) {  // development aid: synchronises (the time of the stage is the gap between these lines' events)
+        (void)hipStreamSynchronize(stream);
+        uint32_t handed = 0, took = in_n; (void)hipMemcpy(&handed, out_count, sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (in_count) (void)hipMemcpy(&took, in_count, sizeof(uint32_t), hipMemcpyDeviceToHost);
+        const auto t_now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[wfa_hip] band stage %d (%d diagonals): took %u pairs, handed on %u; %.3f ms\n", i, 64 * band_nch[i], took, handed,
+                std::chrono::duration<double, std::milli>(t_now - band_prev).count());
+        band_prev = std::chrono::steady_clock::now();
+      }
       if (first_stage) b->last_kernel_pairs = in_n;
       in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
     }
@@ -2063,7 +2109,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       hipEvent_t se0 = nullptr, se1 = nullptr;
       const bool stage_timing = knob(al, K_STAGE_TIMING, 0) != 0;
       if (stage_timing) { (void)hipEventCreate(&se0); (void)hipEventCreate(&se1); (void)hipEventRecord(se0, stream); }
-      if (wfa::launch_wide(full, wide_two, wa, st.grid, st.threads, st.smem, stream, st.w32) != 0) { al->err = "wide kernel launch failed"; return WFA_HIP_EDEVICE; }
+      if (wfa::launch_wide(full, wide_two, st.grows, wa, st.grid, st.threads, st.smem, stream, st.w32) != 0) { al->err = "wide kernel launch failed"; return WFA_HIP_EDEVICE; }
       if (stage_timing) {  // development aid: synchronises
         (void)hipEventRecord(se1, stream); (void)hipEventSynchronize(se1);
         float ms = 0.f; (void)hipEventElapsedTime(&ms, se0, se1);

@@ -64,9 +64,20 @@ struct WideArgs {
 };
 
 #define WFA_WIDE_NULL (-16384)
-#define WFA_WIDE_CTRL_INTS 32
+#define WFA_WIDE_CTRL_INTS 64
 
 __device__ __forceinline__ uint32_t wide_ffbl(uint32_t x) { uint32_t r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+// minimum over the wave without LDS traffic (the step of a lone alignment is a dependent chain: six ds_bpermute hops per reduction
+// were a fifth of it): butterfly inside each row of 16 lanes with DPP, then the four row leaders
+__device__ __forceinline__ int wide_wave_min(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141 /* row_half_mirror */, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140 /* row_mirror */, 0xf, 0xf, false));
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wide_wave_max(int v) { return ~wide_wave_min(~v); }
 
 // rows of one alignment: M for the last max(x, o+e, o2+e2)/g + 1 steps, I1 / D1 for the last e/g + 1, I2 / D2 for the last
 // e2/g + 1, and one row that is always NULL (inputs before score 0)
@@ -77,9 +88,9 @@ static inline int wide_rows(int X, int OE, int E, int OE2, int E2) {
 }
 static inline size_t wide_row_halfs(int wcap) { return (size_t)((wcap + 2 + 1) & ~1); }
 // LDS of a workgroup: control words, row limits, the two sequences, and (rows in LDS) the rows
-static inline size_t wide_smem_bytes(int X, int OE, int E, int OE2, int E2, int wcap, int seq_words, bool rows_in_lds) {
+static inline size_t wide_smem_bytes(int X, int OE, int E, int OE2, int E2, int wcap, int seq_words, bool rows_in_lds, int offset_bytes = 2) {
   const int NR = wide_rows(X, OE, E, OE2, E2);
-  return (size_t)(WFA_WIDE_CTRL_INTS + 2 * NR) * 4 + (size_t)2 * seq_words * 4 + (rows_in_lds ? (size_t)NR * wide_row_halfs(wcap) * 2 : 0);
+  return (size_t)(WFA_WIDE_CTRL_INTS + 2 * NR) * 4 + (size_t)2 * seq_words * 4 + (rows_in_lds ? (size_t)NR * wide_row_halfs(wcap) * (size_t)offset_bytes : 0);
 }
 
 // Full CIGAR of the wide-wavefront kernels (this file and wfa_tile.hpp): one lane walks the origin codes back from the end cell
@@ -141,11 +152,11 @@ __device__ inline long long wide_walk_unpack(const int* hist, long long hist_str
 
 // FULL: piggy-back history + walk; TWO: gap-affine-2p (components M, I1, D1, I2, D2); GROWS: the rows live in the workgroup's
 // slice of the HBM workspace (L2-resident) instead of LDS — the 2p form: 37 rows x 20 000 diagonals for 10 kb reads
-// W32: rows of int32 offsets (GROWS only): reads beyond 16 kb (plen + tlen > 32 000), any number of steps
+// W32: rows of int32 offsets: reads beyond 16 kb (plen + tlen > 32 000), any number of steps.  (Round 4: also with the rows in LDS —
+// the wf-adaptive leftovers of the banded stages, a few hundred diagonals wide: a step without a round trip to L2)
 template <bool FULL, bool TWO, bool GROWS, bool W32 = false>
 __global__ void __launch_bounds__(1024)
 wfa_wide_kernel(const WideArgs a) {
-  static_assert(!W32 || GROWS, "int32 rows live in the workspace");
   typedef typename std::conditional<W32, int, short>::type row_t;
   constexpr int RNULL = W32 ? WFA_OFFSET_NULL : WFA_WIDE_NULL;
   constexpr int NC = TWO ? 5 : 3;
@@ -154,7 +165,7 @@ wfa_wide_kernel(const WideArgs a) {
   const int DM = TWO ? max(max(a.X, a.OE), a.OE2) : max(a.X, a.OE);
   const int NM = DM + 1, NG1 = a.E + 1, NG2 = TWO ? a.E2 + 1 : 0, NR = NM + 2 * NG1 + 2 * NG2 + 1;
   const int rw = (a.wcap + 2 + 1) & ~1;            // halfs per row: guard, wcap diagonals, guard (+ pad)
-  int* const ctrl = wsm;                           // [10 par .. 10 par + 9] trim min x NC / max x NC, [20 + par] end k
+  int* const ctrl = wsm;                           // three scratch slots of 16 ints (layout at the step loop)
   int* const rlo = wsm + WFA_WIDE_CTRL_INTS;       // trimmed limits of every row
   int* const rhi = rlo + NR;
   uint32_t* const sP = reinterpret_cast<uint32_t*>(rhi + NR);
@@ -182,12 +193,9 @@ wfa_wide_kernel(const WideArgs a) {
       const uint32_t* gp = a.words + pm.p_woff;
       const uint32_t* gt = a.words + pm.t_woff;
       for (int i = tid; i < a.seq_words; i += T) { sP[i] = (i < nwp) ? gp[i] : 0u; sT[i] = (i < nwt) ? gt[i] : 0u; }
-      uint32_t* r32 = reinterpret_cast<uint32_t*>(rows);
-      const int n32 = W32 ? NR * rw : NR * rw / 2;
-      for (int i = tid; i < n32; i += T) r32[i] = W32 ? (uint32_t)WFA_OFFSET_NULL : 0xC000C000u;   // NULL (, NULL)
-      for (int i = tid; i < NR; i += T) { rlo[i] = 1; rhi[i] = -1; }
-      if (tid < 22) ctrl[tid] = (tid >= 20 || (tid % 10) < NC) ? INT_MAX : INT_MIN;
-      if (tid >= 22 && tid < 28) ctrl[tid] = ((tid - 22) % 3 == 2) ? INT_MIN : INT_MAX;   // cut-off scratch per parity: min distance, first / last kept diagonal
+      // (of the rows only the guard cell below kmin needs a value — NULL: every read goes through the limits of its row)
+      for (int i = tid; i < NR; i += T) { rlo[i] = 1; rhi[i] = -1; rows[(long long)i * rw] = (row_t)RNULL; }
+      if (tid < 48) { const int j = tid & 15; ctrl[tid] = (j < 5 || (j >= 10 && j <= 12)) ? INT_MAX : INT_MIN; }   // three scratch slots (layout at the step loop)
     }
     bool hand_on = (!W32 && plen + tlen > 32000) || (-pbf < kmin) || (tbf > kmax) || (ak < kmin) || (ak > kmax);
     int end_reason = 0;   // 1 reached, 3 handed on, 4 step limit
@@ -199,36 +207,46 @@ wfa_wide_kernel(const WideArgs a) {
     int steps_wait = a.steps_between;   // wf-adaptive: steps until the cut-off is looked at again
     __syncthreads();
 
-    for (int t = 0; !hand_on; ++t) {
+    int tM = 0, tG1 = 0, tG2 = 0, tS = 0;   // t mod NM, NG1, NG2, 3 (carried from step to step: no division by run-time values in a step)
+    for (int t = 0; !hand_on; ++t, tM = (tM + 1 == NM) ? 0 : tM + 1, tG1 = (tG1 + 1 == NG1) ? 0 : tG1 + 1, tG2 = (TWO && tG2 + 1 < NG2) ? tG2 + 1 : 0,
+             tS = (tS == 2) ? 0 : tS + 1) {
       const int s = t * a.g;
-      const int par = t & 1;
-      int* const TRmin = ctrl + 10 * par;
-      int* const TRmax = TRmin + NC;
+      // scratch of this step: one of three slots (the slot of step t + 2 is reset during step t, behind this step's barrier: no barrier
+      // of its own) — [0 .. NC) trim min, [5 .. 5 + NC) trim max, [10] end k, [11] smallest distance, [12] / [13] first / last kept diagonal
+      int* const TRmin = ctrl + 16 * tS;
+      int* const TRmax = TRmin + 5;
       // the limit is tested after compute-next of a score and before its extension (R/wavefront_unialign.c:98-107)
       if (t > 0 && s >= a.max_steps) { end_reason = 4; break; }
       if (!W32 && t > 16000) { end_reason = 3; break; }   // (int16 rows: a NULL gains at most 1 per step and must stay negative)
       // ---- rows of this step (M, I1, D1, I2, D2) and its inputs ----
       int rW[NC];
-      rW[0] = t % NM; rW[1] = NM + t % NG1; rW[2] = NM + NG1 + t % NG1;
-      if (TWO) { rW[3] = NM + 2 * NG1 + t % NG2; rW[4] = NM + 2 * NG1 + NG2 + t % NG2; }
-      const int iX = (t >= a.X) ? (t - a.X) % NM : NULLROW;
-      const int iO = (t >= a.OE) ? (t - a.OE) % NM : NULLROW;
-      const int iI = (t >= a.E) ? NM + (t - a.E) % NG1 : NULLROW;
-      const int iD = (t >= a.E) ? NM + NG1 + (t - a.E) % NG1 : NULLROW;
-      const int iO2 = (TWO && t >= a.OE2) ? (t - a.OE2) % NM : NULLROW;
-      const int iI2 = (TWO && t >= a.E2) ? NM + 2 * NG1 + (t - a.E2) % NG2 : NULLROW;
-      const int iD2 = (TWO && t >= a.E2) ? NM + 2 * NG1 + NG2 + (t - a.E2) % NG2 : NULLROW;
+      rW[0] = tM; rW[1] = NM + tG1; rW[2] = NM + NG1 + tG1;
+      if (TWO) { rW[3] = NM + 2 * NG1 + tG2; rW[4] = NM + 2 * NG1 + NG2 + tG2; }
+      auto back = [](int pos, int lag, int n) { const int x = pos - lag; return x < 0 ? x + n : x; };   // (lag < n)
+      const int iX = (t >= a.X) ? back(tM, a.X, NM) : NULLROW;
+      const int iO = (t >= a.OE) ? back(tM, a.OE, NM) : NULLROW;
+      const int iI = (t >= a.E) ? NM + back(tG1, a.E, NG1) : NULLROW;
+      const int iD = (t >= a.E) ? NM + NG1 + back(tG1, a.E, NG1) : NULLROW;
+      const int iO2 = (TWO && t >= a.OE2) ? back(tM, a.OE2, NM) : NULLROW;
+      const int iI2 = (TWO && t >= a.E2) ? NM + 2 * NG1 + back(tG2, a.E2, NG2) : NULLROW;
+      const int iD2 = (TWO && t >= a.E2) ? NM + 2 * NG1 + NG2 + back(tG2, a.E2, NG2) : NULLROW;
+      // Trimmed limits of the input rows.  A row is READ through them (a cell outside reads NULL): what a row still holds of the wavefront
+      // it held NM steps ago, its cells the trimming or the cut-off dropped, and a pair's first steps need no store of NULLs at all —
+      // those loops (up to 17 of them, each a divergent loop) were most of a narrow wavefront's step.
+      const int xl = rlo[iX], xh = rhi[iX], ol = rlo[iO], oh = rhi[iO], il = rlo[iI], ih = rhi[iI], dl = rlo[iD], dh = rhi[iD];
+      int o2l = 1, o2h = -1, i2l = 1, i2h = -1, d2l = 1, d2h = -1;
+      if (TWO) { o2l = rlo[iO2]; o2h = rhi[iO2]; i2l = rlo[iI2]; i2h = rhi[iI2]; d2l = rlo[iD2]; d2h = rhi[iD2]; }
       int lo, hi;
       if (t == 0) { lo = -pbf; hi = tbf; }
       else {
         // R/wavefront_compute.c:40-86 (a null input counts with lo = 1, hi = -1, as there)
-        lo = min(min(rlo[iX], rlo[iO] - 1), min(rlo[iI] + 1, rlo[iD] - 1));
-        hi = max(max(rhi[iX], rhi[iO] + 1), max(rhi[iI] + 1, rhi[iD] - 1));
-        bool all_null = rlo[iX] > rhi[iX] && rlo[iO] > rhi[iO] && rlo[iI] > rhi[iI] && rlo[iD] > rhi[iD];
+        lo = min(min(xl, ol - 1), min(il + 1, dl - 1));
+        hi = max(max(xh, oh + 1), max(ih + 1, dh - 1));
+        bool all_null = xl > xh && ol > oh && il > ih && dl > dh;
         if (TWO) {
-          lo = min(lo, min(rlo[iO2] - 1, min(rlo[iI2] + 1, rlo[iD2] - 1)));
-          hi = max(hi, max(rhi[iO2] + 1, max(rhi[iI2] + 1, rhi[iD2] - 1)));
-          all_null = all_null && rlo[iO2] > rhi[iO2] && rlo[iI2] > rhi[iI2] && rlo[iD2] > rhi[iD2];
+          lo = min(lo, min(o2l - 1, min(i2l + 1, d2l - 1)));
+          hi = max(hi, max(o2h + 1, max(i2h + 1, d2h - 1)));
+          all_null = all_null && o2l > o2h && i2l > i2h && d2l > d2h;
         }
         if (all_null) { lo = 1; hi = -1; }
       }
@@ -251,24 +269,24 @@ wfa_wide_kernel(const WideArgs a) {
       const row_t* const pO2 = rows + (long long)iO2 * rw + koff;
       const row_t* const pI2 = rows + (long long)iI2 * rw + koff;
       const row_t* const pD2 = rows + (long long)iD2 * rw + koff;
-      // stale cells of the rows written now (their previous wavefronts) outside the range written below
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        const int olo = rlo[rW[c]], ohi = rhi[rW[c]];
-        if (olo > ohi) continue;
-        if (lo > hi) { for (int k = olo + tid; k <= ohi; k += T) wR[c][k] = (row_t)RNULL; continue; }
-        for (int k = olo + tid; k <= min(ohi, lo - 1); k += T) wR[c][k] = (row_t)RNULL;
-        for (int k = max(olo, hi + 1) + tid; k <= ohi; k += T) wR[c][k] = (row_t)RNULL;
-      }
+      // (the index is redirected to the row's guard cell, which holds NULL, rather than the value selected afterwards: a load whose value is
+      // used under a condition is moved under it by the compiler — five loads, each behind its own branch and wait)
+      const int kg = kmin - 1;
+      auto rd = [kg](const row_t* p, int k, int l, int h) -> int { return p[((unsigned)(k - l) <= (unsigned)(h - l) && l <= h) ? k : kg]; };
       // ---- the pass: compute, clamp, extend, store; trimmed limits by wave ballots ----
       int wmin[NC], wmax[NC];   // (wave-uniform)
 #pragma unroll
       for (int c = 0; c < NC; ++c) { wmin[c] = INT_MAX; wmax[c] = INT_MIN; }
       // wf-adaptive: the smallest distance to the end over the extended M cells, and this thread's cell if it had just one
       int dloc = INT_MAX, my_cells = 0, my_off = RNULL, my_k = 0;
+      // diagonals whose every input lies inside its row's limits: a wave whose 64 diagonals are all of that kind reads without the tests
+      // (a wide exact wavefront is mostly such waves)
+      int fl = max(max(xl, ol + 1), max(il + 1, dl - 1)), fh = min(min(xh, oh - 1), min(ih + 1, dh - 1));
+      if (TWO) { fl = max(fl, max(o2l + 1, max(i2l + 1, d2l - 1))); fh = min(fh, min(o2h - 1, min(i2h + 1, d2h - 1))); }
       for (int k0 = lo + (tid & ~63); k0 <= hi; k0 += T) {
         const int k = k0 + lane;
         const bool in = k <= hi;
+        const bool inner = k0 >= fl && k0 + 63 <= fh;   // (wave-uniform)
         int v5[NC];   // M, I1, D1, I2, D2 of this diagonal
 #pragma unroll
         for (int c = 0; c < NC; ++c) v5[c] = RNULL;
@@ -277,13 +295,17 @@ wfa_wide_kernel(const WideArgs a) {
           if (t == 0) {
             v5[0] = max(k, 0);   // R/wavefront_aligner.c:251-310: offset 0 on diagonal 0, the free begins on theirs
           } else {
-            const int mo_lo = pO[k - 1], ie_lo = pI[k - 1], mo_hi = pO[k + 1], de_hi = pD[k + 1];
+            int mo_lo, ie_lo, mo_hi, de_hi, xv;
+            if (inner) { mo_lo = pO[k - 1]; ie_lo = pI[k - 1]; mo_hi = pO[k + 1]; de_hi = pD[k + 1]; xv = pX[k]; }
+            else { mo_lo = rd(pO, k - 1, ol, oh); ie_lo = rd(pI, k - 1, il, ih); mo_hi = rd(pO, k + 1, ol, oh); de_hi = rd(pD, k + 1, dl, dh); xv = rd(pX, k, xl, xh); }
             v5[1] = max(mo_lo, ie_lo) + 1;
             v5[2] = max(mo_hi, de_hi);
-            const int x1 = pX[k] + 1;
+            const int x1 = xv + 1;
             if (TWO) {
               // R/wavefront_compute_affine2p.c:45-106
-              const int mo2_lo = pO2[k - 1], i2e_lo = pI2[k - 1], mo2_hi = pO2[k + 1], d2e_hi = pD2[k + 1];
+              int mo2_lo, i2e_lo, mo2_hi, d2e_hi;
+              if (inner) { mo2_lo = pO2[k - 1]; i2e_lo = pI2[k - 1]; mo2_hi = pO2[k + 1]; d2e_hi = pD2[k + 1]; }
+              else { mo2_lo = rd(pO2, k - 1, o2l, o2h); i2e_lo = rd(pI2, k - 1, i2l, i2h); mo2_hi = rd(pO2, k + 1, o2l, o2h); d2e_hi = rd(pD2, k + 1, d2l, d2h); }
               v5[3] = max(mo2_lo, i2e_lo) + 1;
               v5[4] = max(mo2_hi, d2e_hi);
               const int best = max(max(v5[2], v5[4]), max(x1, max(v5[1], v5[3])));
@@ -336,9 +358,9 @@ wfa_wide_kernel(const WideArgs a) {
             if (more) {
               const int pi = v >> 4, ti = h >> 4;
               const uint32_t p0 = sP[pi], p1 = sP[pi + 1], p2 = sP[pi + 2], t0 = sT[ti], t1 = sT[ti + 1], t2 = sT[ti + 2];
-              const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h << 1);
-              const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t2, t1, (uint32_t)h << 1);
-              const uint32_t fb = min(wide_ffbl(xl), wide_ffbl(xh) | 32u);   // (v_ffbl_b32 gives ~0 for 0)
+              const uint32_t xl_ = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h << 1);
+              const uint32_t xh_ = __builtin_amdgcn_alignbit(p2, p1, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t2, t1, (uint32_t)h << 1);
+              const uint32_t fb = min(wide_ffbl(xl_), wide_ffbl(xh_) | 32u);   // (v_ffbl_b32 gives ~0 for 0)
               const int m = min((int)(fb >> 1), min(32, left));
               v += m; h += m; left -= m;
               more = (m == 32) && (left > 0);
@@ -348,9 +370,9 @@ wfa_wide_kernel(const WideArgs a) {
             v5[0] = h;
             // termination on the extended offset
             if (a.ef) {
-              if ((h >= tlen && plen - v <= a.pef) || (v >= plen && tlen - h <= a.tef)) atomicMin(&ctrl[20 + par], k);
+              if ((h >= tlen && plen - v <= a.pef) || (v >= plen && tlen - h <= a.tef)) atomicMin(&TRmin[10], k);
             } else if (k == ak && h >= tlen) {
-              ctrl[20 + par] = k;
+              TRmin[10] = k;
             }
           }
         }
@@ -366,14 +388,11 @@ wfa_wide_kernel(const WideArgs a) {
           if (FULL) pb_codes[code_base + (k - lo)] = (uint8_t)code;
         }
       }
-      if (a.heur == 1) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) dloc = min(dloc, __shfl_xor(dloc, m, 64));
-      }
+      if (a.heur == 1) dloc = wide_wave_min(dloc);
       if (lane == 0) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) if (wmin[c] != INT_MAX) { atomicMin(&TRmin[c], wmin[c]); atomicMax(&TRmax[c], wmax[c]); }
-        if (a.heur == 1 && dloc != INT_MAX) atomicMin(&ctrl[22 + 3 * par], dloc);
+        if (a.heur == 1 && dloc != INT_MAX) atomicMin(&TRmin[11], dloc);
       }
       __syncthreads();   // rows, trimmed limits, the end flag and the smallest distance of this step are visible
       // ---- trimmed limits (R/wavefront_compute.c:571-605): first / last in-bounds cell; none -> null ----
@@ -383,8 +402,14 @@ wfa_wide_kernel(const WideArgs a) {
         const int mn = TRmin[c], mx = TRmax[c];
         if (mn != INT_MAX) { tlo[c] = mn; thi[c] = mx; } else { tlo[c] = 1; thi[c] = -1; }
       }
-      const int ek = ctrl[20 + par];
+      const int ek = TRmin[10];
       if (ek != INT_MAX) { end_reason = 1; end_k = ek; end_t = t; }
+      if (tid == 0) {   // the slot of step t + 2 (last read in step t - 1; next written behind the barrier of step t + 1)
+        int* o = ctrl + 16 * ((tS == 0) ? 2 : tS - 1);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) { o[c] = INT_MAX; o[5 + c] = INT_MIN; }
+        o[10] = INT_MAX; o[11] = INT_MAX; o[12] = INT_MAX; o[13] = INT_MIN;
+      }
       // ---- wf-adaptive cut-off on the extended M wavefront (R/wavefront_heuristic.c:257-293, dispatcher :509-567): the diagonals whose
       // distance to the end exceeds the smallest by more than the threshold are dropped from both ends, never past the end diagonal;
       // the gap wavefronts are cut to the same limits (the equate) ----
@@ -392,8 +417,7 @@ wfa_wide_kernel(const WideArgs a) {
         --steps_wait;
         const int mlo = tlo[0], mhi = thi[0];
         if (steps_wait <= 0 && mhi - mlo + 1 >= a.min_wf_len) {   // (uniform: every thread read the same limits)
-          int* const cut = ctrl + 22 + 3 * par;
-          const int dmin = min(cut[0], max(plen, tlen));   // (collected in the pass above)
+          const int dmin = min(TRmin[11], max(plen, tlen));   // (collected in the pass above)
           int fk = INT_MAX, lk = INT_MIN;
           if (my_cells <= 1) {   // the usual case: this thread's one cell is still in registers
             if (my_cells == 1 && my_off >= 0 && max(tlen, plen + my_k) - my_off - dmin <= a.max_dist_thr) fk = lk = my_k;
@@ -403,52 +427,31 @@ wfa_wide_kernel(const WideArgs a) {
               if (off >= 0 && max(tlen, plen + k) - off - dmin <= a.max_dist_thr) { fk = min(fk, k); lk = max(lk, k); }
             }
           }
-#pragma unroll
-          for (int m = 32; m >= 1; m >>= 1) { fk = min(fk, __shfl_xor(fk, m, 64)); lk = max(lk, __shfl_xor(lk, m, 64)); }
-          if (lane == 0 && fk != INT_MAX) { atomicMin(&cut[1], fk); atomicMax(&cut[2], lk); }
+          fk = wide_wave_min(fk); lk = wide_wave_max(lk);
+          if (lane == 0 && fk != INT_MAX) { atomicMin(&TRmin[12], fk); atomicMax(&TRmin[13], lk); }
           __syncthreads();
-          const int lc = cut[1], hc = cut[2];   // (INT_MAX / INT_MIN: no diagonal qualifies)
+          const int lc = TRmin[12], hc = TRmin[13];   // (INT_MAX / INT_MIN: no diagonal qualifies)
           int new_lo = mlo, new_hi = mhi;
           const int top_limit = min(ak, mhi);
           if (top_limit > mlo) new_lo = min(lc, top_limit);
           const int bottom_limit = max(ak, new_lo);
           if (bottom_limit < mhi) new_hi = max(hc, bottom_limit);
           steps_wait = a.steps_between;
-          if (new_lo != mlo || new_hi != mhi) {
+          if (new_lo != mlo || new_hi != mhi) {   // (the dropped cells read NULL from now on: the limits say so)
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-              for (int k = lo + tid; k < new_lo; k += T) wR[c][k] = (row_t)RNULL;
-              for (int k = max(new_hi + 1, lo) + tid; k <= hi; k += T) wR[c][k] = (row_t)RNULL;
               tlo[c] = max(tlo[c], new_lo); thi[c] = min(thi[c], new_hi);
               if (tlo[c] > thi[c]) { tlo[c] = 1; thi[c] = -1; }
             }
           }
         }
       }
-      // gap cells outside their trimmed limits become NULL (M's are NULL already)
-      if (lo <= hi) {
-#pragma unroll
-        for (int c = 1; c < NC; ++c) {
-          const int l = tlo[c], h2 = thi[c];
-          if (l > h2) { for (int k = lo + tid; k <= hi; k += T) wR[c][k] = (row_t)RNULL; }
-          else {
-            for (int k = lo + tid; k < l; k += T) wR[c][k] = (row_t)RNULL;
-            for (int k = h2 + 1 + tid; k <= hi; k += T) wR[c][k] = (row_t)RNULL;
-          }
-        }
-      }
-      if (tid == 0) {
+      // every wave notes the limits of the rows written in this step itself (the same values from every wave): it reads them back in the
+      // next steps without waiting for another wave
+      if (lane == 0) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) { rlo[rW[c]] = tlo[c]; rhi[rW[c]] = thi[c]; }
-        // the other parity's scratch for the next step
-        int* o = ctrl + 10 * (par ^ 1);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) { o[c] = INT_MAX; o[NC + c] = INT_MIN; }
-        ctrl[20 + (par ^ 1)] = INT_MAX;
-        o = ctrl + 22 + 3 * (par ^ 1);
-        o[0] = INT_MAX; o[1] = INT_MAX; o[2] = INT_MIN;
       }
-      __syncthreads();
       if (end_reason) break;
     }
     if (hand_on) end_reason = 3;
@@ -486,6 +489,6 @@ wfa_wide_kernel(const WideArgs a) {
 }
 
 // host entry point (csrc/k_wide.hip): two = gap-affine-2p with the rows in the HBM workspace
-int launch_wide(bool full, bool two, const WideArgs& a, int grid, int threads, size_t smem, hipStream_t stream, bool w32 = false);
+int launch_wide(bool full, bool two, bool grows, const WideArgs& a, int grid, int threads, size_t smem, hipStream_t stream, bool w32 = false);
 
 }  // namespace wfa

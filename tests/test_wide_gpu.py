@@ -233,13 +233,16 @@ ADAPT_CASES = [
 ]
 
 
+@pytest.mark.parametrize("lds", [1, 0, 48])
 @pytest.mark.parametrize("idx", range(len(ADAPT_CASES)))
-def test_wide_kernel_wf_adaptive(gpu, idx, monkeypatch):
+def test_wide_kernel_wf_adaptive(gpu, idx, lds, monkeypatch):
     """Round 3: the wide kernel evaluates the wf-adaptive cut-off itself (R/wavefront_heuristic.c:257-293) and takes what the banded
     stages hand on.  Here the banded stages are off and the form is forced (WFA_HIP_WIDE_ADAPT=2), so every pair runs through it:
-    results must equal the oracle's, which prunes the same diagonals."""
+    results must equal the oracle's, which prunes the same diagonals.  Round 4: the rows of that form live in LDS first (lds = 1),
+    in the workspace for what outgrows them (0: the LDS stage off; 48: LDS rows of 48 diagonals, so most pairs take both stages)."""
     monkeypatch.setenv("WFA_HIP_NO_BAND", "1")
     monkeypatch.setenv("WFA_HIP_WIDE_ADAPT", "2")
+    monkeypatch.setenv("WFA_HIP_WIDE_ADAPT_LDS", str(lds))
     batch = ragged_batch(180, 2500, 0.10, 9300 + idx)
     kw = common.clamp_free(dict(ADAPT_CASES[idx]), batch)
     oc, nc = common.configs_pair(**kw)
