@@ -851,7 +851,7 @@ __device__ __forceinline__ int pb_lcp(const uint32_t* __restrict__ P, const uint
 template <int NCH>
 __global__ void __launch_bounds__(64)
 wfa_band_pb_bt_kernel(const BandArgs a) {
-  constexpr int W = Band<NCH>::WI;
+  const int W = a.seg_w ? a.seg_w : Band<NCH>::WI;   // (a.seg_w: the codes of wfa_seg_kernel<.., FULL>, records of seg_w bytes)
   const uint32_t t = blockIdx.x * 64u + threadIdx.x;
   if (t >= a.nwork) return;
   const int4 es = a.end_state[t];
@@ -987,29 +987,30 @@ wfa_seg_expand_kernel(const BandArgs a) {
     pair = a.worklist ? a.worklist[wi] : wi;
     pm = a.meta[pair];
   }
-  const uint32_t* top = reinterpret_cast<const uint32_t*>(a.hist + (long long)t * a.hist_stride) + a.hist_stride - 1;
+  // (round 4: the segments' history is piggy-back codes; the walk leaves its runs in forward order behind the codes and events)
+  const uint32_t* fruns = reinterpret_cast<const uint32_t*>(a.hist + (long long)t * a.hist_stride + a.pb_code_ints + a.pb_event_ints);
   uint8_t* buf = live ? a.cigar_ops + a.cigar_off[pair] : nullptr;
   const int nruns = live ? es.y : 0;
-  int end = pm.plen + pm.tlen;
+  int start = es.x;
   int maxruns = nruns;  // the four alignments of the wave loop together
 #pragma unroll
   for (int d = 16; d < 64; d <<= 1) maxruns = max(maxruns, __shfl_xor(maxruns, d, 64));
   for (int r0 = 0; r0 < maxruns; r0 += 16) {
     const int r = r0 + l;
-    const uint32_t rec = (r < nruns) ? *(top - r) : 0u;
+    const uint32_t rec = (r < nruns) ? fruns[r] : 0u;
     const int len = (int)(rec >> 8);
     const int op = (int)(rec & 0xFFu);
     int cum = len;  // inclusive prefix sum over the 16 lanes of the alignment
 #pragma unroll
     for (int d = 1; d < 16; d <<= 1) { const int o = __shfl_up(cum, d, 16); if (l >= d) cum += o; }
-    const int pos = end - cum;  // first byte of this lane's run
+    const int pos = start + cum - len;  // first byte of this lane's run
 #pragma unroll 4
     for (int j = 0; j < 16; ++j) {
       const int src = (lane & 48) + j;
       const int jpos = __shfl(pos, src, 64), jlen = __shfl(len, src, 64), jop = __shfl(op, src, 64);
       for (int i = l; i < jlen; i += 16) buf[jpos + i] = (uint8_t)jop;
     }
-    end -= __shfl(cum, (lane & 48) + 15, 64);
+    start += __shfl(cum, (lane & 48) + 15, 64);
   }
   if (live && l == 0) {
     a.cigar_begin[pair] = a.cigar_off[pair] + es.x;

@@ -42,6 +42,7 @@ struct FastArgs {
   int ef, pbf, pef, tbf, tef;                                // ends-free span with these free ends (R/wavefront_termination.c:115-162)
   int heur, min_wf_len, max_dist_thr, steps_between;         // 1 = wf-adaptive (R/wavefront_heuristic.c:257-293)
   int max_steps;                                             // INT_MAX = unlimited (R/wavefront_unialign.c:98-107)
+  int xdrop;                                                 // heur = 2: X-drop (R/wavefront_heuristic.c:297-383), the segmented form only
 };
 
 // neighbour diagonals inside a segment of W lanes (wfa_seg.hpp): lanes at a segment border receive NULL

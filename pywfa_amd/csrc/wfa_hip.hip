@@ -1101,11 +1101,13 @@ static int pilot_lane_heur(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t st
   if (b->laneh_pick != 0 || b->cfg.scope == WFA_SCOPE_FULL) return WFA_HIP_OK;
   b->laneh_pick = 2; b->segh_pick = 2;
   int X, OE, E;
-  if (!wfa::lane_heur_config(b->dcfg, b->ncomp) || wfa::seg_supported(b->dcfg, b->ncomp, false) ||
+  const bool lane_ok = wfa::lane_heur_config(b->dcfg, b->ncomp);
+  const bool seg_ok = wfa::seg_heur_config(b->dcfg, b->ncomp);
+  if ((!lane_ok && !seg_ok) || wfa::seg_supported(b->dcfg, b->ncomp, false) ||
       wfa::seg_shape(b->dcfg, &X, &OE, &E) < 0 || b->max_len > WFA_FAST_MAX_LEN || knob(al, K_NO_FAST, 0) != 0) return WFA_HIP_OK;
   const bool free_begins = b->dcfg.endsfree && (b->dcfg.pbf | b->dcfg.tbf) != 0;
-  const bool seg_ok = wfa::seg_heur_config(b->dcfg, b->ncomp);
   int forced = knob(al, K_LANE_HEUR, -1);       // (WFA_HIP_LANE_HEUR = 1 / 0: always / never, whatever the batch)
+  if (!lane_ok) forced = 0;                     // (X-drop: the segmented form only)
   if (wfa::seg_shape(b->dcfg, &X, &OE, &E) == WFA_SHAPE_RTC && !wfa::rtc_lane_shape_ok(X, OE, E)) forced = 0;   // (a run-time shape whose rings outgrow the lane kernel's registers)
   const int forced_seg = knob(al, K_SEG_HEUR, -1);    // (WFA_HIP_SEG_HEUR likewise)
   if (forced >= 0) b->laneh_pick = forced ? 1 : 2;
@@ -1127,7 +1129,7 @@ static int pilot_lane_heur(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t st
   fa.ef = (b->dcfg.endsfree && (b->dcfg.pbf | b->dcfg.pef | b->dcfg.tbf | b->dcfg.tef)) ? 1 : 0;
   fa.pbf = b->dcfg.pbf; fa.pef = b->dcfg.pef; fa.tbf = b->dcfg.tbf; fa.tef = b->dcfg.tef;
   fa.heur = b->dcfg.heuristic; fa.min_wf_len = b->dcfg.min_wf_len; fa.max_dist_thr = b->dcfg.max_dist_thr;
-  fa.steps_between = b->dcfg.steps_between; fa.max_steps = b->dcfg.max_steps;
+  fa.steps_between = b->dcfg.steps_between; fa.max_steps = b->dcfg.max_steps; fa.xdrop = b->dcfg.xdrop;
   if (forced < 0 &&
       wfa::launch_lane_args(wfa::seg_shape(b->dcfg, &X, &OE, &E), OE, E, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8),
                             b->max_len, stream, fa, false, 0, 256, true, X) != 0) { al->err = "pilot launch failed"; return WFA_HIP_EDEVICE; }
@@ -1140,7 +1142,9 @@ static int pilot_lane_heur(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t st
   HIP_TRY(al, hipStreamSynchronize(stream));
   HIP_TRY(al, hipMemsetAsync(pcount, 0, 2 * sizeof(uint32_t), stream));
   if (forced < 0) b->laneh_pick = (handed[0] * 4u <= np) ? 1 : 2;                  // at most a quarter handed on
-  if (forced_seg < 0 && seg_ok) b->segh_pick = (handed[1] * 4u <= np) ? 1 : 2;
+  // (X-drop keeps whole wavefronts: what outgrows the 32 diagonals are the expensive pairs, and the stage pays only below ~1/8 handed on —
+  // 150 bp at 2 %, xdrop 100: 21 % handed on, 7.0 ms with the stage, 5.9 ms without)
+  if (forced_seg < 0 && seg_ok) b->segh_pick = (handed[1] * (b->dcfg.heuristic == WFA_HEUR_XDROP ? 8u : 4u) <= np) ? 1 : 2;
   return WFA_HIP_OK;
 }
 
@@ -1731,10 +1735,14 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     if (use_segfull) {
       for (int i = 0; i < n_segfull; ++i) {
         const int rank = i + (use_lanefull ? 1 : 0);   // position in the cascade: 0 = takes the whole batch
-        segfull_slot_ints[i] = (int64_t)wfa::seg_full_records(b->dcfg, segfull_w[i]) * segfull_w[i] * 2;  // records of w entries x 8 bytes
+        { long long ci, ei, si; wfa::seg_full_slot(b->dcfg, segfull_w[i], b->max_len, &ci, &ei, &si); segfull_slot_ints[i] = si; }   // code records of w bytes, events, runs
         const int64_t slot_bytes = segfull_slot_ints[i] * 4 + (int64_t)sizeof(int4);
         int64_t want = (rank == 0) ? std::min<int64_t>((int64_t)knob(al, K_SEGFULL_PAIRS, 2000000), std::max<int64_t>(1, ((int64_t)8 << 30) / slot_bytes))
                                    : std::max<int64_t>(4096, (int64_t)in_n / (rank == 1 ? 8 : 32));
+        // (the stage that takes the whole batch runs it as two balanced launches at least, once each still fills the chip: the walks and
+        // the expand of a launch — a third of the stage's time at 10 % divergence — run under the alignment kernel of the next)
+        if (rank == 0 && in_count == nullptr && (int64_t)in_n >= 262144 && !al->knobs.set[K_SEGFULL_PAIRS] && knob(al, K_NO_DUAL, 0) == 0)
+          want = std::min<int64_t>(want, (((int64_t)in_n + 1) / 2 + 63) & ~63ll);
         segfull_cap[i] = std::max<int64_t>(1, std::min<int64_t>(in_n, std::min<int64_t>(want, free_budget(al) / slot_bytes)));
         // (several launches: two slot arrays, the walks of a launch run under the alignment kernel of the next)
         need = std::max(need, (size_t)(segfull_cap[i] * slot_bytes) * ((rank == 0 && segfull_cap[i] < (int64_t)in_n) ? 2 : 1));
@@ -1838,6 +1846,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       ba.x = b->dcfg.x; ba.oe = b->dcfg.o1 + b->dcfg.e1; ba.e = b->dcfg.e1;
       ba.hist = al->ws; ba.hist_stride = segfull_slot_ints[sf]; ba.end_state = fa.end_state;
       ba.split = 1; ba.h16 = 1; ba.seg_w = segfull_w[sf];
+      { long long ci, ei, si; wfa::seg_full_slot(b->dcfg, segfull_w[sf], b->max_len, &ci, &ei, &si); ba.pb = 1; ba.pb_code_ints = ci; ba.pb_event_ints = ei; }
       // (first stage: the host knows the count and walks it in launches of `cap` pairs; later stages: one launch over
       // the device-side list, slots for `cap` of its pairs)
       const int64_t total = (in_count == nullptr) ? (int64_t)in_n : segfull_cap[sf];
@@ -1955,7 +1964,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       fa.ef = (b->dcfg.endsfree && (b->dcfg.pbf | b->dcfg.pef | b->dcfg.tbf | b->dcfg.tef)) ? 1 : 0;
       fa.pbf = b->dcfg.pbf; fa.pef = b->dcfg.pef; fa.tbf = b->dcfg.tbf; fa.tef = b->dcfg.tef;
       fa.heur = b->dcfg.heuristic; fa.min_wf_len = b->dcfg.min_wf_len; fa.max_dist_thr = b->dcfg.max_dist_thr;
-      fa.steps_between = b->dcfg.steps_between; fa.max_steps = b->dcfg.max_steps;
+      fa.steps_between = b->dcfg.steps_between; fa.max_steps = b->dcfg.max_steps; fa.xdrop = b->dcfg.xdrop;
       if (wfa::launch_seg_heur(b->dcfg, al->cu_count, knob(al, K_FAST_WAVES_PER_CU, 256), stream, fa) != 0) {
         al->err = "segmented kernel launch failed"; return WFA_HIP_EDEVICE;
       }

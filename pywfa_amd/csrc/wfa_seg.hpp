@@ -166,9 +166,13 @@ wfa_seg_kernel(const FastArgs a) {
   int target = NEVER;  // tlen on the lane of diagonal tlen - plen: reaching it ends the alignment
   int lim = WFA_OFFSET_NULL, cur = WFA_OFFSET_NULL, s0 = 0, deadline = NEVER;
   uint32_t spair = 0;
-  // FULL: slot of my pair and my entry {M, I, D, -} x int16 in the record of the current step
+  // FULL (round 4: piggy-back history, as the banded kernel's — one byte of origin codes per diagonal and step instead of an 8-byte
+  // record of offsets: the history of a 64-lane segment was written at the rate of HBM): slot of my pair, my byte in the record of the
+  // current step (position k mod W), and the code of my cell made by the last compute-next — origin of M (bits 0-1: 0 mismatch,
+  // 1 deletion, 2 insertion), of I (bit 2: extension) and of D (bit 3); wfa_band_pb_bt_kernel walks it (a.seg_w = W)
   uint32_t tslot = 0;
-  int2* hp = nullptr;
+  uint8_t* hp = nullptr;
+  int code = 0;
   int Mh[DM], Ih[E], Dh[E];
 #pragma unroll
   for (int d = 0; d < DM; ++d) Mh[d] = WFA_OFFSET_NULL;
@@ -177,6 +181,7 @@ wfa_seg_kernel(const FastArgs a) {
   // HEUR: max(tlen, plen + k) of my diagonal (distance to the end = hdl - offset), lane of the end diagonal in my segment, the
   // distance of an empty wavefront, steps until the cut-off is looked at again, "a cell of an outermost lane is alive"
   int hdl = 0, hjt = 0, hdinit = 0, steps_wait = 0;
+  int max_sw = 0; bool have_max_sw = false;   // X-drop: the largest cell score seen at a cut-off so far (segment-uniform)
   bool edge = false;
   uint32_t want = (1u << NS) - 1u;  // segments waiting for a pair
   uint32_t busy = 0;                // segments aligning
@@ -237,7 +242,7 @@ wfa_seg_kernel(const FastArgs a) {
                            : HEUR ? gstep + 4 * (pl + tl) + 64   // (no bound to prove: only a cap on the steps a pair may take here)
                            : gstep + min(2 * (OE - E) + E * (2 * c + 2 * H - akk), 2 * (OE - E) + E * (2 * H + 2 - 2 * c + akk)) + (LAZY ? 1 : 0)
                                    - (FULL ? 1 : 0);  // FULL: S' < Bmin strictly, so that no co-optimal alignment leaves the band
-            if (FULL) { tslot = i; hp = reinterpret_cast<int2*>(a.hist + (long long)i * a.hist_stride) + l; }
+            if (FULL) { tslot = i; hp = reinterpret_cast<uint8_t*>(a.hist + (long long)i * a.hist_stride) + (k & (W - 1)); code = 0; }
             cur = (bad || k != 0) ? WFA_OFFSET_NULL : 0;
             if (HEUR) {
               // wavefront 0 over the free begins (offset max(k, 0) on diagonals -pbf .. tbf); the threshold that ends the alignment on
@@ -245,7 +250,7 @@ wfa_seg_kernel(const FastArgs a) {
               // tlen - h <= tef, i.e. offset >= min(max(tlen, plen + k - pef), max(plen + k, tlen - tef))
               if (!bad && a.ef && k >= -pbf_ && k <= tbf_) cur = max(k, 0);
               if (a.ef) target = bad ? NEVER : min(max(tl, pl + k - a.pef), max(pl + k, tl - a.tef));
-              hdl = max(tl, pl + k); hjt = akk - (c - H); hdinit = max(pl, tl); steps_wait = a.steps_between; edge = false;
+              hdl = max(tl, pl + k); hjt = akk - (c - H); hdinit = max(pl, tl); steps_wait = a.steps_between; edge = false; have_max_sw = false;
             }
 #pragma unroll
             for (int d = 0; d < DM; ++d) Mh[d] = WFA_OFFSET_NULL;
@@ -313,13 +318,8 @@ wfa_seg_kernel(const FastArgs a) {
       }
     }
     if (FULL) {
-      // record of this step: entry l of W, 8 bytes {M (extended), I, D, -} as int16 (offsets <= 512; NULL -> -1);
-      // the thread-per-alignment walk of wfa_band.hpp reads it back (band_backtrace, a.seg_w = W)
-      if (deadline != NEVER) {
-        const int m16 = max(cur, -1), i16 = max(Ih[0], -1), d16 = max(Dh[0], -1);
-        *hp = make_int2((m16 & 0xffff) | (i16 << 16), d16 & 0xffff);
-        hp += W;
-      }
+      // record of this step: the codes of its cells (step 0: none)
+      if (deadline != NEVER) { *hp = (uint8_t)code; hp += W; }
     }
     // ---------------- termination / hand-over ----------------
     {
@@ -396,6 +396,31 @@ wfa_seg_kernel(const FastArgs a) {
             if ((new_lo != lo || new_hi != hi) && (l < new_lo || l > new_hi)) { cur = WFA_OFFSET_NULL; Ih[0] = WFA_OFFSET_NULL; Dh[0] = WFA_OFFSET_NULL; }
           }
         }
+      } else if (a.heur == 2) {
+        // X-drop (R/wavefront_heuristic.c:297-383; round 4): match = 0, so the "score" of a cell is (-(v + h) - s) / 2 (C division); the
+        // cells more than xdrop below the largest score of the earlier cut-offs are dropped from both ends of this score's wavefront
+        // (all of them, if none qualifies: the wavefronts of the other scores go on)
+        const uint32_t f = (uint32_t)((__ballot(cur >= 0) >> (seg * W)) & FIELD);
+        if (f != 0u) --steps_wait;
+        const bool consider = f != 0u && steps_wait <= 0 && deadline != NEVER;
+        if (__any(consider)) {
+          const int lo = (int)__builtin_ctz(f | 0x80000000u), hi = 31 - (int)__builtin_clz(f | 1u);
+          const int sw = (-(2 * max(cur, 0) - (pbias - kb)) - __mul24(gstep - s0, a.g)) / 2;   // (v + h = 2 offset - k)
+          int cmax = (cur >= 0) ? sw : -0x40000000;
+#pragma unroll
+          for (int m = 1; m < W; m <<= 1) cmax = max(cmax, __shfl_xor(cmax, m, 64));
+          if (consider) {
+            if (have_max_sw) {
+              const uint32_t okf = (uint32_t)((__ballot(cur >= 0 && max_sw - sw < a.xdrop) >> (seg * W)) & FIELD);
+              const int new_lo = okf ? (int)__builtin_ctz(okf) : hi + 1, new_hi = okf ? 31 - (int)__builtin_clz(okf) : hi;
+              if ((new_lo != lo || new_hi != hi) && (l < new_lo || l > new_hi)) { cur = WFA_OFFSET_NULL; Ih[0] = WFA_OFFSET_NULL; Dh[0] = WFA_OFFSET_NULL; }
+              if (cmax > max_sw) max_sw = cmax;
+            } else {
+              max_sw = cmax; have_max_sw = true;
+            }
+            steps_wait = a.steps_between;
+          }
+        }
       }
     }
     // ---------------- compute-next ----------------
@@ -405,8 +430,19 @@ wfa_seg_kernel(const FastArgs a) {
     {
       // I(k) = max(M_oe, I_e)(k-1) + 1 and D(k) = max(M_oe, D_e)(k+1): the max commutes with the lane shift
       const int mx = Mh[X - 1], mo = Mh[OE - 1], ie = Ih[E - 1], de = Dh[E - 1];
-      const int ni = seg_from_below<W>(max(mo, ie)) + 1;
-      const int nd = seg_from_above<W>(max(mo, de));
+      int ni, nd;
+      if (FULL) {
+        // the choices the backtrace would make (R/wavefront_backtrace.c:49-59: mismatch > deletion > insertion, extension > opening on
+        // equal offsets), taken here where the candidates are in registers (as wfa_band.hpp, PB)
+        const int mo_lo = seg_from_below<W>(mo), ie_lo = seg_from_below<W>(ie), mo_hi = seg_from_above<W>(mo), de_hi = seg_from_above<W>(de);
+        ni = max(mo_lo, ie_lo) + 1;
+        nd = max(mo_hi, de_hi);
+        const int mc = (mx + 1 >= max(nd, ni)) ? 0 : ((nd >= ni) ? 1 : 2);
+        code = mc | ((ie_lo >= mo_lo) ? 4 : 0) | ((de_hi >= mo_hi) ? 8 : 0);
+      } else {
+        ni = seg_from_below<W>(max(mo, ie)) + 1;
+        nd = seg_from_above<W>(max(mo, de));
+      }
       int nm = max(nd, max(mx + 1, ni));
       if (nm > lim) nm = WFA_OFFSET_NULL;
 #pragma unroll
@@ -531,7 +567,7 @@ inline int launch_seg_full(const WfaDevConfig& c, int cu_count, int per_cu, hipS
 // lane_heur_config), without a step limit (the banded kernel reports the limit's status)
 inline bool seg_heur_config(const WfaDevConfig& c, int ncomp) {
   int X, OE, E;
-  return ncomp == 3 && c.match == 0 && c.wildcard < 0 && (c.heuristic == 0 || c.heuristic == 1) && c.max_steps == INT_MAX &&
+  return ncomp == 3 && c.match == 0 && c.wildcard < 0 && (c.heuristic == 0 || c.heuristic == 1 || c.heuristic == 2) && c.max_steps == INT_MAX &&
          seg_shape(c, &X, &OE, &E) >= 0;
 }
 // a.ef / a.pbf .. / a.heur .. set by the caller (wfa_fast.hpp); the work list is a.worklist / a.nwork_dev / a.nwork
@@ -552,10 +588,18 @@ inline int launch_seg_heur(const WfaDevConfig& c, int cu_count, int per_cu, hipS
 }
 
 // steps a w-lane segment can take before it hands its pair on (+ 1), i.e. the records a history slot needs
+// ints of a pair's history slot of the FULL form: the code records (w bytes each), the walk's event bytes, its run records
+inline void seg_full_slot(const WfaDevConfig& c, int w, int max_len, long long* code_ints, long long* event_ints, long long* slot_ints);
 inline int seg_full_records(const WfaDevConfig& c, int w) {
   int X, OE, E;
   if (seg_shape(c, &X, &OE, &E) < 0) return 0;
   return 2 * (OE - E) + E * (w + 1) + 3;
+}
+
+inline void seg_full_slot(const WfaDevConfig& c, int w, int max_len, long long* code_ints, long long* event_ints, long long* slot_ints) {
+  *code_ints = (((long long)seg_full_records(c, w) * w + 15) & ~15ll) / 4;
+  *event_ints = ((2ll * max_len + 16 + 15) & ~15ll) / 4;     // one event per edit
+  *slot_ints = (*code_ints + *event_ints + 2ll * max_len + 8 + 15) & ~15ll;   // + one run record per op at most
 }
 
 // variant 6/7/8/9 = segments of 16/8/32/64 lanes (4/8/2/1 alignments per wave) with the two-round extension,

@@ -174,6 +174,35 @@ def test_segmented_kernel_general_form(gpu, corpora, cfg_idx, lane_first, monkey
         common.assert_same(o, score, status, None, batch, f"segment general form {name} {kw}")
 
 
+SEG_XDROP = [dict(span="end-to-end", heuristic="X-drop", xdrop=100), dict(span="end-to-end", heuristic="X-drop", xdrop=20),
+             dict(span="end-to-end", heuristic="X-drop", xdrop=8, steps_between_cutoffs=3),
+             dict(span="ends-free", heuristic="X-drop", xdrop=30, pattern_begin_free=4, pattern_end_free=6, text_begin_free=2, text_end_free=9),
+             dict(span="end-to-end", heuristic="X-drop", xdrop=15, mismatch=2, gap_opening=3, gap_extension=1)]
+
+
+@pytest.mark.parametrize("cfg_idx", range(len(SEG_XDROP)))
+def test_segmented_kernel_general_form_xdrop(gpu, corpora, cfg_idx, monkeypatch):
+    """Round 4: X-drop (R/wavefront_heuristic.c:297-383) in the general form of the 32-lane segments, forced on: scores and statuses
+    (a dropped alignment ends unreachable in the banded stage it is handed on to) must equal the oracle's."""
+    monkeypatch.setenv("WFA_HIP_SEG_HEUR", "1")
+    for name in ("150bp_2pct", "150bp_15pct", "special"):
+        batch = corpora[name]
+        kw = common.clamp_free(dict(SEG_XDROP[cfg_idx], scope="score"), batch)
+        oc, nc = common.configs_pair(**kw)
+        o = loader.run(loader.oracle(), oc, batch, want_cigar=False)
+        score, status, _ = common.gpu_run(nc, batch, False, resident=(cfg_idx % 2 == 0))
+        common.assert_same(o, score, status, None, batch, f"segment general form, X-drop {name} {kw}")
+
+
+def test_segmented_kernel_general_form_xdrop_pilot(gpu):
+    """A batch large enough for the pilot (>= 64 k pairs): it takes the segmented form for X-drop(100) at 2 %; compared with the real library."""
+    batch = datagen.generate(70000, 150, 0.02, 4456)
+    oc, nc = common.configs_pair(span="end-to-end", scope="score", heuristic="X-drop", xdrop=100)
+    o = loader.run(loader.reference() if loader.have_reference() else loader.oracle(), oc, batch, want_cigar=False)
+    score, status, _ = common.gpu_run(nc, batch, False, resident=True)
+    common.assert_same(o, score, status, None, batch, "segment general form, X-drop, pilot")
+
+
 @pytest.mark.parametrize("error", [0.005, 0.03])
 def test_lane_kernel_general_form_pilot(gpu, error):
     """Batches of >= 64 k pairs let a pilot decide whether the general form goes first (few pairs outgrow its 16 slots at 0.5 %
