@@ -71,8 +71,8 @@ struct BandArgs {
   int pb;                 // FULL + split: 1 = piggy-back history: one byte of origin codes per (step, diagonal)
                           // instead of the offsets; the walk follows the codes and the matches are re-extended afterwards
   const uint2* lane_codes; // wfa_lane_kernel<.., FULL>: the comparison bits of every wave-step (64 lanes x 8 bytes per record)
-  int seg_w;              // > 0: the history was written by wfa_seg_kernel<.., FULL>: records of seg_w entries {M, I, D, -} x
-                          // int16, entry k - klo, klo = ceil((tlen - plen) / 2) - seg_w / 2
+  int seg_w;              // > 0: the history was written by wfa_seg_kernel<.., FULL>: piggy-back code records of seg_w bytes, the byte of
+                          // diagonal k at k mod seg_w (a.pb = 1)
 };
 
 // index of the lowest set bit, ~0u for 0 (v_ffbl_b32 semantics)
@@ -182,19 +182,13 @@ __device__ void band_backtrace(const int* hist, const BandArgs& a, int plen, int
   struct Ent { int m, i1, d1, i2, d2; };
   int nruns = 0;
   const bool two = a.oe2 > 0;
-  const int seg_klo = a.seg_w ? ((tlen - plen + 1) >> 1) - a.seg_w / 2 : 0;
   // entry of (score index, diagonal): the banded kernel's window records (gap-affine: {M, I, D, base}; 2p: 16 bytes of
-  // int16 halves {M | I1, D1 | base, I2 | D2, -}) or a segment's records
+  // int16 halves {M | I1, D1 | base, I2 | D2, -})
   auto entry = [&](int si, int kk) -> Ent {
     Ent e = {WFA_OFFSET_NULL, WFA_OFFSET_NULL, WFA_OFFSET_NULL, WFA_OFFSET_NULL, WFA_OFFSET_NULL};
     if (si < 0) return e;
     auto nz = [](int v) { return v < 0 ? WFA_OFFSET_NULL : v; };
-    if (a.seg_w) {
-      if (kk >= seg_klo && kk < seg_klo + a.seg_w) {
-        const short4 q = reinterpret_cast<const short4*>(hist + (long long)si * (a.seg_w * 2))[kk - seg_klo];
-        e.m = nz(q.x); e.i1 = nz(q.y); e.d1 = nz(q.z);
-      }
-    } else if (two) {
+    if (two) {
       const int4 q = reinterpret_cast<const int4*>(hist + (long long)si * BD::REC)[kk & (BD::WI - 1)];
       const int base = q.y >> 16;
       if (kk >= base && kk < base + BD::W) {
