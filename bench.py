@@ -448,6 +448,7 @@ def multi_leg(pairs_per_device, length=100000, calls=2):
     from pywfa_amd import _native, datagen
     ndev = _native.lib().wfa_hip_device_count()
     devices = list(range(ndev))
+    pairs_per_device = max(64, min(pairs_per_device, 16384 // max(ndev, 1)))   # (200 KB of ASCII and of op bytes per pair on the host)
     n = pairs_per_device * ndev
     batch = datagen.generate(n, length, 0.08, datagen.SEEDS["C5"])
     out = {"devices": ndev, "pairs": n, "read_length": length}
@@ -484,7 +485,7 @@ def main():
     ap.add_argument("--c3-leg", action="store_true", help="run the C3 leg of the N > 1 runs at N = 1 too (it has no CPU reference: transcripts are validated)")
     ap.add_argument("--multi", action="store_true",
                     help="only the C5 leg: one process, wfa_hip_multi_align_batch over every visible device")
-    ap.add_argument("--multi-pairs", type=int, default=1024, help="100 kb pairs per device of the C5 leg")
+    ap.add_argument("--multi-pairs", type=int, default=4096, help="100 kb pairs per device of the C5 leg (at most 16 384 pairs in all)")
     args = ap.parse_args()
 
     if args.multi:
@@ -494,7 +495,7 @@ def main():
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
                 "config": {"workload": f"C5: {m['pairs']} x 100kb pairs, 8% error, wf-adaptive, full CIGAR, one process, "
                                        f"wfa_hip_multi_align_batch over {m['devices']} device(s), host in -> host out",
-                           "pairs_per_gpu": args.multi_pairs, "read_length": 100000,
+                           "pairs_per_gpu": m["pairs"] // max(m["devices"], 1), "read_length": 100000,
                            "parallelism": f"contiguous shards over {m['devices']} device(s), no collective",
                            "c5_multi_adaptive_alignments_per_s": m["adaptive"]["alignments_per_s"],
                            "c5_multi_adaptive_violations": m["adaptive"]["violations"],
