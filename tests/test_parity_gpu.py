@@ -194,13 +194,15 @@ def test_segmented_kernel_general_form_xdrop(gpu, corpora, cfg_idx, monkeypatch)
         common.assert_same(o, score, status, None, batch, f"segment general form, X-drop {name} {kw}")
 
 
-def test_segmented_kernel_general_form_xdrop_pilot(gpu):
-    """A batch large enough for the pilot (>= 64 k pairs): it takes the segmented form for X-drop(100) at 2 %; compared with the real library."""
-    batch = datagen.generate(70000, 150, 0.02, 4456)
+@pytest.mark.parametrize("error", [0.005, 0.02])
+def test_segmented_kernel_general_form_xdrop_pilot(gpu, error):
+    """A batch large enough for the pilot (>= 64 k pairs): X-drop(100) takes the segmented form at 0.5 % divergence (few pairs outgrow
+    its 32 diagonals) and the banded kernel alone at 2 % (a fifth would be handed on); either way the results are the real library's."""
+    batch = datagen.generate(70000, 150, error, 4456)
     oc, nc = common.configs_pair(span="end-to-end", scope="score", heuristic="X-drop", xdrop=100)
     o = loader.run(loader.reference() if loader.have_reference() else loader.oracle(), oc, batch, want_cigar=False)
     score, status, _ = common.gpu_run(nc, batch, False, resident=True)
-    common.assert_same(o, score, status, None, batch, "segment general form, X-drop, pilot")
+    common.assert_same(o, score, status, None, batch, f"segment general form, X-drop, pilot {error}")
 
 
 @pytest.mark.parametrize("error", [0.005, 0.03])
