@@ -51,6 +51,21 @@ __device__ __forceinline__ uint32_t ffbl_u32(uint32_t x) {
 // (R/wavefront_heuristic.c:257-293), free ends (R/wavefront_termination.c:115-162, wavefront 0 over the free begins).  The rule that
 // keeps it exact is the lane kernel's (wfa_lane.hpp, HEUR): NO CLIPPING — a segment hands its pair on as soon as a cell of one of
 // its two outermost lanes is alive, i.e. before the band has dropped anything the unbanded run would have kept.
+// minimum over the W lanes of my segment, in every lane of it: butterflies inside the rows of 16 lanes by DPP (the move folds into the
+// v_min), the two rows of a 32-lane segment by one ds_swizzle (lane ^ 16) — five ds_bpermute round trips before (round 4)
+template <int W>
+__device__ __forceinline__ int seg_min(int v) {
+  static_assert(W == 8 || W == 16 || W == 32, "segments inside a 32-lane group");
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141 /* row_half_mirror */, 0xf, 0xf, false));
+  if (W >= 16) v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140 /* row_mirror */, 0xf, 0xf, false));
+  if (W == 32) v = min(v, __builtin_amdgcn_ds_swizzle(v, 0x401F /* bit mode: and 0x1f, or 0, xor 0x10 */));
+  return v;
+}
+template <int W>
+__device__ __forceinline__ int seg_max(int v) { return ~seg_min<W>(~v); }
+
 template <int X, int OE, int E, int W, bool LAZY, bool FULL, bool HEUR = false>
 __global__ void __launch_bounds__(64)
 wfa_seg_kernel(const FastArgs a) {
@@ -379,9 +394,7 @@ wfa_seg_kernel(const FastArgs a) {
         if (__any(consider)) {
           // d = max(plen - v, tlen - h) = max(tlen, plen + k) - offset; dead lanes: far away
           const int d = (cur >= 0) ? hdl - cur : 0x3fffffff;
-          int dmin = d;
-#pragma unroll
-          for (int m = 1; m < W; m <<= 1) dmin = min(dmin, __shfl_xor(dmin, m, 64));
+          int dmin = seg_min<(W > 32 ? 32 : W)>(d);
           dmin = min(dmin, hdinit);
           const uint32_t okf = (uint32_t)((__ballot(cur >= 0 && d - dmin <= a.max_dist_thr) >> (seg * W)) & FIELD);
           const int lc = okf ? (int)__builtin_ctz(okf) : 0x7fffffff, hc = okf ? 31 - (int)__builtin_clz(okf) : -0x7fffffff;
@@ -406,9 +419,7 @@ wfa_seg_kernel(const FastArgs a) {
         if (__any(consider)) {
           const int lo = (int)__builtin_ctz(f | 0x80000000u), hi = 31 - (int)__builtin_clz(f | 1u);
           const int sw = (-(2 * max(cur, 0) - (pbias - kb)) - __mul24(gstep - s0, a.g)) / 2;   // (v + h = 2 offset - k)
-          int cmax = (cur >= 0) ? sw : -0x40000000;
-#pragma unroll
-          for (int m = 1; m < W; m <<= 1) cmax = max(cmax, __shfl_xor(cmax, m, 64));
+          const int cmax = seg_max<(W > 32 ? 32 : W)>((cur >= 0) ? sw : -0x40000000);
           if (consider) {
             if (have_max_sw) {
               const uint32_t okf = (uint32_t)((__ballot(cur >= 0 && max_sw - sw < a.xdrop) >> (seg * W)) & FIELD);
