@@ -1755,7 +1755,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     const int64_t lanefull_slot_bytes = (int64_t)WFA_LANE_RUN_SLOT * 4 + (int64_t)sizeof(int4);
     int64_t lanefull_cap = 0;
     long long lanefull_grid = 0;
-    int lanefull_recs = 0, lf_x = 0, lf_oe = 0, lf_e = 0;
+    int lanefull_recs = 0, lf_x = 0, lf_oe = 0, lf_e = 0, lf_min_pairs = 256;
     size_t lanefull_off = 0, lanefull_codes_off = 0, lanefull_codes_bytes = 0, lanefull_list_off = 0;
     int lanefull_split = 1;   // > 1: every launch has slots and code lists of its own
     if (use_lanefull) {
@@ -1771,7 +1771,11 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         lanefull_split = std::max(1, std::min(8, knob(al, K_LANE_FULL_SPLIT, (int64_t)in_n >= 524288 ? 2 : 1)));
         lanefull_cap = ((((int64_t)in_n + lanefull_split - 1) / lanefull_split) + 63) & ~63ll;
       }
-      wfa::lane_full_geometry((uint32_t)lanefull_cap, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_MIN_PAIRS, 0), lf_oe, lf_e,
+      // pairs per wave: 256 for launches that fill the chip; a launch of up to 256 k pairs is cut into lane-fulls of 64 (a run is as long as
+      // a wave's life: 65 536 pairs with CIGAR 397 -> 289 us; 1 M pairs in two launches: 1.07 ms with 256, 1.15 with 64).  One value for the
+      // geometry and every launch of the stage: a shorter last launch must not have more waves than the record lists were sized for
+      lf_min_pairs = knob(al, K_LANE_MIN_PAIRS, lanefull_cap <= 262144 ? 64 : 256);
+      wfa::lane_full_geometry((uint32_t)lanefull_cap, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), lf_min_pairs, lf_oe, lf_e,
                               &lanefull_grid, &lanefull_recs);
       lanefull_codes_off = lanefull_off + (((size_t)(lanefull_cap * lanefull_split * lanefull_slot_bytes) + 255) & ~(size_t)255);
       lanefull_codes_bytes = ((size_t)lanefull_grid * (size_t)lanefull_recs * 512 + 255) & ~(size_t)255;
@@ -1819,7 +1823,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
           ba.hist = fa.hist; ba.end_state = fa.end_state; ba.lane_codes = fa.codes;
         }
         // (a shorter last launch has fewer waves and needs fewer records than the lists were sized for)
-        if (wfa::launch_lane_args(shape, OE, E, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, fa, true, 0, knob(al, K_LANE_MIN_PAIRS, 0), false, X) != 0) {
+        if (wfa::launch_lane_args(shape, OE, E, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, fa, true, 0, lf_min_pairs, false, X) != 0) {
           al->err = "lane kernel launch failed"; return WFA_HIP_EDEVICE;
         }
         ba.work_begin = (uint32_t)w0; ba.nwork = cnt;
@@ -1911,7 +1915,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
           lrc = wfa::launch_lane(shape, wfa::gcd_int(wfa::gcd_int(b->dcfg.x, b->dcfg.o1 + b->dcfg.e1), b->dcfg.e1), al->cu_count,
                                  knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, b->d_words, b->d_meta,
                                  in_list, in_count, in_n, b->d_score, b->d_status, out_list, out_count,
-                                 (knob(al, K_LANE_DEBUG, 0) && al->ws) ? al->ws : nullptr, knob(al, K_LANE_LDS_PAD_KB, 0), X, OE, E);
+                                 (knob(al, K_LANE_DEBUG, 0) && al->ws) ? al->ws : nullptr, knob(al, K_LANE_LDS_PAD_KB, 0), X, OE, E, knob(al, K_LANE_MIN_PAIRS, 0));
           if (knob(al, K_LANE_DEBUG, 0) && al->ws) {  // development aid (build with -DWFA_LANE_DEBUG_COUNTERS=1)
             unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             hipStreamSynchronize(stream); hipMemcpy(c, al->ws, sizeof(c), hipMemcpyDeviceToHost); hipMemset(al->ws, 0, sizeof(c));

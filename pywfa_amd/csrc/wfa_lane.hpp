@@ -646,14 +646,14 @@ inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_
 inline int launch_lane(int shape_idx, int g, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, const uint32_t* words,
                        const WfaPairMeta* meta, const uint32_t* worklist, const uint32_t* nwork_dev, uint32_t nwork,
                        int32_t* score, int32_t* status, uint32_t* fb_list, uint32_t* fb_count, int32_t* debug_counters = nullptr, int lds_pad_kb = 0,
-                       int X = 0, int OE = 0, int E = 0) {
+                       int X = 0, int OE = 0, int E = 0, int min_pairs = 0) {
   FastArgs a;
   a.words = words; a.meta = meta; a.worklist = worklist; a.nwork_dev = nwork_dev; a.nwork = nwork;
   a.score = score; a.status = status; a.fb_list = fb_list; a.fb_count = fb_count;
   a.g = g;
   a.hist = debug_counters; a.hist_stride = 0; a.end_state = nullptr; a.work_begin = 0;
   a.ef = a.pbf = a.pef = a.tbf = a.tef = 0; a.heur = 0; a.min_wf_len = a.max_dist_thr = a.steps_between = 0; a.max_steps = INT_MAX;
-  return launch_lane_args(shape_idx, OE, E, cu_count, per_cu, refill_min, max_len, stream, a, false, lds_pad_kb, 0, false, X);
+  return launch_lane_args(shape_idx, OE, E, cu_count, per_cu, refill_min, max_len, stream, a, false, lds_pad_kb, min_pairs, false, X);
 }
 
 inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full, int lds_pad_kb, int min_pairs, bool heur, int X) {
@@ -663,8 +663,11 @@ inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_
   const size_t smem = ((size_t)64 * slot_words + 8) * sizeof(uint32_t) + (size_t)lds_pad_kb * 1024;   // (lds_pad_kb: occupancy experiments)
   // every wave should see several hundred pairs (64 lanes x a few refills), and there should be several waves per SIMD
   long long grid = (long long)cu_count * per_cu;
-  // a wave should see a few refills' worth of pairs
-  if (min_pairs <= 0) min_pairs = 256;
+  // a wave should see a few refills' worth of pairs (256) — when the batch is large enough to give every SIMD four such waves.  A smaller
+  // batch is cut into more waves of fewer pairs, down to one lane-full each: a run is then as long as a wave's life, and 256 pairs per
+  // wave made every score-only run of up to 260 k pairs last 275 us (65 536 pairs: 274 -> 155 us with 64; 1 M pairs: 550 us with 256, 616
+  // with 64; tools/probes/midbatch_probe.py).  The full-CIGAR form keeps 256 (its walks like long lists: C1 1.06 ms against 1.11).
+  if (min_pairs <= 0) min_pairs = full ? 256 : (int)std::max<long long>(64, std::min<long long>(256, (long long)nwork / ((long long)cu_count * 16)));
   const long long max_grid = ((long long)nwork + min_pairs - 1) / std::max(min_pairs, 64);
   if (!nwork_dev && grid > max_grid) grid = max_grid;
   if (grid < 1) grid = 1;
