@@ -31,7 +31,7 @@ struct FastArgs {
   uint32_t* fb_count;
   int g;  // score step = gcd(x, o+e, e)
   // full-CIGAR variant of the segmented kernel (wfa_seg.hpp): history slot per work item of this launch
-  int32_t* hist;          // slot t: hist + t * hist_stride, records of W entries {M, I, D, -} x int16
+  int32_t* hist;          // slot t: hist + t * hist_stride: piggy-back code records of W bytes (one per step), then the walk's events and runs
   long long hist_stride;  // ints per slot
   int4* end_state;        // per slot {end score, end k, end offset, 1 = walk it}
   uint32_t work_begin;    // first work item of this launch (slot = item - work_begin)

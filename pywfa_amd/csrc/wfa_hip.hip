@@ -1728,7 +1728,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     }
     // Round 3: the 16-diagonal stage of that cascade is the lane-per-pair kernel with origin codes (wfa_lane_kernel<.., FULL>):
     // it walks in-kernel and leaves only run records in HBM (WFA_LANE_RUN_SLOT ints + an end state per pair), so the whole batch
-    // is one launch; WFA_HIP_LANE_FULL=0 keeps round 2's 16-lane segments with explicit offset records
+    // is one launch; WFA_HIP_LANE_FULL=0 keeps the 16-lane segments (round 4: with piggy-back code records) as the first stage
     int lfs_x = 0, lfs_oe = 0, lfs_e = 0;
     const bool lane_shape_fits = wfa::seg_shape(b->dcfg, &lfs_x, &lfs_oe, &lfs_e) != WFA_SHAPE_RTC || wfa::rtc_lane_shape_ok(lfs_x, lfs_oe, lfs_e);
     const bool use_lanefull = use_segfull && n_segfull >= 1 && segfull_w[0] == 16 && knob(al, K_LANE_FULL, 1) != 0 && lane_shape_fits;
@@ -1951,7 +1951,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       fa.heur = b->dcfg.heuristic; fa.min_wf_len = b->dcfg.min_wf_len; fa.max_dist_thr = b->dcfg.max_dist_thr;
       fa.steps_between = b->dcfg.steps_between; fa.max_steps = b->dcfg.max_steps;
       const int shape = wfa::seg_shape(b->dcfg, &lh_x, &lh_oe, &lh_e);
-      if (wfa::launch_lane_args(shape, lh_oe, lh_e, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, fa, false, 0, 256, true, lh_x) != 0) {
+      if (wfa::launch_lane_args(shape, lh_oe, lh_e, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, fa, false, 0, knob(al, K_LANE_MIN_PAIRS, 0), true, lh_x) != 0) {   // (pairs per wave by the size of the batch, as the plain form)
         al->err = "lane kernel launch failed"; return WFA_HIP_EDEVICE;
       }
       if (first_stage) b->last_kernel_pairs = in_n;
