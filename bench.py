@@ -522,7 +522,11 @@ def main():
     if args.gpus != world:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     dist = None
-    backend = "nccl"
+    # (development aid: WFA_BENCH_BACKEND=gloo WFA_BENCH_SHARE_DEVICE=1 runs the N > 1 path with every rank on device 0 of a 1-GPU box —
+    # everything but RCCL itself; the driver's runs use RCCL and one device per rank)
+    backend = os.environ.get("WFA_BENCH_BACKEND", "nccl")
+    if os.environ.get("WFA_BENCH_SHARE_DEVICE") == "1":
+        local_rank = 0
     if world > 1:
         dist = dist_setup(backend, local_rank)
     n_gpus = world
