@@ -73,6 +73,8 @@ struct BandArgs {
   const uint2* lane_codes; // wfa_lane_kernel<.., FULL>: the comparison bits of every wave-step (64 lanes x 8 bytes per record)
   int seg_w;              // > 0: the history was written by wfa_seg_kernel<.., FULL>: piggy-back code records of seg_w bytes, the byte of
                           // diagonal k at k mod seg_w (a.pb = 1)
+  int slim;               // 1: launches that fit wfa_slim_kernel (wfa_slim.hpp: 128 diagonals, gap-affine, wf-adaptive, end-to-end,
+                          // sequences in LDS, score-only or piggy-back split history) take it instead of wfa_band_kernel (same results)
 };
 
 // index of the lowest set bit, ~0u for 0 (v_ffbl_b32 semantics)
@@ -1239,6 +1241,15 @@ int launch_lane_expand(const BandArgs& a, hipStream_t walk_stream, hipStream_t e
 WFA_BAND_SHAPES(WFA_BAND_DECL)
 #undef WFA_BAND_DECL
 int launch_band_s4(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds, long long grid, hipStream_t stream);  // 2p
+// the slim form (wfa_slim.hpp, csrc/k_slim.hip): one translation unit per gap-affine shape
+#define WFA_SLIM_DECL(i, x, oe, e) int launch_slim_s##i(const BandArgs& a, bool full, long long grid, hipStream_t stream);
+WFA_BAND_SHAPES(WFA_SLIM_DECL)
+#undef WFA_SLIM_DECL
+// launches the slim form covers
+inline bool slim_takes(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds) {
+  return a.slim && nch == 2 && adapt && a.heur == 1 && seqlds && a.oe2 == 0 && !a.ef && !a.done && a.debug == 0 &&
+         (!full || (a.split && a.pb));
+}
 
 // configurations the band kernel covers: gap-affine / gap-affine-2p with an instantiated penalty shape
 // (x, o1 + e1, e1 [, o2 + e2, e2]) / gcd; 2p: pywfa's default 4/6/2/24/1
@@ -1292,7 +1303,7 @@ inline int launch_band(const BandArgs& a, int nch, bool full, bool adapt, bool s
 #undef WFA_BAND_LAUNCH2
     return launch_band_rtc(a, nch, full, adapt, seqlds, grid, stream);
   }
-#define WFA_BAND_LAUNCH(i, x, oe, e) if (X == x && OE == oe && E == e) return launch_band_s##i(a, nch, full, adapt, seqlds, grid, stream);
+#define WFA_BAND_LAUNCH(i, x, oe, e) if (X == x && OE == oe && E == e) return slim_takes(a, nch, full, adapt, seqlds) ? launch_slim_s##i(a, full, grid, stream) : launch_band_s##i(a, nch, full, adapt, seqlds, grid, stream);
   WFA_BAND_SHAPES(WFA_BAND_LAUNCH)
 #undef WFA_BAND_LAUNCH
   return launch_band_rtc(a, nch, full, adapt, seqlds, grid, stream);

@@ -42,7 +42,7 @@ static thread_local std::string g_error;
 // never call getenv.
 #define WFA_COUNTER_WORDS 64   // counters of a batch (wfa_hip_batch::d_counters)
 #define WFA_KNOBS(F)                                                                                              \
-  F(ARENA_KB) F(BAND_DEBUG) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
+  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
   F(LANE_FULL) F(LANE_FULL_SPLIT) F(LANE_HEUR) F(SEG_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_ADAPT) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(TILE) F(TILE_T) F(TILE_WT) F(TILE_THREADS) F(TILE_PER_CU) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY) F(PILOT_PCT) F(WIDE_ADAPT_LDS)
@@ -1995,6 +1995,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       const bool seqlds = ((size_t)words * 8 <= 5120) && knob(al, K_BAND_NO_LDS, 0) == 0;
       ba.lds_words = seqlds ? words : 0;
       ba.debug = knob(al, K_BAND_DEBUG, 0);
+      ba.slim = knob(al, K_BAND_SLIM, 1);   // (0: wfa_band_kernel also where wfa_slim_kernel would take the launch)
       ba.h16 = (b->max_len < 32000) ? 1 : 0;
       ba.ef = (b->dcfg.endsfree && (b->dcfg.pbf | b->dcfg.pef | b->dcfg.tbf | b->dcfg.tef)) ? 1 : 0;
       ba.pbf = b->dcfg.pbf; ba.pef = b->dcfg.pef; ba.tbf = b->dcfg.tbf; ba.tef = b->dcfg.tef;

@@ -1,0 +1,67 @@
+"""The slim form of the banded kernel (csrc/wfa_slim.hpp: the C3 hot path — gap-affine, wf-adaptive, end-to-end, reads of 1-10 kb,
+score-only or piggy-back history) against the oracle and against wfa_band_kernel on the same batches (WFA_HIP_BAND_SLIM=0)."""
+import numpy as np
+import pytest
+
+import common
+from oracle import loader
+from pywfa_amd import datagen
+
+pytestmark = pytest.mark.gpu
+
+
+def ragged(seed, n, lmin, lmax, err, indel_bias=0.0):
+    """n pairs with lengths drawn from [lmin, lmax]; indel_bias > 0 deletes runs from every third text so that the end diagonal
+    lies far from diagonal 0 (the window has to travel, and the 128-diagonal form gets its turn)."""
+    rng = np.random.default_rng(seed)
+    pats, txts = [], []
+    for i in range(n):
+        L = int(rng.integers(lmin, lmax + 1))
+        b = datagen.generate(1, L, err, seed * 1000 + i)
+        p, t = datagen.pair_strings(b, 0)
+        if indel_bias and i % 3 == 0:
+            for _ in range(int(indel_bias)):
+                a = int(rng.integers(0, max(1, len(t) - 40)))
+                t = t[:a] + t[a + int(rng.integers(5, 30)):]
+        pats.append(p); txts.append(t)
+    return datagen.from_strings(pats, txts)
+
+
+CONFIGS = [
+    dict(span="end-to-end", heuristic="adaptive"),
+    dict(span="end-to-end", heuristic="adaptive", min_wavefront_length=5, max_distance_threshold=10, steps_between_cutoffs=3),
+    dict(span="end-to-end", heuristic="adaptive", min_wavefront_length=30, max_distance_threshold=90, steps_between_cutoffs=2),
+    dict(span="end-to-end", heuristic="adaptive", max_steps=700),
+    dict(span="end-to-end", heuristic="adaptive", mismatch=4, gap_opening=4, gap_extension=2),
+    dict(span="end-to-end", heuristic="adaptive", mismatch=4, gap_opening=6, gap_extension=1),
+    dict(span="end-to-end", heuristic="adaptive", mismatch=3, gap_opening=4, gap_extension=1),
+    dict(span="end-to-end", heuristic="adaptive", mismatch=2, gap_opening=2, gap_extension=1),
+]
+
+
+@pytest.mark.parametrize("scope", ["full", "score"])
+@pytest.mark.parametrize("cfg_idx", range(len(CONFIGS)))
+def test_slim_kernel_matches_oracle_and_band_kernel(gpu, cfg_idx, scope, monkeypatch):
+    batches = [ragged(31 + cfg_idx, 96, 1100, 4000, 0.08, indel_bias=6), datagen.generate(48, 10000, 0.08, 4100 + cfg_idx),
+               ragged(77 + cfg_idx, 64, 1200, 9000, 0.03), datagen.generate(200, 1500, 0.15, 4200 + cfg_idx)]
+    for bi, batch in enumerate(batches):
+        kw = dict(CONFIGS[cfg_idx], scope=scope)
+        oc, nc = common.configs_pair(**kw)
+        full = oc.scope == 1
+        o = loader.run(loader.oracle(), oc, batch, want_cigar=full)
+        monkeypatch.delenv("WFA_HIP_BAND_SLIM", raising=False)
+        score, status, cigars = common.gpu_run(nc, batch, full, resident=(bi % 2 == 0))
+        common.assert_same(o, score, status, cigars, batch, f"slim {kw} batch {bi}")
+        monkeypatch.setenv("WFA_HIP_BAND_SLIM", "0")
+        score0, status0, cigars0 = common.gpu_run(nc, batch, full, resident=(bi % 2 == 0))
+        assert np.array_equal(score, score0) and np.array_equal(status, status0) and cigars == cigars0
+
+
+def test_slim_kernel_window_overflow_is_handed_on(gpu):
+    """Reads whose wavefront outgrows the 128 diagonals (a cut-off that keeps everything) go on to the 256-diagonal stage."""
+    batch = datagen.generate(40, 6000, 0.12, 515)
+    kw = dict(span="end-to-end", heuristic="adaptive", min_wavefront_length=10, max_distance_threshold=400, scope="full")
+    oc, nc = common.configs_pair(**kw)
+    o = loader.run(loader.oracle(), oc, batch)
+    score, status, cigars = common.gpu_run(nc, batch, True, resident=True)
+    common.assert_same(o, score, status, cigars, batch, "slim, wide wavefronts")
