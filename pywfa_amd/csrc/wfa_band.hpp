@@ -73,6 +73,10 @@ struct BandArgs {
   const uint2* lane_codes; // wfa_lane_kernel<.., FULL>: the comparison bits of every wave-step (64 lanes x 8 bytes per record)
   int seg_w;              // > 0: the history was written by wfa_seg_kernel<.., FULL>: piggy-back code records of seg_w bytes, the byte of
                           // diagonal k at k mod seg_w (a.pb = 1)
+  int pb_raw;             // piggy-back codes written by wfa_slim_kernel: the four comparison bits as they fall out of the subtractions
+                          // (bit 3: mismatch below the best gap, 2: deletion below insertion, 1 / 0: extension of I / D below its
+                          // opening); the walk maps them to the codes above through a 16-entry table
+  uint32_t* dbg;          // counting builds (-DWFA_SLIM_COUNTERS=1) with WFA_HIP_STAGE_TIMING=1: eight counters of wfa_slim_kernel
   int slim;               // 1: launches that fit wfa_slim_kernel (wfa_slim.hpp: 128 diagonals, gap-affine, wf-adaptive, end-to-end,
                           // sequences in LDS, score-only or piggy-back split history) take it instead of wfa_band_kernel (same results)
 };
@@ -867,7 +871,8 @@ wfa_band_pb_bt_kernel(const BandArgs a) {
   // ---- walk the codes back from the end cell (R/wavefront_backtrace.c:320-529 with the choices made at compute time)
   int si = es.x / a.g, k = es.y, comp = 0, nev = 0;
   while (si > 0 && nev < ev_cap) {
-    const int cd = codes[(long long)si * W + (k & (W - 1))];
+    int cd = codes[(long long)si * W + (k & (W - 1))];
+    if (a.pb_raw) cd = (int)((0x2a6e195d084c084cull >> ((cd & 15) * 4)) & 15ull);   // comparison bits -> origin codes (wfa_slim.hpp)
     if (two) {
       // comp: 0 M, 1 I1, 2 D1, 3 I2, 4 D2; an event flagged 0x80 lands in M (a run of matches follows it)
       const int src = (comp == 0) ? (cd & 7) : (comp == 1) ? 3 : (comp == 2) ? 1 : (comp == 3) ? 4 : 2;  // 0 X, 1 D1, 2 D2, 3 I1, 4 I2
@@ -1291,6 +1296,17 @@ inline int launch_band_rtc(const BandArgs& a, int nch, bool full, bool adapt, bo
                            std::to_string(OE2) + ", " + std::to_string(E2) + ">";
   const size_t smem = seqlds ? (size_t)a.lds_words * 2 * sizeof(uint32_t) : 0;
   return rtc_launch("wfa_band.hpp", name, (unsigned)grid, 64, smem, stream, &a, sizeof(a));
+}
+
+// true when launch_band() sends this launch to wfa_slim_kernel: slim_takes() and a shape the library has an instantiation of
+// (the host sets BandArgs::pb_raw from it before the launch: the walk must know which kernel wrote the codes)
+inline bool slim_launches(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds) {
+  if (!slim_takes(a, nch, full, adapt, seqlds) || (rtc_force_all() && rtc_available())) return false;
+  const int g = a.g, X = a.x / g, OE = a.oe / g, E = a.e / g;
+#define WFA_SLIM_MATCH(i, x, oe, e) if (X == x && OE == oe && E == e) return true;
+  WFA_BAND_SHAPES(WFA_SLIM_MATCH)
+#undef WFA_SLIM_MATCH
+  return false;
 }
 
 inline int launch_band(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds, long long grid, hipStream_t stream) {

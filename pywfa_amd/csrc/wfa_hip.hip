@@ -1996,6 +1996,11 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
       ba.lds_words = seqlds ? words : 0;
       ba.debug = knob(al, K_BAND_DEBUG, 0);
       ba.slim = knob(al, K_BAND_SLIM, 1);   // (0: wfa_band_kernel also where wfa_slim_kernel would take the launch)
+      ba.pb_raw = 0;
+      if (knob(al, K_STAGE_TIMING, 0) != 0 && b->max_len > WFA_FAST_MAX_LEN) {   // (counting builds; [8..15] belong to the short-read stages otherwise)
+        ba.dbg = b->d_counters + 8;
+        (void)hipMemsetAsync(b->d_counters + 8, 0, 8 * sizeof(uint32_t), stream);
+      }
       ba.h16 = (b->max_len < 32000) ? 1 : 0;
       ba.ef = (b->dcfg.endsfree && (b->dcfg.pbf | b->dcfg.pef | b->dcfg.tbf | b->dcfg.tef)) ? 1 : 0;
       ba.pbf = b->dcfg.pbf; ba.pef = b->dcfg.pef; ba.tbf = b->dcfg.tbf; ba.tef = b->dcfg.tef;
@@ -2044,6 +2049,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
           ba.work_begin = (uint32_t)w0; ba.nwork = cnt;
           const long long grid = std::min<long long>((long long)al->cu_count * knob(al, K_BAND_WAVES_PER_CU, 128), cnt);
           if (!all_fit) { const int drc = dual.before_align(launch); if (drc != WFA_HIP_OK) return drc; }
+          ba.pb_raw = wfa::slim_launches(ba, band_nch[i], full, adapt, seqlds) ? 1 : 0;   // (wfa_slim_kernel writes comparison bits; the walk below decodes them)
           if (wfa::launch_band(ba, band_nch[i], full, adapt, seqlds, grid, stream) != 0) { al->err = "band kernel launch failed"; return WFA_HIP_EDEVICE; }
           hipStream_t ws_ = stream;
           { const int drc = dual.walk_stream(launch, &ws_); if (drc != WFA_HIP_OK) return drc; }
@@ -2064,6 +2070,11 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
         const auto t_now = std::chrono::steady_clock::now();
         fprintf(stderr, "[wfa_hip] band stage %d (%d diagonals): took %u pairs, handed on %u; %.3f ms\n", i, 64 * band_nch[i], took, handed,
                 std::chrono::duration<double, std::milli>(t_now - band_prev).count());
+        if (ba.dbg) {
+          uint32_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)hipMemcpy(dbg, ba.dbg, sizeof(dbg), hipMemcpyDeviceToHost);
+          if (dbg[0] | dbg[1]) fprintf(stderr, "[wfa_hip]   slim counters: steps of 64 diagonals %u, of 128 %u, extension rounds %u, cut-offs that cut %u, window shifts %u, end trims %u, live diagonals / 64 %u\n",
+                                       dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6]);
+        }
         band_prev = std::chrono::steady_clock::now();
       }
       if (first_stage) b->last_kernel_pairs = in_n;

@@ -24,9 +24,10 @@
 namespace wfa {
 
 // wave-wide minimum: butterflies inside the rows of 16 lanes, then row_bcast:15 / row_bcast:31 carry it to lane 63
-__device__ __forceinline__ int slim_wave_min(int v) {
+__device__ __forceinline__ int slim_wave_min(int x) {
+  int v;
   asm("s_nop 1\n\t"
-      "v_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_min_i32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
       "s_nop 1\n\t"
       "v_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
       "s_nop 1\n\t"
@@ -36,9 +37,8 @@ __device__ __forceinline__ int slim_wave_min(int v) {
       "s_nop 1\n\t"
       "v_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
       "s_nop 1\n\t"
-      "v_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "s_nop 1"
-      : "+v"(v));
+      "v_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+      : "=&v"(v) : "v"(x));
   return __builtin_amdgcn_readlane(v, 63);
 }
 
@@ -95,14 +95,14 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
     int stop_status = 0, stop_score = 0;
     bool done = false;
     if (!fallback) {
-      // per lane and chunk (doubled): kk2 = 2k, lim2 = 2 min(tlen, plen + k), dlim2 = 2 max(tlen, plen + k)
-      int kk2[NCH], lim2[NCH], dlim2[NCH], cur[NCH], Mh[DM][NCH], Ih[E][NCH], Dh[E][NCH];
+      // per lane and chunk (doubled): kk2 = 2k, lim2 = 2 min(tlen, plen + k) (lim2c: not below 0), dlim2 = 2 max(tlen, plen + k)
+      int kk2[NCH], lim2[NCH], lim2c[NCH], dlim2[NCH], cur[NCH], Mh[DM][NCH], Ih[E][NCH], Dh[E][NCH];
       uint32_t hoff[NCH];  // byte of this diagonal in the history record compute-next fills: (step + 1) * 128 + (k mod 128)
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         const int k = B + c * 64 + lane;
         kk2[c] = 2 * k; hoff[c] = WI + ((uint32_t)k & (WI - 1));
-        lim2[c] = 2 * min(tlen, plen + k); dlim2[c] = 2 * max(tlen, plen + k);
+        lim2[c] = 2 * min(tlen, plen + k); lim2c[c] = max(lim2[c], 0); dlim2[c] = 2 * max(tlen, plen + k);
         cur[c] = (k == 0) ? 0 : NUL;  // wavefront 0
 #pragma unroll
         for (int j = 0; j < E; ++j) { Ih[j][c] = NUL; Dh[j][c] = NUL; }
@@ -119,6 +119,9 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
       int tlen2_eff = INT_MAX;    // 2 tlen while the end diagonal lies in an active chunk (the termination test reads lane akp & 63)
       bool big = true;
       int leave = 0;              // 1 reached the end, 2 step limit, 3 hand the pair on
+#ifdef WFA_SLIM_COUNTERS
+      uint32_t cnt_small = 0, cnt_big = 0, cnt_rounds = 0, cnt_cut = 0, cnt_shift = 0, cnt_oob = 0, cnt_live = 0;
+#endif
       int togo = 0;               // steps left in the block of HP (an ending clears it)
 
       // One score step on ACT active chunks.  Every branch is a scalar branch and nothing leaves the step early: an ending sets
@@ -128,22 +131,29 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
         constexpr int ACT = decltype(act_tag)::value;
         // ---------------- extend M[s] (R/wavefront_extend_kernels.c:64-110) ----------------
         unsigned long long live[NCH] = {0ull, 0ull};
+        unsigned long long keep[NCH] = {~0ull, ~0ull};   // lanes the cut-off keeps (all, unless it moves the wavefront's limits)
         {
-          // (dead lanes: clamped coordinates, nothing left to compare — they repeat a probe of 0 bits)
-          int h2[NCH], v2[NCH], left2[NCH];
+          // (a dead lane is parked at the end of its diagonal: nothing to compare, and its reads stay inside the staged words)
+          int h2[NCH], v2[NCH];
 #pragma unroll
           for (int c = 0; c < ACT; ++c) {
-            h2[c] = max(cur[c], 0); v2[c] = max(cur[c] - kk2[c], 0);
-            left2[c] = (cur[c] >= 0) ? lim2[c] - cur[c] : 0;
+            h2[c] = (cur[c] >= 0) ? cur[c] : lim2c[c];
+            v2[c] = h2[c] - kk2[c];
           }
+#ifdef WFA_SLIM_COUNTERS
+          if (ACT == 1) ++cnt_small; else ++cnt_big;
+#endif
           bool more;
           do {
             more = false;
+#ifdef WFA_SLIM_COUNTERS
+            ++cnt_rounds;
+#endif
 #pragma unroll
             for (int c = 0; c < ACT; ++c) {
-              const uint32_t m2 = min(min(slim_probe(sP, sT, v2[c], h2[c]), (uint32_t)left2[c]), 64u);
-              v2[c] += (int)m2; h2[c] += (int)m2; left2[c] -= (int)m2;
-              more |= (m2 == 64u);   // (a lane that stopped repeats its last probe: 0 bits)
+              const uint32_t m2 = min(slim_probe(sP, sT, v2[c], h2[c]), 64u);
+              v2[c] += (int)m2; h2[c] += (int)m2;
+              more |= (m2 == 64u) && (h2[c] < lim2[c]);   // (past the end the zero padding of both sequences would match on)
             }
           } while (__builtin_amdgcn_ballot_w64(more) != 0ull);
 #pragma unroll
@@ -152,11 +162,14 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
             asm("" : "+v"(cc));   // (a compare of its own: carried across the loop above, the first one's mask takes a round trip through a VGPR)
             const bool lv = cc >= 0;
             live[c] = __builtin_amdgcn_ballot_w64(lv);
-            cur[c] = lv ? h2[c] : cc;
+            cur[c] = lv ? min(h2[c], lim2[c]) : cc;
           }
         }
         if (live[0] | live[1]) {
           dead_steps = 0;
+#ifdef WFA_SLIM_COUNTERS
+          cnt_live += (uint32_t)__builtin_popcountll(live[0]) + (uint32_t)__builtin_popcountll(live[1]);
+#endif
           // ---------------- termination (R/wavefront_termination.c:37-61) ----------------
           int at_end;
           if (ACT == 1) at_end = __builtin_amdgcn_readlane(cur[0], akp & 63);
@@ -186,15 +199,16 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
               steps_wait = a.steps_between;
               // the wavefront's limits changed <=> a live lane lies outside them; then M, I, D are cut to them (the equate)
               if (ACT == 1) {
-                const unsigned long long keep = (~0ull << new_lo) & (~0ull >> (63 - new_hi));
-                if (live[0] & ~keep) { slim_keep(cur[0], keep); slim_keep(Ih[0][0], keep); slim_keep(Dh[0][0], keep); }
+                const unsigned long long kp = (~0ull << new_lo) & (~0ull >> (63 - new_hi));
+                if (live[0] & ~kp) keep[0] = kp;
+#ifdef WFA_SLIM_COUNTERS
+                if (live[0] & ~kp) ++cnt_cut;
+#endif
               } else if (new_lo != lo_p || new_hi != hi_p) {
-#pragma unroll
-                for (int c = 0; c < ACT; ++c) {
-                  const int p = c * 64 + lane;
-                  const bool kp = p >= new_lo && p <= new_hi;
-                  cur[c] = kp ? cur[c] : NUL; Ih[0][c] = kp ? Ih[0][c] : NUL; Dh[0][c] = kp ? Dh[0][c] : NUL;
-                }
+                // (positions 0..127 over two masks)
+                const unsigned long long lo0 = (new_lo < 64) ? (~0ull << new_lo) : 0ull, lo1 = (new_lo < 64) ? ~0ull : (~0ull << (new_lo - 64));
+                const unsigned long long hi0 = (new_hi < 64) ? (~0ull >> (63 - new_hi)) : ~0ull, hi1 = (new_hi < 64) ? 0ull : (~0ull >> (127 - new_hi));
+                keep[0] = lo0 & hi0; keep[1] = lo1 & hi1;
               }
             }
           }
@@ -203,6 +217,9 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
           if (++dead_steps > 2 * DM + 2) { leave = 3; togo = 0; }
         }
         if (leave == 0) {
+          // (the cut, in each value's own register and without a branch: the paths of the step join on scalars only)
+#pragma unroll
+          for (int c = 0; c < ACT; ++c) { slim_keep(cur[c], keep[c]); slim_keep(Ih[0][c], keep[c]); slim_keep(Dh[0][c], keep[c]); }
           // ---------------- compute-next for score s + g (R/wavefront_compute_affine.c:44-86) ----------------
 #pragma unroll
           for (int j = DM - 1; j > 0; --j)
@@ -235,8 +252,12 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
               // opening on equal offsets), taken where the candidates are in registers
               // — the piggy-back history of score s + g: one byte per active diagonal, stored here (the window may move before the
               // next step begins; the record of score 0 is never read)
-              const int mc = (x1 >= t) ? 0 : ((nd[c] >= ni[c]) ? 1 : 2);
-              rec[hoff[c]] = (uint8_t)(mc | ((ie_lo >= mo_lo) ? 4 : 0) | ((de_hi >= mo_hi) ? 8 : 0));
+              // (BandArgs::pb_raw: the sign bits of four subtractions, shifted in one after the other)
+              uint32_t cd = (uint32_t)(x1 - t) >> 31;
+              cd = __builtin_amdgcn_alignbit(cd, (uint32_t)(nd[c] - ni[c]), 31);
+              cd = __builtin_amdgcn_alignbit(cd, (uint32_t)(ie_lo - mo_lo), 31);
+              cd = __builtin_amdgcn_alignbit(cd, (uint32_t)(de_hi - mo_hi), 31);
+              rec[hoff[c]] = (uint8_t)cd;
               hoff[c] += WI;   // (an inactive chunk's offset is set again when it joins)
             }
             cur[c] = (m > lim2[c]) ? NUL : m;  // only M is clamped; negative values are dead already
@@ -248,6 +269,9 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
             for (int c = 0; c < ACT; ++c) { Ih[j][c] = Ih[j - 1][c]; Dh[j][c] = Dh[j - 1][c]; }
 #pragma unroll
           for (int c = 0; c < ACT; ++c) { Ih[0][c] = ni[c]; Dh[0][c] = nd[c]; }
+#ifdef WFA_SLIM_COUNTERS
+          if (oob) ++cnt_oob;
+#endif
           if (oob) {
             // trim the ends of I and D (R/wavefront_compute.c:571-605): outside [first, last] in-bounds -> NULL
             unsigned long long bi[NCH] = {0ull, 0ull}, bd[NCH] = {0ull, 0ull};
@@ -293,6 +317,9 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
             const bool want_small = width <= (big ? WS - 2 * HP - 6 : WS - 2 * HP - 2);
             const int wa = want_small ? WS : W;
             if (fp < HP + 1 || lp > wa - HP - 2) {
+#ifdef WFA_SLIM_COUNTERS
+              ++cnt_shift;
+#endif
               const int delta = fp - (wa - width) / 2;   // re-centre in the window (or in its small form)
               B += delta; akp -= delta;
               if (!big && want_small) {
@@ -323,7 +350,7 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
               for (int c = 0; c < NCH; ++c) {
                 const int k = B + c * 64 + lane;
                 kk2[c] = 2 * k; hoff[c] = (uint32_t)(step + 1) * WI + ((uint32_t)k & (WI - 1));
-                lim2[c] = 2 * min(tlen, plen + k); dlim2[c] = 2 * max(tlen, plen + k);
+                lim2[c] = 2 * min(tlen, plen + k); lim2c[c] = max(lim2[c], 0); dlim2[c] = 2 * max(tlen, plen + k);
               }
             } else if (!big && !want_small) {
               // small -> big without a shift: the inactive chunk joins as NULLs
@@ -347,6 +374,12 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
           while (togo > 0) { --togo; step_fn(band_int<2>{}); }
         }
       }
+#ifdef WFA_SLIM_COUNTERS
+      if (a.dbg && lane == 0) {
+        atomicAdd(a.dbg + 0, cnt_small); atomicAdd(a.dbg + 1, cnt_big); atomicAdd(a.dbg + 2, cnt_rounds); atomicAdd(a.dbg + 3, cnt_cut);
+        atomicAdd(a.dbg + 4, cnt_shift); atomicAdd(a.dbg + 5, cnt_oob); atomicAdd(a.dbg + 6, cnt_live >> 6);
+      }
+#endif
       const int s_end = step * a.g;
       if (leave == 1) { done = true; result = -s_end; end_k = ak; end_off = tlen; end_s = s_end; }
       else if (leave == 2) { stop_status = WFA_STATUS_MAX_STEPS_REACHED; stop_score = -a.max_steps; }
