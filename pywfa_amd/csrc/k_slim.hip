@@ -1,10 +1,10 @@
-// k_slim.hip — translation unit of the slim form of the banded kernel (wfa_slim.hpp) for ONE gap-affine penalty shape,
-// compiled once per index (-DWFA_TU_INDEX=i, csrc/build.sh): the shapes of WFA_BAND_SHAPES.
+// k_slim.hip — translation unit of the slim form of the banded kernel (wfa_slim.hpp) for ONE penalty shape, compiled once per
+// index (-DWFA_TU_INDEX=i, csrc/build.sh): 0..3 = the gap-affine shapes of WFA_BAND_SHAPES, 4 = gap-affine-2p 4/6/2/24/1.
 #include "wfa_slim.hpp"
 
 namespace wfa {
 #define WFA_SLIM_DEFINE(i, x, oe, e) \
-  int launch_slim_s##i(const BandArgs& a, bool full, long long grid, hipStream_t s) { return launch_slim_shape<x, oe, e>(a, full, grid, s); }
+  int launch_slim_s##i(const BandArgs& a, bool full, long long grid, hipStream_t s) { return launch_slim_shape<x, oe, e, 0, 0>(a, full, grid, s); }
 #if WFA_TU_INDEX == 0
 WFA_SLIM_DEFINE(0, 2, 4, 1)
 #elif WFA_TU_INDEX == 1
@@ -13,7 +13,9 @@ WFA_SLIM_DEFINE(1, 2, 3, 1)
 WFA_SLIM_DEFINE(2, 4, 7, 1)
 #elif WFA_TU_INDEX == 3
 WFA_SLIM_DEFINE(3, 3, 5, 1)
+#elif WFA_TU_INDEX == 4
+int launch_slim_s4(const BandArgs& a, bool full, long long grid, hipStream_t s) { return launch_slim_shape<4, 8, 2, 25, 1>(a, full, grid, s); }
 #else
-#error "WFA_TU_INDEX: 0..3 = the gap-affine shapes of WFA_BAND_SHAPES"
+#error "WFA_TU_INDEX: 0..3 = the gap-affine shapes of WFA_BAND_SHAPES, 4 = gap-affine-2p"
 #endif
 }  // namespace wfa

@@ -872,7 +872,15 @@ wfa_band_pb_bt_kernel(const BandArgs a) {
   int si = es.x / a.g, k = es.y, comp = 0, nev = 0;
   while (si > 0 && nev < ev_cap) {
     int cd = codes[(long long)si * W + (k & (W - 1))];
-    if (a.pb_raw) cd = (int)((0x2a6e195d084c084cull >> ((cd & 15) * 4)) & 15ull);   // comparison bits -> origin codes (wfa_slim.hpp)
+    if (a.pb_raw) {   // comparison bits of wfa_slim_kernel -> origin codes
+      if (two) {
+        const int r = cd;
+        const int mc = !(r & 128) ? 0 : !(r & 64) ? 2 : !(r & 32) ? 1 : !(r & 16) ? 4 : 3;
+        cd = mc | ((r & 8) ? 0 : 8) | ((r & 4) ? 0 : 16) | ((r & 2) ? 0 : 32) | ((r & 1) ? 0 : 64);
+      } else {
+        cd = (int)((0x2a6e195d084c084cull >> ((cd & 15) * 4)) & 15ull);
+      }
+    }
     if (two) {
       // comp: 0 M, 1 I1, 2 D1, 3 I2, 4 D2; an event flagged 0x80 lands in M (a run of matches follows it)
       const int src = (comp == 0) ? (cd & 7) : (comp == 1) ? 3 : (comp == 2) ? 1 : (comp == 3) ? 4 : 2;  // 0 X, 1 D1, 2 D2, 3 I1, 4 I2
@@ -1250,10 +1258,10 @@ int launch_band_s4(const BandArgs& a, int nch, bool full, bool adapt, bool seqld
 #define WFA_SLIM_DECL(i, x, oe, e) int launch_slim_s##i(const BandArgs& a, bool full, long long grid, hipStream_t stream);
 WFA_BAND_SHAPES(WFA_SLIM_DECL)
 #undef WFA_SLIM_DECL
-// launches the slim form covers
+int launch_slim_s4(const BandArgs& a, bool full, long long grid, hipStream_t stream);  // 2p
+// launches the slim form covers: the first window of the wf-adaptive long-read cascade (128 diagonals, gap-affine-2p: 192)
 inline bool slim_takes(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds) {
-  return a.slim && nch == 2 && adapt && a.heur == 1 && seqlds && a.oe2 == 0 && !a.ef && !a.done && a.debug == 0 &&
-         (!full || (a.split && a.pb));
+  return a.slim && nch == (a.oe2 > 0 ? 3 : 2) && adapt && a.heur == 1 && seqlds && !a.done && a.debug == 0 && (!full || (a.split && a.pb));
 }
 
 // configurations the band kernel covers: gap-affine / gap-affine-2p with an instantiated penalty shape
@@ -1303,6 +1311,13 @@ inline int launch_band_rtc(const BandArgs& a, int nch, bool full, bool adapt, bo
 inline bool slim_launches(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds) {
   if (!slim_takes(a, nch, full, adapt, seqlds) || (rtc_force_all() && rtc_available())) return false;
   const int g = a.g, X = a.x / g, OE = a.oe / g, E = a.e / g;
+  if (a.oe2 > 0) {
+    const int OE2 = a.oe2 / g, E2 = a.e2 / g;
+#define WFA_SLIM_MATCH2(x_, oe_, e_, oe2_, e2_) if (X == x_ && OE == oe_ && E == e_ && OE2 == oe2_ && E2 == e2_) return true;
+    WFA_BAND_SHAPES_2P(WFA_SLIM_MATCH2)
+#undef WFA_SLIM_MATCH2
+    return false;
+  }
 #define WFA_SLIM_MATCH(i, x, oe, e) if (X == x && OE == oe && E == e) return true;
   WFA_BAND_SHAPES(WFA_SLIM_MATCH)
 #undef WFA_SLIM_MATCH
@@ -1314,7 +1329,7 @@ inline int launch_band(const BandArgs& a, int nch, bool full, bool adapt, bool s
   if (rtc_force_all() && rtc_available()) return launch_band_rtc(a, nch, full, adapt, seqlds, grid, stream);
   if (a.oe2 > 0) {
     const int OE2 = a.oe2 / g, E2 = a.e2 / g;
-#define WFA_BAND_LAUNCH2(x_, oe_, e_, oe2_, e2_) if (X == x_ && OE == oe_ && E == e_ && OE2 == oe2_ && E2 == e2_) return launch_band_s4(a, nch, full, adapt, seqlds, grid, stream);
+#define WFA_BAND_LAUNCH2(x_, oe_, e_, oe2_, e2_) if (X == x_ && OE == oe_ && E == e_ && OE2 == oe2_ && E2 == e2_) return slim_takes(a, nch, full, adapt, seqlds) ? launch_slim_s4(a, full, grid, stream) : launch_band_s4(a, nch, full, adapt, seqlds, grid, stream);
     WFA_BAND_SHAPES_2P(WFA_BAND_LAUNCH2)
 #undef WFA_BAND_LAUNCH2
     return launch_band_rtc(a, nch, full, adapt, seqlds, grid, stream);

@@ -1,25 +1,37 @@
-// wfa_slim.hpp — the slim form of the banded kernel (wfa_band.hpp): the step of the long-read hot path (BASELINE C3: 10 kb reads,
-// gap-affine, wf-adaptive, full CIGAR) rebuilt around its instruction count.  Same algorithm, same window (128 diagonals that
-// slide, 64 of them active while the hull of the ring fits), same piggy-back history and the same results as
-// wfa_band_kernel<2, FULL, true, true, FULL, FULL, X, OE, E, 0, 0>; what differs is what a wave issues per score step
-// (R = /root/reference/pywfa/WFA2_lib/wavefront):
+// wfa_slim.hpp — the slim form of the banded kernel (wfa_band.hpp): the step of the long-read hot paths (BASELINE C3: 10 kb reads,
+// gap-affine, wf-adaptive, full CIGAR; C4 with wf-adaptive: gap-affine-2p, ends-free) rebuilt around its instruction count.  Same
+// algorithm, same sliding window (128 diagonals for gap-affine, 192 for gap-affine-2p), same piggy-back history layout and the same
+// results as wfa_band_kernel<NCH, FULL, true, true, FULL, FULL, X, OE, E, OE2, E2>; what differs is what a wave issues per score
+// step (R = /root/reference/pywfa/WFA2_lib/wavefront):
 //   * offsets are kept DOUBLED (2 x h): an offset is then the bit position of its base in the 2-bit packed text, the extension
 //     (R/wavefront_extend_kernels.c:64-110) needs no conversion on the way in or out, and every comparison of the step is
 //     invariant under the scaling;
-//   * no divergent branch inside the step: every branch of the loop is a scalar branch, so the compiler keeps the control flow as
-//     written (one lane-dependent `if` makes it linearise the whole loop body behind flag registers);
+//   * no divergent branch and no early exit inside the step: every branch of the loop is a scalar branch and the loops have one
+//     exit each, so the compiler keeps the control flow as written (one lane-dependent `if`, or a `break`, makes it linearise the
+//     whole loop body behind flag registers);
+//   * the step runs on the ACTIVE chunks only — 1 .. NCH chunks of 64 diagonals, chosen once per block of 8 steps at the hull check
+//     — as one straight body per count: the 2p form of wfa_band_kernel always walks its 192 diagonals although the wavefront a
+//     cut-off keeps is a few dozen diagonals wide once the free begin has been trimmed;
 //   * the wf-adaptive cut-off (R/wavefront_heuristic.c:176-293) takes its wave minimum in six DPP steps, its limits in window
-//     positions from two 64-bit masks, and drops lanes through a mask — no per-chunk position arithmetic in the 64-diagonal form;
-//   * the k-1 / k+1 neighbours (R/wavefront_compute_affine.c:44-86) come through registers whose edge lane is NULL for good, so a
-//     shift is one DPP move;
-//   * the 64- and the 128-diagonal form are two straight step bodies, chosen once per block of 8 steps at the hull check, so the
-//     inactive chunk costs nothing;
-//   * one piggy-back byte per ACTIVE diagonal and step is stored (64 B instead of 128 B per step in the small form).
-// Scope: gap-affine, match = 0, wf-adaptive, end-to-end, sequences staged in LDS (reads <= 10 kb), score-only or piggy-back
-// history of a split launch.  Everything else stays with wfa_band_kernel; a pair whose window overflows is handed on exactly as
-// there.
+//     positions from 64-bit masks, and drops lanes through a mask in each value's own register;
+//   * termination (R/wavefront_termination.c:37-61, 115-162) is one compare per chunk against a per-lane threshold that folds the
+//     end-to-end cell and both ends-free borders;
+//   * the k-1 / k+1 neighbours (R/wavefront_compute_affine.c:44-86, R/wavefront_compute_affine2p.c:45-106) of the one-chunk form
+//     come through registers whose edge lane is NULL for good, so a shift is one DPP move;
+//   * one piggy-back byte per ACTIVE diagonal and step: the sign bits of the candidates' differences as they fall out of the
+//     subtractions (BandArgs::pb_raw; the walk decodes them).
+// Scope: gap-affine / gap-affine-2p with an instantiated shape, match = 0, wf-adaptive, end-to-end or ends-free, sequences staged
+// in LDS (reads <= 10 kb), score-only or the piggy-back history of a split launch.  Everything else stays with wfa_band_kernel; a
+// pair whose window overflows is handed on exactly as there.
 #pragma once
 #include "wfa_band.hpp"
+
+#ifndef WFA_SLIM_WAVES
+#define WFA_SLIM_WAVES 7
+#endif
+#ifndef WFA_SLIM_WAVES_2P
+#define WFA_SLIM_WAVES_2P 3
+#endif
 
 namespace wfa {
 
@@ -48,8 +60,8 @@ __device__ __forceinline__ void slim_keep(int& r, unsigned long long mask) {
   asm("v_cndmask_b32 %0, -2.0, %0, %1" : "+v"(r) : "s"(mask));   // (-2.0 = 0xC0000000 = WFA_OFFSET_NULL)
 }
 
-// one probe of the extension on doubled coordinates: v2 / h2 = bit positions in the packed pattern / text (LDS byte offsets
-// sp / st); returns the number of matching BITS (even, <= 64) before the first difference
+// one probe of the extension on doubled coordinates: v2 / h2 = bit positions in the packed pattern / text; returns the number of
+// matching BITS (even; >= 64: none of the 32 bases differs)
 __device__ __forceinline__ uint32_t slim_probe(const uint32_t* sP, const uint32_t* sT, int v2, int h2) {
   const int pi = v2 >> 5, ti = h2 >> 5;
   const uint32_t p0 = sP[pi], p1 = sP[pi + 1], p2 = sP[pi + 2], t0 = sT[ti], t1 = sT[ti + 1], t2 = sT[ti + 2];
@@ -58,12 +70,22 @@ __device__ __forceinline__ uint32_t slim_probe(const uint32_t* sP, const uint32_
   return min(band_ffbl(xl), band_ffbl(xh) | 32u) & ~1u;   // (v_ffbl_b32 gives ~0 for 0)
 }
 
-template <bool FULL, int X, int OE, int E>
+// lanes of chunk c (window positions 64c .. 64c + 63) inside [lo, hi]
+__device__ __forceinline__ unsigned long long slim_range_mask(int c, int lo, int hi) {
+  const int l = lo - 64 * c, h = hi - 64 * c;
+  if (l > 63 || h < 0) return 0ull;
+  return (~0ull << max(l, 0)) & (~0ull >> (63 - min(h, 63)));
+}
+
+template <int NCH, bool FULL, int X, int OE, int E, int OE2, int E2>
 __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
-  constexpr int NCH = 2;
+  constexpr bool TWO = OE2 > 0;  // gap-affine-2p: second pair of gap components (R/wavefront_compute_affine2p.c:45-106)
+  constexpr int E2D = TWO ? E2 : 1;
   typedef Band<NCH> BD;
-  constexpr int W = 128, WI = 128, WS = 64, HP = 8;
-  constexpr int DM = (X > OE) ? X : OE;
+  constexpr int W = BD::W, WI = BD::WI, HP = 8;
+  constexpr int DM = (X > OE) ? X : OE;                      // M history in registers: depths 1 .. DM
+  constexpr int NP = TWO ? (OE2 - DM + 1) / 2 + 1 : 1;       // 2p: depths DM + 1 .. OE2 as int16 pairs, two depths per register
+  static_assert(!TWO || OE2 > DM, "2p: o2 + e2 is the deepest history read");
   constexpr int NUL = WFA_OFFSET_NULL;
   extern __shared__ uint32_t slds[];
   uint32_t* const sP = slds;
@@ -83,7 +105,7 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
     const uint32_t* gT = a.words + pm.t_woff;
     const int nwp = (plen + 15) >> 4, nwt = (tlen + 15) >> 4;
     bool fallback = false;
-    if (nwp + 3 > a.lds_words || nwt + 3 > a.lds_words || max_records <= 1) fallback = true;
+    if (nwp + 3 > a.lds_words || nwt + 3 > a.lds_words || max_records <= 1 || (TWO && 2 * max(plen, tlen) > 32000)) fallback = true;   // (2p: doubled offsets as int16)
     else {
       __syncthreads();
       for (int i = lane; i < nwp + 3; i += 64) sP[i] = (i < nwp) ? gP[i] : 0u;
@@ -91,47 +113,76 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
       __syncthreads();
     }
     int B = -(W / 2);  // diagonal of window position 0
+    if (a.ef) {
+      // wavefront 0 spans the diagonals [-pattern_begin_free, text_begin_free] (R/wavefront_aligner.c:259-302)
+      if (a.pbf + a.tbf + 1 > W - 20) fallback = true;
+      B = (a.tbf - a.pbf) / 2 - W / 2;
+    }
     int result = 0, end_k = 0, end_off = 0, end_s = 0;
     int stop_status = 0, stop_score = 0;
     bool done = false;
     if (!fallback) {
-      // per lane and chunk (doubled): kk2 = 2k, lim2 = 2 min(tlen, plen + k) (lim2c: not below 0), dlim2 = 2 max(tlen, plen + k)
-      int kk2[NCH], lim2[NCH], lim2c[NCH], dlim2[NCH], cur[NCH], Mh[DM][NCH], Ih[E][NCH], Dh[E][NCH];
-      uint32_t hoff[NCH];  // byte of this diagonal in the history record compute-next fills: (step + 1) * 128 + (k mod 128)
+      // per lane and chunk, doubled: kk2 = 2k; lim2 = 2 min(tlen, plen + k) (in-bounds <=> offset <= lim2; lim2c: not below 0);
+      // dlim2 = 2 max(tlen, plen + k) (dlim2 - offset = distance to the end, R/wavefront_heuristic.c:176-192); ethr: the smallest
+      // offset that ends the alignment on this diagonal
+      int kk2[NCH], lim2[NCH], lim2c[NCH], dlim2[NCH], ethr[NCH];
+      int cur[NCH], Mh[DM][NCH], Ih[E][NCH], Dh[E][NCH], I2h[E2D][NCH], D2h[E2D][NCH], PH[NP][NCH];
+      uint32_t hoff[NCH];  // byte of this diagonal in the history record compute-next fills: (step + 1) * WI + (k mod WI)
+      int step = 0;        // (the score of a step is step * g)
+      // window geometry -> the per-lane constants
+      auto set_lane_constants = [&]() {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int k = B + c * 64 + lane;
+          kk2[c] = 2 * k; hoff[c] = (uint32_t)(step + 1) * WI + ((uint32_t)k & (WI - 1));
+          lim2[c] = 2 * min(tlen, plen + k); lim2c[c] = max(lim2[c], 0); dlim2[c] = 2 * max(tlen, plen + k);
+          if (a.ef) {
+            // (h >= tlen and plen - v <= pef) or (v >= plen and tlen - h <= tef), v = h - k (R/wavefront_termination.c:115-162):
+            // two lower bounds on h each, the alignment ends at the smaller pair
+            ethr[c] = 2 * min(max(tlen, plen - a.pef + k), max(plen + k, tlen - a.tef));
+          } else {
+            ethr[c] = (k == ak) ? 2 * tlen : INT_MAX;   // (R/wavefront_termination.c:37-61)
+          }
+        }
+      };
+      set_lane_constants();
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         const int k = B + c * 64 + lane;
-        kk2[c] = 2 * k; hoff[c] = WI + ((uint32_t)k & (WI - 1));
-        lim2[c] = 2 * min(tlen, plen + k); lim2c[c] = max(lim2[c], 0); dlim2[c] = 2 * max(tlen, plen + k);
         cur[c] = (k == 0) ? 0 : NUL;  // wavefront 0
+        if (a.ef && k >= -a.pbf && k <= a.tbf) cur[c] = 2 * max(k, 0);
 #pragma unroll
         for (int j = 0; j < E; ++j) { Ih[j][c] = NUL; Dh[j][c] = NUL; }
 #pragma unroll
+        for (int j = 0; j < E2D; ++j) { I2h[j][c] = NUL; D2h[j][c] = NUL; }
+#pragma unroll
         for (int j = 0; j < DM; ++j) Mh[j][c] = NUL;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) PH[j][c] = -1;  // both halves NULL
       }
-      // neighbour registers of the 64-diagonal form: lane 0 (from below) / lane 63 (from above) never receive a value
-      int nb_mo_lo = NUL, nb_ie_lo = NUL, nb_mo_hi = NUL, nb_de_hi = NUL;
-      int step = 0, steps_wait = a.steps_between, dead_steps = 0;   // (the score of a step is step * g)
+      // neighbour registers of the one-chunk form: lane 0 (from below) / lane 63 (from above) never receive a value
+      int nb_mo_lo = NUL, nb_ie_lo = NUL, nb_mo_hi = NUL, nb_de_hi = NUL, nb_ph_lo = -1, nb_ph_hi = -1, nb_i2_lo = NUL, nb_d2_hi = NUL;
+      int steps_wait = a.steps_between, dead_steps = 0;
       const int min_wf_len_m1 = a.min_wf_len - 1;
       // the first step the loop must not start: the step limit reached (score step * g >= max_steps) or no room for the record it fills
       const int step_stop = (int)min(min((long long)(max_records - 1), ((long long)a.max_steps + a.g - 1) / a.g), 1ll << 24);
       int akp = ak - B;           // window position of the end diagonal
-      int tlen2_eff = INT_MAX;    // 2 tlen while the end diagonal lies in an active chunk (the termination test reads lane akp & 63)
-      bool big = true;
+      int act = NCH;              // active chunks: the hull of the ring (and 8 steps of growth either way) fits the first `act` chunks
       int leave = 0;              // 1 reached the end, 2 step limit, 3 hand the pair on
+      int end_pos = 0, end_off2 = 0;   // leave == 1: window position and (doubled) offset of the cell that ended the alignment
 #ifdef WFA_SLIM_COUNTERS
       uint32_t cnt_small = 0, cnt_big = 0, cnt_rounds = 0, cnt_cut = 0, cnt_shift = 0, cnt_oob = 0, cnt_live = 0;
 #endif
       int togo = 0;               // steps left in the block of HP (an ending clears it)
 
       // One score step on ACT active chunks.  Every branch is a scalar branch and nothing leaves the step early: an ending sets
-      // `leave` (1 reached the end, 2 step limit, 3 hand the pair on) and the rest of the step is skipped, so the loops around it
-      // have one exit each.
+      // `leave` and the rest of the step is skipped, so the loops around it have one exit each.
       auto step_fn = [&](auto act_tag) __attribute__((always_inline)) {
         constexpr int ACT = decltype(act_tag)::value;
         // ---------------- extend M[s] (R/wavefront_extend_kernels.c:64-110) ----------------
-        unsigned long long live[NCH] = {0ull, 0ull};
-        unsigned long long keep[NCH] = {~0ull, ~0ull};   // lanes the cut-off keeps (all, unless it moves the wavefront's limits)
+        unsigned long long live[NCH], keep[NCH], hit[NCH];   // keep: lanes the cut-off keeps (all, unless it moves the wavefront's limits)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { live[c] = 0ull; keep[c] = ~0ull; hit[c] = 0ull; }
         {
           // (a dead lane is parked at the end of its diagonal: nothing to compare, and its reads stay inside the staged words)
           int h2[NCH], v2[NCH];
@@ -143,19 +194,36 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
 #ifdef WFA_SLIM_COUNTERS
           if (ACT == 1) ++cnt_small; else ++cnt_big;
 #endif
-          bool more;
-          do {
-            more = false;
-#ifdef WFA_SLIM_COUNTERS
-            ++cnt_rounds;
-#endif
+          if (TWO && ACT > 1) {
+            // (gap-affine-2p keeps 25 ring registers per chunk: the chunks are extended one after the other, not interleaved, so
+            // that one chunk's probe temporaries are live at a time)
 #pragma unroll
             for (int c = 0; c < ACT; ++c) {
-              const uint32_t m2 = min(slim_probe(sP, sT, v2[c], h2[c]), 64u);
-              v2[c] += (int)m2; h2[c] += (int)m2;
-              more |= (m2 == 64u) && (h2[c] < lim2[c]);   // (past the end the zero padding of both sequences would match on)
+              bool more;
+              do {
+#ifdef WFA_SLIM_COUNTERS
+                ++cnt_rounds;
+#endif
+                const uint32_t m2 = min(slim_probe(sP, sT, v2[c], h2[c]), 64u);
+                v2[c] += (int)m2; h2[c] += (int)m2;
+                more = (m2 == 64u) && (h2[c] < lim2[c]);
+              } while (__builtin_amdgcn_ballot_w64(more) != 0ull);
             }
-          } while (__builtin_amdgcn_ballot_w64(more) != 0ull);
+          } else {
+            bool more;
+            do {
+              more = false;
+#ifdef WFA_SLIM_COUNTERS
+              ++cnt_rounds;
+#endif
+#pragma unroll
+              for (int c = 0; c < ACT; ++c) {
+                const uint32_t m2 = min(slim_probe(sP, sT, v2[c], h2[c]), 64u);
+                v2[c] += (int)m2; h2[c] += (int)m2;
+                more |= (m2 == 64u) && (h2[c] < lim2[c]);   // (past the end the zero padding of both sequences would match on)
+              }
+            } while (__builtin_amdgcn_ballot_w64(more) != 0ull);
+          }
 #pragma unroll
           for (int c = 0; c < ACT; ++c) {
             int cc = cur[c];
@@ -165,17 +233,25 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
             cur[c] = lv ? min(h2[c], lim2[c]) : cc;
           }
         }
-        if (live[0] | live[1]) {
+        unsigned long long any_live = 0ull;
+#pragma unroll
+        for (int c = 0; c < ACT; ++c) any_live |= live[c];
+        if (any_live) {
           dead_steps = 0;
 #ifdef WFA_SLIM_COUNTERS
-          cnt_live += (uint32_t)__builtin_popcountll(live[0]) + (uint32_t)__builtin_popcountll(live[1]);
+#pragma unroll
+          for (int c = 0; c < ACT; ++c) cnt_live += (uint32_t)__builtin_popcountll(live[c]);
 #endif
-          // ---------------- termination (R/wavefront_termination.c:37-61) ----------------
-          int at_end;
-          if (ACT == 1) at_end = __builtin_amdgcn_readlane(cur[0], akp & 63);
-          else at_end = (akp & 64) ? __builtin_amdgcn_readlane(cur[1], akp & 63) : __builtin_amdgcn_readlane(cur[0], akp & 63);
+          // ---------------- termination: the lowest diagonal whose offset reaches its threshold ----------------
+          unsigned long long any_hit = 0ull;
+#pragma unroll
+          for (int c = 0; c < ACT; ++c) { hit[c] = __builtin_amdgcn_ballot_w64(cur[c] >= ethr[c]); any_hit |= hit[c]; }
           --steps_wait;
-          if (at_end >= tlen2_eff) { leave = 1; togo = 0; }
+          if (any_hit) {
+            leave = 1; togo = 0; end_pos = BD::first_pos(hit);
+#pragma unroll
+            for (int c = 0; c < ACT; ++c) if ((end_pos >> 6) == c) end_off2 = __builtin_amdgcn_readlane(cur[c], end_pos & 63);
+          }
           // ---------------- wf-adaptive cut-off (R/wavefront_heuristic.c:257-293, 509-567) ----------------
           else if (steps_wait <= 0) {
             const int lo_p = BD::first_pos(live), hi_p = BD::last_pos(live);   // window positions of the wavefront's ends
@@ -184,7 +260,9 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
 #pragma unroll
               for (int c = 0; c < ACT; ++c) { d[c] = dlim2[c] - cur[c]; dm = min(dm, d[c]); }   // 2 max(plen - v, tlen - h); dead lanes ~ 2^30
               const int dmin = slim_wave_min(dm);   // (a live lane's distance never exceeds max(plen, tlen): the reference's initial value cannot win)
-              unsigned long long ok[NCH] = {0ull, 0ull};
+              unsigned long long ok[NCH];
+#pragma unroll
+              for (int c = 0; c < NCH; ++c) ok[c] = 0ull;
 #pragma unroll
               for (int c = 0; c < ACT; ++c) ok[c] = __builtin_amdgcn_ballot_w64(d[c] <= dmin + thr2);
               // (the lane of the minimum always qualifies: ok is never empty)
@@ -197,7 +275,7 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
               const int bottom_limit = max(akp, new_lo);
               if (bottom_limit < hi_p) new_hi = max(lp, bottom_limit);
               steps_wait = a.steps_between;
-              // the wavefront's limits changed <=> a live lane lies outside them; then M, I, D are cut to them (the equate)
+              // the wavefront's limits changed <=> a live lane lies outside them; then M and the gap components are cut to them (the equate)
               if (ACT == 1) {
                 const unsigned long long kp = (~0ull << new_lo) & (~0ull >> (63 - new_hi));
                 if (live[0] & ~kp) keep[0] = kp;
@@ -205,58 +283,100 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
                 if (live[0] & ~kp) ++cnt_cut;
 #endif
               } else if (new_lo != lo_p || new_hi != hi_p) {
-                // (positions 0..127 over two masks)
-                const unsigned long long lo0 = (new_lo < 64) ? (~0ull << new_lo) : 0ull, lo1 = (new_lo < 64) ? ~0ull : (~0ull << (new_lo - 64));
-                const unsigned long long hi0 = (new_hi < 64) ? (~0ull >> (63 - new_hi)) : ~0ull, hi1 = (new_hi < 64) ? 0ull : (~0ull >> (127 - new_hi));
-                keep[0] = lo0 & hi0; keep[1] = lo1 & hi1;
+#pragma unroll
+                for (int c = 0; c < ACT; ++c) keep[c] = slim_range_mask(c, new_lo, new_hi);
               }
             }
           }
         } else {
           // nothing alive at this score: the first scores of the lattice; a ring that stays dead is left to the next stage
-          if (++dead_steps > 2 * DM + 2) { leave = 3; togo = 0; }
+          if (++dead_steps > 2 * DM + 2 + (TWO ? OE2 : 0)) { leave = 3; togo = 0; }
         }
         if (leave == 0) {
           // (the cut, in each value's own register and without a branch: the paths of the step join on scalars only)
 #pragma unroll
-          for (int c = 0; c < ACT; ++c) { slim_keep(cur[c], keep[c]); slim_keep(Ih[0][c], keep[c]); slim_keep(Dh[0][c], keep[c]); }
-          // ---------------- compute-next for score s + g (R/wavefront_compute_affine.c:44-86) ----------------
+          for (int c = 0; c < ACT; ++c) {
+            slim_keep(cur[c], keep[c]); slim_keep(Ih[0][c], keep[c]); slim_keep(Dh[0][c], keep[c]);
+            if (TWO) { slim_keep(I2h[0][c], keep[c]); slim_keep(D2h[0][c], keep[c]); }
+          }
+          // ---------------- compute-next for score s + g (R/wavefront_compute_affine.c:44-86, R/wavefront_compute_affine2p.c:45-106) ----------------
+          if (TWO) {
+            // the value leaving depth DM enters the packed ring: PH[0].lo = depth DM + 1, PH[0].hi = DM + 2, ...
+#pragma unroll
+            for (int j = NP - 1; j > 0; --j)
+#pragma unroll
+              for (int c = 0; c < ACT; ++c) PH[j][c] = (int)__builtin_amdgcn_alignbit((uint32_t)PH[j][c], (uint32_t)PH[j - 1][c], 16);
+#pragma unroll
+            for (int c = 0; c < ACT; ++c) PH[0][c] = (PH[0][c] << 16) | (max(Mh[DM - 1][c], -1) & 0xffff);
+          }
 #pragma unroll
           for (int j = DM - 1; j > 0; --j)
 #pragma unroll
             for (int c = 0; c < ACT; ++c) Mh[j][c] = Mh[j - 1][c];
 #pragma unroll
           for (int c = 0; c < ACT; ++c) Mh[0][c] = cur[c];
-          int ni[NCH], nd[NCH];
+          int ni[NCH], nd[NCH], ni2[NCH], nd2[NCH];
           unsigned long long oob = 0;
+          constexpr int PD = TWO ? OE2 - 1 - DM : 0;  // depth OE2 (index OE2 - 1) sits in half PD & 1 of PH[PD / 2]
 #pragma unroll
           for (int c = 0; c < ACT; ++c) {
-            int mo_lo, ie_lo, mo_hi, de_hi;
+            int mo_lo, ie_lo, mo_hi, de_hi, plo = -1, phi = -1, i2e_lo = NUL, d2e_hi = NUL;
             if (ACT == 1) {
               nb_mo_lo = __builtin_amdgcn_update_dpp(nb_mo_lo, Mh[OE - 1][0], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
               nb_ie_lo = __builtin_amdgcn_update_dpp(nb_ie_lo, Ih[E - 1][0], 0x138, 0xf, 0xf, false);
               nb_mo_hi = __builtin_amdgcn_update_dpp(nb_mo_hi, Mh[OE - 1][0], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
               nb_de_hi = __builtin_amdgcn_update_dpp(nb_de_hi, Dh[E - 1][0], 0x130, 0xf, 0xf, false);
               mo_lo = nb_mo_lo; ie_lo = nb_ie_lo; mo_hi = nb_mo_hi; de_hi = nb_de_hi;
+              if (TWO) {
+                nb_ph_lo = __builtin_amdgcn_update_dpp(nb_ph_lo, PH[PD / 2][0], 0x138, 0xf, 0xf, false);
+                nb_ph_hi = __builtin_amdgcn_update_dpp(nb_ph_hi, PH[PD / 2][0], 0x130, 0xf, 0xf, false);
+                nb_i2_lo = __builtin_amdgcn_update_dpp(nb_i2_lo, I2h[E2D - 1][0], 0x138, 0xf, 0xf, false);
+                nb_d2_hi = __builtin_amdgcn_update_dpp(nb_d2_hi, D2h[E2D - 1][0], 0x130, 0xf, 0xf, false);
+                plo = nb_ph_lo; phi = nb_ph_hi; i2e_lo = nb_i2_lo; d2e_hi = nb_d2_hi;
+              }
             } else {
               mo_lo = BD::below(Mh[OE - 1], c); ie_lo = BD::below(Ih[E - 1], c);
               mo_hi = BD::above(Mh[OE - 1], c); de_hi = BD::above(Dh[E - 1], c);
+              if (TWO) {
+                plo = BD::below(PH[PD / 2], c, -1); phi = BD::above(PH[PD / 2], c, -1);
+                i2e_lo = BD::below(I2h[E2D - 1], c); d2e_hi = BD::above(D2h[E2D - 1], c);
+              }
             }
             ni[c] = max(mo_lo, ie_lo) + 2;
             nd[c] = max(mo_hi, de_hi);
             const int x1 = Mh[X - 1][c] + 2;
-            const int t = max(ni[c], nd[c]);
+            int t = max(ni[c], nd[c]);
+            int mo2_lo = NUL, mo2_hi = NUL;
+            ni2[c] = NUL; nd2[c] = NUL;
+            if (TWO) {
+              const int m2lo = (PD & 1) ? (plo >> 16) : (int)(short)(plo & 0xffff), m2hi = (PD & 1) ? (phi >> 16) : (int)(short)(phi & 0xffff);
+              mo2_lo = (m2lo < 0) ? NUL : m2lo; mo2_hi = (m2hi < 0) ? NUL : m2hi;
+              ni2[c] = max(mo2_lo, i2e_lo) + 2;
+              nd2[c] = max(mo2_hi, d2e_hi);
+              t = max(t, max(ni2[c], nd2[c]));
+            }
             const int m = max(x1, t);
             if (FULL) {
-              // the choice the backtrace would make (R/wavefront_backtrace.c:49-59: mismatch > deletion > insertion, extension >
-              // opening on equal offsets), taken where the candidates are in registers
-              // — the piggy-back history of score s + g: one byte per active diagonal, stored here (the window may move before the
-              // next step begins; the record of score 0 is never read)
-              // (BandArgs::pb_raw: the sign bits of four subtractions, shifted in one after the other)
-              uint32_t cd = (uint32_t)(x1 - t) >> 31;
-              cd = __builtin_amdgcn_alignbit(cd, (uint32_t)(nd[c] - ni[c]), 31);
-              cd = __builtin_amdgcn_alignbit(cd, (uint32_t)(ie_lo - mo_lo), 31);
-              cd = __builtin_amdgcn_alignbit(cd, (uint32_t)(de_hi - mo_hi), 31);
+              // the choice the backtrace would make (R/wavefront_backtrace.c:49-59: mismatch > D2 > D1 > I2 > I1, extension > opening on
+              // equal offsets), taken where the candidates are in registers — the piggy-back history of score s + g: one byte per
+              // active diagonal, stored here (the window may move before the next step begins; the record of score 0 is never read).
+              // BandArgs::pb_raw: the sign bits of the subtractions, shifted in one after the other
+              uint32_t cd;
+              if (TWO) {
+                cd = (uint32_t)(x1 - m) >> 31;                                              // bit 7: the mismatch is below the best
+                cd = __builtin_amdgcn_alignbit(cd, (uint32_t)(nd2[c] - m), 31);              // 6: D2 below the best
+                cd = __builtin_amdgcn_alignbit(cd, (uint32_t)(nd[c] - m), 31);               // 5: D1 below the best
+                cd = __builtin_amdgcn_alignbit(cd, (uint32_t)(ni2[c] - m), 31);              // 4: I2 below the best (then I1 made it)
+                cd = __builtin_amdgcn_alignbit(cd, (uint32_t)(ie_lo - mo_lo), 31);           // 3: I1 opened (its extension is below)
+                cd = __builtin_amdgcn_alignbit(cd, (uint32_t)(de_hi - mo_hi), 31);           // 2: D1 opened
+                cd = __builtin_amdgcn_alignbit(cd, (uint32_t)(i2e_lo - mo2_lo), 31);         // 1: I2 opened
+                cd = __builtin_amdgcn_alignbit(cd, (uint32_t)(d2e_hi - mo2_hi), 31);         // 0: D2 opened
+              } else {
+                cd = (uint32_t)(x1 - t) >> 31;                                               // bit 3: the mismatch is below the best gap
+                cd = __builtin_amdgcn_alignbit(cd, (uint32_t)(nd[c] - ni[c]), 31);            // 2: the deletion is below the insertion
+                cd = __builtin_amdgcn_alignbit(cd, (uint32_t)(ie_lo - mo_lo), 31);            // 1: I opened
+                cd = __builtin_amdgcn_alignbit(cd, (uint32_t)(de_hi - mo_hi), 31);            // 0: D opened
+              }
               rec[hoff[c]] = (uint8_t)cd;
               hoff[c] += WI;   // (an inactive chunk's offset is set again when it joins)
             }
@@ -269,24 +389,34 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
             for (int c = 0; c < ACT; ++c) { Ih[j][c] = Ih[j - 1][c]; Dh[j][c] = Dh[j - 1][c]; }
 #pragma unroll
           for (int c = 0; c < ACT; ++c) { Ih[0][c] = ni[c]; Dh[0][c] = nd[c]; }
+          if (TWO) {
+#pragma unroll
+            for (int j = E2D - 1; j > 0; --j)
+#pragma unroll
+              for (int c = 0; c < ACT; ++c) { I2h[j][c] = I2h[j - 1][c]; D2h[j][c] = D2h[j - 1][c]; }
+#pragma unroll
+            for (int c = 0; c < ACT; ++c) { I2h[0][c] = ni2[c]; D2h[0][c] = nd2[c]; }
+          }
 #ifdef WFA_SLIM_COUNTERS
           if (oob) ++cnt_oob;
 #endif
           if (oob) {
-            // trim the ends of I and D (R/wavefront_compute.c:571-605): outside [first, last] in-bounds -> NULL
-            unsigned long long bi[NCH] = {0ull, 0ull}, bd[NCH] = {0ull, 0ull};
+            // trim the ends of the gap components (R/wavefront_compute.c:571-605): outside [first, last] in-bounds -> NULL
+            auto trim = [&](int (&g)[NCH]) {
+              unsigned long long b[NCH];
 #pragma unroll
-            for (int c = 0; c < ACT; ++c) {
-              bi[c] = __builtin_amdgcn_ballot_w64(ni[c] >= 0 && ni[c] <= lim2[c]);
-              bd[c] = __builtin_amdgcn_ballot_w64(nd[c] >= 0 && nd[c] <= lim2[c]);
-            }
-            const int ilo = BD::first_pos(bi), ihi = BD::last_pos(bi), dlo = BD::first_pos(bd), dhi = BD::last_pos(bd);
+              for (int c = 0; c < NCH; ++c) b[c] = 0ull;
 #pragma unroll
-            for (int c = 0; c < ACT; ++c) {
-              const int p = c * 64 + lane;
-              Ih[0][c] = (p < ilo || p > ihi) ? NUL : Ih[0][c];
-              Dh[0][c] = (p < dlo || p > dhi) ? NUL : Dh[0][c];
-            }
+              for (int c = 0; c < ACT; ++c) b[c] = __builtin_amdgcn_ballot_w64(g[c] >= 0 && g[c] <= lim2[c]);
+              const int lo = BD::first_pos(b), hi = BD::last_pos(b);
+#pragma unroll
+              for (int c = 0; c < ACT; ++c) {
+                const int p = c * 64 + lane;
+                g[c] = (p < lo || p > hi) ? NUL : g[c];
+              }
+            };
+            trim(Ih[0]); trim(Dh[0]);
+            if (TWO) { trim(I2h[0]); trim(D2h[0]); }
           }
           ++step;
           // ---------------- step limit (R/wavefront_unialign.c:98-107), room for the next step's history record ----------------
@@ -294,6 +424,21 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
         }
       };
 
+      // every register of the chunks from `c0` on: NULL
+      auto null_chunks = [&](int c0) {
+#pragma unroll
+        for (int c = 1; c < NCH; ++c) if (c >= c0) {
+          cur[c] = NUL;
+#pragma unroll
+          for (int j = 0; j < E; ++j) { Ih[j][c] = NUL; Dh[j][c] = NUL; }
+#pragma unroll
+          for (int j = 0; j < E2D; ++j) { I2h[j][c] = NUL; D2h[j][c] = NUL; }
+#pragma unroll
+          for (int j = 0; j < DM; ++j) Mh[j][c] = NUL;
+#pragma unroll
+          for (int j = 0; j < NP; ++j) PH[j][c] = -1;
+        }
+      };
       while (leave == 0) {
         // ---------------- keep the ring inside the window: every HP steps (growth is <= 1 diagonal per step and side) ----------------
         {
@@ -303,75 +448,89 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
             int any = cur[c];
 #pragma unroll
             for (int j = 0; j < E; ++j) any &= Ih[j][c] & Dh[j][c];
+            if (TWO) {
 #pragma unroll
-            for (int j = 0; j < DM - 1; ++j) any &= Mh[j][c];   // (the oldest M is dropped by the next compute-next)
-            hull[c] = __ballot(any >= 0);  // some register of this diagonal is not negative
+              for (int j = 0; j < E2D; ++j) any &= I2h[j][c] & D2h[j][c];
+            }
+#pragma unroll
+            for (int j = 0; j < DM - 1; ++j) any &= Mh[j][c];   // (gap-affine: the oldest M is dropped by the next compute-next)
+            if (TWO) {
+              any &= Mh[DM - 1][c];
+#pragma unroll
+              for (int j = 0; j < NP; ++j) any &= PH[j][c] & (PH[j][c] << 16);  // sign set iff both halves are NULL
+            }
+            hull[c] = (c < act) ? __builtin_amdgcn_ballot_w64(any >= 0) : 0ull;  // (an inactive chunk's registers are stale, not read)
           }
-          if (!big) hull[1] = 0ull;   // (the inactive chunk's registers are stale, not read)
           const int fp = BD::first_pos(hull), lp = BD::last_pos(hull);
           if (lp >= 0) {
             const int width = lp - fp + 1;
-            if (width > W - 20) leave = 3;
-            // small form: the hull (and HP steps of growth either way) fits the first chunk; a little hysteresis keeps a hull near
-            // the limit from being shifted to and fro
-            const bool want_small = width <= (big ? WS - 2 * HP - 6 : WS - 2 * HP - 2);
-            const int wa = want_small ? WS : W;
-            if (fp < HP + 1 || lp > wa - HP - 2) {
+            if (width > W - 20) { leave = 3; }
+            // the fewest chunks that hold the hull and HP steps of growth either way; a little hysteresis keeps a hull near a limit from
+            // being shifted to and fro
+            int want = NCH;
+#pragma unroll
+            for (int n = NCH - 1; n >= 1; --n) if (width <= 64 * n - 2 * HP - (n < act ? 6 : 2)) want = n;
+            const int wa = 64 * want;
+            const bool shift = fp < HP + 1 || lp > wa - HP - 2;
+            if (leave == 0 && (shift || want != act)) {
+              if (!(shift && act == 1 && want == 1)) null_chunks(act);   // (the chunks beyond the active ones hold stale values: they read as NULL)
+              if (shift) {
 #ifdef WFA_SLIM_COUNTERS
-              ++cnt_shift;
+                ++cnt_shift;
 #endif
-              const int delta = fp - (wa - width) / 2;   // re-centre in the window (or in its small form)
-              B += delta; akp -= delta;
-              if (!big && want_small) {
-                // 64 diagonals before and after: one lane shuffle per register
-                const int src = lane + delta;
-                const bool in = (unsigned)src < 64u;
-                auto sh1 = [&](int& r) { const int t = __shfl(r, src & 63, 64); r = in ? t : NUL; };
-                sh1(cur[0]);
+                const int delta = fp - (wa - width) / 2;   // re-centre in the chunks of the form that follows
+                B += delta; akp -= delta;
+                if (act == 1 && want == 1) {
+                  // 64 diagonals before and after: one lane shuffle per register
+                  const int src = lane + delta;
+                  const bool in = (unsigned)src < 64u;
+                  auto sh1 = [&](int& r, int nullv) { const int t = __shfl(r, src & 63, 64); r = in ? t : nullv; };
+                  sh1(cur[0], NUL);
 #pragma unroll
-                for (int j = 0; j < E; ++j) { sh1(Ih[j][0]); sh1(Dh[j][0]); }
+                  for (int j = 0; j < E; ++j) { sh1(Ih[j][0], NUL); sh1(Dh[j][0], NUL); }
+                  if (TWO) {
 #pragma unroll
-                for (int j = 0; j < DM - 1; ++j) sh1(Mh[j][0]);
-              } else {
-                if (!big) {   // the stale registers of the inactive chunk read as NULL
-                  cur[1] = NUL;
+                    for (int j = 0; j < E2D; ++j) { sh1(I2h[j][0], NUL); sh1(D2h[j][0], NUL); }
+                  }
 #pragma unroll
-                  for (int j = 0; j < E; ++j) { Ih[j][1] = NUL; Dh[j][1] = NUL; }
+                  for (int j = 0; j < DM - 1; ++j) sh1(Mh[j][0], NUL);
+                  if (TWO) {
+                    sh1(Mh[DM - 1][0], NUL);
 #pragma unroll
-                  for (int j = 0; j < DM; ++j) Mh[j][1] = NUL;
+                    for (int j = 0; j < NP; ++j) sh1(PH[j][0], -1);
+                  }
+                } else {
+                  BD::shift(cur, delta, lane);
+#pragma unroll
+                  for (int j = 0; j < E; ++j) { BD::shift(Ih[j], delta, lane); BD::shift(Dh[j], delta, lane); }
+                  if (TWO) {
+#pragma unroll
+                    for (int j = 0; j < E2D; ++j) { BD::shift(I2h[j], delta, lane); BD::shift(D2h[j], delta, lane); }
+                  }
+#pragma unroll
+                  for (int j = 0; j < DM - 1; ++j) BD::shift(Mh[j], delta, lane);
+                  if (TWO) {
+                    BD::shift(Mh[DM - 1], delta, lane);
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) BD::shift(PH[j], delta, lane, -1);
+                  }
                 }
-                BD::shift(cur, delta, lane);
-#pragma unroll
-                for (int j = 0; j < E; ++j) { BD::shift(Ih[j], delta, lane); BD::shift(Dh[j], delta, lane); }
-#pragma unroll
-                for (int j = 0; j < DM - 1; ++j) BD::shift(Mh[j], delta, lane);
               }
-#pragma unroll
-              for (int c = 0; c < NCH; ++c) {
-                const int k = B + c * 64 + lane;
-                kk2[c] = 2 * k; hoff[c] = (uint32_t)(step + 1) * WI + ((uint32_t)k & (WI - 1));
-                lim2[c] = 2 * min(tlen, plen + k); lim2c[c] = max(lim2[c], 0); dlim2[c] = 2 * max(tlen, plen + k);
-              }
-            } else if (!big && !want_small) {
-              // small -> big without a shift: the inactive chunk joins as NULLs
-              hoff[1] = (uint32_t)(step + 1) * WI + ((uint32_t)(B + 64 + lane) & (WI - 1));
-              cur[1] = NUL;
-#pragma unroll
-              for (int j = 0; j < E; ++j) { Ih[j][1] = NUL; Dh[j][1] = NUL; }
-#pragma unroll
-              for (int j = 0; j < DM; ++j) Mh[j][1] = NUL;
+              set_lane_constants();
+              act = want;
             }
-            big = !want_small;
           }
-          tlen2_eff = (akp >= 0 && akp < (big ? W : WS)) ? 2 * tlen : INT_MAX;
         }
         togo = (leave == 0) ? HP : 0;
-        if (!big) {
+        if (act == 1) {
 #pragma unroll 1
           while (togo > 0) { --togo; step_fn(band_int<1>{}); }
-        } else {
+        } else if (NCH == 2 || act == 2) {
 #pragma unroll 1
           while (togo > 0) { --togo; step_fn(band_int<2>{}); }
+        } else {
+#pragma unroll 1
+          while (togo > 0) { --togo; step_fn(band_int<(NCH > 2 ? NCH : 2)>{}); }
         }
       }
 #ifdef WFA_SLIM_COUNTERS
@@ -381,7 +540,9 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
       }
 #endif
       const int s_end = step * a.g;
-      if (leave == 1) { done = true; result = -s_end; end_k = ak; end_off = tlen; end_s = s_end; }
+      if (leave == 1) {
+        done = true; result = -s_end; end_s = s_end; end_k = B + end_pos; end_off = end_off2 >> 1;
+      }
       else if (leave == 2) { stop_status = WFA_STATUS_MAX_STEPS_REACHED; stop_score = -a.max_steps; }
       else fallback = true;
     }
@@ -405,20 +566,31 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
   }
 }
 
-template <bool FULL, int X, int OE, int E>
-__global__ void __launch_bounds__(64)
-wfa_slim_kernel(const BandArgs a) {
-  wfa_slim_body<FULL, X, OE, E>(a);
+template <int NCH, bool FULL, int X, int OE, int E, int OE2, int E2>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WFA_SLIM_WAVES, WFA_SLIM_WAVES)))
+wfa_slim_kernel(const BandArgs a) {   // gap-affine: eight waves per SIMD (<= 64 VGPRs; the sequences of 10 kb reads in LDS allow eight)
+  wfa_slim_body<NCH, FULL, X, OE, E, OE2, E2>(a);
+}
+template <int NCH, bool FULL, int X, int OE, int E, int OE2, int E2>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WFA_SLIM_WAVES_2P, WFA_SLIM_WAVES_2P)))
+wfa_slim_kernel_2p(const BandArgs a) {   // gap-affine-2p: 25 ring registers per chunk; three waves per SIMD (<= 168 VGPRs) measured best (C4 with wf-adaptive, 10 k pairs: 21.3 ms against 25.8 ms at four waves with spills and 23.2 ms at two)
+  wfa_slim_body<NCH, FULL, X, OE, E, OE2, E2>(a);
 }
 
 #ifndef __HIPCC_RTC__
-template <int X, int OE, int E>
+template <int X, int OE, int E, int OE2, int E2>
 static int launch_slim_shape(const BandArgs& a, bool full, long long grid, hipStream_t stream) {
+  constexpr int NCH = (OE2 > 0) ? 3 : 2;
   size_t smem = (size_t)a.lds_words * 2 * sizeof(uint32_t);
   static const int pad_kb = getenv("WFA_HIP_SLIM_LDS_PAD_KB") ? atoi(getenv("WFA_HIP_SLIM_LDS_PAD_KB")) : 0;   // (occupancy experiments)
   smem += (size_t)pad_kb << 10;
-  if (full) hipLaunchKernelGGL((wfa_slim_kernel<true, X, OE, E>), dim3((unsigned)grid), dim3(64), smem, stream, a);
-  else hipLaunchKernelGGL((wfa_slim_kernel<false, X, OE, E>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+  if constexpr (OE2 > 0) {
+    if (full) hipLaunchKernelGGL((wfa_slim_kernel_2p<NCH, true, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+    else hipLaunchKernelGGL((wfa_slim_kernel_2p<NCH, false, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+  } else {
+    if (full) hipLaunchKernelGGL((wfa_slim_kernel<NCH, true, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+    else hipLaunchKernelGGL((wfa_slim_kernel<NCH, false, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+  }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 #endif

@@ -36,6 +36,15 @@ CONFIGS = [
     dict(span="end-to-end", heuristic="adaptive", mismatch=4, gap_opening=6, gap_extension=1),
     dict(span="end-to-end", heuristic="adaptive", mismatch=3, gap_opening=4, gap_extension=1),
     dict(span="end-to-end", heuristic="adaptive", mismatch=2, gap_opening=2, gap_extension=1),
+    # ends-free (one compare per chunk against a per-lane threshold), wavefront 0 over the free begins
+    dict(span="ends-free", heuristic="adaptive", pattern_begin_free=40, pattern_end_free=30, text_begin_free=25, text_end_free=35),
+    dict(span="ends-free", heuristic="adaptive", pattern_end_free=60, text_end_free=5, max_steps=900),
+    # gap-affine-2p: 192 diagonals, one to three chunks active (BASELINE C4 with wf-adaptive: free pattern ends of 100)
+    dict(distance="affine2p", span="ends-free", heuristic="adaptive", pattern_begin_free=100, pattern_end_free=100),
+    dict(distance="affine2p", span="end-to-end", heuristic="adaptive"),
+    dict(distance="affine2p", span="ends-free", heuristic="adaptive", pattern_begin_free=20, text_begin_free=30, text_end_free=50,
+         min_wavefront_length=5, max_distance_threshold=20, steps_between_cutoffs=2),
+    dict(distance="affine2p", span="end-to-end", heuristic="adaptive", max_steps=1500),
 ]
 
 
@@ -45,7 +54,7 @@ def test_slim_kernel_matches_oracle_and_band_kernel(gpu, cfg_idx, scope, monkeyp
     batches = [ragged(31 + cfg_idx, 96, 1100, 4000, 0.08, indel_bias=6), datagen.generate(48, 10000, 0.08, 4100 + cfg_idx),
                ragged(77 + cfg_idx, 64, 1200, 9000, 0.03), datagen.generate(200, 1500, 0.15, 4200 + cfg_idx)]
     for bi, batch in enumerate(batches):
-        kw = dict(CONFIGS[cfg_idx], scope=scope)
+        kw = common.clamp_free(dict(CONFIGS[cfg_idx], scope=scope), batch)
         oc, nc = common.configs_pair(**kw)
         full = oc.scope == 1
         o = loader.run(loader.oracle(), oc, batch, want_cigar=full)
@@ -57,10 +66,11 @@ def test_slim_kernel_matches_oracle_and_band_kernel(gpu, cfg_idx, scope, monkeyp
         assert np.array_equal(score, score0) and np.array_equal(status, status0) and cigars == cigars0
 
 
-def test_slim_kernel_window_overflow_is_handed_on(gpu):
-    """Reads whose wavefront outgrows the 128 diagonals (a cut-off that keeps everything) go on to the 256-diagonal stage."""
+@pytest.mark.parametrize("distance", ["affine", "affine2p"])
+def test_slim_kernel_window_overflow_is_handed_on(gpu, distance):
+    """Reads whose wavefront outgrows the window (a cut-off that keeps everything) go on to the 256-diagonal stage."""
     batch = datagen.generate(40, 6000, 0.12, 515)
-    kw = dict(span="end-to-end", heuristic="adaptive", min_wavefront_length=10, max_distance_threshold=400, scope="full")
+    kw = dict(distance=distance, span="end-to-end", heuristic="adaptive", min_wavefront_length=10, max_distance_threshold=400, scope="full")
     oc, nc = common.configs_pair(**kw)
     o = loader.run(loader.oracle(), oc, batch)
     score, status, cigars = common.gpu_run(nc, batch, True, resident=True)
