@@ -406,6 +406,23 @@ def dist_max(dist, backend, value):
     return float(t.item())
 
 
+def dist_all(dist, backend, value):
+    """Every rank's host float, in rank order (per-rank rates: min / max / imbalance of a weak-scaling run)."""
+    if dist is None:
+        return [float(value)]
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
+
+
+def rank_spread(rates):
+    """min / max / imbalance (max over min, minus one) of per-rank rates."""
+    lo, hi = min(rates), max(rates)
+    return {"per_rank": rates, "min": lo, "max": hi, "imbalance": (hi / lo - 1.0) if lo > 0 else None}
+
+
 def dist_sum(dist, backend, value):
     """SUM over ranks of a host number (pairs completed, violations)."""
     if dist is None:
@@ -431,6 +448,7 @@ def c3_leg(rank, world, local_rank, pairs, steps, dist, backend):
     r = run_resident(al, batch, steps, 1, True, barrier=lambda: dist_barrier(dist, backend))
     al.close()
     elapsed = dist_max(dist, backend, r["elapsed"])
+    spread = rank_spread([pairs * steps / t for t in dist_all(dist, backend, r["elapsed"])])
     bad = transcripts_valid(batch, r["score"], r["status"], r["cig"], C3_KW, sample=500)
     bad = dist_sum(dist, backend, bad)
     done = dist_sum(dist, backend, int((r["status"] == 0).sum()))
@@ -438,7 +456,9 @@ def c3_leg(rank, world, local_rank, pairs, steps, dist, backend):
     bytes_pair = 114e3   # SURVEY §8(d), piggy-back history
     return {"pairs_per_gpu": pairs, "steps": steps, "ms_per_step": elapsed / steps * 1e3, "alignments_per_s": rate,
             "kernel_ms_rank0": r["kernel_ms"], "hbm_frac": bytes_pair * pairs / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "completed": int(done), "invalid_transcripts": int(bad), "checked_per_rank": min(500, pairs)}
+            "completed": int(done), "invalid_transcripts": int(bad), "checked_per_rank": min(500, pairs),
+            "rank_alignments_per_s_min": spread["min"], "rank_alignments_per_s_max": spread["max"], "rank_imbalance": spread["imbalance"],
+            "per_rank_alignments_per_s": spread["per_rank"]}
 
 
 def multi_leg(pairs_per_device, length=100000, calls=2):
@@ -529,6 +549,9 @@ def main():
         local_rank = 0
     if world > 1:
         dist = dist_setup(backend, local_rank)
+        # the job the driver asked for: N ranks, one per GPU, over RCCL (backend "nccl" on ROCm)
+        assert dist.get_world_size() == args.gpus and dist.get_rank() == rank, (dist.get_world_size(), args.gpus, dist.get_rank(), rank)
+        assert dist.get_backend() == backend
     n_gpus = world
 
     from pywfa_amd import _native, datagen
@@ -546,6 +569,7 @@ def main():
     al = _native.Aligner(cfg, device=local_rank)
     r = run_resident(al, batch, args.steps, args.warmup, False, barrier=lambda: dist_barrier(dist, backend))
     elapsed = dist_max(dist, backend, r["elapsed"])
+    c2_spread = rank_spread([args.pairs * args.steps / t for t in dist_all(dist, backend, r["elapsed"])])
     kernel_ms, score, status = r["kernel_ms"], r["score"], r["status"]
     # PCIe-inclusive rate (host ASCII in -> host results out), best of five calls (the first pins and sizes the staging; boxes differ in how quiet their host is)
     # (results into caller-owned arrays, as a C caller has them: fresh 2 x 40 MB NumPy arrays per call cost ~10 ms of page faults)
@@ -628,7 +652,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int32",
+            # (the C2 kernel keeps wavefront offsets as packed int16 pairs — reads <= 512 bp, range-guarded, every score
+            # checked against the reference in this run; the reference's wf_offset_t is int32, wavefront_offset.h:38)
+            "dtype": "int16x2 offsets (reads <= 512 bp), int32 results",
             "data": "synthetic",
             "config": {"workload": f"C2: {args.pairs} x {args.length}bp pairs/GPU, {args.error * 100:g}% error, gap-affine 0/4/6/2, "
                                    "end-to-end, scope=score, 2-bit reads resident in HBM",
@@ -636,6 +662,9 @@ def main():
                        #  wfa_hip_align_batch pays it on every call: the end_to_end figures below include it)
                        "pilot_in_timed_region": False, "end_to_end_includes_pilot": True,
                        "pairs_per_gpu": args.pairs, "read_length": args.length, "parallelism": f"pairs sharded over {n_gpus} GPU(s), no collective",
+                       # per-rank rates of the timed steps (weak scaling: every rank the same work; `value` is all pairs over the slowest rank's time)
+                       "rank_alignments_per_s_min": c2_spread["min"], "rank_alignments_per_s_max": c2_spread["max"],
+                       "rank_imbalance": c2_spread["imbalance"],
                        # `value` is the HBM-resident rate; the PCIe-inclusive rate of the same batch (host ASCII in -> host results out, every
                        # rank's call at once, the slowest rank counted) is never `value` but belongs beside it (full detail: "end_to_end")
                        "end_to_end_alignments_per_s": e2e_rate * n_gpus, "end_to_end_seconds_per_batch": t_e2e,
@@ -790,6 +819,7 @@ def main():
             out["config"]["c3_leg_alignments_per_s" if n_gpus == 1 else "c3_alignments_per_s"] = c3["alignments_per_s"]
             out["config"]["c3_leg_hbm_frac" if n_gpus == 1 else "c3_hbm_frac"] = c3["hbm_frac"]
             out["config"]["c3_invalid_transcripts"] = c3["invalid_transcripts"]
+            out["config"]["c3_rank_imbalance"] = c3["rank_imbalance"]
             if c3["invalid_transcripts"] or c3["completed"] != c3["pairs_per_gpu"] * n_gpus:
                 errors.append(f"C3 leg: {c3['invalid_transcripts']} invalid transcripts, {c3['completed']} completed")
         cb = out.get("cpu_baseline") or {}

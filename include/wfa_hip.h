@@ -16,8 +16,13 @@
  * Every entry point below is plain C (pointers + sizes, no torch / HIP types in the
  * signatures; a stream is passed as an opaque void*).  The reference aligns ONE pair per
  * call on one CPU thread; the replacement aligns a BATCH of independent pairs per call on
- * one GPU (one alignment per workgroup), so the batch forms are additive while the config
- * struct carries exactly the kwargs of WavefrontAligner.__init__ (align.pyx:309-334).
+ * one GPU, so the batch forms are additive while the config struct carries exactly the kwargs
+ * of WavefrontAligner.__init__ (align.pyx:309-334).  How the pairs map onto the GPU is the
+ * library's business and depends on the reads: SIXTY-FOUR alignments per wavefront (a lane
+ * each) for short reads — the BASELINE C2 kernel; a measured departure from north_star's
+ * "one alignment per workgroup", DESIGN.md §3.0 —, one alignment per wave for long reads
+ * under a heuristic, one alignment per workgroup with the M / I / D wavefronts in LDS or in
+ * LDS tiles for exact long reads.  Results never depend on the mapping.
  *
  * Error model: the reference calls exit(1) on invalid penalties / ends-free sizes
  * (wavefront_penalties.c:101-112, wavefront_align.c:95-101).  Here every function returns
@@ -239,6 +244,12 @@ typedef struct wfa_hip_multi wfa_hip_multi_t;
 /* The shard planner alone (host only, needs no GPU): shard_begin[nshards + 1], shard s = pairs
  * [shard_begin[s], shard_begin[s + 1]).  Returns WFA_HIP_OK or WFA_HIP_EINVAL. */
 int wfa_hip_plan_shards(int64_t n, const int32_t* p_len, const int32_t* t_len, int nshards, int64_t* shard_begin);
+
+/* The host side of several devices (host only, needs no GPU): the threads ONE device's upload pipeline takes — 2-bit packing into its
+ * pinned ring, and plain copies — when `sharers` aligners or processes feed GPUs from a host of `hw_threads` logical CPUs.  The
+ * devices of a wfa_hip_multi_t count themselves; a one-process-per-GPU job says so through LOCAL_WORLD_SIZE (torch.distributed.run
+ * exports it) or WFA_HIP_HOST_SHARE.  Returns WFA_HIP_OK or WFA_HIP_EINVAL. */
+int wfa_hip_plan_host_threads(int sharers, int hw_threads, int* pack_threads, int* copy_threads);
 
 /* One aligner per entry of devices[] (an ordinal may repeat: several host threads then feed that device).
  * Returns NULL on error (see wfa_hip_global_error). */

@@ -57,7 +57,7 @@ SYMBOLS = [
     "wfa_hip_batch_destroy", "wfa_hip_batch_run", "wfa_hip_batch_sync", "wfa_hip_batch_results",
     "wfa_hip_batch_last_kernel_ms", "wfa_hip_batch_algorithmic_bytes", "wfa_hip_batch_fallback_pairs",
     "wfa_hip_batch_rle_counts", "wfa_hip_batch_rle_runs",
-    "wfa_hip_plan_shards", "wfa_hip_multi_create", "wfa_hip_multi_destroy", "wfa_hip_multi_set_config",
+    "wfa_hip_plan_shards", "wfa_hip_plan_host_threads", "wfa_hip_multi_create", "wfa_hip_multi_destroy", "wfa_hip_multi_set_config",
     "wfa_hip_multi_last_error", "wfa_hip_multi_align_batch", "wfa_hip_pack_2bit", "wfa_hip_batch_extent",
     "wfa_hip_align_batch_packed2bits", "wfa_hip_batch_create_packed2bits", "wfa_hip_cigar_sprint_pretty",
     "wfa_hip_batch_extent_packed2bits", "wfa_hip_align_pair",
@@ -111,6 +111,7 @@ def lib():
     L.wfa_hip_batch_rle_counts.restype = i64
     L.wfa_hip_batch_rle_runs.argtypes = [vp, vp, vp]
     L.wfa_hip_plan_shards.argtypes = [i64, vp, vp, ctypes.c_int, vp]
+    L.wfa_hip_plan_host_threads.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     L.wfa_hip_pack_2bit.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_int]
     L.wfa_hip_batch_extent.argtypes = [i64, vp, vp, vp, vp]
     L.wfa_hip_batch_extent.restype = i64
@@ -129,6 +130,26 @@ def lib():
     _lib = L
     return L
 
+
+
+_HOST = False   # False = not looked for yet; None = absent
+
+
+def compiled_host():
+    """pywfa_amd.host._host (Cython, built in-tree by __graft_entry__.build()) bound to the loaded library, or None when the
+    extension has not been built (WFA_HIP_NO_COMPILED_HOST=1: ignore it — the ctypes / Python host, for tests)."""
+    global _HOST
+    if _HOST is False:
+        _HOST = None
+        if os.environ.get("WFA_HIP_NO_COMPILED_HOST") != "1":
+            try:
+                from .host import _host
+                threads = max(1, min(32, (os.cpu_count() or 2) // 2))
+                _host.bind(ctypes.cast(lib().wfa_hip_align_pair, ctypes.c_void_p).value, threads)
+                _HOST = _host
+            except ImportError:
+                _HOST = None
+    return _HOST
 
 def default_config():
     c = Config()
@@ -206,6 +227,7 @@ class Aligner:
 
     def __init__(self, cfg, device=0):
         L = lib()
+        self._pair_caller = None
         self._h = L.wfa_hip_create(ctypes.byref(cfg), device)
         if not self._h:
             msg = L.wfa_hip_global_error().decode()
@@ -286,7 +308,17 @@ class Aligner:
 
     def align_pair(self, pattern, text, want_cigar):
         """wfa_hip_align_pair: one pair of ASCII ``bytes`` per call, without NumPy arrays on the way (pywfa's loop of
-        ``wavefront_align(text)``).  Returns score, status, op bytes (or None)."""
+        ``wavefront_align(text)``).  Returns score, status, op bytes (or None).  Through the compiled host
+        (pywfa_amd/host/_host.pyx: no ctypes marshalling) when it is built, through ctypes otherwise."""
+        host = compiled_host()
+        if host is not None:
+            pc = self._pair_caller
+            if pc is None:
+                pc = self._pair_caller = host.PairCaller(self._h)
+            rc, score, status, ops = pc.align(pattern, text, want_cigar)
+            if rc != OK:
+                self._raise(rc, "wfa_hip_align_pair")
+            return score, status, ops
         st = self._pair_state
         if st is None:
             st = self._pair_state = {"score": ctypes.c_int32(0), "status": ctypes.c_int32(0), "cbeg": ctypes.c_int64(0),
@@ -320,6 +352,16 @@ def pack_2bit(seq, form=-1):
     if rc < 0:
         raise ValueError("wfa_hip_pack_2bit: invalid arguments")
     return words[:(len(a) + 15) // 16], bool(rc)
+
+
+def plan_host_threads(sharers, hw_threads=None):
+    """wfa_hip_plan_host_threads: (pack, copy) threads of ONE device's upload pipeline when `sharers` aligners / processes feed GPUs
+    from this host (host only)."""
+    pack, copy = ctypes.c_int(0), ctypes.c_int(0)
+    rc = lib().wfa_hip_plan_host_threads(int(sharers), int(hw_threads or os.cpu_count() or 1), ctypes.byref(pack), ctypes.byref(copy))
+    if rc != OK:
+        raise ValueError("wfa_hip_plan_host_threads: invalid arguments")
+    return pack.value, copy.value
 
 
 def plan_shards(p_len, t_len, nshards):

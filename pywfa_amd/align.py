@@ -467,7 +467,13 @@ class WavefrontAligner:
             patterns = list(patterns)
         if self._cfg.wildcard != self._bwildcard:
             self._push()
-        batch = datagen.from_strings(patterns, texts, upper=True)
+        # the compiled host reads the objects' buffers in place and upper-cases on OpenMP threads (pywfa_amd/host/_host.pyx); objects
+        # it does not take (non-ASCII text, other types) and builds without the extension go through datagen.from_strings, which
+        # raises what the reference raises (align.pyx:432,435)
+        host = _native.compiled_host()
+        batch = host.from_strings(patterns, texts) if host is not None else None
+        if batch is None:
+            batch = datagen.from_strings(patterns, texts, upper=True)
         return self.align_batch(batch)
 
     def align_batch(self, batch):

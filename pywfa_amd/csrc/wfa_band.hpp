@@ -2,7 +2,7 @@
 // in VGPRs over a SLIDING window of W = 64*NCH diagonals (diagonal k = B + 64*c + lane for chunk c),
 // sequences staged in LDS when they fit, wf-adaptive cut-off with ballots, and — for scope=full — the
 // per-score wavefronts streamed to an HBM history (fixed-stride records, coalesced stores) followed by
-// an on-device backtrace.  It is the long-read / full-CIGAR companion of wfa_fast.hpp and follows the
+// an on-device backtrace.  It is the long-read / full-CIGAR companion of the short-read kernels (wfa_lane.hpp, wfa_seg.hpp) and follows the
 // same rules (R = /root/reference/pywfa/WFA2_lib/wavefront):
 //   compute-next        R/wavefront_compute_affine.c:44-86   (only M clamped; I/D ends trimmed, :571-605)
 //   extend/termination  R/wavefront_extend_kernels.c:64-110, R/wavefront_termination.c:37-61
@@ -22,7 +22,6 @@
 #endif
 #include "wfa_hip.h"
 #include "wfa_common.hpp"
-#include "wfa_fast.hpp"
 #include "wfa_general.hpp"
 
 namespace wfa {
@@ -1284,12 +1283,12 @@ inline bool band_supported(const WfaDevConfig& c, int ncomp) {
 #define WFA_BAND_MATCH2(x, oe, e, oe2, e2) if (X == x && OE == oe && E == e && OE2 == oe2 && E2 == e2) return true;
     WFA_BAND_SHAPES_2P(WFA_BAND_MATCH2)
 #undef WFA_BAND_MATCH2
-    return c.rtc && rtc_shape_ok(X, OE, E, OE2, E2);
+    return c.rtc && rtc_shape_ok(X, OE, E, OE2, E2) && rtc_available();
   }
 #define WFA_BAND_MATCH(i, x, oe, e) if (X == x && OE == oe && E == e) return true;
   WFA_BAND_SHAPES(WFA_BAND_MATCH)
 #undef WFA_BAND_MATCH
-  return c.rtc && rtc_shape_ok(X, OE, E);
+  return c.rtc && rtc_shape_ok(X, OE, E) && rtc_available();
 }
 
 // the banded kernel of a shape without an instantiation, compiled at run time (csrc/wfa_rtc.cpp): the same choice of kernel and

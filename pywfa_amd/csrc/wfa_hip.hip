@@ -19,6 +19,9 @@
 #include <memory>
 #include <atomic>
 #include <functional>
+#include <ctype.h>
+#include <pthread.h>
+#include <sched.h>
 
 #include "wfa_hip.h"
 #include "wfa_common.hpp"
@@ -27,7 +30,6 @@
 #include "wfa_wide.hpp"
 #include "wfa_tile.hpp"
 #include "wfa_rtc.hpp"
-#include "wfa_fast.hpp"
 #include "wfa_seg.hpp"
 #include "wfa_lane.hpp"
 #include "wfa_band.hpp"
@@ -73,6 +75,11 @@ struct WfaKnobs {
 };
 
 struct wfa_hip_aligner {
+  int numa_state = 0;     // 0 not looked up, 1 worker threads are bound to `numa_cpus`, 2 no binding (no NUMA information, too few CPUs, WFA_HIP_NO_NUMA=1)
+  int numa_node = -1;     // NUMA node of the device's PCIe slot
+  cpu_set_t numa_cpus;    // that node's CPUs, as far as this process may run on them
+  int host_share = 1;     // aligners / processes feeding GPUs from this host (thread plan of the upload pipeline)
+  std::string rtc_note;   // why the run-time kernels were switched off (wfa_hip_batch_run), empty otherwise
   int device = 0;
   wfa_hip_config_t cfg;
   WfaDevConfig dcfg;
@@ -385,7 +392,7 @@ static void derive_dev_config(const wfa_hip_config_t& c, WfaDevConfig* d, int* n
     d->max_steps = (c.max_steps <= 0) ? INT_MAX : c.max_steps;
     d->wildcard = c.wildcard;
     d->biwfa_top = 0;
-    d->rtc = wfa::rtc_available() ? 1 : 0;
+    d->rtc = wfa::rtc_enabled() ? 1 : 0;
     map_to_gap_affine(c, d, ncomp);
     return;
   }
@@ -415,8 +422,9 @@ static void derive_dev_config(const wfa_hip_config_t& c, WfaDevConfig* d, int* n
   d->max_steps = (c.max_steps <= 0) ? INT_MAX : c.max_steps;  // align.pyx:415-417
   d->wildcard = c.wildcard;
   d->biwfa_top = 0;
-  // penalty shapes without an instantiation: the register kernels are compiled for them at run time where hipRTC works
-  d->rtc = wfa::rtc_available() ? 1 : 0;
+  // penalty shapes without an instantiation: the register kernels are compiled for them at run time where hipRTC works (probed
+  // when such a shape first asks: seg_shape / band_supported)
+  d->rtc = wfa::rtc_enabled() ? 1 : 0;
   map_to_gap_affine(c, d, ncomp);
 }
 
@@ -442,6 +450,13 @@ extern "C" wfa_hip_aligner_t* wfa_hip_create(const wfa_hip_config_t* cfg, int de
   if ((e = hipStreamCreateWithFlags(&al->stream, hipStreamNonBlocking)) != hipSuccess) { g_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete al; return nullptr; }
   if ((e = hipEventCreateWithFlags(&al->ws_event, hipEventDisableTiming)) != hipSuccess) { g_error = std::string("hipEventCreate: ") + hipGetErrorString(e); (void)hipStreamDestroy(al->stream); delete al; return nullptr; }
   al->knobs.load();
+  {
+    // one process per GPU (bench.py --gpus N under torch.distributed.run, any launcher that exports LOCAL_WORLD_SIZE): the ranks of the
+    // node share its cores; WFA_HIP_HOST_SHARE says so explicitly
+    const char* hs = getenv("WFA_HIP_HOST_SHARE");
+    if (!(hs && *hs)) hs = getenv("LOCAL_WORLD_SIZE");
+    al->host_share = (hs && atoi(hs) > 0) ? std::min(atoi(hs), 64) : 1;
+  }
   return al;
 }
 
@@ -529,15 +544,74 @@ struct UploadJob { void* dst; const void* src; size_t bytes; std::function<void(
 
 static size_t staged_slot_bytes(const wfa_hip_aligner* al) { return (size_t)std::max(1, knob(al, K_PIPE_CHUNK, 8)) << 20; }
 
-static int staged_copy_threads(const wfa_hip_aligner* al) {
-  return std::max(1, std::min(knob(al, K_PIPE_THREADS, 8), (int)std::thread::hardware_concurrency()));
+// Host threads of one device's upload pipeline.  The host is shared by every aligner / process that feeds a GPU of the node
+// (al->host_share: the devices of a wfa_hip_multi_t, the ranks of a one-process-per-GPU job), so each takes its share of the logical
+// CPUs: 8 devices on 256 CPUs pack with 16 threads and copy with 8 each (24 x 8 = 192 threads), one device alone with 32 + 8 as
+// before (8 x (32 + 8) = 320 threads on 256 CPUs).  WFA_HIP_PACK_THREADS / WFA_HIP_PIPE_THREADS override.
+extern "C" int wfa_hip_plan_host_threads(int sharers, int hw_threads, int* pack_threads, int* copy_threads) {
+  if (sharers < 1 || hw_threads < 1 || !pack_threads || !copy_threads) return WFA_HIP_EINVAL;
+  const int budget = std::max(1, hw_threads / sharers);          // logical CPUs of one sharer
+  *pack_threads = std::max(1, std::min(32, budget / 2));          // (packing is compute: more threads than the plain copy needs)
+  *copy_threads = std::max(1, std::min(8, budget / 4));
+  return WFA_HIP_OK;
 }
-static int staged_pack_threads(const wfa_hip_aligner* al) {   // (packing is compute: more threads than the plain copy needs)
-  return std::max(1, std::min(knob(al, K_PACK_THREADS, 32), std::max(1, (int)std::thread::hardware_concurrency() / 2)));
+static int staged_copy_threads(const wfa_hip_aligner* al) {
+  int pack = 1, copy = 1;
+  (void)wfa_hip_plan_host_threads(std::max(1, al->host_share), std::max(1, (int)std::thread::hardware_concurrency()), &pack, &copy);
+  return al->knobs.set[K_PIPE_THREADS] ? std::max(1, std::min(knob(al, K_PIPE_THREADS, 8), (int)std::thread::hardware_concurrency())) : copy;
+}
+static int staged_pack_threads(const wfa_hip_aligner* al) {
+  int pack = 1, copy = 1;
+  (void)wfa_hip_plan_host_threads(std::max(1, al->host_share), std::max(1, (int)std::thread::hardware_concurrency()), &pack, &copy);
+  return al->knobs.set[K_PACK_THREADS] ? std::max(1, std::min(knob(al, K_PACK_THREADS, 32), std::max(1, (int)std::thread::hardware_concurrency() / 2))) : pack;
 }
 
 // the ring serves both forms of the upload: sized for the larger team so that alternating calls do not re-allocate it
+// The pinned ring is allocated with hipHostMallocDefault: without hipHostMallocNumaUser HIP places pinned host memory on the NUMA node
+// closest to the current device.  The threads that fill it (2-bit packing, copies) are bound to that node's CPUs here, so that on a
+// two-socket host eight devices' pipelines do not pull their slots across the socket link.  The node comes from
+// sysfs (the device's PCI address), the CPUs are intersected with this process's own affinity mask; anything missing = no binding.
+static void numa_lookup(wfa_hip_aligner* al) {
+  al->numa_state = 2;
+  const char* off = getenv("WFA_HIP_NO_NUMA");
+  if (off && *off == '1') return;
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, al->device) != hipSuccess) { (void)hipGetLastError(); return; }
+  for (char* c = bus; *c; ++c) *c = (char)tolower((unsigned char)*c);
+  auto read_line = [](const std::string& path, char* buf, size_t cap) -> bool {
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    const bool ok = fgets(buf, (int)cap, f) != nullptr;
+    fclose(f);
+    return ok;
+  };
+  char line[4096];
+  if (!read_line(std::string("/sys/bus/pci/devices/") + bus + "/numa_node", line, sizeof(line))) return;
+  const int node = atoi(line);
+  if (node < 0) return;
+  if (!read_line("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist", line, sizeof(line))) return;
+  cpu_set_t allowed, want;
+  CPU_ZERO(&want);
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+  for (const char* p = line; *p && *p != '\n';) {   // "0-63,128-191"
+    char* end = nullptr;
+    const long a = strtol(p, &end, 10);
+    if (end == p) break;
+    long b = a;
+    p = end;
+    if (*p == '-') { b = strtol(p + 1, &end, 10); p = end; }
+    for (long c = a; c <= b && c < CPU_SETSIZE; ++c) if (c >= 0 && CPU_ISSET((int)c, &allowed)) CPU_SET((int)c, &want);
+    if (*p == ',') ++p;
+  }
+  if (CPU_COUNT(&want) < 8) return;   // (a container pinned to a few CPUs: leave the scheduler alone)
+  al->numa_node = node; al->numa_cpus = want; al->numa_state = 1;
+}
+static inline void bind_upload_worker(const wfa_hip_aligner* al) {
+  if (al->numa_state == 1) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &al->numa_cpus);
+}
+
 static int staged_ring(wfa_hip_aligner* al) {
+  if (al->numa_state == 0) numa_lookup(al);
   const size_t slot_bytes = staged_slot_bytes(al);
   const int nslots = std::max(staged_copy_threads(al), staged_pack_threads(al)) + 4;
   if (al->pin_slot_bytes != slot_bytes || (int)al->pin_slot.size() != nslots) {
@@ -574,6 +648,7 @@ static int staged_upload(wfa_hip_aligner* al, const std::vector<UploadJob>& jobs
   std::atomic<int> failed(0);
   const int device = al->device;
   auto worker = [&]() {
+    bind_upload_worker(al);
     (void)hipSetDevice(device);
     for (;;) {
       const long i = next.fetch_add(1);
@@ -637,6 +712,7 @@ static int staged_pack_upload(wfa_hip_aligner* al, wfa_hip_batch* b, const std::
   }
   hipStream_t const main_stream = stream;
   auto worker = [&]() {
+    bind_upload_worker(al);
     (void)hipSetDevice(device);
     for (;;) {
       const long i = next.fetch_add(1);
@@ -1064,7 +1140,22 @@ __global__ void __launch_bounds__(256) wfa_pilot_sample_kernel(const uint32_t* _
   if (i < np) out[i] = list ? list[i * stride] : i * stride;
 }
 
+// A pilot's launch failed.  If the run-time path failed under it (wfa::rtc_failure_count moved since `failures`), the batch and its
+// aligner go on without run-time shapes and the pilot's stage is left out (WFA_HIP_OK); any other failure is the device's.
+static int pilot_launch_failed(wfa_hip_aligner* al, wfa_hip_batch* b, unsigned failures) {
+  if (b->dcfg.rtc && wfa::rtc_failure_count() != failures) {
+    (void)hipGetLastError();
+    b->dcfg.rtc = 0; al->dcfg.rtc = 0;
+    al->rtc_note = std::string("run-time kernels switched off for this aligner: ") + wfa::rtc_last_error();
+    b->stage_pick = 128; b->laneh_pick = 2; b->segh_pick = 2;
+    return WFA_HIP_OK;
+  }
+  al->err = "pilot launch failed";
+  return WFA_HIP_EDEVICE;
+}
+
 static int pilot_first_width(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream) {
+  const unsigned rtc_failures = wfa::rtc_failure_count();
   const bool full = (b->cfg.scope == WFA_SCOPE_FULL);
   if (b->stage_pick != 0 || b->n_packed < 65536u) return WFA_HIP_OK;
   if (!wfa::seg_supported(b->dcfg, b->ncomp, false) || b->max_len > WFA_FAST_MAX_LEN || knob(al, K_NO_FAST, 0) != 0) return WFA_HIP_OK;
@@ -1079,7 +1170,7 @@ static int pilot_first_width(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t 
   for (int w = 16; w <= 64; w *= 2) {
     HIP_TRY(al, hipMemsetAsync(pcount, 0, sizeof(uint32_t), stream));
     if (wfa::launch_seg(b->dcfg, al->cu_count, knob(al, K_FAST_WAVES_PER_CU, 256), stream, b->d_words, b->d_meta, psample, nullptr, np, b->d_score, b->d_status,
-                        plist, pcount, w == 16 ? 2 : (w == 32 ? 4 : 5)) != 0) { al->err = "pilot launch failed"; return WFA_HIP_EDEVICE; }
+                        plist, pcount, w == 16 ? 2 : (w == 32 ? 4 : 5)) != 0) return pilot_launch_failed(al, b, rtc_failures);
     uint32_t handed = 0;
     HIP_TRY(al, hipMemcpyAsync(&handed, pcount, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY(al, hipStreamSynchronize(stream));
@@ -1100,6 +1191,7 @@ static int pilot_first_width(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t 
 // decides once per batch, when the batch is created (b->laneh_pick: 1 = first stage, 2 = not used).
 static int pilot_lane_heur(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream) {
   if (b->laneh_pick != 0 || b->cfg.scope == WFA_SCOPE_FULL) return WFA_HIP_OK;
+  const unsigned rtc_failures = wfa::rtc_failure_count();
   b->laneh_pick = 2; b->segh_pick = 2;
   int X, OE, E;
   const bool lane_ok = wfa::lane_heur_config(b->dcfg, b->ncomp);
@@ -1133,10 +1225,10 @@ static int pilot_lane_heur(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t st
   fa.steps_between = b->dcfg.steps_between; fa.max_steps = b->dcfg.max_steps; fa.xdrop = b->dcfg.xdrop;
   if (forced < 0 &&
       wfa::launch_lane_args(wfa::seg_shape(b->dcfg, &X, &OE, &E), OE, E, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8),
-                            b->max_len, stream, fa, false, 0, 256, true, X) != 0) { al->err = "pilot launch failed"; return WFA_HIP_EDEVICE; }
+                            b->max_len, stream, fa, false, 0, 256, true, X) != 0) return pilot_launch_failed(al, b, rtc_failures);
   if (forced_seg < 0 && seg_ok) {   // (the same sample through the 32-lane form; its list is not read, only its count)
     fa.fb_count = pcount + 1;
-    if (wfa::launch_seg_heur(b->dcfg, al->cu_count, knob(al, K_FAST_WAVES_PER_CU, 256), stream, fa) != 0) { al->err = "pilot launch failed"; return WFA_HIP_EDEVICE; }
+    if (wfa::launch_seg_heur(b->dcfg, al->cu_count, knob(al, K_FAST_WAVES_PER_CU, 256), stream, fa) != 0) return pilot_launch_failed(al, b, rtc_failures);
   }
   uint32_t handed[2] = {0, 0};
   HIP_TRY(al, hipMemcpyAsync(handed, pcount, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -1348,8 +1440,33 @@ static int64_t initial_arena_ints(const wfa_hip_aligner* al, const wfa_hip_batch
   return ints;
 }
 
+static int batch_run_once(wfa_hip_batch_t* b, void* stream_);
+
+// A run whose penalties have no instantiated kernel launches kernels compiled at run time.  If one of them cannot be built, loaded or
+// launched (a hipRTC / comgr failure, a shape the compiler rejects), the run is planned again without the run-time path — the tiled
+// and general kernels take those penalties, slower, with the same results — and the compiler's message is kept in the aligner's
+// error text (such a shape used to run on the general kernel before the run-time path existed, and must still run).
 extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
   if (!b) return WFA_HIP_EINVAL;
+  const unsigned failures = wfa::rtc_failure_count();
+  const size_t ev_used = b->ev_used;
+  const int runs_pending = b->runs_pending;
+  int rc = batch_run_once(b, stream_);
+  if (rc == WFA_HIP_EDEVICE && b->dcfg.rtc && wfa::rtc_failure_count() != failures) {
+    wfa_hip_aligner* al = b->al;
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(stream_ ? (hipStream_t)stream_ : al->stream);   // (what the failed run had enqueued before it gave up)
+    if (al->side_stream) (void)hipStreamSynchronize(al->side_stream);
+    b->ev_used = ev_used; b->runs_pending = runs_pending;   // (the failed run's timing events: its end was never recorded)
+    b->dcfg.rtc = 0; al->dcfg.rtc = 0;
+    al->rtc_note = std::string("run-time kernels switched off for this aligner: ") + wfa::rtc_last_error();
+    rc = batch_run_once(b, stream_);
+    if (rc != WFA_HIP_OK) al->err += " (" + al->rtc_note + ")";
+  }
+  return rc;
+}
+
+static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
   wfa_hip_aligner* al = b->al;
   HIP_TRY(al, hipSetDevice(al->device));
   hipStream_t stream = stream_ ? (hipStream_t)stream_ : al->stream;
@@ -2520,7 +2637,17 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
       const bool poll = knob(al, K_NO_TINY_POLL, 0) == 0;
       for (int64_t i = 0; i < n; ++i) hdone[i] = 0;
       ba.done = poll ? reinterpret_cast<int32_t*>(hd + b_done) : nullptr;
-      if (wfa::launch_band(ba, nch, full, al->dcfg.heuristic != WFA_HEUR_NONE, true, (long long)n, stream) != 0) { al->err = "band kernel launch failed"; return WFA_HIP_EDEVICE; }
+      const unsigned rtc_failures = wfa::rtc_failure_count();
+      if (wfa::launch_band(ba, nch, full, al->dcfg.heuristic != WFA_HEUR_NONE, true, (long long)n, stream) != 0) {
+        if (al->dcfg.rtc && wfa::rtc_failure_count() != rtc_failures) {
+          // a run-time shape that cannot be built: this aligner goes on without them (the batch path and the general kernel take the call)
+          (void)hipGetLastError();
+          al->dcfg.rtc = 0;
+          al->rtc_note = std::string("run-time kernels switched off for this aligner: ") + wfa::rtc_last_error();
+          return 0;
+        }
+        al->err = "band kernel launch failed"; return WFA_HIP_EDEVICE;
+      }
       HIP_TRY(al, hipEventRecord(al->ws_event, stream));
       al->ws_event_recorded = true; al->ws_last_stream = stream;
       bool seen = false;
@@ -2731,6 +2858,7 @@ extern "C" wfa_hip_multi_t* wfa_hip_multi_create(const wfa_hip_config_t* cfg, co
   for (int i = 0; i < ndevices; ++i) {
     wfa_hip_aligner* a = wfa_hip_create(cfg, devices[i]);
     if (!a) { for (wfa_hip_aligner* x : m->al) wfa_hip_destroy(x); delete m; return nullptr; }
+    a->host_share *= ndevices;   // (the devices of this handle share the host's cores: each pipeline takes its part)
     m->al.push_back(a);
   }
   return m;

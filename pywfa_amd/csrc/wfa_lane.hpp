@@ -46,7 +46,6 @@
 #include "wfa_rtc_compat.hpp"
 #include "wfa_common.hpp"
 #include "wfa_hip.h"
-#include "wfa_fast.hpp"
 #ifndef __HIPCC_RTC__
 #include "wfa_rtc.hpp"
 #endif

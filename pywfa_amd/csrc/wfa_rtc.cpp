@@ -16,6 +16,7 @@
 #include <string.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -32,7 +33,8 @@ namespace {
 
 std::mutex g_mu;
 std::map<std::string, hipFunction_t> g_functions;   // "device|name expression" -> function
-std::string g_error;
+thread_local std::string g_error;              // (one per host thread: the multi-device entry drives a thread per device)
+std::atomic<unsigned> g_failures{0};            // compile / load / launch failures so far (rtc_failure_count)
 
 uint64_t fnv1a(const void* p, size_t n, uint64_t h) {
   const unsigned char* c = static_cast<const unsigned char*>(p);
@@ -45,8 +47,9 @@ std::string cache_dir() {
   std::string d;
   if (e && *e) d = e;
   else {
+    // (no HOME: a directory of this user's own under /tmp — a shared name there could be prepared by someone else)
     const char* home = getenv("HOME");
-    d = std::string((home && *home) ? home : "/tmp") + "/.cache/pywfa_amd";
+    d = (home && *home) ? std::string(home) + "/.cache/pywfa_amd" : "/tmp/pywfa_amd-" + std::to_string((long)geteuid()) + "/rtc";
   }
   return d;
 }
@@ -55,14 +58,17 @@ void mkdirs(const std::string& d) {
   std::string cur;
   for (size_t i = 0; i < d.size(); ++i) {
     cur += d[i];
-    if (d[i] == '/' && cur.size() > 1) mkdir(cur.c_str(), 0755);
+    if (d[i] == '/' && cur.size() > 1) mkdir(cur.c_str(), 0700);
   }
-  mkdir(d.c_str(), 0755);
+  mkdir(d.c_str(), 0700);
 }
 
 bool read_file(const std::string& path, std::vector<char>* out) {
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) return false;
+  // a code object is loaded into this process: only a file this user owns and nobody else may write
+  struct stat st;
+  if (fstat(fileno(f), &st) != 0 || st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH)) != 0) { fclose(f); return false; }
   fseek(f, 0, SEEK_END);
   const long n = ftell(f);
   fseek(f, 0, SEEK_SET);
@@ -77,6 +83,7 @@ void write_file_atomic(const std::string& path, const std::vector<char>& data) {
   const std::string tmp = path + "." + std::to_string((long)getpid()) + ".tmp";
   FILE* f = fopen(tmp.c_str(), "wb");
   if (!f) return;
+  (void)fchmod(fileno(f), 0600);
   const bool ok = fwrite(data.data(), 1, data.size(), f) == data.size();
   fclose(f);
   if (ok) rename(tmp.c_str(), path.c_str()); else unlink(tmp.c_str());
@@ -95,15 +102,25 @@ bool code_object(const char* header, const std::string& name_expr, std::vector<c
   snprintf(key, sizeof(key), "%016llx", (unsigned long long)h);
   const std::string dir = cache_dir(), path = dir + "/rtc_" + key + ".co";
   const bool use_cache = !(getenv("WFA_HIP_RTC_NO_CACHE") && *getenv("WFA_HIP_RTC_NO_CACHE") == '1');
+  if (getenv("WFA_HIP_RTC_FAIL") && *getenv("WFA_HIP_RTC_FAIL") == '1') {   // (tests: a shape hipRTC cannot build)
+    g_error = "hipRTC could not compile " + name_expr + ": forced failure (WFA_HIP_RTC_FAIL=1)";
+    return false;
+  }
   std::vector<char> blob;
   if (use_cache && read_file(path, &blob) && blob.size() > 8) {
-    // file = u32 length of the lowered name, the name, the code object
+    // file = u32 length of the lowered name, the name, u64 FNV-1a of the code object, the code object
     uint32_t ln = 0;
     memcpy(&ln, blob.data(), 4);
-    if (ln > 0 && ln < 4096 && blob.size() > 4 + (size_t)ln) {
-      lowered->assign(blob.data() + 4, ln);
-      code->assign(blob.begin() + 4 + ln, blob.end());
-      return true;
+    if (ln > 0 && ln < 4096 && blob.size() > 4 + (size_t)ln + 8) {
+      uint64_t sum = 0;
+      memcpy(&sum, blob.data() + 4 + ln, 8);
+      const char* payload = blob.data() + 4 + ln + 8;
+      const size_t nbytes = blob.size() - (4 + ln + 8);
+      if (sum == fnv1a(payload, nbytes, 14695981039346656037ull)) {
+        lowered->assign(blob.data() + 4, ln);
+        code->assign(payload, payload + nbytes);
+        return true;
+      }
     }
   }
   std::vector<const char*> texts, names;
@@ -139,11 +156,13 @@ bool code_object(const char* header, const std::string& name_expr, std::vector<c
   hiprtcDestroyProgram(&prog);
   if (use_cache) {
     mkdirs(dir);
-    std::vector<char> out(4 + lowered->size() + code->size());
+    std::vector<char> out(4 + lowered->size() + 8 + code->size());
     const uint32_t ln = (uint32_t)lowered->size();
+    const uint64_t sum = fnv1a(code->data(), code->size(), 14695981039346656037ull);
     memcpy(out.data(), &ln, 4);
     memcpy(out.data() + 4, lowered->data(), ln);
-    memcpy(out.data() + 4 + ln, code->data(), code->size());
+    memcpy(out.data() + 4 + ln, &sum, 8);
+    memcpy(out.data() + 4 + ln + 8, code->data(), code->size());
     write_file_atomic(path, out);
   }
   return true;
@@ -152,6 +171,7 @@ bool code_object(const char* header, const std::string& name_expr, std::vector<c
 }  // namespace
 
 const char* rtc_last_error() { return g_error.c_str(); }
+unsigned rtc_failure_count() { return g_failures.load(); }
 
 bool rtc_force_all() {
   static const bool on = getenv("WFA_HIP_RTC_ALL") && *getenv("WFA_HIP_RTC_ALL") == '1';
@@ -164,18 +184,22 @@ hipFunction_t rtc_kernel(const char* header, const std::string& name_expr) {
   const std::string key = std::to_string(dev) + "|" + name_expr;
   std::lock_guard<std::mutex> lock(g_mu);
   auto it = g_functions.find(key);
-  if (it != g_functions.end()) return it->second;
+  if (it != g_functions.end()) {
+    if (!it->second) { g_error = "hipRTC could not build " + name_expr + " earlier in this process"; g_failures.fetch_add(1); }
+    return it->second;
+  }
   std::vector<char> code;
   std::string lowered;
-  if (!code_object(header, name_expr, &code, &lowered)) { g_functions[key] = nullptr; return nullptr; }
+  if (!code_object(header, name_expr, &code, &lowered)) { g_functions[key] = nullptr; g_failures.fetch_add(1); return nullptr; }
   hipModule_t mod;
   hipFunction_t fn = nullptr;
   if (hipModuleLoadData(&mod, code.data()) != hipSuccess || hipModuleGetFunction(&fn, mod, lowered.c_str()) != hipSuccess) {
     (void)hipGetLastError();
     g_error = "could not load the hipRTC code object of " + name_expr;
     fn = nullptr;
+    g_failures.fetch_add(1);
   }
-  g_functions[key] = fn;   // (a failure is remembered too: the launch sites fall back once, not on every call)
+  g_functions[key] = fn;   // (a failure is remembered too: wfa_hip_batch_run then re-plans the run without the run-time shapes)
   return fn;
 }
 
@@ -188,12 +212,20 @@ int rtc_launch(const char* header, const std::string& name_expr, unsigned grid, 
   if (hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, (unsigned)smem, stream, nullptr, config) != hipSuccess) {
     (void)hipGetLastError();
     g_error = "launch of " + name_expr + " failed";
+    g_failures.fetch_add(1);
     return -1;
   }
   return 0;
 }
 
-// can hipRTC compile at all here (libhiprtc / comgr present and working)?  Checked once per process on a trivial kernel.
+// WFA_HIP_NO_RTC=1 switches the run-time path off; no compile happens here (every aligner asks this when it is created)
+bool rtc_enabled() {
+  static const bool off = getenv("WFA_HIP_NO_RTC") && *getenv("WFA_HIP_NO_RTC") == '1';
+  return !off;
+}
+
+// can hipRTC compile at all here (libhiprtc / comgr present and working)?  Checked once per process on a trivial kernel, the
+// first time a penalty shape without an instantiation asks.
 bool rtc_available() {
   static int state = -1;
   std::lock_guard<std::mutex> lock(g_mu);

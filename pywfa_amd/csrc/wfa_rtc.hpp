@@ -5,8 +5,13 @@
 
 namespace wfa {
 
-// true when hipRTC can compile here (checked once per process; WFA_HIP_NO_RTC=1 switches it off)
+// false under WFA_HIP_NO_RTC=1 (no compile: what an aligner records when it is created)
+bool rtc_enabled();
+// true when hipRTC can compile here (a probe kernel, compiled once per process the first time a shape without an instantiation asks)
 bool rtc_available();
+// failures of the run-time path so far in this process (compile, module load, launch): wfa_hip_batch_run compares the count before
+// and after a run to tell a failed run-time shape from any other device error, and re-plans without them
+unsigned rtc_failure_count();
 // the kernel `name_expr` (a C++ name expression, e.g. "wfa::wfa_lane_kernel<5, 8, 2, false, false>") of the kernel header
 // `header` (e.g. "wfa_lane.hpp") for the current device; compiled on first use, nullptr on failure (rtc_last_error())
 hipFunction_t rtc_kernel(const char* header, const std::string& name_expr);

@@ -1,8 +1,8 @@
 // wfa_seg.hpp — segmented register kernel: the C2 hot loop (gap-affine 4/6/2-shaped penalties, match 0,
-// end-to-end, score only, no heuristic, reads <= 512 bases; same scope as wfa_fast.hpp).
+// end-to-end, score only, no heuristic, reads <= 512 bases; same scope as the lane kernel, wfa_lane.hpp).
 //
 // Why segments.  On CDNA a VALU instruction occupies its SIMD for 4 cycles however few of the 64 lanes
-// are live, and the one-alignment-per-wave kernel of wfa_fast.hpp already runs at the VALU issue limit
+// are live, and the one-alignment-per-wave kernel of round 1 already ran at the VALU issue limit
 // (rocprofv3 SQ_INSTS_VALU x 4 cycles = kernel time).  At a few percent divergence a wavefront is a dozen
 // diagonals wide, so lanes are the resource to share: the wave is cut into 64/W segments of W lanes
 // (W = 8, 16, 32 or 64), each aligning its own pair inside a band of W diagonals, k in [c - W/2, c + W/2),
@@ -32,7 +32,6 @@
 #pragma once
 #include "wfa_rtc_compat.hpp"
 #include "wfa_common.hpp"
-#include "wfa_fast.hpp"
 #ifndef __HIPCC_RTC__
 #include <string>
 #include "wfa_rtc.hpp"
@@ -500,7 +499,7 @@ inline int seg_shape(const WfaDevConfig& c, int* X, int* OE, int* E) {
 #define WFA_SEG_MATCH(i, x, oe, e) if (*X == x && *OE == oe && *E == e && !(c.rtc && rtc_force_all())) return i;
   WFA_SEG_SHAPES(WFA_SEG_MATCH)
 #undef WFA_SEG_MATCH
-  if (c.rtc && rtc_shape_ok(*X, *OE, *E)) return WFA_SHAPE_RTC;
+  if (c.rtc && rtc_shape_ok(*X, *OE, *E) && rtc_available()) return WFA_SHAPE_RTC;
   return -1;
 }
 // the segmented kernel of a run-time shape: wfa_seg_kernel<X, OE, E, W, LAZY, FULL, HEUR>
@@ -581,7 +580,7 @@ inline bool seg_heur_config(const WfaDevConfig& c, int ncomp) {
   return ncomp == 3 && c.match == 0 && c.wildcard < 0 && (c.heuristic == 0 || c.heuristic == 1 || c.heuristic == 2) && c.max_steps == INT_MAX &&
          seg_shape(c, &X, &OE, &E) >= 0;
 }
-// a.ef / a.pbf .. / a.heur .. set by the caller (wfa_fast.hpp); the work list is a.worklist / a.nwork_dev / a.nwork
+// a.ef / a.pbf .. / a.heur .. set by the caller (FastArgs, wfa_common.hpp); the work list is a.worklist / a.nwork_dev / a.nwork
 inline int launch_seg_heur(const WfaDevConfig& c, int cu_count, int per_cu, hipStream_t stream, FastArgs a) {
   int X, OE, E;
   const int idx = seg_shape(c, &X, &OE, &E);

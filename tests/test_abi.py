@@ -213,3 +213,21 @@ def test_packed2bits_helper_layout():
     assert np.array_equal(pk2["packed"], pk["packed"]) and np.array_equal(pk2["t_off"], pk["t_off"])
     with pytest.raises(ValueError):
         datagen.to_packed2bits(datagen.from_strings(["ACGN"], ["ACGT"]))
+
+
+def test_host_thread_plan_fits_the_host_for_eight_devices():
+    """each device's upload pipeline takes its share of the host — 8 devices on 256 logical CPUs must not ask
+    for more threads than there are CPUs (round 4: 8 x (32 + 8) = 320), one device alone keeps 32 + 8 (host only, no GPU)."""
+    import ctypes
+    L = _native.lib()
+    L.wfa_hip_plan_host_threads.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    pack, copy = ctypes.c_int(0), ctypes.c_int(0)
+    for hw in (8, 64, 96, 128, 256, 384):
+        for sharers in (1, 2, 4, 8):
+            assert L.wfa_hip_plan_host_threads(sharers, hw, ctypes.byref(pack), ctypes.byref(copy)) == 0
+            assert pack.value >= 1 and copy.value >= 1
+            if hw >= 4 * sharers:
+                assert sharers * (pack.value + copy.value) <= hw, (hw, sharers, pack.value, copy.value)
+    assert L.wfa_hip_plan_host_threads(1, 256, ctypes.byref(pack), ctypes.byref(copy)) == 0 and (pack.value, copy.value) == (32, 8)
+    assert L.wfa_hip_plan_host_threads(8, 256, ctypes.byref(pack), ctypes.byref(copy)) == 0 and (pack.value, copy.value) == (16, 8)
+    assert L.wfa_hip_plan_host_threads(0, 256, ctypes.byref(pack), ctypes.byref(copy)) != 0
