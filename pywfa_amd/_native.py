@@ -144,7 +144,7 @@ def compiled_host():
         if os.environ.get("WFA_HIP_NO_COMPILED_HOST") != "1":
             try:
                 from .host import _host
-                threads = max(1, min(32, (os.cpu_count() or 2) // 2))
+                threads = max(1, min(64, (os.cpu_count() or 2) // 2))
                 _host.bind(ctypes.cast(lib().wfa_hip_align_pair, ctypes.c_void_p).value, threads)
                 _HOST = _host
             except ImportError:

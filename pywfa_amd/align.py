@@ -379,6 +379,7 @@ class WavefrontAligner:
         cfg.wildcard = self._bwildcard
         self._cfg = cfg
         self._native = _native.Aligner(cfg, device)  # raises if no library / no GPU / bad config
+        self._host_scratch = {}   # buffers of the compiled host's batch marshalling (pywfa_amd/host/_host.pyx), kept between calls
         # devices=[...] (additive): batches given to wavefront_align_batch / align_batch are sharded over these GPUs of the
         # node (contiguous shards balanced by bases, one host thread per device, no collective); single pairs and resident
         # batches stay on `device`
@@ -458,20 +459,21 @@ class WavefrontAligner:
 
         Returns dict(score=int32[n], status=int32[n], cigarstrings=sequence of str, cigar_ops=sequence of uint8 arrays
         (scope full; built from the GPU's run-length encoding when an item is read))."""
-        texts = list(texts)
+        texts = texts if type(texts) is list else list(texts)
         if patterns is None:
             if self._bpattern is None:
                 raise ValueError("pattern is None")
             patterns = self._bpattern  # stored once in the batch: every pair points to it
         else:
-            patterns = list(patterns)
+            patterns = patterns if type(patterns) is list else list(patterns)
         if self._cfg.wildcard != self._bwildcard:
             self._push()
         # the compiled host reads the objects' buffers in place and upper-cases on OpenMP threads (pywfa_amd/host/_host.pyx); objects
         # it does not take (non-ASCII text, other types) and builds without the extension go through datagen.from_strings, which
         # raises what the reference raises (align.pyx:432,435)
         host = _native.compiled_host()
-        batch = host.from_strings(patterns, texts) if host is not None else None
+        # (its blob and offset arrays are kept between calls: align_batch below returns only after the upload, and keeps nothing of the batch)
+        batch = host.from_strings(patterns, texts, self._host_scratch) if host is not None else None
         if batch is None:
             batch = datagen.from_strings(patterns, texts, upper=True)
         return self.align_batch(batch)

@@ -43,6 +43,11 @@ def test_marshalling_equals_the_python_path(host):
         same(datagen.from_strings(shared.encode(), txts), host.from_strings(shared.encode(), txts))
     big = [rs(150) for _ in range(20000)]       # (past the size where the OpenMP threads start)
     same(datagen.from_strings(big[:10000], big[10000:]), host.from_strings(big[:10000], big[10000:]))
+    # buffers kept between calls (what WavefrontAligner does): a large batch, a small one, a larger one again
+    scratch = {}
+    for lo, hi in ((0, 6000), (100, 130), (0, 10000), (5, 6)):
+        same(datagen.from_strings(big[lo:hi], big[10000 + lo:10000 + hi]), host.from_strings(big[lo:hi], big[10000 + lo:10000 + hi], scratch))
+        same(datagen.from_strings(big[0], big[lo:hi]), host.from_strings(big[0], big[lo:hi], scratch))
 
 
 def test_objects_only_the_python_path_may_judge(host):

@@ -1,5 +1,7 @@
 """Parity tests proper: the HIP path (through the C ABI of libwfa_hip.so) against the oracle on the
 same seeded inputs, and against the committed golden vectors.  Bit-exact: status, score, op string."""
+import os
+
 import numpy as np
 import pytest
 
@@ -83,6 +85,11 @@ def corpora():
 @pytest.mark.parametrize("cfg_idx", range(len(GRID)))
 @pytest.mark.parametrize("corpus", list(SHAPES) + ["special"])
 def test_hip_matches_oracle(gpu, corpora, corpus, cfg_idx, monkeypatch):
+    # (the 4-corpus x 90-configuration grid is sampled by a fixed stride under -m gpu — every configuration on
+    # two of the four corpora, every corpus under half of the configurations; WFA_TEST_FULL=1 runs all of it, as the builder does
+    # through gpurun)
+    if os.environ.get("WFA_TEST_FULL") != "1" and (cfg_idx + (list(SHAPES) + ["special"]).index(corpus)) % 2 == 1:
+        pytest.skip("grid sampled by stride (WFA_TEST_FULL=1 runs every cell)")
     # (non-resident calls of <= 4 096 short pairs take the single-launch path; every fourth configuration keeps the batch machinery —
     # pageable upload, device pack, the kernel cascade — covered at these sizes)
     if cfg_idx % 4 == 0:
@@ -373,7 +380,8 @@ def test_piggyback_history_gives_the_same_cigars(gpu, kw, band_pb, monkeypatch):
     The reference returns the same alignments in all its memory modes, and so must both forms."""
     if band_pb != "default":
         monkeypatch.setenv("WFA_HIP_BAND_PB", band_pb)
-    for i, (n, L, e) in enumerate([(700, 1500, 0.06), (300, 4000, 0.08), (120, 10000, 0.08), (400, 2500, 0.01)]):
+    # (sizes on the suite's time budget, VERDICT r04 item 6: the oracle's CPU time is what these tests take)
+    for i, (n, L, e) in enumerate([(300, 1500, 0.06), (100, 4000, 0.08), (32, 10000, 0.08), (150, 2500, 0.01)]):
         batch = datagen.generate(n, L, e, 8800 + i)
         kw2 = common.clamp_free(dict(kw, scope="full"), batch)
         oc, nc = common.configs_pair(**kw2)
@@ -398,7 +406,7 @@ def test_piggyback_history_gap_affine_2p(gpu, kw, band_pb, monkeypatch):
     if band_pb != "default":
         monkeypatch.setenv("WFA_HIP_BAND_PB", band_pb)
     exact = "heuristic" not in kw
-    shapes = [(300, 1500, 0.06), (24, 3000, 0.08)] if exact else [(500, 1500, 0.06), (200, 4000, 0.08), (100, 10000, 0.08), (300, 2500, 0.01)]
+    shapes = [(300, 1500, 0.06), (24, 3000, 0.08)] if exact else [(200, 1500, 0.06), (60, 4000, 0.08), (24, 10000, 0.08), (100, 2500, 0.01)]
     for i, (n, L, e) in enumerate(shapes):
         batch = datagen.generate(n, L, e, 8900 + i)
         if i == 0:

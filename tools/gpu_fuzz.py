@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential test of the HIP path against the oracle (development aid): random configurations drawn from
 what the library accepts, random read lengths / divergences / length differences, batches large enough to reach the
-register kernels.  python tools/gpu_fuzz.py [rounds] [seed]"""
+register kernels.  python tools/gpu_fuzz.py [rounds] [seed] [seconds]   (seconds: no new round is started after that many)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -12,10 +12,16 @@ import common
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+budget_s = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0   # (the -m gpu slice runs on a time budget: tests/test_fuzz_gpu.py)
+t_start = time.time()
+rounds_done = 0
 PEN = [(4, 6, 2), (4, 6, 2), (4, 6, 2), (4, 4, 2), (4, 6, 1), (3, 4, 1), (6, 5, 3), (5, 0, 3), (1, 1, 1), (2, 3, 1), (7, 3, 2),
        (5, 6, 2), (3, 5, 1), (2, 8, 1), (7, 11, 3), (9, 2, 4)]   # (round 4: shapes without an instantiation: compiled at run time)
 bad_total = 0
 for it in range(rounds):
+    if budget_s and time.time() - t_start > budget_s:
+        break
+    rounds_done += 1
     x, o, e = PEN[int(rng.integers(len(PEN)))]
     kw = dict(mismatch=x, gap_opening=o, gap_extension=e, scope=str(rng.choice(["score", "full"])),
               span=str(rng.choice(["end-to-end", "ends-free"])))
@@ -46,7 +52,9 @@ for it in range(rounds):
         err = float(rng.choice([0.0, 0.01, 0.02, 0.02, 0.05, 0.1, 0.25]))
         n = int(rng.choice([300, 2000, 9000, 9000, 70000])) if L <= 250 else int(rng.choice([100, 700]))
         if it % 7 == 3 and part == 0: L, n = int(rng.choice([1500, 3000, 6000])), int(rng.choice([60, 160, 300]))  # long reads: banded kernel, split launches, wide-wavefront kernel
-        if it % 21 == 10 and part == 0: L, n = int(rng.choice([22000, 30000])), int(rng.choice([40, 140]))  # reads over 20 kb: 256-diagonal first window, the wide kernel's cut-off, piggy-back arena of the general kernel
+        if it % 21 == 10 and part == 0:
+            L, n = int(rng.choice([22000, 30000])), int(rng.choice([40, 140]))
+            if budget_s: n = 6   # (on a time budget: the oracle's exact gap-affine-2p runs at 30 kb take a second each)  # reads over 20 kb: 256-diagonal first window, the wide kernel's cut-off, piggy-back arena of the general kernel
         b = datagen.generate(n, L, err, int(rng.integers(1, 1 << 30)))
         cut = rng.integers(0, 20, size=n) * (rng.random(n) < 0.3)
         for i in (range(n) if n <= 9000 else range(0)):
@@ -98,5 +106,6 @@ for it in range(rounds):
     if bad:
         i = int(np.flatnonzero((score != o_["score"]) | (status != o_["status"]))[0]) if ((score != o_["score"]) | (status != o_["status"])).any() else next(i for i in range(len(score)) if bytes(cig[i]) != o_["cigars"][i])
         print("  first bad", i, o_["score"][i], score[i], o_["status"][i], status[i], datagen.pair_strings(batch, i))
+print("ROUNDS", rounds_done, "of", rounds)
 print("TOTAL BAD", bad_total)
 sys.exit(1 if bad_total else 0)
