@@ -4,7 +4,7 @@
 
 namespace wfa {
 #define WFA_SLIM_DEFINE(i, x, oe, e) \
-  int launch_slim_s##i(const BandArgs& a, bool full, long long grid, hipStream_t s) { return launch_slim_shape<x, oe, e, 0, 0>(a, full, grid, s); }
+  int launch_slim_s##i(const BandArgs& a, int nch, bool full, long long grid, hipStream_t s) { return launch_slim_shape<x, oe, e, 0, 0>(a, nch, full, grid, s); }
 #if WFA_TU_INDEX == 0
 WFA_SLIM_DEFINE(0, 2, 4, 1)
 #elif WFA_TU_INDEX == 1
@@ -14,7 +14,7 @@ WFA_SLIM_DEFINE(2, 4, 7, 1)
 #elif WFA_TU_INDEX == 3
 WFA_SLIM_DEFINE(3, 3, 5, 1)
 #elif WFA_TU_INDEX == 4
-int launch_slim_s4(const BandArgs& a, bool full, long long grid, hipStream_t s) { return launch_slim_shape<4, 8, 2, 25, 1>(a, full, grid, s); }
+int launch_slim_s4(const BandArgs& a, int nch, bool full, long long grid, hipStream_t s) { return launch_slim_shape<4, 8, 2, 25, 1>(a, nch, full, grid, s); }
 #else
 #error "WFA_TU_INDEX: 0..3 = the gap-affine shapes of WFA_BAND_SHAPES, 4 = gap-affine-2p"
 #endif

@@ -910,11 +910,13 @@ wfa_band_pb_bt_kernel(const BandArgs a) {
   int h = max(k, 0), v = h - k;
   int nruns = 0;
   long long total = 0;
+  uint32_t run_op = 0, run_len = 0;   // the run being built stays in registers (round 5: the record was re-read from memory at every emit)
   auto emit = [&](int op, int n) {
     if (n <= 0) return;
     total += n;
-    if (nruns > 0 && (int)(runs[nruns - 1] & 0xFFu) == op) runs[nruns - 1] += (uint32_t)n << 8;
-    else runs[nruns++] = ((uint32_t)n << 8) | (uint32_t)op;
+    if (run_len > 0 && (int)run_op == op) { run_len += (uint32_t)n; return; }
+    if (run_len > 0) runs[nruns++] = (run_len << 8) | run_op;
+    run_op = (uint32_t)op; run_len = (uint32_t)n;
   };
   emit('I', h); emit('D', v);
   { const int n = pb_lcp(P, T, v, h, min(plen - v, tlen - h)); emit('M', n); v += n; h += n; }
@@ -926,6 +928,7 @@ wfa_band_pb_bt_kernel(const BandArgs a) {
     if (ev[e] & 0x80) { const int n = pb_lcp(P, T, v, h, min(plen - v, tlen - h)); emit('M', n); v += n; h += n; }
   }
   emit('I', tlen - h); emit('D', plen - v);
+  if (run_len > 0) runs[nruns++] = (run_len << 8) | run_op;
   a.end_state[t] = make_int4((int)((long long)plen + tlen - total), nruns, 1, 2);  // .z = 1: runs in forward order
 }
 
@@ -1254,13 +1257,18 @@ WFA_BAND_SHAPES(WFA_BAND_DECL)
 #undef WFA_BAND_DECL
 int launch_band_s4(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds, long long grid, hipStream_t stream);  // 2p
 // the slim form (wfa_slim.hpp, csrc/k_slim.hip): one translation unit per gap-affine shape
-#define WFA_SLIM_DECL(i, x, oe, e) int launch_slim_s##i(const BandArgs& a, bool full, long long grid, hipStream_t stream);
+#define WFA_SLIM_DECL(i, x, oe, e) int launch_slim_s##i(const BandArgs& a, int nch, bool full, long long grid, hipStream_t stream);
 WFA_BAND_SHAPES(WFA_SLIM_DECL)
 #undef WFA_SLIM_DECL
-int launch_slim_s4(const BandArgs& a, bool full, long long grid, hipStream_t stream);  // 2p
-// launches the slim form covers: the first window of the wf-adaptive long-read cascade (128 diagonals, gap-affine-2p: 192)
+int launch_slim_s4(const BandArgs& a, int nch, bool full, long long grid, hipStream_t stream);  // 2p
+// launches the slim form covers: the wf-adaptive long-read cascade — its first window (128 diagonals, gap-affine-2p: 192; score-only
+// or the piggy-back history of a split launch) and the 256-diagonal stage behind it (score-only or the explicit int16 history, walked
+// in-kernel)
 inline bool slim_takes(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds) {
-  return a.slim && nch == (a.oe2 > 0 ? 3 : 2) && adapt && a.heur == 1 && seqlds && !a.done && a.debug == 0 && (!full || (a.split && a.pb));
+  if (!a.slim || !adapt || a.heur != 1 || !seqlds || a.done || a.debug != 0) return false;
+  if (nch == (a.oe2 > 0 ? 3 : 2)) return !full || (a.split && a.pb);
+  if (nch == 4) return !full || (!a.split && a.h16);
+  return false;
 }
 
 // configurations the band kernel covers: gap-affine / gap-affine-2p with an instantiated penalty shape
@@ -1328,12 +1336,12 @@ inline int launch_band(const BandArgs& a, int nch, bool full, bool adapt, bool s
   if (rtc_force_all() && rtc_available()) return launch_band_rtc(a, nch, full, adapt, seqlds, grid, stream);
   if (a.oe2 > 0) {
     const int OE2 = a.oe2 / g, E2 = a.e2 / g;
-#define WFA_BAND_LAUNCH2(x_, oe_, e_, oe2_, e2_) if (X == x_ && OE == oe_ && E == e_ && OE2 == oe2_ && E2 == e2_) return slim_takes(a, nch, full, adapt, seqlds) ? launch_slim_s4(a, full, grid, stream) : launch_band_s4(a, nch, full, adapt, seqlds, grid, stream);
+#define WFA_BAND_LAUNCH2(x_, oe_, e_, oe2_, e2_) if (X == x_ && OE == oe_ && E == e_ && OE2 == oe2_ && E2 == e2_) return slim_takes(a, nch, full, adapt, seqlds) ? launch_slim_s4(a, nch, full, grid, stream) : launch_band_s4(a, nch, full, adapt, seqlds, grid, stream);
     WFA_BAND_SHAPES_2P(WFA_BAND_LAUNCH2)
 #undef WFA_BAND_LAUNCH2
     return launch_band_rtc(a, nch, full, adapt, seqlds, grid, stream);
   }
-#define WFA_BAND_LAUNCH(i, x, oe, e) if (X == x && OE == oe && E == e) return slim_takes(a, nch, full, adapt, seqlds) ? launch_slim_s##i(a, full, grid, stream) : launch_band_s##i(a, nch, full, adapt, seqlds, grid, stream);
+#define WFA_BAND_LAUNCH(i, x, oe, e) if (X == x && OE == oe && E == e) return slim_takes(a, nch, full, adapt, seqlds) ? launch_slim_s##i(a, nch, full, grid, stream) : launch_band_s##i(a, nch, full, adapt, seqlds, grid, stream);
   WFA_BAND_SHAPES(WFA_BAND_LAUNCH)
 #undef WFA_BAND_LAUNCH
   return launch_band_rtc(a, nch, full, adapt, seqlds, grid, stream);

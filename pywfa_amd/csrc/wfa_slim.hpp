@@ -26,6 +26,9 @@
 #pragma once
 #include "wfa_band.hpp"
 
+#ifndef WFA_SLIM_HP
+#define WFA_SLIM_HP 8
+#endif
 #ifndef WFA_SLIM_WAVES
 #define WFA_SLIM_WAVES 7
 #endif
@@ -77,12 +80,17 @@ __device__ __forceinline__ unsigned long long slim_range_mask(int c, int lo, int
   return (~0ull << max(l, 0)) & (~0ull >> (63 - min(h, 63)));
 }
 
-template <int NCH, bool FULL, int X, int OE, int E, int OE2, int E2>
+// HIST: 0 score only; 1 piggy-back history of a split launch (one byte per active diagonal and step in the pair's slot; the walk runs
+// in wfa_band_pb_bt_kernel afterwards); 2 the explicit history of wfa_band_kernel's unsplit form ({M, I, D, window base} per window
+// position and step in the workgroup's slice, walked in-kernel by band_backtrace) — the stage BEHIND the split one, which takes the
+// few pairs a window hands on: there the latency of one alignment is what counts, and this step is a third of wfa_band_kernel's.
+template <int NCH, int HIST, int X, int OE, int E, int OE2, int E2>
 __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
+  constexpr bool FULL = HIST != 0, PBH = HIST == 1, XH = HIST == 2;
   constexpr bool TWO = OE2 > 0;  // gap-affine-2p: second pair of gap components (R/wavefront_compute_affine2p.c:45-106)
   constexpr int E2D = TWO ? E2 : 1;
   typedef Band<NCH> BD;
-  constexpr int W = BD::W, WI = BD::WI, HP = 8;
+  constexpr int W = BD::W, WI = BD::WI, HP = WFA_SLIM_HP;   // steps between hull checks
   constexpr int DM = (X > OE) ? X : OE;                      // M history in registers: depths 1 .. DM
   constexpr int NP = TWO ? (OE2 - DM + 1) / 2 + 1 : 1;       // 2p: depths DM + 1 .. OE2 as int16 pairs, two depths per register
   static_assert(!TWO || OE2 > DM, "2p: o2 + e2 is the deepest history read");
@@ -92,15 +100,18 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
   uint32_t* const sT = slds + a.lds_words;
   const int lane = threadIdx.x;
   const uint32_t nwork = a.nwork_dev ? *a.nwork_dev : a.nwork;
-  const uint32_t w0 = FULL ? a.work_begin : 0u;
-  const int max_records = FULL ? (int)min((long long)INT_MAX, a.pb_code_ints / (WI / 4)) : INT_MAX;
+  const uint32_t w0 = PBH ? a.work_begin : 0u;
+  constexpr int XREC = TWO ? BD::REC : BD::REC / 2;   // explicit history: ints per record (gap-affine: 4 x int16 per position; 2p: 16 bytes)
+  const int max_records = PBH ? (int)min((long long)INT_MAX, a.pb_code_ints / (WI / 4))
+                              : (XH ? (int)min((long long)INT_MAX, a.hist_stride / XREC) : INT_MAX);
+  int* const xhist = XH ? a.hist + (long long)blockIdx.x * a.hist_stride : nullptr;   // explicit history: this workgroup's slice
   const int thr2 = 2 * a.max_dist_thr;
   for (uint32_t wi = w0 + blockIdx.x; wi < w0 + nwork; wi += gridDim.x) {
     const uint32_t pair = a.worklist ? a.worklist[wi] : wi;
     const WfaPairMeta pm = a.meta[pair];
     const int plen = pm.plen, tlen = pm.tlen;
     const int ak = tlen - plen;
-    uint8_t* const rec = FULL ? reinterpret_cast<uint8_t*>(a.hist + (long long)(wi - w0) * a.hist_stride) : nullptr;   // this pair's history slot
+    uint8_t* const rec = PBH ? reinterpret_cast<uint8_t*>(a.hist + (long long)(wi - w0) * a.hist_stride) : nullptr;   // this pair's history slot
     const uint32_t* gP = a.words + pm.p_woff;
     const uint32_t* gT = a.words + pm.t_woff;
     const int nwp = (plen + 15) >> 4, nwt = (tlen + 15) >> 4;
@@ -127,14 +138,15 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
       // offset that ends the alignment on this diagonal
       int kk2[NCH], lim2[NCH], lim2c[NCH], dlim2[NCH], ethr[NCH];
       int cur[NCH], Mh[DM][NCH], Ih[E][NCH], Dh[E][NCH], I2h[E2D][NCH], D2h[E2D][NCH], PH[NP][NCH];
-      uint32_t hoff[NCH];  // byte of this diagonal in the history record compute-next fills: (step + 1) * WI + (k mod WI)
+      uint32_t hoff[NCH];  // piggy-back: byte of this diagonal in the history record compute-next fills: (step + 1) * WI + (k mod WI);
+                           // explicit history: its position k mod WI in a record
       int step = 0;        // (the score of a step is step * g)
       // window geometry -> the per-lane constants
       auto set_lane_constants = [&]() {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
           const int k = B + c * 64 + lane;
-          kk2[c] = 2 * k; hoff[c] = (uint32_t)(step + 1) * WI + ((uint32_t)k & (WI - 1));
+          kk2[c] = 2 * k; hoff[c] = (PBH ? (uint32_t)(step + 1) * WI : 0u) + ((uint32_t)k & (WI - 1));
           lim2[c] = 2 * min(tlen, plen + k); lim2c[c] = max(lim2[c], 0); dlim2[c] = 2 * max(tlen, plen + k);
           if (a.ef) {
             // (h >= tlen and plen - v <= pef) or (v >= plen and tlen - h <= tef), v = h - k (R/wavefront_termination.c:115-162):
@@ -299,6 +311,22 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
             slim_keep(cur[c], keep[c]); slim_keep(Ih[0][c], keep[c]); slim_keep(Dh[0][c], keep[c]);
             if (TWO) { slim_keep(I2h[0][c], keep[c]); slim_keep(D2h[0][c], keep[c]); }
           }
+          if (XH) {
+            // explicit history of score s (after the cut-off, so dropped lanes read NULL): one entry per window position, the layout
+            // band_backtrace reads (wfa_band.hpp: int16 halves, negative -> -1; offsets are doubled here); inactive chunks hold nothing
+            int* const xr = xhist + (long long)step * XREC;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+              const bool on = c < ACT;
+              const int m_ = on ? sat16(cur[c] >> 1) : -1, i_ = on ? sat16(Ih[0][c] >> 1) : -1, d_ = on ? sat16(Dh[0][c] >> 1) : -1;
+              if (TWO) {
+                const int i2_ = on ? sat16(I2h[0][c] >> 1) : -1, d2_ = on ? sat16(D2h[0][c] >> 1) : -1;
+                reinterpret_cast<int4*>(xr)[hoff[c]] = make_int4((m_ & 0xffff) | (i_ << 16), (d_ & 0xffff) | (B << 16), (i2_ & 0xffff) | (d2_ << 16), 0);
+              } else {
+                reinterpret_cast<short4*>(xr)[hoff[c]] = make_short4((short)m_, (short)i_, (short)d_, (short)B);
+              }
+            }
+          }
           // ---------------- compute-next for score s + g (R/wavefront_compute_affine.c:44-86, R/wavefront_compute_affine2p.c:45-106) ----------------
           if (TWO) {
             // the value leaving depth DM enters the packed ring: PH[0].lo = depth DM + 1, PH[0].hi = DM + 2, ...
@@ -356,7 +384,7 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
               t = max(t, max(ni2[c], nd2[c]));
             }
             const int m = max(x1, t);
-            if (FULL) {
+            if (PBH) {
               // the choice the backtrace would make (R/wavefront_backtrace.c:49-59: mismatch > D2 > D1 > I2 > I1, extension > opening on
               // equal offsets), taken where the candidates are in registers — the piggy-back history of score s + g: one byte per
               // active diagonal, stored here (the window may move before the next step begins; the record of score 0 is never read).
@@ -528,9 +556,12 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
         } else if (NCH == 2 || act == 2) {
 #pragma unroll 1
           while (togo > 0) { --togo; step_fn(band_int<2>{}); }
+        } else if (NCH == 3 || act == 3) {
+#pragma unroll 1
+          while (togo > 0) { --togo; step_fn(band_int<(NCH > 3 ? 3 : NCH)>{}); }
         } else {
 #pragma unroll 1
-          while (togo > 0) { --togo; step_fn(band_int<(NCH > 2 ? NCH : 2)>{}); }
+          while (togo > 0) { --togo; step_fn(band_int<NCH>{}); }
         }
       }
 #ifdef WFA_SLIM_COUNTERS
@@ -550,7 +581,17 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
       a.cigar_begin[pair] = a.cigar_off[pair + 1];
       a.cigar_len[pair] = 0;
     }
-    if (FULL && lane == 0) a.end_state[wi - w0] = make_int4(end_s, end_k, end_off, (fallback || stop_status != 0 || !done) ? 0 : 1);
+    if (PBH && lane == 0) a.end_state[wi - w0] = make_int4(end_s, end_k, end_off, (fallback || stop_status != 0 || !done) ? 0 : 1);
+    if (XH && done && !fallback && stop_status == 0) {
+      __syncthreads();   // this wave's history stores before its own loads
+      long long begin = 0;
+      uint8_t* buf = a.cigar_ops + a.cigar_off[pair];
+      band_backtrace<NCH>(xhist, a, plen, tlen, end_s, end_k, end_off, buf, &begin, lane, 64);
+      if (lane == 0) {
+        a.cigar_begin[pair] = a.cigar_off[pair] + begin;
+        a.cigar_len[pair] = (int)((long long)plen + tlen - begin);
+      }
+    }
     if (lane == 0) {
       if (fallback) {
         a.status[pair] = WFA_INTERNAL_FALLBACK;
@@ -566,30 +607,39 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
   }
 }
 
-template <int NCH, bool FULL, int X, int OE, int E, int OE2, int E2>
+template <int NCH, int HIST, int X, int OE, int E, int OE2, int E2>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WFA_SLIM_WAVES, WFA_SLIM_WAVES)))
-wfa_slim_kernel(const BandArgs a) {   // gap-affine: eight waves per SIMD (<= 64 VGPRs; the sequences of 10 kb reads in LDS allow eight)
-  wfa_slim_body<NCH, FULL, X, OE, E, OE2, E2>(a);
+wfa_slim_kernel(const BandArgs a) {   // gap-affine, 128 diagonals: seven waves per SIMD (<= 72 VGPRs; the sequences of 10 kb reads in LDS allow eight)
+  wfa_slim_body<NCH, HIST, X, OE, E, OE2, E2>(a);
 }
-template <int NCH, bool FULL, int X, int OE, int E, int OE2, int E2>
+template <int NCH, int HIST, int X, int OE, int E, int OE2, int E2>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
+wfa_slim_kernel_tail(const BandArgs a) {   // 256 diagonals, the stage behind the first window: few pairs; at least two waves per SIMD
+  wfa_slim_body<NCH, HIST, X, OE, E, OE2, E2>(a);   // (gap-affine-2p would take 297 registers: C4's tail is a few thousand pairs)
+}
+template <int NCH, int HIST, int X, int OE, int E, int OE2, int E2>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WFA_SLIM_WAVES_2P, WFA_SLIM_WAVES_2P)))
 wfa_slim_kernel_2p(const BandArgs a) {   // gap-affine-2p: 25 ring registers per chunk; three waves per SIMD (<= 168 VGPRs) measured best (C4 with wf-adaptive, 10 k pairs: 21.3 ms against 25.8 ms at four waves with spills and 23.2 ms at two)
-  wfa_slim_body<NCH, FULL, X, OE, E, OE2, E2>(a);
+  wfa_slim_body<NCH, HIST, X, OE, E, OE2, E2>(a);
 }
 
 #ifndef __HIPCC_RTC__
 template <int X, int OE, int E, int OE2, int E2>
-static int launch_slim_shape(const BandArgs& a, bool full, long long grid, hipStream_t stream) {
-  constexpr int NCH = (OE2 > 0) ? 3 : 2;
+static int launch_slim_shape(const BandArgs& a, int nch, bool full, long long grid, hipStream_t stream) {
+  constexpr int NCH1 = (OE2 > 0) ? 3 : 2;   // the first window: 128 diagonals, gap-affine-2p 192
   size_t smem = (size_t)a.lds_words * 2 * sizeof(uint32_t);
   static const int pad_kb = getenv("WFA_HIP_SLIM_LDS_PAD_KB") ? atoi(getenv("WFA_HIP_SLIM_LDS_PAD_KB")) : 0;   // (occupancy experiments)
   smem += (size_t)pad_kb << 10;
-  if constexpr (OE2 > 0) {
-    if (full) hipLaunchKernelGGL((wfa_slim_kernel_2p<NCH, true, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
-    else hipLaunchKernelGGL((wfa_slim_kernel_2p<NCH, false, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+  if (nch == 4) {
+    // the stage behind it: 256 diagonals, explicit history walked in-kernel
+    if (full) hipLaunchKernelGGL((wfa_slim_kernel_tail<4, 2, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+    else hipLaunchKernelGGL((wfa_slim_kernel_tail<4, 0, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+  } else if constexpr (OE2 > 0) {
+    if (full) hipLaunchKernelGGL((wfa_slim_kernel_2p<NCH1, 1, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+    else hipLaunchKernelGGL((wfa_slim_kernel_2p<NCH1, 0, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
   } else {
-    if (full) hipLaunchKernelGGL((wfa_slim_kernel<NCH, true, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
-    else hipLaunchKernelGGL((wfa_slim_kernel<NCH, false, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+    if (full) hipLaunchKernelGGL((wfa_slim_kernel<NCH1, 1, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+    else hipLaunchKernelGGL((wfa_slim_kernel<NCH1, 0, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -45,6 +45,10 @@ CONFIGS = [
     dict(distance="affine2p", span="ends-free", heuristic="adaptive", pattern_begin_free=20, text_begin_free=30, text_end_free=50,
          min_wavefront_length=5, max_distance_threshold=20, steps_between_cutoffs=2),
     dict(distance="affine2p", span="end-to-end", heuristic="adaptive", max_steps=1500),
+    # wavefronts that outgrow the first window: the 256-diagonal stage behind it (explicit history, walked in-kernel)
+    dict(span="end-to-end", heuristic="adaptive", max_distance_threshold=130),
+    dict(span="ends-free", heuristic="adaptive", max_distance_threshold=160, pattern_begin_free=30, text_end_free=20),
+    dict(distance="affine2p", span="end-to-end", heuristic="adaptive", max_distance_threshold=110),
 ]
 
 
