@@ -461,6 +461,39 @@ def c3_leg(rank, world, local_rank, pairs, steps, dist, backend):
             "per_rank_alignments_per_s": spread["per_rank"]}
 
 
+def python_host_leg(n=1_000_000):
+    """The drop-in surface itself: `WavefrontAligner.wavefront_align_batch(texts, patterns)` on `n` Python str pairs
+    of 150 bp (scope = score; best of three calls after a warm-up: the first large call pins the upload ring), and the per-call cost of
+    `wavefront_align(text)` — pywfa's own usage pattern.  Scores are checked against the resident C2 path's."""
+    import pywfa_amd
+    from pywfa_amd import _native, datagen
+    b = datagen.generate(n, 150, 0.02, datagen.SEEDS["C2"])
+    blob = b["seqs"].tobytes().decode("ascii")
+    po, pl, to, tl = (b[k].tolist() for k in ("p_off", "p_len", "t_off", "t_len"))
+    pats = [blob[po[i]:po[i] + pl[i]] for i in range(n)]
+    txts = [blob[to[i]:to[i] + tl[i]] for i in range(n)]
+    a = pywfa_amd.WavefrontAligner(scope="score", span="end-to-end")
+    a.wavefront_align_batch(txts[:1000], pats[:1000])
+    a.wavefront_align_batch(txts, pats)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        r = a.wavefront_align_batch(txts, pats)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    al = _native.Aligner(a._cfg, 0)
+    ref, _, _ = al.align_batch(b, False)
+    al.close()
+    m = 2000
+    t0 = time.perf_counter()
+    for i in range(m):
+        a.wavefront_align(txts[i], pats[i])
+    single = (time.perf_counter() - t0) / m
+    return {"pairs": n, "seconds_per_call": best, "pairs_per_s": n / best, "single_call_us": single * 1e6,
+            "compiled_host": _native.compiled_host() is not None, "score_mismatches": int((r["score"] != ref).sum()),
+            "what": "WavefrontAligner.wavefront_align_batch(list[str], list[str]), scope=score, 150 bp; wavefront_align(text, pattern) per call"}
+
+
 def multi_leg(pairs_per_device, length=100000, calls=2):
     """C5 through ONE process's wfa_hip_multi_align_batch over every visible device (the product's own sharding):
     host ASCII in -> host results out, so this rate includes PCIe.  X-drop(20) as BASELINE writes C5 (every pair is dropped
@@ -775,6 +808,13 @@ def main():
                      cfg_kw=dict(distance="linear", span="end-to-end", scope="score"), scheme="none", survey_bytes=84, cpu_pairs=200000, cpu_budget=2.0),
                 dict(name="C4-adaptive-mismatch5", n=20_000, length=10000, error=0.08, seed=datagen.SEEDS["C4"], cfg_kw=dict(C4, heuristic="adaptive", mismatch=5),
                      scheme="piggyback", survey_bytes=114e3 * 5 / 3, trim=50, cpu_pairs=60),
+                # BiWFA (memory_mode="biwfa", SURVEY §8 f4: the O(s)-memory form the reference offers for long reads): bytes per pair = the packed
+                # sequences + the op string (its rings live in the workspace and are re-used per score)
+                dict(name="BiWFA-10kb", n=2000, length=10000, error=0.08, seed=datagen.SEEDS["C3"],
+                     cfg_kw=dict(span="end-to-end", scope="full", memory_mode="biwfa"), scheme="none", survey_bytes=2 * 2500 + 10_800 + 8, cpu_pairs=16, cpu_budget=3.0),
+                dict(name="BiWFA-100kb", n=64, length=100000, error=0.08, seed=datagen.SEEDS["C5"],
+                     cfg_kw=dict(span="end-to-end", scope="full", memory_mode="biwfa"), scheme="none", survey_bytes=2 * 25000 + 108_000 + 8, cpu_pairs=1, cpu_budget=3.0,
+                     steps=1),
                 dict(name="C3-explicit-history", n=100_000, length=10000, error=0.08, seed=datagen.SEEDS["C3"],
                      cfg_kw=dict(span="end-to-end", scope="full", heuristic="adaptive"), scheme="explicit", survey_bytes=750e3, env={"WFA_HIP_BAND_PB": "0"}),
                 dict(name="C4-adaptive-explicit-history", n=20_000, length=10000, error=0.08, seed=datagen.SEEDS["C4"], cfg_kw=dict(C4, heuristic="adaptive"),
@@ -803,6 +843,12 @@ def main():
                     out["config"][f"{key}_parity_mismatches"] = x["parity_mismatches"]
                     if x["parity_mismatches"]:
                         errors.append(f"{x['name']}: {x['parity_mismatches']} parity mismatches of {x['parity_checked_pairs']}")
+            try:   # what a pywfa user calls: WavefrontAligner.wavefront_align_batch(list of str) through the compiled host (pywfa_amd/host)
+                out["extra"]["python_host"] = python_host_leg()
+                out["config"]["python_batch_pairs_per_s"] = out["extra"]["python_host"]["pairs_per_s"]
+                out["config"]["python_single_call_us"] = out["extra"]["python_host"]["single_call_us"]
+            except Exception as e:
+                errors.append(f"python host leg: {e!r}")
             try:   # C5 through the product's own multi-device entry (one process, every visible device)
                 m = multi_leg(args.multi_pairs)
                 out["extra"]["multi"] = m

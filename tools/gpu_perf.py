@@ -70,6 +70,8 @@ if "A150l" in which: run("150bp adaptive score, 0.5 %", 2000000, 150, 0.005, 100
 if "A150" in which: run("150bp adaptive score", 2000000, 150, 0.02, 1002, dict(span="end-to-end", scope="score", heuristic="adaptive"), cpu_n=100000)
 if "N150" in which: run("150bp no heuristic score", 2000000, 150, 0.02, 1002, dict(span="end-to-end", scope="score"), cpu_n=100000)
 if "B10k" in which: run("10kb BiWFA full", 2000, 10000, 0.08, 1003, dict(span="end-to-end", scope="full", memory_mode="biwfa"), cpu_n=40)
+if "B10kbig" in which: run("10kb BiWFA full, 16384 pairs", 16384, 10000, 0.08, 1003, dict(span="end-to-end", scope="full", memory_mode="biwfa"), cpu_n=16, reps=1)
+if "B100k" in which: run("100kb BiWFA full, 256 pairs", 256, 100000, 0.08, 1005, dict(span="end-to-end", scope="full", memory_mode="biwfa"), cpu_n=1, reps=1)
 if "B1k" in which: run("1kb BiWFA full", 50000, 1000, 0.08, 1003, dict(span="end-to-end", scope="full", memory_mode="biwfa"), cpu_n=2000)
 if "A30k" in which: run("30kb adaptive full", 4096, 30000, 0.08, 1005, dict(span="end-to-end", scope="full", heuristic="adaptive"), cpu_n=8, reps=1)
 if "C5a8k" in which: run("100kb adaptive full, 8192 pairs", 8192, 100000, 0.08, 1005, dict(span="end-to-end", scope="full", heuristic="adaptive"), cpu_n=4, reps=1)

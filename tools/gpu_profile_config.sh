@@ -3,7 +3,7 @@
 #   bash tools/gpu_profile_config.sh <tag> <config>       e.g.  r03 C3      -> gpurun_out/<tag>_<config>_*
 # --kernel-trace --stats, the two SQ passes, FETCH_SIZE and WRITE_SIZE, each its own run (--pmc only with --kernel-trace), the
 # program directly after `--`.  tools/make_profiles.py turns the outputs into the files kept under profiles/.
-TAG=${1:-r04}; CFG=${2:-C3}
+TAG=${1:-r05}; CFG=${2:-C3}
 OUT=gpurun_out
 P=$OUT/${TAG}_${CFG}
 mkdir -p $OUT
@@ -20,6 +20,9 @@ pass sq1 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ
 pass sq2 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
+# (which of the L2's fabric requests go to the memory controller?  TCC_EA0_RDREQ_DRAM counts the requests routed to
+# DRAM — the Infinity Cache sits behind that interface, memory-side, so its hits are not told apart here; kept for the record)
+if [ "$CFG" = "C3x8k" ]; then pass dram TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum; fi
 # keep the merged-back volume small: the per-dispatch CSVs are summarised above
 find $OUT -name "*.csv" -size +4M -delete
 rm -rf ${P}_stats
