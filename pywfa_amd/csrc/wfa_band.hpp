@@ -1265,8 +1265,9 @@ int launch_slim_s4(const BandArgs& a, int nch, bool full, long long grid, hipStr
 // or the piggy-back history of a split launch) and the 256-diagonal stage behind it (score-only or the explicit int16 history, walked
 // in-kernel)
 inline bool slim_takes(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds) {
-  if (!a.slim || !adapt || a.heur != 1 || !seqlds || a.done || a.debug != 0) return false;
-  if (nch == (a.oe2 > 0 ? 3 : 2)) return !full || (a.split && a.pb);
+  if (!a.slim || !seqlds || a.debug != 0) return false;
+  if (adapt ? a.heur != 1 : a.heur != 0) return false;                          // wf-adaptive or no heuristic (X-drop: wfa_band_kernel)
+  if (nch == (a.oe2 > 0 ? 3 : 2)) return !full || (a.split ? a.pb != 0 : a.h16 != 0);   // piggy-back slots, or the explicit int16 history walked in-kernel
   if (nch == 4) return !full || (!a.split && a.h16);
   return false;
 }

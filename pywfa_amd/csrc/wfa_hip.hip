@@ -2613,6 +2613,7 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
       ba.heur = al->dcfg.heuristic; ba.xdrop = al->dcfg.xdrop; ba.max_steps = al->dcfg.max_steps; ba.scope = al->dcfg.scope;
       ba.lds_words = ((max_len + 15) >> 4) + 4;
       ba.h16 = 1;
+      ba.slim = knob(al, K_BAND_SLIM, 1);   // (wf-adaptive or no heuristic: wfa_slim_kernel — a third of the instructions per score step)
       ba.ef = (al->dcfg.endsfree && (al->dcfg.pbf | al->dcfg.pef | al->dcfg.tbf | al->dcfg.tef)) ? 1 : 0;
       ba.pbf = al->dcfg.pbf; ba.pef = al->dcfg.pef; ba.tbf = al->dcfg.tbf; ba.tef = al->dcfg.tef;
       if (full) {

@@ -20,9 +20,10 @@
 //     come through registers whose edge lane is NULL for good, so a shift is one DPP move;
 //   * one piggy-back byte per ACTIVE diagonal and step: the sign bits of the candidates' differences as they fall out of the
 //     subtractions (BandArgs::pb_raw; the walk decodes them).
-// Scope: gap-affine / gap-affine-2p with an instantiated shape, match = 0, wf-adaptive, end-to-end or ends-free, sequences staged
-// in LDS (reads <= 10 kb), score-only or the piggy-back history of a split launch.  Everything else stays with wfa_band_kernel; a
-// pair whose window overflows is handed on exactly as there.
+// Scope: gap-affine / gap-affine-2p with an instantiated shape, match = 0, wf-adaptive or no heuristic, end-to-end or ends-free,
+// sequences staged in LDS (reads <= 10 kb); score-only, the piggy-back history of a split launch, or the explicit history of an
+// unsplit one (walked in-kernel; the single-call path included).  Everything else (X-drop, longer reads, run-time shapes) stays with
+// wfa_band_kernel; a pair whose window overflows is handed on exactly as there.
 #pragma once
 #include "wfa_band.hpp"
 
@@ -264,8 +265,8 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
 #pragma unroll
             for (int c = 0; c < ACT; ++c) if ((end_pos >> 6) == c) end_off2 = __builtin_amdgcn_readlane(cur[c], end_pos & 63);
           }
-          // ---------------- wf-adaptive cut-off (R/wavefront_heuristic.c:257-293, 509-567) ----------------
-          else if (steps_wait <= 0) {
+          // ---------------- wf-adaptive cut-off (R/wavefront_heuristic.c:257-293, 509-567); a.heur == 0: no heuristic ----------------
+          else if (a.heur == 1 && steps_wait <= 0) {
             const int lo_p = BD::first_pos(live), hi_p = BD::last_pos(live);   // window positions of the wavefront's ends
             if (hi_p - lo_p >= min_wf_len_m1) {
               int d[NCH], dm = 0x7fffffff;
@@ -592,10 +593,11 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
         a.cigar_len[pair] = (int)((long long)plen + tlen - begin);
       }
     }
+    if (a.done) __threadfence_system();   // the single-call path: the op bytes of every lane before the flag below
     if (lane == 0) {
       if (fallback) {
         a.status[pair] = WFA_INTERNAL_FALLBACK;
-        if (a.fb_list) a.fb_list[atomicAdd(a.fb_count, 1u)] = pair;
+        if (a.fb_list) a.fb_list[atomicAdd(a.fb_count, 1u)] = pair;   // (no list: the single-call path reads the status)
       } else if (stop_status != 0) {
         a.score[pair] = stop_score;
         a.status[pair] = stop_status;
@@ -603,6 +605,8 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
         a.score[pair] = result;
         a.status[pair] = 0;
       }
+      // (the host polls this flag in the pinned block instead of waiting for the stream)
+      if (a.done) { __threadfence_system(); __hip_atomic_store(&a.done[pair], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
     }
   }
 }
@@ -635,10 +639,13 @@ static int launch_slim_shape(const BandArgs& a, int nch, bool full, long long gr
     if (full) hipLaunchKernelGGL((wfa_slim_kernel_tail<4, 2, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
     else hipLaunchKernelGGL((wfa_slim_kernel_tail<4, 0, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
   } else if constexpr (OE2 > 0) {
-    if (full) hipLaunchKernelGGL((wfa_slim_kernel_2p<NCH1, 1, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+    if (full && a.split) hipLaunchKernelGGL((wfa_slim_kernel_2p<NCH1, 1, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+    else if (full) hipLaunchKernelGGL((wfa_slim_kernel_2p<NCH1, 2, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
     else hipLaunchKernelGGL((wfa_slim_kernel_2p<NCH1, 0, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
   } else {
-    if (full) hipLaunchKernelGGL((wfa_slim_kernel<NCH1, 1, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+    // (unsplit with a history: reads of up to 1 kb, the single-call path — explicit history, walked in-kernel)
+    if (full && a.split) hipLaunchKernelGGL((wfa_slim_kernel<NCH1, 1, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+    else if (full) hipLaunchKernelGGL((wfa_slim_kernel<NCH1, 2, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
     else hipLaunchKernelGGL((wfa_slim_kernel<NCH1, 0, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -296,6 +296,8 @@ def test_segmented_stages_accept_only_proven_scores(gpu, stages, monkeypatch):
     pair on otherwise: whatever the stage order, the scores must be the reference's.  The batch mixes pairs
     that finish in every band width (0 % .. 30 % divergence, 30 .. 500 bases, |tlen - plen| up to 40), is long
     enough for a wave's slice to outrun its two metadata windows (> 128 pairs per wave) and has repeats."""
+    if os.environ.get("WFA_TEST_FULL") != "1" and stages in ("4", "5", "7", "3245", "189", "19", "12", "245"):
+        pytest.skip("stage orders sampled on the suite's time budget (WFA_TEST_FULL=1 runs all)")
     monkeypatch.setenv("WFA_HIP_FAST_STAGES", stages)
     monkeypatch.setenv("WFA_HIP_FAST_WAVES_PER_CU", "1")   # 256 waves -> ~200 pairs per slice
     rng = np.random.default_rng(11)

@@ -80,3 +80,46 @@ def test_slim_kernel_window_overflow_is_handed_on(gpu, distance):
     o = loader.run(loader.oracle(), oc, batch)
     score, status, cigars = common.gpu_run(nc, batch, True, resident=True)
     common.assert_same(o, score, status, cigars, batch, "slim, wide wavefronts")
+
+
+EXACT = [
+    dict(span="end-to-end"), dict(span="ends-free", pattern_begin_free=20, pattern_end_free=10, text_begin_free=5, text_end_free=30),
+    dict(span="end-to-end", max_steps=300), dict(span="end-to-end", mismatch=4, gap_opening=6, gap_extension=1),
+    dict(distance="affine2p", span="end-to-end"), dict(distance="affine2p", span="ends-free", pattern_end_free=40, text_end_free=40),
+]
+
+
+@pytest.mark.parametrize("scope", ["full", "score"])
+@pytest.mark.parametrize("cfg_idx", range(len(EXACT)))
+def test_slim_kernel_without_a_heuristic(gpu, cfg_idx, scope, monkeypatch):
+    """No heuristic: the banded stages of reads up to 1.2 kb (what the lane / segment kernels hand on, and batches they do not take)
+    and the single-call path run the slim step too — unsplit launches keep the explicit history and walk it in-kernel."""
+    import pywfa_amd
+    batches = [ragged(500 + cfg_idx, 400, 520, 1150, 0.06, indel_bias=3), ragged(600 + cfg_idx, 300, 200, 700, 0.12),
+               datagen.generate(200, 1000, 0.03, 4300 + cfg_idx)]
+    for bi, batch in enumerate(batches):
+        kw = common.clamp_free(dict(EXACT[cfg_idx], scope=scope), batch)
+        oc, nc = common.configs_pair(**kw)
+        full = oc.scope == 1
+        o = loader.run(loader.oracle(), oc, batch, want_cigar=full)
+        monkeypatch.delenv("WFA_HIP_BAND_SLIM", raising=False)
+        score, status, cigars = common.gpu_run(nc, batch, full, resident=(bi % 2 == 0))
+        common.assert_same(o, score, status, cigars, batch, f"slim exact {kw} batch {bi}")
+        monkeypatch.setenv("WFA_HIP_BAND_SLIM", "0")
+        score0, status0, cigars0 = common.gpu_run(nc, batch, full, resident=(bi % 2 == 0))
+        assert np.array_equal(score, score0) and np.array_equal(status, status0) and cigars == cigars0
+    # one pair per call (the pinned-block path: completion flags polled by the host)
+    monkeypatch.delenv("WFA_HIP_BAND_SLIM", raising=False)
+    kw = common.clamp_free(dict(EXACT[cfg_idx], scope=scope), batches[1])
+    a = pywfa_amd.WavefrontAligner(**{k: v for k, v in kw.items()})
+    oc, nc = common.configs_pair(**kw)
+    sub = datagen.subset(batches[1], np.arange(12))
+    o = loader.run(loader.oracle(), oc, sub, want_cigar=(scope == "full"))
+    for i in range(12):
+        p, t = datagen.pair_strings(batches[1], i)
+        got = a.wavefront_align(t, p)
+        if a.status == 0:
+            assert got == o["score"][i], (i, got, o["score"][i])
+        assert a.status == o["status"][i]
+        if scope == "full":
+            assert bytes(a._ops) == o["cigars"][i]
