@@ -869,39 +869,40 @@ wfa_band_pb_bt_kernel(const BandArgs a) {
   const int doe2 = two ? a.oe2 / a.g : 0, de2 = two ? a.e2 / a.g : 0;
   // ---- walk the codes back from the end cell (R/wavefront_backtrace.c:320-529 with the choices made at compute time)
   int si = es.x / a.g, k = es.y, comp = 0, nev = 0;
-  while (si > 0 && nev < ev_cap) {
-    int cd = codes[(long long)si * W + (k & (W - 1))];
-    if (a.pb_raw) {   // comparison bits of wfa_slim_kernel -> origin codes
-      if (two) {
+  // (round 5: the hop is selects, not branches — 64 walks per wave sit in different components and take different origins at every
+  // hop; as an if / else ladder every path ran for every wave)
+  if (two) {
+    // comp: 0 M, 1 I1, 2 D1, 3 I2, 4 D2; src: 0 X, 1 D1, 2 D2, 3 I1, 4 I2; an event flagged 0x80 lands in M (a run of matches follows it)
+    while (si > 0 && nev < ev_cap) {
+      int cd = codes[(long long)si * W + (k & (W - 1))];
+      if (a.pb_raw) {   // comparison bits of wfa_slim_kernel -> origin codes
         const int r = cd;
         const int mc = !(r & 128) ? 0 : !(r & 64) ? 2 : !(r & 32) ? 1 : !(r & 16) ? 4 : 3;
         cd = mc | ((r & 8) ? 0 : 8) | ((r & 4) ? 0 : 16) | ((r & 2) ? 0 : 32) | ((r & 1) ? 0 : 64);
-      } else {
-        cd = (int)((0x2a6e195d084c084cull >> ((cd & 15) * 4)) & 15ull);
       }
+      const int src = (comp == 0) ? (cd & 7) : (int)((0x24130u >> (4 * comp)) & 7u);   // comp 1 -> I1 (3), 2 -> D1 (1), 3 -> I2 (4), 4 -> D2 (2)
+      const bool is_d = src == 1 || src == 2, is_x = src == 0;
+      // extension bit of the source component: I1 8, D1 16, I2 32, D2 64; the component it leads to when set; its lags
+      const int ebit = (src == 3) ? 8 : (src == 1) ? 16 : (src == 4) ? 32 : 64;
+      const bool ext = !is_x && (cd & ebit) != 0;
+      const bool second = src == 2 || src == 4;
+      const int lag = is_x ? dx : (ext ? (second ? de2 : de) : (second ? doe2 : doe));
+      const int ncomp = ext ? ((src == 3) ? 1 : (src == 1) ? 2 : (src == 4) ? 3 : 4) : 0;
+      ev[nev++] = (uint8_t)((is_x ? 'X' : (is_d ? 'D' : 'I')) | ((comp == 0) ? 0x80 : 0));
+      k += is_x ? 0 : (is_d ? 1 : -1);
+      si -= lag; comp = ncomp;
     }
-    if (two) {
-      // comp: 0 M, 1 I1, 2 D1, 3 I2, 4 D2; an event flagged 0x80 lands in M (a run of matches follows it)
-      const int src = (comp == 0) ? (cd & 7) : (comp == 1) ? 3 : (comp == 2) ? 1 : (comp == 3) ? 4 : 2;  // 0 X, 1 D1, 2 D2, 3 I1, 4 I2
-      const uint8_t flag = (comp == 0) ? 0x80 : 0;
-      if (src == 0) { ev[nev++] = (uint8_t)('X' | 0x80); si -= dx; }
-      else if (src == 1) { ev[nev++] = (uint8_t)('D' | flag); ++k; if (cd & 16) { si -= de; comp = 2; } else { si -= doe; comp = 0; } }
-      else if (src == 2) { ev[nev++] = (uint8_t)('D' | flag); ++k; if (cd & 64) { si -= de2; comp = 4; } else { si -= doe2; comp = 0; } }
-      else if (src == 3) { ev[nev++] = (uint8_t)('I' | flag); --k; if (cd & 8) { si -= de; comp = 1; } else { si -= doe; comp = 0; } }
-      else { ev[nev++] = (uint8_t)('I' | flag); --k; if (cd & 32) { si -= de2; comp = 3; } else { si -= doe2; comp = 0; } }
-      continue;
-    }
-    if (comp == 0) {
-      const int mc = cd & 3;
-      if (mc == 0) { ev[nev++] = (uint8_t)('X' | 0x80); si -= dx; }
-      else if (mc == 1) { ev[nev++] = (uint8_t)('D' | 0x80); ++k; if (cd & 8) { si -= de; comp = 2; } else si -= doe; }
-      else { ev[nev++] = (uint8_t)('I' | 0x80); --k; if (cd & 4) { si -= de; comp = 1; } else si -= doe; }
-    } else if (comp == 1) {
-      ev[nev++] = (uint8_t)'I'; --k;
-      if (cd & 4) si -= de; else { si -= doe; comp = 0; }
-    } else {
-      ev[nev++] = (uint8_t)'D'; ++k;
-      if (cd & 8) si -= de; else { si -= doe; comp = 0; }
+  } else {
+    // comp: 0 M, 1 I, 2 D; op: 0 X, 1 D, 2 I (the numbering of the origin code's low bits)
+    while (si > 0 && nev < ev_cap) {
+      int cd = codes[(long long)si * W + (k & (W - 1))];
+      if (a.pb_raw) cd = (int)((0x2a6e195d084c084cull >> ((cd & 15) * 4)) & 15ull);   // comparison bits of wfa_slim_kernel -> origin codes
+      const int op = (comp == 0) ? (cd & 3) : 3 - comp;
+      const bool ext = op != 0 && ((cd >> (4 - op)) & 1) != 0;     // I: bit 2, D: bit 3
+      ev[nev++] = (uint8_t)(((0x494458u >> (8 * op)) & 0xffu) | ((comp == 0) ? 0x80u : 0u));   // 'X', 'D', 'I'
+      k += (op == 1) - (op == 2);
+      si -= (op == 0) ? dx : (ext ? de : doe);
+      comp = ext ? 3 - op : 0;
     }
   }
   // ---- unpack forwards from the cell of wavefront 0 on diagonal k (ends-free: offset max(k, 0), R/wavefront_aligner.c:259-302)
