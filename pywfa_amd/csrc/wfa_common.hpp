@@ -110,6 +110,11 @@ struct FastArgs {
   int heur, min_wf_len, max_dist_thr, steps_between;         // 1 = wf-adaptive (R/wavefront_heuristic.c:257-293)
   int max_steps;                                             // INT_MAX = unlimited (R/wavefront_unialign.c:98-107)
   int xdrop;                                                 // heur = 2: X-drop (R/wavefront_heuristic.c:297-383), the segmented form only
+  // the lane kernel's score-only forms: slices of the work list taken at run time (round 5).  Non-null: a device counter (zero at launch);
+  // a wave takes `dyn_chunk` pairs at a time from it until the list is used up, instead of one fixed slice per wave — the lanes of a
+  // wave drain (few busy lanes, full instruction cost) once per kernel, not once per slice
+  uint32_t* dyn_next;
+  uint32_t dyn_chunk;
 };
 
 // neighbour diagonals inside a segment of W lanes (wfa_seg.hpp): lanes at a segment border receive NULL

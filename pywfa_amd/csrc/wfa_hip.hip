@@ -44,7 +44,7 @@ static thread_local std::string g_error;
 // never call getenv.
 #define WFA_COUNTER_WORDS 64   // counters of a batch (wfa_hip_batch::d_counters)
 #define WFA_KNOBS(F)                                                                                              \
-  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
+  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(LANE_DYN) F(LANE_DYN_WAVES) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
   F(LANE_FULL) F(LANE_FULL_SPLIT) F(LANE_HEUR) F(SEG_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_ADAPT) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(TILE) F(TILE_T) F(TILE_WT) F(TILE_THREADS) F(TILE_PER_CU) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY) F(PILOT_PCT) F(WIDE_ADAPT_LDS)
@@ -2029,10 +2029,15 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
         if (variants[pass] == 1) {
           int X, OE, E;
           const int shape = wfa::seg_shape(b->dcfg, &X, &OE, &E);
+          // (slices of the list taken at run time: as many waves as the chip holds at once — every wave goes on until the list is used up)
+          const uint32_t lane_dyn = (in_count == nullptr && in_n >= 65536u) ? (uint32_t)std::max(0, knob(al, K_LANE_DYN, 192)) : 0u;
           lrc = wfa::launch_lane(shape, wfa::gcd_int(wfa::gcd_int(b->dcfg.x, b->dcfg.o1 + b->dcfg.e1), b->dcfg.e1), al->cu_count,
-                                 knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, b->d_words, b->d_meta,
+                                 lane_dyn ? knob(al, K_LANE_DYN_WAVES, 16) : knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, b->d_words, b->d_meta,
                                  in_list, in_count, in_n, b->d_score, b->d_status, out_list, out_count,
-                                 (knob(al, K_LANE_DEBUG, 0) && al->ws) ? al->ws : nullptr, knob(al, K_LANE_LDS_PAD_KB, 0), X, OE, E, knob(al, K_LANE_MIN_PAIRS, 0));
+                                 (knob(al, K_LANE_DEBUG, 0) && al->ws) ? al->ws : nullptr, knob(al, K_LANE_LDS_PAD_KB, 0), X, OE, E, knob(al, K_LANE_MIN_PAIRS, 0),
+                                 // (slices of the list taken at run time, 256 pairs at a time, from a counter zeroed with the run's others;
+                                 // a list whose length only the device knows keeps the fixed slices; WFA_HIP_LANE_DYN=0: fixed slices)
+                                 b->d_counters + 12, lane_dyn);
           if (knob(al, K_LANE_DEBUG, 0) && al->ws) {  // development aid (build with -DWFA_LANE_DEBUG_COUNTERS=1)
             unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             hipStreamSynchronize(stream); hipMemcpy(c, al->ws, sizeof(c), hipMemcpyDeviceToHost); hipMemset(al->ws, 0, sizeof(c));
@@ -2068,7 +2073,10 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
       fa.heur = b->dcfg.heuristic; fa.min_wf_len = b->dcfg.min_wf_len; fa.max_dist_thr = b->dcfg.max_dist_thr;
       fa.steps_between = b->dcfg.steps_between; fa.max_steps = b->dcfg.max_steps;
       const int shape = wfa::seg_shape(b->dcfg, &lh_x, &lh_oe, &lh_e);
-      if (wfa::launch_lane_args(shape, lh_oe, lh_e, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, fa, false, 0, knob(al, K_LANE_MIN_PAIRS, 0), true, lh_x) != 0) {   // (pairs per wave by the size of the batch, as the plain form)
+      // (slices of the list taken at run time, as the plain score-only form)
+      const uint32_t laneh_dyn = (in_count == nullptr && in_n >= 65536u) ? (uint32_t)std::max(0, knob(al, K_LANE_DYN, 192)) : 0u;
+      if (laneh_dyn) { fa.dyn_next = b->d_counters + 13; fa.dyn_chunk = laneh_dyn; }
+      if (wfa::launch_lane_args(shape, lh_oe, lh_e, al->cu_count, laneh_dyn ? knob(al, K_LANE_DYN_WAVES, 16) : knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, fa, false, 0, knob(al, K_LANE_MIN_PAIRS, 0), true, lh_x) != 0) {   // (pairs per wave by the size of the batch, as the plain form)
         al->err = "lane kernel launch failed"; return WFA_HIP_EDEVICE;
       }
       if (first_stage) b->last_kernel_pairs = in_n;

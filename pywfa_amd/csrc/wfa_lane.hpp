@@ -126,11 +126,28 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
   const int slot_words = slot_words_seq;
   const int lane = threadIdx.x;
   uint32_t nwork = __builtin_amdgcn_readfirstlane(a.nwork_dev ? *a.nwork_dev : a.nwork);
-  const uint32_t per = __builtin_amdgcn_readfirstlane((nwork + gridDim.x - 1) / gridDim.x);
-  const unsigned long long begin64 = (unsigned long long)blockIdx.x * per;
-  if (begin64 >= nwork) return;
-  const uint32_t begin = (uint32_t)begin64;
-  const uint32_t end = (uint32_t)min((unsigned long long)nwork, begin64 + per);
+  // the wave's slice of the work list: a fixed one (blockIdx.x-th of gridDim.x), or — score-only forms with a.dyn_next — chunks taken
+  // from a device counter until the list is used up
+  const bool dyn = !FULL && a.dyn_next != nullptr;
+  bool exhausted = !dyn;
+  uint32_t begin, end;
+  auto grab = [&](uint32_t& b_, uint32_t& e_) -> bool {
+    uint32_t nb = 0;
+    if (lane == 0) nb = atomicAdd(a.dyn_next, a.dyn_chunk);
+    nb = __builtin_amdgcn_readfirstlane(nb);
+    if (nb >= nwork) return false;
+    b_ = nb; e_ = (uint32_t)min((unsigned long long)nwork, (unsigned long long)nb + a.dyn_chunk);
+    return true;
+  };
+  if (dyn) {
+    if (!grab(begin, end)) return;
+  } else {
+    const uint32_t per = __builtin_amdgcn_readfirstlane((nwork + gridDim.x - 1) / gridDim.x);
+    const unsigned long long begin64 = (unsigned long long)blockIdx.x * per;
+    if (begin64 >= nwork) return;
+    begin = (uint32_t)begin64;
+    end = (uint32_t)min((unsigned long long)nwork, begin64 + per);
+  }
 
   // ---- two windows of 64 pairs' metadata: lane i holds pair wbase + i / wbase + 64 + i
   uint32_t pid0, pw0, ln0, pid1, pw1, ln1;        // ln = plen | tlen << 16 (0xffffffff: too long for this stage)
@@ -183,6 +200,12 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
     WFA_LANE_MARK("looptop_begin");   // (analysis builds: what precedes the first of these is the prologue)
     // =================== take pairs ===================
     const int nidle = __builtin_popcountll(idle);
+    if (!exhausted && next_i >= end && (nidle >= refill_min || idle == ~0ull)) {
+      // this slice is used up: the next chunk of the list, if any (its metadata windows replace the old ones: every pair of the old
+      // slice has been taken)
+      if (grab(begin, end)) { wbase = begin; next_i = begin; load_window(wbase, pid0, pw0, ln0); load_window(wbase + 64u, pid1, pw1, ln1); }
+      else exhausted = true;
+    }
     if (next_i < end && (nidle >= refill_min || idle == ~0ull)) {
       WFA_LANE_MARK("refill_begin");
       WFA_LANE_COUNT(1);
@@ -279,7 +302,7 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
         load_window(wbase + 64u, pid1, pw1, ln1);
       }
       WFA_LANE_MARK("refill_end");
-    } else if (idle == ~0ull) {
+    } else if (idle == ~0ull && exhausted) {
       break;                                 // nothing left
     }
 
@@ -451,7 +474,7 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
         }
         idle |= bd;
         WFA_LANE_MARK("bd_end");
-        if (idle == ~0ull && next_i >= end) break;
+        if (idle == ~0ull && next_i >= end && exhausted) break;
       }
     }
 
@@ -645,8 +668,9 @@ inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_
 inline int launch_lane(int shape_idx, int g, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, const uint32_t* words,
                        const WfaPairMeta* meta, const uint32_t* worklist, const uint32_t* nwork_dev, uint32_t nwork,
                        int32_t* score, int32_t* status, uint32_t* fb_list, uint32_t* fb_count, int32_t* debug_counters = nullptr, int lds_pad_kb = 0,
-                       int X = 0, int OE = 0, int E = 0, int min_pairs = 0) {
-  FastArgs a;
+                       int X = 0, int OE = 0, int E = 0, int min_pairs = 0, uint32_t* dyn_next = nullptr, uint32_t dyn_chunk = 0) {
+  FastArgs a = FastArgs();
+  a.dyn_next = dyn_chunk ? dyn_next : nullptr; a.dyn_chunk = dyn_chunk;
   a.words = words; a.meta = meta; a.worklist = worklist; a.nwork_dev = nwork_dev; a.nwork = nwork;
   a.score = score; a.status = status; a.fb_list = fb_list; a.fb_count = fb_count;
   a.g = g;
