@@ -14,7 +14,7 @@ the full issue rate (development aid).
    rounds, parked runs and rounds, hand-over blocks.
 3. Dynamic count of a class = sum over regions of executions x static count; what lies outside the marks inside the main loop is
    straight-line per-step code (tests, termination, compute-next).  The total is checked against SQ_INSTS_VALU of the counter pass.
-Writes profiles/r03_lane_mix.json (tools/make_traffic.py takes full_rate_share from it)."""
+Writes profiles/<tag>_lane_mix.json (tag: WFA_PROFILE_TAG, default r05) (tools/make_traffic.py takes full_rate_share from it)."""
 import json, os, re, subprocess, sys, collections
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 CSRC = os.path.join(ROOT, "pywfa_amd", "csrc")
@@ -79,7 +79,8 @@ def static_counts():
 def main():
     compile_marks()
     regions, copies = static_counts()
-    counts_file = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_lane_regions.txt")
+    TAG = os.environ.get("WFA_PROFILE_TAG", "r05")
+    counts_file = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", TAG + "_lane_regions.txt")
     txt = open(counts_file).read()
     m = re.search(r"(\d+) wave-steps, (\d+) refills, (\d+) parked runs, (\d+) parked rounds, (\d+) probe blocks, (\d+) second-run rounds, (\d+) hand-over blocks, (\d+) second runs", txt)
     steps, refills, parked, prounds, probes, now_rounds, bd, now_runs = [int(x) for x in m.groups()]
@@ -105,7 +106,7 @@ def main():
            "note": "v_mov_b32 / v_readlane are counted at the half rate in the roofline (they are none of the measured full-rate ops)"}
     try:
         import glob
-        for f in glob.glob(os.path.join(ROOT, "profiles", "r03_pmc_sq2.txt")) + glob.glob(os.path.join(ROOT, "profiles", "r02_pmc_sq2.txt")):
+        for f in glob.glob(os.path.join(ROOT, "profiles", TAG + "_pmc_sq2.txt")) + glob.glob(os.path.join(ROOT, "profiles", "r03_pmc_sq2.txt")):
             cur = None
             for line in open(f):
                 if "wfa_lane_kernel<2, 4, 1" in line:
@@ -120,7 +121,7 @@ def main():
             out["model_over_counter"] = total / out["sq_insts_valu_per_dispatch"]
     except OSError:
         pass
-    with open(os.path.join(ROOT, "profiles", "r03_lane_mix.json"), "w") as f:
+    with open(os.path.join(ROOT, "profiles", TAG + "_lane_mix.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "regions"}, indent=1))
 

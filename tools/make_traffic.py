@@ -52,7 +52,8 @@ for r in csv.DictReader(open(os.path.join(root, f"{tag}_kernel_stats.csv"))):
 # the kernel's DYNAMIC instruction mix (tools/lane_mix.py: static counts per region of the step x the region counters of the
 # counting build; its total reproduces SQ_INSTS_VALU): the share of add / and / or / xor ("full rate"), of plain v_mov_b32 (priced
 # at its own measured cost when the microbenchmark has it, otherwise at the half rate) — everything else at the half rate
-mix = json.load(open(os.path.join(ROOT, "profiles", "r03_lane_mix.json")))
+MIX_FILE = next(f for f in (os.path.join(ROOT, "profiles", t + "_lane_mix.json") for t in (os.environ.get("WFA_PROFILE_TAG", "r05"), "r03")) if os.path.exists(f))
+mix = json.load(open(MIX_FILE))
 FULL_RATE_SHARE, MOV_SHARE = mix["full_rate_share"], mix["mov_share"]
 t_mov = issue_ns("v_mov_b32 ") or t_half
 valu = s2.get("SQ_INSTS_VALU", 0.0)
@@ -62,12 +63,12 @@ sec = {
     "bound": "valu_issue",
     "what": "vector-issue time of the kernel's instruction stream = SQ_INSTS_VALU / 1024 SIMDs x the measured cost of a wave64 vector "
             "instruction on this chip (tools/issue_rate.hip, wall clock: full-rate add/logic ops and half-rate min/max/alignbit/cndmask/"
-            "shift/pk/dpp ops, weighted by the kernel's DYNAMIC instruction mix: profiles/r03_lane_mix.json, tools/lane_mix.py), divided by the "
+            "shift/pk/dpp ops, weighted by the kernel's DYNAMIC instruction mix: profiles/<tag>_lane_mix.json, tools/lane_mix.py), divided by the "
             "kernel's average duration (rocprofv3 --stats)",
     "frac": issue_ms / (kernel_ns * 1e-6),
     "valu_issue_ms": issue_ms, "kernel_ms": kernel_ns * 1e-6,
     "ns_per_full_rate_instr": t_full, "ns_per_half_rate_instr": t_half, "ns_per_v_mov": t_mov, "full_rate_share": FULL_RATE_SHARE, "v_mov_share": MOV_SHARE,
-    "instruction_mix": {"file": "profiles/r03_lane_mix.json", "dynamic_valu_total_model": mix["dynamic_valu_total"], "model_over_counter": mix.get("model_over_counter")},
+    "instruction_mix": {"file": os.path.relpath(MIX_FILE, ROOT), "dynamic_valu_total_model": mix["dynamic_valu_total"], "model_over_counter": mix.get("model_over_counter")},
     "frac_if_all_half_rate": valu / simds * t_half * 1e-6 / (kernel_ns * 1e-6), "frac_if_all_full_rate": valu / simds * t_full * 1e-6 / (kernel_ns * 1e-6),
     "valu_insts_per_dispatch": valu, "salu_insts_per_dispatch": s2.get("SQ_INSTS_SALU"), "lds_insts_per_dispatch": s2.get("SQ_INSTS_LDS"),
     "salu_insts_per_cycle_per_cu": s2.get("SQ_INSTS_SALU", 0.0) / (cycles * 256),
