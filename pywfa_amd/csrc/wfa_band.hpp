@@ -75,6 +75,7 @@ struct BandArgs {
   int pb_raw;             // piggy-back codes written by wfa_slim_kernel: the four comparison bits as they fall out of the subtractions
                           // (bit 3: mismatch below the best gap, 2: deletion below insertion, 1 / 0: extension of I / D below its
                           // opening); the walk maps them to the codes above through a 16-entry table
+  const uint32_t* one;    // host side only: the single pair's SlimOne block (wfa_slim.hpp) — launch_slim_shape passes it as a kernel argument
   uint32_t* dbg;          // counting builds (-DWFA_SLIM_COUNTERS=1) with WFA_HIP_STAGE_TIMING=1: eight counters of wfa_slim_kernel
   int slim;               // 1: launches that fit wfa_slim_kernel (wfa_slim.hpp: 128 diagonals, gap-affine, wf-adaptive, end-to-end,
                           // sequences in LDS, score-only or piggy-back split history) take it instead of wfa_band_kernel (same results)

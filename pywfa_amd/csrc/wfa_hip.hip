@@ -34,6 +34,7 @@
 #include "wfa_lane.hpp"
 #include "wfa_band.hpp"
 #include "wfa_biwfa.hpp"
+#include "wfa_bilevel.hpp"
 #include "wfa_rle.hpp"
 
 #define WFA_HIP_ABI_VERSION 3
@@ -44,7 +45,7 @@ static thread_local std::string g_error;
 // never call getenv.
 #define WFA_COUNTER_WORDS 64   // counters of a batch (wfa_hip_batch::d_counters)
 #define WFA_KNOBS(F)                                                                                              \
-  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(LANE_DYN) F(LANE_DYN_WAVES) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
+  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(NO_TINY_INLINE) F(BILEVEL) F(BILEVEL_WIDE_LEVELS) F(BILEVEL_PER_CU) F(BILEVEL_I32) F(BILEVEL_QCAP) F(BILEVEL_LEVELS) F(LANE_DYN) F(LANE_DYN_WAVES) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
   F(LANE_FULL) F(LANE_FULL_SPLIT) F(LANE_HEUR) F(SEG_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_ADAPT) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(TILE) F(TILE_T) F(TILE_WT) F(TILE_THREADS) F(TILE_PER_CU) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY) F(PILOT_PCT) F(WIDE_ADAPT_LDS)
@@ -111,6 +112,7 @@ struct wfa_hip_aligner {
   // single calls of a pywfa-style loop (a handful of pairs): one pinned, device-visible staging block + its device copy,
   // allocated once; the call is then host writes -> copy kernel -> alignment kernel -> one stream sync -> host reads
   uint8_t* tiny_h = nullptr;
+  uint8_t* tiny_hd = nullptr;
   uint8_t* tiny_d = nullptr;
   size_t pin_slot_bytes = 0;
   int cu_count = 256;
@@ -1518,19 +1520,112 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
     // (reads of <= 100 bases under large penalties) are aligned by the ordinary algorithm, which is what that base case is
     b->dcfg.biwfa_top = full ? 1 : 0;
     Geometry g = plan_general(al, b, (uint32_t)std::min<int64_t>(b->n, (int64_t)al->cu_count * 16), b->arena_fixed + b->arena_ints);
-    int rc = ensure_ws(al, std::max((size_t)grid * stride * 4, full ? (size_t)g.grid * g.ws_stride * 4 : (size_t)0));
+    // Round 5: full CIGARs go level by level (csrc/wfa_bilevel.hpp: every window of a recursion level is a work item of one launch);
+    // the depth-first kernel keeps the score-only form and what the level queues could not hold (redo list).
+    //   workspace: [ring / base-history slices][window queues, leaves, per-pair words, counters][slices of the depth-first kernel]
+    wfa::BlArgs la;
+    memset(&la, 0, sizeof(la));
+    const bool bilevel = full && knob(al, K_BILEVEL, 1) != 0;
+    const bool bl_i16 = b->max_len <= 32000 && knob(al, K_BILEVEL_I32, 0) == 0;
+    int bl_grid = 0, bl_levels = 0;
+    int64_t dfs_off = 0;
+    size_t bl_bytes = 0;
+    if (bilevel) {
+      const int64_t esz = bl_i16 ? 2 : 4;
+      la.ring_stride = (b->max_width + 1) & ~1;
+      la.ring_elems = ((int64_t)b->dcfg.scope * b->ncomp * la.ring_stride + 63) & ~63ll;
+      la.base_stride = ba.base_stride; la.base_ints = ba.base_ints;
+      la.slice_bytes = (std::max<int64_t>(2 * la.ring_elems * esz, ba.base_ints * 4) + 255) & ~255ll;
+      bl_grid = al->cu_count * std::max(1, knob(al, K_BILEVEL_PER_CU, 16));
+      // windows a pair can be in at once: about two per 250 of score; queues sized from the longest pair, what overflows is redone
+      const int64_t per_pair = std::min<int64_t>(1024, std::max<int64_t>(4, b->max_width / 96));
+      const int64_t nmax = std::max<int64_t>(b->n_packed, b->n_bytes);
+      const int64_t qcap = knob(al, K_BILEVEL_QCAP, 0) > 0 ? knob(al, K_BILEVEL_QCAP, 0) : std::min<int64_t>(nmax * per_pair + 1024, (int64_t)1 << 28);   // (the knob: tests of the redo path)
+      const int64_t meta_bytes = qcap * 32 * 4 + (int64_t)b->n * (4 + 4 + 4 + 8 + 4) + WFA_BL_COUNTER_WORDS * 4 + 4096;
+      // the depth-first kernel behind it: a few slices (its int32 rings are the large ones)
+      grid = std::min<int64_t>(grid, al->cu_count);
+      while (bl_grid > al->cu_count && (int64_t)bl_grid * la.slice_bytes + meta_bytes + grid * stride * 4 > budget) bl_grid /= 2;
+      while (grid > 1 && (int64_t)bl_grid * la.slice_bytes + meta_bytes + grid * stride * 4 > budget) grid = (grid + 1) / 2;
+      la.qcap = la.qbcap = la.leafcap = (uint32_t)qcap;
+      bl_bytes = (size_t)((int64_t)bl_grid * la.slice_bytes + meta_bytes);
+      dfs_off = (int64_t)((bl_bytes + 255) & ~(size_t)255);
+      // levels: a window's score halves per level (to within the ring's scope) until it is <= 250
+      const int64_t pmax = std::max<int64_t>(1, std::max<int64_t>(b->dcfg.x, std::max<int64_t>(b->dcfg.o1 + b->dcfg.e1, b->dcfg.o2 + b->dcfg.e2)));
+      int64_t smax = pmax * (int64_t)b->max_width;
+      bl_levels = 3;
+      while (smax > 250 && bl_levels < WFA_BL_MAX_LEVELS - 1) { smax /= 2; ++bl_levels; }
+      if (knob(al, K_BILEVEL_LEVELS, 0) > 0) bl_levels = std::min(knob(al, K_BILEVEL_LEVELS, 0), WFA_BL_MAX_LEVELS - 1);
+    }
+    int rc = ensure_ws(al, std::max((size_t)dfs_off + (size_t)grid * stride * 4, full ? (size_t)g.grid * g.ws_stride * 4 : (size_t)0));
     if (rc != WFA_HIP_OK) return rc;
     WfaKernelArgs& a = ba.k;
     a.words = b->d_words; a.bytes = b->d_bytes; a.meta = b->d_meta; a.p_boff = b->d_pboff; a.t_boff = b->d_tboff;
     a.score = b->d_score; a.status = b->d_status;
     a.cigar_ops = b->d_ops; a.cigar_off = b->d_cigar_off; a.cigar_begin = b->d_cigar_begin; a.cigar_len = b->d_cigar_len;
-    a.ws = al->ws; a.ws_stride = stride; a.cfg = b->dcfg;
+    a.ws = reinterpret_cast<int*>(reinterpret_cast<char*>(al->ws) + dfs_off); a.ws_stride = stride; a.cfg = b->dcfg;
+    if (bilevel) {
+      char* p = reinterpret_cast<char*>(al->ws);
+      la.rings = p; p += (int64_t)bl_grid * la.slice_bytes;
+      la.q[0] = reinterpret_cast<wfa::BlWindow*>(p); p += (int64_t)la.qcap * 32;
+      la.q[1] = reinterpret_cast<wfa::BlWindow*>(p); p += (int64_t)la.qcap * 32;
+      la.qb = reinterpret_cast<wfa::BlWindow*>(p); p += (int64_t)la.qcap * 32;
+      la.leaves = reinterpret_cast<wfa::BlLeaf*>(p); p += (int64_t)la.qcap * 32;
+      la.failkey = reinterpret_cast<unsigned long long*>(p); p += (int64_t)b->n * 8;
+      la.head = reinterpret_cast<int*>(p); p += (int64_t)b->n * 4;
+      la.flags = reinterpret_cast<int*>(p); p += (int64_t)b->n * 4;
+      la.top = reinterpret_cast<int*>(p); p += (int64_t)b->n * 4;
+      la.redo_list = reinterpret_cast<uint32_t*>(p); p += (int64_t)b->n * 4;
+      la.cnt = reinterpret_cast<uint32_t*>(p);
+    }
     for (int kind = 0; kind < 2; ++kind) {   // 2-bit pairs, then the pairs aligned on their bytes
       const uint32_t cnt = kind ? b->n_bytes : b->n_packed;
       if (cnt == 0) continue;
       a.worklist = kind ? b->d_list_bytes : b->d_list_packed; a.nwork_dev = nullptr; a.nwork = cnt;
       a.fb_list = full ? b->d_fb_list2[kind] : nullptr; a.fb_count = b->d_counters + 4 + kind;
-      if (wfa::launch_biwfa_any(b->ncomp, kind == 0, ba, (int)std::min<int64_t>(grid, cnt), stream) != 0) { al->err = "BiWFA kernel launch failed"; return WFA_HIP_EDEVICE; }
+      int64_t dfs_grid = std::min<int64_t>(grid, cnt);
+      if (bilevel) {
+        la.k = a;
+        HIP_TRY(al, hipMemsetAsync(la.cnt, 0, WFA_BL_COUNTER_WORDS * sizeof(uint32_t), stream));
+        const bool stage_timing = knob(al, K_STAGE_TIMING, 0) != 0;   // development aid: synchronises
+        std::vector<hipEvent_t> tev;
+        auto mark = [&]() { if (stage_timing) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, stream); tev.push_back(e); } };
+        mark();
+        bool ok = wfa::launch_bl_seed(la, stream) == 0;
+        // four waves per window while the wavefronts are expected to span several chunks (about max_len / 8 diagonals at the top
+        // level for reads at 8 - 10 %, half of it per level)
+        int wide_auto = 0;
+        while (wide_auto < 8 && ((b->max_len / 8) >> wide_auto) >= 256) ++wide_auto;
+        const int wide_levels = knob(al, K_BILEVEL_WIDE_LEVELS, wide_auto);
+        for (int lv = 0; lv < bl_levels && ok; ++lv) {
+          la.level = lv;
+          const int threads = (lv < wide_levels) ? 256 : 64;
+          const int lgrid = (threads == 256) ? std::max(al->cu_count, bl_grid / 2) : bl_grid;
+          ok = wfa::launch_bl_split_any(b->ncomp, kind == 0, bl_i16, threads, la, (int)std::min<int64_t>(lgrid, lv == 0 ? (int64_t)cnt : (int64_t)lgrid), stream) == 0;
+          mark();
+        }
+        ok = ok && wfa::launch_bl_base_any(b->ncomp, kind == 0, la, bl_grid, stream) == 0;
+        mark();
+        ok = ok && wfa::launch_bl_finish(la, (int)std::min<int64_t>((int64_t)al->cu_count * 16, cnt), stream) == 0;
+        mark();
+        if (!ok) { al->err = "BiWFA level kernel launch failed"; return WFA_HIP_EDEVICE; }
+        a.worklist = la.redo_list; a.nwork_dev = la.cnt + WFA_BL_MAX_LEVELS + 2; a.nwork = cnt;
+        dfs_grid = grid;
+        if (wfa::launch_biwfa_any(b->ncomp, kind == 0, ba, (int)dfs_grid, stream) != 0) { al->err = "BiWFA kernel launch failed"; return WFA_HIP_EDEVICE; }
+        mark();
+        if (stage_timing) {
+          (void)hipStreamSynchronize(stream);
+          uint32_t hc[WFA_BL_COUNTER_WORDS];
+          (void)hipMemcpy(hc, la.cnt, sizeof(hc), hipMemcpyDeviceToHost);
+          fprintf(stderr, "[wfa_hip] biwfa levels (%s, %d pairs, grid %d, slice %.2f MB, %s rings):", kind ? "bytes" : "2-bit", (int)cnt, bl_grid, la.slice_bytes / 1048576.0, bl_i16 ? "int16" : "int32");
+          for (int lv = 0; lv < bl_levels; ++lv) { float ms = 0; (void)hipEventElapsedTime(&ms, tev[lv], tev[lv + 1]); fprintf(stderr, " L%d %u windows %.3f ms;", lv, hc[lv], ms); }
+          float mb = 0, mf = 0, md = 0;
+          (void)hipEventElapsedTime(&mb, tev[bl_levels], tev[bl_levels + 1]); (void)hipEventElapsedTime(&mf, tev[bl_levels + 1], tev[bl_levels + 2]); (void)hipEventElapsedTime(&md, tev[bl_levels + 2], tev[bl_levels + 3]);
+          fprintf(stderr, " base %u windows %.3f ms; finish %.3f ms (%u leaves); redo %u pairs %.3f ms\n", hc[WFA_BL_MAX_LEVELS], mb, mf, hc[WFA_BL_MAX_LEVELS + 1], hc[WFA_BL_MAX_LEVELS + 2], md);
+          for (hipEvent_t e : tev) (void)hipEventDestroy(e);
+        }
+        continue;
+      }
+      if (wfa::launch_biwfa_any(b->ncomp, kind == 0, ba, (int)dfs_grid, stream) != 0) { al->err = "BiWFA kernel launch failed"; return WFA_HIP_EDEVICE; }
     }
     if (full) {
       for (int kind = 0; kind < 2; ++kind) {
@@ -2575,8 +2670,8 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
     HIP_TRY(al, hipMalloc((void**)&al->tiny_d, TINY_IN_BYTES));
   }
   uint8_t* h = al->tiny_h;
-  uint8_t* hd = nullptr;   // the pinned block as the device sees it
-  HIP_TRY(al, hipHostGetDevicePointer((void**)&hd, h, 0));
+  if (!al->tiny_hd) HIP_TRY(al, hipHostGetDevicePointer((void**)&al->tiny_hd, h, 0));
+  uint8_t* hd = al->tiny_hd;   // the pinned block as the device sees it
   // ---- gap-affine / gap-affine-2p with an instantiated penalty shape, pure ACGT: ONE launch of the banded kernel (one wave per
   // pair, 128 diagonals in registers).  The host packs the sequences to 2 bits into the pinned block; the kernel stages them
   // in LDS straight from there (no copy kernel), aligns, walks back in-kernel and writes results and op bytes into the pinned
@@ -2646,6 +2741,13 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
       const bool poll = knob(al, K_NO_TINY_POLL, 0) == 0;
       for (int64_t i = 0; i < n; ++i) hdone[i] = 0;
       ba.done = poll ? reinterpret_cast<int32_t*>(hd + b_done) : nullptr;
+      // one pair: lengths, op-region offsets and packed words ride in the kernel arguments (wfa_slim_kernel_one)
+      uint32_t one[8 + 136];
+      if (n == 1 && w + 4 <= 136 && ba.slim && knob(al, K_NO_TINY_INLINE, 0) == 0) {
+        memcpy(one, &bm[0], 16); memcpy(one + 4, &bco[0], 16);
+        memcpy(one + 8, bw, (size_t)(w + 4) * 4);
+        ba.one = one;
+      }
       const unsigned rtc_failures = wfa::rtc_failure_count();
       if (wfa::launch_band(ba, nch, full, al->dcfg.heuristic != WFA_HEUR_NONE, true, (long long)n, stream) != 0) {
         if (al->dcfg.rtc && wfa::rtc_failure_count() != rtc_failures) {
@@ -2657,8 +2759,8 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
         }
         al->err = "band kernel launch failed"; return WFA_HIP_EDEVICE;
       }
-      HIP_TRY(al, hipEventRecord(al->ws_event, stream));
-      al->ws_event_recorded = true; al->ws_last_stream = stream;
+      // (no event for the workspace: the call returns only after every pair's flag — stored behind its walk, the history's last
+      // reader — or after the stream has drained)
       bool seen = false;
       if (poll) {
         const double t_poll = now_ms();

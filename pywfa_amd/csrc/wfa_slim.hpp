@@ -86,7 +86,7 @@ __device__ __forceinline__ unsigned long long slim_range_mask(int c, int lo, int
 // position and step in the workgroup's slice, walked in-kernel by band_backtrace) — the stage BEHIND the split one, which takes the
 // few pairs a window hands on: there the latency of one alignment is what counts, and this step is a third of wfa_band_kernel's.
 template <int NCH, int HIST, int X, int OE, int E, int OE2, int E2>
-__device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
+__device__ __forceinline__ void wfa_slim_body(const BandArgs& a, const uint32_t* __restrict__ inl = nullptr) {
   constexpr bool FULL = HIST != 0, PBH = HIST == 1, XH = HIST == 2;
   constexpr bool TWO = OE2 > 0;  // gap-affine-2p: second pair of gap components (R/wavefront_compute_affine2p.c:45-106)
   constexpr int E2D = TWO ? E2 : 1;
@@ -109,12 +109,24 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
   const int thr2 = 2 * a.max_dist_thr;
   for (uint32_t wi = w0 + blockIdx.x; wi < w0 + nwork; wi += gridDim.x) {
     const uint32_t pair = a.worklist ? a.worklist[wi] : wi;
-    const WfaPairMeta pm = a.meta[pair];
+    // (inl: the single-call form — meta, op-region offsets and the packed words of the one pair arrive in the kernel arguments)
+    WfaPairMeta pm;
+    int64_t coff_one[2] = {0, 0};
+    if (inl) {   // (loads through a generic pointer: made wave-uniform by hand, or every mask below would live in vector registers)
+      pm.p_woff = __builtin_amdgcn_readfirstlane(inl[0]); pm.t_woff = __builtin_amdgcn_readfirstlane(inl[1]);
+      pm.plen = __builtin_amdgcn_readfirstlane(inl[2]); pm.tlen = __builtin_amdgcn_readfirstlane(inl[3]);
+      coff_one[0] = ((int64_t)__builtin_amdgcn_readfirstlane(inl[5]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(inl[4]);
+      coff_one[1] = ((int64_t)__builtin_amdgcn_readfirstlane(inl[7]) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(inl[6]);
+    } else {
+      pm = a.meta[pair];
+    }
+    const int64_t* const coff = inl ? coff_one : a.cigar_off;
     const int plen = pm.plen, tlen = pm.tlen;
     const int ak = tlen - plen;
     uint8_t* const rec = PBH ? reinterpret_cast<uint8_t*>(a.hist + (long long)(wi - w0) * a.hist_stride) : nullptr;   // this pair's history slot
-    const uint32_t* gP = a.words + pm.p_woff;
-    const uint32_t* gT = a.words + pm.t_woff;
+    const uint32_t* const wbase = inl ? inl + 8 : a.words;
+    const uint32_t* gP = wbase + pm.p_woff;
+    const uint32_t* gT = wbase + pm.t_woff;
     const int nwp = (plen + 15) >> 4, nwt = (tlen + 15) >> 4;
     bool fallback = false;
     if (nwp + 3 > a.lds_words || nwt + 3 > a.lds_words || max_records <= 1 || (TWO && 2 * max(plen, tlen) > 32000)) fallback = true;   // (2p: doubled offsets as int16)
@@ -579,17 +591,17 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a) {
       else fallback = true;
     }
     if (FULL && stop_status != 0 && lane == 0) {   // no end cell: no walk, empty op string (R/wavefront_unialign.c:147-237)
-      a.cigar_begin[pair] = a.cigar_off[pair + 1];
+      a.cigar_begin[pair] = coff[pair + 1];
       a.cigar_len[pair] = 0;
     }
     if (PBH && lane == 0) a.end_state[wi - w0] = make_int4(end_s, end_k, end_off, (fallback || stop_status != 0 || !done) ? 0 : 1);
     if (XH && done && !fallback && stop_status == 0) {
       __syncthreads();   // this wave's history stores before its own loads
       long long begin = 0;
-      uint8_t* buf = a.cigar_ops + a.cigar_off[pair];
+      uint8_t* buf = a.cigar_ops + coff[pair];
       band_backtrace<NCH>(xhist, a, plen, tlen, end_s, end_k, end_off, buf, &begin, lane, 64);
       if (lane == 0) {
-        a.cigar_begin[pair] = a.cigar_off[pair] + begin;
+        a.cigar_begin[pair] = coff[pair] + begin;
         a.cigar_len[pair] = (int)((long long)plen + tlen - begin);
       }
     }
@@ -627,6 +639,19 @@ wfa_slim_kernel_2p(const BandArgs a) {   // gap-affine-2p: 25 ring registers per
   wfa_slim_body<NCH, HIST, X, OE, E, OE2, E2>(a);
 }
 
+// One pair per call (wfa_hip_align_pair): everything the wave reads from the host — lengths, op-region offsets, the packed words —
+// rides in the kernel arguments, so the kernel starts without a load from the pinned block (two dependent PCIe round trips less).
+#define WFA_SLIM_ONE_WORDS 136   // 2 x (1000 bases + the look-ahead words)
+struct SlimOne { uint32_t w[8 + WFA_SLIM_ONE_WORDS]; };   // [0,4) WfaPairMeta, [4,8) cigar_off[0..1], [8,..) words
+template <int NCH, int HIST, int X, int OE, int E, int OE2, int E2>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WFA_SLIM_WAVES, WFA_SLIM_WAVES)))
+wfa_slim_kernel_one(const BandArgs a, const SlimOne q) {
+  typedef const char __attribute__((address_space(4))) * kernarg_ptr;
+  constexpr size_t off = (sizeof(BandArgs) + alignof(SlimOne) - 1) & ~(alignof(SlimOne) - 1);
+  const uint32_t* inl = (const uint32_t*)((kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + off);
+  wfa_slim_body<NCH, HIST, X, OE, E, OE2, E2>(a, inl);
+}
+
 #ifndef __HIPCC_RTC__
 template <int X, int OE, int E, int OE2, int E2>
 static int launch_slim_shape(const BandArgs& a, int nch, bool full, long long grid, hipStream_t stream) {
@@ -642,6 +667,10 @@ static int launch_slim_shape(const BandArgs& a, int nch, bool full, long long gr
     if (full && a.split) hipLaunchKernelGGL((wfa_slim_kernel_2p<NCH1, 1, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
     else if (full) hipLaunchKernelGGL((wfa_slim_kernel_2p<NCH1, 2, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
     else hipLaunchKernelGGL((wfa_slim_kernel_2p<NCH1, 0, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+  } else if (a.one && !a.split && grid == 1) {
+    const SlimOne& q = *reinterpret_cast<const SlimOne*>(a.one);
+    if (full) hipLaunchKernelGGL((wfa_slim_kernel_one<NCH1, 2, X, OE, E, OE2, E2>), dim3(1), dim3(64), smem, stream, a, q);
+    else hipLaunchKernelGGL((wfa_slim_kernel_one<NCH1, 0, X, OE, E, OE2, E2>), dim3(1), dim3(64), smem, stream, a, q);
   } else {
     // (unsplit with a history: reads of up to 1 kb, the single-call path — explicit history, walked in-kernel)
     if (full && a.split) hipLaunchKernelGGL((wfa_slim_kernel<NCH1, 1, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);

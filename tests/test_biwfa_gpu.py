@@ -32,6 +32,25 @@ def test_biwfa_full_cigar_matches_oracle(gpu, cfg_idx):
         common.assert_same(o, score, status, cigars, batch, f"biwfa {kw} corpus {i}")
 
 
+@pytest.mark.parametrize("env", [dict(WFA_HIP_BILEVEL_QCAP="40"), dict(WFA_HIP_BILEVEL_LEVELS="2"), dict(WFA_HIP_BILEVEL="0"),
+                                 dict(WFA_HIP_BILEVEL_I32="1", WFA_HIP_BILEVEL_WIDE_LEVELS="0"), dict(WFA_HIP_BILEVEL_WIDE_LEVELS="9")])
+def test_biwfa_level_queues_that_overflow_are_redone(gpu, env, monkeypatch):
+    """The level-by-level form (csrc/wfa_bilevel.hpp) with queues too small for the batch / too few levels: the pairs it cannot finish
+    are aligned again by the depth-first kernel; and the depth-first kernel alone, int32 rings, one-wave / four-wave windows only —
+    the same op strings every time."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    pairs = [datagen.pair_strings(b, i) for b in (datagen.generate(24, 3000, 0.10, 99), datagen.generate(40, 700, 0.15, 98), datagen.generate(30, 90, 0.1, 97))
+             for i in range(len(b["p_len"]))]
+    batch = datagen.from_strings([p for p, _ in pairs], [t for _, t in pairs])
+    for kw in (dict(span="end-to-end"), dict(distance="affine2p", span="end-to-end"), dict(span="end-to-end", max_steps=400),
+               dict(span="end-to-end", heuristic="adaptive")):
+        oc, nc = common.configs_pair(scope="full", memory_mode="biwfa", **kw)
+        o = loader.run(loader.oracle(), oc, batch)
+        score, status, cigars = common.gpu_run(nc, batch, True, resident=True)
+        common.assert_same(o, score, status, cigars, batch, f"biwfa levels {env} {kw}")
+
+
 def test_biwfa_long_reads_and_memory(gpu):
     """40 kb reads at 10 % (scores ~ 20 k: the recursion splits eight levels deep): op strings equal to the oracle's, valid
     transcripts whose penalty is the score, and the same scores as memory_mode high."""
