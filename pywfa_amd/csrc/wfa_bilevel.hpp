@@ -31,6 +31,9 @@ namespace wfa {
 struct BlWindow { int pair, pbeg, pend, tbeg, tend, flags, score_remaining, pad; };
 struct BlLeaf { int start, region, begin, n, next, pad0, pad1, pad2; };   // begin: relative to the pair's op region
 
+#ifndef WFA_BL_FLY
+#define WFA_BL_FLY 2      // chunks of loads a thread of the workspace form keeps in flight (4: 128 registers, four waves per SIMD — measured slower)
+#endif
 #define WFA_BL_MAX_LEVELS 40
 #define WFA_BL_LEAF_LDS 1024          // leaves of a pair bl_finish_kernel sorts in LDS (more: redo)
 #define WFA_BL_FLAG_REDO 1
@@ -40,10 +43,11 @@ struct BlArgs {
   WfaKernelArgs k;
   BlWindow* q[2];          // windows of the even / odd levels
   BlWindow* qb;            // base windows
+  BlWindow* qw;            // windows of the current level that outgrew the LDS form (taken by the workspace form of the same level)
   BlLeaf* leaves;
-  uint32_t* cnt;           // [l] windows of level l (l < WFA_BL_MAX_LEVELS), [40] base windows, [41] leaves, [42] redo pairs; [64 + l], [64 + 40]: windows taken
-#define WFA_BL_COUNTER_WORDS 128
-  uint32_t qcap, qbcap, leafcap;
+  uint32_t* cnt;           // [l] windows of level l (l < WFA_BL_MAX_LEVELS), [40] base windows, [41] leaves, [42] redo pairs; [64 + l], [64 + 40]: windows taken; [128 + l]: windows of level l handed to the workspace form, [192 + l]: taken
+#define WFA_BL_COUNTER_WORDS 256
+  uint32_t qcap, qbcap, leafcap, qwcap;
   int* head;               // per pair: first leaf of its list (-1: none)
   int* flags;              // per pair: WFA_BL_FLAG_*
   int* top;                // per pair: score of the top-level breakpoint (INT_MIN: none)
@@ -56,106 +60,171 @@ struct BlArgs {
   long long base_ints;
   int base_stride;
   int level;
+  int from_wide;           // 1: the launch reads qw (count cnt[128 + level]) instead of q[level & 1]
+  int lds_w, lds_slots, lds_seq_words;   // LDS form: diagonals per row (a power of two), rows per component, words per sequence buffer
 };
 
-template <typename OT> __device__ __forceinline__ int bl_ld(const OT* __restrict__ p, long long i) {
+// pointer to ring offsets / packed words: generic (workspace) or LDS (address space 3: ds_read / ds_write instead of flat accesses)
+template <typename T, bool LDSR> struct BlPtr { typedef T* type; };
+template <typename T> struct BlPtr<T, true> { typedef __attribute__((address_space(3))) T* type; };
+
+template <typename P> __device__ __forceinline__ int bl_ld(P p, long long i) {
   int v = p[i];
-  if (sizeof(OT) == 2) v = (v < 0) ? WFA_OFFSET_NULL : v;
+  if (sizeof(p[0]) == 2) v = (v < 0) ? WFA_OFFSET_NULL : v;
   return v;
 }
-template <typename OT> __device__ __forceinline__ void bl_st(OT* __restrict__ p, long long i, int v) {
-  if (sizeof(OT) == 2) p[i] = (OT)min(max(v, -16384), 32767);
-  else p[i] = (OT)v;
+template <typename P> __device__ __forceinline__ void bl_st(P p, long long i, int v) {
+  if (sizeof(p[0]) == 2) p[i] = (short)min(max(v, -16384), 32767);
+  else p[i] = v;
 }
 
-// n values reduced over the workgroup: bit i of maxmask set = maximum, else minimum.  red: NW * 16 ints of LDS.
+// N values reduced over the workgroup: bit i of maxmask set = maximum, else minimum.  One wave: shuffles.  More: the waves' partial
+// results meet in LDS atomics — red holds three buffers of 16 minima + 16 maxima used in rotation (`phase`), the buffer of the call
+// after the next is re-set before this call's barrier, so a call costs ONE barrier whatever the number of waves.
 template <int THREADS, int N>
-__device__ __forceinline__ void bl_reduce(int (&v)[N], uint32_t maxmask, int* red, int tid) {
+__device__ __forceinline__ void bl_reduce(int (&v)[N], uint32_t maxmask, int* red, int& phase, int tid) {
 #pragma unroll
   for (int i = 0; i < N; ++i) v[i] = ((maxmask >> i) & 1) ? wave_max(v[i]) : wave_min(v[i]);
   if (THREADS > 64) {
-    constexpr int NW = THREADS / 64;
-    const int w = tid >> 6;
+    int* const cur = red + phase * 32;
+    int* const nxt = red + ((phase + 1) % 3) * 32;
+    if (tid < 32) nxt[tid] = (tid < 16) ? INT_MAX : INT_MIN;
     if ((tid & 63) == 0) {
 #pragma unroll
-      for (int i = 0; i < N; ++i) red[w * 16 + i] = v[i];
+      for (int i = 0; i < N; ++i) { if ((maxmask >> i) & 1) atomicMax(cur + 16 + i, v[i]); else atomicMin(cur + i, v[i]); }
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      int r = red[i];
-#pragma unroll
-      for (int j = 1; j < NW; ++j) r = ((maxmask >> i) & 1) ? max(r, red[j * 16 + i]) : min(r, red[j * 16 + i]);
-      v[i] = r;
-    }
-    __syncthreads();
+    for (int i = 0; i < N; ++i) v[i] = ((maxmask >> i) & 1) ? cur[16 + i] : cur[i];
+    phase = (phase + 1) % 3;
   }
 }
+__device__ __forceinline__ void bl_reduce_init(int* red, int tid) { if (tid < 96) red[tid] = ((tid & 31) < 16) ? INT_MAX : INT_MIN; }
 
-// One unidirectional aligner of the workgroup: directory ring in LDS, offsets in the workspace.
-template <int NCOMP, typename OT>
-struct BlSide {
-  int* ring;
-  OT* ws;
-  int stride, rbase;
-  int null_steps;
-  int cur_lo, cur_hi, cur_exists;
-  long long cur_idx0;
-  int steps_wait, have_max_sw, max_sw;
-  __device__ __forceinline__ int data_index(int s, int scope) const { return (s % scope) * NCOMP * stride; }
+// a window of the two sequences, read forwards or backwards (R/wavefront_sequences.c:275-310): wfa_biwfa.hpp's BiView over either
+// pointer kind
+template <bool PACKED, bool LDSR>
+struct BlView {
+  typedef typename BlPtr<const uint32_t, LDSR>::type WP;
+  WP pw; WP tw;
+  const uint8_t* pb; const uint8_t* tb;
+  int pbeg, pend, tbeg, tend, wildcard;
+  bool reverse;
+  static __device__ __forceinline__ uint32_t w16(WP w, int pos) {
+    const int i = pos >> 4;
+    const uint32_t lo = w[i], hi = w[i + 1];
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(pos & 15) << 1);
+  }
+  __device__ __forceinline__ int run(int v, int h, int maxrun) const {
+    int n = 0;
+    if (PACKED) {
+      if (!reverse) {
+        const int pv = pbeg + v, th = tbeg + h;
+        while (n < maxrun) {
+          const uint32_t x = w16(pw, pv + n) ^ w16(tw, th + n);
+          const int m = x ? (__builtin_ctz(x) >> 1) : 16;
+          n += m;
+          if (m < 16) break;
+        }
+      } else {
+        const int pq = pend - 1 - v, tq = tend - 1 - h;
+        while (n < maxrun) {
+          const int a = pq - n, b = tq - n;
+          const int sa = (a >= 15) ? 0 : 15 - a, sb = (b >= 15) ? 0 : 15 - b;
+          const uint32_t wa = w16(pw, a - 15 + sa) << (2 * sa), wb = w16(tw, b - 15 + sb) << (2 * sb);
+          const uint32_t x = wa ^ wb;
+          const int m = x ? (__builtin_clz(x) >> 1) : 16;
+          n += m;
+          if (m < 16) break;
+        }
+      }
+      return min(n, maxrun);
+    }
+    while (n < maxrun) {
+      const int pc = reverse ? pb[pend - 1 - v - n] : pb[pbeg + v + n];
+      const int tc = reverse ? tb[tend - 1 - h - n] : tb[tbeg + h + n];
+      if (!(pc == tc || (wildcard >= 0 && (pc == wildcard || tc == wildcard)))) break;
+      ++n;
+    }
+    return n;
+  }
 };
 
-template <int NCOMP, typename OT>
-__device__ __forceinline__ void bl_side_init(BlSide<NCOMP, OT>& sd, int scope, int comp_begin, int plen, int tlen, int tid) {
+// One unidirectional aligner of the workgroup: directory ring in LDS; the offsets in the workgroup's slice of the workspace (rows of
+// `stride` diagonals, element k - rbase, row of score s = s mod scope) or, LDSR, in LDS (rows of W diagonals, element k mod W, the row
+// of a score taken from a counter of the non-null steps: scope / g + 1 rows per component are enough, scores between multiples of g
+// being null).  Either way element (row, k) = idx0 + (k & kmask) with the row's idx0 kept in the directory record.
+template <int NCOMP, typename OT, bool LDSR>
+struct BlSide {
+  typedef typename BlPtr<OT, LDSR>::type P;
+  int* ring;
+  P ws;
+  int stride, rbase, kmask;
+  int lds_slots, cur_slot;
+  int null_steps;
+  int cur_lo, cur_hi, cur_exists, end_reached;
+  long long cur_idx0;
+  int steps_wait, have_max_sw, max_sw;
+  __device__ __forceinline__ int next_data(int s, int scope) {
+    if (LDSR) { cur_slot = (cur_slot + 1 == lds_slots) ? 0 : cur_slot + 1; return cur_slot * NCOMP * stride; }
+    return (s % scope) * NCOMP * stride;
+  }
+};
+
+template <int NCOMP, typename OT, bool LDSR>
+__device__ __forceinline__ void bl_side_init(BlSide<NCOMP, OT, LDSR>& sd, int scope, int comp_begin, int plen, int tlen, int tid) {
   typedef Meta<NCOMP> MT;
-  sd.rbase = -plen - 1;
-  sd.null_steps = 0;
+  sd.rbase = LDSR ? 0 : -plen - 1;
+  sd.kmask = LDSR ? sd.stride - 1 : -1;
+  sd.cur_slot = 0;
+  sd.null_steps = 0; sd.end_reached = 0;
   sd.steps_wait = 0; sd.have_max_sw = 0; sd.max_sw = 0;
-  const int data = sd.data_index(0, scope);
+  const int data = 0;
   __syncthreads();
   if (tid == 0) {
     int* m = sd.ring;
     for (int c = 0; c < NCOMP; ++c) { m[MT::LO + c] = 1; m[MT::HI + c] = -1; }
     m[MT::LO + comp_begin] = 0; m[MT::HI + comp_begin] = 0;
     m[MT::BASE] = sd.rbase; m[MT::WIDTH] = sd.stride; m[MT::DATA] = data; m[MT::EXISTS] = (comp_begin == 0) ? 1 : 0;
-    bl_st<OT>(sd.ws, data + comp_begin * sd.stride + (0 - sd.rbase), 0);
+    bl_st(sd.ws, (long long)data + comp_begin * sd.stride - sd.rbase, 0);
   }
   sd.cur_exists = (comp_begin == 0) ? 1 : 0;
   sd.cur_lo = sd.cur_exists ? 0 : 1; sd.cur_hi = sd.cur_exists ? 0 : -1;
-  sd.cur_idx0 = data - sd.rbase;
+  sd.cur_idx0 = (long long)data - sd.rbase;
   __syncthreads();
 }
 
 // extension of wavefront 0 (the later ones are extended inside bl_side_step)
-template <int NCOMP, bool PACKED, typename OT, int THREADS>
-__device__ __forceinline__ int bl_side_extend0(BlSide<NCOMP, OT>& sd, const BiView<PACKED>& view, int plen, int tlen, int* red, int tid) {
+template <int NCOMP, typename OT, int THREADS, bool LDSR, typename V>
+__device__ __forceinline__ int bl_side_extend0(BlSide<NCOMP, OT, LDSR>& sd, const V& view, int plen, int tlen, int* red, int& phase, int tid) {
   int best[1] = {0};
   if (sd.cur_exists) {
     if (tid == 0) {
-      const int off = bl_ld<OT>(sd.ws, sd.cur_idx0 + 0);
+      const int off = bl_ld(sd.ws, sd.cur_idx0 + 0);
       const int ext = off + view.run(off, off, min(plen - off, tlen - off));
-      if (ext != off) bl_st<OT>(sd.ws, sd.cur_idx0 + 0, ext);
+      if (ext != off) bl_st(sd.ws, sd.cur_idx0 + 0, ext);
       best[0] = 2 * ext;
     }
-    bl_reduce<THREADS, 1>(best, 1u, red, tid);
+    bl_reduce<THREADS, 1>(best, 1u, red, phase, tid);
   }
   __syncthreads();
   return best[0];
 }
 
-template <int NCOMP, typename OT>
+template <int NCOMP, typename OT, bool LDSR>
 struct BlIn {
-  int lo, hi; long long idx0;
+  typedef typename BlPtr<OT, LDSR>::type P;
+  int lo, hi, kmask; long long idx0;
   __device__ __forceinline__ bool null() const { return lo > hi; }
-  __device__ __forceinline__ int get(const OT* __restrict__ ws, int k) const { return (k >= lo && k <= hi) ? bl_ld<OT>(ws, idx0 + k) : WFA_OFFSET_NULL; }
+  __device__ __forceinline__ int get(P ws, int k) const { return (k >= lo && k <= hi) ? bl_ld(ws, idx0 + (k & kmask)) : WFA_OFFSET_NULL; }
 };
-template <int NCOMP, typename OT>
-__device__ __forceinline__ BlIn<NCOMP, OT> bl_fetch_in(const int* ring, int scope, int s, int c) {
+template <int NCOMP, typename OT, bool LDSR>
+__device__ __forceinline__ BlIn<NCOMP, OT, LDSR> bl_fetch_in(const BlSide<NCOMP, OT, LDSR>& sd, int scope, int s, int c) {
   typedef Meta<NCOMP> MT;
-  BlIn<NCOMP, OT> in;
-  in.lo = 1; in.hi = -1; in.idx0 = 0;
+  BlIn<NCOMP, OT, LDSR> in;
+  in.lo = 1; in.hi = -1; in.idx0 = 0; in.kmask = sd.kmask;
   if (s >= 0) {
-    const int* m = ring + (s % scope) * MT::INTS;
+    const int* m = sd.ring + (s % scope) * MT::INTS;
     const int lo = m[MT::LO + c], hi = m[MT::HI + c];
     if (lo <= hi) { in.lo = lo; in.hi = hi; in.idx0 = (long long)m[MT::DATA] + c * m[MT::WIDTH] - m[MT::BASE]; }
   }
@@ -164,29 +233,32 @@ __device__ __forceinline__ BlIn<NCOMP, OT> bl_fetch_in(const int* ring, int scop
 
 // compute-next of score s and the extension of its M wavefront in one pass (R/wavefront_compute_affine.c:44-86,229-260,
 // R/wavefront_compute_affine2p.c:45-106,334-368, R/wavefront_compute_edit.c / _linear.c, limits R/wavefront_compute.c:40-86,
-// trimming :571-605 on the offsets before the extension, R/wavefront_extend.c:90-125).  Returns the largest antidiagonal
-// 2 * offset - k of the extended M wavefront (0: none).
-template <int NCOMP, bool PACKED, typename OT, int THREADS>
-__device__ __forceinline__ int bl_side_step(BlSide<NCOMP, OT>& sd, const BiView<PACKED>& view, const WfaDevConfig& cfg, int scope, int s,
-                                            int plen, int tlen, int* red, int tid) {
+// trimming :571-605 on the offsets before the extension, R/wavefront_extend.c:90-125), and the end test of R/wavefront_termination.c:
+// 37-113 on the values as they pass (sd.end_reached).  Returns the largest antidiagonal 2 * offset - k of the extended M wavefront
+// (0: none); -1: the wavefront does not fit the LDS rows (LDSR).
+template <int NCOMP, typename OT, int THREADS, bool LDSR, typename V>
+__device__ __forceinline__ int bl_side_step(BlSide<NCOMP, OT, LDSR>& sd, const V& view, const WfaDevConfig& cfg, int scope, int s,
+                                            int comp_end, int plen, int tlen, int* red, int& phase, int tid) {
   typedef Meta<NCOMP> MT;
-  typedef BlIn<NCOMP, OT> In;
-  const OT* ws = sd.ws;
-  In nullin; nullin.lo = 1; nullin.hi = -1; nullin.idx0 = 0;
-  const In mx = (NCOMP == 1 && cfg.metric == 0) ? nullin : bl_fetch_in<NCOMP, OT>(sd.ring, scope, s - cfg.x, 0);
-  const In mo1 = bl_fetch_in<NCOMP, OT>(sd.ring, scope, s - cfg.o1 - cfg.e1, 0);
-  const In i1e = (NCOMP == 1) ? nullin : bl_fetch_in<NCOMP, OT>(sd.ring, scope, s - cfg.e1, 1);
-  const In d1e = (NCOMP == 1) ? nullin : bl_fetch_in<NCOMP, OT>(sd.ring, scope, s - cfg.e1, 2);
+  typedef BlIn<NCOMP, OT, LDSR> In;
+  typedef typename BlPtr<OT, LDSR>::type P;
+  const P ws = sd.ws;
+  In nullin; nullin.lo = 1; nullin.hi = -1; nullin.idx0 = 0; nullin.kmask = -1;
+  const In mx = (NCOMP == 1 && cfg.metric == 0) ? nullin : bl_fetch_in<NCOMP, OT, LDSR>(sd, scope, s - cfg.x, 0);
+  const In mo1 = bl_fetch_in<NCOMP, OT, LDSR>(sd, scope, s - cfg.o1 - cfg.e1, 0);
+  const In i1e = (NCOMP == 1) ? nullin : bl_fetch_in<NCOMP, OT, LDSR>(sd, scope, s - cfg.e1, 1);
+  const In d1e = (NCOMP == 1) ? nullin : bl_fetch_in<NCOMP, OT, LDSR>(sd, scope, s - cfg.e1, 2);
   In mo2 = nullin, i2e = nullin, d2e = nullin;
   if (NCOMP == 5) {
-    mo2 = bl_fetch_in<NCOMP, OT>(sd.ring, scope, s - cfg.o2 - cfg.e2, 0);
-    i2e = bl_fetch_in<NCOMP, OT>(sd.ring, scope, s - cfg.e2, 3);
-    d2e = bl_fetch_in<NCOMP, OT>(sd.ring, scope, s - cfg.e2, 4);
+    mo2 = bl_fetch_in<NCOMP, OT, LDSR>(sd, scope, s - cfg.o2 - cfg.e2, 0);
+    i2e = bl_fetch_in<NCOMP, OT, LDSR>(sd, scope, s - cfg.e2, 3);
+    d2e = bl_fetch_in<NCOMP, OT, LDSR>(sd, scope, s - cfg.e2, 4);
   }
   const bool all_null = mx.null() && mo1.null() && i1e.null() && d1e.null() && (NCOMP != 5 || (mo2.null() && i2e.null() && d2e.null()));
   int* const mslot = sd.ring + (s % scope) * MT::INTS;
   int tlo[NCOMP], thi[NCOMP];
   int base = 0, width = 0, data = 0, exists = 0, best = 0;
+  sd.end_reached = 0;
 #pragma unroll
   for (int c = 0; c < NCOMP; ++c) { tlo[c] = 1; thi[c] = -1; }
   if (all_null) {
@@ -205,20 +277,24 @@ __device__ __forceinline__ int bl_side_step(BlSide<NCOMP, OT>& sd, const BiView<
       lo = min(lo, i2e.lo + 1); hi = max(hi, i2e.hi + 1);
       lo = min(lo, d2e.lo - 1); hi = max(hi, d2e.hi - 1);
     }
-    // (a ring row spans every diagonal of the window: lo >= -plen - 1 and hi <= tlen + 1 by the trimming of the inputs)
+    if (LDSR && hi - lo + 1 > sd.stride) return -1;   // (uniform: every thread leaves)
+    // (a workspace row spans every diagonal of the window: lo >= -plen - 1 and hi <= tlen + 1 by the trimming of the inputs)
     const bool has_i1 = (NCOMP != 1) && (!mo1.null() || !i1e.null());
     const bool has_d1 = (NCOMP != 1) && (!mo1.null() || !d1e.null());
     const bool has_i2 = (NCOMP == 5) && (!mo2.null() || !i2e.null());
     const bool has_d2 = (NCOMP == 5) && (!mo2.null() || !d2e.null());
-    base = sd.rbase; width = sd.stride; data = sd.data_index(s, scope); exists = 1;
+    base = sd.rbase; width = sd.stride; data = sd.next_data(s, scope); exists = 1;
+    const int kmask = sd.kmask;
     const long long o_m = (long long)data - base;
     const long long o_i1 = o_m + width, o_d1 = o_m + 2 * width, o_i2 = o_m + 3 * width, o_d2 = o_m + 4 * width;
-    OT* wsw = sd.ws;
-    // reduced below: [0, NCOMP) first in-bounds diagonal per component (min), [NCOMP, 2 NCOMP) last (max), [2 NCOMP] antidiagonal (max)
-    int r[2 * NCOMP + 1];
+    const P wsw = sd.ws;
+    const int ak = tlen - plen;
+    // reduced below: [0, NCOMP) first in-bounds diagonal per component (min), [NCOMP, 2 NCOMP) last (max), [2 NCOMP] antidiagonal (max),
+    // [2 NCOMP + 1] the end component's offset on diagonal tlen - plen (max)
+    int r[2 * NCOMP + 2];
 #pragma unroll
     for (int c = 0; c < NCOMP; ++c) { r[c] = INT_MAX; r[NCOMP + c] = INT_MIN; }
-    r[2 * NCOMP] = 0;
+    r[2 * NCOMP] = 0; r[2 * NCOMP + 1] = INT_MIN;
     struct Cell { int mo1l, i1l, mo1r, d1r, mxc, mo2l, i2l, mo2r, d2r; };
     auto load = [&](int k, Cell& c) {
       c.mo1l = mo1.get(ws, k - 1); c.mo1r = mo1.get(ws, k + 1);
@@ -228,16 +304,17 @@ __device__ __forceinline__ int bl_side_step(BlSide<NCOMP, OT>& sd, const BiView<
     };
     auto inb = [&](int off, int k) -> bool { return (uint32_t)off <= (uint32_t)tlen && (uint32_t)(off - k) <= (uint32_t)plen; };
     auto finish = [&](int k, const Cell& c) {
+      const int km = k & kmask;
       const int ins1 = max(c.mo1l, c.i1l) + 1;
       const int del1 = max(c.mo1r, c.d1r);
-      int ins = ins1, del = del1;
-      if (has_i1) { bl_st<OT>(wsw, o_i1 + k, ins1); if (inb(ins1, k)) { r[1 % NCOMP] = min(r[1 % NCOMP], k); r[NCOMP + 1 % NCOMP] = max(r[NCOMP + 1 % NCOMP], k); } }
-      if (has_d1) { bl_st<OT>(wsw, o_d1 + k, del1); if (inb(del1, k)) { r[2 % NCOMP] = min(r[2 % NCOMP], k); r[NCOMP + 2 % NCOMP] = max(r[NCOMP + 2 % NCOMP], k); } }
+      int ins = ins1, del = del1, endv = INT_MIN;
+      if (has_i1) { bl_st(wsw, o_i1 + km, ins1); if (inb(ins1, k)) { r[1 % NCOMP] = min(r[1 % NCOMP], k); r[NCOMP + 1 % NCOMP] = max(r[NCOMP + 1 % NCOMP], k); } if (comp_end == 1) endv = ins1; }
+      if (has_d1) { bl_st(wsw, o_d1 + km, del1); if (inb(del1, k)) { r[2 % NCOMP] = min(r[2 % NCOMP], k); r[NCOMP + 2 % NCOMP] = max(r[NCOMP + 2 % NCOMP], k); } if (comp_end == 2) endv = del1; }
       if (NCOMP == 5) {
         const int ins2 = max(c.mo2l, c.i2l) + 1;
         const int del2 = max(c.mo2r, c.d2r);
-        if (has_i2) { bl_st<OT>(wsw, o_i2 + k, ins2); if (inb(ins2, k)) { r[3 % NCOMP] = min(r[3 % NCOMP], k); r[NCOMP + 3 % NCOMP] = max(r[NCOMP + 3 % NCOMP], k); } }
-        if (has_d2) { bl_st<OT>(wsw, o_d2 + k, del2); if (inb(del2, k)) { r[4 % NCOMP] = min(r[4 % NCOMP], k); r[NCOMP + 4 % NCOMP] = max(r[NCOMP + 4 % NCOMP], k); } }
+        if (has_i2) { bl_st(wsw, o_i2 + km, ins2); if (inb(ins2, k)) { r[3 % NCOMP] = min(r[3 % NCOMP], k); r[NCOMP + 3 % NCOMP] = max(r[NCOMP + 3 % NCOMP], k); } if (comp_end == 3) endv = ins2; }
+        if (has_d2) { bl_st(wsw, o_d2 + km, del2); if (inb(del2, k)) { r[4 % NCOMP] = min(r[4 % NCOMP], k); r[NCOMP + 4 % NCOMP] = max(r[NCOMP + 4 % NCOMP], k); } if (comp_end == 4) endv = del2; }
         ins = max(ins1, ins2);
         del = max(del1, del2);
       }
@@ -250,23 +327,30 @@ __device__ __forceinline__ int bl_side_step(BlSide<NCOMP, OT>& sd, const BiView<
         mv += view.run(v, mv, min(plen - v, tlen - mv));
         r[2 * NCOMP] = max(r[2 * NCOMP], 2 * mv - k);
       }
-      bl_st<OT>(wsw, o_m + k, mv);
+      if (comp_end == 0) endv = mv;
+      if (k == ak) r[2 * NCOMP + 1] = endv;
+      bl_st(wsw, o_m + km, mv);
     };
-    for (int k = lo + tid; k <= hi; k += 2 * THREADS) {
-      Cell c0, c1;
-      const bool two = (k + THREADS <= hi);
-      load(k, c0);
-      if (two) load(k + THREADS, c1);
-      finish(k, c0);
-      if (two) finish(k + THREADS, c1);
+    // (the workspace form: four chunks of loads in flight per thread — a step is one round trip to the rows however wide the wavefront)
+    constexpr int FLY = LDSR ? 2 : WFA_BL_FLY;
+    for (int k = lo + tid; k <= hi; k += FLY * THREADS) {
+      Cell c[FLY];
+#pragma unroll
+      for (int j = 0; j < FLY; ++j) if (j == 0 || k + j * THREADS <= hi) load(k + j * THREADS, c[j]);
+#pragma unroll
+      for (int j = 0; j < FLY; ++j) if (j == 0 || k + j * THREADS <= hi) finish(k + j * THREADS, c[j]);
     }
-    bl_reduce<THREADS, 2 * NCOMP + 1>(r, (((1u << NCOMP) - 1) << NCOMP) | (1u << (2 * NCOMP)), red, tid);
+    bl_reduce<THREADS, 2 * NCOMP + 2>(r, (((1u << NCOMP) - 1) << NCOMP) | (3u << (2 * NCOMP)), red, phase, tid);
 #pragma unroll
     for (int c = 0; c < NCOMP; ++c) {
       const bool has = (c == 0) || (c == 1 && has_i1) || (c == 2 && has_d1) || (NCOMP == 5 && c == 3 && has_i2) || (NCOMP == 5 && c == 4 && has_d2);
       if (has && r[c] != INT_MAX) { tlo[c] = r[c]; thi[c] = r[NCOMP + c]; }
     }
     best = r[2 * NCOMP];
+    int elo = tlo[0], ehi = thi[0];
+#pragma unroll
+    for (int c = 1; c < NCOMP; ++c) if (comp_end == c) { elo = tlo[c]; ehi = thi[c]; }
+    sd.end_reached = (elo <= ak && ak <= ehi && r[2 * NCOMP + 1] >= tlen) ? 1 : 0;
     sd.cur_exists = 1; sd.cur_lo = tlo[0]; sd.cur_hi = thi[0]; sd.cur_idx0 = o_m;
   }
   __syncthreads();   // every thread has read the inputs' directory records before the slot of score s is overwritten
@@ -281,30 +365,31 @@ __device__ __forceinline__ int bl_side_step(BlSide<NCOMP, OT>& sd, const BiView<
 
 // R/wavefront_heuristic.c:509-567 on the extended M wavefront of score s (wf-adaptive :257-293, X-drop :297-383), the gap
 // wavefronts cut to the same limits (:161-172)
-template <int NCOMP, typename OT, int THREADS>
-__device__ __forceinline__ void bl_side_cutoff(BlSide<NCOMP, OT>& sd, const WfaDevConfig& cfg, int scope, int s, int plen, int tlen, int* red, int tid) {
+template <int NCOMP, typename OT, int THREADS, bool LDSR>
+__device__ __forceinline__ void bl_side_cutoff(BlSide<NCOMP, OT, LDSR>& sd, const WfaDevConfig& cfg, int scope, int s, int plen, int tlen, int* red, int& phase, int tid) {
   typedef Meta<NCOMP> MT;
   if (cfg.heuristic == 0 || !sd.cur_exists || sd.cur_lo > sd.cur_hi) return;
   --sd.steps_wait;
   const int cur_lo = sd.cur_lo, cur_hi = sd.cur_hi;
   int new_lo = cur_lo, new_hi = cur_hi;
-  const OT* ws = sd.ws;
+  const auto ws = sd.ws;
+  const int kmask = sd.kmask;
   if (cfg.heuristic == 1) {
     if (sd.steps_wait <= 0 && (cur_hi - cur_lo + 1) >= cfg.min_wf_len) {
       int dm[1] = {max(plen, tlen)};
       for (int k = cur_lo + tid; k <= cur_hi; k += THREADS) {
-        const int off = bl_ld<OT>(ws, sd.cur_idx0 + k);
+        const int off = bl_ld(ws, sd.cur_idx0 + (k & kmask));
         const int d = (off >= 0) ? max(plen - (off - k), tlen - off) : -WFA_OFFSET_NULL;
         dm[0] = min(dm[0], d);
       }
-      bl_reduce<THREADS, 1>(dm, 0u, red, tid);
+      bl_reduce<THREADS, 1>(dm, 0u, red, phase, tid);
       int lh[2] = {INT_MAX, INT_MIN};
       for (int k = cur_lo + tid; k <= cur_hi; k += THREADS) {
-        const int off = bl_ld<OT>(ws, sd.cur_idx0 + k);
+        const int off = bl_ld(ws, sd.cur_idx0 + (k & kmask));
         const int d = (off >= 0) ? max(plen - (off - k), tlen - off) : -WFA_OFFSET_NULL;
         if (d - dm[0] <= cfg.max_dist_thr) { lh[0] = min(lh[0], k); lh[1] = max(lh[1], k); }
       }
-      bl_reduce<THREADS, 2>(lh, 2u, red, tid);
+      bl_reduce<THREADS, 2>(lh, 2u, red, phase, tid);
       const int ak = tlen - plen;
       const int top_limit = min(ak, cur_hi);
       if (top_limit > cur_lo) new_lo = min(lh[0], top_limit);
@@ -317,13 +402,13 @@ __device__ __forceinline__ void bl_side_cutoff(BlSide<NCOMP, OT>& sd, const WfaD
       const int g = (cfg.match != 0) ? -cfg.match : -1;  // R/wavefront_heuristic.c:306-307
       int v[3] = {INT_MIN, INT_MAX, INT_MIN};   // cmax, lc, hc
       for (int k = cur_lo + tid; k <= cur_hi; k += THREADS) {
-        const int off = bl_ld<OT>(ws, sd.cur_idx0 + k);
+        const int off = bl_ld(ws, sd.cur_idx0 + (k & kmask));
         if (off < 0) continue;
         const int sw = (g * ((off - k) + off) - s) / 2;
         v[0] = max(v[0], sw);
         if (sd.have_max_sw && sd.max_sw - sw < cfg.xdrop) { v[1] = min(v[1], k); v[2] = max(v[2], k); }
       }
-      bl_reduce<THREADS, 3>(v, 5u, red, tid);
+      bl_reduce<THREADS, 3>(v, 5u, red, phase, tid);
       if (sd.have_max_sw) {
         if (v[1] == INT_MAX) { new_lo = cur_hi + 1; new_hi = cur_hi; }
         else { new_lo = v[1]; new_hi = v[2]; }
@@ -351,21 +436,21 @@ __device__ __forceinline__ void bl_side_cutoff(BlSide<NCOMP, OT>& sd, const WfaD
   }
 }
 
-// R/wavefront_termination.c:37-113 (evaluated only when M[s] exists)
-template <int NCOMP, typename OT>
-__device__ __forceinline__ bool bl_side_terminated(const BlSide<NCOMP, OT>& sd, int scope, int s, int comp_end, int plen, int tlen) {
+// R/wavefront_termination.c:37-113 for wavefront 0 (evaluated only when M[s] exists)
+template <int NCOMP, typename OT, bool LDSR>
+__device__ __forceinline__ bool bl_side_terminated(const BlSide<NCOMP, OT, LDSR>& sd, int scope, int s, int comp_end, int plen, int tlen) {
   typedef Meta<NCOMP> MT;
   if (!sd.cur_exists) return false;
   const int* m = sd.ring + (s % scope) * MT::INTS;
   const int ak = tlen - plen;
   if (m[MT::LO + comp_end] > ak || ak > m[MT::HI + comp_end]) return false;
-  return bl_ld<OT>(sd.ws, (long long)m[MT::DATA] + comp_end * m[MT::WIDTH] + (ak - m[MT::BASE])) >= tlen;
+  return bl_ld(sd.ws, (long long)m[MT::DATA] + comp_end * m[MT::WIDTH] - m[MT::BASE] + (ak & sd.kmask)) >= tlen;
 }
 
 // R/wavefront_bialign.c:189-311 over the workgroup: the lowest diagonal of aligner 0 on which the two offsets meet wins.
 // hitbuf: NW * 4 ints of LDS.
-template <int NCOMP, typename OT, int THREADS>
-__device__ __forceinline__ void bl_breakpoint_cc(const BlSide<NCOMP, OT>& s0, const BlSide<NCOMP, OT>& s1, const int* m0, const int* m1,
+template <int NCOMP, typename OT, int THREADS, bool LDSR>
+__device__ __forceinline__ void bl_breakpoint_cc(const BlSide<NCOMP, OT, LDSR>& s0, const BlSide<NCOMP, OT, LDSR>& s1, const int* m0, const int* m1,
                                                  const WfaDevConfig& cfg, bool forward, int score_0, int score_1, int c,
                                                  int plen, int tlen, BiBreakpoint& bp, int* hitbuf, int tid) {
   typedef Meta<NCOMP> MT;
@@ -376,13 +461,14 @@ __device__ __forceinline__ void bl_breakpoint_cc(const BlSide<NCOMP, OT>& s0, co
   if (score_0 + score_1 - gap_open >= bp.score) return;
   const int min_hi = min(hi_0, hi_1), max_lo = max(lo_0, lo_1);
   const long long i0 = (long long)m0[MT::DATA] + c * m0[MT::WIDTH] - m0[MT::BASE], i1 = (long long)m1[MT::DATA] + c * m1[MT::WIDTH] - m1[MT::BASE];
+  const int kmask = s0.kmask;
   for (int kb = max_lo; kb <= min_hi; kb += THREADS) {
     const int k_0 = kb + tid;
     bool hit = false;
     int o0 = 0, o1 = 0;
     if (k_0 <= min_hi) {
       const int k_1 = tlen - plen - k_0;
-      o0 = bl_ld<OT>(s0.ws, i0 + k_0); o1 = bl_ld<OT>(s1.ws, i1 + k_1);
+      o0 = bl_ld(s0.ws, i0 + (k_0 & kmask)); o1 = bl_ld(s1.ws, i1 + (k_1 & kmask));
       hit = (long long)o0 + o1 >= tlen;
       if (hit && c != 0) {   // interior I/D offsets may lie outside the matrix (they are not clamped): skipped (:222-226,236-240)
         const int kk = forward ? k_0 : k_1, oo = forward ? o0 : o1;
@@ -424,8 +510,8 @@ __device__ __forceinline__ void bl_breakpoint_cc(const BlSide<NCOMP, OT>& s0, co
 }
 
 // R/wavefront_bialign.c:315-395 (wavefront_bialign_overlap)
-template <int NCOMP, typename OT, int THREADS>
-__device__ __forceinline__ void bl_overlap(const BlSide<NCOMP, OT>& s0, const BlSide<NCOMP, OT>& s1, const WfaDevConfig& cfg, int scope,
+template <int NCOMP, typename OT, int THREADS, bool LDSR>
+__device__ __forceinline__ void bl_overlap(const BlSide<NCOMP, OT, LDSR>& s0, const BlSide<NCOMP, OT, LDSR>& s1, const WfaDevConfig& cfg, int scope,
                                            int score_0, int score_1, bool forward, int plen, int tlen, BiBreakpoint& bp, int* hitbuf, int tid) {
   typedef Meta<NCOMP> MT;
   const int* m0 = s0.ring + (score_0 % scope) * MT::INTS;
@@ -436,16 +522,16 @@ __device__ __forceinline__ void bl_overlap(const BlSide<NCOMP, OT>& s0, const Bl
     const int* m1 = s1.ring + (score_i % scope) * MT::INTS;
     if (NCOMP == 5) {
       if (score_0 + score_i - cfg.o2 >= bp.score) continue;
-      bl_breakpoint_cc<NCOMP, OT, THREADS>(s0, s1, m0, m1, cfg, forward, score_0, score_i, 4, plen, tlen, bp, hitbuf, tid);
-      bl_breakpoint_cc<NCOMP, OT, THREADS>(s0, s1, m0, m1, cfg, forward, score_0, score_i, 3, plen, tlen, bp, hitbuf, tid);
+      bl_breakpoint_cc<NCOMP, OT, THREADS, LDSR>(s0, s1, m0, m1, cfg, forward, score_0, score_i, 4, plen, tlen, bp, hitbuf, tid);
+      bl_breakpoint_cc<NCOMP, OT, THREADS, LDSR>(s0, s1, m0, m1, cfg, forward, score_0, score_i, 3, plen, tlen, bp, hitbuf, tid);
     }
     if (NCOMP >= 3) {
       if (score_0 + score_i - cfg.o1 >= bp.score) continue;
-      bl_breakpoint_cc<NCOMP, OT, THREADS>(s0, s1, m0, m1, cfg, forward, score_0, score_i, 2, plen, tlen, bp, hitbuf, tid);
-      bl_breakpoint_cc<NCOMP, OT, THREADS>(s0, s1, m0, m1, cfg, forward, score_0, score_i, 1, plen, tlen, bp, hitbuf, tid);
+      bl_breakpoint_cc<NCOMP, OT, THREADS, LDSR>(s0, s1, m0, m1, cfg, forward, score_0, score_i, 2, plen, tlen, bp, hitbuf, tid);
+      bl_breakpoint_cc<NCOMP, OT, THREADS, LDSR>(s0, s1, m0, m1, cfg, forward, score_0, score_i, 1, plen, tlen, bp, hitbuf, tid);
     }
     if (score_0 + score_i >= bp.score) continue;
-    if (m1[MT::EXISTS]) bl_breakpoint_cc<NCOMP, OT, THREADS>(s0, s1, m0, m1, cfg, forward, score_0, score_i, 0, plen, tlen, bp, hitbuf, tid);
+    if (m1[MT::EXISTS]) bl_breakpoint_cc<NCOMP, OT, THREADS, LDSR>(s0, s1, m0, m1, cfg, forward, score_0, score_i, 0, plen, tlen, bp, hitbuf, tid);
   }
 }
 
@@ -523,107 +609,159 @@ __global__ void __launch_bounds__(256) bl_seed_kernel(const BlArgs a) {
   }
 }
 
-template <int NCOMP, bool PACKED, typename OT, int THREADS>
-__global__ void __launch_bounds__(THREADS)
+template <int NCOMP, bool PACKED, typename OT, int THREADS, bool LDSR, bool SEQL>
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 1024 ? 4 : 5)))   // (<= 96 registers: five waves per SIMD)
 bl_split_kernel(const BlArgs a) {
   typedef Meta<NCOMP> MT;
+  typedef typename BlPtr<OT, LDSR>::type P;
+  typedef typename BlPtr<const uint32_t, SEQL>::type WP;
+  typedef BlView<PACKED, SEQL> View;
+  static_assert(!LDSR || SEQL, "rows in LDS: the sequences too");
+  static_assert(!SEQL || PACKED, "sequences in LDS: 2-bit pairs");
   extern __shared__ int smem[];
   const WfaDevConfig& cfg = a.k.cfg;
   const int scope = cfg.scope;
   const int tid = threadIdx.x;
   int* const ring_f = smem;
   int* const ring_r = ring_f + scope * MT::INTS;
-  int* const red = ring_r + scope * MT::INTS;          // (THREADS / 64) * 16
-  int* const hitbuf = red + (THREADS / 64) * 16;       // (THREADS / 64) * 4
-  OT* const wsb = reinterpret_cast<OT*>(reinterpret_cast<char*>(a.rings) + (long long)blockIdx.x * a.slice_bytes);
-  const uint32_t nwork = min(a.cnt[a.level], a.qcap);
-  const BlWindow* const q = a.q[a.level & 1];
-  const long long max_steps = cfg.max_steps;
+  int* const red = ring_r + scope * MT::INTS;          // three buffers of 32 (bl_reduce)
+  int* const hitbuf = red + 96;                        // (THREADS / 64) * 4, then the window index
   int* const next_wi = hitbuf + (THREADS / 64) * 4;
+  // LDSR: the two sequences' words and the rows of both aligners behind it
+  int* const lds_seq = next_wi + 8;
+  const int row_elems = a.lds_slots * NCOMP * a.lds_w;
+  OT* const wsb = LDSR ? nullptr : reinterpret_cast<OT*>(reinterpret_cast<char*>(a.rings) + (long long)blockIdx.x * a.slice_bytes);
+  const int cnt_word = a.from_wide ? 128 + a.level : a.level;
+  const uint32_t nwork = min(a.cnt[cnt_word], a.from_wide ? a.qwcap : a.qcap);
+  const BlWindow* const q = a.from_wide ? a.qw : a.q[a.level & 1];
+  const long long max_steps = cfg.max_steps;
+  int phase = 0;
+  bl_reduce_init(red, tid);
 
   for (;;) {
     // windows differ in cost by orders of magnitude: taken one at a time from the level's counter
     __syncthreads();
-    if (tid == 0) next_wi[0] = (int)atomicAdd(a.cnt + 64 + a.level, 1u);
+    if (tid == 0) next_wi[0] = (int)atomicAdd(a.cnt + cnt_word + 64, 1u);
     __syncthreads();
     const uint32_t wi = (uint32_t)next_wi[0];
     if (wi >= nwork) break;
     const BlWindow w = q[wi];
     const uint32_t pair = (uint32_t)w.pair;
     const WfaPairMeta pm = a.k.meta[pair];
-    BiView<PACKED> view;
-    view.wildcard = cfg.wildcard;
-    if (PACKED) { view.pw = a.k.words + pm.p_woff; view.tw = a.k.words + pm.t_woff; view.pb = nullptr; view.tb = nullptr; }
-    else { view.pb = a.k.bytes + a.k.p_boff[pair]; view.tb = a.k.bytes + a.k.t_boff[pair]; view.pw = nullptr; view.tw = nullptr; }
     const int pbeg = w.pbeg, pend = w.pend, tbeg = w.tbeg, tend = w.tend;
     const int comp_begin = w.flags & 15, comp_end = (w.flags >> 4) & 15;
     const bool level0 = (w.flags >> 8) & 1;
     const int plen = pend - pbeg, tlen = tend - tbeg;
+    bool overflow = false;
+    View view;
+    view.wildcard = cfg.wildcard;
+    view.pb = nullptr; view.tb = nullptr; view.pw = nullptr; view.tw = nullptr;
+    if (SEQL) {
+      // the words the window's probes can touch (one word before its first base: the backward probes; two behind its last)
+      const uint32_t* gP = a.k.words + pm.p_woff; const uint32_t* gT = a.k.words + pm.t_woff;
+      const int nwp = (pm.plen + 15) >> 4, nwt = (pm.tlen + 15) >> 4;
+      const int p0 = max(0, (pbeg >> 4) - 1), p1 = ((pend + 15) >> 4) + 2;
+      const int t0 = max(0, (tbeg >> 4) - 1), t1 = ((tend + 15) >> 4) + 2;
+      if (p1 - p0 > a.lds_seq_words || t1 - t0 > a.lds_seq_words) overflow = true;
+      else {
+        uint32_t* sP = reinterpret_cast<uint32_t*>(lds_seq); uint32_t* sT = sP + a.lds_seq_words;
+        for (int i = p0 + tid; i < p1; i += THREADS) sP[i - p0] = (i < nwp) ? gP[i] : 0u;
+        for (int i = t0 + tid; i < t1; i += THREADS) sT[i - t0] = (i < nwt) ? gT[i] : 0u;
+        view.pw = (WP)sP - p0; view.tw = (WP)sT - t0;
+      }
+    } else if (PACKED) {
+      view.pw = (WP)(a.k.words + pm.p_woff); view.tw = (WP)(a.k.words + pm.t_woff);
+    } else {
+      view.pb = a.k.bytes + a.k.p_boff[pair]; view.tb = a.k.bytes + a.k.t_boff[pair];
+    }
     view.pbeg = pbeg; view.pend = pend; view.tbeg = tbeg; view.tend = tend; view.reverse = false;
-    BiView<PACKED> rview = view; rview.reverse = true;
-    BlSide<NCOMP, OT> F, R;
-    const int stride = min(a.ring_stride, (plen + tlen + 3 + 1) & ~1);
-    F.ring = ring_f; F.ws = wsb; F.stride = stride;
-    R.ring = ring_r; R.ws = wsb + a.ring_elems; R.stride = stride;
+    View rview = view; rview.reverse = true;
+    BlSide<NCOMP, OT, LDSR> F, R;
+    F.ring = ring_f; R.ring = ring_r;
+    F.lds_slots = R.lds_slots = a.lds_slots;
+    if (LDSR) {
+      OT* rows = reinterpret_cast<OT*>(lds_seq + 2 * a.lds_seq_words);
+      F.ws = (P)rows; R.ws = (P)(rows + row_elems);
+      F.stride = R.stride = a.lds_w;
+    } else {
+      const int stride = min(a.ring_stride, (plen + tlen + 3 + 1) & ~1);
+      F.ws = (P)wsb; R.ws = (P)(wsb + a.ring_elems);
+      F.stride = R.stride = stride;
+    }
     BiBreakpoint bp;
     bp.score = INT_MAX; bp.score_forward = 0; bp.score_reverse = 0; bp.k_forward = 0; bp.k_reverse = 0;
     bp.offset_forward = 0; bp.offset_reverse = 0; bp.component = 0;
     // ---------------- R/wavefront_bialign.c:411-519 (wavefront_bialign_find_breakpoint) ----------------
     int st = WFA_BI_OK, reached = 0;
-    bl_side_init<NCOMP, OT>(F, scope, comp_begin, plen, tlen, tid);
-    bl_side_init<NCOMP, OT>(R, scope, comp_end, plen, tlen, tid);
-    F.steps_wait = R.steps_wait = cfg.steps_between;   // (R/wavefront_heuristic.c:114-121)
-    const int max_antidiagonal = plen + tlen - 1;
-    int score_f = 0, score_r = 0;
-    // what follows the extension of a wavefront: end test, cut-off; true when that aligner is done
-    auto after = [&](BlSide<NCOMP, OT>& sd, int s, int cend, int best, int* max_ak) -> bool {
-      if (!sd.cur_exists) {
-        *max_ak = 0;
-        if (sd.null_steps > scope) { st = WFA_BI_END_UNREACHABLE; reached = s; return true; }
-        return false;
-      }
-      if (bl_side_terminated<NCOMP, OT>(sd, scope, s, cend, plen, tlen)) { st = WFA_BI_END_REACHED; reached = s; *max_ak = 0; return true; }
-      bl_side_cutoff<NCOMP, OT, THREADS>(sd, cfg, scope, s, plen, tlen, red, tid);
-      *max_ak = best;
-      return false;
-    };
-    int f_max_ak = 0, r_max_ak = 0, max_ak = 0;
-    bool quit = after(F, 0, comp_end, bl_side_extend0<NCOMP, PACKED, OT, THREADS>(F, view, plen, tlen, red, tid), &f_max_ak);
-    if (!quit) quit = after(R, 0, comp_begin, bl_side_extend0<NCOMP, PACKED, OT, THREADS>(R, rview, plen, tlen, red, tid), &r_max_ak);
-    bool last_forward = false;
-    while (!quit) {
-      if (f_max_ak + r_max_ak >= max_antidiagonal) break;
-      ++score_f;
-      quit = after(F, score_f, comp_end, bl_side_step<NCOMP, PACKED, OT, THREADS>(F, view, cfg, scope, score_f, plen, tlen, red, tid), &max_ak);
-      if (f_max_ak < max_ak) f_max_ak = max_ak;
-      last_forward = true;
-      if (quit) break;
-      if (f_max_ak + r_max_ak >= max_antidiagonal) break;
-      ++score_r;
-      quit = after(R, score_r, comp_begin, bl_side_step<NCOMP, PACKED, OT, THREADS>(R, rview, cfg, scope, score_r, plen, tlen, red, tid), &max_ak);
-      if (r_max_ak < max_ak) r_max_ak = max_ak;
-      last_forward = false;
-      if (quit) break;
-      if ((long long)score_r + score_f >= max_steps) { st = WFA_STATUS_MAX_STEPS_REACHED; quit = true; }
-    }
-    if (!quit) {
-      const int gap_opening = (NCOMP == 3) ? cfg.o1 : (NCOMP == 5) ? max(cfg.o1, cfg.o2) : 0;
-      while (true) {
-        if (last_forward) {
-          const int min_score_reverse = (score_r > scope - 1) ? score_r - (scope - 1) : 0;
-          if (score_f + min_score_reverse - gap_opening >= bp.score) break;
-          bl_overlap<NCOMP, OT, THREADS>(F, R, cfg, scope, score_f, score_r, true, plen, tlen, bp, hitbuf, tid);
-          ++score_r;
-          if (after(R, score_r, comp_begin, bl_side_step<NCOMP, PACKED, OT, THREADS>(R, rview, cfg, scope, score_r, plen, tlen, red, tid), &max_ak)) { quit = true; break; }
+    bool quit = false;
+    if (!overflow) {
+      bl_side_init<NCOMP, OT, LDSR>(F, scope, comp_begin, plen, tlen, tid);
+      bl_side_init<NCOMP, OT, LDSR>(R, scope, comp_end, plen, tlen, tid);
+      F.steps_wait = R.steps_wait = cfg.steps_between;   // (R/wavefront_heuristic.c:114-121)
+      const int max_antidiagonal = plen + tlen - 1;
+      int score_f = 0, score_r = 0;
+      // what follows the extension of a wavefront: end test, cut-off; true when that aligner is done
+      auto after = [&](BlSide<NCOMP, OT, LDSR>& sd, int s, int cend, int best, int* max_ak) -> bool {
+        if (best < 0) { overflow = true; return true; }
+        if (!sd.cur_exists) {
+          *max_ak = 0;
+          if (sd.null_steps > scope) { st = WFA_BI_END_UNREACHABLE; reached = s; return true; }
+          return false;
         }
-        const int min_score_forward = (score_f > scope - 1) ? score_f - (scope - 1) : 0;
-        if (min_score_forward + score_r - gap_opening >= bp.score) break;
-        bl_overlap<NCOMP, OT, THREADS>(R, F, cfg, scope, score_r, score_f, false, plen, tlen, bp, hitbuf, tid);
+        const bool ended = (s == 0) ? bl_side_terminated<NCOMP, OT, LDSR>(sd, scope, s, cend, plen, tlen) : (sd.end_reached != 0);
+        if (ended) { st = WFA_BI_END_REACHED; reached = s; *max_ak = 0; return true; }
+        bl_side_cutoff<NCOMP, OT, THREADS, LDSR>(sd, cfg, scope, s, plen, tlen, red, phase, tid);
+        *max_ak = best;
+        return false;
+      };
+      auto stepF = [&]() -> int { return bl_side_step<NCOMP, OT, THREADS, LDSR, View>(F, view, cfg, scope, score_f, comp_end, plen, tlen, red, phase, tid); };
+      auto stepR = [&]() -> int { return bl_side_step<NCOMP, OT, THREADS, LDSR, View>(R, rview, cfg, scope, score_r, comp_begin, plen, tlen, red, phase, tid); };
+      int f_max_ak = 0, r_max_ak = 0, max_ak = 0;
+      quit = after(F, 0, comp_end, bl_side_extend0<NCOMP, OT, THREADS, LDSR, View>(F, view, plen, tlen, red, phase, tid), &f_max_ak);
+      if (!quit) quit = after(R, 0, comp_begin, bl_side_extend0<NCOMP, OT, THREADS, LDSR, View>(R, rview, plen, tlen, red, phase, tid), &r_max_ak);
+      bool last_forward = false;
+      while (!quit) {
+        if (f_max_ak + r_max_ak >= max_antidiagonal) break;
         ++score_f;
-        if (after(F, score_f, comp_end, bl_side_step<NCOMP, PACKED, OT, THREADS>(F, view, cfg, scope, score_f, plen, tlen, red, tid), &max_ak)) { quit = true; break; }
-        if ((long long)score_r + score_f >= max_steps) { st = WFA_STATUS_MAX_STEPS_REACHED; quit = true; break; }
+        quit = after(F, score_f, comp_end, stepF(), &max_ak);
+        if (f_max_ak < max_ak) f_max_ak = max_ak;
         last_forward = true;
+        if (quit) break;
+        if (f_max_ak + r_max_ak >= max_antidiagonal) break;
+        ++score_r;
+        quit = after(R, score_r, comp_begin, stepR(), &max_ak);
+        if (r_max_ak < max_ak) r_max_ak = max_ak;
+        last_forward = false;
+        if (quit) break;
+        if ((long long)score_r + score_f >= max_steps) { st = WFA_STATUS_MAX_STEPS_REACHED; quit = true; }
       }
+      if (!quit) {
+        const int gap_opening = (NCOMP == 3) ? cfg.o1 : (NCOMP == 5) ? max(cfg.o1, cfg.o2) : 0;
+        while (true) {
+          if (last_forward) {
+            const int min_score_reverse = (score_r > scope - 1) ? score_r - (scope - 1) : 0;
+            if (score_f + min_score_reverse - gap_opening >= bp.score) break;
+            bl_overlap<NCOMP, OT, THREADS, LDSR>(F, R, cfg, scope, score_f, score_r, true, plen, tlen, bp, hitbuf, tid);
+            ++score_r;
+            if (after(R, score_r, comp_begin, stepR(), &max_ak)) { quit = true; break; }
+          }
+          const int min_score_forward = (score_f > scope - 1) ? score_f - (scope - 1) : 0;
+          if (min_score_forward + score_r - gap_opening >= bp.score) break;
+          bl_overlap<NCOMP, OT, THREADS, LDSR>(R, F, cfg, scope, score_r, score_f, false, plen, tlen, bp, hitbuf, tid);
+          ++score_f;
+          if (after(F, score_f, comp_end, stepF(), &max_ak)) { quit = true; break; }
+          if ((long long)score_r + score_f >= max_steps) { st = WFA_STATUS_MAX_STEPS_REACHED; quit = true; break; }
+          last_forward = true;
+        }
+      }
+    }
+    if (overflow) {
+      // the LDS rows (or the sequence buffers) do not hold this window: the workspace form of the same level takes it
+      if (tid == 0) {
+        const uint32_t qi = atomicAdd(a.cnt + 128 + a.level, 1u);
+        if (qi >= a.qwcap) bl_flag(a, (int)pair, WFA_BL_FLAG_REDO); else a.qw[qi] = w;
+      }
+      continue;
     }
     if (quit) {
       // R/wavefront_bialign.c:520-548 (wavefront_bialign_find_breakpoint_exception)
@@ -805,9 +943,11 @@ bl_finish_kernel(const BlArgs a) {
 }
 
 // host entry points (csrc/k_bilevel.hip, one translation unit per component count)
-int launch_bl_split_c1(bool packed, bool i16, int threads, const BlArgs& a, int grid, size_t smem, hipStream_t stream);
-int launch_bl_split_c3(bool packed, bool i16, int threads, const BlArgs& a, int grid, size_t smem, hipStream_t stream);
-int launch_bl_split_c5(bool packed, bool i16, int threads, const BlArgs& a, int grid, size_t smem, hipStream_t stream);
+int launch_bl_split_c1(bool packed, bool i16, int threads, bool seql, const BlArgs& a, int grid, size_t smem, hipStream_t stream);
+int launch_bl_split_c3(bool packed, bool i16, int threads, bool seql, const BlArgs& a, int grid, size_t smem, hipStream_t stream);
+int launch_bl_split_c5(bool packed, bool i16, int threads, bool seql, const BlArgs& a, int grid, size_t smem, hipStream_t stream);
+int launch_bl_split_lds_c1(int threads, const BlArgs& a, int grid, size_t smem, hipStream_t stream);
+int launch_bl_split_lds_c3(int threads, const BlArgs& a, int grid, size_t smem, hipStream_t stream);
 int launch_bl_base_c1(bool packed, const BlArgs& a, int grid, size_t smem, hipStream_t stream);
 int launch_bl_base_c3(bool packed, const BlArgs& a, int grid, size_t smem, hipStream_t stream);
 int launch_bl_base_c5(bool packed, const BlArgs& a, int grid, size_t smem, hipStream_t stream);
@@ -815,15 +955,30 @@ int launch_bl_seed(const BlArgs& a, hipStream_t stream);
 int launch_bl_finish(const BlArgs& a, int grid, hipStream_t stream);
 
 template <int NCOMP>
-inline int launch_bl_split_ncomp(bool packed, bool i16, int threads, const BlArgs& a, int grid, size_t smem, hipStream_t stream) {
-#define WFA_BL_LAUNCH(P, OT, T) hipLaunchKernelGGL((bl_split_kernel<NCOMP, P, OT, T>), dim3(grid), dim3(T), smem, stream, a)
+inline int launch_bl_split_ncomp(bool packed, bool i16, int threads, bool seql, const BlArgs& a, int grid, size_t smem, hipStream_t stream) {
+#define WFA_BL_LAUNCH(P, OT, T, SQ) hipLaunchKernelGGL((bl_split_kernel<NCOMP, P, OT, T, false, SQ>), dim3(grid), dim3(T), smem, stream, a)
   if (threads == 256) {
-    if (packed) { if (i16) WFA_BL_LAUNCH(true, short, 256); else WFA_BL_LAUNCH(true, int, 256); }
-    else { if (i16) WFA_BL_LAUNCH(false, short, 256); else WFA_BL_LAUNCH(false, int, 256); }
+    if (packed && seql) { if (i16) WFA_BL_LAUNCH(true, short, 256, true); else WFA_BL_LAUNCH(true, int, 256, true); }
+    else if (packed) { if (i16) WFA_BL_LAUNCH(true, short, 256, false); else WFA_BL_LAUNCH(true, int, 256, false); }
+    else { if (i16) WFA_BL_LAUNCH(false, short, 256, false); else WFA_BL_LAUNCH(false, int, 256, false); }
   } else {
-    if (packed) { if (i16) WFA_BL_LAUNCH(true, short, 64); else WFA_BL_LAUNCH(true, int, 64); }
-    else { if (i16) WFA_BL_LAUNCH(false, short, 64); else WFA_BL_LAUNCH(false, int, 64); }
+    if (packed && seql) { if (i16) WFA_BL_LAUNCH(true, short, 64, true); else WFA_BL_LAUNCH(true, int, 64, true); }
+    else if (packed) { if (i16) WFA_BL_LAUNCH(true, short, 64, false); else WFA_BL_LAUNCH(true, int, 64, false); }
+    else { if (i16) WFA_BL_LAUNCH(false, short, 64, false); else WFA_BL_LAUNCH(false, int, 64, false); }
   }
+#undef WFA_BL_LAUNCH
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+// the LDS form: 2-bit pairs, int16 rows; 64 / 256 / 1024 threads
+template <int NCOMP>
+inline int launch_bl_split_lds_ncomp(int threads, const BlArgs& a, int grid, size_t smem, hipStream_t stream) {
+#define WFA_BL_LAUNCH(T) do { \
+    static bool attr_set = false; \
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bl_split_kernel<NCOMP, true, short, T, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; } \
+    hipLaunchKernelGGL((bl_split_kernel<NCOMP, true, short, T, true, true>), dim3(grid), dim3(T), smem, stream, a); } while (0)
+  if (threads == 1024) WFA_BL_LAUNCH(1024);
+  else if (threads == 256) WFA_BL_LAUNCH(256);
+  else WFA_BL_LAUNCH(64);
 #undef WFA_BL_LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -835,15 +990,24 @@ inline int launch_bl_base_ncomp(bool packed, const BlArgs& a, int grid, size_t s
 }
 
 inline size_t bl_split_smem(int ncomp, int scope, int threads) {
-  return ((size_t)2 * scope * (2 * ncomp + 4) + (size_t)(threads / 64) * 20 + 8) * sizeof(int);
+  return ((size_t)2 * scope * (2 * ncomp + 4) + 96 + (size_t)(threads / 64) * 4 + 16) * sizeof(int);
+}
+// the LDS form: + two sequence buffers + the rows of both aligners (int16)
+inline size_t bl_split_lds_smem(int ncomp, int scope, int threads, int w, int slots, int seq_words) {
+  return bl_split_smem(ncomp, scope, threads) + (size_t)2 * seq_words * 4 + (size_t)2 * slots * ncomp * w * 2;
 }
 inline size_t bl_base_smem(int ncomp, int scope) { return ((size_t)scope * (2 * ncomp + 4) + 8) * sizeof(int); }
 
-inline int launch_bl_split_any(int ncomp, bool packed, bool i16, int threads, const BlArgs& a, int grid, hipStream_t stream) {
-  const size_t smem = bl_split_smem(ncomp, a.k.cfg.scope, threads);
-  if (ncomp == 1) return launch_bl_split_c1(packed, i16, threads, a, grid, smem, stream);
-  if (ncomp == 3) return launch_bl_split_c3(packed, i16, threads, a, grid, smem, stream);
-  return launch_bl_split_c5(packed, i16, threads, a, grid, smem, stream);
+inline int launch_bl_split_any(int ncomp, bool packed, bool i16, int threads, bool seql, const BlArgs& a, int grid, hipStream_t stream) {
+  const size_t smem = bl_split_smem(ncomp, a.k.cfg.scope, threads) + (seql ? (size_t)2 * a.lds_seq_words * 4 : 0);
+  if (ncomp == 1) return launch_bl_split_c1(packed, i16, threads, seql, a, grid, smem, stream);
+  if (ncomp == 3) return launch_bl_split_c3(packed, i16, threads, seql, a, grid, smem, stream);
+  return launch_bl_split_c5(packed, i16, threads, seql, a, grid, smem, stream);
+}
+inline int launch_bl_split_lds_any(int ncomp, int threads, const BlArgs& a, int grid, hipStream_t stream) {
+  const size_t smem = bl_split_lds_smem(ncomp, a.k.cfg.scope, threads, a.lds_w, a.lds_slots, a.lds_seq_words);
+  if (ncomp == 1) return launch_bl_split_lds_c1(threads, a, grid, smem, stream);
+  return launch_bl_split_lds_c3(threads, a, grid, smem, stream);
 }
 inline int launch_bl_base_any(int ncomp, bool packed, const BlArgs& a, int grid, hipStream_t stream) {
   const size_t smem = bl_base_smem(ncomp, a.k.cfg.scope);

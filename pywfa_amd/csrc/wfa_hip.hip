@@ -45,7 +45,7 @@ static thread_local std::string g_error;
 // never call getenv.
 #define WFA_COUNTER_WORDS 64   // counters of a batch (wfa_hip_batch::d_counters)
 #define WFA_KNOBS(F)                                                                                              \
-  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(NO_TINY_INLINE) F(BILEVEL) F(BILEVEL_WIDE_LEVELS) F(BILEVEL_PER_CU) F(BILEVEL_I32) F(BILEVEL_QCAP) F(BILEVEL_LEVELS) F(LANE_DYN) F(LANE_DYN_WAVES) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
+  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(NO_TINY_INLINE) F(BILEVEL) F(BILEVEL_WIDE_LEVELS) F(BILEVEL_PER_CU) F(BILEVEL_I32) F(BILEVEL_QCAP) F(BILEVEL_LEVELS) F(BILEVEL_LDS) F(BILEVEL_LDS_W) F(BILEVEL_NO_SEQL) F(LANE_DYN) F(LANE_DYN_WAVES) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
   F(LANE_FULL) F(LANE_FULL_SPLIT) F(LANE_HEUR) F(SEG_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_ADAPT) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(TILE) F(TILE_T) F(TILE_WT) F(TILE_THREADS) F(TILE_PER_CU) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY) F(PILOT_PCT) F(WIDE_ADAPT_LDS)
@@ -1536,17 +1536,19 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
       la.ring_elems = ((int64_t)b->dcfg.scope * b->ncomp * la.ring_stride + 63) & ~63ll;
       la.base_stride = ba.base_stride; la.base_ints = ba.base_ints;
       la.slice_bytes = (std::max<int64_t>(2 * la.ring_elems * esz, ba.base_ints * 4) + 255) & ~255ll;
-      bl_grid = al->cu_count * std::max(1, knob(al, K_BILEVEL_PER_CU, 16));
+      bl_grid = al->cu_count * std::max(1, knob(al, K_BILEVEL_PER_CU, 32));
+      // (a slice is megabytes: no more of them than the batch can keep busy — a few windows per pair are in flight at the deep levels)
+      bl_grid = (int)std::min<int64_t>(bl_grid, std::max<int64_t>(al->cu_count, 8 * (int64_t)std::max<int64_t>(b->n_packed, b->n_bytes)));
       // windows a pair can be in at once: about two per 250 of score; queues sized from the longest pair, what overflows is redone
       const int64_t per_pair = std::min<int64_t>(1024, std::max<int64_t>(4, b->max_width / 96));
       const int64_t nmax = std::max<int64_t>(b->n_packed, b->n_bytes);
       const int64_t qcap = knob(al, K_BILEVEL_QCAP, 0) > 0 ? knob(al, K_BILEVEL_QCAP, 0) : std::min<int64_t>(nmax * per_pair + 1024, (int64_t)1 << 28);   // (the knob: tests of the redo path)
-      const int64_t meta_bytes = qcap * 32 * 4 + (int64_t)b->n * (4 + 4 + 4 + 8 + 4) + WFA_BL_COUNTER_WORDS * 4 + 4096;
+      const int64_t meta_bytes = qcap * 32 * 5 + (int64_t)b->n * (4 + 4 + 4 + 8 + 4) + WFA_BL_COUNTER_WORDS * 4 + 4096;
       // the depth-first kernel behind it: a few slices (its int32 rings are the large ones)
       grid = std::min<int64_t>(grid, al->cu_count);
       while (bl_grid > al->cu_count && (int64_t)bl_grid * la.slice_bytes + meta_bytes + grid * stride * 4 > budget) bl_grid /= 2;
       while (grid > 1 && (int64_t)bl_grid * la.slice_bytes + meta_bytes + grid * stride * 4 > budget) grid = (grid + 1) / 2;
-      la.qcap = la.qbcap = la.leafcap = (uint32_t)qcap;
+      la.qcap = la.qbcap = la.leafcap = la.qwcap = (uint32_t)qcap;
       bl_bytes = (size_t)((int64_t)bl_grid * la.slice_bytes + meta_bytes);
       dfs_off = (int64_t)((bl_bytes + 255) & ~(size_t)255);
       // levels: a window's score halves per level (to within the ring's scope) until it is <= 250
@@ -1569,6 +1571,7 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
       la.q[0] = reinterpret_cast<wfa::BlWindow*>(p); p += (int64_t)la.qcap * 32;
       la.q[1] = reinterpret_cast<wfa::BlWindow*>(p); p += (int64_t)la.qcap * 32;
       la.qb = reinterpret_cast<wfa::BlWindow*>(p); p += (int64_t)la.qcap * 32;
+      la.qw = reinterpret_cast<wfa::BlWindow*>(p); p += (int64_t)la.qcap * 32;
       la.leaves = reinterpret_cast<wfa::BlLeaf*>(p); p += (int64_t)la.qcap * 32;
       la.failkey = reinterpret_cast<unsigned long long*>(p); p += (int64_t)b->n * 8;
       la.head = reinterpret_cast<int*>(p); p += (int64_t)b->n * 4;
@@ -1594,13 +1597,42 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
         // four waves per window while the wavefronts are expected to span several chunks (about max_len / 8 diagonals at the top
         // level for reads at 8 - 10 %, half of it per level)
         int wide_auto = 0;
-        while (wide_auto < 8 && ((b->max_len / 8) >> wide_auto) >= 256) ++wide_auto;
+        while (wide_auto < 8 && ((b->max_len / 8) >> wide_auto) >= 512) ++wide_auto;   // (10 kb: two levels, measured best of 0 / 2 / 3)
         const int wide_levels = knob(al, K_BILEVEL_WIDE_LEVELS, wide_auto);
+        // Per level: the LDS form first where it pays (2-bit pairs, int16 offsets, gap-affine and the one-component metrics): both
+        // aligners' rows and the window's sub-sequences in LDS, W diagonals per row — W halves per level as the windows' scores do;
+        // used where at least two windows fit a CU (W <= 1024 for gap-affine 4/6/2).  A window whose wavefront outgrows W (or whose
+        // sub-sequences outgrow the buffers) moves to the level's second launch, the workspace form: rows in HBM / L2, the pair's
+        // sequences in LDS when they fit, four chunks of loads in flight per thread.
+        const bool lds_form = kind == 0 && bl_i16 && b->ncomp <= 3 && knob(al, K_BILEVEL_LDS, 0) != 0;   // (off: measured slower than the workspace form at every level of 1 kb and 10 kb reads — per-step overheads, not the rows' latency, are what a narrow window pays)
+        const int gsc = std::max(1, wfa::band_gcd(b->dcfg, false));
+        la.lds_slots = (b->dcfg.scope - 1) / gsc + 1;
+        const int full_seq_words = (b->max_len + 15) / 16 + 4;
+        const bool seql = kind == 0 && (size_t)2 * full_seq_words * 4 <= (size_t)48 * 1024 && knob(al, K_BILEVEL_NO_SEQL, 0) == 0;
+        const int lds_w_max = knob(al, K_BILEVEL_LDS_W, 1024);
         for (int lv = 0; lv < bl_levels && ok; ++lv) {
           la.level = lv;
+          la.from_wide = 0;
+          // expected width of a level's wavefronts: a quarter of the window's length at 8 - 10 % error; rows of 1.3 x that, a power of two
+          int w = 128;
+          while (w < 8192 && w < (int)((((int64_t)b->max_len * 13 / 40) >> lv))) w *= 2;
+          if (lds_form && w <= lds_w_max) {
+            la.lds_seq_words = std::min(full_seq_words, (int)(((int64_t)b->max_len * 3 / 2) >> lv) / 16 + 12);
+            const int lthreads = (w >= 2048) ? 1024 : (w >= 512) ? 256 : 64;
+            const size_t lsm = wfa::bl_split_lds_smem(b->ncomp, b->dcfg.scope, lthreads, w, la.lds_slots, la.lds_seq_words);
+            if (lsm <= (size_t)156 * 1024) {
+              la.lds_w = w;
+              const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / (lsm + 512), (size_t)(2048 / lthreads)));
+              const int64_t lgrid = (int64_t)al->cu_count * per_cu;
+              ok = wfa::launch_bl_split_lds_any(b->ncomp, lthreads, la, (int)std::min<int64_t>(lgrid, lv == 0 ? (int64_t)cnt : lgrid), stream) == 0;
+              la.from_wide = 1;
+            }
+          }
           const int threads = (lv < wide_levels) ? 256 : 64;
           const int lgrid = (threads == 256) ? std::max(al->cu_count, bl_grid / 2) : bl_grid;
-          ok = wfa::launch_bl_split_any(b->ncomp, kind == 0, bl_i16, threads, la, (int)std::min<int64_t>(lgrid, lv == 0 ? (int64_t)cnt : (int64_t)lgrid), stream) == 0;
+          la.lds_seq_words = full_seq_words;
+          ok = ok && wfa::launch_bl_split_any(b->ncomp, kind == 0, bl_i16, threads, seql, la, (int)std::min<int64_t>(lgrid, lv == 0 ? (int64_t)cnt : (int64_t)lgrid), stream) == 0;
+          la.from_wide = 0;
           mark();
         }
         ok = ok && wfa::launch_bl_base_any(b->ncomp, kind == 0, la, bl_grid, stream) == 0;
@@ -1617,7 +1649,7 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
           uint32_t hc[WFA_BL_COUNTER_WORDS];
           (void)hipMemcpy(hc, la.cnt, sizeof(hc), hipMemcpyDeviceToHost);
           fprintf(stderr, "[wfa_hip] biwfa levels (%s, %d pairs, grid %d, slice %.2f MB, %s rings):", kind ? "bytes" : "2-bit", (int)cnt, bl_grid, la.slice_bytes / 1048576.0, bl_i16 ? "int16" : "int32");
-          for (int lv = 0; lv < bl_levels; ++lv) { float ms = 0; (void)hipEventElapsedTime(&ms, tev[lv], tev[lv + 1]); fprintf(stderr, " L%d %u windows %.3f ms;", lv, hc[lv], ms); }
+          for (int lv = 0; lv < bl_levels; ++lv) { float ms = 0; (void)hipEventElapsedTime(&ms, tev[lv], tev[lv + 1]); fprintf(stderr, " L%d %u windows (%u past the LDS form) %.3f ms;", lv, hc[lv], hc[128 + lv], ms); }
           float mb = 0, mf = 0, md = 0;
           (void)hipEventElapsedTime(&mb, tev[bl_levels], tev[bl_levels + 1]); (void)hipEventElapsedTime(&mf, tev[bl_levels + 1], tev[bl_levels + 2]); (void)hipEventElapsedTime(&md, tev[bl_levels + 2], tev[bl_levels + 3]);
           fprintf(stderr, " base %u windows %.3f ms; finish %.3f ms (%u leaves); redo %u pairs %.3f ms\n", hc[WFA_BL_MAX_LEVELS], mb, mf, hc[WFA_BL_MAX_LEVELS + 1], hc[WFA_BL_MAX_LEVELS + 2], md);

@@ -32,23 +32,31 @@ def test_biwfa_full_cigar_matches_oracle(gpu, cfg_idx):
         common.assert_same(o, score, status, cigars, batch, f"biwfa {kw} corpus {i}")
 
 
-@pytest.mark.parametrize("env", [dict(WFA_HIP_BILEVEL_QCAP="40"), dict(WFA_HIP_BILEVEL_LEVELS="2"), dict(WFA_HIP_BILEVEL="0"),
-                                 dict(WFA_HIP_BILEVEL_I32="1", WFA_HIP_BILEVEL_WIDE_LEVELS="0"), dict(WFA_HIP_BILEVEL_WIDE_LEVELS="9")])
-def test_biwfa_level_queues_that_overflow_are_redone(gpu, env, monkeypatch):
+LEVEL_ENVS = [dict(WFA_HIP_BILEVEL_QCAP="40"), dict(WFA_HIP_BILEVEL_LEVELS="2"), dict(WFA_HIP_BILEVEL="0"),
+              dict(WFA_HIP_BILEVEL_I32="1", WFA_HIP_BILEVEL_WIDE_LEVELS="0"), dict(WFA_HIP_BILEVEL_WIDE_LEVELS="9", WFA_HIP_BILEVEL_NO_SEQL="1"),
+              dict(WFA_HIP_BILEVEL_LDS="1", WFA_HIP_BILEVEL_LDS_W="4096")]
+LEVEL_KWS = [dict(span="end-to-end"), dict(distance="affine2p", span="end-to-end"), dict(span="end-to-end", max_steps=400),
+             dict(span="end-to-end", heuristic="adaptive"), dict(distance="levenshtein", span="end-to-end")]
+
+
+@pytest.mark.parametrize("kw_idx", range(len(LEVEL_KWS)))
+def test_biwfa_level_queues_that_overflow_are_redone(gpu, kw_idx, monkeypatch):
     """The level-by-level form (csrc/wfa_bilevel.hpp) with queues too small for the batch / too few levels: the pairs it cannot finish
-    are aligned again by the depth-first kernel; and the depth-first kernel alone, int32 rings, one-wave / four-wave windows only —
-    the same op strings every time."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    pairs = [datagen.pair_strings(b, i) for b in (datagen.generate(24, 3000, 0.10, 99), datagen.generate(40, 700, 0.15, 98), datagen.generate(30, 90, 0.1, 97))
+    are aligned again by the depth-first kernel; and the depth-first kernel alone, int32 rings, one-wave / four-wave windows only, the
+    sequences read from HBM, the rows in LDS — the same op strings every time."""
+    pairs = [datagen.pair_strings(b, i) for b in (datagen.generate(8, 3000, 0.10, 99), datagen.generate(20, 700, 0.15, 98), datagen.generate(20, 90, 0.1, 97))
              for i in range(len(b["p_len"]))]
     batch = datagen.from_strings([p for p, _ in pairs], [t for _, t in pairs])
-    for kw in (dict(span="end-to-end"), dict(distance="affine2p", span="end-to-end"), dict(span="end-to-end", max_steps=400),
-               dict(span="end-to-end", heuristic="adaptive")):
-        oc, nc = common.configs_pair(scope="full", memory_mode="biwfa", **kw)
-        o = loader.run(loader.oracle(), oc, batch)
+    oc, nc = common.configs_pair(scope="full", memory_mode="biwfa", **LEVEL_KWS[kw_idx])
+    o = loader.run(loader.oracle(), oc, batch)
+    for env in LEVEL_ENVS:
+        for k in ("WFA_HIP_BILEVEL_QCAP", "WFA_HIP_BILEVEL_LEVELS", "WFA_HIP_BILEVEL", "WFA_HIP_BILEVEL_I32", "WFA_HIP_BILEVEL_WIDE_LEVELS",
+                  "WFA_HIP_BILEVEL_NO_SEQL", "WFA_HIP_BILEVEL_LDS", "WFA_HIP_BILEVEL_LDS_W"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         score, status, cigars = common.gpu_run(nc, batch, True, resident=True)
-        common.assert_same(o, score, status, cigars, batch, f"biwfa levels {env} {kw}")
+        common.assert_same(o, score, status, cigars, batch, f"biwfa levels {env} {LEVEL_KWS[kw_idx]}")
 
 
 def test_biwfa_long_reads_and_memory(gpu):
