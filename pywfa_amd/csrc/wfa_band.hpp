@@ -1316,8 +1316,19 @@ inline int launch_band_rtc(const BandArgs& a, int nch, bool full, bool adapt, bo
   return rtc_launch("wfa_band.hpp", name, (unsigned)grid, 64, smem, stream, &a, sizeof(a));
 }
 
-// true when launch_band() sends this launch to wfa_slim_kernel: slim_takes() and a shape the library has an instantiation of
-// (the host sets BandArgs::pb_raw from it before the launch: the walk must know which kernel wrote the codes)
+// gap-affine shapes without an instantiation whose slim form is compiled at run time (round 5): rings of up to twelve steps — beyond,
+// and gap-affine-2p, take wfa_band_kernel's run-time form as before
+inline bool slim_rtc_shape_ok(int X, int OE, int E, int OE2) { return OE2 == 0 && (X > OE ? X : OE) <= 12 && E <= 3; }
+inline int launch_slim_rtc(const BandArgs& a, int nch, bool full, long long grid, hipStream_t stream) {
+  const int g = a.g, X = a.x / g, OE = a.oe / g, E = a.e / g;
+  const int hist = (nch == 4) ? (full ? 2 : 0) : (full && a.split) ? 1 : full ? 2 : 0;
+  const std::string name = std::string("wfa::") + (nch == 4 ? "wfa_slim_kernel_tail<4, " : "wfa_slim_kernel<2, ") + std::to_string(hist) + ", " + std::to_string(X) + ", " +
+                           std::to_string(OE) + ", " + std::to_string(E) + ", 0, 0>";
+  return rtc_launch("wfa_slim.hpp", name, (unsigned)grid, 64, (size_t)a.lds_words * 2 * sizeof(uint32_t), stream, &a, sizeof(a));
+}
+
+// true when launch_band() sends this launch to wfa_slim_kernel: slim_takes() and a shape the library has an instantiation of or
+// compiles the slim form of (the host sets BandArgs::pb_raw from it before the launch: the walk must know which kernel wrote the codes)
 inline bool slim_launches(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds) {
   if (!slim_takes(a, nch, full, adapt, seqlds) || (rtc_force_all() && rtc_available())) return false;
   const int g = a.g, X = a.x / g, OE = a.oe / g, E = a.e / g;
@@ -1331,7 +1342,7 @@ inline bool slim_launches(const BandArgs& a, int nch, bool full, bool adapt, boo
 #define WFA_SLIM_MATCH(i, x, oe, e) if (X == x && OE == oe && E == e) return true;
   WFA_BAND_SHAPES(WFA_SLIM_MATCH)
 #undef WFA_SLIM_MATCH
-  return false;
+  return slim_rtc_shape_ok(X, OE, E, 0) && rtc_available();
 }
 
 inline int launch_band(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds, long long grid, hipStream_t stream) {
@@ -1347,6 +1358,7 @@ inline int launch_band(const BandArgs& a, int nch, bool full, bool adapt, bool s
 #define WFA_BAND_LAUNCH(i, x, oe, e) if (X == x && OE == oe && E == e) return slim_takes(a, nch, full, adapt, seqlds) ? launch_slim_s##i(a, nch, full, grid, stream) : launch_band_s##i(a, nch, full, adapt, seqlds, grid, stream);
   WFA_BAND_SHAPES(WFA_BAND_LAUNCH)
 #undef WFA_BAND_LAUNCH
+  if (slim_takes(a, nch, full, adapt, seqlds) && slim_rtc_shape_ok(X, OE, E, 0)) return launch_slim_rtc(a, nch, full, grid, stream);
   return launch_band_rtc(a, nch, full, adapt, seqlds, grid, stream);
 }
 

@@ -623,8 +623,14 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a, const uint32_t*
   }
 }
 
+// waves per SIMD of the 128-diagonal form by the registers a shape's rings take (two chunks of max(x, o+e) + 2 e each): the library's
+// shapes (<= 18) run seven; deeper rings compiled at run time get the registers they need instead of spilling
+constexpr int slim_waves(int X, int OE, int E) {
+  const int ring = 2 * ((X > OE ? X : OE) + 2 * E);
+  return ring <= 18 ? WFA_SLIM_WAVES : ring <= 24 ? 6 : ring <= 32 ? 5 : 4;
+}
 template <int NCH, int HIST, int X, int OE, int E, int OE2, int E2>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WFA_SLIM_WAVES, WFA_SLIM_WAVES)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(slim_waves(X, OE, E), slim_waves(X, OE, E))))
 wfa_slim_kernel(const BandArgs a) {   // gap-affine, 128 diagonals: seven waves per SIMD (<= 72 VGPRs; the sequences of 10 kb reads in LDS allow eight)
   wfa_slim_body<NCH, HIST, X, OE, E, OE2, E2>(a);
 }
