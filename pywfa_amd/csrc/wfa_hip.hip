@@ -231,6 +231,7 @@ struct wfa_hip_batch {
   hipEvent_t upload_event = nullptr;
   int stage_pick = 0;  // first register-kernel stage chosen by the pilot of the first run (0 = not yet): 16, 32 or 64 lanes
   int segh_pick = 0;   // the same for the general form of the 32-lane segments (wfa_seg_kernel<.., HEUR>)
+  int band_pick = 0;   // exact reads of 300 - 1 200 bases: the 256-diagonal register window first (1) or not (2: its pilot handed on most pairs), 0 undecided
   int laneh_pick = 0;  // general score-only form of the lane kernel first (wf-adaptive / free ends / step limit): 1 yes, 2 no (its pilot), 0 undecided
   int64_t arena_ints = 0;  // FULL: arena size used by the last launch (the part that grows 8x when a pair overflows it)
   int64_t arena_fixed = 0; // FULL, piggy-back history of the general kernel: the score-only ring in front of the growing part
@@ -766,6 +767,7 @@ static int staged_pack_upload(wfa_hip_aligner* al, wfa_hip_batch* b, const std::
 
 static int pilot_first_width(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream);
 static int pilot_lane_heur(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream);
+static int pilot_band(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream);
 
 // in2bit: `seqs` holds 2-bit reads in the reference's packed form (wavefront_sequences.c:102-139: four bases per byte, base j
 // of a byte in bits 2j..2j+1, A 0 / C 1 / G 2 / T 3), a sequence of len bases = (len + 3) / 4 bytes at its BYTE offset
@@ -1049,6 +1051,8 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
       b->h_meta = std::move(meta);
       { const int prc = pilot_first_width(al, b, al->stream); if (prc != WFA_HIP_OK) return prc; }
       { const int prc = pilot_lane_heur(al, b, al->stream); if (prc != WFA_HIP_OK) return prc; }
+  { const int prc = pilot_band(al, b, al->stream); if (prc != WFA_HIP_OK) return prc; }
+      { const int prc = pilot_band(al, b, al->stream); if (prc != WFA_HIP_OK) return prc; }
       HIP_TRY(al, hipEventCreateWithFlags(&b->upload_event, hipEventDisableTiming));
       HIP_TRY(al, hipEventRecord(b->upload_event, al->stream));
       return WFA_HIP_OK;
@@ -1117,6 +1121,7 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
   b->h_meta = std::move(meta);
   { const int prc = pilot_first_width(al, b, al->stream); if (prc != WFA_HIP_OK) return prc; }
   { const int prc = pilot_lane_heur(al, b, al->stream); if (prc != WFA_HIP_OK) return prc; }
+  { const int prc = pilot_band(al, b, al->stream); if (prc != WFA_HIP_OK) return prc; }
   HIP_TRY(al, hipEventCreateWithFlags(&b->upload_event, hipEventDisableTiming));
   HIP_TRY(al, hipEventRecord(b->upload_event, al->stream));
   return WFA_HIP_OK;
@@ -1149,7 +1154,7 @@ static int pilot_launch_failed(wfa_hip_aligner* al, wfa_hip_batch* b, unsigned f
     (void)hipGetLastError();
     b->dcfg.rtc = 0; al->dcfg.rtc = 0;
     al->rtc_note = std::string("run-time kernels switched off for this aligner: ") + wfa::rtc_last_error();
-    b->stage_pick = 128; b->laneh_pick = 2; b->segh_pick = 2;
+    b->stage_pick = 128; b->laneh_pick = 2; b->segh_pick = 2; if (b->band_pick == 0) b->band_pick = 1;
     return WFA_HIP_OK;
   }
   al->err = "pilot launch failed";
@@ -1183,6 +1188,45 @@ static int pilot_first_width(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t 
     if (knob(al, K_STAGE_TIMING, 0)) fprintf(stderr, "[wfa_hip] pilot: %d diagonals hand on %u of %u\n", w, handed, np);
     if (handed * 100u <= np * pct) { b->stage_pick = w; break; }
   }
+  HIP_TRY(al, hipMemsetAsync(pcount, 0, sizeof(uint32_t), stream));
+  return WFA_HIP_OK;
+}
+
+// Exact reads of 300 - 1 200 bases (no heuristic): the 256-diagonal register window is several times faster than the tiled rows for the
+// pairs it can finish, and wasted work for those whose wavefront outgrows it (scores beyond ~250 steps: 1 kb at 5 %, 600 bp at 10 % —
+// 91 / 99 % handed on, 17 - 20 % of the run).  A pilot on 4 096 sampled pairs decides once per batch (b->band_pick).
+static int pilot_band(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream) {
+  const unsigned rtc_failures = wfa::rtc_failure_count();
+  if (b->band_pick != 0 || b->n_packed < 32768u) return WFA_HIP_OK;
+  if (b->dcfg.heuristic != WFA_HEUR_NONE || b->ncomp != 3 || b->max_len <= 300 || b->max_len > 1200) return WFA_HIP_OK;
+  if (!wfa::band_supported(b->dcfg, b->ncomp) || knob(al, K_NO_BAND, 0) != 0 || knob(al, K_BAND_NCH, 0) != 0) return WFA_HIP_OK;
+  const uint32_t np = 4096u, stride = b->n_packed / np;
+  uint32_t* plist = b->d_fb_list2[0];
+  uint32_t* psample = b->d_fb_list2[1];
+  uint32_t* pcount = b->d_counters + 4;
+  hipLaunchKernelGGL(wfa_pilot_sample_kernel, dim3((np + 255u) / 256u), dim3(256), 0, stream, b->d_list_packed, stride, np, psample);
+  HIP_TRY(al, hipGetLastError());
+  HIP_TRY(al, hipMemsetAsync(pcount, 0, sizeof(uint32_t), stream));
+  wfa::BandArgs ba;
+  memset(&ba, 0, sizeof(ba));
+  ba.words = b->d_words; ba.meta = b->d_meta; ba.worklist = psample; ba.nwork = np;
+  ba.score = b->d_score; ba.status = b->d_status; ba.fb_list = plist; ba.fb_count = pcount;
+  ba.g = wfa::band_gcd(b->dcfg, false);
+  ba.x = b->dcfg.x; ba.oe = b->dcfg.o1 + b->dcfg.e1; ba.e = b->dcfg.e1;
+  ba.min_wf_len = b->dcfg.min_wf_len; ba.max_dist_thr = b->dcfg.max_dist_thr; ba.steps_between = b->dcfg.steps_between;
+  ba.heur = b->dcfg.heuristic; ba.xdrop = b->dcfg.xdrop; ba.max_steps = b->dcfg.max_steps; ba.scope = b->dcfg.scope;
+  const int words = ((b->max_len + 15) >> 4) + 4;
+  ba.lds_words = words;
+  ba.slim = knob(al, K_BAND_SLIM, 1);
+  ba.h16 = 1;
+  ba.ef = (b->dcfg.endsfree && (b->dcfg.pbf | b->dcfg.pef | b->dcfg.tbf | b->dcfg.tef)) ? 1 : 0;
+  ba.pbf = b->dcfg.pbf; ba.pef = b->dcfg.pef; ba.tbf = b->dcfg.tbf; ba.tef = b->dcfg.tef;
+  if (wfa::launch_band(ba, 4, false, false, true, (long long)np, stream) != 0) return pilot_launch_failed(al, b, rtc_failures);
+  uint32_t handed = 0;
+  HIP_TRY(al, hipMemcpyAsync(&handed, pcount, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(al, hipStreamSynchronize(stream));
+  if (knob(al, K_STAGE_TIMING, 0)) fprintf(stderr, "[wfa_hip] pilot: 256-diagonal window hands on %u of %u\n", handed, np);
+  b->band_pick = (handed * 2u >= np) ? 2 : 1;
   HIP_TRY(al, hipMemsetAsync(pcount, 0, sizeof(uint32_t), stream));
   return WFA_HIP_OK;
 }
@@ -1538,14 +1582,14 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
       la.slice_bytes = (std::max<int64_t>(2 * la.ring_elems * esz, ba.base_ints * 4) + 255) & ~255ll;
       bl_grid = al->cu_count * std::max(1, knob(al, K_BILEVEL_PER_CU, 32));
       // (a slice is megabytes: no more of them than the batch can keep busy — a few windows per pair are in flight at the deep levels)
-      bl_grid = (int)std::min<int64_t>(bl_grid, std::max<int64_t>(al->cu_count, 8 * (int64_t)std::max<int64_t>(b->n_packed, b->n_bytes)));
+      bl_grid = (int)std::min<int64_t>(bl_grid, std::max<int64_t>(64, 8 * (int64_t)std::max<int64_t>(b->n_packed, b->n_bytes)));
       // windows a pair can be in at once: about two per 250 of score; queues sized from the longest pair, what overflows is redone
       const int64_t per_pair = std::min<int64_t>(1024, std::max<int64_t>(4, b->max_width / 96));
       const int64_t nmax = std::max<int64_t>(b->n_packed, b->n_bytes);
       const int64_t qcap = knob(al, K_BILEVEL_QCAP, 0) > 0 ? knob(al, K_BILEVEL_QCAP, 0) : std::min<int64_t>(nmax * per_pair + 1024, (int64_t)1 << 28);   // (the knob: tests of the redo path)
       const int64_t meta_bytes = qcap * 32 * 5 + (int64_t)b->n * (4 + 4 + 4 + 8 + 4) + WFA_BL_COUNTER_WORDS * 4 + 4096;
       // the depth-first kernel behind it: a few slices (its int32 rings are the large ones)
-      grid = std::min<int64_t>(grid, al->cu_count);
+      grid = std::min<int64_t>(std::min<int64_t>(grid, al->cu_count), std::max<int64_t>(1, nmax));   // (the redo list holds pairs of this batch)
       while (bl_grid > al->cu_count && (int64_t)bl_grid * la.slice_bytes + meta_bytes + grid * stride * 4 > budget) bl_grid /= 2;
       while (grid > 1 && (int64_t)bl_grid * la.slice_bytes + meta_bytes + grid * stride * 4 > budget) grid = (grid + 1) / 2;
       la.qcap = la.qbcap = la.leafcap = la.qwcap = (uint32_t)qcap;
@@ -1629,7 +1673,7 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
             }
           }
           const int threads = (lv < wide_levels) ? 256 : 64;
-          const int lgrid = (threads == 256) ? std::max(al->cu_count, bl_grid / 2) : bl_grid;
+          const int lgrid = (threads == 256) ? std::min(bl_grid, std::max(al->cu_count, bl_grid / 2)) : bl_grid;   // (a slice of the workspace per workgroup: never more than bl_grid)
           la.lds_seq_words = full_seq_words;
           ok = ok && wfa::launch_bl_split_any(b->ncomp, kind == 0, bl_i16, threads, seql, la, (int)std::min<int64_t>(lgrid, lv == 0 ? (int64_t)cnt : (int64_t)lgrid), stream) == 0;
           la.from_wide = 0;
@@ -1724,7 +1768,7 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
         if (!use_fast && !use_segfull) band_nch[n_stages++] = 1;
         band_nch[n_stages++] = 2; band_nch[n_stages++] = 4;
       } else if (b->max_len <= 1200) {
-        band_nch[n_stages++] = 4;
+        if (b->band_pick != 2) band_nch[n_stages++] = 4;   // (2: the pilot of batch_build saw most pairs outgrow the window)
       }
       const int only = knob(al, K_BAND_NCH, 0);
       if (only) { n_stages = 1; band_nch[0] = only; }
@@ -1851,10 +1895,14 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
         wfa::TileGeom& tg = ta.g;
         tg.X = w0.X; tg.OE = w0.OE; tg.E = w0.E; tg.OE2 = w0.OE2; tg.E2 = w0.E2;
         tg.DM = std::max(std::max(tg.X, tg.OE), tg.OE2);
-        tg.T = knob(al, K_TILE_T, wide_two ? 8 : 16) & ~1;
-        tg.Wt = knob(al, K_TILE_WT, wide_two ? 128 : 256);
+        // geometry by read length (round 5): reads of up to 4 kb have wavefronts of a few hundred diagonals and scores of a few hundred
+        // steps — tiles of 128 diagonals advanced 8 steps by two waves per alignment keep more alignments in flight and waste less of
+        // a tile on halo (1 kb at 5 %: 4.3 -> 6.6 M aln/s, 2 kb at 1 %: 6.8 -> 15.1 M, 600 bp at 10 %: 3.9 -> 5.9 M; 4 kb at 5 %: equal)
+        const bool small_geom = !wide_two && b->max_len <= 4000;
+        tg.T = knob(al, K_TILE_T, (wide_two || small_geom) ? 8 : 16) & ~1;
+        tg.Wt = knob(al, K_TILE_WT, (wide_two || small_geom) ? 128 : 256);
         const int bw = tg.Wt - 2 * tg.T;
-        const int tthreads = std::max(64, std::min(512, knob(al, K_TILE_THREADS, 256) & ~63));
+        const int tthreads = std::max(64, std::min(512, knob(al, K_TILE_THREADS, small_geom ? 128 : 256) & ~63));
         if (tg.T >= 2 && tg.T <= WFA_TILE_MAX_T && tg.Wt >= 64 && tg.Wt % 64 == 0 && tg.Wt <= 256 && bw >= 16 &&
             wfa::tile_cand_count(tg) <= WFA_TILE_MAX_ROWS) {
           ta.gs = w0.g; ta.seq_words = w0.seq_words;
