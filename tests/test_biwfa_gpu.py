@@ -150,7 +150,7 @@ def test_biwfa_short_divergent_reads_under_large_penalties(gpu, kw):
 def test_biwfa_step_limit_matches_oracle(gpu, kw0, scope):
     import validate_oracle as vo
     corpora = [datagen.generate(500, 150, 0.05, 21), datagen.generate(200, 150, 0.2, 22), datagen.generate(300, 60, 0.1, 23),
-               datagen.generate(40, 1500, 0.08, 24), datagen.generate(6, 10000, 0.08, 25), vo.corpus_special(seed=6)]
+               datagen.generate(40, 1500, 0.08, 24), datagen.generate(3, 10000, 0.08, 25), vo.corpus_special(seed=6)]
     for ms in (5, 60, 300, 1200):
         oc, nc = common.configs_pair(**dict(kw0, scope=scope, memory_mode="biwfa", max_steps=ms))
         for i, batch in enumerate(corpora):
