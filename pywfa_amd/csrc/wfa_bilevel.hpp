@@ -68,13 +68,15 @@ struct BlArgs {
 template <typename T, bool LDSR> struct BlPtr { typedef T* type; };
 template <typename T> struct BlPtr<T, true> { typedef __attribute__((address_space(3))) T* type; };
 
-template <typename P> __device__ __forceinline__ int bl_ld(P p, long long i) {
+template <typename P> __device__ __forceinline__ int bl_ld(P p, int i) {
   int v = p[i];
   if (sizeof(p[0]) == 2) v = (v < 0) ? WFA_OFFSET_NULL : v;
   return v;
 }
-template <typename P> __device__ __forceinline__ void bl_st(P p, long long i, int v) {
-  if (sizeof(p[0]) == 2) p[i] = (short)min(max(v, -16384), 32767);
+// the step's own loads: int16 rows hold -16384 for every dead cell (bl_st), which max / + 1 / the bound tests treat as NULL
+template <typename P> __device__ __forceinline__ int bl_ld_raw(P p, int i) { return p[i]; }
+template <typename P> __device__ __forceinline__ void bl_st(P p, int i, int v) {
+  if (sizeof(p[0]) == 2) p[i] = (short)((v < 0) ? -16384 : min(v, 32767));
   else p[i] = v;
 }
 
@@ -163,7 +165,7 @@ struct BlSide {
   int lds_slots, cur_slot;
   int null_steps;
   int cur_lo, cur_hi, cur_exists, end_reached;
-  long long cur_idx0;
+  int cur_idx0;
   int steps_wait, have_max_sw, max_sw;
   __device__ __forceinline__ int next_data(int s, int scope) {
     if (LDSR) { cur_slot = (cur_slot + 1 == lds_slots) ? 0 : cur_slot + 1; return cur_slot * NCOMP * stride; }
@@ -186,11 +188,11 @@ __device__ __forceinline__ void bl_side_init(BlSide<NCOMP, OT, LDSR>& sd, int sc
     for (int c = 0; c < NCOMP; ++c) { m[MT::LO + c] = 1; m[MT::HI + c] = -1; }
     m[MT::LO + comp_begin] = 0; m[MT::HI + comp_begin] = 0;
     m[MT::BASE] = sd.rbase; m[MT::WIDTH] = sd.stride; m[MT::DATA] = data; m[MT::EXISTS] = (comp_begin == 0) ? 1 : 0;
-    bl_st(sd.ws, (long long)data + comp_begin * sd.stride - sd.rbase, 0);
+    bl_st(sd.ws, data + comp_begin * sd.stride - sd.rbase, 0);
   }
   sd.cur_exists = (comp_begin == 0) ? 1 : 0;
   sd.cur_lo = sd.cur_exists ? 0 : 1; sd.cur_hi = sd.cur_exists ? 0 : -1;
-  sd.cur_idx0 = (long long)data - sd.rbase;
+  sd.cur_idx0 = data - sd.rbase;
   __syncthreads();
 }
 
@@ -214,19 +216,23 @@ __device__ __forceinline__ int bl_side_extend0(BlSide<NCOMP, OT, LDSR>& sd, cons
 template <int NCOMP, typename OT, bool LDSR>
 struct BlIn {
   typedef typename BlPtr<OT, LDSR>::type P;
-  int lo, hi, kmask; long long idx0;
+  int lo, hi, kmask, idx0;
+  int klo; uint32_t span;   // the range as one unsigned test: k - klo <= span (a null wavefront: klo = 2^30, span = 0 — no diagonal passes)
   __device__ __forceinline__ bool null() const { return lo > hi; }
-  __device__ __forceinline__ int get(P ws, int k) const { return (k >= lo && k <= hi) ? bl_ld(ws, idx0 + (k & kmask)) : WFA_OFFSET_NULL; }
+  __device__ __forceinline__ void set_null() { lo = 1; hi = -1; idx0 = 0; klo = 1 << 30; span = 0; }
+  __device__ __forceinline__ int get(P ws, int k) const {
+    return ((uint32_t)(k - klo) <= span) ? bl_ld_raw(ws, idx0 + (k & kmask)) : (sizeof(ws[0]) == 2 ? -16384 : WFA_OFFSET_NULL);
+  }
 };
 template <int NCOMP, typename OT, bool LDSR>
 __device__ __forceinline__ BlIn<NCOMP, OT, LDSR> bl_fetch_in(const BlSide<NCOMP, OT, LDSR>& sd, int scope, int s, int c) {
   typedef Meta<NCOMP> MT;
   BlIn<NCOMP, OT, LDSR> in;
-  in.lo = 1; in.hi = -1; in.idx0 = 0; in.kmask = sd.kmask;
+  in.set_null(); in.kmask = sd.kmask;
   if (s >= 0) {
     const int* m = sd.ring + (s % scope) * MT::INTS;
     const int lo = m[MT::LO + c], hi = m[MT::HI + c];
-    if (lo <= hi) { in.lo = lo; in.hi = hi; in.idx0 = (long long)m[MT::DATA] + c * m[MT::WIDTH] - m[MT::BASE]; }
+    if (lo <= hi) { in.lo = lo; in.hi = hi; in.klo = lo; in.span = (uint32_t)(hi - lo); in.idx0 = m[MT::DATA] + c * m[MT::WIDTH] - m[MT::BASE]; }
   }
   return in;
 }
@@ -243,7 +249,7 @@ __device__ __forceinline__ int bl_side_step(BlSide<NCOMP, OT, LDSR>& sd, const V
   typedef BlIn<NCOMP, OT, LDSR> In;
   typedef typename BlPtr<OT, LDSR>::type P;
   const P ws = sd.ws;
-  In nullin; nullin.lo = 1; nullin.hi = -1; nullin.idx0 = 0; nullin.kmask = -1;
+  In nullin; nullin.set_null(); nullin.kmask = -1;
   const In mx = (NCOMP == 1 && cfg.metric == 0) ? nullin : bl_fetch_in<NCOMP, OT, LDSR>(sd, scope, s - cfg.x, 0);
   const In mo1 = bl_fetch_in<NCOMP, OT, LDSR>(sd, scope, s - cfg.o1 - cfg.e1, 0);
   const In i1e = (NCOMP == 1) ? nullin : bl_fetch_in<NCOMP, OT, LDSR>(sd, scope, s - cfg.e1, 1);
@@ -285,8 +291,8 @@ __device__ __forceinline__ int bl_side_step(BlSide<NCOMP, OT, LDSR>& sd, const V
     const bool has_d2 = (NCOMP == 5) && (!mo2.null() || !d2e.null());
     base = sd.rbase; width = sd.stride; data = sd.next_data(s, scope); exists = 1;
     const int kmask = sd.kmask;
-    const long long o_m = (long long)data - base;
-    const long long o_i1 = o_m + width, o_d1 = o_m + 2 * width, o_i2 = o_m + 3 * width, o_d2 = o_m + 4 * width;
+    const int o_m = data - base;
+    const int o_i1 = o_m + width, o_d1 = o_m + 2 * width, o_i2 = o_m + 3 * width, o_d2 = o_m + 4 * width;
     const P wsw = sd.ws;
     const int ak = tlen - plen;
     // reduced below: [0, NCOMP) first in-bounds diagonal per component (min), [NCOMP, 2 NCOMP) last (max), [2 NCOMP] antidiagonal (max),
@@ -444,7 +450,7 @@ __device__ __forceinline__ bool bl_side_terminated(const BlSide<NCOMP, OT, LDSR>
   const int* m = sd.ring + (s % scope) * MT::INTS;
   const int ak = tlen - plen;
   if (m[MT::LO + comp_end] > ak || ak > m[MT::HI + comp_end]) return false;
-  return bl_ld(sd.ws, (long long)m[MT::DATA] + comp_end * m[MT::WIDTH] - m[MT::BASE] + (ak & sd.kmask)) >= tlen;
+  return bl_ld(sd.ws, m[MT::DATA] + comp_end * m[MT::WIDTH] - m[MT::BASE] + (ak & sd.kmask)) >= tlen;
 }
 
 // R/wavefront_bialign.c:189-311 over the workgroup: the lowest diagonal of aligner 0 on which the two offsets meet wins.
@@ -460,7 +466,7 @@ __device__ __forceinline__ void bl_breakpoint_cc(const BlSide<NCOMP, OT, LDSR>& 
   if (hi_1 < lo_0 || hi_0 < lo_1) return;
   if (score_0 + score_1 - gap_open >= bp.score) return;
   const int min_hi = min(hi_0, hi_1), max_lo = max(lo_0, lo_1);
-  const long long i0 = (long long)m0[MT::DATA] + c * m0[MT::WIDTH] - m0[MT::BASE], i1 = (long long)m1[MT::DATA] + c * m1[MT::WIDTH] - m1[MT::BASE];
+  const int i0 = m0[MT::DATA] + c * m0[MT::WIDTH] - m0[MT::BASE], i1 = m1[MT::DATA] + c * m1[MT::WIDTH] - m1[MT::BASE];
   const int kmask = s0.kmask;
   for (int kb = max_lo; kb <= min_hi; kb += THREADS) {
     const int k_0 = kb + tid;

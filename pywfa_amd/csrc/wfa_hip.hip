@@ -1895,10 +1895,10 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
         wfa::TileGeom& tg = ta.g;
         tg.X = w0.X; tg.OE = w0.OE; tg.E = w0.E; tg.OE2 = w0.OE2; tg.E2 = w0.E2;
         tg.DM = std::max(std::max(tg.X, tg.OE), tg.OE2);
-        // geometry by read length (round 5): reads of up to 4 kb have wavefronts of a few hundred diagonals and scores of a few hundred
+        // geometry by read length (round 5): reads of up to 8 kb have wavefronts of a few hundred diagonals and scores of a few hundred
         // steps — tiles of 128 diagonals advanced 8 steps by two waves per alignment keep more alignments in flight and waste less of
         // a tile on halo (1 kb at 5 %: 4.3 -> 6.6 M aln/s, 2 kb at 1 %: 6.8 -> 15.1 M, 600 bp at 10 %: 3.9 -> 5.9 M; 4 kb at 5 %: equal)
-        const bool small_geom = !wide_two && b->max_len <= 4000;
+        const bool small_geom = !wide_two && b->max_len <= 8000;   // (3 / 5 / 7 kb at 5 %: equal / +10 % / +2 % score, 5 kb full +35 %; 10 kb: -20 %)
         tg.T = knob(al, K_TILE_T, (wide_two || small_geom) ? 8 : 16) & ~1;
         tg.Wt = knob(al, K_TILE_WT, (wide_two || small_geom) ? 128 : 256);
         const int bw = tg.Wt - 2 * tg.T;
