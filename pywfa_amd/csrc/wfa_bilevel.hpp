@@ -84,9 +84,13 @@ template <typename P> __device__ __forceinline__ void bl_st(P p, int i, int v) {
 // results meet in LDS atomics — red holds three buffers of 16 minima + 16 maxima used in rotation (`phase`), the buffer of the call
 // after the next is re-set before this call's barrier, so a call costs ONE barrier whatever the number of waves.
 template <int THREADS, int N>
-__device__ __forceinline__ void bl_reduce(int (&v)[N], uint32_t maxmask, int* red, int& phase, int tid) {
+__device__ __forceinline__ void bl_reduce(int (&v)[N], uint32_t maxmask, int* red, int& phase, int tid, uint32_t wave_uniform = 0u) {
 #pragma unroll
-  for (int i = 0; i < N; ++i) v[i] = ((maxmask >> i) & 1) ? wave_max(v[i]) : wave_min(v[i]);
+  for (int i = 0; i < N; ++i) {
+    // (wave_uniform: lane 0 — the lane that stays longest in the chunk loop — holds the wave's value already)
+    if ((wave_uniform >> i) & 1) v[i] = __builtin_amdgcn_readfirstlane(v[i]);
+    else v[i] = ((maxmask >> i) & 1) ? wave_max(v[i]) : wave_min(v[i]);
+  }
   if (THREADS > 64) {
     int* const cur = red + phase * 32;
     int* const nxt = red + ((phase + 1) % 3) * 32;
@@ -163,6 +167,7 @@ struct BlSide {
   P ws;
   int stride, rbase, kmask;
   int lds_slots, cur_slot;
+  int g;             // bl_lattice_gcd
   int null_steps;
   int cur_lo, cur_hi, cur_exists, end_reached;
   int cur_idx0;
@@ -242,12 +247,29 @@ __device__ __forceinline__ BlIn<NCOMP, OT, LDSR> bl_fetch_in(const BlSide<NCOMP,
 // trimming :571-605 on the offsets before the extension, R/wavefront_extend.c:90-125), and the end test of R/wavefront_termination.c:
 // 37-113 on the values as they pass (sd.end_reached).  Returns the largest antidiagonal 2 * offset - k of the extended M wavefront
 // (0: none); -1: the wavefront does not fit the LDS rows (LDSR).
+// scores are sums of the penalties the recurrences of this metric use: every other score is a null step (R/wavefront_compute.c:
+// the reference walks them one by one; nothing is computed and nothing is read from them later)
+template <int NCOMP>
+__device__ __forceinline__ int bl_lattice_gcd(const WfaDevConfig& cfg) {
+  auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+  int g = cfg.o1 + cfg.e1;
+  if (!(NCOMP == 1 && cfg.metric == 0)) g = gcd(g, cfg.x);
+  if (NCOMP != 1) g = gcd(g, cfg.e1);
+  if (NCOMP == 5) { g = gcd(g, cfg.o2 + cfg.e2); g = gcd(g, cfg.e2); }
+  return g > 0 ? g : 1;
+}
+
 template <int NCOMP, typename OT, int THREADS, bool LDSR, typename V>
 __device__ __forceinline__ int bl_side_step(BlSide<NCOMP, OT, LDSR>& sd, const V& view, const WfaDevConfig& cfg, int scope, int s,
                                             int comp_end, int plen, int tlen, int* red, int& phase, int tid) {
   typedef Meta<NCOMP> MT;
   typedef BlIn<NCOMP, OT, LDSR> In;
   typedef typename BlPtr<OT, LDSR>::type P;
+  if (sd.g > 1 && s % sd.g != 0) {   // off the lattice: a null step, registers only (its directory record is never read: bl_overlap skips these scores)
+    ++sd.null_steps;
+    sd.cur_exists = 0; sd.cur_lo = 1; sd.cur_hi = -1; sd.cur_idx0 = 0; sd.end_reached = 0;
+    return 0;
+  }
   const P ws = sd.ws;
   In nullin; nullin.set_null(); nullin.kmask = -1;
   const In mx = (NCOMP == 1 && cfg.metric == 0) ? nullin : bl_fetch_in<NCOMP, OT, LDSR>(sd, scope, s - cfg.x, 0);
@@ -308,36 +330,45 @@ __device__ __forceinline__ int bl_side_step(BlSide<NCOMP, OT, LDSR>& sd, const V
       c.mxc = (NCOMP == 1 && cfg.metric == 0) ? WFA_OFFSET_NULL : mx.get(ws, k);
       if (NCOMP == 5) { c.mo2l = mo2.get(ws, k - 1); c.mo2r = mo2.get(ws, k + 1); c.i2l = i2e.get(ws, k - 1); c.d2r = d2e.get(ws, k + 1); }
     };
+    int best_lane = 0;
     auto inb = [&](int off, int k) -> bool { return (uint32_t)off <= (uint32_t)tlen && (uint32_t)(off - k) <= (uint32_t)plen; };
+    // first / last in-bounds diagonal of a component: lanes hold ascending diagonals, so a chunk's are the ends of the compare's lane mask
+    auto ends = [&](bool in, int kbase, int c) {
+      const unsigned long long m = __ballot(in);
+      if (m) { r[c] = min(r[c], kbase + (int)__builtin_ctzll(m)); r[NCOMP + c] = max(r[NCOMP + c], kbase + 63 - (int)__builtin_clzll(m)); }
+    };
     auto finish = [&](int k, const Cell& c) {
       const int km = k & kmask;
+      const int kbase = __builtin_amdgcn_readfirstlane(k);   // (lanes hold ascending diagonals and leave the loop from the top: the first live lane is lane 0)
       const int ins1 = max(c.mo1l, c.i1l) + 1;
       const int del1 = max(c.mo1r, c.d1r);
       int ins = ins1, del = del1, endv = INT_MIN;
-      if (has_i1) { bl_st(wsw, o_i1 + km, ins1); if (inb(ins1, k)) { r[1 % NCOMP] = min(r[1 % NCOMP], k); r[NCOMP + 1 % NCOMP] = max(r[NCOMP + 1 % NCOMP], k); } if (comp_end == 1) endv = ins1; }
-      if (has_d1) { bl_st(wsw, o_d1 + km, del1); if (inb(del1, k)) { r[2 % NCOMP] = min(r[2 % NCOMP], k); r[NCOMP + 2 % NCOMP] = max(r[NCOMP + 2 % NCOMP], k); } if (comp_end == 2) endv = del1; }
+      if (has_i1) { bl_st(wsw, o_i1 + km, ins1); ends(inb(ins1, k), kbase, 1 % NCOMP); if (comp_end == 1) endv = ins1; }
+      if (has_d1) { bl_st(wsw, o_d1 + km, del1); ends(inb(del1, k), kbase, 2 % NCOMP); if (comp_end == 2) endv = del1; }
       if (NCOMP == 5) {
         const int ins2 = max(c.mo2l, c.i2l) + 1;
         const int del2 = max(c.mo2r, c.d2r);
-        if (has_i2) { bl_st(wsw, o_i2 + km, ins2); if (inb(ins2, k)) { r[3 % NCOMP] = min(r[3 % NCOMP], k); r[NCOMP + 3 % NCOMP] = max(r[NCOMP + 3 % NCOMP], k); } if (comp_end == 3) endv = ins2; }
-        if (has_d2) { bl_st(wsw, o_d2 + km, del2); if (inb(del2, k)) { r[4 % NCOMP] = min(r[4 % NCOMP], k); r[NCOMP + 4 % NCOMP] = max(r[NCOMP + 4 % NCOMP], k); } if (comp_end == 4) endv = del2; }
+        if (has_i2) { bl_st(wsw, o_i2 + km, ins2); ends(inb(ins2, k), kbase, 3 % NCOMP); if (comp_end == 3) endv = ins2; }
+        if (has_d2) { bl_st(wsw, o_d2 + km, del2); ends(inb(del2, k), kbase, 4 % NCOMP); if (comp_end == 4) endv = del2; }
         ins = max(ins1, ins2);
         del = max(del1, del2);
       }
       int mv = (NCOMP == 1 && cfg.metric == 0) ? max(del, ins) : max(del, max(c.mxc + 1, ins));
-      if (!inb(mv, k)) {
+      const bool min_b = inb(mv, k);
+      ends(min_b, kbase, 0);
+      if (!min_b) {
         mv = WFA_OFFSET_NULL;   // only M is clamped
       } else {
-        r[0] = min(r[0], k); r[NCOMP] = max(r[NCOMP], k);
         const int v = mv - k;
         mv += view.run(v, mv, min(plen - v, tlen - mv));
-        r[2 * NCOMP] = max(r[2 * NCOMP], 2 * mv - k);
+        best_lane = max(best_lane, 2 * mv - k);
       }
       if (comp_end == 0) endv = mv;
-      if (k == ak) r[2 * NCOMP + 1] = endv;
+      const unsigned long long mak = __ballot(k == ak);
+      if (mak) r[2 * NCOMP + 1] = __builtin_amdgcn_readlane(endv, (int)__builtin_ctzll(mak));
       bl_st(wsw, o_m + km, mv);
     };
-    // (the workspace form: four chunks of loads in flight per thread — a step is one round trip to the rows however wide the wavefront)
+    // (the workspace form: WFA_BL_FLY chunks of loads in flight per thread — a step is one round trip to the rows)
     constexpr int FLY = LDSR ? 2 : WFA_BL_FLY;
     for (int k = lo + tid; k <= hi; k += FLY * THREADS) {
       Cell c[FLY];
@@ -346,7 +377,8 @@ __device__ __forceinline__ int bl_side_step(BlSide<NCOMP, OT, LDSR>& sd, const V
 #pragma unroll
       for (int j = 0; j < FLY; ++j) if (j == 0 || k + j * THREADS <= hi) finish(k + j * THREADS, c[j]);
     }
-    bl_reduce<THREADS, 2 * NCOMP + 2>(r, (((1u << NCOMP) - 1) << NCOMP) | (3u << (2 * NCOMP)), red, phase, tid);
+    r[2 * NCOMP] = best_lane;
+    bl_reduce<THREADS, 2 * NCOMP + 2>(r, (((1u << NCOMP) - 1) << NCOMP) | (3u << (2 * NCOMP)), red, phase, tid, ~(1u << (2 * NCOMP)));   // (all but the antidiagonal are wave values already)
 #pragma unroll
     for (int c = 0; c < NCOMP; ++c) {
       const bool has = (c == 0) || (c == 1 && has_i1) || (c == 2 && has_d1) || (NCOMP == 5 && c == 3 && has_i2) || (NCOMP == 5 && c == 4 && has_d2);
@@ -520,11 +552,13 @@ template <int NCOMP, typename OT, int THREADS, bool LDSR>
 __device__ __forceinline__ void bl_overlap(const BlSide<NCOMP, OT, LDSR>& s0, const BlSide<NCOMP, OT, LDSR>& s1, const WfaDevConfig& cfg, int scope,
                                            int score_0, int score_1, bool forward, int plen, int tlen, BiBreakpoint& bp, int* hitbuf, int tid) {
   typedef Meta<NCOMP> MT;
+  if (s0.g > 1 && score_0 % s0.g != 0) return;   // (null steps leave no record)
   const int* m0 = s0.ring + (score_0 % scope) * MT::INTS;
   if (!m0[MT::EXISTS]) return;
   for (int i = 0; i < scope; ++i) {
     const int score_i = score_1 - i;
     if (score_i < 0) break;
+    if (s0.g > 1 && score_i % s0.g != 0) continue;
     const int* m1 = s1.ring + (score_i % scope) * MT::INTS;
     if (NCOMP == 5) {
       if (score_0 + score_i - cfg.o2 >= bp.score) continue;
@@ -643,6 +677,7 @@ bl_split_kernel(const BlArgs a) {
   const long long max_steps = cfg.max_steps;
   int phase = 0;
   bl_reduce_init(red, tid);
+  const int lattice_g = bl_lattice_gcd<NCOMP>(cfg);
 
   for (;;) {
     // windows differ in cost by orders of magnitude: taken one at a time from the level's counter
@@ -685,6 +720,7 @@ bl_split_kernel(const BlArgs a) {
     BlSide<NCOMP, OT, LDSR> F, R;
     F.ring = ring_f; R.ring = ring_r;
     F.lds_slots = R.lds_slots = a.lds_slots;
+    F.g = R.g = lattice_g;
     if (LDSR) {
       OT* rows = reinterpret_cast<OT*>(lds_seq + 2 * a.lds_seq_words);
       F.ws = (P)rows; R.ws = (P)(rows + row_elems);
