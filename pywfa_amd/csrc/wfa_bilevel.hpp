@@ -369,7 +369,7 @@ __device__ __forceinline__ int bl_side_step(BlSide<NCOMP, OT, LDSR>& sd, const V
       bl_st(wsw, o_m + km, mv);
     };
     // (the workspace form: WFA_BL_FLY chunks of loads in flight per thread — a step is one round trip to the rows)
-    constexpr int FLY = LDSR ? 2 : WFA_BL_FLY;
+    constexpr int FLY = LDSR ? 2 : (sizeof(OT) == 4 ? 4 : WFA_BL_FLY);   // (int32 rows = reads beyond 32 kb: wavefronts of tens of thousands of diagonals, 100 kb +16 % with four)
     for (int k = lo + tid; k <= hi; k += FLY * THREADS) {
       Cell c[FLY];
 #pragma unroll
@@ -649,8 +649,11 @@ __global__ void __launch_bounds__(256) bl_seed_kernel(const BlArgs a) {
   }
 }
 
+#ifndef WFA_BL_WAVES
+#define WFA_BL_WAVES 5
+#endif
 template <int NCOMP, bool PACKED, typename OT, int THREADS, bool LDSR, bool SEQL>
-__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 1024 ? 4 : 5)))   // (<= 96 registers: five waves per SIMD)
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 1024 ? 4 : (THREADS == 256 && !LDSR ? WFA_BL_WAVES : 5))))   // (<= 96 registers: five waves per SIMD)
 bl_split_kernel(const BlArgs a) {
   typedef Meta<NCOMP> MT;
   typedef typename BlPtr<OT, LDSR>::type P;
@@ -843,6 +846,7 @@ bl_base_kernel(const BlArgs a) {
   const uint32_t nwork = min(a.cnt[WFA_BL_MAX_LEVELS], a.qbcap);
   const long long max_steps = cfg.max_steps;
   int* const next_wi = ring_b + scope * MT::INTS;
+  const int lattice_g = bl_lattice_gcd<NCOMP>(cfg);
   for (;;) {
     __syncthreads();
     if (lane == 0) next_wi[0] = (int)atomicAdd(a.cnt + 64 + WFA_BL_MAX_LEVELS, 1u);
@@ -882,6 +886,10 @@ bl_base_kernel(const BlArgs a) {
       ++s;
       if (s >= max_steps) { fail = true; break; }
       if (s >= WFA_BI_BASE_SLOTS - 1) { hand_on = true; break; }
+      if (lattice_g > 1 && s % lattice_g != 0) {   // a null step (no sum of the penalties): registers only, its records are never read
+        ++B.null_steps; B.cur_exists = 0; B.cur_lo = 1; B.cur_hi = -1; B.cur_idx0 = 0;
+        continue;
+      }
       if (!bi_side_compute<NCOMP>(B, cfg, scope, s, plen, tlen, lane)) { hand_on = true; break; }
     }
     const int start = w.pbeg + w.tbeg;
