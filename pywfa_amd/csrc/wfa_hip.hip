@@ -186,6 +186,7 @@ struct wfa_hip_batch {
   // free ends) follows it, so run / sync / results use this snapshot, never the aligner's current configuration
   wfa_hip_config_t cfg;
   WfaDevConfig dcfg;
+  int wild = -1;           // the wildcard letter of the 8-bit pairs when dcfg.wildcard was cleared for the 2-bit ones (round 5, below)
   int ncomp = 3;
   int64_t n = 0;
   // host copies needed later
@@ -774,6 +775,13 @@ static int pilot_band(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream)
 static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const uint8_t* seqs,
                        const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len, bool in2bit = false) {
   b->cfg = al->cfg; b->dcfg = al->dcfg; b->ncomp = al->ncomp;
+  // Round 5: a wildcard letter outside ACGT cannot occur in a pair whose letters are all ACGT — such pairs take the 2-bit kernels as if
+  // no wildcard were set (same result: nothing in them matches by wildcard), only the pairs holding other letters are aligned on their
+  // bytes with the wildcard rule (150 bp, clean reads: 44 M -> the 2-bit rates).  A wildcard that IS one of ACGT keeps every pair on bytes.
+  {
+    const int wc = b->cfg.wildcard;
+    if (wc >= 0 && !(wc == 'A' || wc == 'C' || wc == 'G' || wc == 'T' || wc == 'a' || wc == 'c' || wc == 'g' || wc == 't')) { b->wild = wc; b->dcfg.wildcard = -1; }
+  }
   const wfa_hip_config_t& c = b->cfg;
   const bool timing = al->knobs.set[K_TIMING];
   double t0 = now_ms();
@@ -1084,7 +1092,7 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
       uint32_t any_flag = 0;
       HIP_TRY(al, hipMemcpyAsync(&any_flag, b->d_counters + 15, sizeof(uint32_t), hipMemcpyDeviceToHost, al->stream));
       HIP_TRY(al, hipStreamSynchronize(al->stream));
-      if (any_flag || c.wildcard >= 0) {
+      if (any_flag || (c.wildcard >= 0 && b->wild < 0)) {
         flags.assign((size_t)n, 0);
         HIP_TRY(al, hipMemcpy(flags.data(), b->d_flags, (size_t)n, hipMemcpyDeviceToHost));
       }
@@ -1092,7 +1100,7 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
     if (timing) { fprintf(stderr, "[wfa_hip] H2D + pack + flags D2H %.3f ms (%.2f GB)\n", now_ms() - t0, blob_end / 1e9); t0 = now_ms(); }
     // split into the 2-bit and the 8-bit work lists (wildcard matching needs the bytes)
     std::vector<uint32_t> lp, lb;
-    if (c.wildcard >= 0) {
+    if (c.wildcard >= 0 && b->wild < 0) {   // (a wildcard among ACGT: every pair on its bytes)
       lb.resize((size_t)n);
       for (int64_t i = 0; i < n; ++i) lb[i] = (uint32_t)i;
     } else {
@@ -1427,6 +1435,7 @@ static int launch_general_dyn(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t
   a.ws = al->ws; a.ws_stride = ws_stride;
   a.fb_list = ovf_list; a.fb_count = ovf_count;
   a.cfg = b->dcfg;
+  if (!packed && b->wild >= 0) a.cfg.wildcard = b->wild;   // (the 8-bit pairs of a batch whose 2-bit pairs run without the wildcard rule)
   if (a.cfg.biwfa_top) a.cfg.heuristic = WFA_HEUR_NONE;   // (standing in for a BiWFA base case: the base aligner has no heuristic, R/wavefront_bialigner.c:66-68)
   if (wfa::launch_general_any(b->ncomp, packed, b->cfg.scope == WFA_SCOPE_FULL, general_pb(al, b->cfg, b->ncomp, b->max_len), a, grid, threads, stream) != 0) {
     al->err = std::string("general kernel launch failed: ") + hipGetErrorString(hipGetLastError());
@@ -1629,6 +1638,7 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
       if (cnt == 0) continue;
       a.worklist = kind ? b->d_list_bytes : b->d_list_packed; a.nwork_dev = nullptr; a.nwork = cnt;
       a.fb_list = full ? b->d_fb_list2[kind] : nullptr; a.fb_count = b->d_counters + 4 + kind;
+      a.cfg.wildcard = (kind && b->wild >= 0) ? b->wild : b->dcfg.wildcard;   // (the 8-bit pairs keep the wildcard rule)
       int64_t dfs_grid = std::min<int64_t>(grid, cnt);
       if (bilevel) {
         la.k = a;
@@ -2487,7 +2497,7 @@ static int retry_overflows(wfa_hip_batch* b) {
     HIP_TRY(al, hipMemcpy(ids.data(), b->d_ovf_list[cur], novf * sizeof(uint32_t), hipMemcpyDeviceToHost));
     std::vector<uint8_t> flags((size_t)b->n, 0);
     if (b->n_bytes) HIP_TRY(al, hipMemcpy(flags.data(), b->d_flags, (size_t)b->n, hipMemcpyDeviceToHost));
-    const bool all_bytes = (b->cfg.wildcard >= 0);
+    const bool all_bytes = (b->cfg.wildcard >= 0 && b->wild < 0);
     std::vector<uint32_t> lp, lb;
     for (uint32_t id : ids) ((all_bytes || flags[id]) ? lb : lp).push_back(id);
     b->arena_ints *= 8;

@@ -561,3 +561,38 @@ def test_align_pair_entry_matches_the_batch_entry_and_the_oracle(gpu, kw):
     a = pywfa_amd.WavefrontAligner("TCTTTACTCGCGCGTTGGAGAAATACAATAGT", **{k: v for k, v in kw.items() if k in ("scope", "span")})
     s = a.wavefront_align("TCTATACTGCGCGTTTGGAGAAATAAAATAGT")
     assert s == -24 and (a.cigarstring == "3M1X4M1D7M1I9M1X6M" if kw.get("scope", "full") == "full" else a.cigarstring == "")
+
+
+WILD = [dict(), dict(scope="score", span="end-to-end"), dict(heuristic="adaptive", span="end-to-end"), dict(distance="affine2p"),
+        dict(distance="levenshtein"), dict(span="ends-free", pattern_begin_free=5, text_end_free=9, scope="score"),
+        dict(memory_mode="biwfa", span="end-to-end"), dict(wildcard="A", scope="score")]
+
+
+@pytest.mark.parametrize("cfg_idx", range(len(WILD)))
+def test_wildcard_batches_split_by_letters(gpu, cfg_idx):
+    """Round 5: with a wildcard letter outside ACGT, pairs whose letters are all ACGT take the 2-bit kernels (nothing in them can match by
+    wildcard) and only the pairs holding other letters are aligned on their bytes with the wildcard rule (align.pyx:297-304,
+    R/wavefront_extend_kernels.c:142-163).  Mixed batches — clean pairs, pairs with N in the pattern, the text, both, runs of N — against
+    the oracle; a wildcard that is one of ACGT keeps every pair on its bytes."""
+    rng = np.random.default_rng(400 + cfg_idx)
+    pats, txts = [], []
+    for b in (datagen.generate(700, 150, 0.03, 71 + cfg_idx), datagen.generate(40, 900, 0.06, 72 + cfg_idx)):
+        for i in range(len(b["p_len"])):
+            p, t = datagen.pair_strings(b, i)
+            u = rng.random()
+            if u < 0.25:
+                k = int(rng.integers(0, len(p))); p = p[:k] + "N" * int(rng.integers(1, 4)) + p[k + 1:]
+            elif u < 0.4:
+                k = int(rng.integers(0, len(t))); t = t[:k] + "N" + t[k + 1:]
+            elif u < 0.5:
+                p = p.replace("ACG", "ANG", 2); t = t.replace("TT", "TN", 1)
+            pats.append(p); txts.append(t)
+    batch = datagen.from_strings(pats, txts)
+    kw = dict(dict(scope="full", wildcard="N"), **WILD[cfg_idx])
+    kw = common.clamp_free(kw, batch)
+    oc, nc = common.configs_pair(**kw)
+    full = oc.scope == 1
+    o = loader.run(loader.oracle(), oc, batch, want_cigar=full)
+    for resident in (True, False):
+        score, status, cigars = common.gpu_run(nc, batch, full, resident=resident)
+        common.assert_same(o, score, status, cigars, batch, f"wildcard {kw} resident={resident}")
