@@ -45,7 +45,7 @@ static thread_local std::string g_error;
 // never call getenv.
 #define WFA_COUNTER_WORDS 64   // counters of a batch (wfa_hip_batch::d_counters)
 #define WFA_KNOBS(F)                                                                                              \
-  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(NO_TINY_INLINE) F(BILEVEL) F(BILEVEL_WIDE_LEVELS) F(BILEVEL_PER_CU) F(BILEVEL_I32) F(BILEVEL_QCAP) F(BILEVEL_LEVELS) F(BILEVEL_LDS) F(BILEVEL_LDS_W) F(BILEVEL_NO_SEQL) F(LANE_DYN) F(LANE_DYN_WAVES) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
+  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(BAND_SPLIT_MIN) F(NO_TINY_INLINE) F(BILEVEL) F(BILEVEL_WIDE_LEVELS) F(BILEVEL_PER_CU) F(BILEVEL_I32) F(BILEVEL_QCAP) F(BILEVEL_LEVELS) F(BILEVEL_LDS) F(BILEVEL_LDS_W) F(BILEVEL_NO_SEQL) F(LANE_DYN) F(LANE_DYN_WAVES) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
   F(LANE_FULL) F(LANE_FULL_SPLIT) F(LANE_HEUR) F(SEG_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_ADAPT) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(TILE) F(TILE_T) F(TILE_WT) F(TILE_THREADS) F(TILE_PER_CU) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY) F(PILOT_PCT) F(WIDE_ADAPT_LDS)
@@ -1824,7 +1824,7 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
         const int64_t budget = free_budget(al);
         while (grid > 1 && grid * band_stride[i] * 4 > budget) grid = (grid + 1) / 2;
         need = std::max(need, (size_t)grid * band_stride[i] * 4);
-        if (i == 0 && !use_fast && !use_segfull && b->max_len > 1000 && knob(al, K_BAND_NO_SPLIT, 0) == 0) {
+        if (i == 0 && !use_fast && !use_segfull && b->max_len > knob(al, K_BAND_SPLIT_MIN, 100) && knob(al, K_BAND_NO_SPLIT, 0) == 0) {
           // split backtrace: one history slot per pair of a launch; take up to 4x the wave count (or all pairs)
           if (pb_mode) {
             pb_code_ints = ((int64_t)records * ((band_nch[i] == 3 ? 256 : 64 * band_nch[i]) / 4) + 63) & ~63ll;  // one byte per window position and step
@@ -2315,7 +2315,7 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
       ba.ef = (b->dcfg.endsfree && (b->dcfg.pbf | b->dcfg.pef | b->dcfg.tbf | b->dcfg.tef)) ? 1 : 0;
       ba.pbf = b->dcfg.pbf; ba.pef = b->dcfg.pef; ba.tbf = b->dcfg.tbf; ba.tef = b->dcfg.tef;
       ba.hist = (i > 0 && later_off) ? al->ws + later_off / 4 : al->ws; ba.hist_stride = band_stride[i];
-      const bool split = full && in_count == nullptr && b->max_len > 1000 && knob(al, K_BAND_NO_SPLIT, 0) == 0;
+      const bool split = full && in_count == nullptr && b->max_len > knob(al, K_BAND_SPLIT_MIN, 100) && knob(al, K_BAND_NO_SPLIT, 0) == 0;
       if (split) {
         // history slot per PAIR: as many pairs per launch as the workspace holds; the walks of a launch run
         // afterwards in a thread-per-alignment kernel
