@@ -1270,7 +1270,7 @@ inline bool slim_takes(const BandArgs& a, int nch, bool full, bool adapt, bool s
   if (!a.slim || !seqlds || a.debug != 0) return false;
   if (adapt ? a.heur != 1 : a.heur != 0) return false;                          // wf-adaptive or no heuristic (X-drop: wfa_band_kernel)
   if (nch == (a.oe2 > 0 ? 3 : 2)) return !full || (a.split ? a.pb != 0 : a.h16 != 0);   // piggy-back slots, or the explicit int16 history walked in-kernel
-  if (nch == 4) return !full || (!a.split && a.h16);
+  if (nch == 4) return !full || (a.split ? (a.pb != 0 && a.oe2 == 0) : a.h16 != 0);   // (split: gap-affine only — the 2p form of 256 diagonals would take ~300 registers)
   return false;
 }
 
@@ -1321,7 +1321,7 @@ inline int launch_band_rtc(const BandArgs& a, int nch, bool full, bool adapt, bo
 inline bool slim_rtc_shape_ok(int X, int OE, int E, int OE2) { return OE2 == 0 && (X > OE ? X : OE) <= 12 && E <= 3; }
 inline int launch_slim_rtc(const BandArgs& a, int nch, bool full, long long grid, hipStream_t stream) {
   const int g = a.g, X = a.x / g, OE = a.oe / g, E = a.e / g;
-  const int hist = (nch == 4) ? (full ? 2 : 0) : (full && a.split) ? 1 : full ? 2 : 0;
+  const int hist = (full && a.split) ? 1 : full ? 2 : 0;
   const std::string name = std::string("wfa::") + (nch == 4 ? "wfa_slim_kernel_tail<4, " : "wfa_slim_kernel<2, ") + std::to_string(hist) + ", " + std::to_string(X) + ", " +
                            std::to_string(OE) + ", " + std::to_string(E) + ", 0, 0>";
   return rtc_launch("wfa_slim.hpp", name, (unsigned)grid, 64, (size_t)a.lds_words * 2 * sizeof(uint32_t), stream, &a, sizeof(a));

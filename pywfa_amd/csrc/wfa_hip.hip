@@ -45,7 +45,7 @@ static thread_local std::string g_error;
 // never call getenv.
 #define WFA_COUNTER_WORDS 64   // counters of a batch (wfa_hip_batch::d_counters)
 #define WFA_KNOBS(F)                                                                                              \
-  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(BAND_SPLIT_MIN) F(NO_TINY_INLINE) F(BILEVEL) F(BILEVEL_WIDE_LEVELS) F(BILEVEL_PER_CU) F(BILEVEL_I32) F(BILEVEL_QCAP) F(BILEVEL_LEVELS) F(BILEVEL_LDS) F(BILEVEL_LDS_W) F(BILEVEL_NO_SEQL) F(LANE_DYN) F(LANE_DYN_WAVES) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
+  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(BAND_LDS_MAX) F(BAND_SPLIT_MIN) F(NO_TINY_INLINE) F(BILEVEL) F(BILEVEL_WIDE_LEVELS) F(BILEVEL_PER_CU) F(BILEVEL_I32) F(BILEVEL_QCAP) F(BILEVEL_LEVELS) F(BILEVEL_LDS) F(BILEVEL_LDS_W) F(BILEVEL_NO_SEQL) F(LANE_DYN) F(LANE_DYN_WAVES) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
   F(LANE_FULL) F(LANE_FULL_SPLIT) F(LANE_HEUR) F(SEG_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_ADAPT) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(TILE) F(TILE_T) F(TILE_WT) F(TILE_THREADS) F(TILE_PER_CU) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY) F(PILOT_PCT) F(WIDE_ADAPT_LDS)
@@ -2302,7 +2302,10 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
       ba.min_wf_len = b->dcfg.min_wf_len; ba.max_dist_thr = b->dcfg.max_dist_thr; ba.steps_between = b->dcfg.steps_between;
       ba.heur = b->dcfg.heuristic; ba.xdrop = b->dcfg.xdrop; ba.max_steps = b->dcfg.max_steps; ba.scope = b->dcfg.scope;
       const int words = ((b->max_len + 15) >> 4) + 4;
-      const bool seqlds = ((size_t)words * 8 <= 5120) && knob(al, K_BAND_NO_LDS, 0) == 0;
+      // (round 5: up to 13 KB per wave — reads of up to 26 kb: the 128-diagonal slim kernel then runs four waves per SIMD instead of
+      // seven and is still twice as fast as wfa_band_kernel on HBM-resident sequences (15 kb: 3.1 -> 5.9 M aln/s score); beyond, the
+      // waves a CU can hold are too few)
+      const bool seqlds = ((size_t)words * 8 <= (size_t)knob(al, K_BAND_LDS_MAX, 13312)) && knob(al, K_BAND_NO_LDS, 0) == 0;
       ba.lds_words = seqlds ? words : 0;
       ba.debug = knob(al, K_BAND_DEBUG, 0);
       ba.slim = knob(al, K_BAND_SLIM, 1);   // (0: wfa_band_kernel also where wfa_slim_kernel would take the launch)

@@ -667,7 +667,9 @@ static int launch_slim_shape(const BandArgs& a, int nch, bool full, long long gr
   smem += (size_t)pad_kb << 10;
   if (nch == 4) {
     // the stage behind it: 256 diagonals, explicit history walked in-kernel
-    if (full) hipLaunchKernelGGL((wfa_slim_kernel_tail<4, 2, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+    // (round 5: also as the FIRST stage of reads over 20 kb with CIGARs — piggy-back history of a split launch)
+    if (full && a.split) hipLaunchKernelGGL((wfa_slim_kernel_tail<4, 1, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+    else if (full) hipLaunchKernelGGL((wfa_slim_kernel_tail<4, 2, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
     else hipLaunchKernelGGL((wfa_slim_kernel_tail<4, 0, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
   } else if constexpr (OE2 > 0) {
     if (full && a.split) hipLaunchKernelGGL((wfa_slim_kernel_2p<NCH1, 1, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
