@@ -75,6 +75,7 @@ struct BandArgs {
   int pb_raw;             // piggy-back codes written by wfa_slim_kernel: the four comparison bits as they fall out of the subtractions
                           // (bit 3: mismatch below the best gap, 2: deletion below insertion, 1 / 0: extension of I / D below its
                           // opening); the walk maps them to the codes above through a 16-entry table
+  int win;                // 1: the sequences do not fit LDS — wfa_slim_kernel's windowed form stages lds_words words of each and moves the windows along
   const uint32_t* one;    // host side only: the single pair's SlimOne block (wfa_slim.hpp) — launch_slim_shape passes it as a kernel argument
   uint32_t* dbg;          // counting builds (-DWFA_SLIM_COUNTERS=1) with WFA_HIP_STAGE_TIMING=1: eight counters of wfa_slim_kernel
   int slim;               // 1: launches that fit wfa_slim_kernel (wfa_slim.hpp: 128 diagonals, gap-affine, wf-adaptive, end-to-end,
@@ -1270,6 +1271,7 @@ inline bool slim_takes(const BandArgs& a, int nch, bool full, bool adapt, bool s
   if (!a.slim || !seqlds || a.debug != 0) return false;
   if (adapt ? a.heur != 1 : a.heur != 0) return false;                          // wf-adaptive or no heuristic (X-drop: wfa_band_kernel)
   if (nch == (a.oe2 > 0 ? 3 : 2)) return !full || (a.split ? a.pb != 0 : a.h16 != 0);   // piggy-back slots, or the explicit int16 history walked in-kernel
+  if (a.win) return nch == 4 && a.oe2 == 0 && (!full || (a.split && a.pb != 0));   // (windowed sequences: the 256-diagonal first stage of reads over 26 kb)
   if (nch == 4) return !full || (a.split ? (a.pb != 0 && a.oe2 == 0) : a.h16 != 0);   // (split: gap-affine only — the 2p form of 256 diagonals would take ~300 registers)
   return false;
 }
@@ -1323,7 +1325,7 @@ inline int launch_slim_rtc(const BandArgs& a, int nch, bool full, long long grid
   const int g = a.g, X = a.x / g, OE = a.oe / g, E = a.e / g;
   const int hist = (full && a.split) ? 1 : full ? 2 : 0;
   const std::string name = std::string("wfa::") + (nch == 4 ? "wfa_slim_kernel_tail<4, " : "wfa_slim_kernel<2, ") + std::to_string(hist) + ", " + std::to_string(X) + ", " +
-                           std::to_string(OE) + ", " + std::to_string(E) + ", 0, 0>";
+                           std::to_string(OE) + ", " + std::to_string(E) + (a.win ? ", 0, 0, true>" : ", 0, 0>");
   return rtc_launch("wfa_slim.hpp", name, (unsigned)grid, 64, (size_t)a.lds_words * 2 * sizeof(uint32_t), stream, &a, sizeof(a));
 }
 

@@ -45,7 +45,7 @@ static thread_local std::string g_error;
 // never call getenv.
 #define WFA_COUNTER_WORDS 64   // counters of a batch (wfa_hip_batch::d_counters)
 #define WFA_KNOBS(F)                                                                                              \
-  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(BAND_LDS_MAX) F(BAND_SPLIT_MIN) F(NO_TINY_INLINE) F(BILEVEL) F(BILEVEL_WIDE_LEVELS) F(BILEVEL_PER_CU) F(BILEVEL_I32) F(BILEVEL_QCAP) F(BILEVEL_LEVELS) F(BILEVEL_LDS) F(BILEVEL_LDS_W) F(BILEVEL_NO_SEQL) F(LANE_DYN) F(LANE_DYN_WAVES) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
+  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(BAND_LDS_MAX) F(BAND_NO_WIN) F(BAND_SPLIT_MIN) F(NO_TINY_INLINE) F(BILEVEL) F(BILEVEL_WIDE_LEVELS) F(BILEVEL_PER_CU) F(BILEVEL_I32) F(BILEVEL_QCAP) F(BILEVEL_LEVELS) F(BILEVEL_LDS) F(BILEVEL_LDS_W) F(BILEVEL_NO_SEQL) F(LANE_DYN) F(LANE_DYN_WAVES) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
   F(LANE_FULL) F(LANE_FULL_SPLIT) F(LANE_HEUR) F(SEG_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_ADAPT) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(TILE) F(TILE_T) F(TILE_WT) F(TILE_THREADS) F(TILE_PER_CU) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY) F(PILOT_PCT) F(WIDE_ADAPT_LDS)
@@ -2305,8 +2305,11 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
       // (round 5: up to 13 KB per wave — reads of up to 26 kb: the 128-diagonal slim kernel then runs four waves per SIMD instead of
       // seven and is still twice as fast as wfa_band_kernel on HBM-resident sequences (15 kb: 3.1 -> 5.9 M aln/s score); beyond, the
       // waves a CU can hold are too few)
-      const bool seqlds = ((size_t)words * 8 <= (size_t)knob(al, K_BAND_LDS_MAX, 13312)) && knob(al, K_BAND_NO_LDS, 0) == 0;
+      bool seqlds = ((size_t)words * 8 <= (size_t)knob(al, K_BAND_LDS_MAX, 13312)) && knob(al, K_BAND_NO_LDS, 0) == 0;
       ba.lds_words = seqlds ? words : 0;
+      // longer reads, wf-adaptive or no heuristic, gap-affine: wfa_slim_kernel on WINDOWS of the sequences (10 k bases of each in LDS,
+      // moved along as the alignment advances) — launches it does not take (slim_takes) read the sequences from HBM as before
+      const bool try_win = !seqlds && b->ncomp == 3 && b->dcfg.heuristic != WFA_HEUR_XDROP && knob(al, K_BAND_NO_LDS, 0) == 0 && knob(al, K_BAND_NO_WIN, 0) == 0;
       ba.debug = knob(al, K_BAND_DEBUG, 0);
       ba.slim = knob(al, K_BAND_SLIM, 1);   // (0: wfa_band_kernel also where wfa_slim_kernel would take the launch)
       ba.pb_raw = 0;
@@ -2362,6 +2365,10 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
           ba.work_begin = (uint32_t)w0; ba.nwork = cnt;
           const long long grid = std::min<long long>((long long)al->cu_count * knob(al, K_BAND_WAVES_PER_CU, 128), cnt);
           if (!all_fit) { const int drc = dual.before_align(launch); if (drc != WFA_HIP_OK) return drc; }
+          if (try_win && !ba.win) {   // (decided once per stage: the launches of a stage share everything slim_takes looks at)
+            wfa::BandArgs t = ba; t.win = 1; t.lds_words = 643;
+            if (wfa::slim_launches(t, band_nch[i], full, adapt, true)) { ba.win = 1; ba.lds_words = 643; seqlds = true; }
+          }
           ba.pb_raw = wfa::slim_launches(ba, band_nch[i], full, adapt, seqlds) ? 1 : 0;   // (wfa_slim_kernel writes comparison bits; the walk below decodes them)
           if (wfa::launch_band(ba, band_nch[i], full, adapt, seqlds, grid, stream) != 0) { al->err = "band kernel launch failed"; return WFA_HIP_EDEVICE; }
           hipStream_t ws_ = stream;
@@ -2374,6 +2381,10 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
         if (later_off && i + 1 < n_stages && dual.on) pending_walks = dual;
         else { const int drc = dual.end(); if (drc != WFA_HIP_OK) return drc; }
       } else {
+        if (try_win) {
+          wfa::BandArgs t = ba; t.win = 1; t.lds_words = 643;
+          if (wfa::slim_launches(t, band_nch[i], full, adapt, true)) { ba.win = 1; ba.lds_words = 643; seqlds = true; }
+        }
         if (wfa::launch_band(ba, band_nch[i], full, adapt, seqlds, band_grid[i], stream) != 0) { al->err = "band kernel launch failed"; return WFA_HIP_EDEVICE; }
       }
       if (knob(al, K_STAGE_TIMING, 0) != 0) {  // development aid: synchronises (the time of the stage is the gap between these lines' events)

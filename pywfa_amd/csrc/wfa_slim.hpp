@@ -66,8 +66,8 @@ __device__ __forceinline__ void slim_keep(int& r, unsigned long long mask) {
 
 // one probe of the extension on doubled coordinates: v2 / h2 = bit positions in the packed pattern / text; returns the number of
 // matching BITS (even; >= 64: none of the 32 bases differs)
-__device__ __forceinline__ uint32_t slim_probe(const uint32_t* sP, const uint32_t* sT, int v2, int h2) {
-  const int pi = v2 >> 5, ti = h2 >> 5;
+__device__ __forceinline__ uint32_t slim_probe(const uint32_t* sP, const uint32_t* sT, int v2, int h2, int pwb = 0, int twb = 0) {
+  const int pi = (v2 >> 5) - pwb, ti = (h2 >> 5) - twb;   // (pwb / twb: first word of the staged window, 0 unless WIN)
   const uint32_t p0 = sP[pi], p1 = sP[pi + 1], p2 = sP[pi + 2], t0 = sT[ti], t1 = sT[ti + 1], t2 = sT[ti + 2];
   const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v2) ^ __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h2);
   const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, (uint32_t)v2) ^ __builtin_amdgcn_alignbit(t2, t1, (uint32_t)h2);
@@ -85,9 +85,15 @@ __device__ __forceinline__ unsigned long long slim_range_mask(int c, int lo, int
 // in wfa_band_pb_bt_kernel afterwards); 2 the explicit history of wfa_band_kernel's unsplit form ({M, I, D, window base} per window
 // position and step in the workgroup's slice, walked in-kernel by band_backtrace) — the stage BEHIND the split one, which takes the
 // few pairs a window hands on: there the latency of one alignment is what counts, and this step is a third of wfa_band_kernel's.
-template <int NCH, int HIST, int X, int OE, int E, int OE2, int E2>
+// WIN (round 5): reads too long for LDS — a WINDOW of a.lds_words words of each sequence is staged and moved along as the alignment
+// advances.  Offsets never decrease from one wavefront to the next (M, I: h + 1; D: the same h on the diagonal below, where v = h - k
+// is one more), so the smallest position of a live diagonal is a lower bound for every later read; the extension tests before each
+// round of probes whether a live diagonal is about to read past the window's end and then re-stages both windows from the smallest
+// live positions (a pair whose live diagonals span more than a window is handed on).
+template <int NCH, int HIST, int X, int OE, int E, int OE2, int E2, bool WIN = false>
 __device__ __forceinline__ void wfa_slim_body(const BandArgs& a, const uint32_t* __restrict__ inl = nullptr) {
   constexpr bool FULL = HIST != 0, PBH = HIST == 1, XH = HIST == 2;
+  static_assert(!WIN || OE2 == 0, "the windowed form: gap-affine");
   constexpr bool TWO = OE2 > 0;  // gap-affine-2p: second pair of gap components (R/wavefront_compute_affine2p.c:45-106)
   constexpr int E2D = TWO ? E2 : 1;
   typedef Band<NCH> BD;
@@ -129,7 +135,19 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a, const uint32_t*
     const uint32_t* gT = wbase + pm.t_woff;
     const int nwp = (plen + 15) >> 4, nwt = (tlen + 15) >> 4;
     bool fallback = false;
-    if (nwp + 3 > a.lds_words || nwt + 3 > a.lds_words || max_records <= 1 || (TWO && 2 * max(plen, tlen) > 32000)) fallback = true;   // (2p: doubled offsets as int16)
+    int pwb = 0, twb = 0;             // WIN: first staged word of each sequence
+    int plim2 = INT_MAX, tlim2 = INT_MAX;   // WIN: the first (doubled) position whose probe would read past the staged words
+    auto restage = [&](int np_, int nt_) {   // (uniform: every lane of the wave)
+      pwb = np_; twb = nt_;
+      __syncthreads();
+      for (int i = lane; i < a.lds_words; i += 64) { const int gi = pwb + i; sP[i] = (gi < nwp) ? gP[gi] : 0u; }
+      for (int i = lane; i < a.lds_words; i += 64) { const int gi = twb + i; sT[i] = (gi < nwt) ? gT[gi] : 0u; }
+      __syncthreads();
+      plim2 = (pwb + a.lds_words - 2) << 5; tlim2 = (twb + a.lds_words - 2) << 5;
+    };
+    if (max_records <= 1 || (TWO && 2 * max(plen, tlen) > 32000)) fallback = true;   // (2p: doubled offsets as int16)
+    else if (WIN) restage(0, 0);
+    else if (nwp + 3 > a.lds_words || nwt + 3 > a.lds_words) fallback = true;
     else {
       __syncthreads();
       for (int i = lane; i < nwp + 3; i += 64) sP[i] = (i < nwp) ? gP[i] : 0u;
@@ -236,18 +254,37 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a, const uint32_t*
             }
           } else {
             bool more;
+            bool go = true;   // (WIN: cleared when the live diagonals do not fit a window: the pair is handed on)
             do {
               more = false;
 #ifdef WFA_SLIM_COUNTERS
               ++cnt_rounds;
 #endif
+              if (WIN) {
+                auto past = [&]() {
+                  bool o = false;
 #pragma unroll
-              for (int c = 0; c < ACT; ++c) {
-                const uint32_t m2 = min(slim_probe(sP, sT, v2[c], h2[c]), 64u);
-                v2[c] += (int)m2; h2[c] += (int)m2;
-                more |= (m2 == 64u) && (h2[c] < lim2[c]);   // (past the end the zero padding of both sequences would match on)
+                  for (int c = 0; c < ACT; ++c) o |= (cur[c] >= 0) && (h2[c] >= tlim2 || v2[c] >= plim2);
+                  return __builtin_amdgcn_ballot_w64(o) != 0ull;
+                };
+                if (past()) {   // (scalar branch) move both windows up to the smallest live positions
+                  int mh = INT_MAX, mv = INT_MAX;
+#pragma unroll
+                  for (int c = 0; c < ACT; ++c) { const bool lv = cur[c] >= 0; mh = min(mh, lv ? h2[c] : INT_MAX); mv = min(mv, lv ? v2[c] : INT_MAX); }
+                  mh = slim_wave_min(mh); mv = slim_wave_min(mv);
+                  restage(max(0, (mv >> 5) - 1), max(0, (mh >> 5) - 1));
+                  if (past()) { leave = 3; togo = 0; go = false; }
+                }
               }
-            } while (__builtin_amdgcn_ballot_w64(more) != 0ull);
+              if (go) {
+#pragma unroll
+                for (int c = 0; c < ACT; ++c) {
+                  const uint32_t m2 = min(slim_probe(sP, sT, v2[c], h2[c], pwb, twb), 64u);
+                  v2[c] += (int)m2; h2[c] += (int)m2;
+                  more |= (m2 == 64u) && (h2[c] < lim2[c]);   // (past the end the zero padding of both sequences would match on)
+                }
+              }
+            } while (go && __builtin_amdgcn_ballot_w64(more) != 0ull);
           }
 #pragma unroll
           for (int c = 0; c < ACT; ++c) {
@@ -261,6 +298,7 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a, const uint32_t*
         unsigned long long any_live = 0ull;
 #pragma unroll
         for (int c = 0; c < ACT; ++c) any_live |= live[c];
+        if (WIN && leave != 0) any_live = 0ull;   // (handed on inside the extension: nothing of this step counts)
         if (any_live) {
           dead_steps = 0;
 #ifdef WFA_SLIM_COUNTERS
@@ -634,10 +672,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(slim_wa
 wfa_slim_kernel(const BandArgs a) {   // gap-affine, 128 diagonals: seven waves per SIMD (<= 72 VGPRs; the sequences of 10 kb reads in LDS allow eight)
   wfa_slim_body<NCH, HIST, X, OE, E, OE2, E2>(a);
 }
-template <int NCH, int HIST, int X, int OE, int E, int OE2, int E2>
+template <int NCH, int HIST, int X, int OE, int E, int OE2, int E2, bool WIN = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 8)))
 wfa_slim_kernel_tail(const BandArgs a) {   // 256 diagonals, the stage behind the first window: few pairs; at least two waves per SIMD
-  wfa_slim_body<NCH, HIST, X, OE, E, OE2, E2>(a);   // (gap-affine-2p would take 297 registers: C4's tail is a few thousand pairs)
+  wfa_slim_body<NCH, HIST, X, OE, E, OE2, E2, WIN>(a);   // (gap-affine-2p would take 297 registers: C4's tail is a few thousand pairs)
 }
 template <int NCH, int HIST, int X, int OE, int E, int OE2, int E2>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WFA_SLIM_WAVES_2P, WFA_SLIM_WAVES_2P)))
@@ -668,6 +706,14 @@ static int launch_slim_shape(const BandArgs& a, int nch, bool full, long long gr
   if (nch == 4) {
     // the stage behind it: 256 diagonals, explicit history walked in-kernel
     // (round 5: also as the FIRST stage of reads over 20 kb with CIGARs — piggy-back history of a split launch)
+    if constexpr (OE2 == 0) {
+      // reads beyond what LDS holds: the windowed form (first stage of reads over 26 kb: score only, or the piggy-back history)
+      if (a.win && (!full || a.split)) {
+        if (full) hipLaunchKernelGGL((wfa_slim_kernel_tail<4, 1, X, OE, E, OE2, E2, true>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+        else hipLaunchKernelGGL((wfa_slim_kernel_tail<4, 0, X, OE, E, OE2, E2, true>), dim3((unsigned)grid), dim3(64), smem, stream, a);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+      }
+    }
     if (full && a.split) hipLaunchKernelGGL((wfa_slim_kernel_tail<4, 1, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
     else if (full) hipLaunchKernelGGL((wfa_slim_kernel_tail<4, 2, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);
     else hipLaunchKernelGGL((wfa_slim_kernel_tail<4, 0, X, OE, E, OE2, E2>), dim3((unsigned)grid), dim3(64), smem, stream, a);

@@ -126,3 +126,37 @@ def test_slim_kernel_without_a_heuristic(gpu, cfg_idx, scope, monkeypatch):
         assert a.status == o["status"][i]
         if scope == "full":
             assert bytes(a._ops) == o["cigars"][i]
+
+
+@pytest.mark.parametrize("kw", [dict(span="end-to-end", heuristic="adaptive"),
+                                dict(span="ends-free", heuristic="adaptive", pattern_begin_free=30, text_end_free=50),
+                                dict(span="end-to-end", heuristic="adaptive", mismatch=5, gap_opening=6, gap_extension=2)])
+@pytest.mark.parametrize("scope", ["full", "score"])
+def test_slim_kernel_on_windows_of_long_reads(gpu, kw, scope, monkeypatch):
+    """Reads whose sequences do not fit LDS (over 26 kb): the 256-diagonal slim kernel stages WINDOWS of the two sequences and moves them
+    along (csrc/wfa_slim.hpp, WIN).  30-70 kb reads at 2-10 %, a pair of identical 60 kb sequences and one with a 40 kb identical stretch
+    (extensions that cross several windows) against the oracle, and against wfa_band_kernel on HBM-resident sequences (WFA_HIP_BAND_NO_WIN=1)."""
+    rng = np.random.default_rng(5)
+    pats, txts = [], []
+    for i, (L, e) in enumerate([(30000, 0.08), (45000, 0.02), (70000, 0.05), (33000, 0.10), (52000, 0.08), (28000, 0.03)]):
+        b = datagen.generate(2, L, e, 900 + i)
+        for j in range(2):
+            p, t = datagen.pair_strings(b, j)
+            pats.append(p); txts.append(t)
+    same = "".join(rng.choice(list("ACGT"), size=60000))
+    pats.append(same); txts.append(same)
+    stretch = "".join(rng.choice(list("ACGT"), size=40000))
+    b = datagen.generate(1, 8000, 0.08, 77)
+    p, t = datagen.pair_strings(b, 0)
+    pats.append(p[:4000] + stretch + p[4000:]); txts.append(t[:4000] + stretch + t[4000:])
+    batch = datagen.from_strings(pats, txts)
+    kw = common.clamp_free(dict(kw, scope=scope), batch)
+    oc, nc = common.configs_pair(**kw)
+    full = oc.scope == 1
+    o = loader.run(loader.oracle(), oc, batch, want_cigar=full)
+    monkeypatch.delenv("WFA_HIP_BAND_NO_WIN", raising=False)
+    score, status, cigars = common.gpu_run(nc, batch, full, resident=True)
+    common.assert_same(o, score, status, cigars, batch, f"slim on windows {kw}")
+    monkeypatch.setenv("WFA_HIP_BAND_NO_WIN", "1")
+    score0, status0, cigars0 = common.gpu_run(nc, batch, full, resident=False)
+    assert np.array_equal(score, score0) and np.array_equal(status, status0) and cigars == cigars0
