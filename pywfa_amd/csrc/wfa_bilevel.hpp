@@ -1007,7 +1007,10 @@ int launch_bl_finish(const BlArgs& a, int grid, hipStream_t stream);
 template <int NCOMP>
 inline int launch_bl_split_ncomp(bool packed, bool i16, int threads, bool seql, const BlArgs& a, int grid, size_t smem, hipStream_t stream) {
 #define WFA_BL_LAUNCH(P, OT, T, SQ) hipLaunchKernelGGL((bl_split_kernel<NCOMP, P, OT, T, false, SQ>), dim3(grid), dim3(T), smem, stream, a)
-  if (threads == 256) {
+  if (threads == 1024 && packed) {   // (windows tens of thousands of diagonals wide: 100 kb reads' top levels; 2-bit pairs)
+    if (seql) { if (i16) WFA_BL_LAUNCH(true, short, 1024, true); else WFA_BL_LAUNCH(true, int, 1024, true); }
+    else { if (i16) WFA_BL_LAUNCH(true, short, 1024, false); else WFA_BL_LAUNCH(true, int, 1024, false); }
+  } else if (threads >= 256) {
     if (packed && seql) { if (i16) WFA_BL_LAUNCH(true, short, 256, true); else WFA_BL_LAUNCH(true, int, 256, true); }
     else if (packed) { if (i16) WFA_BL_LAUNCH(true, short, 256, false); else WFA_BL_LAUNCH(true, int, 256, false); }
     else { if (i16) WFA_BL_LAUNCH(false, short, 256, false); else WFA_BL_LAUNCH(false, int, 256, false); }

@@ -45,7 +45,7 @@ static thread_local std::string g_error;
 // never call getenv.
 #define WFA_COUNTER_WORDS 64   // counters of a batch (wfa_hip_batch::d_counters)
 #define WFA_KNOBS(F)                                                                                              \
-  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(BAND_LDS_MAX) F(BAND_NO_WIN) F(BAND_SPLIT_MIN) F(NO_TINY_INLINE) F(BILEVEL) F(BILEVEL_WIDE_LEVELS) F(BILEVEL_PER_CU) F(BILEVEL_I32) F(BILEVEL_QCAP) F(BILEVEL_LEVELS) F(BILEVEL_LDS) F(BILEVEL_LDS_W) F(BILEVEL_NO_SEQL) F(LANE_DYN) F(LANE_DYN_WAVES) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
+  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(BAND_LDS_MAX) F(BAND_NO_WIN) F(BAND_SPLIT_MIN) F(NO_TINY_INLINE) F(BILEVEL) F(BILEVEL_WIDE_LEVELS) F(BILEVEL_PER_CU) F(BILEVEL_I32) F(BILEVEL_QCAP) F(BILEVEL_LEVELS) F(BILEVEL_LDS) F(BILEVEL_NO_1024) F(BILEVEL_HUGE_MIN) F(BILEVEL_LDS_W) F(BILEVEL_NO_SEQL) F(LANE_DYN) F(LANE_DYN_WAVES) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
   F(LANE_FULL) F(LANE_FULL_SPLIT) F(LANE_HEUR) F(SEG_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_ADAPT) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(TILE) F(TILE_T) F(TILE_WT) F(TILE_THREADS) F(TILE_PER_CU) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY) F(PILOT_PCT) F(WIDE_ADAPT_LDS)
@@ -1682,8 +1682,12 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
               la.from_wide = 1;
             }
           }
-          const int threads = (lv < wide_levels) ? 256 : 64;
-          const int lgrid = (threads == 256) ? std::min(bl_grid, std::max(al->cu_count, bl_grid / 2)) : bl_grid;   // (a slice of the workspace per workgroup: never more than bl_grid)
+          // (expected width of a level's wavefronts: a quarter of the read length at the top, half of it per level; sixteen waves per
+          // window from 8 192 diagonals on (measured at 20 / 40 / 100 kb: 1 024 / 2 048 / 4 096 / 8 192): 100 kb reads' top levels — a step is then 6 passes over the wavefront instead of 24)
+          const bool huge = kind == 0 && (((int64_t)b->max_len / 4) >> lv) >= knob(al, K_BILEVEL_HUGE_MIN, 8192) && knob(al, K_BILEVEL_NO_1024, 0) == 0;
+          const int threads = huge ? 1024 : (lv < wide_levels) ? 256 : 64;
+          const int lgrid = huge ? std::min(bl_grid, 2 * al->cu_count)
+                                 : (threads == 256) ? std::min(bl_grid, std::max(al->cu_count, bl_grid / 2)) : bl_grid;   // (a slice of the workspace per workgroup: never more than bl_grid)
           la.lds_seq_words = full_seq_words;
           ok = ok && wfa::launch_bl_split_any(b->ncomp, kind == 0, bl_i16, threads, seql, la, (int)std::min<int64_t>(lgrid, lv == 0 ? (int64_t)cnt : (int64_t)lgrid), stream) == 0;
           la.from_wide = 0;
