@@ -1684,7 +1684,10 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
           }
           // (expected width of a level's wavefronts: a quarter of the read length at the top, half of it per level; sixteen waves per
           // window from 8 192 diagonals on (measured at 20 / 40 / 100 kb: 1 024 / 2 048 / 4 096 / 8 192): 100 kb reads' top levels — a step is then 6 passes over the wavefront instead of 24)
-          const bool huge = kind == 0 && (((int64_t)b->max_len / 4) >> lv) >= knob(al, K_BILEVEL_HUGE_MIN, 8192) && knob(al, K_BILEVEL_NO_1024, 0) == 0;
+          const int64_t w_est = ((int64_t)b->max_len / 4) >> lv;
+          const bool few_windows = ((int64_t)cnt << std::min(lv, 20)) <= 2 * (int64_t)al->cu_count;   // (every window of the level resident at sixteen waves each)
+          const bool huge = kind == 0 && knob(al, K_BILEVEL_NO_1024, 0) == 0 &&
+                            (w_est >= knob(al, K_BILEVEL_HUGE_MIN, 8192) || (few_windows && w_est >= 2048));   // (small batches: 64 / 256 x 10 kb +20 %)
           const int threads = huge ? 1024 : (lv < wide_levels) ? 256 : 64;
           const int lgrid = huge ? std::min(bl_grid, 2 * al->cu_count)
                                  : (threads == 256) ? std::min(bl_grid, std::max(al->cu_count, bl_grid / 2)) : bl_grid;   // (a slice of the workspace per workgroup: never more than bl_grid)
