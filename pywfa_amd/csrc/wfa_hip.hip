@@ -1206,7 +1206,8 @@ static int pilot_first_width(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t 
 static int pilot_band(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream) {
   const unsigned rtc_failures = wfa::rtc_failure_count();
   if (b->band_pick != 0 || b->n_packed < 32768u) return WFA_HIP_OK;
-  if (b->dcfg.heuristic != WFA_HEUR_NONE || b->ncomp != 3 || b->max_len <= 300 || b->max_len > 1200) return WFA_HIP_OK;
+  const bool two = b->ncomp == 5;   // (gap-affine-2p: the 192- and the 256-diagonal stage, reads of up to 2 kb)
+  if (b->dcfg.heuristic != WFA_HEUR_NONE || (b->ncomp != 3 && !two) || (two ? (b->max_len <= 100 || b->max_len > 2000) : (b->max_len <= 300 || b->max_len > 1200))) return WFA_HIP_OK;
   if (!wfa::band_supported(b->dcfg, b->ncomp) || knob(al, K_NO_BAND, 0) != 0 || knob(al, K_BAND_NCH, 0) != 0) return WFA_HIP_OK;
   const uint32_t np = 4096u, stride = b->n_packed / np;
   uint32_t* plist = b->d_fb_list2[0];
@@ -1219,8 +1220,9 @@ static int pilot_band(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream)
   memset(&ba, 0, sizeof(ba));
   ba.words = b->d_words; ba.meta = b->d_meta; ba.worklist = psample; ba.nwork = np;
   ba.score = b->d_score; ba.status = b->d_status; ba.fb_list = plist; ba.fb_count = pcount;
-  ba.g = wfa::band_gcd(b->dcfg, false);
+  ba.g = wfa::band_gcd(b->dcfg, two);
   ba.x = b->dcfg.x; ba.oe = b->dcfg.o1 + b->dcfg.e1; ba.e = b->dcfg.e1;
+  if (two) { ba.oe2 = b->dcfg.o2 + b->dcfg.e2; ba.e2 = b->dcfg.e2; }
   ba.min_wf_len = b->dcfg.min_wf_len; ba.max_dist_thr = b->dcfg.max_dist_thr; ba.steps_between = b->dcfg.steps_between;
   ba.heur = b->dcfg.heuristic; ba.xdrop = b->dcfg.xdrop; ba.max_steps = b->dcfg.max_steps; ba.scope = b->dcfg.scope;
   const int words = ((b->max_len + 15) >> 4) + 4;
@@ -1229,7 +1231,7 @@ static int pilot_band(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream)
   ba.h16 = 1;
   ba.ef = (b->dcfg.endsfree && (b->dcfg.pbf | b->dcfg.pef | b->dcfg.tbf | b->dcfg.tef)) ? 1 : 0;
   ba.pbf = b->dcfg.pbf; ba.pef = b->dcfg.pef; ba.tbf = b->dcfg.tbf; ba.tef = b->dcfg.tef;
-  if (wfa::launch_band(ba, 4, false, false, true, (long long)np, stream) != 0) return pilot_launch_failed(al, b, rtc_failures);
+  if (wfa::launch_band(ba, 4, false, false, true, (long long)np, stream) != 0) return pilot_launch_failed(al, b, rtc_failures);   // (the widest window: what it hands on, both stages hand on)
   uint32_t handed = 0;
   HIP_TRY(al, hipMemcpyAsync(&handed, pcount, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   HIP_TRY(al, hipStreamSynchronize(stream));
@@ -1773,7 +1775,7 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
     if (!tiny && wfa::band_supported(b->dcfg, b->ncomp) && (b->ncomp != 5 || b->max_len < 32000) && knob(al, K_NO_BAND, 0) == 0) {
       if (b->ncomp == 5) {
         // gap-affine-2p wavefronts are wide (C4: 99 % need more than 108 diagonals, 2.6 % more than 172)
-        band_nch[n_stages++] = 3; band_nch[n_stages++] = 4;
+        if (b->band_pick != 2) { band_nch[n_stages++] = 3; band_nch[n_stages++] = 4; }   // (2: the pilot of batch_build saw most pairs outgrow 256 diagonals)
       } else if (adapt) {
         // (the wavefront a cut-off keeps grows with the read: at 10 kb 3 % of the pairs outgrow the 128-diagonal window, at 100 kb 46 % —
         // and a second stage of few, lone waves runs at its pairs' latency: reads over 20 kb start in the 256-diagonal window.
@@ -1919,7 +1921,8 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
         tg.T = knob(al, K_TILE_T, (wide_two || small_geom) ? 8 : 16) & ~1;
         tg.Wt = knob(al, K_TILE_WT, (wide_two || small_geom) ? 128 : 256);
         const int bw = tg.Wt - 2 * tg.T;
-        const int tthreads = std::max(64, std::min(512, knob(al, K_TILE_THREADS, small_geom ? 128 : 256) & ~63));
+        // (gap-affine-2p reads of up to 1.2 kb: one wave per alignment — 300 / 600 / 1 000 bp at 8 %: +28 / +51 / +29 % over four)
+        const int tthreads = std::max(64, std::min(512, knob(al, K_TILE_THREADS, small_geom ? 128 : (wide_two && b->max_len <= 1200) ? 64 : 256) & ~63));
         if (tg.T >= 2 && tg.T <= WFA_TILE_MAX_T && tg.Wt >= 64 && tg.Wt % 64 == 0 && tg.Wt <= 256 && bw >= 16 &&
             wfa::tile_cand_count(tg) <= WFA_TILE_MAX_ROWS) {
           ta.gs = w0.g; ta.seq_words = w0.seq_words;

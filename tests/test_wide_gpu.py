@@ -270,17 +270,17 @@ def test_wide_kernel_takes_wf_adaptive_leftovers_of_the_banded_stages(gpu):
     common.assert_same(o, score, status, cigars, batch, "wide takes the banded stages' wf-adaptive leftovers")
 
 
-@pytest.mark.parametrize("L,e", [(600, 0.10), (900, 0.01)])
-def test_exact_midlength_batches_with_the_band_pilot(gpu, L, e):
+@pytest.mark.parametrize("L,e,dist", [(600, 0.10, "affine"), (900, 0.01, "affine"), (300, 0.08, "affine2p"), (500, 0.01, "affine2p")])
+def test_exact_midlength_batches_with_the_band_pilot(gpu, L, e, dist):
     """Round 5: exact reads of 300 - 1 200 bases in batches of >= 32 768 pairs — a pilot on 4 096 sampled pairs decides whether the
     256-diagonal register window runs before the tiled rows (csrc/wfa_hip.hip: pilot_band; 600 bp at 10 %: it does not, 900 bp at
-    1 %: it does) — against the oracle on every 80th pair, score and full CIGAR."""
+    1 %: it does; gap-affine-2p likewise with its 192- and 256-diagonal stages) — against the oracle on every 80th pair, score and full CIGAR."""
     n = 33000
     batch = datagen.generate(n, L, e, 131)
     idx = np.arange(0, n, 80)
     sub = datagen.subset(batch, idx)
     for scope in ("score", "full"):
-        oc, nc = common.configs_pair(span="end-to-end", scope=scope)
+        oc, nc = common.configs_pair(span="end-to-end", scope=scope, distance=dist)
         full = scope == "full"
         o = loader.run(loader.oracle(), oc, sub, want_cigar=full)
         score, status, cigars = common.gpu_run(nc, batch, full, resident=True)
