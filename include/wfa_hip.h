@@ -251,6 +251,14 @@ int wfa_hip_plan_shards(int64_t n, const int32_t* p_len, const int32_t* t_len, i
  * exports it) or WFA_HIP_HOST_SHARE.  Returns WFA_HIP_OK or WFA_HIP_EINVAL. */
 int wfa_hip_plan_host_threads(int sharers, int hw_threads, int* pack_threads, int* copy_threads);
 
+/* What the upload pipeline of this aligner knows about the host, and what its last pipelined upload (a batch of >= 256 k pairs) did
+ * (diagnostics for the PCIe-inclusive rate; no counterpart in the reference, whose aligner never leaves the host).  info[0..7]:
+ * NUMA node of the device's PCIe slot (-1 unknown), CPUs of that node this process may use (0: no binding possible), binding mode
+ * (WFA_HIP_NUMA: 0 never, 1 always, 2 only when the caller's input lives on the device's node), node of the caller's pages in the last
+ * upload (-1 unknown), whether that upload's spawned workers were bound (the caller's own thread never is), packing threads, copy
+ * threads, CPUs of the process.  n >= 8.  Returns WFA_HIP_OK or WFA_HIP_EINVAL. */
+int wfa_hip_upload_info(const wfa_hip_aligner_t* aligner, int32_t* info, int n);
+
 /* One aligner per entry of devices[] (an ordinal may repeat: several host threads then feed that device).
  * Returns NULL on error (see wfa_hip_global_error). */
 wfa_hip_multi_t* wfa_hip_multi_create(const wfa_hip_config_t* cfg, const int* devices, int ndevices);

@@ -60,7 +60,7 @@ SYMBOLS = [
     "wfa_hip_plan_shards", "wfa_hip_plan_host_threads", "wfa_hip_multi_create", "wfa_hip_multi_destroy", "wfa_hip_multi_set_config",
     "wfa_hip_multi_last_error", "wfa_hip_multi_align_batch", "wfa_hip_pack_2bit", "wfa_hip_batch_extent",
     "wfa_hip_align_batch_packed2bits", "wfa_hip_batch_create_packed2bits", "wfa_hip_cigar_sprint_pretty",
-    "wfa_hip_batch_extent_packed2bits", "wfa_hip_align_pair",
+    "wfa_hip_batch_extent_packed2bits", "wfa_hip_align_pair", "wfa_hip_upload_info",
 ]
 
 
@@ -113,6 +113,7 @@ def lib():
     L.wfa_hip_plan_shards.argtypes = [i64, vp, vp, ctypes.c_int, vp]
     L.wfa_hip_plan_host_threads.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     L.wfa_hip_pack_2bit.argtypes = [vp, ctypes.c_int32, vp, ctypes.c_int]
+    L.wfa_hip_upload_info.argtypes = [vp, vp, ctypes.c_int]
     L.wfa_hip_batch_extent.argtypes = [i64, vp, vp, vp, vp]
     L.wfa_hip_batch_extent.restype = i64
     L.wfa_hip_batch_extent_packed2bits.argtypes = [i64, vp, vp, vp, vp]
@@ -240,6 +241,14 @@ class Aligner:
         self.device = device
         self._batches = weakref.WeakSet()
         self._pair_state = None
+
+    def upload_info(self):
+        """wfa_hip_upload_info: what the upload pipeline knows about the host and what its last pipelined upload did."""
+        info = np.zeros(8, np.int32)
+        if lib().wfa_hip_upload_info(self._h, _ptr(info), 8) != OK:
+            raise NativeError("wfa_hip_upload_info failed")
+        keys = ("gpu_numa_node", "gpu_node_cpus", "numa_mode", "input_numa_node", "workers_bound", "pack_threads", "copy_threads", "process_cpus")
+        return dict(zip(keys, (int(x) for x in info)))
 
     def close(self):
         if getattr(self, "_h", None):

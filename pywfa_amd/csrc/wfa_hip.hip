@@ -22,6 +22,8 @@
 #include <ctype.h>
 #include <pthread.h>
 #include <sched.h>
+#include <unistd.h>
+#include <sys/syscall.h>
 
 #include "wfa_hip.h"
 #include "wfa_common.hpp"
@@ -76,9 +78,13 @@ struct WfaKnobs {
 };
 
 struct wfa_hip_aligner {
-  int numa_state = 0;     // 0 not looked up, 1 worker threads are bound to `numa_cpus`, 2 no binding (no NUMA information, too few CPUs, WFA_HIP_NO_NUMA=1)
+  int numa_state = 0;     // 0 not looked up, 1 the device's node and its CPUs are known (`numa_cpus`), 2 no binding ever (no NUMA information, one node, too few CPUs, WFA_HIP_NUMA=0)
   int numa_node = -1;     // NUMA node of the device's PCIe slot
   cpu_set_t numa_cpus;    // that node's CPUs, as far as this process may run on them
+  int numa_mode = 0;      // WFA_HIP_NUMA: 0 never bind, 1 always bind the spawned upload workers to the device's node, 2 only when the caller's input lives there
+  cpu_set_t proc_cpus;    // the process's affinity mask when the aligner was created (before anything here bound a thread)
+  bool proc_cpus_valid = false;
+  int last_src_node = -1, last_bound = 0;   // the last pipelined upload: node of the caller's pages (-1 unknown), workers bound or not
   int host_share = 1;     // aligners / processes feeding GPUs from this host (thread plan of the upload pipeline)
   std::string rtc_note;   // why the run-time kernels were switched off (wfa_hip_batch_run), empty otherwise
   int device = 0;
@@ -461,6 +467,8 @@ extern "C" wfa_hip_aligner_t* wfa_hip_create(const wfa_hip_config_t* cfg, int de
     if (!(hs && *hs)) hs = getenv("LOCAL_WORLD_SIZE");
     al->host_share = (hs && atoi(hs) > 0) ? std::min(atoi(hs), 64) : 1;
   }
+  // the process's CPUs as they are now, before any upload worker is bound (numa_lookup must not read a mask this library narrowed)
+  al->proc_cpus_valid = sched_getaffinity(getpid(), sizeof(al->proc_cpus), &al->proc_cpus) == 0;
   return al;
 }
 
@@ -572,13 +580,25 @@ static int staged_pack_threads(const wfa_hip_aligner* al) {
 
 // the ring serves both forms of the upload: sized for the larger team so that alternating calls do not re-allocate it
 // The pinned ring is allocated with hipHostMallocDefault: without hipHostMallocNumaUser HIP places pinned host memory on the NUMA node
-// closest to the current device.  The threads that fill it (2-bit packing, copies) are bound to that node's CPUs here, so that on a
-// two-socket host eight devices' pipelines do not pull their slots across the socket link.  The node comes from
-// sysfs (the device's PCI address), the CPUs are intersected with this process's own affinity mask; anything missing = no binding.
+// closest to the current device.  Round 5 bound the threads that fill it (2-bit packing, copies) to that node's CPUs whatever the
+// call; the driver's run of round 5 then measured 187 M aln/s where round 4 had 332 M: a packer READS 300 B of the caller's pages per
+// pair and WRITES 92 B into the ring, so where the caller's pages live matters three times more than where the ring lives, and on
+// a box whose GPU hangs off the other socket every bound packer pulled its input across the socket link.  Round 6 (WFA_HIP_NUMA):
+//   "auto" (default) — per call, ask the kernel which node holds the caller's sequences (get_mempolicy on a few sampled pages);
+//                      bind the spawned workers to the device's node only when the input lives there too, otherwise leave the
+//                      scheduler alone (round 4's behaviour);
+//   "1" — always bind to the device's node (round 5's behaviour); "0" / WFA_HIP_NO_NUMA=1 — never.
+// Only the threads this library spawns are ever bound; the caller's thread, which works a share of the pieces too, keeps its mask
+// (binding it narrowed the application's main thread for good, and every thread it created afterwards).
+// The node comes from sysfs (the device's PCI address), the CPUs are intersected with the process's affinity mask as it was when the
+// aligner was created; anything missing = no binding.
 static void numa_lookup(wfa_hip_aligner* al) {
   al->numa_state = 2;
   const char* off = getenv("WFA_HIP_NO_NUMA");
   if (off && *off == '1') return;
+  const char* mode = getenv("WFA_HIP_NUMA");
+  if (mode && *mode == '0') return;
+  al->numa_mode = (mode && *mode == '1') ? 1 : 2;   // 1 always, 2 auto
   char bus[64] = {0};
   if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, al->device) != hipSuccess) { (void)hipGetLastError(); return; }
   for (char* c = bus; *c; ++c) *c = (char)tolower((unsigned char)*c);
@@ -593,10 +613,11 @@ static void numa_lookup(wfa_hip_aligner* al) {
   if (!read_line(std::string("/sys/bus/pci/devices/") + bus + "/numa_node", line, sizeof(line))) return;
   const int node = atoi(line);
   if (node < 0) return;
+  al->numa_node = node;
   if (!read_line("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist", line, sizeof(line))) return;
-  cpu_set_t allowed, want;
+  cpu_set_t want;
   CPU_ZERO(&want);
-  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+  if (!al->proc_cpus_valid) return;
   for (const char* p = line; *p && *p != '\n';) {   // "0-63,128-191"
     char* end = nullptr;
     const long a = strtol(p, &end, 10);
@@ -604,14 +625,49 @@ static void numa_lookup(wfa_hip_aligner* al) {
     long b = a;
     p = end;
     if (*p == '-') { b = strtol(p + 1, &end, 10); p = end; }
-    for (long c = a; c <= b && c < CPU_SETSIZE; ++c) if (c >= 0 && CPU_ISSET((int)c, &allowed)) CPU_SET((int)c, &want);
+    for (long c = a; c <= b && c < CPU_SETSIZE; ++c) if (c >= 0 && CPU_ISSET((int)c, &al->proc_cpus)) CPU_SET((int)c, &want);
     if (*p == ',') ++p;
   }
   if (CPU_COUNT(&want) < 8) return;   // (a container pinned to a few CPUs: leave the scheduler alone)
-  al->numa_node = node; al->numa_cpus = want; al->numa_state = 1;
+  if (CPU_EQUAL(&want, &al->proc_cpus)) return;   // (one node, or the process is confined to this node already: nothing to bind)
+  al->numa_cpus = want; al->numa_state = 1;
 }
-static inline void bind_upload_worker(const wfa_hip_aligner* al) {
-  if (al->numa_state == 1) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &al->numa_cpus);
+// NUMA node of the page that holds `addr` (-1: unknown — no NUMA, the call is not permitted here, the page is not resident)
+static int page_node(const void* addr) {
+#if defined(SYS_get_mempolicy)
+  int node = -1;
+  if (syscall(SYS_get_mempolicy, &node, nullptr, 0ul, const_cast<void*>(addr), 3ul /* MPOL_F_NODE | MPOL_F_ADDR */) != 0) return -1;
+  return node;
+#else
+  (void)addr; return -1;
+#endif
+}
+// decide, for one call, whether the spawned upload workers are bound to the device's node: the input must live there (auto)
+static bool upload_binds(wfa_hip_aligner* al, const uint8_t* src, size_t bytes) {
+  al->last_src_node = -1; al->last_bound = 0;
+  if (al->numa_state != 1) return false;
+  if (al->numa_mode == 1) { al->last_bound = 1; return true; }
+  if (!src || bytes == 0) return false;
+  int votes = 0, seen = 0;
+  for (int i = 0; i < 5; ++i) {   // five pages spread over the blob
+    const int nd = page_node(src + (size_t)((double)bytes * (0.1 + 0.2 * i)));
+    if (nd < 0) continue;
+    ++seen; al->last_src_node = nd;
+    if (nd == al->numa_node) ++votes;
+  }
+  const bool bind = seen > 0 && votes == seen;
+  al->last_bound = bind ? 1 : 0;
+  return bind;
+}
+static inline void bind_upload_worker(const wfa_hip_aligner* al, bool bind) {
+  if (bind) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &al->numa_cpus);
+}
+extern "C" int wfa_hip_upload_info(const wfa_hip_aligner_t* al, int32_t* info, int n) {
+  if (!al || !info || n < 8) return WFA_HIP_EINVAL;
+  info[0] = al->numa_node; info[1] = al->numa_state == 1 ? CPU_COUNT(&al->numa_cpus) : 0; info[2] = al->numa_mode;
+  info[3] = al->last_src_node; info[4] = al->last_bound; info[5] = staged_pack_threads(al); info[6] = staged_copy_threads(al);
+  info[7] = al->proc_cpus_valid ? CPU_COUNT(&al->proc_cpus) : 0;
+  return WFA_HIP_OK;
 }
 
 static int staged_ring(wfa_hip_aligner* al) {
@@ -651,8 +707,9 @@ static int staged_upload(wfa_hip_aligner* al, const std::vector<UploadJob>& jobs
   for (auto& x : issued) x.store(-1);
   std::atomic<int> failed(0);
   const int device = al->device;
-  auto worker = [&]() {
-    bind_upload_worker(al);
+  const bool bind = upload_binds(al, jobs.empty() ? nullptr : (const uint8_t*)jobs[0].src, jobs.empty() ? 0 : jobs[0].bytes);
+  auto worker = [&](bool spawned) {
+    bind_upload_worker(al, bind && spawned);   // (never the caller's own thread: ADVICE r05)
     (void)hipSetDevice(device);
     for (;;) {
       const long i = next.fetch_add(1);
@@ -672,8 +729,8 @@ static int staged_upload(wfa_hip_aligner* al, const std::vector<UploadJob>& jobs
     }
   };
   std::vector<std::thread> th;
-  for (int t = 1; t < nthreads; ++t) th.emplace_back(worker);
-  worker();
+  for (int t = 1; t < nthreads; ++t) th.emplace_back(worker, true);
+  worker(false);
   for (auto& x : th) x.join();
   if (failed.load()) { al->err = "pipelined upload failed"; return WFA_HIP_EDEVICE; }
   return WFA_HIP_OK;
@@ -715,8 +772,11 @@ static int staged_pack_upload(wfa_hip_aligner* al, wfa_hip_batch* b, const std::
     HIP_TRY(al, hipStreamWaitEvent(al->up_stream, al->up_fork, 0));
   }
   hipStream_t const main_stream = stream;
-  auto worker = [&]() {
-    bind_upload_worker(al);
+  int64_t src_lo = 0, src_hi = 0;
+  if (!pieces.empty()) { src_lo = p_off[pieces.front().lo]; src_hi = t_off[pieces.back().hi - 1] + t_len[pieces.back().hi - 1]; }
+  const bool bind = upload_binds(al, seqs + std::min(src_lo, src_hi), (size_t)std::llabs(src_hi - src_lo));
+  auto worker = [&](bool spawned) {
+    bind_upload_worker(al, bind && spawned);   // (never the caller's own thread: ADVICE r05)
     (void)hipSetDevice(device);
     for (;;) {
       const long i = next.fetch_add(1);
@@ -753,8 +813,8 @@ static int staged_pack_upload(wfa_hip_aligner* al, wfa_hip_batch* b, const std::
     }
   };
   std::vector<std::thread> th;
-  for (int t = 1; t < nthreads; ++t) th.emplace_back(worker);
-  worker();
+  for (int t = 1; t < nthreads; ++t) th.emplace_back(worker, true);
+  worker(false);
   for (auto& x : th) x.join();
   if (two_up) {
     HIP_TRY(al, hipEventRecord(al->up_join, al->up_stream));
@@ -1059,7 +1119,6 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
       b->h_meta = std::move(meta);
       { const int prc = pilot_first_width(al, b, al->stream); if (prc != WFA_HIP_OK) return prc; }
       { const int prc = pilot_lane_heur(al, b, al->stream); if (prc != WFA_HIP_OK) return prc; }
-  { const int prc = pilot_band(al, b, al->stream); if (prc != WFA_HIP_OK) return prc; }
       { const int prc = pilot_band(al, b, al->stream); if (prc != WFA_HIP_OK) return prc; }
       HIP_TRY(al, hipEventCreateWithFlags(&b->upload_event, hipEventDisableTiming));
       HIP_TRY(al, hipEventRecord(b->upload_event, al->stream));
@@ -1597,10 +1656,18 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
       // windows a pair can be in at once: about two per 250 of score; queues sized from the longest pair, what overflows is redone
       const int64_t per_pair = std::min<int64_t>(1024, std::max<int64_t>(4, b->max_width / 96));
       const int64_t nmax = std::max<int64_t>(b->n_packed, b->n_bytes);
-      const int64_t qcap = knob(al, K_BILEVEL_QCAP, 0) > 0 ? knob(al, K_BILEVEL_QCAP, 0) : std::min<int64_t>(nmax * per_pair + 1024, (int64_t)1 << 28);   // (the knob: tests of the redo path)
-      const int64_t meta_bytes = qcap * 32 * 5 + (int64_t)b->n * (4 + 4 + 4 + 8 + 4) + WFA_BL_COUNTER_WORDS * 4 + 4096;
+      int64_t qcap = knob(al, K_BILEVEL_QCAP, 0) > 0 ? knob(al, K_BILEVEL_QCAP, 0) : std::min<int64_t>(nmax * per_pair + 1024, (int64_t)1 << 28);   // (the knob: tests of the redo path)
+      const int64_t pair_bytes = (int64_t)b->n * (4 + 4 + 4 + 8 + 4) + WFA_BL_COUNTER_WORDS * 4 + 4096;
       // the depth-first kernel behind it: a few slices (its int32 rings are the large ones)
       grid = std::min<int64_t>(std::min<int64_t>(grid, al->cu_count), std::max<int64_t>(1, nmax));   // (the redo list holds pairs of this batch)
+      // the queues must leave room for one ring slice per CU and one slice of the depth-first kernel — a large batch of
+      // short reads (10 M pairs: 6.4 GB of queues) would otherwise ask for more than the device has.  Queue overflow is a speed matter
+      // only (the redo list), so the capacity is clamped to half of what remains
+      if (knob(al, K_BILEVEL_QCAP, 0) <= 0) {
+        const int64_t room = budget - (int64_t)al->cu_count * la.slice_bytes - pair_bytes - stride * 4;
+        qcap = std::max<int64_t>(1024, std::min<int64_t>(qcap, room / 2 / 160));
+      }
+      const int64_t meta_bytes = qcap * 32 * 5 + pair_bytes;
       while (bl_grid > al->cu_count && (int64_t)bl_grid * la.slice_bytes + meta_bytes + grid * stride * 4 > budget) bl_grid /= 2;
       while (grid > 1 && (int64_t)bl_grid * la.slice_bytes + meta_bytes + grid * stride * 4 > budget) grid = (grid + 1) / 2;
       la.qcap = la.qbcap = la.leafcap = la.qwcap = (uint32_t)qcap;

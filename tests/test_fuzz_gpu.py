@@ -19,6 +19,9 @@ def test_fuzz_slice(gpu, seed):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz.py"), "14", str(seed), seconds], capture_output=True, text=True, timeout=1500)
     tail = "\n".join(out.stdout.splitlines()[-20:])
     assert out.returncode == 0 and "TOTAL BAD 0" in out.stdout, tail + out.stderr[-2000:]
+    # (a slice that stopped after one round on a cold run-time-shape cache would still say "TOTAL BAD 0")
+    rounds = [int(l.split()[1]) for l in out.stdout.splitlines() if l.startswith("ROUNDS ")]
+    assert rounds and rounds[-1] >= 4, tail
 
 
 @pytest.mark.gpu

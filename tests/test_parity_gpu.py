@@ -79,17 +79,37 @@ def corpora():
     import validate_oracle as vo
     out = {name: datagen.generate(n, L, e, 7000 + L + int(e * 1000)) for name, (n, L, e) in SHAPES.items()}
     out["special"] = vo.corpus_special(seed=99)   # empty / length-1 / N / repeats / long gaps / windows
+    # (every configuration meets the edge cases whatever the sampling below skips — 64 pairs of the special corpus: the
+    # empty / length-1 / identical / unrelated block, then homopolymers, two-letter reads, reads with N, long gaps, windows)
+    sp = out["special"]
+    n_sp = len(sp["p_len"])
+    pick = list(range(27)) + [27 + 30 * i for i in range(10)] + [327 + 33 * i for i in range(6)] + [527 + 12 * i for i in range(8)] + \
+           [627 + 25 * i for i in range(8)] + [827 + 40 * i for i in range(5)]
+    pick = [i for i in pick if i < n_sp]
+    pats = [bytes(sp["seqs"][sp["p_off"][i]:sp["p_off"][i] + sp["p_len"][i]]).decode() for i in pick]
+    txts = [bytes(sp["seqs"][sp["t_off"][i]:sp["t_off"][i] + sp["t_len"][i]]).decode() for i in pick]
+    out["special_mini"] = datagen.from_strings(pats, txts)
     return out
 
 
+# which two of the four large corpora a configuration runs on under -m gpu: the six possible pairs in turn, advanced so that neither
+# `scope` (alternates with cfg_idx), the heuristic (every 2), the span (every 8) nor the distance (every 32) is tied to a corpus
+# (the old stride (cfg_idx + corpus_idx) % 2 ran scope=score on two corpora only and scope=full on the other two)
+CORPUS_PAIRS = [(0, 1), (2, 3), (0, 2), (1, 3), (0, 3), (1, 2)]
+
+
+def sampled(cfg_idx, corpus_idx):
+    return corpus_idx in CORPUS_PAIRS[(cfg_idx + cfg_idx // 2 + cfg_idx // 8 + cfg_idx // 32) % 6]
+
+
 @pytest.mark.parametrize("cfg_idx", range(len(GRID)))
-@pytest.mark.parametrize("corpus", list(SHAPES) + ["special"])
+@pytest.mark.parametrize("corpus", list(SHAPES) + ["special", "special_mini"])
 def test_hip_matches_oracle(gpu, corpora, corpus, cfg_idx, monkeypatch):
-    # (the 4-corpus x 90-configuration grid is sampled by a fixed stride under -m gpu — every configuration on
-    # two of the four corpora, every corpus under half of the configurations; WFA_TEST_FULL=1 runs all of it, as the builder does
-    # through gpurun)
-    if os.environ.get("WFA_TEST_FULL") != "1" and (cfg_idx + (list(SHAPES) + ["special"]).index(corpus)) % 2 == 1:
-        pytest.skip("grid sampled by stride (WFA_TEST_FULL=1 runs every cell)")
+    # (the 4-corpus x 90-configuration grid is sampled under -m gpu — every configuration on two of the four large
+    # corpora (CORPUS_PAIRS) and always on the 64 edge-case pairs of `special_mini`; WFA_TEST_FULL=1 runs all of it: the log of such a
+    # run on the round's final kernels is profiles/r06_gputests_full.txt)
+    if os.environ.get("WFA_TEST_FULL") != "1" and corpus != "special_mini" and not sampled(cfg_idx, (list(SHAPES) + ["special"]).index(corpus)):
+        pytest.skip("grid sampled (WFA_TEST_FULL=1 runs every cell)")
     # (non-resident calls of <= 4 096 short pairs take the single-launch path; every fourth configuration keeps the batch machinery —
     # pageable upload, device pack, the kernel cascade — covered at these sizes)
     if cfg_idx % 4 == 0:

@@ -56,8 +56,9 @@ CASES = [
 def test_wide_kernel_matches_oracle(gpu, idx, tile, monkeypatch):
     """tile = 1: the temporally blocked form (csrc/wfa_tile.hpp, round 4) takes the batch first, the step-by-step form what it
     hands on; tile = 0: the step-by-step form alone (what it was before, and still is for wf-adaptive and reads over 16 kb)."""
-    if os.environ.get("WFA_TEST_FULL") != "1" and (idx + int(tile)) % 2 == 1:
-        pytest.skip("sampled by stride on the suite's time budget (WFA_TEST_FULL=1 runs every cell)")
+    # (sampled in pairs of cases: CASES alternates score / full, so a stride on idx itself would tie the scope to `tile` — VERDICT r05)
+    if os.environ.get("WFA_TEST_FULL") != "1" and (idx // 2 + int(tile)) % 2 == 1:
+        pytest.skip("sampled on the suite's time budget (WFA_TEST_FULL=1 runs every cell)")
     monkeypatch.setenv("WFA_HIP_TILE", tile)
     batch = ragged_batch(180, 2500, 0.10, 9100 + idx)
     kw = common.clamp_free(dict(CASES[idx]), batch)
@@ -79,8 +80,8 @@ TILE_GEOMETRIES = [dict(WFA_HIP_TILE_T="4", WFA_HIP_TILE_WT="64"), dict(WFA_HIP_
 def test_tile_kernel_geometries(gpu, idx, geo, monkeypatch):
     """The blocked form under other geometries than the defaults (steps per super-step, tile width, waves per workgroup): ring
     slots, halo widths, the far form of the M rows (gap-affine-2p with T <= 8) and the classic one, run-time penalties."""
-    if os.environ.get("WFA_TEST_FULL") != "1" and (idx + int(geo)) % 2 == 1:
-        pytest.skip("sampled by stride on the suite's time budget (WFA_TEST_FULL=1 runs every cell)")
+    if os.environ.get("WFA_TEST_FULL") != "1" and ([1, 2, 4, 7, 11, 12, 13, 14].index(idx) // 2 + int(geo)) % 2 == 1:
+        pytest.skip("sampled on the suite's time budget (WFA_TEST_FULL=1 runs every cell)")
     for k_, v_ in TILE_GEOMETRIES[geo].items():
         monkeypatch.setenv(k_, v_)
     batch = ragged_batch(150, 2200, 0.10, 9600 + idx)
