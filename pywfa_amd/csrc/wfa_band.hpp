@@ -36,6 +36,8 @@ struct BandArgs {
   const WfaPairMeta* meta;
   const uint32_t* worklist;  // nullptr = identity
   const uint32_t* nwork_dev;  // non-null: the count is read from device memory (leftovers of a previous stage)
+  const uint32_t* wbeg_dev;   // non-null: the first list position of this launch, read from device memory — the leftovers ONE launch of the
+                              // stage in front appended, [*wbeg_dev, *nwork_dev), aligned beside that stage's next launch (round 6)
   uint32_t nwork;
   int32_t* score;
   int32_t* status;
@@ -308,7 +310,8 @@ __device__ __forceinline__ void wfa_band_body(const BandArgs& a) {
   constexpr bool split = SPLIT;  // (a template parameter: the in-kernel walk of the other form costs 20 VGPRs = 2 waves per SIMD)
   const uint32_t nwork = a.nwork_dev ? *a.nwork_dev : a.nwork;
   const uint32_t w0 = split ? a.work_begin : 0u;
-  for (uint32_t wi = w0 + blockIdx.x; wi < w0 + nwork; wi += gridDim.x) {
+  const uint32_t wb = a.wbeg_dev ? *a.wbeg_dev : 0u;
+  for (uint32_t wi = w0 + wb + blockIdx.x; wi < w0 + nwork; wi += gridDim.x) {
     const uint32_t pair = a.worklist ? a.worklist[wi] : wi;
     const WfaPairMeta pm = a.meta[pair];
     const int plen = pm.plen, tlen = pm.tlen;

@@ -54,6 +54,7 @@ struct WfaKernelArgs {
   // work list: pair ids to process (nullptr = identity); count read from *nwork_dev when non-null
   const uint32_t* worklist;
   const uint32_t* nwork_dev;
+  const uint32_t* wbeg_dev;   // non-null: first list position of this launch, read from device memory (see BandArgs::wbeg_dev)
   uint32_t nwork;
   // results
   int32_t* score;

@@ -278,8 +278,9 @@ wfa_general_kernel(const WfaKernelArgs a) {
   int* const ws = a.ws + (long long)blockIdx.x * a.ws_stride;
   const long long ws_stride = a.ws_stride;
   const uint32_t nwork = a.nwork_dev ? *a.nwork_dev : a.nwork;
+  const uint32_t wb = a.wbeg_dev ? *a.wbeg_dev : 0u;
 
-  for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+  for (uint32_t wi = wb + blockIdx.x; wi < nwork; wi += gridDim.x) {
     const uint32_t pair = a.worklist ? a.worklist[wi] : wi;
     const WfaPairMeta pm = a.meta[pair];
     const int plen = pm.plen, tlen = pm.tlen;

@@ -45,9 +45,9 @@ static thread_local std::string g_error;
 
 // Development knobs, read from the environment ONCE per aligner in wfa_hip_create: the hot entry points
 // never call getenv.
-#define WFA_COUNTER_WORDS 64   // counters of a batch (wfa_hip_batch::d_counters)
+#define WFA_COUNTER_WORDS 256  // counters of a batch (wfa_hip_batch::d_counters)
 #define WFA_KNOBS(F)                                                                                              \
-  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(BAND_LDS_MAX) F(BAND_NO_WIN) F(BAND_SPLIT_MIN) F(NO_TINY_INLINE) F(BILEVEL) F(BILEVEL_WIDE_LEVELS) F(BILEVEL_PER_CU) F(BILEVEL_I32) F(BILEVEL_QCAP) F(BILEVEL_LEVELS) F(BILEVEL_LDS) F(BILEVEL_NO_1024) F(BILEVEL_HUGE_MIN) F(BILEVEL_LDS_W) F(BILEVEL_NO_SEQL) F(LANE_DYN) F(LANE_DYN_WAVES) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB)     \
+  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(BAND_LDS_MAX) F(BAND_NO_WIN) F(BAND_SPLIT_MIN) F(NO_TINY_INLINE) F(BILEVEL) F(BILEVEL_WIDE_LEVELS) F(BILEVEL_PER_CU) F(BILEVEL_I32) F(BILEVEL_QCAP) F(BILEVEL_LEVELS) F(BILEVEL_LDS) F(BILEVEL_NO_1024) F(BILEVEL_HUGE_MIN) F(BILEVEL_LDS_W) F(BILEVEL_NO_SEQL) F(LANE_DYN) F(LANE_DYN_WAVES) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB) F(PIPE_TAIL)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
   F(LANE_FULL) F(LANE_FULL_SPLIT) F(LANE_HEUR) F(SEG_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_ADAPT) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(TILE) F(TILE_T) F(TILE_WT) F(TILE_THREADS) F(TILE_PER_CU) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY) F(PILOT_PCT) F(WIDE_ADAPT_LDS)
@@ -105,6 +105,10 @@ struct wfa_hip_aligner {
   // the walks of a split stage's launch run on this stream, under the alignment kernel of the next launch (which writes
   // the other half of the workspace); created on first use
   hipStream_t side_stream = nullptr;
+  // round 6: what ONE launch of a split stage hands on is aligned by the stages behind it on this stream, beside the split stage's
+  // next launch (batch_run_once: "pipelined tail"); created on first use
+  hipStream_t tail_stream = nullptr;
+  hipEvent_t tail_fork[2] = {nullptr, nullptr}, tail_join = nullptr;
   hipEvent_t band_event[4] = {nullptr, nullptr, nullptr, nullptr}, walk_event[4] = {nullptr, nullptr, nullptr, nullptr};   // [0..1] the band stages' walks, [2..3] the lane-full stage's expands
   // second upload stream of the host-packed upload (every other slot's DMAs: two copy engines)
   hipStream_t up_stream = nullptr;
@@ -485,6 +489,9 @@ static void aligner_free(wfa_hip_aligner* al) {
   if (al->up_fork) (void)hipEventDestroy(al->up_fork);
   if (al->up_join) (void)hipEventDestroy(al->up_join);
   if (al->side_stream) (void)hipStreamDestroy(al->side_stream);
+  if (al->tail_stream) (void)hipStreamDestroy(al->tail_stream);
+  for (int i = 0; i < 2; ++i) if (al->tail_fork[i]) (void)hipEventDestroy(al->tail_fork[i]);
+  if (al->tail_join) (void)hipEventDestroy(al->tail_join);
   for (int i = 0; i < 4; ++i) { if (al->band_event[i]) (void)hipEventDestroy(al->band_event[i]); if (al->walk_event[i]) (void)hipEventDestroy(al->walk_event[i]); }
   if (al->stream) (void)hipStreamDestroy(al->stream);
   delete al;
@@ -583,11 +590,15 @@ static int staged_pack_threads(const wfa_hip_aligner* al) {
 // closest to the current device.  Round 5 bound the threads that fill it (2-bit packing, copies) to that node's CPUs whatever the
 // call; the driver's run of round 5 then measured 187 M aln/s where round 4 had 332 M: a packer READS 300 B of the caller's pages per
 // pair and WRITES 92 B into the ring, so where the caller's pages live matters three times more than where the ring lives, and on
-// a box whose GPU hangs off the other socket every bound packer pulled its input across the socket link.  Round 6 (WFA_HIP_NUMA):
-//   "auto" (default) — per call, ask the kernel which node holds the caller's sequences (get_mempolicy on a few sampled pages);
-//                      bind the spawned workers to the device's node only when the input lives there too, otherwise leave the
-//                      scheduler alone (round 4's behaviour);
-//   "1" — always bind to the device's node (round 5's behaviour); "0" / WFA_HIP_NO_NUMA=1 — never.
+// a box whose GPU hangs off the other socket every bound packer pulled its input across the socket link.  Measured in round 6
+// (tools/probes/e2e_numa.py, profiles/r06_e2e_numa.txt: 2 x EPYC 9575F, GPU on node 0, 10 M x 150 bp, median of 7 calls):
+//   input on the GPU's node:   never bound 323 M aln/s, always bound 301 M, bound because the input is local 303 M
+//   input on the other node:   never bound 271 M,       always bound 228 M, auto (= not bound) 278 M
+// Binding never won: the upload is bound by the DMA (0.96 GB at ~46 GB/s; 16 to 64 packing threads measure the same), and threads
+// spread over both sockets reach it with room to spare.  So the default is NOT to bind (WFA_HIP_NUMA unset or "0" = round 4's
+// behaviour); "auto" binds the spawned workers to the device's node only when the kernel says the caller's sequences live there
+// (get_mempolicy on five sampled pages), "1" always (round 5's behaviour) — both kept for hosts where the socket link is the
+// scarcer resource (eight GPUs uploading at once).
 // Only the threads this library spawns are ever bound; the caller's thread, which works a share of the pieces too, keeps its mask
 // (binding it narrowed the application's main thread for good, and every thread it created afterwards).
 // The node comes from sysfs (the device's PCI address), the CPUs are intersected with the process's affinity mask as it was when the
@@ -597,8 +608,7 @@ static void numa_lookup(wfa_hip_aligner* al) {
   const char* off = getenv("WFA_HIP_NO_NUMA");
   if (off && *off == '1') return;
   const char* mode = getenv("WFA_HIP_NUMA");
-  if (mode && *mode == '0') return;
-  al->numa_mode = (mode && *mode == '1') ? 1 : 2;   // 1 always, 2 auto
+  al->numa_mode = (mode && *mode == '1') ? 1 : (mode && *mode == 'a') ? 2 : 0;   // 1 always, 2 auto, 0 (default) never
   char bus[64] = {0};
   if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, al->device) != hipSuccess) { (void)hipGetLastError(); return; }
   for (char* c = bus; *c; ++c) *c = (char)tolower((unsigned char)*c);
@@ -645,7 +655,7 @@ static int page_node(const void* addr) {
 // decide, for one call, whether the spawned upload workers are bound to the device's node: the input must live there (auto)
 static bool upload_binds(wfa_hip_aligner* al, const uint8_t* src, size_t bytes) {
   al->last_src_node = -1; al->last_bound = 0;
-  if (al->numa_state != 1) return false;
+  if (al->numa_state != 1 || al->numa_mode == 0) return false;
   if (al->numa_mode == 1) { al->last_bound = 1; return true; }
   if (!src || bytes == 0) return false;
   int votes = 0, seen = 0;
@@ -1404,6 +1414,9 @@ extern "C" int wfa_hip_align_batch_packed2bits(wfa_hip_aligner_t* al, int64_t n,
   return rc;
 }
 
+// hand-over count of a stage as it stands between two of its launches (the pipelined tail of batch_run_once)
+__global__ void wfa_snapshot_kernel(const uint32_t* src, uint32_t* dst) { *dst = *src; }
+
 // ---- the walks of a split stage on a stream of their own ----------------------------------------------
 // Launch i of a split stage = alignment kernel (history into half i & 1 of the workspace) + the walks of its pairs.  The
 // walks are latency-bound chains with little parallelism (one thread per alignment): they run on the side stream, under the
@@ -1486,14 +1499,16 @@ static bool general_pb(const wfa_hip_aligner* al, const wfa_hip_config_t& c, int
 
 static int launch_general_dyn(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream, bool packed,
                               const uint32_t* worklist, const uint32_t* nwork_dev, uint32_t nwork_host,
-                              int64_t ws_stride, int grid, int threads, uint32_t* ovf_list, uint32_t* ovf_count) {
+                              int64_t ws_stride, int grid, int threads, uint32_t* ovf_list, uint32_t* ovf_count,
+                              int32_t* ws_base = nullptr, const uint32_t* wbeg_dev = nullptr) {
   WfaKernelArgs a;
   memset(&a, 0, sizeof(a));
   a.words = b->d_words; a.bytes = b->d_bytes; a.meta = b->d_meta; a.p_boff = b->d_pboff; a.t_boff = b->d_tboff;
   a.worklist = worklist; a.nwork_dev = nwork_dev; a.nwork = nwork_host;
   a.score = b->d_score; a.status = b->d_status;
   a.cigar_ops = b->d_ops; a.cigar_off = b->d_cigar_off; a.cigar_begin = b->d_cigar_begin; a.cigar_len = b->d_cigar_len;
-  a.ws = al->ws; a.ws_stride = ws_stride;
+  a.ws = ws_base ? ws_base : al->ws; a.ws_stride = ws_stride;
+  a.wbeg_dev = wbeg_dev;
   a.fb_list = ovf_list; a.fb_count = ovf_count;
   a.cfg = b->dcfg;
   if (!packed && b->wild >= 0) a.cfg.wildcard = b->wild;   // (the 8-bit pairs of a batch whose 2-bit pairs run without the wildcard rule)
@@ -1573,6 +1588,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
     (void)hipGetLastError();
     (void)hipStreamSynchronize(stream_ ? (hipStream_t)stream_ : al->stream);   // (what the failed run had enqueued before it gave up)
     if (al->side_stream) (void)hipStreamSynchronize(al->side_stream);
+    if (al->tail_stream) (void)hipStreamSynchronize(al->tail_stream);
     b->ev_used = ev_used; b->runs_pending = runs_pending;   // (the failed run's timing events: its end was never recorded)
     b->dcfg.rtc = 0; al->dcfg.rtc = 0;
     al->rtc_note = std::string("run-time kernels switched off for this aligner: ") + wfa::rtc_last_error();
@@ -1595,7 +1611,10 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
   // destroy next
   struct SideGuard {
     wfa_hip_aligner* al; bool ok = false;
-    ~SideGuard() { if (!ok && al->side_stream) (void)hipStreamSynchronize(al->side_stream); }
+    ~SideGuard() {
+      if (!ok && al->side_stream) (void)hipStreamSynchronize(al->side_stream);
+      if (!ok && al->tail_stream) (void)hipStreamSynchronize(al->tail_stream);
+    }
   } side_guard{al};
   b->last_stream = stream;
   b->ran = true; b->synced = false;
@@ -1884,12 +1903,21 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
     const int pb_env = knob(al, K_BAND_PB, -1);
     const bool pb_mode = full && (pb_env >= 0 ? pb_env != 0 : true);
     int64_t pb_code_ints = 0, pb_event_ints = 0, pb_stride = 0;
+    // Round 6, the pipelined tail (16 % of a C4-adaptive run was a latency tail — the 256-diagonal stage 22.7 ms
+    // and the general kernel 17.4 ms for ONE pair, both after the last launch of the split stage).  What launch j of the split stage
+    // hands on is aligned by the stage behind it — and what THAT hands on by the general kernel — on a third stream beside launch
+    // j + 1: [snapshot of the hand-over count before, after) is the launch's part of the list (BandArgs::wbeg_dev).  Only the last
+    // launch's leftovers remain exposed.  Needs a region of its own for each of the two (behind the split stage's slots), two band
+    // stages, long reads with CIGARs (the split form), no tile / wide stage in the chain.  WFA_HIP_PIPE_TAIL=0: off
+    const bool want_pipe_tail = full && n_stages == 2 && b->max_len > 1000 && knob(al, K_PIPE_TAIL, 1) != 0 && knob(al, K_NO_DUAL, 0) == 0 &&
+                                knob(al, K_STAGE_TIMING, 0) == 0 && !al->knobs.set[K_BAND_LEFTOVER_WAVES_PER_CU];
     for (int i = 0; i < n_stages; ++i) {
       // 4x more waves than a CU holds at once: waves retire one after the other (oldest-first issue) and the
       // dispatcher refills the CU, instead of a tail of lone waves (C1 +20 %, C3 +13 %)
       long long grid = (long long)al->cu_count * knob(al, K_BAND_WAVES_PER_CU, 128);
       grid = std::min<long long>(grid, in_n);
       if (i > 0 || use_fast || use_laneh || use_segh || use_segfull) grid = std::min<long long>(grid, (long long)al->cu_count * knob(al, K_BAND_LEFTOVER_WAVES_PER_CU, 64));
+      if (i > 0 && want_pipe_tail) grid = std::min<long long>(grid, (long long)al->cu_count * 8);   // (one launch's leftovers at a time: a few hundred pairs; the history slices are tens of megabytes each)
       if (full) {
         const bool h16 = b->max_len < 32000;
         const int rec = ((h16 && b->ncomp != 5) ? 2 : 4) * (band_nch[i] == 3 ? 256 : 64 * band_nch[i]);  // ints per record (2p: 16-byte entries)
@@ -1925,10 +1953,16 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
     }
     // the band stages behind a split stage get a region of their own behind its slots when both fit: the walks of the split
     // stage's last launch then run under them
-    size_t later_off = 0;
+    size_t later_off = 0, gen_off = 0;
+    int gen_grid = 0;
     if (split_region && later_need && (int64_t)(split_region + later_need) <= free_budget(al)) {
       later_off = split_region;
       need = std::max(need, split_region + later_need);
+      if (want_pipe_tail) {   // ... and the general kernel behind them a few slices of its own
+        gen_grid = std::max(1, std::min(g.grid, 16));
+        const size_t at = (split_region + later_need + 255) & ~(size_t)255, gen_need = (size_t)gen_grid * (size_t)g.ws_stride * 4;
+        if ((int64_t)(at + gen_need) <= free_budget(al)) { gen_off = at; need = std::max(need, at + gen_need); }
+      }
     }
     // Wide-wavefront stage (wfa_wide.hpp): exact gap-affine pairs the register windows cannot hold (or never try: reads
     // over 1.2 kb without a heuristic) — one alignment per workgroup, the wavefront rows in LDS; what it hands on goes to
@@ -2362,6 +2396,7 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
       in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
     }
     DualStream pending_walks{al, stream};   // walks of a split stage left running under the band stages behind it
+    bool pipe_tail = false;                 // the stages behind the split stage ran beside it, the general kernel included
     std::chrono::steady_clock::time_point band_prev;
     if (knob(al, K_STAGE_TIMING, 0) != 0) { (void)hipStreamSynchronize(stream); band_prev = std::chrono::steady_clock::now(); }
     for (int i = 0; i < n_stages; ++i) {
@@ -2427,6 +2462,26 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
           nl = ((int64_t)in_n + lmax - 1) / lmax;
           per_launch = std::min<int64_t>(lmax, (((int64_t)in_n + nl - 1) / nl + 63) & ~63ll);
         }
+        // the pipelined tail (see want_pipe_tail): this stage's launches and, beside each, the later stages on its leftovers
+        pipe_tail = want_pipe_tail && i == 0 && gen_off != 0 && nl >= 2 && nl <= 90 && !tile_stage.on && n_wide == 0 && (all_fit || halves);
+        uint32_t* const snap_a = b->d_counters + 64;    // [j] = this stage's hand-over count before launch j
+        uint32_t* const snap_b = b->d_counters + 160;   // the same for the stage behind it
+        uint32_t* tail_list = nullptr; uint32_t* tail_count = nullptr;
+        wfa::BandArgs tb = ba;   // the stage behind: everything but lists, history region and window width is this stage's
+        if (pipe_tail) {
+          if (!al->tail_stream) {
+            HIP_TRY(al, hipStreamCreateWithFlags(&al->tail_stream, hipStreamNonBlocking));
+            for (int q = 0; q < 2; ++q) HIP_TRY(al, hipEventCreateWithFlags(&al->tail_fork[q], hipEventDisableTiming));
+            HIP_TRY(al, hipEventCreateWithFlags(&al->tail_join, hipEventDisableTiming));
+          }
+          tail_list = b->d_fb_list2[out_sel ^ 1]; tail_count = next_count();
+          tb.worklist = out_list; tb.fb_list = tail_list; tb.fb_count = tail_count;
+          tb.hist = al->ws + later_off / 4; tb.hist_stride = band_stride[1];
+          tb.pb = 0; tb.pb_code_ints = 0; tb.pb_event_ints = 0; tb.pb_raw = 0; tb.split = 0;   // (unsplit: explicit history, walked in-kernel)
+          // (the tail stream's first kernel must see the counters zeroed and the previous run's use of the regions over)
+          HIP_TRY(al, hipEventRecord(al->tail_fork[0], stream));
+          HIP_TRY(al, hipStreamWaitEvent(al->tail_stream, al->tail_fork[0], 0));
+        }
         ba.split = 1;
         char* const es_base = reinterpret_cast<char*>(al->ws) + (size_t)cap * slot_ints * 4;   // end states behind the slots
         DualStream dual{al, stream};
@@ -2448,6 +2503,18 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
           }
           ba.pb_raw = wfa::slim_launches(ba, band_nch[i], full, adapt, seqlds) ? 1 : 0;   // (wfa_slim_kernel writes comparison bits; the walk below decodes them)
           if (wfa::launch_band(ba, band_nch[i], full, adapt, seqlds, grid, stream) != 0) { al->err = "band kernel launch failed"; return WFA_HIP_EDEVICE; }
+          if (pipe_tail) {
+            // [snap_a[launch], snap_a[launch + 1]) = what this launch handed on (snap_a[0] = 0: the counters are zeroed per run)
+            hipLaunchKernelGGL(wfa_snapshot_kernel, dim3(1), dim3(1), 0, stream, out_count, snap_a + launch + 1);
+            HIP_TRY(al, hipEventRecord(al->tail_fork[launch & 1], stream));
+            HIP_TRY(al, hipStreamWaitEvent(al->tail_stream, al->tail_fork[launch & 1], 0));
+            tb.wbeg_dev = snap_a + launch; tb.nwork_dev = snap_a + launch + 1; tb.nwork = in_n;
+            if (wfa::launch_band(tb, band_nch[1], full, adapt, seqlds, band_grid[1], al->tail_stream) != 0) { al->err = "band kernel launch failed"; return WFA_HIP_EDEVICE; }
+            hipLaunchKernelGGL(wfa_snapshot_kernel, dim3(1), dim3(1), 0, al->tail_stream, tail_count, snap_b + launch + 1);
+            const int grc = launch_general_dyn(al, b, al->tail_stream, true, tail_list, snap_b + launch + 1, in_n, g.ws_stride, gen_grid, g.threads,
+                                               b->d_ovf_list[0], b->d_counters + 1, reinterpret_cast<int32_t*>(reinterpret_cast<char*>(al->ws) + gen_off), snap_b + launch);
+            if (grc != WFA_HIP_OK) return grc;
+          }
           hipStream_t ws_ = stream;
           { const int drc = dual.walk_stream(launch, &ws_); if (drc != WFA_HIP_OK) return drc; }
           if (wfa::launch_band_bt(ba, band_nch[i], ws_) != 0) { al->err = "band backtrace launch failed"; return WFA_HIP_EDEVICE; }
@@ -2457,6 +2524,15 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
         // its own region
         if (later_off && i + 1 < n_stages && dual.on) pending_walks = dual;
         else { const int drc = dual.end(); if (drc != WFA_HIP_OK) return drc; }
+        if (pipe_tail) {
+          // everything behind this stage has been enqueued beside it: the main stream joins the tail stream, the stage behind is
+          // skipped below and so is the last launch of the general kernel; the lists move on as if the stages had run here
+          HIP_TRY(al, hipEventRecord(al->tail_join, al->tail_stream));
+          HIP_TRY(al, hipStreamWaitEvent(stream, al->tail_join, 0));
+          if (first_stage) b->last_kernel_pairs = in_n;
+          in_list = tail_list; in_count = tail_count; first_stage = false;   // (out_sel: two lists were used, the selector is where it was)
+          break;
+        }
       } else {
         if (try_win) {
           wfa::BandArgs t = ba; t.win = 1; t.lds_words = 643;
@@ -2543,9 +2619,11 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
       in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
     }
     b->leftover_count = in_count;
-    rc = launch_general_dyn(al, b, stream, true, in_list, in_count, in_n, g.ws_stride, g.grid, g.threads,
-                            b->d_ovf_list[0], b->d_counters + 1);
-    if (rc != WFA_HIP_OK) return rc;
+    if (!pipe_tail) {   // (the pipelined tail has run the general kernel on every launch's leftovers already)
+      rc = launch_general_dyn(al, b, stream, true, in_list, in_count, in_n, g.ws_stride, g.grid, g.threads,
+                              b->d_ovf_list[0], b->d_counters + 1);
+      if (rc != WFA_HIP_OK) return rc;
+    }
     if (first_stage) b->last_kernel_pairs = in_n;
     { const int drc = lane_expands.end(); if (drc != WFA_HIP_OK) return drc; }
     if (use_lanefull) {   // what the walks of the lane-full stage handed on (nothing, as a rule)

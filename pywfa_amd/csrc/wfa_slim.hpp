@@ -98,13 +98,26 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a, const uint32_t*
   constexpr int E2D = TWO ? E2 : 1;
   typedef Band<NCH> BD;
   constexpr int W = BD::W, WI = BD::WI, HP = WFA_SLIM_HP;   // steps between hull checks
-  constexpr int DM = (X > OE) ? X : OE;                      // M history in registers: depths 1 .. DM
-  constexpr int NP = TWO ? (OE2 - DM + 1) / 2 + 1 : 1;       // 2p: depths DM + 1 .. OE2 as int16 pairs, two depths per register
-  static_assert(!TWO || OE2 > DM, "2p: o2 + e2 is the deepest history read");
+  // M history in registers: depths 1 .. DM.  gap-affine: max(x, o + e).  gap-affine-2p (round 6): depths 1 .. x only — the deeper
+  // history (depths x + 1 .. o2 + e2, read on the neighbour diagonals at depths o + e and o2 + e2) lives in an LDS ring of
+  // RR = o2 + e2 - x rows of int16 (doubled) offsets indexed by window position, one pad cell at either end that is NULL for good:
+  // a neighbour read is a ds_read_i16 at a constant byte offset, the ring needs no register moves, and 14 of the 25 ring registers
+  // per chunk (and every spill: round 5 ran 256 B of scratch per lane) are gone.  A row is written when its value leaves the
+  // registers (step s writes M[s - x] over M[s - o2 - e2], which the previous step read last); NULL is stored as -32768 and read back
+  // as such — a dead gap cell can then be a small negative number instead of WFA_OFFSET_NULL, which every test of the step treats
+  // alike (>= 0 is alive); so that such values cannot creep up to 0 (+2 per step at most) the gap rings are cleaned at every hull
+  // check, and M itself is kept exact by the clamp of compute-next.
+  constexpr bool RING = TWO;
+  constexpr int DM = RING ? X : ((X > OE) ? X : OE);
+  constexpr int NP = 1;
+  constexpr int RR = RING ? OE2 - X : 1;                     // rows of the LDS ring
+  static_assert(!TWO || (OE > X && OE2 > OE), "2p: x < o + e < o2 + e2 (the ring holds the depths beyond x)");
   constexpr int NUL = WFA_OFFSET_NULL;
   extern __shared__ uint32_t slds[];
   uint32_t* const sP = slds;
   uint32_t* const sT = slds + a.lds_words;
+  constexpr int RW = 64 * NCH + 2;                           // cells of a ring row: [pad][window positions][pad]
+  short* const ring = reinterpret_cast<short*>(slds + 2 * a.lds_words);   // (RING only: launch_slim_shape sizes the dynamic LDS for it)
   const int lane = threadIdx.x;
   const uint32_t nwork = a.nwork_dev ? *a.nwork_dev : a.nwork;
   const uint32_t w0 = PBH ? a.work_begin : 0u;
@@ -113,7 +126,8 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a, const uint32_t*
                               : (XH ? (int)min((long long)INT_MAX, a.hist_stride / XREC) : INT_MAX);
   int* const xhist = XH ? a.hist + (long long)blockIdx.x * a.hist_stride : nullptr;   // explicit history: this workgroup's slice
   const int thr2 = 2 * a.max_dist_thr;
-  for (uint32_t wi = w0 + blockIdx.x; wi < w0 + nwork; wi += gridDim.x) {
+  const uint32_t wb = a.wbeg_dev ? *a.wbeg_dev : 0u;   // (the leftovers of one launch of the stage in front: BandArgs::wbeg_dev)
+  for (uint32_t wi = w0 + wb + blockIdx.x; wi < w0 + nwork; wi += gridDim.x) {
     const uint32_t pair = a.worklist ? a.worklist[wi] : wi;
     // (inl: the single-call form — meta, op-region offsets and the packed words of the one pair arrive in the kernel arguments)
     WfaPairMeta pm;
@@ -154,6 +168,10 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a, const uint32_t*
       for (int i = lane; i < nwt + 3; i += 64) sT[i] = (i < nwt) ? gT[i] : 0u;
       __syncthreads();
     }
+    if (RING) {   // every cell NULL (the pads stay so)
+      for (int i = lane; i < RR * RW; i += 64) ring[i] = (short)-32768;
+      __syncthreads();
+    }
     int B = -(W / 2);  // diagonal of window position 0
     if (a.ef) {
       // wavefront 0 spans the diagonals [-pattern_begin_free, text_begin_free] (R/wavefront_aligner.c:259-302)
@@ -168,7 +186,8 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a, const uint32_t*
       // dlim2 = 2 max(tlen, plen + k) (dlim2 - offset = distance to the end, R/wavefront_heuristic.c:176-192); ethr: the smallest
       // offset that ends the alignment on this diagonal
       int kk2[NCH], lim2[NCH], lim2c[NCH], dlim2[NCH], ethr[NCH];
-      int cur[NCH], Mh[DM][NCH], Ih[E][NCH], Dh[E][NCH], I2h[E2D][NCH], D2h[E2D][NCH], PH[NP][NCH];
+      int cur[NCH], Mh[DM][NCH], Ih[E][NCH], Dh[E][NCH], I2h[E2D][NCH], D2h[E2D][NCH];
+      int rw_off = 0;      // RING: cell offset of the row the next compute-next writes (row (s - x) mod RR)
       uint32_t hoff[NCH];  // piggy-back: byte of this diagonal in the history record compute-next fills: (step + 1) * WI + (k mod WI);
                            // explicit history: its position k mod WI in a record
       int step = 0;        // (the score of a step is step * g)
@@ -200,11 +219,9 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a, const uint32_t*
         for (int j = 0; j < E2D; ++j) { I2h[j][c] = NUL; D2h[j][c] = NUL; }
 #pragma unroll
         for (int j = 0; j < DM; ++j) Mh[j][c] = NUL;
-#pragma unroll
-        for (int j = 0; j < NP; ++j) PH[j][c] = -1;  // both halves NULL
       }
       // neighbour registers of the one-chunk form: lane 0 (from below) / lane 63 (from above) never receive a value
-      int nb_mo_lo = NUL, nb_ie_lo = NUL, nb_mo_hi = NUL, nb_de_hi = NUL, nb_ph_lo = -1, nb_ph_hi = -1, nb_i2_lo = NUL, nb_d2_hi = NUL;
+      int nb_mo_lo = NUL, nb_ie_lo = NUL, nb_mo_hi = NUL, nb_de_hi = NUL, nb_i2_lo = NUL, nb_d2_hi = NUL;
       int steps_wait = a.steps_between, dead_steps = 0;
       const int min_wf_len_m1 = a.min_wf_len - 1;
       // the first step the loop must not start: the step limit reached (score step * g >= max_steps) or no room for the record it fills
@@ -379,14 +396,16 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a, const uint32_t*
             }
           }
           // ---------------- compute-next for score s + g (R/wavefront_compute_affine.c:44-86, R/wavefront_compute_affine2p.c:45-106) ----------------
-          if (TWO) {
-            // the value leaving depth DM enters the packed ring: PH[0].lo = depth DM + 1, PH[0].hi = DM + 2, ...
+          // RING: the value leaving the registers, M[s - x], goes to the row M[s - o2 - e2] held (written before this step's reads: with
+          // o + e = x + 1 the shallow read is that very row); the reads are rows (s + 1 - o - e) and (s + 1 - o2 - e2)
+          int roe_off = 0, roe2_off = 0;
+          if (RING) {
+            short* const wrow = ring + rw_off + 1 + lane;
 #pragma unroll
-            for (int j = NP - 1; j > 0; --j)
-#pragma unroll
-              for (int c = 0; c < ACT; ++c) PH[j][c] = (int)__builtin_amdgcn_alignbit((uint32_t)PH[j][c], (uint32_t)PH[j - 1][c], 16);
-#pragma unroll
-            for (int c = 0; c < ACT; ++c) PH[0][c] = (PH[0][c] << 16) | (max(Mh[DM - 1][c], -1) & 0xffff);
+            for (int c = 0; c < ACT; ++c) wrow[64 * c] = (short)max(Mh[DM - 1][c], -32768);
+            roe_off = rw_off - (OE - 1 - X) * RW; roe_off += (roe_off < 0) ? RR * RW : 0;
+            roe2_off = rw_off + RW; roe2_off = (roe2_off == RR * RW) ? 0 : roe2_off;   // (row s + 1 - o2 - e2 = the next row to be written)
+            rw_off = roe2_off;
           }
 #pragma unroll
           for (int j = DM - 1; j > 0; --j)
@@ -396,40 +415,43 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a, const uint32_t*
           for (int c = 0; c < ACT; ++c) Mh[0][c] = cur[c];
           int ni[NCH], nd[NCH], ni2[NCH], nd2[NCH];
           unsigned long long oob = 0;
-          constexpr int PD = TWO ? OE2 - 1 - DM : 0;  // depth OE2 (index OE2 - 1) sits in half PD & 1 of PH[PD / 2]
+          constexpr int MOD = RING ? 0 : OE - 1;   // (register depth of M[s + 1 - o - e]; RING reads it from LDS)
 #pragma unroll
           for (int c = 0; c < ACT; ++c) {
-            int mo_lo, ie_lo, mo_hi, de_hi, plo = -1, phi = -1, i2e_lo = NUL, d2e_hi = NUL;
+            int mo_lo, ie_lo, mo_hi, de_hi, i2e_lo = NUL, d2e_hi = NUL;
+            int mo2_lo = NUL, mo2_hi = NUL;
+            if (RING) {
+              // cell of window position p = 64 c + lane is at index p + 1: its neighbours k - 1 / k + 1 at p and p + 2 (pads NULL)
+              const short* const r1 = ring + roe_off + 64 * c + lane;
+              const short* const r2 = ring + roe2_off + 64 * c + lane;
+              mo_lo = r1[0]; mo_hi = r1[2]; mo2_lo = r2[0]; mo2_hi = r2[2];
+            }
             if (ACT == 1) {
-              nb_mo_lo = __builtin_amdgcn_update_dpp(nb_mo_lo, Mh[OE - 1][0], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+              if (!RING) {
+                nb_mo_lo = __builtin_amdgcn_update_dpp(nb_mo_lo, Mh[MOD][0], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                nb_mo_hi = __builtin_amdgcn_update_dpp(nb_mo_hi, Mh[MOD][0], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+                mo_lo = nb_mo_lo; mo_hi = nb_mo_hi;
+              }
               nb_ie_lo = __builtin_amdgcn_update_dpp(nb_ie_lo, Ih[E - 1][0], 0x138, 0xf, 0xf, false);
-              nb_mo_hi = __builtin_amdgcn_update_dpp(nb_mo_hi, Mh[OE - 1][0], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
               nb_de_hi = __builtin_amdgcn_update_dpp(nb_de_hi, Dh[E - 1][0], 0x130, 0xf, 0xf, false);
-              mo_lo = nb_mo_lo; ie_lo = nb_ie_lo; mo_hi = nb_mo_hi; de_hi = nb_de_hi;
+              ie_lo = nb_ie_lo; de_hi = nb_de_hi;
               if (TWO) {
-                nb_ph_lo = __builtin_amdgcn_update_dpp(nb_ph_lo, PH[PD / 2][0], 0x138, 0xf, 0xf, false);
-                nb_ph_hi = __builtin_amdgcn_update_dpp(nb_ph_hi, PH[PD / 2][0], 0x130, 0xf, 0xf, false);
                 nb_i2_lo = __builtin_amdgcn_update_dpp(nb_i2_lo, I2h[E2D - 1][0], 0x138, 0xf, 0xf, false);
                 nb_d2_hi = __builtin_amdgcn_update_dpp(nb_d2_hi, D2h[E2D - 1][0], 0x130, 0xf, 0xf, false);
-                plo = nb_ph_lo; phi = nb_ph_hi; i2e_lo = nb_i2_lo; d2e_hi = nb_d2_hi;
+                i2e_lo = nb_i2_lo; d2e_hi = nb_d2_hi;
               }
             } else {
-              mo_lo = BD::below(Mh[OE - 1], c); ie_lo = BD::below(Ih[E - 1], c);
-              mo_hi = BD::above(Mh[OE - 1], c); de_hi = BD::above(Dh[E - 1], c);
-              if (TWO) {
-                plo = BD::below(PH[PD / 2], c, -1); phi = BD::above(PH[PD / 2], c, -1);
-                i2e_lo = BD::below(I2h[E2D - 1], c); d2e_hi = BD::above(D2h[E2D - 1], c);
-              }
+              if (!RING) { mo_lo = BD::below(Mh[MOD], c); mo_hi = BD::above(Mh[MOD], c); }
+              ie_lo = BD::below(Ih[E - 1], c);
+              de_hi = BD::above(Dh[E - 1], c);
+              if (TWO) { i2e_lo = BD::below(I2h[E2D - 1], c); d2e_hi = BD::above(D2h[E2D - 1], c); }
             }
             ni[c] = max(mo_lo, ie_lo) + 2;
             nd[c] = max(mo_hi, de_hi);
             const int x1 = Mh[X - 1][c] + 2;
             int t = max(ni[c], nd[c]);
-            int mo2_lo = NUL, mo2_hi = NUL;
             ni2[c] = NUL; nd2[c] = NUL;
             if (TWO) {
-              const int m2lo = (PD & 1) ? (plo >> 16) : (int)(short)(plo & 0xffff), m2hi = (PD & 1) ? (phi >> 16) : (int)(short)(phi & 0xffff);
-              mo2_lo = (m2lo < 0) ? NUL : m2lo; mo2_hi = (m2hi < 0) ? NUL : m2hi;
               ni2[c] = max(mo2_lo, i2e_lo) + 2;
               nd2[c] = max(mo2_hi, d2e_hi);
               t = max(t, max(ni2[c], nd2[c]));
@@ -459,7 +481,11 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a, const uint32_t*
               rec[hoff[c]] = (uint8_t)cd;
               hoff[c] += WI;   // (an inactive chunk's offset is set again when it joins)
             }
-            cur[c] = (m > lim2[c]) ? NUL : m;  // only M is clamped; negative values are dead already
+            // only M is clamped.  RING: a dead cell may be a small negative number here (NULL is read from the ring as -32768), and M must
+            // stay exact (its values go back into the ring, the hull and the cut-off): one unsigned compare covers both ends (lim2c =
+            // max(lim2, 0); a diagonal with lim2 < 0 holds no cell, and nothing can reach 0 there)
+            if (RING) cur[c] = ((uint32_t)m > (uint32_t)lim2c[c]) ? NUL : m;
+            else cur[c] = (m > lim2[c]) ? NUL : m;  // (negative values are dead already)
             oob |= __builtin_amdgcn_ballot_w64(t > lim2[c]);
           }
 #pragma unroll
@@ -514,8 +540,8 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a, const uint32_t*
           for (int j = 0; j < E2D; ++j) { I2h[j][c] = NUL; D2h[j][c] = NUL; }
 #pragma unroll
           for (int j = 0; j < DM; ++j) Mh[j][c] = NUL;
-#pragma unroll
-          for (int j = 0; j < NP; ++j) PH[j][c] = -1;
+          // (RING: the cells of an inactive chunk are NULL already — only active chunks are written, and what a shift or a smaller
+          // form leaves beyond them lay outside the hull)
         }
       };
       while (leave == 0) {
@@ -535,8 +561,16 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a, const uint32_t*
             for (int j = 0; j < DM - 1; ++j) any &= Mh[j][c];   // (gap-affine: the oldest M is dropped by the next compute-next)
             if (TWO) {
               any &= Mh[DM - 1][c];
+              // the rows of the ring (an inactive chunk's cells are NULL: not read); and the gap rings are cleaned: a dead cell computed from
+              // a NULL of the ring is a small negative number that would otherwise creep upwards by 2 per step
+              if (c < act) {
+#pragma unroll 3
+                for (int r = 0; r < RR; ++r) any &= (int)ring[r * RW + 1 + 64 * c + lane];
+              }
 #pragma unroll
-              for (int j = 0; j < NP; ++j) any &= PH[j][c] & (PH[j][c] << 16);  // sign set iff both halves are NULL
+              for (int j = 0; j < E; ++j) { Ih[j][c] = (Ih[j][c] < 0) ? NUL : Ih[j][c]; Dh[j][c] = (Dh[j][c] < 0) ? NUL : Dh[j][c]; }
+#pragma unroll
+              for (int j = 0; j < E2D; ++j) { I2h[j][c] = (I2h[j][c] < 0) ? NUL : I2h[j][c]; D2h[j][c] = (D2h[j][c] < 0) ? NUL : D2h[j][c]; }
             }
             hull[c] = (c < act) ? __builtin_amdgcn_ballot_w64(any >= 0) : 0ull;  // (an inactive chunk's registers are stale, not read)
           }
@@ -575,8 +609,13 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a, const uint32_t*
                   for (int j = 0; j < DM - 1; ++j) sh1(Mh[j][0], NUL);
                   if (TWO) {
                     sh1(Mh[DM - 1][0], NUL);
-#pragma unroll
-                    for (int j = 0; j < NP; ++j) sh1(PH[j][0], -1);
+                    // the ring rows: window position p takes what p + delta held (one chunk before and after: the source is inside it or NULL)
+#pragma unroll 1
+                    for (int r = 0; r < RR; ++r) {
+                      short* const row = ring + r * RW + 1;
+                      const short t = in ? row[src & 63] : (short)-32768;
+                      row[lane] = t;
+                    }
                   }
                 } else {
                   BD::shift(cur, delta, lane);
@@ -590,8 +629,15 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a, const uint32_t*
                   for (int j = 0; j < DM - 1; ++j) BD::shift(Mh[j], delta, lane);
                   if (TWO) {
                     BD::shift(Mh[DM - 1], delta, lane);
+#pragma unroll 1
+                    for (int r = 0; r < RR; ++r) {
+                      short* const row = ring + r * RW + 1;
+                      short t[NCH];
 #pragma unroll
-                    for (int j = 0; j < NP; ++j) BD::shift(PH[j], delta, lane, -1);
+                      for (int c = 0; c < NCH; ++c) { const int sp = 64 * c + lane + delta; t[c] = ((unsigned)sp < (unsigned)W) ? row[sp] : (short)-32768; }
+#pragma unroll
+                      for (int c = 0; c < NCH; ++c) row[64 * c + lane] = t[c];
+                    }
                   }
                 }
               }
@@ -701,6 +747,7 @@ template <int X, int OE, int E, int OE2, int E2>
 static int launch_slim_shape(const BandArgs& a, int nch, bool full, long long grid, hipStream_t stream) {
   constexpr int NCH1 = (OE2 > 0) ? 3 : 2;   // the first window: 128 diagonals, gap-affine-2p 192
   size_t smem = (size_t)a.lds_words * 2 * sizeof(uint32_t);
+  if (OE2 > 0) smem += (size_t)(OE2 - X) * (size_t)(64 * (nch == 4 ? 4 : NCH1) + 2) * sizeof(short);   // gap-affine-2p: the LDS ring of the deep M history
   static const int pad_kb = getenv("WFA_HIP_SLIM_LDS_PAD_KB") ? atoi(getenv("WFA_HIP_SLIM_LDS_PAD_KB")) : 0;   // (occupancy experiments)
   smem += (size_t)pad_kb << 10;
   if (nch == 4) {
