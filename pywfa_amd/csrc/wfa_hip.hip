@@ -1940,7 +1940,9 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
           // per pair), otherwise for as many pairs as do (explicit history: up to 4 x the resident waves)
           int64_t pairs = in_n;
           if (pairs * slot_bytes > budget / 2) {
-            pairs = std::min<int64_t>(in_n, (int64_t)al->cu_count * 32 * knob(al, K_BAND_SPLIT_ROUNDS, 4));
+            // (round 6: gap-affine-2p 8 — its kernel holds 12 waves per CU, so a launch of cu_count x 64 pairs was 1.17 rounds of resident
+            // waves with most of the chip idle in the second one; with twice the slots a launch is 2.7 rounds: C4-adaptive 214 -> 204 ms)
+            pairs = std::min<int64_t>(in_n, (int64_t)al->cu_count * 32 * knob(al, K_BAND_SPLIT_ROUNDS, b->ncomp == 5 ? 8 : 4));
             while (pairs > 1 && pairs * slot_bytes > budget) pairs = (pairs + 1) / 2;
           }
           split_region = ((size_t)(pairs * slot_bytes) + 255) & ~(size_t)255;
@@ -1955,12 +1957,18 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
     // stage's last launch then run under them
     size_t later_off = 0, gen_off = 0;
     int gen_grid = 0;
+    int64_t gen_stride = g.ws_stride;
     if (split_region && later_need && (int64_t)(split_region + later_need) <= free_budget(al)) {
       later_off = split_region;
       need = std::max(need, split_region + later_need);
       if (want_pipe_tail) {   // ... and the general kernel behind them a few slices of its own
+        // (a pair that reaches it has outgrown 256 diagonals: the arena of the first attempt would overflow and the pair be re-run with
+        // an 8 x larger one after a host round trip — 62 ms for ONE pair of a C4-adaptive run; these few slices start that large)
         gen_grid = std::max(1, std::min(g.grid, 16));
-        const size_t at = (split_region + later_need + 255) & ~(size_t)255, gen_need = (size_t)gen_grid * (size_t)g.ws_stride * 4;
+        const size_t at = (split_region + later_need + 255) & ~(size_t)255;
+        if (full) gen_stride = ((b->arena_fixed + 8 * b->arena_ints) + 63) & ~63ll;
+        size_t gen_need = (size_t)gen_grid * (size_t)gen_stride * 4;
+        if ((int64_t)(at + gen_need) > free_budget(al)) { gen_stride = g.ws_stride; gen_need = (size_t)gen_grid * (size_t)gen_stride * 4; }
         if ((int64_t)(at + gen_need) <= free_budget(al)) { gen_off = at; need = std::max(need, at + gen_need); }
       }
     }
@@ -2511,7 +2519,7 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
             tb.wbeg_dev = snap_a + launch; tb.nwork_dev = snap_a + launch + 1; tb.nwork = in_n;
             if (wfa::launch_band(tb, band_nch[1], full, adapt, seqlds, band_grid[1], al->tail_stream) != 0) { al->err = "band kernel launch failed"; return WFA_HIP_EDEVICE; }
             hipLaunchKernelGGL(wfa_snapshot_kernel, dim3(1), dim3(1), 0, al->tail_stream, tail_count, snap_b + launch + 1);
-            const int grc = launch_general_dyn(al, b, al->tail_stream, true, tail_list, snap_b + launch + 1, in_n, g.ws_stride, gen_grid, g.threads,
+            const int grc = launch_general_dyn(al, b, al->tail_stream, true, tail_list, snap_b + launch + 1, in_n, gen_stride, gen_grid, g.threads,
                                                b->d_ovf_list[0], b->d_counters + 1, reinterpret_cast<int32_t*>(reinterpret_cast<char*>(al->ws) + gen_off), snap_b + launch);
             if (grc != WFA_HIP_OK) return grc;
           }

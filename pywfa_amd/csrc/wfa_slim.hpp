@@ -254,9 +254,12 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a, const uint32_t*
 #ifdef WFA_SLIM_COUNTERS
           if (ACT == 1) ++cnt_small; else ++cnt_big;
 #endif
-          if (TWO && ACT > 1) {
-            // (gap-affine-2p keeps 25 ring registers per chunk: the chunks are extended one after the other, not interleaved, so
-            // that one chunk's probe temporaries are live at a time)
+#ifndef WFA_SLIM_2P_SERIAL_EXT
+#define WFA_SLIM_2P_SERIAL_EXT 0
+#endif
+          if (WFA_SLIM_2P_SERIAL_EXT && TWO && ACT > 1) {
+            // (round 5, when gap-affine-2p kept 25 ring registers per chunk: the chunks extended one after the other, not interleaved, so
+            // that one chunk's probe temporaries are live at a time; with the LDS ring of round 6 there is room to interleave them)
 #pragma unroll
             for (int c = 0; c < ACT; ++c) {
               bool more;
