@@ -1321,15 +1321,27 @@ inline int launch_band_rtc(const BandArgs& a, int nch, bool full, bool adapt, bo
   return rtc_launch("wfa_band.hpp", name, (unsigned)grid, 64, smem, stream, &a, sizeof(a));
 }
 
-// gap-affine shapes without an instantiation whose slim form is compiled at run time (round 5): rings of up to twelve steps — beyond,
-// and gap-affine-2p, take wfa_band_kernel's run-time form as before
-inline bool slim_rtc_shape_ok(int X, int OE, int E, int OE2) { return OE2 == 0 && (X > OE ? X : OE) <= 12 && E <= 3; }
+// shapes without an instantiation whose slim form is compiled at run time: gap-affine with rings of up to twelve steps (round 5) and,
+// since the deep M history of gap-affine-2p lives in an LDS ring (round 6: eleven ring registers per chunk whatever o2 + e2 is),
+// gap-affine-2p with x < o + e < o2 + e2 and a ring of up to 40 rows; the rest takes wfa_band_kernel's run-time form as before
+inline bool slim_rtc_shape_ok(int X, int OE, int E, int OE2, int E2 = 0) {
+  if (OE2 == 0) return (X > OE ? X : OE) <= 12 && E <= 3;
+  return X < OE && OE < OE2 && X <= 8 && E <= 3 && E2 >= 1 && E2 <= 2 && OE2 - X <= 40;
+}
 inline int launch_slim_rtc(const BandArgs& a, int nch, bool full, long long grid, hipStream_t stream) {
-  const int g = a.g, X = a.x / g, OE = a.oe / g, E = a.e / g;
+  const int g = a.g, X = a.x / g, OE = a.oe / g, E = a.e / g, OE2 = a.oe2 / g, E2 = a.e2 / g;
   const int hist = (full && a.split) ? 1 : full ? 2 : 0;
-  const std::string name = std::string("wfa::") + (nch == 4 ? "wfa_slim_kernel_tail<4, " : "wfa_slim_kernel<2, ") + std::to_string(hist) + ", " + std::to_string(X) + ", " +
-                           std::to_string(OE) + ", " + std::to_string(E) + (a.win ? ", 0, 0, true>" : ", 0, 0>");
-  return rtc_launch("wfa_slim.hpp", name, (unsigned)grid, 64, (size_t)a.lds_words * 2 * sizeof(uint32_t), stream, &a, sizeof(a));
+  size_t smem = (size_t)a.lds_words * 2 * sizeof(uint32_t);
+  std::string name;
+  if (OE2 > 0) {
+    name = std::string("wfa::") + (nch == 4 ? "wfa_slim_kernel_tail<4, " : "wfa_slim_kernel_2p<3, ") + std::to_string(hist) + ", " + std::to_string(X) + ", " +
+           std::to_string(OE) + ", " + std::to_string(E) + ", " + std::to_string(OE2) + ", " + std::to_string(E2) + ">";
+    smem += (size_t)(OE2 - X) * (size_t)(64 * (nch == 4 ? 4 : 3) + 2) * sizeof(short);   // the LDS ring of the deep M history (wfa_slim.hpp)
+  } else {
+    name = std::string("wfa::") + (nch == 4 ? "wfa_slim_kernel_tail<4, " : "wfa_slim_kernel<2, ") + std::to_string(hist) + ", " + std::to_string(X) + ", " +
+           std::to_string(OE) + ", " + std::to_string(E) + (a.win ? ", 0, 0, true>" : ", 0, 0>");
+  }
+  return rtc_launch("wfa_slim.hpp", name, (unsigned)grid, 64, smem, stream, &a, sizeof(a));
 }
 
 // true when launch_band() sends this launch to wfa_slim_kernel: slim_takes() and a shape the library has an instantiation of or
@@ -1342,7 +1354,7 @@ inline bool slim_launches(const BandArgs& a, int nch, bool full, bool adapt, boo
 #define WFA_SLIM_MATCH2(x_, oe_, e_, oe2_, e2_) if (X == x_ && OE == oe_ && E == e_ && OE2 == oe2_ && E2 == e2_) return true;
     WFA_BAND_SHAPES_2P(WFA_SLIM_MATCH2)
 #undef WFA_SLIM_MATCH2
-    return false;
+    return slim_rtc_shape_ok(X, OE, E, OE2, E2) && rtc_available();
   }
 #define WFA_SLIM_MATCH(i, x, oe, e) if (X == x && OE == oe && E == e) return true;
   WFA_BAND_SHAPES(WFA_SLIM_MATCH)
@@ -1358,6 +1370,7 @@ inline int launch_band(const BandArgs& a, int nch, bool full, bool adapt, bool s
 #define WFA_BAND_LAUNCH2(x_, oe_, e_, oe2_, e2_) if (X == x_ && OE == oe_ && E == e_ && OE2 == oe2_ && E2 == e2_) return slim_takes(a, nch, full, adapt, seqlds) ? launch_slim_s4(a, nch, full, grid, stream) : launch_band_s4(a, nch, full, adapt, seqlds, grid, stream);
     WFA_BAND_SHAPES_2P(WFA_BAND_LAUNCH2)
 #undef WFA_BAND_LAUNCH2
+    if (slim_takes(a, nch, full, adapt, seqlds) && slim_rtc_shape_ok(X, OE, E, OE2, E2)) return launch_slim_rtc(a, nch, full, grid, stream);
     return launch_band_rtc(a, nch, full, adapt, seqlds, grid, stream);
   }
 #define WFA_BAND_LAUNCH(i, x, oe, e) if (X == x && OE == oe && E == e) return slim_takes(a, nch, full, adapt, seqlds) ? launch_slim_s##i(a, nch, full, grid, stream) : launch_band_s##i(a, nch, full, adapt, seqlds, grid, stream);

@@ -52,6 +52,10 @@ CONFIGS = [
     dict(span="end-to-end", heuristic="adaptive", max_distance_threshold=130),
     dict(span="ends-free", heuristic="adaptive", max_distance_threshold=160, pattern_begin_free=30, text_end_free=20),
     dict(distance="affine2p", span="end-to-end", heuristic="adaptive", max_distance_threshold=110),
+    # gap-affine-2p shapes the library has no instantiation of (round 6: the slim form compiled at run time — the LDS ring of the deep M
+    # history takes any o2 + e2): 5/6/2/24/1 (ring of 20 rows) and 3/4/2/12/1 (ring of 10 rows, g = 1)
+    dict(distance="affine2p", span="ends-free", heuristic="adaptive", mismatch=5, pattern_begin_free=50, pattern_end_free=100),
+    dict(distance="affine2p", span="end-to-end", heuristic="adaptive", mismatch=3, gap_opening=4, gap_extension=2, gap_opening2=12, gap_extension2=1),
 ]
 
 

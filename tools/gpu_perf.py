@@ -50,6 +50,7 @@ if "C3s" in which: run("10kb adaptive score", 100000, 10000, 0.08, 1003, dict(sp
 if "C1big" in which: run("C1 150bp full, 10M pairs", 10000000, 150, 0.02, 1001, dict(scope="full"), cpu_n=200000, reps=2)
 if "C3big" in which: run("C3 10kb adaptive full, 400k pairs", 400000, 10000, 0.08, 1003, dict(span="end-to-end", scope="full", heuristic="adaptive"), cpu_n=100, reps=2)
 if "C4abig" in which: run("C4 adaptive full, 100k pairs", 100000, 10000, 0.08, 1004, dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="full", heuristic="adaptive"), cpu_n=50, reps=2)
+if "C4ax5" in which: run("C4 adaptive full, mismatch=5 (run-time shape), 100k pairs", 100000, 10000, 0.08, 1004, dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="full", heuristic="adaptive", mismatch=5), cpu_n=50, reps=2)
 if "C4sbig" in which: run("C4 adaptive score, 100k pairs", 100000, 10000, 0.08, 1004, dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="score", heuristic="adaptive"), cpu_n=50, reps=2)
 if "C3x8k" in which: run("10kb exact score, 8192 pairs", 8192, 10000, 0.08, 1003, dict(span="end-to-end", scope="score"), cpu_n=16, reps=1)
 if "C3xf8k" in which: run("10kb exact full, 8192 pairs", 8192, 10000, 0.08, 1003, dict(span="end-to-end", scope="full"), cpu_n=16, reps=1)
