@@ -118,4 +118,18 @@ bool host_pack_seq(const uint8_t* s, int len, uint32_t* out, int form) {
   return pack_scalar(s, len, out);
 }
 
+// 2-bit input (the reference's packed form, R/wavefront_sequences.c:102-139: four bases per byte, base j of a byte in bits 2 j .. 2 j + 1,
+// A 0 / C 1 / G 2 / T 3) -> the device layout above: the same bit positions, G and T swapped (code ^ (code >> 1)), zero beyond the end.
+// What wfa_repack2_kernel does on the device, done by the upload workers on their way into the pinned ring (round 6: the 2-bit
+// entry then sends the same words + 4 B of lengths per pair as the ASCII entry instead of the caller's bytes + 48 B per pair).
+void host_repack2_seq(const uint8_t* s, int len, uint32_t* out) {
+  if (len <= 0) return;
+  const int nw = (len + 15) >> 4, nbytes = (len + 3) >> 2;
+  out[nw - 1] = 0u;                                  // (the last word is only partly covered by the caller's bytes)
+  memcpy(out, s, (size_t)nbytes);
+  const int tail = len & 15;
+  for (int w = 0; w < nw; ++w) { const uint32_t v = out[w]; out[w] = v ^ ((v >> 1) & 0x55555555u); }
+  if (tail) out[nw - 1] &= (1u << (2 * tail)) - 1u;
+}
+
 }  // namespace wfa

@@ -47,7 +47,7 @@ static thread_local std::string g_error;
 // never call getenv.
 #define WFA_COUNTER_WORDS 256  // counters of a batch (wfa_hip_batch::d_counters)
 #define WFA_KNOBS(F)                                                                                              \
-  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(BAND_LDS_MAX) F(BAND_NO_WIN) F(BAND_SPLIT_MIN) F(NO_TINY_INLINE) F(BILEVEL) F(BILEVEL_WIDE_LEVELS) F(BILEVEL_PER_CU) F(BILEVEL_I32) F(BILEVEL_QCAP) F(BILEVEL_LEVELS) F(BILEVEL_LDS) F(BILEVEL_NO_1024) F(BILEVEL_HUGE_MIN) F(BILEVEL_LDS_W) F(BILEVEL_NO_SEQL) F(LANE_DYN) F(LANE_DYN_WAVES) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB) F(PIPE_TAIL)     \
+  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(BAND_LDS_MAX) F(BAND_NO_WIN) F(BAND_SPLIT_MIN) F(NO_TINY_INLINE) F(BILEVEL) F(BILEVEL_WIDE_LEVELS) F(BILEVEL_PER_CU) F(BILEVEL_I32) F(BILEVEL_QCAP) F(BILEVEL_LEVELS) F(BILEVEL_LDS) F(BILEVEL_NO_1024) F(BILEVEL_HUGE_MIN) F(BILEVEL_LDS_W) F(BILEVEL_NO_SEQL) F(LANE_DYN) F(LANE_DYN_WAVES) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB) F(PIPE_TAIL) F(LEN16)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
   F(LANE_FULL) F(LANE_FULL_SPLIT) F(LANE_HEUR) F(SEG_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_ADAPT) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(TILE) F(TILE_T) F(TILE_WT) F(TILE_THREADS) F(TILE_PER_CU) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY) F(PILOT_PCT) F(WIDE_ADAPT_LDS)
@@ -203,6 +203,9 @@ struct wfa_hip_batch {
   std::vector<int32_t> h_plen, h_tlen;
   std::vector<int64_t> h_coff;
   std::unique_ptr<WfaPairMeta[]> h_meta;  // kept until the batch dies: its upload may still be in flight when batch_build returns
+  std::vector<wfa::WfaPieceDesc> h_pieces;   // host-packed upload with 16-bit lengths: the pieces' first pair / first word (uploaded; kept like h_meta)
+  uint32_t* d_len16 = nullptr;               // ... the {plen, tlen} halves as uploaded, and the piece table on the device
+  wfa::WfaPieceDesc* d_pieces = nullptr;
   int max_width = 0;       // max(plen+tlen)+3
   int max_len = 0;         // max(plen, tlen)
   int64_t packed_bytes = 0;  // sum of ceil(len/4) over all sequences (algorithmic 2-bit bytes)
@@ -532,7 +535,7 @@ static void batch_free(wfa_hip_batch* b) {
   void* ptrs[] = {b->d_bytes, b->d_pboff, b->d_tboff, b->d_meta, b->d_words, b->d_flags, b->d_score, b->d_status,
                   b->d_ops, b->d_cigar_off, b->d_cigar_begin, b->d_cigar_len, b->d_list_packed, b->d_list_bytes,
                   b->d_fb_list2[0], b->d_fb_list2[1], b->d_ovf_list[0], b->d_ovf_list[1], b->d_counters,
-                  b->d_plen, b->d_tlen, b->d_run_count, b->d_locs, b->d_run_off};
+                  b->d_plen, b->d_tlen, b->d_run_count, b->d_locs, b->d_run_off, b->d_len16, b->d_pieces};
   // blocks go back to the aligner's pool: nothing of this batch may still be running
   const bool timing = b->al->knobs.set[K_TIMING];
   const double t0 = timing ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
@@ -752,13 +755,16 @@ static int staged_upload(wfa_hip_aligner* al, const std::vector<UploadJob>& jobs
 // A piece is a run of whole 64-pair blocks whose words and metadata fit one slot.  Pairs with a letter outside ACGT are
 // listed in `flagged` (ascending); the caller uploads their bytes separately.  Returns after every piece is ENQUEUED:
 // the caller's arrays are not read after that.
-namespace wfa { bool host_pack_seq(const uint8_t* s, int len, uint32_t* out, int form); }
+namespace wfa { bool host_pack_seq(const uint8_t* s, int len, uint32_t* out, int form); void host_repack2_seq(const uint8_t* s, int len, uint32_t* out); }
 
 struct PackPiece { int64_t lo, hi; uint64_t wlo; uint64_t nwords; };
 
 static int staged_pack_upload(wfa_hip_aligner* al, wfa_hip_batch* b, const std::vector<PackPiece>& pieces, const uint8_t* seqs,
                               const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len,
-                              hipStream_t stream, std::vector<uint32_t>* flagged) {
+                              hipStream_t stream, std::vector<uint32_t>* flagged, bool in2bit = false, uint32_t* d_len16 = nullptr) {
+  // in2bit: the caller's sequences are 2-bit already (four bases per byte at BYTE offsets): re-based to whole words and re-coded here
+  // d_len16: the metadata crosses PCIe as 4 B per pair {plen, tlen} (16-bit each) into d_len16; wfa_meta_from_len16_kernel rebuilds
+  //          the 16 B records on the device (round 6: 96 -> 84 B per 150 bp pair)
   { const int rrc = staged_ring(al); if (rrc != WFA_HIP_OK) return rrc; }
   const int nslots = (int)al->pin_slot.size();
   const int nthreads = std::min<int>(staged_pack_threads(al), std::max<int>(1, (int)pieces.size()));
@@ -783,7 +789,7 @@ static int staged_pack_upload(wfa_hip_aligner* al, wfa_hip_batch* b, const std::
   }
   hipStream_t const main_stream = stream;
   int64_t src_lo = 0, src_hi = 0;
-  if (!pieces.empty()) { src_lo = p_off[pieces.front().lo]; src_hi = t_off[pieces.back().hi - 1] + t_len[pieces.back().hi - 1]; }
+  if (!pieces.empty()) { src_lo = p_off[pieces.front().lo]; src_hi = t_off[pieces.back().hi - 1] + (in2bit ? (t_len[pieces.back().hi - 1] + 3) / 4 : t_len[pieces.back().hi - 1]); }
   const bool bind = upload_binds(al, seqs + std::min(src_lo, src_hi), (size_t)std::llabs(src_hi - src_lo));
   auto worker = [&](bool spawned) {
     bind_upload_worker(al, bind && spawned);   // (never the caller's own thread: ADVICE r05)
@@ -799,23 +805,28 @@ static int staged_pack_upload(wfa_hip_aligner* al, wfa_hip_batch* b, const std::
       uint32_t* words = reinterpret_cast<uint32_t*>(al->pin_slot[(size_t)sl]);
       const size_t meta_at = ((size_t)pc.nwords * 4 + 15) & ~(size_t)15;
       WfaPairMeta* meta = reinterpret_cast<WfaPairMeta*>(al->pin_slot[(size_t)sl] + meta_at);
+      uint32_t* const l16 = reinterpret_cast<uint32_t*>(al->pin_slot[(size_t)sl] + meta_at);
       uint64_t w = pc.wlo;
       for (int64_t q = pc.lo; q < pc.hi; ++q) {
         const int pl = p_len[q], tl = t_len[q];
         if (p_off[q] < 0 || t_off[q] < 0) { failed.store(2); return; }
-        WfaPairMeta& m = meta[q - pc.lo];
-        m.plen = pl; m.tlen = tl;
-        m.p_woff = (uint32_t)w;
-        bool bd = wfa::host_pack_seq(seqs + p_off[q], pl, words + (w - pc.wlo), -1);
+        const uint32_t pw = (uint32_t)w;
+        bool bd = false;
+        if (in2bit) wfa::host_repack2_seq(seqs + p_off[q], pl, words + (w - pc.wlo));
+        else bd = wfa::host_pack_seq(seqs + p_off[q], pl, words + (w - pc.wlo), -1);
         w += (uint64_t)((pl + 15) >> 4);
-        m.t_woff = (uint32_t)w;
-        bd |= wfa::host_pack_seq(seqs + t_off[q], tl, words + (w - pc.wlo), -1);
+        const uint32_t tw = (uint32_t)w;
+        if (in2bit) wfa::host_repack2_seq(seqs + t_off[q], tl, words + (w - pc.wlo));
+        else bd |= wfa::host_pack_seq(seqs + t_off[q], tl, words + (w - pc.wlo), -1);
         w += (uint64_t)((tl + 15) >> 4);
+        if (d_len16) l16[q - pc.lo] = (uint32_t)pl | ((uint32_t)tl << 16);
+        else { WfaPairMeta& m = meta[q - pc.lo]; m.plen = pl; m.tlen = tl; m.p_woff = pw; m.t_woff = tw; }
         if (bd) bad[(size_t)i].push_back((uint32_t)q);
       }
       bool ok = true;
       if (pc.nwords) ok = hipMemcpyAsync(b->d_words + pc.wlo, words, (size_t)pc.nwords * 4, hipMemcpyHostToDevice, stream) == hipSuccess;
-      ok = ok && hipMemcpyAsync(b->d_meta + pc.lo, meta, (size_t)(pc.hi - pc.lo) * sizeof(WfaPairMeta), hipMemcpyHostToDevice, stream) == hipSuccess;
+      if (d_len16) ok = ok && hipMemcpyAsync(d_len16 + pc.lo, l16, (size_t)(pc.hi - pc.lo) * sizeof(uint32_t), hipMemcpyHostToDevice, stream) == hipSuccess;
+      else ok = ok && hipMemcpyAsync(b->d_meta + pc.lo, meta, (size_t)(pc.hi - pc.lo) * sizeof(WfaPairMeta), hipMemcpyHostToDevice, stream) == hipSuccess;
       ok = ok && hipEventRecord(al->pin_ev[(size_t)sl], stream) == hipSuccess;
       if (!ok) failed.store(1);
       al->pin_ev_recorded[(size_t)sl] = 1;
@@ -886,7 +897,8 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
   // host-packed upload: large batches without a wildcard (a wildcard aligns every pair on its bytes).  Pass 1 then also
   // sums the words of every block of 64 pairs (the parts start on block boundaries), the pieces of the upload are cut
   // from those below
-  bool host_pack = pipelined && !in2bit && c.wildcard < 0 && knob(al, K_HOST_PACK, 1) != 0;
+  // (round 6: 2-bit input too — its bytes are re-based to whole words and re-coded by the same workers: wfa::host_repack2_seq)
+  bool host_pack = pipelined && c.wildcard < 0 && knob(al, K_HOST_PACK, 1) != 0;
   const bool light = host_pack;   // (pass 1 reads the lengths only; see pass1_light)
   std::vector<uint32_t> blk_words(host_pack ? (size_t)((n + 63) >> 6) : 0, 0u);
   auto pass1 = [&](int t) {
@@ -986,6 +998,10 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
   }
   if (woff > 0xFFFFFFF0ull) { al->err = "batch too large: more than 2^32 packed words (split the batch)"; return WFA_HIP_EINVAL; }
   std::vector<PackPiece> pack_pieces;
+  // the metadata of a host-packed upload as 4 B per pair (16-bit lengths; the word offsets are rebuilt on the device) when no sequence
+  // is longer than 65 535 bases (WFA_HIP_LEN16=0: the 16 B records)
+  const bool len16 = host_pack && b->max_len < 65536 && knob(al, K_LEN16, 1) != 0;
+  const size_t meta_wire = len16 ? sizeof(uint32_t) : sizeof(WfaPairMeta);
   if (host_pack) {
     const size_t slot = staged_slot_bytes(al);
     PackPiece cur{0, 0, 0, 0};
@@ -994,7 +1010,7 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
       const int64_t blo = bi << 6, bhi = std::min<int64_t>(n, blo + 64);
       const uint64_t bw = blk_words[(size_t)bi];
       if ((size_t)bw * 4 + 16 + 64 * sizeof(WfaPairMeta) > slot) host_pack = false;   // (very long reads: the plain form)
-      if (cur.hi > cur.lo && (size_t)(cur.nwords + bw) * 4 + 16 + (size_t)(bhi - cur.lo) * sizeof(WfaPairMeta) > slot) {
+      if (cur.hi > cur.lo && (size_t)(cur.nwords + bw) * 4 + 16 + (size_t)(bhi - cur.lo) * meta_wire > slot) {
         pack_pieces.push_back(cur);
         cur = PackPiece{blo, blo, cur.wlo + cur.nwords, 0};
       }
@@ -1055,8 +1071,20 @@ static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const u
   if (timing) { fprintf(stderr, "[wfa_hip] mallocs %.3f ms\n", now_ms() - t0); t0 = now_ms(); }
   if (n > 0 && host_pack) {
     std::vector<uint32_t> flagged;
-    const int urc = staged_pack_upload(al, b, pack_pieces, seqs, p_off, p_len, t_off, t_len, al->stream, &flagged);
+    const bool use16 = len16 && host_pack;
+    if (use16) {
+      HIP_TRY(al, pool_alloc(al, (void**)&b->d_len16, nn * sizeof(uint32_t)));
+      HIP_TRY(al, pool_alloc(al, (void**)&b->d_pieces, pack_pieces.size() * sizeof(wfa::WfaPieceDesc)));
+    }
+    const int urc = staged_pack_upload(al, b, pack_pieces, seqs, p_off, p_len, t_off, t_len, al->stream, &flagged, in2bit, use16 ? b->d_len16 : nullptr);
     if (urc != WFA_HIP_OK) return urc;
+    if (use16) {
+      b->h_pieces.resize(pack_pieces.size());
+      for (size_t q = 0; q < pack_pieces.size(); ++q) b->h_pieces[q] = wfa::WfaPieceDesc{(long long)pack_pieces[q].lo, (long long)pack_pieces[q].hi, (unsigned long long)pack_pieces[q].wlo};
+      HIP_TRY(al, hipMemcpyAsync(b->d_pieces, b->h_pieces.data(), b->h_pieces.size() * sizeof(wfa::WfaPieceDesc), hipMemcpyHostToDevice, al->stream));
+      hipLaunchKernelGGL(wfa::wfa_meta_from_len16_kernel, dim3((unsigned)pack_pieces.size()), dim3(256), 0, al->stream, b->d_pieces, b->d_len16, b->d_meta);
+      HIP_TRY(al, hipGetLastError());
+    }
     if (timing) { fprintf(stderr, "[wfa_hip] host pack + H2D enqueue %.3f ms (%.2f GB of ASCII, %.2f GB sent)\n", now_ms() - t0, b->ops_bytes / 1e9,
                           (woff * 4.0 + n * 16.0) / 1e9); t0 = now_ms(); }
     b->n_bytes = (uint32_t)flagged.size();

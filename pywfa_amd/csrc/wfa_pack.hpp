@@ -95,6 +95,40 @@ wfa_repack2_kernel(const uint8_t* __restrict__ bytes, const int64_t* __restrict_
   }
 }
 
+// Host-packed upload with 16-bit lengths (round 6): the pinned ring carries 4 B per pair {plen, tlen} instead of the 16 B WfaPairMeta;
+// the word offsets are rebuilt here, one workgroup per piece of the upload (a piece knows its first pair and its first word: the
+// host's pass 1 summed the words of every 64-pair block): thread t takes a contiguous run of the piece's pairs, the runs' word
+// counts are scanned through LDS, then every thread writes its pairs' metadata.
+struct WfaPieceDesc { long long lo, hi; unsigned long long wlo; };
+__global__ void __launch_bounds__(256)
+wfa_meta_from_len16_kernel(const WfaPieceDesc* __restrict__ pieces, const uint32_t* __restrict__ len16, WfaPairMeta* __restrict__ meta) {
+  __shared__ uint32_t part[256];
+  const WfaPieceDesc pc = pieces[blockIdx.x];
+  const long long npairs = pc.hi - pc.lo;
+  const long long per = (npairs + 255) / 256;
+  const long long a = pc.lo + (long long)threadIdx.x * per, b = (a + per < pc.hi) ? a + per : pc.hi;
+  uint32_t sum = 0;
+  for (long long i = a; i < b; ++i) { const uint32_t v = len16[i]; sum += (((v & 0xffffu) + 15u) >> 4) + (((v >> 16) + 15u) >> 4); }
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {   // inclusive scan
+    const uint32_t add = (threadIdx.x >= (unsigned)d) ? part[threadIdx.x - d] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  uint32_t w = (uint32_t)pc.wlo + part[threadIdx.x] - sum;
+  for (long long i = a; i < b; ++i) {
+    const uint32_t v = len16[i];
+    const uint32_t pl = v & 0xffffu, tl = v >> 16;
+    WfaPairMeta m;
+    m.p_woff = w; w += (pl + 15u) >> 4;
+    m.t_woff = w; w += (tl + 15u) >> 4;
+    m.plen = (int)pl; m.tlen = (int)tl;
+    meta[i] = m;
+  }
+}
+
 // Host-packed upload: byte offsets and flags of the pairs that hold a letter outside ACGT (their bytes sit in a compact blob).
 __global__ void __launch_bounds__(256)
 wfa_flag_scatter_kernel(const uint32_t* __restrict__ ids, const int64_t* __restrict__ pb, const int64_t* __restrict__ tb, uint32_t nb,
