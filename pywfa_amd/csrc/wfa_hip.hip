@@ -466,6 +466,28 @@ extern "C" wfa_hip_aligner_t* wfa_hip_create(const wfa_hip_config_t* cfg, int de
   al->total_mem = prop.totalGlobalMem;
   if ((e = hipStreamCreateWithFlags(&al->stream, hipStreamNonBlocking)) != hipSuccess) { g_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete al; return nullptr; }
   if ((e = hipEventCreateWithFlags(&al->ws_event, hipEventDisableTiming)) != hipSuccess) { g_error = std::string("hipEventCreate: ") + hipGetErrorString(e); (void)hipStreamDestroy(al->stream); delete al; return nullptr; }
+  // Round 6: the aligner's other streams (walks, the pipelined tail, the second upload engine) are created HERE, back to back, and each is
+  // given a first command at once.  The runtime spreads streams over a handful of hardware queues as they first submit work; created
+  // lazily, in the middle of a process that has opened and closed other aligners, the main and the side stream of an aligner could land
+  // on the SAME hardware queue — the walks of a launch then ran after the next alignment kernel instead of under it (bench.py's C3 after
+  // the C2 / C1 legs: 44.7 ms where a fresh process measured 40.0; rocprofv3 showed both on queue 4).  Four streams bound in a row take
+  // four different queues whatever was bound before.
+  {
+    // (the second upload stream stays lazy — WFA_HIP_EAGER_UP=1 binds it here too: bound in this row the ASCII upload of 10 M pairs
+    // measured 93 ms instead of 30 ms)
+    static const bool eager_up = getenv("WFA_HIP_EAGER_UP") && *getenv("WFA_HIP_EAGER_UP") == '1';
+    hipStream_t* extra[3] = {&al->side_stream, &al->tail_stream, eager_up ? &al->up_stream : nullptr};
+    bool ok = true;
+    for (hipStream_t* sp : extra) ok = ok && (sp == nullptr || hipStreamCreateWithFlags(sp, hipStreamNonBlocking) == hipSuccess);
+    hipStream_t all[4] = {al->stream, al->side_stream, al->tail_stream, al->up_stream};
+    for (hipStream_t st : all) ok = ok && (st == nullptr || hipEventRecord(al->ws_event, st) == hipSuccess);
+    if (!ok) {
+      g_error = std::string("hipStreamCreate: ") + hipGetErrorString(hipGetLastError());
+      for (hipStream_t st : all) if (st) (void)hipStreamDestroy(st);
+      (void)hipEventDestroy(al->ws_event);
+      delete al; return nullptr;
+    }
+  }
   al->knobs.load();
   {
     // one process per GPU (bench.py --gpus N under torch.distributed.run, any launcher that exports LOCAL_WORLD_SIZE): the ranks of the
@@ -779,8 +801,8 @@ static int staged_pack_upload(wfa_hip_aligner* al, wfa_hip_batch* b, const std::
   // engines: pack + upload of 10 M x 150 bp 23 -> 21 ms)
   const bool two_up = knob(al, K_UP_STREAMS, 2) >= 2 && np >= 4;
   if (two_up) {
-    if (!al->up_stream) {
-      HIP_TRY(al, hipStreamCreateWithFlags(&al->up_stream, hipStreamNonBlocking));
+    if (!al->up_stream) HIP_TRY(al, hipStreamCreateWithFlags(&al->up_stream, hipStreamNonBlocking));
+    if (!al->up_fork) {
       HIP_TRY(al, hipEventCreateWithFlags(&al->up_fork, hipEventDisableTiming));
       HIP_TRY(al, hipEventCreateWithFlags(&al->up_join, hipEventDisableTiming));
     }
@@ -1456,8 +1478,7 @@ struct DualStream {
   int begin(bool want) {
     on = false; used[0] = used[1] = false;
     if (!want || knob(al, K_NO_DUAL, 0) != 0) return WFA_HIP_OK;
-    if (!al->side_stream) {
-      HIP_TRY(al, hipStreamCreateWithFlags(&al->side_stream, hipStreamNonBlocking));
+    if (!al->band_event[0]) {
       for (int i = 0; i < 4; ++i) {
         HIP_TRY(al, hipEventCreateWithFlags(&al->band_event[i], hipEventDisableTiming));
         HIP_TRY(al, hipEventCreateWithFlags(&al->walk_event[i], hipEventDisableTiming));
@@ -2505,8 +2526,7 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
         uint32_t* tail_list = nullptr; uint32_t* tail_count = nullptr;
         wfa::BandArgs tb = ba;   // the stage behind: everything but lists, history region and window width is this stage's
         if (pipe_tail) {
-          if (!al->tail_stream) {
-            HIP_TRY(al, hipStreamCreateWithFlags(&al->tail_stream, hipStreamNonBlocking));
+          if (!al->tail_join) {
             for (int q = 0; q < 2; ++q) HIP_TRY(al, hipEventCreateWithFlags(&al->tail_fork[q], hipEventDisableTiming));
             HIP_TRY(al, hipEventCreateWithFlags(&al->tail_join, hipEventDisableTiming));
           }

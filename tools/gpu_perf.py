@@ -8,8 +8,9 @@ from oracle import loader
 from pywfa_amd import datagen, _native
 import common
 
-def run(label, n, L, e, seed, kw, cpu_n=None, reps=2, check=True):
+def run(label, n, L, e, seed, kw, cpu_n=None, reps=2, check=True, trim=0):
     batch = datagen.generate(n, L, e, seed)
+    if trim: batch = datagen.trim_text(batch, trim)   # (bench.py's C4 configurations: 50 bases cut off both ends of every text)
     kw = common.clamp_free(kw, batch)
     oc, nc = common.configs_pair(**kw)
     full = oc.scope == 1
@@ -51,6 +52,7 @@ if "C1big" in which: run("C1 150bp full, 10M pairs", 10000000, 150, 0.02, 1001, 
 if "C3big" in which: run("C3 10kb adaptive full, 400k pairs", 400000, 10000, 0.08, 1003, dict(span="end-to-end", scope="full", heuristic="adaptive"), cpu_n=100, reps=2)
 if "C4abig" in which: run("C4 adaptive full, 100k pairs", 100000, 10000, 0.08, 1004, dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="full", heuristic="adaptive"), cpu_n=50, reps=2)
 if "C4ax5" in which: run("C4 adaptive full, mismatch=5 (run-time shape), 100k pairs", 100000, 10000, 0.08, 1004, dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="full", heuristic="adaptive", mismatch=5), cpu_n=50, reps=2)
+if "C4bench" in which: run("C4 adaptive full as bench.py runs it (texts trimmed by 50), 100k pairs", 100000, 10000, 0.08, 1004, dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="full", heuristic="adaptive"), cpu_n=50, reps=2, trim=50)
 if "C4sbig" in which: run("C4 adaptive score, 100k pairs", 100000, 10000, 0.08, 1004, dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="score", heuristic="adaptive"), cpu_n=50, reps=2)
 if "C3x8k" in which: run("10kb exact score, 8192 pairs", 8192, 10000, 0.08, 1003, dict(span="end-to-end", scope="score"), cpu_n=16, reps=1)
 if "C3xf8k" in which: run("10kb exact full, 8192 pairs", 8192, 10000, 0.08, 1003, dict(span="end-to-end", scope="full"), cpu_n=16, reps=1)
