@@ -4,7 +4,8 @@
 
 namespace wfa {
 #define WFA_SLIM_DEFINE(i, x, oe, e) \
-  int launch_slim_s##i(const BandArgs& a, int nch, bool full, long long grid, hipStream_t s) { return launch_slim_shape<x, oe, e, 0, 0>(a, nch, full, grid, s); }
+  int launch_slim_s##i(const BandArgs& a, int nch, bool full, long long grid, hipStream_t s) { return launch_slim_shape<x, oe, e, 0, 0>(a, nch, full, grid, s); } \
+  int launch_slim_mailbox_s##i(const BandArgs& a, bool full, hipStream_t s, SlimMailbox* mb) { return launch_slim_mailbox_shape<x, oe, e, 0, 0>(a, full, s, mb); }
 #if WFA_TU_INDEX == 0
 WFA_SLIM_DEFINE(0, 2, 4, 1)
 #elif WFA_TU_INDEX == 1

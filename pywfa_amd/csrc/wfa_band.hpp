@@ -84,6 +84,23 @@ struct BandArgs {
                           // sequences in LDS, score-only or piggy-back split history) take it instead of wfa_band_kernel (same results)
 };
 
+// One pair per call (wfa_slim.hpp: wfa_slim_kernel_one / wfa_slim_kernel_mailbox): everything the wave reads from the host about the pair
+#define WFA_SLIM_ONE_WORDS 136   // 2 x (1000 bases + the look-ahead words)
+struct SlimOne { uint32_t w[8 + WFA_SLIM_ONE_WORDS]; };   // [0,4) WfaPairMeta, [4,8) cigar_off[0..1], [8,..) words
+// The mailbox of the resident one-pair kernel (pinned host memory; host and device sides on lines of their own)
+struct SlimMailbox {
+  uint32_t req_seq;      // host -> device: number of the request that `req` holds
+  uint32_t quit;         // host -> device: leave now
+  uint32_t idle_ticks;   // leave after this many ticks of the 100 MHz clock without a request
+  uint32_t pad0[29];
+  uint32_t done_seq;     // device -> host: the last request whose results are in the pinned block
+  uint32_t alive;        // 1 from the host's launch of an instance until the instance leaves (the instance's last store)
+  uint32_t served;       // requests this instance has served (diagnostics)
+  uint32_t pad1[29];
+  SlimOne req;           // the request
+};
+
+
 // index of the lowest set bit, ~0u for 0 (v_ffbl_b32 semantics)
 __device__ __forceinline__ uint32_t band_ffbl(uint32_t x) {
   uint32_t r;
@@ -1263,7 +1280,8 @@ WFA_BAND_SHAPES(WFA_BAND_DECL)
 #undef WFA_BAND_DECL
 int launch_band_s4(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds, long long grid, hipStream_t stream);  // 2p
 // the slim form (wfa_slim.hpp, csrc/k_slim.hip): one translation unit per gap-affine shape
-#define WFA_SLIM_DECL(i, x, oe, e) int launch_slim_s##i(const BandArgs& a, int nch, bool full, long long grid, hipStream_t stream);
+#define WFA_SLIM_DECL(i, x, oe, e) int launch_slim_s##i(const BandArgs& a, int nch, bool full, long long grid, hipStream_t stream); \
+  int launch_slim_mailbox_s##i(const BandArgs& a, bool full, hipStream_t stream, SlimMailbox* mb);
 WFA_BAND_SHAPES(WFA_SLIM_DECL)
 #undef WFA_SLIM_DECL
 int launch_slim_s4(const BandArgs& a, int nch, bool full, long long grid, hipStream_t stream);  // 2p
@@ -1360,6 +1378,17 @@ inline bool slim_launches(const BandArgs& a, int nch, bool full, bool adapt, boo
   WFA_BAND_SHAPES(WFA_SLIM_MATCH)
 #undef WFA_SLIM_MATCH
   return slim_rtc_shape_ok(X, OE, E, 0) && rtc_available();
+}
+
+// an instance of the resident one-pair kernel (wfa_slim.hpp) for this configuration; -1: none (gap-affine-2p, a shape without an
+// instantiation, a launch the slim form does not take)
+inline int launch_slim_mailbox(const BandArgs& a, bool full, bool adapt, hipStream_t stream, SlimMailbox* mb) {
+  if (a.oe2 > 0 || a.split || !slim_takes(a, 2, full, adapt, true) || (rtc_force_all() && rtc_available())) return -1;
+  const int g = a.g, X = a.x / g, OE = a.oe / g, E = a.e / g;
+#define WFA_SLIM_MB(i, x, oe, e) if (X == x && OE == oe && E == e) return launch_slim_mailbox_s##i(a, full, stream, mb);
+  WFA_BAND_SHAPES(WFA_SLIM_MB)
+#undef WFA_SLIM_MB
+  return -1;
 }
 
 inline int launch_band(const BandArgs& a, int nch, bool full, bool adapt, bool seqlds, long long grid, hipStream_t stream) {

@@ -18,6 +18,7 @@
 #include <thread>
 #include <memory>
 #include <atomic>
+#include <mutex>
 #include <functional>
 #include <ctype.h>
 #include <pthread.h>
@@ -47,7 +48,7 @@ static thread_local std::string g_error;
 // never call getenv.
 #define WFA_COUNTER_WORDS 256  // counters of a batch (wfa_hip_batch::d_counters)
 #define WFA_KNOBS(F)                                                                                              \
-  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(BAND_LDS_MAX) F(BAND_NO_WIN) F(BAND_SPLIT_MIN) F(NO_TINY_INLINE) F(BILEVEL) F(BILEVEL_WIDE_LEVELS) F(BILEVEL_PER_CU) F(BILEVEL_I32) F(BILEVEL_QCAP) F(BILEVEL_LEVELS) F(BILEVEL_LDS) F(BILEVEL_NO_1024) F(BILEVEL_HUGE_MIN) F(BILEVEL_LDS_W) F(BILEVEL_NO_SEQL) F(LANE_DYN) F(LANE_DYN_WAVES) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB) F(PIPE_TAIL) F(LEN16)     \
+  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(BAND_LDS_MAX) F(BAND_NO_WIN) F(BAND_SPLIT_MIN) F(NO_TINY_INLINE) F(BILEVEL) F(BILEVEL_WIDE_LEVELS) F(BILEVEL_PER_CU) F(BILEVEL_I32) F(BILEVEL_QCAP) F(BILEVEL_LEVELS) F(BILEVEL_LDS) F(BILEVEL_NO_1024) F(BILEVEL_HUGE_MIN) F(BILEVEL_LDS_W) F(BILEVEL_NO_SEQL) F(LANE_DYN) F(LANE_DYN_WAVES) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB) F(PIPE_TAIL) F(LEN16) F(MAILBOX) F(MAILBOX_IDLE_US)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
   F(LANE_FULL) F(LANE_FULL_SPLIT) F(LANE_HEUR) F(SEG_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_ADAPT) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(TILE) F(TILE_T) F(TILE_WT) F(TILE_THREADS) F(TILE_PER_CU) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY) F(PILOT_PCT) F(WIDE_ADAPT_LDS)
@@ -124,6 +125,15 @@ struct wfa_hip_aligner {
   uint8_t* tiny_h = nullptr;
   uint8_t* tiny_hd = nullptr;
   uint8_t* tiny_d = nullptr;
+  // the resident one-pair kernel (round 6; wfa_slim.hpp: wfa_slim_kernel_mailbox): its mailbox in pinned host memory, the stream its
+  // instances run on, the arguments the running instance was started with (another configuration / workspace: it is told to leave first)
+  wfa::SlimMailbox* mb_h = nullptr;
+  wfa::SlimMailbox* mb_d = nullptr;
+  hipStream_t mb_stream = nullptr;
+  wfa::BandArgs mb_args;
+  bool mb_args_valid = false;
+  uint32_t mb_seq = 0;
+  int mb_failures = 0;
   size_t pin_slot_bytes = 0;
   int cu_count = 256;
   size_t total_mem = 0;
@@ -501,12 +511,15 @@ extern "C" wfa_hip_aligner_t* wfa_hip_create(const wfa_hip_config_t* cfg, int de
   return al;
 }
 
+static void mailbox_quit(wfa_hip_aligner* al);
 static void aligner_free(wfa_hip_aligner* al) {
   (void)hipSetDevice(al->device);
   if (al->ws) (void)hipFree(al->ws);
   pool_drain(al);
   if (al->ws_event) (void)hipEventDestroy(al->ws_event);
   for (uint8_t* p : al->pin_slot) (void)hipHostFree(p);
+  if (al->mb_h) { mailbox_quit(al); (void)hipHostFree(al->mb_h); }
+  if (al->mb_stream) (void)hipStreamDestroy(al->mb_stream);
   if (al->tiny_h) (void)hipHostFree(al->tiny_h);
   if (al->tiny_d) (void)hipFree(al->tiny_d);
   for (hipEvent_t e : al->pin_ev) (void)hipEventDestroy(e);
@@ -771,6 +784,50 @@ static int staged_upload(wfa_hip_aligner* al, const std::vector<UploadJob>& jobs
   return WFA_HIP_OK;
 }
 
+// The mirror image for large results (round 6: the op bytes of long reads — C5's 8 192 x 100 kb pairs are 1.6 GB): device -> pinned slot
+// by DMA, pinned slot -> the caller's pageable array by the host threads, a few pieces in flight.  A plain hipMemcpy into pageable
+// memory moves such a block at a few GB/s, and into a FRESH array (np.zeros: untouched pages) every page fault is taken by the one
+// thread the runtime copies with; here the faults are spread over the team.  Returns when the caller's array is complete.
+static int staged_download(wfa_hip_aligner* al, uint8_t* dst, const uint8_t* src_dev, size_t bytes, hipStream_t stream) {
+  const size_t slot_bytes = staged_slot_bytes(al);
+  { const int rrc = staged_ring(al); if (rrc != WFA_HIP_OK) return rrc; }
+  const int nslots = (int)al->pin_slot.size();
+  const long np = (long)((bytes + slot_bytes - 1) / slot_bytes);
+  const int nthreads = (int)std::max<long>(1, std::min<long>(std::min<long>(staged_pack_threads(al), nslots - 2), np));
+  std::atomic<long> next(0);
+  std::vector<std::atomic<long>> drained((size_t)nslots);   // index of the last piece copied OUT of the slot
+  for (auto& x : drained) x.store(-1);
+  std::atomic<int> failed(0);
+  std::mutex enq;   // DMAs are enqueued in piece order (a slot's event must be the one of its own piece)
+  const int device = al->device;
+  auto worker = [&]() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      const long i = next.fetch_add(1);
+      if (i >= np || failed.load()) return;
+      const int sl = (int)(i % nslots);
+      const size_t off = (size_t)i * slot_bytes, nb = std::min(slot_bytes, bytes - off);
+      if (i >= nslots) while (drained[(size_t)sl].load(std::memory_order_acquire) != i - nslots) { if (failed.load()) return; std::this_thread::yield(); }
+      if (al->pin_ev_recorded[(size_t)sl] && hipEventSynchronize(al->pin_ev[(size_t)sl]) != hipSuccess) failed.store(1);   // (an upload that used the slot)
+      {
+        std::lock_guard<std::mutex> lock(enq);
+        if (hipMemcpyAsync(al->pin_slot[(size_t)sl], src_dev + off, nb, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipEventRecord(al->pin_ev[(size_t)sl], stream) != hipSuccess) failed.store(1);
+        al->pin_ev_recorded[(size_t)sl] = 1;
+      }
+      if (!failed.load() && hipEventSynchronize(al->pin_ev[(size_t)sl]) != hipSuccess) failed.store(1);
+      if (!failed.load()) memcpy(dst + off, al->pin_slot[(size_t)sl], nb);
+      drained[(size_t)sl].store(i, std::memory_order_release);
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nthreads; ++t) th.emplace_back(worker);
+  worker();
+  for (auto& x : th) x.join();
+  if (failed.load()) { (void)hipGetLastError(); al->err = "pipelined download failed"; return WFA_HIP_EDEVICE; }
+  return WFA_HIP_OK;
+}
+
 // Host-packed form of the pipelined upload: the host threads pack the caller's ASCII sequences to
 // 2 bits per base (host_pack.cpp: AVX-512 / AVX2 / plain C) straight into the pinned slots, together with the per-pair
 // metadata, so 76 + 16 B per 150 bp pair cross PCIe instead of 300 + 32 B and the device pack kernel is not run.
@@ -877,6 +934,7 @@ static int pilot_band(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream)
 // of a byte in bits 2j..2j+1, A 0 / C 1 / G 2 / T 3), a sequence of len bases = (len + 3) / 4 bytes at its BYTE offset
 static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const uint8_t* seqs,
                        const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len, bool in2bit = false) {
+  if (al->mb_h && __atomic_load_n(&al->mb_h->alive, __ATOMIC_ACQUIRE) != 0) mailbox_quit(al);   // (the resident one-pair kernel: batches take the device)
   b->cfg = al->cfg; b->dcfg = al->dcfg; b->ncomp = al->ncomp;
   // Round 5: a wildcard letter outside ACGT cannot occur in a pair whose letters are all ACGT — such pairs take the 2-bit kernels as if
   // no wildcard were set (same result: nothing in them matches by wildcard), only the pairs holding other letters are aligned on their
@@ -1269,6 +1327,19 @@ __global__ void __launch_bounds__(256) wfa_score_translate_kernel(int32_t* __res
   else score[i] = (int)(((long long)sw_match * ((long long)meta[i].plen + meta[i].tlen) + raw) / 2);
 }
 
+// ... of the listed pairs only (full scope: the pairs whose arena overflowed are re-run after the stream's translation pass)
+__global__ void __launch_bounds__(256) wfa_score_translate_list_kernel(const uint32_t* __restrict__ list, uint32_t count, int32_t* __restrict__ score,
+                                                                       const int32_t* __restrict__ status, const WfaPairMeta* __restrict__ meta,
+                                                                       int mode, int sw_match) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  if (j >= count) return;
+  const uint32_t i = list[j];
+  if (status[i] != 0) return;
+  const int raw = score[i];
+  if (mode == 2) score[i] = -raw;
+  else score[i] = (int)(((long long)sw_match * ((long long)meta[i].plen + meta[i].tlen) + raw) / 2);
+}
+
 __global__ void __launch_bounds__(256) wfa_pilot_sample_kernel(const uint32_t* __restrict__ list, uint32_t stride, uint32_t np, uint32_t* __restrict__ out) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i < np) out[i] = list ? list[i * stride] : i * stride;
@@ -1650,6 +1721,7 @@ extern "C" int wfa_hip_batch_run(wfa_hip_batch_t* b, void* stream_) {
 static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
   wfa_hip_aligner* al = b->al;
   HIP_TRY(al, hipSetDevice(al->device));
+  if (al->mb_h && __atomic_load_n(&al->mb_h->alive, __ATOMIC_ACQUIRE) != 0) mailbox_quit(al);
   hipStream_t stream = stream_ ? (hipStream_t)stream_ : al->stream;
   // every run of this aligner uses the one workspace (al->ws): order this run after the previous one when it was
   // enqueued on another stream
@@ -2698,8 +2770,10 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
                             b->d_ovf_list[0], b->d_counters + 1);
     if (rc != WFA_HIP_OK) return rc;
   }
-  // score scope: translate in-stream (full scope: after the arena re-runs, wfa_hip_batch_sync)
-  if (b->dcfg.score_mode != 0 && !full)
+  // scores of a configuration that was mapped onto another (match < 0, the one-component distances): translated in-stream, in every
+  // scope (round 6: full scope used to wait for wfa_hip_batch_sync — an extra launch and a second synchronisation; now only the pairs an
+  // arena overflow re-runs are translated there: a pair that is still to be re-run carries a non-zero status and is skipped here)
+  if (b->dcfg.score_mode != 0)
     hipLaunchKernelGGL(wfa_score_translate_kernel, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, stream, b->d_score, b->d_status, b->d_meta,
                        (long long)b->n, b->dcfg.score_mode, b->dcfg.sw_match);
   HIP_TRY(al, hipEventRecord(al->ws_event, stream));
@@ -2750,6 +2824,9 @@ static int retry_overflows(wfa_hip_batch* b) {
       rc = launch_general_dyn(al, b, stream, kind == 0, d_l, nullptr, (uint32_t)l.size(), g.ws_stride, g.grid, g.threads,
                               b->d_ovf_list[nxt], b->d_counters + 1 + nxt);
       if (rc != WFA_HIP_OK) return rc;
+      if (b->dcfg.score_mode != 0)   // (the stream's translation pass skipped these pairs: their status was not 0 then)
+        hipLaunchKernelGGL(wfa_score_translate_list_kernel, dim3((unsigned)((l.size() + 255) / 256)), dim3(256), 0, stream, d_l, (uint32_t)l.size(),
+                           b->d_score, b->d_status, b->d_meta, b->dcfg.score_mode, b->dcfg.sw_match);
       HIP_TRY(al, hipStreamSynchronize(stream));
     }
     cur = nxt;
@@ -2779,11 +2856,6 @@ extern "C" int wfa_hip_batch_sync(wfa_hip_batch_t* b) {
     if (b->cfg.scope == WFA_SCOPE_FULL) {
       const int rc = retry_overflows(b);
       if (rc != WFA_HIP_OK) return rc;
-      if (b->dcfg.score_mode != 0) {   // (every run rewrites the raw scores: once per synchronisation)
-        hipLaunchKernelGGL(wfa_score_translate_kernel, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, b->last_stream, b->d_score, b->d_status,
-                           b->d_meta, (long long)b->n, b->dcfg.score_mode, b->dcfg.sw_match);
-        HIP_TRY(al, hipStreamSynchronize(b->last_stream));
-      }
     }
   }
   b->synced = true;
@@ -2820,7 +2892,10 @@ extern "C" int wfa_hip_batch_results(wfa_hip_batch_t* b, int32_t* score, int32_t
     const int64_t base0 = cigar_off[0];
     for (int64_t i = 0; i < n && same; ++i) { same = (cigar_off[i] == base0 + acc); acc += b->h_plen[i] + b->h_tlen[i]; }
     if (same) {
-      if (b->ops_bytes) HIP_TRY(al, hipMemcpy(cigar_ops + base0, b->d_ops, (size_t)b->ops_bytes, hipMemcpyDeviceToHost));
+      if (b->ops_bytes >= ((int64_t)64 << 20) && knob(al, K_NO_PIPE, 0) == 0) {   // (long reads: through the pinned ring, the host copies on a team of threads)
+        const int drc = staged_download(al, cigar_ops + base0, b->d_ops, (size_t)b->ops_bytes, b->last_stream ? b->last_stream : al->stream);
+        if (drc != WFA_HIP_OK) return drc;
+      } else if (b->ops_bytes) HIP_TRY(al, hipMemcpy(cigar_ops + base0, b->d_ops, (size_t)b->ops_bytes, hipMemcpyDeviceToHost));
       if (base0) for (int64_t i = 0; i < n; ++i) cigar_begin[i] += base0;
     } else {
       std::vector<uint8_t> tmp((size_t)std::max<int64_t>(b->ops_bytes, 1));
@@ -2949,6 +3024,73 @@ static inline int32_t tiny_score(const WfaDevConfig& d, int32_t raw, int32_t sta
   return (int32_t)(((long long)d.sw_match * ((long long)plen + tlen) + raw) / 2);
 }
 
+// ---- the resident one-pair kernel (wfa_slim.hpp: wfa_slim_kernel_mailbox) ----------------------------------------------
+// tell the running instance, if any, to leave, and wait until it has (its last store is alive = 0)
+static void mailbox_quit(wfa_hip_aligner* al) {
+  if (!al->mb_h) return;
+  if (__atomic_load_n(&al->mb_h->alive, __ATOMIC_ACQUIRE) != 0) {
+    __atomic_store_n(&al->mb_h->quit, 1u, __ATOMIC_RELEASE);
+    const double t0 = now_ms();
+    while (__atomic_load_n(&al->mb_h->alive, __ATOMIC_ACQUIRE) != 0 && now_ms() - t0 < 100.0) __builtin_ia32_pause();
+  }
+  if (al->mb_stream) (void)hipStreamSynchronize(al->mb_stream);   // (the instance has left, or never started: the stream drains at once)
+  __atomic_store_n(&al->mb_h->alive, 0u, __ATOMIC_RELEASE);
+  __atomic_store_n(&al->mb_h->quit, 0u, __ATOMIC_RELEASE);
+  al->mb_args_valid = false;
+}
+
+// one pair through the mailbox: 1 = served (results in the pinned block), 0 = not this way (the caller launches a kernel as before)
+static int mailbox_call(wfa_hip_aligner* al, const wfa::BandArgs& ba, bool full, bool adapt, const uint32_t* one, size_t one_words) {
+  if (knob(al, K_MAILBOX, 1) == 0 || al->mb_failures >= 3) return 0;
+  if (!al->mb_h) {
+    if (hipHostMalloc((void**)&al->mb_h, sizeof(wfa::SlimMailbox), hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); al->mb_h = nullptr; al->mb_failures = 3; return 0; }
+    memset(al->mb_h, 0, sizeof(wfa::SlimMailbox));
+    if (hipHostGetDevicePointer((void**)&al->mb_d, al->mb_h, 0) != hipSuccess ||
+        hipStreamCreateWithFlags(&al->mb_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); al->mb_failures = 3; return 0; }
+  }
+  wfa::SlimMailbox* const mb = al->mb_h;
+  wfa::BandArgs want = ba;
+  want.one = nullptr; want.done = nullptr;
+  // an instance started for another configuration / workspace leaves first
+  if (__atomic_load_n(&mb->alive, __ATOMIC_ACQUIRE) != 0 && (!al->mb_args_valid || memcmp(&want, &al->mb_args, sizeof(want)) != 0)) mailbox_quit(al);
+  memcpy(mb->req.w, one, one_words * sizeof(uint32_t));
+  const uint32_t k = ++al->mb_seq;
+  __atomic_store_n(&mb->req_seq, k, __ATOMIC_RELEASE);
+  auto start = [&]() -> bool {
+    // (idle time of an instance: long enough for the next call of a loop of single alignments, short enough that nothing lingers)
+    mb->idle_ticks = (uint32_t)std::max(1, knob(al, K_MAILBOX_IDLE_US, 2000)) * 100u;
+    __atomic_store_n(&mb->quit, 0u, __ATOMIC_RELEASE);
+    __atomic_store_n(&mb->alive, 1u, __ATOMIC_RELEASE);
+    if (wfa::launch_slim_mailbox(want, full, adapt, al->mb_stream, al->mb_d) != 0) {
+      (void)hipGetLastError();
+      __atomic_store_n(&mb->alive, 0u, __ATOMIC_RELEASE);
+      return false;
+    }
+    al->mb_args = want; al->mb_args_valid = true;
+    return true;
+  };
+  auto give_up = [&]() {
+    mailbox_quit(al);
+    __atomic_store_n(&mb->done_seq, k, __ATOMIC_RELEASE);   // (no instance is running: the request counts as consumed)
+    ++al->mb_failures;
+    return 0;
+  };
+  if (__atomic_load_n(&mb->alive, __ATOMIC_ACQUIRE) == 0 && !start()) return give_up();
+  const double t0 = now_ms();
+  for (uint32_t spins = 1;; ++spins) {
+    if (__atomic_load_n(&mb->done_seq, __ATOMIC_ACQUIRE) == k) return 1;
+    if ((spins & 255u) == 0) {
+      if (__atomic_load_n(&mb->alive, __ATOMIC_ACQUIRE) == 0) {
+        // the instance left (idle time over) as the request arrived: its results, if any, were stored before alive = 0
+        if (__atomic_load_n(&mb->done_seq, __ATOMIC_ACQUIRE) == k) return 1;
+        if (!start()) return give_up();
+      }
+      if (now_ms() - t0 > 100.0) return give_up();   // (something is wrong: the launch-per-call path takes the pair)
+    }
+    __builtin_ia32_pause();
+  }
+}
+
 static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const int64_t* p_off, const int32_t* p_len,
                       const int64_t* t_off, const int32_t* t_len, int32_t* score, int32_t* status, uint8_t* cigar_ops,
                       const int64_t* cigar_off, int64_t* cigar_begin, int32_t* cigar_len) {
@@ -3030,13 +3172,18 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
       ba.min_wf_len = al->dcfg.min_wf_len; ba.max_dist_thr = al->dcfg.max_dist_thr; ba.steps_between = al->dcfg.steps_between;
       ba.heur = al->dcfg.heuristic; ba.xdrop = al->dcfg.xdrop; ba.max_steps = al->dcfg.max_steps; ba.scope = al->dcfg.scope;
       ba.lds_words = ((max_len + 15) >> 4) + 4;
+      // one pair, gap-affine: the resident kernel takes it from its mailbox when it can (mailbox_call) — its instance outlives the call,
+      // so everything in its arguments is sized for the longest pair of this path, not for this one
+      const bool try_mb = n == 1 && w + 4 <= 136 && al->ncomp == 3 && knob(al, K_BAND_SLIM, 1) != 0 && knob(al, K_NO_TINY_INLINE, 0) == 0 &&
+                          knob(al, K_MAILBOX, 1) != 0 && knob(al, K_NO_TINY_POLL, 0) == 0 && al->mb_failures < 3;
+      if (try_mb) ba.lds_words = ((1000 + 15) >> 4) + 5;
       ba.h16 = 1;
       ba.slim = knob(al, K_BAND_SLIM, 1);   // (wf-adaptive or no heuristic: wfa_slim_kernel — a third of the instructions per score step)
       ba.ef = (al->dcfg.endsfree && (al->dcfg.pbf | al->dcfg.pef | al->dcfg.tbf | al->dcfg.tef)) ? 1 : 0;
       ba.pbf = al->dcfg.pbf; ba.pef = al->dcfg.pef; ba.tbf = al->dcfg.tbf; ba.tef = al->dcfg.tef;
       if (full) {
         const int rec = ((al->ncomp != 5) ? 2 : 4) * 64 * nch;
-        const long long records = std::max<long long>(256, (long long)(max_len * 0.9 * penalty_scale(al->dcfg)) / ba.g + 64);
+        const long long records = std::max<long long>(256, (long long)((try_mb ? 1000 : max_len) * 0.9 * penalty_scale(al->dcfg)) / ba.g + 64);
         ba.hist_stride = ((int64_t)records * rec + 63) & ~63ll;
         // (one history slice per pair — 256 KB for 150 bp gap-affine — stays allocated for the aligner's lifetime: calls
         // whose slices exceed 256 MB or the free memory take the batch path, and so does a call whose workspace cannot be had)
@@ -3063,8 +3210,17 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
         memcpy(one + 8, bw, (size_t)(w + 4) * 4);
         ba.one = one;
       }
+      bool seen = false;
+      if (try_mb && ba.one) {
+        // (a batch run still in flight may be using the workspace this pair's history goes to)
+        if (full && al->ws_event_recorded) HIP_TRY(al, hipEventSynchronize(al->ws_event));
+        wfa::BandArgs mba = ba;
+        mba.done = nullptr;
+        seen = mailbox_call(al, mba, full, al->dcfg.heuristic != WFA_HEUR_NONE, one, (size_t)8 + w + 4) == 1;
+        if (seen) std::atomic_thread_fence(std::memory_order_acquire);
+      }
       const unsigned rtc_failures = wfa::rtc_failure_count();
-      if (wfa::launch_band(ba, nch, full, al->dcfg.heuristic != WFA_HEUR_NONE, true, (long long)n, stream) != 0) {
+      if (!seen && wfa::launch_band(ba, nch, full, al->dcfg.heuristic != WFA_HEUR_NONE, true, (long long)n, stream) != 0) {
         if (al->dcfg.rtc && wfa::rtc_failure_count() != rtc_failures) {
           // a run-time shape that cannot be built: this aligner goes on without them (the batch path and the general kernel take the call)
           (void)hipGetLastError();
@@ -3076,8 +3232,8 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
       }
       // (no event for the workspace: the call returns only after every pair's flag — stored behind its walk, the history's last
       // reader — or after the stream has drained)
-      bool seen = false;
-      if (poll) {
+      const bool served = seen;
+      if (poll && !served) {
         const double t_poll = now_ms();
         for (;;) {
           int64_t got = 0;

@@ -734,8 +734,7 @@ wfa_slim_kernel_2p(const BandArgs a) {   // gap-affine-2p: 25 ring registers per
 
 // One pair per call (wfa_hip_align_pair): everything the wave reads from the host — lengths, op-region offsets, the packed words —
 // rides in the kernel arguments, so the kernel starts without a load from the pinned block (two dependent PCIe round trips less).
-#define WFA_SLIM_ONE_WORDS 136   // 2 x (1000 bases + the look-ahead words)
-struct SlimOne { uint32_t w[8 + WFA_SLIM_ONE_WORDS]; };   // [0,4) WfaPairMeta, [4,8) cigar_off[0..1], [8,..) words
+// (SlimOne, the block of one pair: wfa_band.hpp)
 template <int NCH, int HIST, int X, int OE, int E, int OE2, int E2>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WFA_SLIM_WAVES, WFA_SLIM_WAVES)))
 wfa_slim_kernel_one(const BandArgs a, const SlimOne q) {
@@ -745,7 +744,61 @@ wfa_slim_kernel_one(const BandArgs a, const SlimOne q) {
   wfa_slim_body<NCH, HIST, X, OE, E, OE2, E2>(a, inl);
 }
 
+// The same, resident (round 6): pywfa's own usage is one wavefront_align(text) per call, 1-2 us on a host core; a
+// kernel launch per call costs ~13 us launch-to-flag on this platform.  A one-wave instance of this kernel stays on the device between
+// calls and takes its pairs from a MAILBOX in pinned host memory: the host writes the pair (the block wfa_slim_kernel_one gets as kernel
+// arguments) and then the request number; the wave polls the number at system scope (s_sleep between reads), aligns, writes results and
+// op bytes into the pinned block as the one-pair kernel does, and publishes the request number as done.  It leaves by itself after
+// `idle_ticks` of the 100 MHz clock without a request (or when told to quit): nothing of it outlives an idle aligner or a process that
+// forgets to close one, and the host starts a new instance with the next call.
+// (SlimMailbox: wfa_band.hpp)
+template <int NCH, int HIST, int X, int OE, int E, int OE2, int E2>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WFA_SLIM_WAVES, WFA_SLIM_WAVES)))
+wfa_slim_kernel_mailbox(const BandArgs a, SlimMailbox* const mb) {
+  const int lane = threadIdx.x;
+  uint32_t last = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&mb->done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+  const uint64_t idle = mb->idle_ticks;
+  uint32_t served = 0;
+  for (;;) {
+    const uint64_t t0 = wall_clock64();
+    uint32_t seq;
+    uint64_t polls = 0;   // (a bound of its own on the wait, should the clock not be what it is taken for: a poll is a PCIe round trip, > 0.25 us)
+    for (;;) {
+      seq = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&mb->req_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
+      if (seq != last) break;
+      const uint32_t q = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&mb->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+      if (q != 0 || wall_clock64() - t0 > idle || ++polls > idle / 16 + 4096) {
+        // (a request posted after the read above is not lost: the host sees alive == 0 with its request not done and starts an instance)
+        if (lane == 0) __hip_atomic_store(&mb->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    wfa_slim_body<NCH, HIST, X, OE, E, OE2, E2>(a, mb->req.w);
+    __threadfence_system();   // results and op bytes of every lane before the number below
+    ++served;
+    if (lane == 0) {
+      mb->served = served;
+      __hip_atomic_store(&mb->done_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    last = seq;
+  }
+}
+
 #ifndef __HIPCC_RTC__
+// starts an instance of the resident kernel (gap-affine shapes of the library, 128 diagonals; score-only or the explicit history walked
+// in-kernel); -1: this launch has no such form (the caller takes the launch-per-call path)
+template <int X, int OE, int E, int OE2, int E2>
+static int launch_slim_mailbox_shape(const BandArgs& a, bool full, hipStream_t stream, SlimMailbox* mb) {
+  if constexpr (OE2 > 0) { return -1; }
+  else {
+    const size_t smem = (size_t)a.lds_words * 2 * sizeof(uint32_t);
+    if (full) hipLaunchKernelGGL((wfa_slim_kernel_mailbox<2, 2, X, OE, E, 0, 0>), dim3(1), dim3(64), smem, stream, a, mb);
+    else hipLaunchKernelGGL((wfa_slim_kernel_mailbox<2, 0, X, OE, E, 0, 0>), dim3(1), dim3(64), smem, stream, a, mb);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
+}
+
 template <int X, int OE, int E, int OE2, int E2>
 static int launch_slim_shape(const BandArgs& a, int nch, bool full, long long grid, hipStream_t stream) {
   constexpr int NCH1 = (OE2 > 0) ? 3 : 2;   // the first window: 128 diagonals, gap-affine-2p 192
