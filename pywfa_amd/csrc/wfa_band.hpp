@@ -87,17 +87,21 @@ struct BandArgs {
 // One pair per call (wfa_slim.hpp: wfa_slim_kernel_one / wfa_slim_kernel_mailbox): everything the wave reads from the host about the pair
 #define WFA_SLIM_ONE_WORDS 136   // 2 x (1000 bases + the look-ahead words)
 struct SlimOne { uint32_t w[8 + WFA_SLIM_ONE_WORDS]; };   // [0,4) WfaPairMeta, [4,8) cigar_off[0..1], [8,..) words
-// The mailbox of the resident one-pair kernel (pinned host memory; host and device sides on lines of their own)
+// The mailbox of the resident one-pair kernel (pinned host memory; host and device sides on lines of their own).  The request travels
+// as WFA_MB_LINES lines of 64 B: 15 words of the SlimOne block + the request number, so that the line is its own "ready" flag
+#define WFA_MB_LINES 10   // 150 >= 8 + WFA_SLIM_ONE_WORDS words
 struct SlimMailbox {
-  uint32_t req_seq;      // host -> device: number of the request that `req` holds
+  uint32_t req[WFA_MB_LINES][16];   // host -> device
   uint32_t quit;         // host -> device: leave now
   uint32_t idle_ticks;   // leave after this many ticks of the 100 MHz clock without a request
-  uint32_t pad0[29];
-  uint32_t done_seq;     // device -> host: the last request whose results are in the pinned block
+  uint32_t pad0[14];
+  unsigned long long done;   // device -> host, ONE 8-byte store: bits 0-23 the last request served, 24-31 its status code (0 done, 2 step limit,
+                             // 255 handed on), 32-63 its score
+  uint32_t served;       // requests served by this instance (diagnostics)
+  uint32_t ticks;        // 10 ns ticks the last request took on the device, arrival to answer (diagnostics)
+  uint32_t pad1[12];
   uint32_t alive;        // 1 from the host's launch of an instance until the instance leaves (the instance's last store)
-  uint32_t served;       // requests this instance has served (diagnostics)
-  uint32_t pad1[29];
-  SlimOne req;           // the request
+  uint32_t pad2[15];
 };
 
 

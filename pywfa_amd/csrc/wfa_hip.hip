@@ -3028,6 +3028,8 @@ static inline int32_t tiny_score(const WfaDevConfig& d, int32_t raw, int32_t sta
 // tell the running instance, if any, to leave, and wait until it has (its last store is alive = 0)
 static void mailbox_quit(wfa_hip_aligner* al) {
   if (!al->mb_h) return;
+  if (getenv("WFA_HIP_MAILBOX_DEBUG")) fprintf(stderr, "[wfa_hip] mailbox: instance served %u requests, the last one in %.2f us on the device (request %u)\n",
+                                               al->mb_h->served, al->mb_h->ticks * 0.01, al->mb_seq);
   if (__atomic_load_n(&al->mb_h->alive, __ATOMIC_ACQUIRE) != 0) {
     __atomic_store_n(&al->mb_h->quit, 1u, __ATOMIC_RELEASE);
     const double t0 = now_ms();
@@ -3039,8 +3041,10 @@ static void mailbox_quit(wfa_hip_aligner* al) {
   al->mb_args_valid = false;
 }
 
-// one pair through the mailbox: 1 = served (results in the pinned block), 0 = not this way (the caller launches a kernel as before)
-static int mailbox_call(wfa_hip_aligner* al, const wfa::BandArgs& ba, bool full, bool adapt, const uint32_t* one, size_t one_words) {
+// one pair through the mailbox: 1 = served (score and raw status in *score_raw / *status_raw, op bytes in the pinned block), 0 = not this
+// way (the caller launches a kernel as before)
+static int mailbox_call(wfa_hip_aligner* al, const wfa::BandArgs& ba, bool full, bool adapt, const uint32_t* one, size_t one_words,
+                        int32_t* score_raw, int32_t* status_raw) {
   if (knob(al, K_MAILBOX, 1) == 0 || al->mb_failures >= 3) return 0;
   if (!al->mb_h) {
     if (hipHostMalloc((void**)&al->mb_h, sizeof(wfa::SlimMailbox), hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); al->mb_h = nullptr; al->mb_failures = 3; return 0; }
@@ -3053,9 +3057,25 @@ static int mailbox_call(wfa_hip_aligner* al, const wfa::BandArgs& ba, bool full,
   want.one = nullptr; want.done = nullptr;
   // an instance started for another configuration / workspace leaves first
   if (__atomic_load_n(&mb->alive, __ATOMIC_ACQUIRE) != 0 && (!al->mb_args_valid || memcmp(&want, &al->mb_args, sizeof(want)) != 0)) mailbox_quit(al);
-  memcpy(mb->req.w, one, one_words * sizeof(uint32_t));
-  const uint32_t k = ++al->mb_seq;
-  __atomic_store_n(&mb->req_seq, k, __ATOMIC_RELEASE);
+  // the request: 15 words of the block + the request number per 64-byte line (the number is the line's own "ready" flag; lines the block
+  // does not reach carry the number alone)
+  al->mb_seq = (al->mb_seq + 1u) & 0xFFFFFFu;
+  const uint32_t k = al->mb_seq;
+  for (int ln = 0; ln < WFA_MB_LINES; ++ln) {
+    uint32_t line[16];
+    for (int j = 0; j < 15; ++j) { const size_t src = (size_t)ln * 15 + j; line[j] = src < one_words ? one[src] : 0u; }
+    line[15] = k;
+    memcpy(mb->req[ln], line, sizeof(line));
+  }
+  std::atomic_thread_fence(std::memory_order_release);
+  auto answered = [&]() -> bool {
+    const unsigned long long d = __atomic_load_n(&mb->done, __ATOMIC_ACQUIRE);
+    if ((uint32_t)(d & 0xFFFFFFull) != k) return false;
+    const uint32_t code = (uint32_t)(d >> 24) & 0xFFu;
+    *score_raw = (int32_t)(uint32_t)(d >> 32);
+    *status_raw = code == 0 ? 0 : code == 255u ? WFA_INTERNAL_FALLBACK : WFA_STATUS_MAX_STEPS_REACHED;
+    return true;
+  };
   auto start = [&]() -> bool {
     // (idle time of an instance: long enough for the next call of a loop of single alignments, short enough that nothing lingers)
     mb->idle_ticks = (uint32_t)std::max(1, knob(al, K_MAILBOX_IDLE_US, 2000)) * 100u;
@@ -3071,18 +3091,18 @@ static int mailbox_call(wfa_hip_aligner* al, const wfa::BandArgs& ba, bool full,
   };
   auto give_up = [&]() {
     mailbox_quit(al);
-    __atomic_store_n(&mb->done_seq, k, __ATOMIC_RELEASE);   // (no instance is running: the request counts as consumed)
+    __atomic_store_n(&mb->done, (unsigned long long)k | (255ull << 24), __ATOMIC_RELEASE);   // (no instance is running: the request counts as consumed)
     ++al->mb_failures;
     return 0;
   };
   if (__atomic_load_n(&mb->alive, __ATOMIC_ACQUIRE) == 0 && !start()) return give_up();
   const double t0 = now_ms();
   for (uint32_t spins = 1;; ++spins) {
-    if (__atomic_load_n(&mb->done_seq, __ATOMIC_ACQUIRE) == k) return 1;
+    if (answered()) return 1;
     if ((spins & 255u) == 0) {
       if (__atomic_load_n(&mb->alive, __ATOMIC_ACQUIRE) == 0) {
         // the instance left (idle time over) as the request arrived: its results, if any, were stored before alive = 0
-        if (__atomic_load_n(&mb->done_seq, __ATOMIC_ACQUIRE) == k) return 1;
+        if (answered()) return 1;
         if (!start()) return give_up();
       }
       if (now_ms() - t0 > 100.0) return give_up();   // (something is wrong: the launch-per-call path takes the pair)
@@ -3216,8 +3236,12 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
         if (full && al->ws_event_recorded) HIP_TRY(al, hipEventSynchronize(al->ws_event));
         wfa::BandArgs mba = ba;
         mba.done = nullptr;
-        seen = mailbox_call(al, mba, full, al->dcfg.heuristic != WFA_HEUR_NONE, one, (size_t)8 + w + 4) == 1;
-        if (seen) std::atomic_thread_fence(std::memory_order_acquire);
+        int32_t sr = 0, st = WFA_INTERNAL_FALLBACK;
+        seen = mailbox_call(al, mba, full, al->dcfg.heuristic != WFA_HEUR_NONE, one, (size_t)8 + w + 4, &sr, &st) == 1;
+        if (seen) {   // (the answer came in the mailbox's own word: the pinned block's score / status are what the launch path reads)
+          std::atomic_thread_fence(std::memory_order_acquire);
+          reinterpret_cast<int32_t*>(h + o_score)[0] = sr; hst0[0] = st;
+        }
       }
       const unsigned rtc_failures = wfa::rtc_failure_count();
       if (!seen && wfa::launch_band(ba, nch, full, al->dcfg.heuristic != WFA_HEUR_NONE, true, (long long)n, stream) != 0) {

@@ -91,7 +91,8 @@ __device__ __forceinline__ unsigned long long slim_range_mask(int c, int lo, int
 // round of probes whether a live diagonal is about to read past the window's end and then re-stages both windows from the smallest
 // live positions (a pair whose live diagonals span more than a window is handed on).
 template <int NCH, int HIST, int X, int OE, int E, int OE2, int E2, bool WIN = false>
-__device__ __forceinline__ void wfa_slim_body(const BandArgs& a, const uint32_t* __restrict__ inl = nullptr) {
+__device__ __forceinline__ void wfa_slim_body(const BandArgs& a, const uint32_t* __restrict__ inl = nullptr, int* __restrict__ res2 = nullptr) {
+  // (res2: the resident one-pair kernel takes the pair's {score, status} in registers as well: its score-only answer is one store)
   constexpr bool FULL = HIST != 0, PBH = HIST == 1, XH = HIST == 2;
   static_assert(!WIN || OE2 == 0, "the windowed form: gap-affine");
   constexpr bool TWO = OE2 > 0;  // gap-affine-2p: second pair of gap components (R/wavefront_compute_affine2p.c:45-106)
@@ -694,6 +695,7 @@ __device__ __forceinline__ void wfa_slim_body(const BandArgs& a, const uint32_t*
     }
     if (a.done) __threadfence_system();   // the single-call path: the op bytes of every lane before the flag below
     if (lane == 0) {
+      if (res2) { res2[0] = fallback ? 0 : (stop_status != 0 ? stop_score : result); res2[1] = fallback ? WFA_INTERNAL_FALLBACK : stop_status; }
       if (fallback) {
         a.status[pair] = WFA_INTERNAL_FALLBACK;
         if (a.fb_list) a.fb_list[atomicAdd(a.fb_count, 1u)] = pair;   // (no list: the single-call path reads the status)
@@ -755,33 +757,54 @@ wfa_slim_kernel_one(const BandArgs a, const SlimOne q) {
 template <int NCH, int HIST, int X, int OE, int E, int OE2, int E2>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WFA_SLIM_WAVES, WFA_SLIM_WAVES)))
 wfa_slim_kernel_mailbox(const BandArgs a, SlimMailbox* const mb) {
+  extern __shared__ uint32_t slds[];
+  uint32_t* const rq = slds + 2 * a.lds_words;   // the request, de-tagged: the block wfa_slim_body takes (launch_slim_mailbox_shape sizes the LDS for it)
   const int lane = threadIdx.x;
-  uint32_t last = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&mb->done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+  uint32_t last = __builtin_amdgcn_readfirstlane((uint32_t)__hip_atomic_load(&mb->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) & 0xFFFFFFu;
   const uint64_t idle = mb->idle_ticks;
   uint32_t served = 0;
+  // the request: WFA_MB_LINES lines of 15 data words + the request number in the 16th.  A line is read (and written) as a whole, so a
+  // line that carries the awaited number carries that request's words: ONE round trip over PCIe both finds the request and fetches it
+  const uint32_t* const rl = &mb->req[0][0];
+  const bool t0 = (lane & 15) == 15;   // this lane's word of a 64-word slice is a line's number
   for (;;) {
-    const uint64_t t0 = wall_clock64();
-    uint32_t seq;
+    const uint64_t tbeg = wall_clock64();
+    const uint32_t want = (last + 1u) & 0xFFFFFFu;
     uint64_t polls = 0;   // (a bound of its own on the wait, should the clock not be what it is taken for: a poll is a PCIe round trip, > 0.25 us)
+    uint32_t v0, v1, v2;
     for (;;) {
-      seq = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&mb->req_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
-      if (seq != last) break;
+      v0 = __hip_atomic_load(rl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      v1 = __hip_atomic_load(rl + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      v2 = (lane < 16 * WFA_MB_LINES - 128) ? __hip_atomic_load(rl + 128 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : want;
+      const bool stale = t0 && (v0 != want || v1 != want || v2 != want);
+      if (__builtin_amdgcn_ballot_w64(stale) == 0ull) break;
       const uint32_t q = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&mb->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-      if (q != 0 || wall_clock64() - t0 > idle || ++polls > idle / 16 + 4096) {
-        // (a request posted after the read above is not lost: the host sees alive == 0 with its request not done and starts an instance)
+      if (q != 0 || wall_clock64() - tbeg > idle || ++polls > idle / 16 + 4096) {
+        // (a request posted after the reads above is not lost: the host sees alive == 0 with its request not done and starts an instance)
         if (lane == 0) __hip_atomic_store(&mb->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
       }
-      __builtin_amdgcn_s_sleep(4);
+      __builtin_amdgcn_s_sleep(2);
     }
-    wfa_slim_body<NCH, HIST, X, OE, E, OE2, E2>(a, mb->req.w);
-    __threadfence_system();   // results and op bytes of every lane before the number below
+    const uint64_t t_req = wall_clock64();
+    __syncthreads();   // (the previous request's readers of rq are done)
+    if (!t0) { rq[(lane >> 4) * 15 + (lane & 15)] = v0; rq[((64 + lane) >> 4) * 15 + (lane & 15)] = v1; }
+    if (!t0 && lane < 16 * WFA_MB_LINES - 128) rq[((128 + lane) >> 4) * 15 + (lane & 15)] = v2;
+    __syncthreads();
+    int res2[2] = {0, 0};
+    wfa_slim_body<NCH, HIST, X, OE, E, OE2, E2>(a, rq, res2);
+    if (HIST != 0) __threadfence_system();   // op bytes, their begin and length, of every lane before the answer below
     ++served;
     if (lane == 0) {
+      // the answer — request number, status code, score — is ONE 8-byte store: score-only needs nothing else, and no fence before it
+      const uint32_t code = (res2[1] == 0) ? 0u : (res2[1] == WFA_INTERNAL_FALLBACK) ? 255u : 2u;   // (the kernel's statuses: done, handed on, step limit)
+      const unsigned long long ans = ((unsigned long long)(uint32_t)res2[0] << 32) | (code << 24) | want;
       mb->served = served;
-      __hip_atomic_store(&mb->done_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      mb->ticks = (uint32_t)(wall_clock64() - t_req);   // (diagnostics: 10 ns ticks from the request's arrival to its answer)
+      if (HIST != 0) __hip_atomic_store(&mb->done, ans, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      else __hip_atomic_store(&mb->done, ans, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    last = seq;
+    last = want;
   }
 }
 
@@ -792,7 +815,7 @@ template <int X, int OE, int E, int OE2, int E2>
 static int launch_slim_mailbox_shape(const BandArgs& a, bool full, hipStream_t stream, SlimMailbox* mb) {
   if constexpr (OE2 > 0) { return -1; }
   else {
-    const size_t smem = (size_t)a.lds_words * 2 * sizeof(uint32_t);
+    const size_t smem = (size_t)a.lds_words * 2 * sizeof(uint32_t) + (size_t)(15 * WFA_MB_LINES + 16) * sizeof(uint32_t);   // + the de-tagged request
     if (full) hipLaunchKernelGGL((wfa_slim_kernel_mailbox<2, 2, X, OE, E, 0, 0>), dim3(1), dim3(64), smem, stream, a, mb);
     else hipLaunchKernelGGL((wfa_slim_kernel_mailbox<2, 0, X, OE, E, 0, 0>), dim3(1), dim3(64), smem, stream, a, mb);
     return hipGetLastError() == hipSuccess ? 0 : -1;
