@@ -515,7 +515,10 @@ def multi_leg(pairs_per_device, length=100000, calls=2):
     for name, kw in (("xdrop", C5_XDROP_KW), ("adaptive", C5_ADAPT_KW)):
         ma = _native.MultiAligner(native_config(**kw), devices)
         best = None
+        score = status = cig = None
         for _ in range(calls):
+            # (the previous call's results go first: giving 1.6 GB of op bytes back to the system is ~50 ms that belongs to no call)
+            del score, status, cig
             t0 = time.perf_counter()
             score, status, cig = ma.align_batch(batch, True)
             dt = time.perf_counter() - t0
@@ -832,6 +835,9 @@ def main():
                      cfg_kw=dict(span="end-to-end", scope="score", match=-1), scheme="none", survey_bytes=84, cpu_pairs=200000, cpu_budget=2.0),
                 dict(name="150bp-levenshtein", n=2_000_000, length=150, error=0.02, seed=datagen.SEEDS["C2"],
                      cfg_kw=dict(distance="levenshtein", span="end-to-end", scope="score"), scheme="none", survey_bytes=84, cpu_pairs=200000, cpu_budget=2.0),
+                # (round 6: the one-component distances WITH CIGARs on the register kernels' LIN form; round 5: general kernel, 0.17 G aln/s)
+                dict(name="150bp-levenshtein-full", n=2_000_000, length=150, error=0.02, seed=datagen.SEEDS["C2"],
+                     cfg_kw=dict(distance="levenshtein", span="end-to-end", scope="full"), scheme="explicit", survey_bytes=236, cpu_pairs=100000, cpu_budget=2.0),
                 dict(name="150bp-linear", n=2_000_000, length=150, error=0.02, seed=datagen.SEEDS["C2"],
                      cfg_kw=dict(distance="linear", span="end-to-end", scope="score"), scheme="none", survey_bytes=84, cpu_pairs=200000, cpu_budget=2.0),
                 dict(name="C4-adaptive-mismatch5", n=20_000, length=10000, error=0.08, seed=datagen.SEEDS["C4"], cfg_kw=dict(C4, heuristic="adaptive", mismatch=5),

@@ -38,6 +38,8 @@ struct WfaDevConfig {
                                // 0 as it is; 1 (sw_match (plen + tlen) - s) / 2 (match < 0, R/wavefront_penalties.h:73); 2 +s (indel / edit)
   int32_t sw_match;            // -match of the original configuration (score_mode 1)
   int32_t rtc;                 // 1: penalty shapes without an instantiation are compiled at run time (csrc/wfa_rtc.cpp)
+  int32_t lin;                 // 1 (host side): a one-component distance with CIGARs mapped onto the gap-affine register kernels' LIN form
+                               // (wfa_lane.hpp); the general kernel keeps the original one-component configuration
   int32_t biwfa_top;           // 1: the general kernel stands in for the top-level base case of BiWFA (reads of <= 100 bases whose
                                // score outgrows the BiWFA kernel's base-case history): a completed pair keeps the unset score
                                // (SURVEY Q6), every other ending is "unattainable" (R/wavefront_bialign.c:182-187,725-729)
@@ -116,6 +118,7 @@ struct FastArgs {
   // wave drain (few busy lanes, full instruction cost) once per kernel, not once per slice
   uint32_t* dyn_next;
   uint32_t dyn_chunk;
+  int lin;                // 1: the one-component form of the FULL kernels (wfa_lane.hpp: LIN) — host side: selects the run-time instantiation
 };
 
 // neighbour diagonals inside a segment of W lanes (wfa_seg.hpp): lanes at a segment border receive NULL

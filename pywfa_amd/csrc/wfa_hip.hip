@@ -92,6 +92,8 @@ struct wfa_hip_aligner {
   wfa_hip_config_t cfg;
   WfaDevConfig dcfg;
   int ncomp = 3;
+  WfaDevConfig gcfg;      // what the general kernel runs (= dcfg unless dcfg.lin)
+  int gncomp = 3;
   WfaKnobs knobs;
   hipStream_t stream = nullptr;
   std::vector<uint8_t> pair_blob;   // wfa_hip_align_pair: the two sequences of the call, back to back
@@ -206,6 +208,8 @@ struct wfa_hip_batch {
   // free ends) follows it, so run / sync / results use this snapshot, never the aligner's current configuration
   wfa_hip_config_t cfg;
   WfaDevConfig dcfg;
+  WfaDevConfig gcfg;       // the general kernel's configuration (= dcfg unless dcfg.lin: the original one-component distance)
+  int gncomp = 3;
   int wild = -1;           // the wildcard letter of the 8-bit pairs when dcfg.wildcard was cleared for the 2-bit ones (round 5, below)
   int ncomp = 3;
   int64_t n = 0;
@@ -383,7 +387,14 @@ static void map_to_gap_affine(const wfa_hip_config_t& c, WfaDevConfig* d, int* n
   if (free_ends || c.max_steps > 0 || c.wildcard >= 0 || c.memory_mode == WFA_MEM_BIWFA) return;
   if (c.heuristic != WFA_HEUR_NONE && !(c.heuristic == WFA_HEUR_ADAPTIVE && *ncomp != 1)) return;
   if (*ncomp == 1) {
-    if (c.scope != WFA_SCOPE_SCORE) return;
+    // Round 6, with CIGARs: gap-linear and levenshtein (match = 0) take the register kernels' LIN form (wfa_lane.hpp: gap-affine with o = 0 and
+    // no extension candidates = the one-component recurrences and the linear backtrace's choices); what those stages hand on goes to the
+    // general kernel under the ORIGINAL configuration (derive_dev_config keeps it).  indel has no mismatch candidate: general kernel.
+    if (c.scope != WFA_SCOPE_SCORE) {
+      static const bool lin_off = getenv("WFA_HIP_NO_LIN") && *getenv("WFA_HIP_NO_LIN") == '1';
+      if (lin_off || c.distance == WFA_DIST_INDEL || d->match != 0 || !d->rtc) return;
+      d->lin = 1;
+    }
     const int indel = d->o1;   // (derive_dev_config keeps the indel penalty there)
     if (c.distance == WFA_DIST_INDEL) d->x = 2;
     d->o1 = 0; d->e1 = indel; d->o2 = 0; d->e2 = indel;
@@ -398,8 +409,10 @@ static void map_to_gap_affine(const wfa_hip_config_t& c, WfaDevConfig* d, int* n
   if (d->match < 0) { d->sw_match = -d->match; d->match = 0; }
 }
 
-static void derive_dev_config(const wfa_hip_config_t& c, WfaDevConfig* d, int* ncomp) {
+// gd / gncomp: the configuration the GENERAL kernel runs — the same, unless a one-component distance with CIGARs was mapped (d->lin)
+static void derive_dev_config(const wfa_hip_config_t& c, WfaDevConfig* d, int* ncomp, WfaDevConfig* gd = nullptr, int* gncomp = nullptr) {
   const bool two = (c.distance == WFA_DIST_AFFINE2P);
+  d->lin = 0;
   d->metric = c.distance;
   if (c.distance <= WFA_DIST_LINEAR) {
     // single-component metrics: wavefront_penalties.c:39-94, wavefront_components.c:43-74
@@ -420,7 +433,9 @@ static void derive_dev_config(const wfa_hip_config_t& c, WfaDevConfig* d, int* n
     d->wildcard = c.wildcard;
     d->biwfa_top = 0;
     d->rtc = wfa::rtc_enabled() ? 1 : 0;
+    const WfaDevConfig orig1 = *d;
     map_to_gap_affine(c, d, ncomp);
+    if (gd) { *gd = d->lin ? orig1 : *d; *gncomp = d->lin ? 1 : *ncomp; }
     return;
   }
   *ncomp = two ? 5 : 3;
@@ -452,7 +467,10 @@ static void derive_dev_config(const wfa_hip_config_t& c, WfaDevConfig* d, int* n
   // penalty shapes without an instantiation: the register kernels are compiled for them at run time where hipRTC works (probed
   // when such a shape first asks: seg_shape / band_supported)
   d->rtc = wfa::rtc_enabled() ? 1 : 0;
+  const WfaDevConfig orig = *d;
+  const int orig_ncomp = *ncomp;
   map_to_gap_affine(c, d, ncomp);
+  if (gd) { *gd = d->lin ? orig : *d; *gncomp = d->lin ? orig_ncomp : *ncomp; }
 }
 
 extern "C" wfa_hip_aligner_t* wfa_hip_create(const wfa_hip_config_t* cfg, int device) {
@@ -469,7 +487,7 @@ extern "C" wfa_hip_aligner_t* wfa_hip_create(const wfa_hip_config_t* cfg, int de
   wfa_hip_aligner* al = new wfa_hip_aligner();
   al->device = device;
   al->cfg = *cfg;
-  derive_dev_config(al->cfg, &al->dcfg, &al->ncomp);
+  derive_dev_config(al->cfg, &al->dcfg, &al->ncomp, &al->gcfg, &al->gncomp);
   hipDeviceProp_t prop;
   if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { g_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e); delete al; return nullptr; }
   al->cu_count = prop.multiProcessorCount;
@@ -549,7 +567,7 @@ extern "C" int wfa_hip_set_config(wfa_hip_aligner_t* al, const wfa_hip_config_t*
   const int rc = wfa_hip_config_validate(cfg, msg, sizeof(msg));
   if (rc != WFA_HIP_OK) { al->err = msg; return rc; }
   al->cfg = *cfg;
-  derive_dev_config(al->cfg, &al->dcfg, &al->ncomp);
+  derive_dev_config(al->cfg, &al->dcfg, &al->ncomp, &al->gcfg, &al->gncomp);
   return WFA_HIP_OK;
 }
 
@@ -935,13 +953,13 @@ static int pilot_band(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t stream)
 static int batch_build(wfa_hip_aligner* al, wfa_hip_batch* b, int64_t n, const uint8_t* seqs,
                        const int64_t* p_off, const int32_t* p_len, const int64_t* t_off, const int32_t* t_len, bool in2bit = false) {
   if (al->mb_h && __atomic_load_n(&al->mb_h->alive, __ATOMIC_ACQUIRE) != 0) mailbox_quit(al);   // (the resident one-pair kernel: batches take the device)
-  b->cfg = al->cfg; b->dcfg = al->dcfg; b->ncomp = al->ncomp;
+  b->cfg = al->cfg; b->dcfg = al->dcfg; b->ncomp = al->ncomp; b->gcfg = al->gcfg; b->gncomp = al->gncomp;
   // Round 5: a wildcard letter outside ACGT cannot occur in a pair whose letters are all ACGT — such pairs take the 2-bit kernels as if
   // no wildcard were set (same result: nothing in them matches by wildcard), only the pairs holding other letters are aligned on their
   // bytes with the wildcard rule (150 bp, clean reads: 44 M -> the 2-bit rates).  A wildcard that IS one of ACGT keeps every pair on bytes.
   {
     const int wc = b->cfg.wildcard;
-    if (wc >= 0 && !(wc == 'A' || wc == 'C' || wc == 'G' || wc == 'T' || wc == 'a' || wc == 'c' || wc == 'g' || wc == 't')) { b->wild = wc; b->dcfg.wildcard = -1; }
+    if (wc >= 0 && !(wc == 'A' || wc == 'C' || wc == 'G' || wc == 'T' || wc == 'a' || wc == 'c' || wc == 'g' || wc == 't')) { b->wild = wc; b->dcfg.wildcard = -1; b->gcfg.wildcard = -1; }
   }
   const wfa_hip_config_t& c = b->cfg;
   const bool timing = al->knobs.set[K_TIMING];
@@ -1630,10 +1648,10 @@ static int launch_general_dyn(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t
   a.ws = ws_base ? ws_base : al->ws; a.ws_stride = ws_stride;
   a.wbeg_dev = wbeg_dev;
   a.fb_list = ovf_list; a.fb_count = ovf_count;
-  a.cfg = b->dcfg;
+  a.cfg = b->gcfg;
   if (!packed && b->wild >= 0) a.cfg.wildcard = b->wild;   // (the 8-bit pairs of a batch whose 2-bit pairs run without the wildcard rule)
   if (a.cfg.biwfa_top) a.cfg.heuristic = WFA_HEUR_NONE;   // (standing in for a BiWFA base case: the base aligner has no heuristic, R/wavefront_bialigner.c:66-68)
-  if (wfa::launch_general_any(b->ncomp, packed, b->cfg.scope == WFA_SCOPE_FULL, general_pb(al, b->cfg, b->ncomp, b->max_len), a, grid, threads, stream) != 0) {
+  if (wfa::launch_general_any(b->gncomp, packed, b->cfg.scope == WFA_SCOPE_FULL, general_pb(al, b->cfg, b->gncomp, b->max_len), a, grid, threads, stream) != 0) {
     al->err = std::string("general kernel launch failed: ") + hipGetErrorString(hipGetLastError());
     return WFA_HIP_EDEVICE;
   }
@@ -1684,7 +1702,7 @@ static int64_t initial_arena_ints(const wfa_hip_aligner* al, const wfa_hip_batch
   // less than what wavefront 0 and a few hundred scores need; overflowing pairs are re-run larger
   ll ints = (ll)b->max_len * (b->ncomp * 64 + mi) / 4 + (ll)b->max_width * b->ncomp * 4 + 4096 * mi;
   // piggy-back history: one byte per cell + 12 bytes per score (the ring of offsets is b->arena_fixed)
-  if (general_pb(al, b->cfg, b->ncomp, b->max_len)) ints = (ll)b->max_len * (64 + 12) / 4 + 4096;
+  if (general_pb(al, b->cfg, b->gncomp, b->max_len)) ints = (ll)b->max_len * (64 + 12) / 4 + 4096;
   ints = std::max<ll>(ints, 1 << 14);
   const int e = knob(al, K_ARENA_KB, 0);
   if (e > 0) ints = (ll)e * 256;
@@ -1745,7 +1763,7 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
   const bool full = (b->cfg.scope == WFA_SCOPE_FULL);
   HIP_TRY(al, hipMemsetAsync(b->d_counters, 0, WFA_COUNTER_WORDS * sizeof(uint32_t), stream));   // (every stage's hand-over count too: one fill per run, not one per stage)
   b->arena_ints = full ? initial_arena_ints(al, b) : 0;
-  b->arena_fixed = general_pb(al, b->cfg, b->ncomp, b->max_len) ? (((int64_t)b->dcfg.scope * b->ncomp * b->max_width + 64 + 63) & ~63ll) : 0;
+  b->arena_fixed = general_pb(al, b->cfg, b->gncomp, b->max_len) ? (((int64_t)b->dcfg.scope * b->ncomp * b->max_width + 64 + 63) & ~63ll) : 0;
 
   // A cascade of kernels over the 2-bit pairs: each stage aligns what fits it and appends the rest to
   // a leftover list (pair ids + a device-side count) that the next stage consumes on the same stream;
@@ -1964,7 +1982,11 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
     const bool use_fast = !tiny && !full && wfa::seg_supported(b->dcfg, b->ncomp, full) && b->max_len <= WFA_FAST_MAX_LEN &&
                           knob(al, K_NO_FAST, 0) == 0;
     // full CIGARs of short reads: the segmented kernel with a history slot per pair, then the thread-per-alignment walk
-    const bool use_segfull = !tiny && full && wfa::seg_supported(b->dcfg, b->ncomp, false) && b->max_len <= WFA_FAST_MAX_LEN &&
+    // (round 6: a one-component distance with CIGARs, mapped — b->dcfg.lin: the register stages' LIN form exists as a run-time instantiation
+    // only; without hipRTC, and for what those stages hand on, the general kernel under the original configuration)
+    const bool lin = b->dcfg.lin != 0;
+    const bool lin_regs = lin && b->dcfg.rtc != 0 && wfa::rtc_available();
+    const bool use_segfull = (!lin || lin_regs) && !tiny && full && wfa::seg_supported(b->dcfg, b->ncomp, false) && b->max_len <= WFA_FAST_MAX_LEN &&
                              knob(al, K_NO_FAST, 0) == 0 && knob(al, K_NO_SEGFULL, 0) == 0;
     // Round 3: score-only short reads with wf-adaptive, free ends or a step limit — what the bound of the register kernels cannot
     // prove — start in the general form of the lane kernel (wfa_lane_kernel<.., HEUR>: the pair is handed on the moment its
@@ -1979,7 +2001,7 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
     const bool use_segh = !tiny && !full && !use_fast && wfa::seg_heur_config(b->dcfg, b->ncomp) && b->max_len <= WFA_FAST_MAX_LEN &&
                           knob(al, K_NO_FAST, 0) == 0 && !wfa::seg_supported(b->dcfg, b->ncomp, false) &&
                           (b->segh_pick == 1 || (b->segh_pick == 0 && knob(al, K_SEG_HEUR, 0) != 0));   // (the pilot of batch_build, or WFA_HIP_SEG_HEUR=1)
-    if (!tiny && wfa::band_supported(b->dcfg, b->ncomp) && (b->ncomp != 5 || b->max_len < 32000) && knob(al, K_NO_BAND, 0) == 0) {
+    if (!lin && !tiny && wfa::band_supported(b->dcfg, b->ncomp) && (b->ncomp != 5 || b->max_len < 32000) && knob(al, K_NO_BAND, 0) == 0) {
       if (b->ncomp == 5) {
         // gap-affine-2p wavefronts are wide (C4: 99 % need more than 108 diagonals, 2.6 % more than 172)
         if (b->band_pick != 2) { band_nch[n_stages++] = 3; band_nch[n_stages++] = 4; }   // (2: the pilot of batch_build saw most pairs outgrow 256 diagonals)
@@ -2005,7 +2027,7 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
     const int wide_adapt_knob = knob(al, K_WIDE_ADAPT, 1);
     const bool wide_adapt = b->dcfg.heuristic == WFA_HEUR_ADAPTIVE && b->max_len > 1000 &&
                             (wide_adapt_knob == 2 || (n_stages > 0 && wide_adapt_knob != 0 && b->max_len > 20000));   // (2: any length, also without banded stages in front: tests)
-    const bool wide_ok = !tiny && ((b->ncomp == 3 && b->dcfg.metric == 3) || (b->ncomp == 5 && b->dcfg.metric == 4 && b->dcfg.e2 >= 1)) &&
+    const bool wide_ok = !lin && !tiny && ((b->ncomp == 3 && b->dcfg.metric == 3) || (b->ncomp == 5 && b->dcfg.metric == 4 && b->dcfg.e2 >= 1)) &&
                          (b->dcfg.heuristic == WFA_HEUR_NONE || wide_adapt) && b->dcfg.match == 0 &&
                          b->max_len > 64 && 2 * (int64_t)b->max_len <= 0x3fffff00ll && b->dcfg.e1 >= 1 && b->dcfg.x >= 1 && knob(al, K_NO_WIDE, 0) == 0;
     // reads beyond 16 kb (plen + tlen > 32 000 does not fit int16 offsets): the workspace-row form with int32 rows (round 3)
@@ -2335,6 +2357,7 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
       const int shape = wfa::seg_shape(b->dcfg, &X, &OE, &E);
       wfa::FastArgs fa;
       memset(&fa, 0, sizeof(fa));
+      fa.lin = b->dcfg.lin;
       fa.words = b->d_words; fa.meta = b->d_meta; fa.worklist = in_list; fa.nwork_dev = nullptr;
       fa.score = b->d_score; fa.status = b->d_status; fa.fb_list = out_list; fa.fb_count = out_count;
       fa.g = wfa::gcd_int(wfa::gcd_int(b->dcfg.x, b->dcfg.o1 + b->dcfg.e1), b->dcfg.e1);
@@ -2382,6 +2405,7 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
       uint32_t* out_count = next_count();
       wfa::FastArgs fa;
       memset(&fa, 0, sizeof(fa));
+      fa.lin = b->dcfg.lin;
       fa.words = b->d_words; fa.meta = b->d_meta; fa.worklist = in_list; fa.nwork_dev = in_count;
       fa.score = b->d_score; fa.status = b->d_status; fa.fb_list = out_list; fa.fb_count = out_count;
       fa.hist = al->ws; fa.hist_stride = segfull_slot_ints[sf];
@@ -2747,6 +2771,11 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
       in_list = out_list; in_count = out_count; out_sel ^= 1; first_stage = false;
     }
     b->leftover_count = in_count;
+    // (lin: what the register stages finished carries raw scores, what the general kernel finishes below — under the original
+    // configuration — final ones: the translation comes here, before it; a pair still to be aligned carries a non-zero status)
+    if (lin && b->dcfg.score_mode != 0)
+      hipLaunchKernelGGL(wfa_score_translate_kernel, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, stream, b->d_score, b->d_status, b->d_meta,
+                         (long long)b->n, b->dcfg.score_mode, b->dcfg.sw_match);
     if (!pipe_tail) {   // (the pipelined tail has run the general kernel on every launch's leftovers already)
       rc = launch_general_dyn(al, b, stream, true, in_list, in_count, in_n, g.ws_stride, g.grid, g.threads,
                               b->d_ovf_list[0], b->d_counters + 1);
@@ -2773,7 +2802,7 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
   // scores of a configuration that was mapped onto another (match < 0, the one-component distances): translated in-stream, in every
   // scope (round 6: full scope used to wait for wfa_hip_batch_sync — an extra launch and a second synchronisation; now only the pairs an
   // arena overflow re-runs are translated there: a pair that is still to be re-run carries a non-zero status and is skipped here)
-  if (b->dcfg.score_mode != 0)
+  if (b->dcfg.score_mode != 0 && !b->dcfg.lin)
     hipLaunchKernelGGL(wfa_score_translate_kernel, dim3((unsigned)((b->n + 255) / 256)), dim3(256), 0, stream, b->d_score, b->d_status, b->d_meta,
                        (long long)b->n, b->dcfg.score_mode, b->dcfg.sw_match);
   HIP_TRY(al, hipEventRecord(al->ws_event, stream));
@@ -2824,7 +2853,7 @@ static int retry_overflows(wfa_hip_batch* b) {
       rc = launch_general_dyn(al, b, stream, kind == 0, d_l, nullptr, (uint32_t)l.size(), g.ws_stride, g.grid, g.threads,
                               b->d_ovf_list[nxt], b->d_counters + 1 + nxt);
       if (rc != WFA_HIP_OK) return rc;
-      if (b->dcfg.score_mode != 0)   // (the stream's translation pass skipped these pairs: their status was not 0 then)
+      if (b->dcfg.score_mode != 0 && !b->dcfg.lin)   // (the stream's translation pass skipped these pairs: their status was not 0 then; lin: the general kernel's scores are final)
         hipLaunchKernelGGL(wfa_score_translate_list_kernel, dim3((unsigned)((l.size() + 255) / 256)), dim3(256), 0, stream, d_l, (uint32_t)l.size(),
                            b->d_score, b->d_status, b->d_meta, b->dcfg.score_mode, b->dcfg.sw_match);
       HIP_TRY(al, hipStreamSynchronize(stream));
@@ -3139,7 +3168,7 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
                o_ops = (o_cl + (size_t)n * 4 + 15) & ~(size_t)15;
   if (full && o_ops + (size_t)ops_total + 16 > TINY_BLOCK_BYTES) return 0;
   const bool general_fits = n <= TINY_MAX_PAIRS && in_bytes <= TINY_IN_BYTES;
-  const bool band_form = wfa::band_supported(al->dcfg, al->ncomp) && c.wildcard < 0 && knob(al, K_NO_TINY_BAND, 0) == 0 && knob(al, K_NO_BAND, 0) == 0;
+  const bool band_form = !al->dcfg.lin && wfa::band_supported(al->dcfg, al->ncomp) && c.wildcard < 0 && knob(al, K_NO_TINY_BAND, 0) == 0 && knob(al, K_NO_BAND, 0) == 0;   // (lin: the banded kernel has no one-component form)
   if (!general_fits && !band_form) return 0;
   HIP_TRY(al, hipSetDevice(al->device));
   if (!al->tiny_h) {
@@ -3326,11 +3355,11 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
   a.nwork = (uint32_t)n;
   a.score = reinterpret_cast<int32_t*>(hd + o_score); a.status = reinterpret_cast<int32_t*>(hd + o_status);
   a.cigar_begin = reinterpret_cast<int64_t*>(hd + o_cb); a.cigar_len = reinterpret_cast<int32_t*>(hd + o_cl); a.cigar_ops = hd + o_ops;
-  a.ws = al->ws; a.ws_stride = stride; a.cfg = al->dcfg;
+  a.ws = al->ws; a.ws_stride = stride; a.cfg = al->gcfg;
   // (no overflow list: an arena that is too small shows as status WFA_INTERNAL_OVERFLOW below and the call takes the batch path)
   static uint32_t* const no_list = nullptr;
   a.fb_list = no_list; a.fb_count = nullptr;
-  if (wfa::launch_general_any(al->ncomp, false, full, false, a, (int)n, threads, stream) != 0) { al->err = "general kernel launch failed"; return WFA_HIP_EDEVICE; }
+  if (wfa::launch_general_any(al->gncomp, false, full, false, a, (int)n, threads, stream) != 0) { al->err = "general kernel launch failed"; return WFA_HIP_EDEVICE; }
   HIP_TRY(al, hipEventRecord(al->ws_event, stream));
   al->ws_event_recorded = true; al->ws_last_stream = stream;
   HIP_TRY(al, hipStreamSynchronize(stream));
@@ -3338,7 +3367,7 @@ static int align_tiny(wfa_hip_aligner* al, int64_t n, const uint8_t* seqs, const
   for (int64_t i = 0; i < n; ++i) if (hst[i] == WFA_STATUS_OOM && full) return 0;   // arena too small for this pair: the batch path grows it
   const int64_t* hcb = reinterpret_cast<const int64_t*>(h + o_cb); const int32_t* hcl = reinterpret_cast<const int32_t*>(h + o_cl);
   for (int64_t i = 0; i < n; ++i) {
-    score[i] = tiny_score(al->dcfg, hs[i], hst[i], p_len[i], t_len[i]); status[i] = hst[i];
+    score[i] = tiny_score(al->gcfg, hs[i], hst[i], p_len[i], t_len[i]); status[i] = hst[i];
     if (cigar_len) cigar_len[i] = full ? hcl[i] : 0;
     if (cigar_begin) cigar_begin[i] = 0;
     if (full && cigar_ops) {

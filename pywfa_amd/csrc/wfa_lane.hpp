@@ -113,7 +113,13 @@ __device__ __forceinline__ uint32_t pk_clamp(uint32_t nm, uint32_t lim) {
 template <int OE, int E>
 struct LaneFull { static constexpr int NREC = 2 * (OE - E) + E * 17 + 1; };
 
-template <int X, int OE, int E, bool FULL, bool HEUR = false>
+// LIN (round 6): the one-component distances with CIGARs (gap-linear, levenshtein: R/wavefront_compute_linear.c:44-74, R/wavefront_compute_edit.c:
+// 44-100, R/wavefront_backtrace.c:223-319) as gap-affine with o = 0 WITHOUT the extension candidates: I(k) = M_e(k - 1) + 1, D(k) = M_e(k + 1)
+// are then exactly the one-component recurrences, and the origin codes say "opened" for every gap — the walk never enters a gap component,
+// which is the linear backtrace (the same priority: mismatch > deletion > insertion).  With the extension candidates the values are the
+// same but ties between an opening and an extension go to the extension (R/wavefront_backtrace.c:49-59), and the walk is then bound to
+// the gap component where the linear backtrace would be free to take a mismatch: different op strings.  Instantiated at run time only.
+template <int X, int OE, int E, bool FULL, bool HEUR = false, bool LIN = false>
 __global__ void __launch_bounds__(64) WFA_LANE_OCCUPANCY
 wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg) {
   static_assert(!(FULL && HEUR), "the general form is score only");
@@ -545,8 +551,8 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         const uint32_t mo = (OE == 1) ? cur[r] : Mh[OE - 2][r];   // M at s - (o + e): depth OE counted from the new score
-        gi[r] = pk_max(mo, Ih[E - 1][r]);
-        gd[r] = pk_max(mo, Dh[E - 1][r]);
+        gi[r] = LIN ? mo : pk_max(mo, Ih[E - 1][r]);
+        gd[r] = LIN ? mo : pk_max(mo, Dh[E - 1][r]);
       }
       uint32_t nm[NR], ni[NR], nd[NR];
       const uint32_t one2 = 0x00010001u;
@@ -556,8 +562,8 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
           const uint32_t mo = (OE == 1) ? cur[r] : Mh[OE - 2][r];
-          cmp_i[r] = pk_sub(Ih[E - 1][r], mo);
-          cmp_d[r] = pk_sub(Dh[E - 1][r], mo);
+          cmp_i[r] = LIN ? 0x80008000u : pk_sub(Ih[E - 1][r], mo);   // (LIN: every gap is an opening)
+          cmp_d[r] = LIN ? 0x80008000u : pk_sub(Dh[E - 1][r], mo);
         }
       }
 #pragma unroll
@@ -695,6 +701,7 @@ inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_
   if (!nwork_dev && grid > max_grid) grid = max_grid;
   if (grid < 1) grid = 1;
   if (full && a.codes_cap <= 0) return -1;   // (the caller sizes the record lists with lane_full_geometry)
+  if (a.lin) shape_idx = WFA_SHAPE_RTC;      // (the one-component form: instantiated at run time whatever the shape)
   switch (shape_idx) {
     case 0: return launch_lane_s0((unsigned)grid, smem, stream, a, slot_words, refill_min, full, heur);
     case 1: return launch_lane_s1((unsigned)grid, smem, stream, a, slot_words, refill_min, full, heur);
@@ -706,7 +713,7 @@ inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_
     case WFA_SHAPE_RTC: {
       struct { FastArgs a; int slot_words; int refill_min; } args = {a, slot_words, refill_min};   // (the kernel's argument list)
       const std::string name = "wfa::wfa_lane_kernel<" + std::to_string(X) + ", " + std::to_string(OE) + ", " + std::to_string(E) + ", " +
-                               rtc_bool(full && !heur) + ", " + rtc_bool(heur) + ">";
+                               rtc_bool(full && !heur) + ", " + rtc_bool(heur) + (a.lin ? ", true>" : ">");
       return rtc_launch("wfa_lane.hpp", name, (unsigned)grid, 64, smem, stream, &args, sizeof(args));
     }
     default: return -1;
