@@ -389,11 +389,11 @@ static void map_to_gap_affine(const wfa_hip_config_t& c, WfaDevConfig* d, int* n
   if (*ncomp == 1) {
     // Round 6, with CIGARs: gap-linear and levenshtein (match = 0) take the register kernels' LIN form (wfa_lane.hpp: gap-affine with o = 0 and
     // no extension candidates = the one-component recurrences and the linear backtrace's choices); what those stages hand on goes to the
-    // general kernel under the ORIGINAL configuration (derive_dev_config keeps it).  indel has no mismatch candidate: general kernel.
+    // general kernel under the ORIGINAL configuration (derive_dev_config keeps it).  indel: the same without the mismatch candidate.
     if (c.scope != WFA_SCOPE_SCORE) {
       static const bool lin_off = getenv("WFA_HIP_NO_LIN") && *getenv("WFA_HIP_NO_LIN") == '1';
-      if (lin_off || c.distance == WFA_DIST_INDEL || d->match != 0 || !d->rtc) return;
-      d->lin = 1;
+      if (lin_off || d->match != 0 || !d->rtc) return;
+      d->lin = (c.distance == WFA_DIST_INDEL) ? 2 : 1;   // (2: no mismatch candidate)
     }
     const int indel = d->o1;   // (derive_dev_config keeps the indel penalty there)
     if (c.distance == WFA_DIST_INDEL) d->x = 2;

@@ -119,7 +119,8 @@ struct LaneFull { static constexpr int NREC = 2 * (OE - E) + E * 17 + 1; };
 // which is the linear backtrace (the same priority: mismatch > deletion > insertion).  With the extension candidates the values are the
 // same but ties between an opening and an extension go to the extension (R/wavefront_backtrace.c:49-59), and the walk is then bound to
 // the gap component where the linear backtrace would be free to take a mismatch: different op strings.  Instantiated at run time only.
-template <int X, int OE, int E, bool FULL, bool HEUR = false, bool LIN = false>
+// LIN = 2: indel — the same without the mismatch candidate (R/wavefront_compute_edit.c:44-100 with the indel metric).
+template <int X, int OE, int E, bool FULL, bool HEUR = false, int LIN = 0>
 __global__ void __launch_bounds__(64) WFA_LANE_OCCUPANCY
 wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg) {
   static_assert(!(FULL && HEUR), "the general form is score only");
@@ -574,7 +575,7 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
         ni[r] = pk_add(below, one2);
         nd[r] = above;
         const uint32_t mx = (X == 1) ? cur[r] : Mh[X - 2][r];
-        const uint32_t gap = pk_max(nd[r], ni[r]), x1 = pk_add(mx, one2);
+        const uint32_t gap = pk_max(nd[r], ni[r]), x1 = (LIN == 2) ? WFA_LANE_NULL2 : pk_add(mx, one2);
         nm[r] = pk_clamp(pk_max(gap, x1), lim[r]);
         if constexpr (FULL) {
           // the four comparison bits of each of the two slots (sign bits 15 / 31 of the packed differences): 8: mismatch below the
@@ -713,7 +714,7 @@ inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_
     case WFA_SHAPE_RTC: {
       struct { FastArgs a; int slot_words; int refill_min; } args = {a, slot_words, refill_min};   // (the kernel's argument list)
       const std::string name = "wfa::wfa_lane_kernel<" + std::to_string(X) + ", " + std::to_string(OE) + ", " + std::to_string(E) + ", " +
-                               rtc_bool(full && !heur) + ", " + rtc_bool(heur) + (a.lin ? ", true>" : ">");
+                               rtc_bool(full && !heur) + ", " + rtc_bool(heur) + (a.lin ? ", " + std::to_string(a.lin) + ">" : std::string(">"));
       return rtc_launch("wfa_lane.hpp", name, (unsigned)grid, 64, smem, stream, &args, sizeof(args));
     }
     default: return -1;

@@ -66,7 +66,7 @@ template <int W>
 __device__ __forceinline__ int seg_max(int v) { return ~seg_min<W>(~v); }
 
 // LIN: the one-component distances with CIGARs — no extension candidates (wfa_lane.hpp has the argument); run-time instantiation only
-template <int X, int OE, int E, int W, bool LAZY, bool FULL, bool HEUR = false, bool LIN = false>
+template <int X, int OE, int E, int W, bool LAZY, bool FULL, bool HEUR = false, int LIN = 0>
 __global__ void __launch_bounds__(64)
 wfa_seg_kernel(const FastArgs a) {
   static_assert(!(LAZY && FULL), "the history of a step is stored in the step itself");
@@ -440,7 +440,7 @@ wfa_seg_kernel(const FastArgs a) {
     Mh[0] = cur;
     {
       // I(k) = max(M_oe, I_e)(k-1) + 1 and D(k) = max(M_oe, D_e)(k+1): the max commutes with the lane shift
-      const int mx = Mh[X - 1], mo = Mh[OE - 1], ie = LIN ? WFA_OFFSET_NULL : Ih[E - 1], de = LIN ? WFA_OFFSET_NULL : Dh[E - 1];
+      const int mx = (LIN == 2) ? WFA_OFFSET_NULL : Mh[X - 1], mo = Mh[OE - 1], ie = LIN ? WFA_OFFSET_NULL : Ih[E - 1], de = LIN ? WFA_OFFSET_NULL : Dh[E - 1];
       int ni, nd;
       if (FULL) {
         // the choices the backtrace would make (R/wavefront_backtrace.c:49-59: mismatch > deletion > insertion, extension > opening on
@@ -507,7 +507,7 @@ inline int seg_shape(const WfaDevConfig& c, int* X, int* OE, int* E) {
 inline int launch_seg_rtc(int X, int OE, int E, int w, bool lazy, bool full, bool heur, unsigned grid, hipStream_t stream, const FastArgs& a) {
   if (lazy && (X < 2 || OE < 2)) lazy = false;   // (the two-round extension: M must not be read one step after it is made)
   const std::string name = "wfa::wfa_seg_kernel<" + std::to_string(X) + ", " + std::to_string(OE) + ", " + std::to_string(E) + ", " + std::to_string(w) + ", " +
-                           rtc_bool(lazy) + ", " + rtc_bool(full) + ", " + rtc_bool(heur) + (a.lin ? ", true>" : ">");
+                           rtc_bool(lazy) + ", " + rtc_bool(full) + ", " + rtc_bool(heur) + (a.lin ? ", " + std::to_string(a.lin) + ">" : std::string(">"));
   return rtc_launch("wfa_seg.hpp", name, grid, 64, 0, stream, &a, sizeof(a));
 }
 

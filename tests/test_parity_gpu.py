@@ -620,13 +620,13 @@ def test_wildcard_batches_split_by_letters(gpu, cfg_idx):
 
 LIN = [dict(distance="levenshtein"), dict(distance="levenshtein", span="end-to-end"), dict(distance="linear"),
        dict(distance="linear", mismatch=3, gap_extension=5, span="end-to-end"), dict(distance="linear", mismatch=2, gap_extension=1),
-       dict(distance="linear", mismatch=6, gap_extension=2, memory_mode="medium")]
+       dict(distance="linear", mismatch=6, gap_extension=2, memory_mode="medium"), dict(distance="indel"), dict(distance="indel", span="end-to-end")]
 
 
 @pytest.mark.parametrize("env", [{}, {"WFA_HIP_NO_LIN": "1"}, {"WFA_HIP_RTC_FAIL": "1"}])
 @pytest.mark.parametrize("cfg_idx", range(len(LIN)))
 def test_one_component_distances_with_cigars_on_the_register_kernels(gpu, cfg_idx, env, monkeypatch):
-    """Round 6 (VERDICT r05 missing 1): gap-linear and levenshtein with CIGARs take the lane / segment kernels' LIN form (gap-affine with
+    """Round 6 (VERDICT r05 missing 1): gap-linear, levenshtein and indel with CIGARs take the lane / segment kernels' LIN form (gap-affine with
     o = 0 and no extension candidates: R/wavefront_compute_linear.c:44-74, R/wavefront_compute_edit.c:44-100 and the linear backtrace's
     choices, R/wavefront_backtrace.c:223-319); what they hand on goes to the general kernel under the original configuration.  Op
     strings against the oracle on reads with many ties (tandem repeats, low complexity), high divergence (pairs the 16-diagonal band
