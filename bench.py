@@ -846,7 +846,9 @@ def main():
                 # sequences + the op string (its rings live in the workspace and are re-used per score)
                 dict(name="BiWFA-10kb", n=2000, length=10000, error=0.08, seed=datagen.SEEDS["C3"],
                      cfg_kw=dict(span="end-to-end", scope="full", memory_mode="biwfa"), scheme="none", survey_bytes=2 * 2500 + 10_800 + 8, cpu_pairs=16, cpu_budget=3.0),
-                dict(name="BiWFA-100kb", n=64, length=100000, error=0.08, seed=datagen.SEEDS["C5"],
+                # (256 pairs: one per CU — the top levels of a 100 kb pair are one window per pair, 64 pairs left three quarters of the chip idle
+                # and the line quoted 94 aln/s where README's 215 was measured on 256: VERDICT r05)
+                dict(name="BiWFA-100kb", n=256, length=100000, error=0.08, seed=datagen.SEEDS["C5"],
                      cfg_kw=dict(span="end-to-end", scope="full", memory_mode="biwfa"), scheme="none", survey_bytes=2 * 25000 + 108_000 + 8, cpu_pairs=1, cpu_budget=3.0,
                      steps=1),
                 dict(name="C3-explicit-history", n=100_000, length=10000, error=0.08, seed=datagen.SEEDS["C3"],

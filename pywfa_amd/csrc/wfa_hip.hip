@@ -1791,6 +1791,7 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
     // the general kernel behind it (full scope): pairs whose top-level base case outgrew the BiWFA kernel's history
     // (reads of <= 100 bases under large penalties) are aligned by the ordinary algorithm, which is what that base case is
     b->dcfg.biwfa_top = full ? 1 : 0;
+    b->gcfg.biwfa_top = b->dcfg.biwfa_top;   // (the general kernel's copy of the configuration)
     Geometry g = plan_general(al, b, (uint32_t)std::min<int64_t>(b->n, (int64_t)al->cu_count * 16), b->arena_fixed + b->arena_ints);
     // Round 5: full CIGARs go level by level (csrc/wfa_bilevel.hpp: every window of a recursion level is a work item of one launch);
     // the depth-first kernel keeps the score-only form and what the level queues could not hold (redo list).

@@ -619,7 +619,7 @@ inline void seg_full_slot(const WfaDevConfig& c, int w, int max_len, long long* 
 inline int launch_seg(const WfaDevConfig& c, int cu_count, int per_cu, hipStream_t stream, const uint32_t* words,
                       const WfaPairMeta* meta, const uint32_t* worklist, const uint32_t* nwork_dev, uint32_t nwork,
                       int32_t* score, int32_t* status, uint32_t* fb_list, uint32_t* fb_count, int variant) {
-  FastArgs a;
+  FastArgs a = FastArgs();   // (value-initialised: lin = 0 and every field no launch path sets)
   a.words = words; a.meta = meta; a.worklist = worklist; a.nwork_dev = nwork_dev; a.nwork = nwork;
   a.score = score; a.status = status; a.fb_list = fb_list; a.fb_count = fb_count;
   a.g = gcd_int(gcd_int(c.x, c.o1 + c.e1), c.e1);
