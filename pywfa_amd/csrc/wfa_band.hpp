@@ -873,11 +873,22 @@ __device__ __forceinline__ int pb_lcp(const uint32_t* __restrict__ P, const uint
   return n;
 }
 
+// Round 6: the forward unpack keeps a WINDOW of eight words of either sequence per lane in LDS ([word][lane]: no bank conflicts): the
+// sequences are read forwards a few bases per event, so a refill (two 16-byte loads per sequence, for every active lane whenever any
+// lane misses) serves several events.  (The back-walk is left on direct loads: windows of code rows fetch lines a walk never visits,
+// DESIGN §8.)  -DWFA_WALK_WINDOWS=0: the direct loads of pb_lcp.
+#ifndef WFA_WALK_WINDOWS
+#define WFA_WALK_WINDOWS 1
+#endif
 template <int NCH>
 __global__ void __launch_bounds__(64)
 wfa_band_pb_bt_kernel(const BandArgs a) {
   const int W = a.seg_w ? a.seg_w : Band<NCH>::WI;   // (a.seg_w: the codes of wfa_seg_kernel<.., FULL>, records of seg_w bytes)
   const uint32_t t = blockIdx.x * 64u + threadIdx.x;
+#if WFA_WALK_WINDOWS
+  __shared__ uint32_t s_pw[8 * 64], s_tw[8 * 64];        // word j of the window: [j * 64 + lane]
+  const int lane = threadIdx.x;
+#endif
   if (t >= a.nwork) return;
   const int4 es = a.end_state[t];
   if (!es.w) return;
@@ -945,14 +956,53 @@ wfa_band_pb_bt_kernel(const BandArgs a) {
     if (run_len > 0) runs[nruns++] = (run_len << 8) | run_op;
     run_op = (uint32_t)op; run_len = (uint32_t)n;
   };
+#if WFA_WALK_WINDOWS
+  int pw0 = -(1 << 20), tw0 = -(1 << 20);
+  const int nwp_last = ((plen + 15) >> 4) + 1, nwt_last = ((tlen + 15) >> 4) + 1;   // (pb_lcp reads up to two words beyond a sequence: they exist)
+  auto lcp = [&](int v_, int h_, int maxn) -> int {
+    int n = 0;
+    while (n < maxn) {
+      const int vv = v_ + n, hh = h_ + n;
+      const int pi = vv >> 4, ti = hh >> 4;
+      const bool miss = !(pi >= pw0 && pi + 2 < pw0 + 8 && ti >= tw0 && ti + 2 < tw0 + 8);
+      if (__any(miss)) {
+        pw0 = pi; tw0 = ti;
+        if (pi + 7 <= nwp_last && ti + 7 <= nwt_last) {
+          typedef uint32_t walk_w4 __attribute__((ext_vector_type(4), aligned(4)));
+          const walk_w4 pa = *reinterpret_cast<const walk_w4*>(P + pi), pb = *reinterpret_cast<const walk_w4*>(P + pi + 4);
+          const walk_w4 ta = *reinterpret_cast<const walk_w4*>(T + ti), tb = *reinterpret_cast<const walk_w4*>(T + ti + 4);
+          s_pw[0 * 64 + lane] = pa.x; s_pw[1 * 64 + lane] = pa.y; s_pw[2 * 64 + lane] = pa.z; s_pw[3 * 64 + lane] = pa.w;
+          s_pw[4 * 64 + lane] = pb.x; s_pw[5 * 64 + lane] = pb.y; s_pw[6 * 64 + lane] = pb.z; s_pw[7 * 64 + lane] = pb.w;
+          s_tw[0 * 64 + lane] = ta.x; s_tw[1 * 64 + lane] = ta.y; s_tw[2 * 64 + lane] = ta.z; s_tw[3 * 64 + lane] = ta.w;
+          s_tw[4 * 64 + lane] = tb.x; s_tw[5 * 64 + lane] = tb.y; s_tw[6 * 64 + lane] = tb.z; s_tw[7 * 64 + lane] = tb.w;
+        } else {   // (near a sequence's end word by word: nothing beyond its two look-ahead words is read)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { s_pw[j * 64 + lane] = P[min(pi + j, nwp_last)]; s_tw[j * 64 + lane] = T[min(ti + j, nwt_last)]; }
+        }
+      }
+      const int po = pi - pw0, to = ti - tw0;
+      const uint32_t p0 = s_pw[po * 64 + lane], p1 = s_pw[(po + 1) * 64 + lane], p2 = s_pw[(po + 2) * 64 + lane];
+      const uint32_t t0 = s_tw[to * 64 + lane], t1 = s_tw[(to + 1) * 64 + lane], t2 = s_tw[(to + 2) * 64 + lane];
+      const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)vv << 1) ^ __builtin_amdgcn_alignbit(t1, t0, (uint32_t)hh << 1);
+      const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, (uint32_t)vv << 1) ^ __builtin_amdgcn_alignbit(t2, t1, (uint32_t)hh << 1);
+      int m = xl ? (__builtin_ctz(xl) >> 1) : (xh ? 16 + (__builtin_ctz(xh) >> 1) : 32);
+      m = min(m, maxn - n);
+      n += m;
+      if (m < 32) break;
+    }
+    return n;
+  };
+#else
+  auto lcp = [&](int v_, int h_, int maxn) -> int { return pb_lcp(P, T, v_, h_, maxn); };
+#endif
   emit('I', h); emit('D', v);
-  { const int n = pb_lcp(P, T, v, h, min(plen - v, tlen - h)); emit('M', n); v += n; h += n; }
+  { const int n = lcp(v, h, min(plen - v, tlen - h)); emit('M', n); v += n; h += n; }
   for (int e = nev - 1; e >= 0; --e) {
     const int op = ev[e] & 0x7F;
     if (op == 'X') { emit('X', 1); ++v; ++h; }
     else if (op == 'I') { emit('I', 1); ++h; }
     else { emit('D', 1); ++v; }
-    if (ev[e] & 0x80) { const int n = pb_lcp(P, T, v, h, min(plen - v, tlen - h)); emit('M', n); v += n; h += n; }
+    if (ev[e] & 0x80) { const int n = lcp(v, h, min(plen - v, tlen - h)); emit('M', n); v += n; h += n; }
   }
   emit('I', tlen - h); emit('D', plen - v);
   if (run_len > 0) runs[nruns++] = (run_len << 8) | run_op;
