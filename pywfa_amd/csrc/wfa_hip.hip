@@ -2161,7 +2161,8 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
       // block of diagonals by T steps inside an LDS tile, the rows in the workspace are read and written once per T steps.  What it
       // hands on (pairs where the reference's per-step trimming would change a value, a history that does not fit) goes to the
       // step-by-step forms below.  WFA_HIP_TILE=0: off; WFA_HIP_TILE_T / _WT / _THREADS / _PER_CU: geometry
-      if (b->dcfg.heuristic == WFA_HEUR_NONE && !wide32 && knob(al, K_TILE, 1) != 0) {
+      // (round 6: reads of up to 32 000 bases — the int16 rows' NULL is -32768; beyond, int32 rows: the step-by-step forms below)
+      if (b->dcfg.heuristic == WFA_HEUR_NONE && b->max_len <= WFA_TILE_MAX_LEN && knob(al, K_TILE, 1) != 0) {
         wfa::TileArgs& ta = tile_stage.a;
         memset(&ta, 0, sizeof(ta));
         wfa::TileGeom& tg = ta.g;

@@ -14,7 +14,7 @@
 //                 when it would not.  tools/tile_model.cpp + tests/test_tile_model.py pin that argument on CPU.
 // Penalties are run-time values (rings are indexed in LDS, nothing is unrolled over them): any x, o, e (, o2, e2), match = 0.
 // Scope: 2-bit pairs, no heuristic, end-to-end / ends-free, score or full CIGAR (piggy-back codes + directory exactly as
-// wfa_wide.hpp, walked by wide_walk_unpack), plen + tlen <= 32 000 (int16 rows).
+// wfa_wide.hpp, walked by wide_walk_unpack), reads of up to 32 000 bases (int16 rows; round 6: NULL = -32768).
 //
 // Layout.  Column c = k + plen.  Block b owns columns [b Bw, (b+1) Bw), Bw = Wt - 2 T; its tile holds columns
 // [b Bw - T, (b+1) Bw + T).  HBM row element = column + T (so tile b starts at element b Bw: dword-aligned).  HBM ring slots
@@ -138,10 +138,10 @@ wfa_tile_kernel(const TileArgs a) {
       const int used32 = min(a.rwh, nb * Bw + 2 * T) / 2;
       uint32_t* r32 = reinterpret_cast<uint32_t*>(rows);
       for (int r = 0; r < nhrows; ++r)
-        for (int i = tid; i < used32; i += blockDim.x) r32[(size_t)r * (a.rwh / 2) + i] = 0xC000C000u;
+        for (int i = tid; i < used32; i += blockDim.x) r32[(size_t)r * (a.rwh / 2) + i] = WFA_TILE_NULL2;
       if (tid < WFA_TILE_CTRL_INTS) ctrl[tid] = (tid == 0) ? -1 : 0;
     }
-    int end_reason = (plen + tlen > 32000 || (plen + tlen + 1 + Bw - 1) / Bw * Bw + 2 * T > a.rwh) ? 3 : 0;   // 1 reached, 3 handed on, 4 step limit
+    int end_reason = (plen > WFA_TILE_MAX_LEN || tlen > WFA_TILE_MAX_LEN || (plen + tlen + 1 + Bw - 1) / Bw * Bw + 2 * T > a.rwh) ? 3 : 0;   // 1 reached, 3 handed on, 4 step limit
     int end_k = 0, end_t = 0;
     long long pb_used = 0;
     const int t_lim = (a.max_steps == INT_MAX) ? INT_MAX : (int)max(1ll, ((long long)a.max_steps + a.gs - 1) / a.gs);   // first step whose score reaches the limit
@@ -149,7 +149,7 @@ wfa_tile_kernel(const TileArgs a) {
 
     for (int ss = 0; !end_reason; ++ss) {
       const int t0 = ss * T;
-      if (t0 + T > 16000) { end_reason = 3; break; }   // (int16 rows: a dead value gains at most 1 per step and must stay negative)
+      if (t0 + T > WFA_TILE_MAX_LEN) { end_reason = 3; break; }   // (int16 rows: a dead value gains at most 1 per step and must stay negative)
       // ---- the T steps' diagonal ranges and, full scope, their code bytes + directory records ----
       if (tid < T) { lo_j[tid] = tile_lo(g, t0 + tid, plen, pbf); hi_j[tid] = tile_hi(g, t0 + tid, tlen, tbf); }
       for (int i = tid; i < ncand; i += blockDim.x) {
@@ -240,7 +240,7 @@ wfa_tile_kernel(const TileArgs a) {
           }
           for (unsigned long long m = null_mask; m; m &= m - 1) {   // rows before score 0 (the first super-steps only)
             uint32_t* const dst = tile32 + __builtin_amdgcn_readlane(my_ld_lds, (int)__builtin_ctzll(m));
-            for (int c = lane; c < Wt / 2; c += 64) dst[c] = 0xC000C000u;
+            for (int c = lane; c < Wt / 2; c += 64) dst[c] = WFA_TILE_NULL2;
           }
           __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the rows are in LDS
           __builtin_amdgcn_wave_barrier();

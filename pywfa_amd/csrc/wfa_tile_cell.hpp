@@ -33,7 +33,12 @@
 #define WFA_TILE_HD static inline
 #endif
 
-#define WFA_TILE_NULL (-16384)
+// NULL of the int16 rows.  Round 6: -32768 (was -16384): offsets are loaded into ints before any arithmetic, so nothing needs the headroom
+// of a half-range NULL, and with the whole positive range for offsets the tiled kernel takes reads of up to 32 000 bases (round 5:
+// 16 000; exact 30 kb ran the step-by-step wide kernel).  A dead value gains at most 1 per step and must stay negative: 32 000 steps.
+#define WFA_TILE_NULL (-32768)
+#define WFA_TILE_NULL2 0x80008000u   // two of them
+#define WFA_TILE_MAX_LEN 32000       // longest sequence, and most steps, of the int16 rows
 
 namespace wfa {
 

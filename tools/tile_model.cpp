@@ -54,11 +54,11 @@ extern "C" int tile_model_align(int X, int OE, int E, int OE2, int E2, int T, in
   std::vector<int> dir;   // lo, hi, base per step
   *careful_passes = 0;
   int end_reason = 0, end_t = 0, end_k = 0;
-  if (plen + tlen > 32000) return 3;
+  if (plen > WFA_TILE_MAX_LEN || tlen > WFA_TILE_MAX_LEN) return 3;
 
   for (int ss = 0; !end_reason; ++ss) {
     const int t0 = ss * T;
-    if (t0 + T > 16000) { end_reason = 3; break; }
+    if (t0 + T > WFA_TILE_MAX_LEN) { end_reason = 3; break; }
     // directory of the T steps
     int lo_j[64], hi_j[64]; long long base_j[64];
     for (int j = 0; j < T; ++j) {
