@@ -48,7 +48,7 @@ static thread_local std::string g_error;
 // never call getenv.
 #define WFA_COUNTER_WORDS 256  // counters of a batch (wfa_hip_batch::d_counters)
 #define WFA_KNOBS(F)                                                                                              \
-  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(BAND_LDS_MAX) F(BAND_NO_WIN) F(BAND_SPLIT_MIN) F(NO_TINY_INLINE) F(BILEVEL) F(BILEVEL_WIDE_LEVELS) F(BILEVEL_PER_CU) F(BILEVEL_I32) F(BILEVEL_QCAP) F(BILEVEL_LEVELS) F(BILEVEL_LDS) F(BILEVEL_NO_1024) F(BILEVEL_HUGE_MIN) F(BILEVEL_LDS_W) F(BILEVEL_NO_SEQL) F(LANE_DYN) F(LANE_DYN_WAVES) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB) F(PIPE_TAIL) F(LEN16) F(MAILBOX) F(MAILBOX_IDLE_US)     \
+  F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(BAND_LDS_MAX) F(BAND_NO_WIN) F(BAND_SPLIT_MIN) F(NO_TINY_INLINE) F(BILEVEL) F(BILEVEL_WIDE_LEVELS) F(BILEVEL_PER_CU) F(BILEVEL_I32) F(BILEVEL_QCAP) F(BILEVEL_LEVELS) F(BILEVEL_LDS) F(BILEVEL_NO_1024) F(BILEVEL_HUGE_MIN) F(BILEVEL_LDS_W) F(BILEVEL_NO_SEQL) F(LANE_DYN) F(LANE_DYN_WAVES) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB) F(PIPE_TAIL) F(LEN16) F(MAILBOX) F(MAILBOX_IDLE_US) F(TILE32)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
   F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
   F(LANE_FULL) F(LANE_FULL_SPLIT) F(LANE_HEUR) F(SEG_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_ADAPT) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(TILE) F(TILE_T) F(TILE_WT) F(TILE_THREADS) F(TILE_PER_CU) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY) F(PILOT_PCT) F(WIDE_ADAPT_LDS)
@@ -2125,7 +2125,7 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
     struct WideStage { wfa::WideArgs a; int grid = 0, threads = 0; size_t smem = 0, hist_off = 0; bool grows = false, w32 = false; };
     WideStage wide_stage[3];
     int n_wide = 0;
-    struct TileStage { wfa::TileArgs a; int grid = 0, threads = 0; size_t smem = 0, hist_off = 0; bool on = false; } tile_stage;
+    struct TileStage { wfa::TileArgs a; int grid = 0, threads = 0; size_t smem = 0, hist_off = 0; bool on = false, w32 = false; } tile_stage;
     const bool wide_two = (b->ncomp == 5);
     if (wide_ok) {
       wfa::WideArgs w0;
@@ -2161,8 +2161,12 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
       // block of diagonals by T steps inside an LDS tile, the rows in the workspace are read and written once per T steps.  What it
       // hands on (pairs where the reference's per-step trimming would change a value, a history that does not fit) goes to the
       // step-by-step forms below.  WFA_HIP_TILE=0: off; WFA_HIP_TILE_T / _WT / _THREADS / _PER_CU: geometry
-      // (round 6: reads of up to 32 000 bases — the int16 rows' NULL is -32768; beyond, int32 rows: the step-by-step forms below)
-      if (b->dcfg.heuristic == WFA_HEUR_NONE && b->max_len <= WFA_TILE_MAX_LEN && knob(al, K_TILE, 1) != 0) {
+      // (round 6: reads of up to 32 000 bases on int16 rows — their NULL is -32768.  Longer ones: wfa_tile_kernel<.., W32> (int32 cells)
+      // exists and is parity-green but measured SLOWER than the step-by-step forms below — exact 100 kb, 256 pairs: 247 against 290 aln/s:
+      // 50 KB of sequences per workgroup in LDS leave one workgroup of eight waves per CU — so it stays behind WFA_HIP_TILE32=1)
+      const bool tile32 = b->max_len > WFA_TILE_MAX_LEN;
+      const int tile_cb = tile32 ? 4 : 2;
+      if (b->dcfg.heuristic == WFA_HEUR_NONE && (!tile32 || (knob(al, K_TILE32, 0) != 0 && 2 * (int64_t)b->max_len < ((int64_t)1 << 29))) && knob(al, K_TILE, 1) != 0) {
         wfa::TileArgs& ta = tile_stage.a;
         memset(&ta, 0, sizeof(ta));
         wfa::TileGeom& tg = ta.g;
@@ -2172,11 +2176,13 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
         // steps — tiles of 128 diagonals advanced 8 steps by two waves per alignment keep more alignments in flight and waste less of
         // a tile on halo (1 kb at 5 %: 4.3 -> 6.6 M aln/s, 2 kb at 1 %: 6.8 -> 15.1 M, 600 bp at 10 %: 3.9 -> 5.9 M; 4 kb at 5 %: equal)
         const bool small_geom = !wide_two && b->max_len <= 8000;   // (3 / 5 / 7 kb at 5 %: equal / +10 % / +2 % score, 5 kb full +35 %; 10 kb: -20 %)
+        tile_stage.w32 = tile32;
         tg.T = knob(al, K_TILE_T, (wide_two || small_geom) ? 8 : 16) & ~1;
-        tg.Wt = knob(al, K_TILE_WT, (wide_two || small_geom) ? 128 : 256);
+        tg.Wt = tile32 ? (wide_two ? 128 : 256) : knob(al, K_TILE_WT, (wide_two || small_geom) ? 128 : 256);   // (int32 cells: the two widths that exist)
         const int bw = tg.Wt - 2 * tg.T;
         // (gap-affine-2p reads of up to 1.2 kb: one wave per alignment — 300 / 600 / 1 000 bp at 8 %: +28 / +51 / +29 % over four)
-        const int tthreads = std::max(64, std::min(512, knob(al, K_TILE_THREADS, small_geom ? 128 : (wide_two && b->max_len <= 1200) ? 64 : 256) & ~63));
+        // (int32 cells: reads beyond 32 kb hold 2 x 6+ KB of sequences per workgroup — eight waves share them)
+        const int tthreads = std::max(64, std::min(512, knob(al, K_TILE_THREADS, tile32 ? 512 : small_geom ? 128 : (wide_two && b->max_len <= 1200) ? 64 : 256) & ~63));
         if (tg.T >= 2 && tg.T <= WFA_TILE_MAX_T && tg.Wt >= 64 && tg.Wt % 64 == 0 && tg.Wt <= 256 && bw >= 16 &&
             wfa::tile_cand_count(tg) <= WFA_TILE_MAX_ROWS) {
           ta.gs = w0.g; ta.seq_words = w0.seq_words;
@@ -2184,17 +2190,17 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
           ta.rwh = (nbmax * bw + 2 * tg.T + 1) & ~1;
           ta.rows_stride = ((int64_t)wfa::tile_hbm_rows(tg) * ta.rwh + 63) & ~63ll;
           tile_stage.threads = tthreads;
-          tile_stage.smem = wfa::tile_smem_bytes(tg, ta.seq_words, tthreads / 64);
+          tile_stage.smem = wfa::tile_smem_bytes(tg, ta.seq_words, tthreads / 64, tile_cb);
           if (tile_stage.smem <= (size_t)160 * 1024) {
-            int per_cu = wfa::tile_occupancy(full, wide_two, tg.Wt / 64, tthreads, tile_stage.smem);
+            int per_cu = wfa::tile_occupancy(full, wide_two, tg.Wt / 64, tthreads, tile_stage.smem, tile32);
             per_cu = std::max(1, std::min(per_cu, knob(al, K_TILE_PER_CU, 16)));
             tile_stage.grid = (int)std::min<int64_t>((int64_t)al->cu_count * per_cu, in_n);
             int64_t hist_bytes = 0;
             if (full) hist_bytes = (int64_t)full_range * ((int64_t)(b->max_len * 0.9 * penalty_scale(b->dcfg)) / w0.g + 64 + tg.T) / 2 + (1 << 20);
-            while (tile_stage.grid > 1 && (int64_t)tile_stage.grid * (ta.rows_stride * 2 + hist_bytes) > budget) tile_stage.grid = (tile_stage.grid + 1) / 2;
-            if ((int64_t)tile_stage.grid * (ta.rows_stride * 2 + hist_bytes) <= budget) {
+            while (tile_stage.grid > 1 && (int64_t)tile_stage.grid * (ta.rows_stride * tile_cb + hist_bytes) > budget) tile_stage.grid = (tile_stage.grid + 1) / 2;
+            if ((int64_t)tile_stage.grid * (ta.rows_stride * tile_cb + hist_bytes) <= budget) {
               ta.hist_stride = (hist_bytes / 4) & ~15ll;
-              tile_stage.hist_off = ((size_t)tile_stage.grid * (size_t)ta.rows_stride * 2 + 255) & ~(size_t)255;
+              tile_stage.hist_off = ((size_t)tile_stage.grid * (size_t)ta.rows_stride * tile_cb + 255) & ~(size_t)255;
               need = std::max(need, tile_stage.hist_off + (size_t)tile_stage.grid * (size_t)ta.hist_stride * 4);
               tile_stage.on = true;
             }
@@ -2729,7 +2735,7 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
       if (stage_timing) { (void)hipEventCreate(&se0); (void)hipEventCreate(&se1); (void)hipEventRecord(se0, stream); }
       ta.dbg = stage_timing ? b->d_counters + 8 : nullptr;   // ([8] is the lane-full stage's list count: short reads only)
       if (stage_timing) (void)hipMemsetAsync(b->d_counters + 8, 0, 8 * sizeof(uint32_t), stream);
-      if (wfa::launch_tile(full, wide_two, ta, tile_stage.grid, tile_stage.threads, tile_stage.smem, stream) != 0) { al->err = "tile kernel launch failed"; return WFA_HIP_EDEVICE; }
+      if (wfa::launch_tile(full, wide_two, ta, tile_stage.grid, tile_stage.threads, tile_stage.smem, stream, tile_stage.w32) != 0) { al->err = "tile kernel launch failed"; return WFA_HIP_EDEVICE; }
       if (stage_timing) {  // development aid: synchronises
         (void)hipEventRecord(se1, stream); (void)hipEventSynchronize(se1);
         float ms = 0.f; (void)hipEventElapsedTime(&ms, se0, se1);

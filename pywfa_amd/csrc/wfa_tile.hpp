@@ -62,9 +62,9 @@ struct TileArgs {
 #define WFA_TILE_MAX_T 32
 #define WFA_TILE_MAX_ROWS 64    // rows a tile loads / writes back: DM + 2 E + 2 E2 candidates
 // ctrl: [0] end key, [1] taint, [2] violation, [8 + comp] LDS ring position of row t0 of component comp
-static inline size_t tile_smem_bytes(const TileGeom& g, int seq_words, int nwaves) {
+static inline size_t tile_smem_bytes(const TileGeom& g, int seq_words, int nwaves, int cell_bytes = 2) {
   return (size_t)(WFA_TILE_CTRL_INTS + 3 * WFA_TILE_MAX_T + 16 * WFA_TILE_MAX_T + 4 * WFA_TILE_MAX_ROWS) * 4 + (size_t)2 * seq_words * 4 +
-         (size_t)nwaves * tile_lds_rows(g) * tile_lds_pitch(g) * 2;
+         (size_t)nwaves * tile_lds_rows(g) * tile_lds_pitch(g) * cell_bytes;
 }
 // candidate row i of the load / write-back tables -> (component, distance d >= 1)
 WFA_TILE_HD int tile_cand_count(const TileGeom& g) { return g.DM + 2 * g.E + (g.OE2 > 0 ? 2 * g.E2 : 0); }
@@ -82,10 +82,18 @@ WFA_TILE_HD void tile_cand(const TileGeom& g, int i, int* comp, int* d) {
 __device__ __forceinline__ uint32_t tile_ffbl(uint32_t x) { uint32_t r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
 
 // NCH: 64-column chunks of a tile (Wt = 64 NCH): the chunks of a step run interleaved, so their LDS latencies overlap
-template <bool FULL, bool TWO, int NCH>
+// W32 (round 6): int32 cells in the rows and the tiles — reads beyond 32 000 bases (exact 100 kb), which ran the step-by-step
+// wfa_wide_kernel<.., W32> until now.  Same schedule; a cell is a dword (CB = 4 bytes, one per dword instead of two), NULL is
+// WFA_OFFSET_NULL, the end key is 64 bits (step << 32 | diagonal + 2^30).
+template <bool FULL, bool TWO, int NCH, bool W32 = false>
 __global__ void __launch_bounds__(512)
 wfa_tile_kernel(const TileArgs a) {
   constexpr int NC = TWO ? 5 : 3;
+  constexpr int CB = W32 ? 4 : 2;                       // bytes per cell
+  constexpr int CS = W32 ? 0 : 1;                       // cells -> dwords: >> CS
+  constexpr int NULLV = W32 ? (int)0xC0000000 : WFA_TILE_NULL;
+  constexpr uint32_t NULLDW = W32 ? 0xC0000000u : WFA_TILE_NULL2;
+  typedef typename std::conditional<W32, int, short>::type cell_t;
   extern __shared__ int tsm[];
   const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: everything per tile then lives in scalar registers)
@@ -107,8 +115,8 @@ wfa_tile_kernel(const TileArgs a) {
   uint32_t* const sP = reinterpret_cast<uint32_t*>(wb_hbm + WFA_TILE_MAX_ROWS);
   const int ncand = tile_cand_count(g);
   uint32_t* const sT = sP + a.seq_words;
-  short* const tile = reinterpret_cast<short*>(sT + a.seq_words) + (size_t)wave * tile_lds_rows(g) * pitch;
-  short* const rows = a.rows + (long long)blockIdx.x * a.rows_stride;
+  cell_t* const tile = reinterpret_cast<cell_t*>(sT + a.seq_words) + (size_t)wave * tile_lds_rows(g) * pitch;
+  cell_t* const rows = reinterpret_cast<cell_t*>(a.rows) + (long long)blockIdx.x * a.rows_stride;
   int* const hist = FULL ? a.hist + (long long)blockIdx.x * a.hist_stride : nullptr;
   uint8_t* const pb_codes = FULL ? reinterpret_cast<uint8_t*>(hist) : nullptr;
   const long long pb_cap = FULL ? a.hist_stride * 4 : 0;
@@ -117,8 +125,8 @@ wfa_tile_kernel(const TileArgs a) {
 
   // guard columns of this wave's tile: NULL, never written again
   for (int r = lane; r < tile_lds_rows(g); r += 64) {
-    short* row = tile + (size_t)r * pitch;
-    row[0] = row[1] = row[pitch - 2] = row[pitch - 1] = (short)WFA_TILE_NULL;
+    cell_t* row = tile + (size_t)r * pitch;
+    row[0] = row[1] = row[pitch - 2] = row[pitch - 1] = (cell_t)NULLV;
   }
 
   for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
@@ -135,13 +143,13 @@ wfa_tile_kernel(const TileArgs a) {
       for (int i = tid; i < a.seq_words; i += blockDim.x) { sP[i] = (i < nwp) ? gp[i] : 0u; sT[i] = (i < nwt) ? gt[i] : 0u; }
       // the rows this pair can touch start as NULL (blocks 0 .. nb-1 and their halos)
       const int nb = (plen + tlen + 1 + Bw - 1) / Bw;
-      const int used32 = min(a.rwh, nb * Bw + 2 * T) / 2;
+      const int used32 = min(a.rwh, nb * Bw + 2 * T) >> CS;
       uint32_t* r32 = reinterpret_cast<uint32_t*>(rows);
       for (int r = 0; r < nhrows; ++r)
-        for (int i = tid; i < used32; i += blockDim.x) r32[(size_t)r * (a.rwh / 2) + i] = WFA_TILE_NULL2;
-      if (tid < WFA_TILE_CTRL_INTS) ctrl[tid] = (tid == 0) ? -1 : 0;
+        for (int i = tid; i < used32; i += blockDim.x) r32[(size_t)r * (a.rwh >> CS) + i] = NULLDW;
+      if (tid < WFA_TILE_CTRL_INTS) ctrl[tid] = (tid == 0 || (W32 && (tid == 4 || tid == 5))) ? -1 : 0;   // ([4..5]: W32's 64-bit end key)
     }
-    int end_reason = (plen > WFA_TILE_MAX_LEN || tlen > WFA_TILE_MAX_LEN || (plen + tlen + 1 + Bw - 1) / Bw * Bw + 2 * T > a.rwh) ? 3 : 0;   // 1 reached, 3 handed on, 4 step limit
+    int end_reason = ((!W32 && (plen > WFA_TILE_MAX_LEN || tlen > WFA_TILE_MAX_LEN)) || (plen + tlen + 1 + Bw - 1) / Bw * Bw + 2 * T > a.rwh) ? 3 : 0;   // 1 reached, 3 handed on, 4 step limit
     int end_k = 0, end_t = 0;
     long long pb_used = 0;
     const int t_lim = (a.max_steps == INT_MAX) ? INT_MAX : (int)max(1ll, ((long long)a.max_steps + a.gs - 1) / a.gs);   // first step whose score reaches the limit
@@ -149,17 +157,17 @@ wfa_tile_kernel(const TileArgs a) {
 
     for (int ss = 0; !end_reason; ++ss) {
       const int t0 = ss * T;
-      if (t0 + T > WFA_TILE_MAX_LEN) { end_reason = 3; break; }   // (int16 rows: a dead value gains at most 1 per step and must stay negative)
+      if (!W32 && t0 + T > WFA_TILE_MAX_LEN) { end_reason = 3; break; }   // (int16 rows: a dead value gains at most 1 per step and must stay negative)
       // ---- the T steps' diagonal ranges and, full scope, their code bytes + directory records ----
       if (tid < T) { lo_j[tid] = tile_lo(g, t0 + tid, plen, pbf); hi_j[tid] = tile_hi(g, t0 + tid, tlen, tbf); }
       for (int i = tid; i < ncand; i += blockDim.x) {
         int comp, d;
         tile_cand(g, i, &comp, &d);
         // (dword offsets: of the row's column 0 / first own column inside the wave's tile, of the row inside the workgroup's rows)
-        ld_lds[i] = (((comp == 0) ? tile_lds_slot_m_old(g, t0, d) : tile_lds_slot(g, comp, t0 - d)) * pitch + 2) / 2;
-        ld_hbm[i] = !tile_loads_row(g, comp, d) ? -2 : (t0 - d < 0) ? -1 : tile_hbm_slot(g, comp, t0 - d) * (a.rwh / 2);
-        wb_lds[i] = (tile_lds_slot(g, comp, t0 + T - d) * pitch + 2 + T) / 2;
-        wb_hbm[i] = (d <= T) ? (tile_hbm_slot(g, comp, t0 + T - d) * a.rwh + T) / 2 : -2;
+        ld_lds[i] = (((comp == 0) ? tile_lds_slot_m_old(g, t0, d) : tile_lds_slot(g, comp, t0 - d)) * pitch + 2) >> CS;
+        ld_hbm[i] = !tile_loads_row(g, comp, d) ? -2 : (t0 - d < 0) ? -1 : tile_hbm_slot(g, comp, t0 - d) * (a.rwh >> CS);
+        wb_lds[i] = (tile_lds_slot(g, comp, t0 + T - d) * pitch + 2 + T) >> CS;
+        wb_hbm[i] = (d <= T) ? (tile_hbm_slot(g, comp, t0 + T - d) * a.rwh + T) >> CS : -2;
       }
       if (tid < NC) ctrl[8 + tid] = t0 % tile_lds_ring_depth(g, tid);
       long long need = 0;
@@ -195,7 +203,7 @@ wfa_tile_kernel(const TileArgs a) {
         bool taint = false;
         // byte offsets (from this lane's column 0 of LDS row 0) of the rows a step reads and writes; they advance by one row per
         // step and wrap inside their ring: 0 X, 1 O, 2 I, 3 D, 4 O2, 5 I2, 6 D2 (inputs), 7 M, 8 I, 9 D, 10 I2, 11 D2 (outputs)
-        const int pitch_b = 2 * pitch;
+        const int pitch_b = CB * pitch;
         constexpr int NP = TWO ? 12 : 10;
         int pos0[12], rlo[12], rhi[12];
         {
@@ -229,18 +237,18 @@ wfa_tile_kernel(const TileArgs a) {
           const long long pc0 = clock64();
 #endif
           // ---- tile load: the rows the T steps read, columns [b Bw - T, (b+1) Bw + T) (the tables sit one entry per lane) ----
-          const uint32_t vcol = (uint32_t)(b * (Bw / 2) + lane);    // this lane's dword of a row
+          const uint32_t vcol = (uint32_t)(b * (Bw >> CS) + lane);    // this lane's dword of a row
           for (unsigned long long m = ld_mask; m; m &= m - 1) {
             const int i = (int)__builtin_ctzll(m);
             uint32_t* const dst = tile32 + __builtin_amdgcn_readlane(my_ld_lds, i);
             const uint32_t* const src = rows32 + ((uint32_t)__builtin_amdgcn_readlane(my_ld_hbm, i) + vcol);
 #pragma unroll
-            for (int c0 = 0; c0 < 32 * NCH; c0 += 64)
-              if (c0 + lane < 32 * NCH) __builtin_amdgcn_global_load_lds(src + c0, dst + c0, 4, 0, 0);
+            for (int c0 = 0; c0 < ((64 * NCH) >> CS); c0 += 64)
+              if (c0 + lane < ((64 * NCH) >> CS)) __builtin_amdgcn_global_load_lds(src + c0, dst + c0, 4, 0, 0);
           }
           for (unsigned long long m = null_mask; m; m &= m - 1) {   // rows before score 0 (the first super-steps only)
             uint32_t* const dst = tile32 + __builtin_amdgcn_readlane(my_ld_lds, (int)__builtin_ctzll(m));
-            for (int c = lane; c < Wt / 2; c += 64) dst[c] = WFA_TILE_NULL2;
+            for (int c = lane; c < (Wt >> CS); c += 64) dst[c] = NULLDW;
           }
           __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the rows are in LDS
           __builtin_amdgcn_wave_barrier();
@@ -269,26 +277,26 @@ wfa_tile_kernel(const TileArgs a) {
           int pos[12];
 #pragma unroll
           for (int i = 0; i < 12; ++i) pos[i] = pos0[i];
-          const char* const tb = reinterpret_cast<const char*>(tile) + 4 + 2 * lane;   // this lane's column 0 (chunk 0) of LDS row 0
+          const char* const tb = reinterpret_cast<const char*>(tile) + 2 * CB + CB * lane;   // this lane's column 0 (chunk 0) of LDS row 0
           auto step = [&](const int j, auto first_tag, auto careful_tag) {
             constexpr bool FIRST = decltype(first_tag)::value, CAREFUL = decltype(careful_tag)::value;
             const int t = t0 + j;
             const char* const pX = tb + pos[0];
-            const char* const pO = tb + pos[1] - 2;        // (column - 1; column + 1 is 4 bytes on)
-            const char* const pI = tb + pos[2] - 2;
-            const char* const pD = tb + pos[3] + 2;
-            const char* const pO2 = tb + pos[4] - 2;
-            const char* const pI2 = tb + pos[5] - 2;
-            const char* const pD2 = tb + pos[6] + 2;
-            auto ld = [](const char* p, int c) { return (int)*reinterpret_cast<const short*>(p + 128 * c); };
-            auto st = [&](int i, int c, int v) { *reinterpret_cast<short*>(const_cast<char*>(tb) + pos[i] + 128 * c) = (short)v; };
+            const char* const pO = tb + pos[1] - CB;        // (column - 1; column + 1 is two cells on)
+            const char* const pI = tb + pos[2] - CB;
+            const char* const pD = tb + pos[3] + CB;
+            const char* const pO2 = tb + pos[4] - CB;
+            const char* const pI2 = tb + pos[5] - CB;
+            const char* const pD2 = tb + pos[6] + CB;
+            auto ld = [](const char* p, int c) { return (int)*reinterpret_cast<const cell_t*>(p + 64 * CB * c); };
+            auto st = [&](int i, int c, int v) { *reinterpret_cast<cell_t*>(const_cast<char*>(tb) + pos[i] + 64 * CB * c) = (cell_t)v; };
             // -- compute-next of every chunk (R/wavefront_compute_affine.c:44-86, R/wavefront_compute_affine2p.c:45-106) --
             int vm[NCH], code[NCH];
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-              const int mx = ld(pX, c), mo_lo = ld(pO, c), mo_hi = ld(pO + 4, c), ie_lo = ld(pI, c), de_hi = ld(pD, c);
-              int mo2_lo = WFA_TILE_NULL, mo2_hi = WFA_TILE_NULL, i2e_lo = WFA_TILE_NULL, d2e_hi = WFA_TILE_NULL;
-              if (TWO) { mo2_lo = ld(pO2, c); mo2_hi = ld(pO2 + 4, c); i2e_lo = ld(pI2, c); d2e_hi = ld(pD2, c); }
+              const int mx = ld(pX, c), mo_lo = ld(pO, c), mo_hi = ld(pO + 2 * CB, c), ie_lo = ld(pI, c), de_hi = ld(pD, c);
+              int mo2_lo = NULLV, mo2_hi = NULLV, i2e_lo = NULLV, d2e_hi = NULLV;
+              if (TWO) { mo2_lo = ld(pO2, c); mo2_hi = ld(pO2 + 2 * CB, c); i2e_lo = ld(pI2, c); d2e_hi = ld(pD2, c); }
               TileCell cc = tile_cell<TWO, FULL>(mx, mo_lo, mo_hi, ie_lo, de_hi, mo2_lo, mo2_hi, i2e_lo, d2e_hi);
               if (FIRST) { if (kk[c] >= -pbf && kk[c] <= tbf) cc.m_raw = max(kk[c], 0); }   // R/wavefront_aligner.c:251-310
               // taint: the untrimmed M candidate passes the end of an own diagonal (signed: a dead value is far below)
@@ -363,7 +371,7 @@ wfa_tile_kernel(const TileArgs a) {
             int reach = INT_MIN;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-              const int mfin = m_in[c] ? hh[c] : WFA_TILE_NULL;   // only M is clamped (R/wavefront_compute_affine.c:80-84)
+              const int mfin = m_in[c] ? hh[c] : NULLV;   // only M is clamped (R/wavefront_compute_affine.c:80-84)
               st(7, c, mfin);
               hh[c] = mfin;
               reach = max(reach, a.ef ? mfin + max(0, -kk[c]) : mfin);
@@ -381,7 +389,10 @@ wfa_tile_kernel(const TileArgs a) {
                 const bool own = (uint32_t)(kk[c] - kown) < (uint32_t)Bw;
                 const bool fin = h >= 0 && own &&
                                  (a.ef ? ((h >= tlen && plen - v <= a.pef) || (v >= plen && tlen - h <= a.tef)) : (kk[c] == ak && h >= tlen));
-                if (fin) atomicMin(reinterpret_cast<unsigned*>(&ctrl[0]), ((unsigned)t << 16) | (unsigned)(kk[c] + 32768));
+                if (fin) {
+                  if (W32) atomicMin(reinterpret_cast<unsigned long long*>(&ctrl[4]), ((unsigned long long)(unsigned)t << 32) | (unsigned)(kk[c] + (1 << 30)));
+                  else atomicMin(reinterpret_cast<unsigned*>(&ctrl[0]), ((unsigned)t << 16) | (unsigned)(kk[c] + 32768));
+                }
               }
             }
             // the rings advance
@@ -422,8 +433,8 @@ wfa_tile_kernel(const TileArgs a) {
               uint32_t* d0 = rows32 + ((uint32_t)__builtin_amdgcn_readlane(my_wb_hbm, i0) + vcol);
               uint32_t* d1 = rows32 + ((uint32_t)__builtin_amdgcn_readlane(my_wb_hbm, i1) + vcol);
 #pragma unroll
-              for (int c0 = 0; c0 < 32 * NCH; c0 += 64) {
-                if (c0 + lane < Bw / 2) {
+              for (int c0 = 0; c0 < ((64 * NCH) >> CS); c0 += 64) {
+                if (c0 + lane < (Bw >> CS)) {
                   const uint32_t v0 = s0[c0 + lane], v1 = s1[c0 + lane];
                   d0[c0] = v0;
                   if (two_rows) d1[c0] = v1;
@@ -450,8 +461,10 @@ wfa_tile_kernel(const TileArgs a) {
         if (!careful && ctrl[1] != 0) continue;   // a cell past the end of its diagonal: repeat the super-step with the trimming statistics
         if (careful) {
           // a gap cell past the end outside [first, last in-bounds] of its row is where the reference's trimming changes a value
+          const unsigned long long key64 = W32 ? *reinterpret_cast<const unsigned long long*>(&ctrl[4]) : 0ull;
           const unsigned key = (unsigned)ctrl[0];
-          const int j_end = (key != 0xFFFFFFFFu) ? (int)(key >> 16) - t0 : T - 1;   // (steps after the end do not count)
+          const bool ended = W32 ? (key64 != ~0ull) : (key != 0xFFFFFFFFu);
+          const int j_end = ended ? (W32 ? (int)(key64 >> 32) : (int)(key >> 16)) - t0 : T - 1;   // (steps after the end do not count)
           for (int i = tid; i < 4 * T; i += blockDim.x) {
             const int* st = stats + i * 4;
             if ((i >> 2) <= j_end && st[2] != INT_MAX && (st[0] == INT_MAX || st[2] < st[0] || st[3] > st[1])) atomicOr(&ctrl[2], 1);
@@ -462,10 +475,12 @@ wfa_tile_kernel(const TileArgs a) {
       }
       if (ctrl[2] != 0) { end_reason = 3; }
       else {
+        const unsigned long long key64 = W32 ? *reinterpret_cast<const unsigned long long*>(&ctrl[4]) : 0ull;
         const unsigned key = (unsigned)ctrl[0];
-        const int t_end = (key != 0xFFFFFFFFu) ? (int)(key >> 16) : INT_MAX;
+        const bool ended = W32 ? (key64 != ~0ull) : (key != 0xFFFFFFFFu);
+        const int t_end = ended ? (W32 ? (int)(key64 >> 32) : (int)(key >> 16)) : INT_MAX;
         if (t_lim < t0 + T && t_lim <= t_end) end_reason = 4;
-        else if (t_end != INT_MAX) { end_reason = 1; end_t = t_end; end_k = (int)(key & 0xFFFFu) - 32768; }
+        else if (t_end != INT_MAX) { end_reason = 1; end_t = t_end; end_k = W32 ? (int)(unsigned)(key64 & 0xFFFFFFFFull) - (1 << 30) : (int)(key & 0xFFFFu) - 32768; }
       }
       if (FULL) { for (int j = 0; j < T; ++j) pb_used += (long long)(hi_j[j] - lo_j[j] + 1); }
       __syncthreads();   // everyone has read ctrl / the tables
@@ -504,8 +519,8 @@ wfa_tile_kernel(const TileArgs a) {
 }
 
 // host entry point (csrc/k_tile.hip)
-int launch_tile(bool full, bool two, const TileArgs& a, int grid, int threads, size_t smem, hipStream_t stream);
+int launch_tile(bool full, bool two, const TileArgs& a, int grid, int threads, size_t smem, hipStream_t stream, bool w32 = false);
 // resident workgroups per CU of that instantiation (LDS, registers, wave slots)
-int tile_occupancy(bool full, bool two, int nch, int threads, size_t smem);
+int tile_occupancy(bool full, bool two, int nch, int threads, size_t smem, bool w32 = false);
 
 }  // namespace wfa

@@ -188,10 +188,13 @@ def test_wide_kernel_10kb_exact_sample(gpu):
 
 @pytest.mark.parametrize("kw", [dict(span="end-to-end", scope="score"), dict(span="end-to-end", scope="full"),
                                 dict(distance="affine2p", span="ends-free", pattern_end_free=50, text_end_free=50, scope="score")])
-def test_exact_reads_beyond_16kb_take_the_int32_rows(gpu, kw):
+@pytest.mark.parametrize("tile32", ["0", "1"])
+def test_exact_reads_beyond_16kb_take_the_int32_rows(gpu, kw, tile32, monkeypatch):
     """Exact (no heuristic) alignment of reads beyond 16 kb against the oracle, score and full CIGAR; nothing is left to the general
     kernel.  Round 6: reads of up to 32 000 bases take the tiled kernel (int16 rows with NULL = -32768: csrc/wfa_tile_cell.hpp) — the
-    30 kb pairs here; the 36 kb pairs take the workspace-row form of the wide-wavefront kernel with int32 offsets (VERDICT r02 item 8)."""
+    30 kb pairs here; the 36 kb pairs take the workspace-row form of the wide-wavefront kernel with int32 offsets (VERDICT r02 item 8) or,
+    with WFA_HIP_TILE32=1, the tiled kernel's int32 form (built in round 6; not the default: it measured no faster at 100 kb)."""
+    monkeypatch.setenv("WFA_HIP_TILE32", tile32)
     batch = datagen.generate(5, 30000, 0.06, 8801)
     long_b = datagen.generate(2, 36000, 0.05, 8802)
     batch = datagen.from_strings(*zip(*([datagen.pair_strings(batch, i) for i in range(5)] + [datagen.pair_strings(long_b, i) for i in range(2)])))
