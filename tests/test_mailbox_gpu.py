@@ -140,3 +140,30 @@ def test_a_process_may_exit_with_an_instance_on_the_device(gpu, how):
     assert "calls done" in out.stdout, out.stdout + out.stderr[-2000:]
     assert out.returncode == (3 if "SystemExit(3)" in how else 0), (out.returncode, out.stderr[-2000:])
     assert time.time() - t0 < 60
+
+
+@pytest.mark.parametrize("mode", ["1", "auto", "0"])
+def test_upload_workers_never_rebind_the_caller(gpu, mode, monkeypatch):
+    """round 5 bound the upload workers to the GPU's NUMA node — and with them the CALLER's thread, which works a
+    share of the pieces: the application's main thread stayed narrowed for good.  Whatever WFA_HIP_NUMA says, the caller's affinity mask
+    is what it was after a pipelined upload (>= 256 k pairs), results are unchanged, and the diagnostics say what was done."""
+    from pywfa_amd import _native
+    monkeypatch.setenv("WFA_HIP_NUMA", mode)
+    before = os.sched_getaffinity(0)
+    batch = datagen.generate(300000, 100, 0.02, 9500)
+    oc, nc = common.configs_pair(scope="score", span="end-to-end")
+    idx = np.arange(0, 300000, 300)
+    o = loader.run(loader.oracle(), oc, datagen.subset(batch, idx), want_cigar=False)
+    al = _native.Aligner(nc)
+    try:
+        for _ in range(2):
+            score, status, _ = al.align_batch(batch, False)
+            assert os.sched_getaffinity(0) == before
+        info = al.upload_info()
+    finally:
+        al.close()
+    assert np.array_equal(score[idx], o["score"]) and int((status != 0).sum()) == 0
+    assert info["numa_mode"] == {"0": 0, "1": 1, "auto": 2}[mode] or info["gpu_node_cpus"] == 0
+    assert info["pack_threads"] >= 1 and info["process_cpus"] == len(before)
+    if mode == "0":
+        assert info["workers_bound"] == 0
