@@ -2161,12 +2161,16 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
       // block of diagonals by T steps inside an LDS tile, the rows in the workspace are read and written once per T steps.  What it
       // hands on (pairs where the reference's per-step trimming would change a value, a history that does not fit) goes to the
       // step-by-step forms below.  WFA_HIP_TILE=0: off; WFA_HIP_TILE_T / _WT / _THREADS / _PER_CU: geometry
-      // (round 6: reads of up to 32 000 bases on int16 rows — their NULL is -32768.  Longer ones: wfa_tile_kernel<.., W32> (int32 cells)
-      // exists and is parity-green but measured SLOWER than the step-by-step forms below — exact 100 kb, 256 pairs: 247 against 290 aln/s:
-      // 50 KB of sequences per workgroup in LDS leave one workgroup of eight waves per CU — so it stays behind WFA_HIP_TILE32=1)
+      // (round 6: reads of up to 32 000 bases on int16 rows — their NULL is -32768.  Longer ones: wfa_tile_kernel<.., W32> — int32 cells,
+      // the sequences read from global memory (50 KB of them per workgroup in LDS left one workgroup per CU), eight waves per pair.  One
+      // workgroup per pair needs pairs to fill the chip: exact 100 kb score, 512 / 1 024 pairs 345 / 351 aln/s against 275 / 192 on the
+      // step-by-step forms below, but 256 pairs 238 against 290 and 64 pairs 62 against 104 — so from two pairs per CU on.
+      // WFA_HIP_TILE32 = 0 never, 1 always)
       const bool tile32 = b->max_len > WFA_TILE_MAX_LEN;
       const int tile_cb = tile32 ? 4 : 2;
-      if (b->dcfg.heuristic == WFA_HEUR_NONE && (!tile32 || (knob(al, K_TILE32, 0) != 0 && 2 * (int64_t)b->max_len < ((int64_t)1 << 29))) && knob(al, K_TILE, 1) != 0) {
+      const int tile32_knob = knob(al, K_TILE32, -1);
+      const bool tile32_on = tile32_knob >= 0 ? tile32_knob != 0 : (int64_t)in_n >= 2 * (int64_t)al->cu_count;
+      if (b->dcfg.heuristic == WFA_HEUR_NONE && (!tile32 || (tile32_on && 2 * (int64_t)b->max_len < ((int64_t)1 << 29))) && knob(al, K_TILE, 1) != 0) {
         wfa::TileArgs& ta = tile_stage.a;
         memset(&ta, 0, sizeof(ta));
         wfa::TileGeom& tg = ta.g;
@@ -2181,11 +2185,10 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
         tg.Wt = tile32 ? (wide_two ? 128 : 256) : knob(al, K_TILE_WT, (wide_two || small_geom) ? 128 : 256);   // (int32 cells: the two widths that exist)
         const int bw = tg.Wt - 2 * tg.T;
         // (gap-affine-2p reads of up to 1.2 kb: one wave per alignment — 300 / 600 / 1 000 bp at 8 %: +28 / +51 / +29 % over four)
-        // (int32 cells: reads beyond 32 kb hold 2 x 6+ KB of sequences per workgroup — eight waves share them)
         const int tthreads = std::max(64, std::min(512, knob(al, K_TILE_THREADS, tile32 ? 512 : small_geom ? 128 : (wide_two && b->max_len <= 1200) ? 64 : 256) & ~63));
         if (tg.T >= 2 && tg.T <= WFA_TILE_MAX_T && tg.Wt >= 64 && tg.Wt % 64 == 0 && tg.Wt <= 256 && bw >= 16 &&
             wfa::tile_cand_count(tg) <= WFA_TILE_MAX_ROWS) {
-          ta.gs = w0.g; ta.seq_words = w0.seq_words;
+          ta.gs = w0.g; ta.seq_words = tile32 ? 0 : w0.seq_words;   // (int32 form: the sequences stay in global memory)
           const int nbmax = (2 * b->max_len + 1 + bw - 1) / bw;
           ta.rwh = (nbmax * bw + 2 * tg.T + 1) & ~1;
           ta.rows_stride = ((int64_t)wfa::tile_hbm_rows(tg) * ta.rwh + 63) & ~63ll;

@@ -136,11 +136,15 @@ wfa_tile_kernel(const TileArgs a) {
     const int ak = tlen - plen;
     const int pbf = a.ef ? a.pbf : 0, tbf = a.ef ? a.tbf : 0;
     __syncthreads();   // the previous pair is done with LDS and the rows
+    // W32 (reads beyond 32 kb): the sequences stay in global memory (a.seq_words = 0: 2 x 6+ KB per pair would leave one workgroup per CU);
+    // the probes read them through the vector cache — a probe never reads beyond a sequence's two look-ahead words, which exist
+    const uint32_t* const gp = a.words + pm.p_woff;
+    const uint32_t* const gt = a.words + pm.t_woff;
+    const uint32_t* const qP = W32 ? gp : sP;
+    const uint32_t* const qT = W32 ? gt : sT;
     {
       const int nwp = (plen + 15) >> 4, nwt = (tlen + 15) >> 4;
-      const uint32_t* gp = a.words + pm.p_woff;
-      const uint32_t* gt = a.words + pm.t_woff;
-      for (int i = tid; i < a.seq_words; i += blockDim.x) { sP[i] = (i < nwp) ? gp[i] : 0u; sT[i] = (i < nwt) ? gt[i] : 0u; }
+      if (!W32) for (int i = tid; i < a.seq_words; i += blockDim.x) { sP[i] = (i < nwp) ? gp[i] : 0u; sT[i] = (i < nwt) ? gt[i] : 0u; }
       // the rows this pair can touch start as NULL (blocks 0 .. nb-1 and their halos)
       const int nb = (plen + tlen + 1 + Bw - 1) / Bw;
       const int used32 = min(a.rwh, nb * Bw + 2 * T) >> CS;
@@ -331,8 +335,9 @@ wfa_tile_kernel(const TileArgs a) {
               hh[c] = m_in[c] ? vm[c] : max(kk[c], 0);   // (a lane without a cell probes some cell of its column and discards the result)
               left[c] = m_in[c] ? bas[c] + span[c] - vm[c] : 0;
               const int v = hh[c] - kk[c], h = hh[c];
-              const int pi = v >> 4, ti = h >> 4;
-              const uint32_t x = __builtin_amdgcn_alignbit(sP[pi + 1], sP[pi], (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(sT[ti + 1], sT[ti], (uint32_t)h << 1);
+              // (W32: a lane without a cell must not read beyond the sequences' look-ahead words: global memory, not a staged LDS area)
+              const int pi = W32 ? min(v >> 4, (plen + 15) >> 4) : v >> 4, ti = W32 ? min(h >> 4, (tlen + 15) >> 4) : h >> 4;
+              const uint32_t x = __builtin_amdgcn_alignbit(qP[pi + 1], qP[pi], (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(qT[ti + 1], qT[ti], (uint32_t)h << 1);
               const int m = min((int)(tile_ffbl(x) >> 1), min(16, left[c]));
               hh[c] += m; left[c] -= m;
               rem |= (m == 16) ? left[c] : 0;
@@ -352,7 +357,7 @@ wfa_tile_kernel(const TileArgs a) {
                   if (more[c]) {
                     const int v = hh[c] - kk[c], h = hh[c];
                     const int pi = v >> 4, ti = h >> 4;
-                    const uint32_t p0 = sP[pi], p1 = sP[pi + 1], p2 = sP[pi + 2], t0_ = sT[ti], t1 = sT[ti + 1], t2 = sT[ti + 2];
+                    const uint32_t p0 = qP[pi], p1 = qP[pi + 1], p2 = qP[pi + 2], t0_ = qT[ti], t1 = qT[ti + 1], t2 = qT[ti + 2];
                     const uint32_t xl = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t1, t0_, (uint32_t)h << 1);
                     const uint32_t xh = __builtin_amdgcn_alignbit(p2, p1, (uint32_t)v << 1) ^ __builtin_amdgcn_alignbit(t2, t1, (uint32_t)h << 1);
                     const uint32_t fb = min(tile_ffbl(xl), tile_ffbl(xh) | 32u);
@@ -501,7 +506,7 @@ wfa_tile_kernel(const TileArgs a) {
         out_score = -(end_t * a.gs);
         if (FULL) {
           const long long n = wide_walk_unpack<TWO>(hist, a.hist_stride, pb_codes, pb_codes + pb_used, pb_cap - pb_used - (long long)(end_t + T + 2) * 12,
-                                                    end_t, end_k, g.X, g.OE, g.E, g.OE2, g.E2, sP, sT, plen, tlen, a.cigar_ops + a.cigar_off[pair]);
+                                                    end_t, end_k, g.X, g.OE, g.E, g.OE2, g.E2, qP, qT, plen, tlen, a.cigar_ops + a.cigar_off[pair]);
           if (n < 0) {
             out_status = WFA_INTERNAL_FALLBACK; out_score = 0;
             a.fb_list[atomicAdd(a.fb_count, 1u)] = pair;

@@ -193,7 +193,8 @@ def test_exact_reads_beyond_16kb_take_the_int32_rows(gpu, kw, tile32, monkeypatc
     """Exact (no heuristic) alignment of reads beyond 16 kb against the oracle, score and full CIGAR; nothing is left to the general
     kernel.  Round 6: reads of up to 32 000 bases take the tiled kernel (int16 rows with NULL = -32768: csrc/wfa_tile_cell.hpp) — the
     30 kb pairs here; the 36 kb pairs take the workspace-row form of the wide-wavefront kernel with int32 offsets (VERDICT r02 item 8) or,
-    with WFA_HIP_TILE32=1, the tiled kernel's int32 form (built in round 6; not the default: it measured no faster at 100 kb)."""
+    with WFA_HIP_TILE32=1, the tiled kernel's int32 form (round 6: what batches of at least two pairs per CU take; sequences read from
+    global memory)."""
     monkeypatch.setenv("WFA_HIP_TILE32", tile32)
     batch = datagen.generate(5, 30000, 0.06, 8801)
     long_b = datagen.generate(2, 36000, 0.05, 8802)
