@@ -2184,8 +2184,9 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
         tg.T = knob(al, K_TILE_T, (wide_two || small_geom) ? 8 : 16) & ~1;
         tg.Wt = tile32 ? (wide_two ? 128 : 256) : knob(al, K_TILE_WT, (wide_two || small_geom) ? 128 : 256);   // (int32 cells: the two widths that exist)
         const int bw = tg.Wt - 2 * tg.T;
-        // (gap-affine-2p reads of up to 1.2 kb: one wave per alignment — 300 / 600 / 1 000 bp at 8 %: +28 / +51 / +29 % over four)
-        const int tthreads = std::max(64, std::min(512, knob(al, K_TILE_THREADS, tile32 ? 512 : small_geom ? 128 : (wide_two && b->max_len <= 1200) ? 64 : 256) & ~63));
+        // (gap-affine-2p reads of up to 1.2 kb: one wave per alignment — 300 / 600 / 1 000 bp at 8 %: +28 / +51 / +29 % over four;
+        // round 6: gap-affine reads over 16 kb eight waves — 30 kb, 512 pairs: 128 / 256 / 512 threads 4.6 / 8.7 / 11.7 k aln/s; 10 kb keeps 256)
+        const int tthreads = std::max(64, std::min(512, knob(al, K_TILE_THREADS, (tile32 || (!wide_two && b->max_len > 16000)) ? 512 : small_geom ? 128 : (wide_two && b->max_len <= 1200) ? 64 : 256) & ~63));
         if (tg.T >= 2 && tg.T <= WFA_TILE_MAX_T && tg.Wt >= 64 && tg.Wt % 64 == 0 && tg.Wt <= 256 && bw >= 16 &&
             wfa::tile_cand_count(tg) <= WFA_TILE_MAX_ROWS) {
           ta.gs = w0.g; ta.seq_words = tile32 ? 0 : w0.seq_words;   // (int32 form: the sequences stay in global memory)
