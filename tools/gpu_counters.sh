@@ -2,7 +2,7 @@
 # Counter passes for the C2 step (development aid; run on the GPU box through gpurun):
 #   bash tools/gpu_counters.sh <tag>      -> gpurun_out/<tag>_*
 # Every rocprofv3 pass is its own run (--pmc only with --kernel-trace), the program directly after `--`.
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -90,6 +90,10 @@ if "M5" in which: run("150bp mismatch=5 score", 2000000, 150, 0.02, 1002, dict(s
 if "M5f" in which: run("150bp mismatch=5 full", 1000000, 150, 0.02, 1002, dict(scope="full", mismatch=5), cpu_n=50000)
 if "LEV" in which: run("150bp levenshtein score", 2000000, 150, 0.02, 1002, dict(distance="levenshtein", span="end-to-end", scope="score"), cpu_n=100000)
 if "LIN" in which: run("150bp gap-linear score", 2000000, 150, 0.02, 1002, dict(distance="linear", span="end-to-end", scope="score"), cpu_n=100000)
+if "LEVf" in which: run("150bp levenshtein full", 2000000, 150, 0.02, 1002, dict(distance="levenshtein", span="end-to-end", scope="full"), cpu_n=50000)
+if "LINf" in which: run("150bp gap-linear full", 2000000, 150, 0.02, 1002, dict(distance="linear", span="end-to-end", scope="full"), cpu_n=50000)
+if "INDf" in which: run("150bp indel full", 2000000, 150, 0.02, 1002, dict(distance="indel", span="end-to-end", scope="full"), cpu_n=50000)
+if "X100kb" in which: run("100kb exact score, 1024 pairs", 1024, 100000, 0.08, 1005, dict(span="end-to-end", scope="score"), cpu_n=1, reps=1)
 if "MN1" in which: run("150bp match=-1 score", 2000000, 150, 0.02, 1002, dict(span="end-to-end", scope="score", match=-1), cpu_n=100000)
 if "MN1f" in which: run("150bp match=-1 full", 1000000, 150, 0.02, 1002, dict(scope="full", match=-1), cpu_n=50000)
 if "C4am5" in which: run("C4 adaptive mismatch=5 full", 20000, 10000, 0.08, 1004, dict(distance="affine2p", span="ends-free", pattern_begin_free=100, pattern_end_free=100, scope="full", heuristic="adaptive", mismatch=5), cpu_n=50)

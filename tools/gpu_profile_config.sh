@@ -3,7 +3,7 @@
 #   bash tools/gpu_profile_config.sh <tag> <config>       e.g.  r03 C3      -> gpurun_out/<tag>_<config>_*
 # --kernel-trace --stats, the two SQ passes, FETCH_SIZE and WRITE_SIZE, each its own run (--pmc only with --kernel-trace), the
 # program directly after `--`.  tools/make_profiles.py turns the outputs into the files kept under profiles/.
-TAG=${1:-r05}; CFG=${2:-C3}
+TAG=${1:-r06}; CFG=${2:-C3}
 OUT=gpurun_out
 P=$OUT/${TAG}_${CFG}
 mkdir -p $OUT

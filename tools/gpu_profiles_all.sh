@@ -4,7 +4,7 @@
 # C2 (bench.py --steps 2): issue-rate microbenchmark, SQ / FETCH_SIZE / WRITE_SIZE passes, kernel stats; the region counters of the
 # lane kernel (counting build pywfa_amd/libwfa_hip_dbg.so, built beforehand: WFA_BUILD_SUFFIX=_dbg WFA_HIP_EXTRA_FLAGS=-DWFA_LANE_DEBUG_COUNTERS=1
 # bash pywfa_amd/csrc/build.sh); then the same passes for the other configurations (tools/gpu_profile_config.sh).
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -1,6 +1,6 @@
 #!/bin/bash
 # After tools/gpu_final.sh <tag> came back through gpurun: turn gpurun_out/<tag>_* into the files kept under profiles/ (development aid).
-TAG=${1:-r05}
+TAG=${1:-r06}
 cp gpurun_out/${TAG}_lane_regions.txt profiles/${TAG}_lane_regions.txt
 python3 tools/make_traffic.py gpurun_out $TAG > /dev/null
 python3 tools/lane_mix.py > /dev/null
