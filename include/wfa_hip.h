@@ -169,10 +169,13 @@ int wfa_hip_align_batch(wfa_hip_aligner_t* aligner, int64_t n,
  * One pair per call — pywfa's own usage pattern: wavefront_align(text) against the cached pattern (align.pyx:421-443, one
  * wavefront_align / wavefront_align_lambda per call, wfa.h:199-210).  The result of wfa_hip_align_batch with n = 1 without its
  * arrays: `pattern` / `text` are the two ASCII sequences; `cigar_ops` (NULL for scope = score) receives plen + tlen bytes of which
- * [*cigar_begin, *cigar_begin + *cigar_len) are the alignment's ops.  Served by the single-launch path (host packs the pair into a
- * pinned block, one wave aligns it, the host polls a completion flag): about 14 us per 150 bp call from C, 19 us with the op
- * string (tools/probes/latency_c.c on MI355X) against 1-2 us for the reference on a host core — the library is batch-oriented,
- * and a loop of single calls, while exact, is what wfa_hip_align_batch with many pairs replaces.
+ * [*cigar_begin, *cigar_begin + *cigar_len) are the alignment's ops.  Round 6: calls in a row are served without a kernel launch — a
+ * one-wave kernel stays on the device and takes the pairs from a mailbox in pinned host memory (it leaves by itself after 2 ms without
+ * a call, before any batch of this aligner, and when the aligner is destroyed; gap-affine shapes of the library, reads of up to 1 000
+ * bases; anything else takes the single-launch path: the pair packed into a pinned block, one wave, a completion flag polled by the
+ * host).  About 9 us per 150 bp call from C score-only, 16.5 us with the op string, against 1-2 us for the reference on a host core —
+ * the library is batch-oriented, and a loop of single calls, while exact, is what wfa_hip_align_batch with many pairs replaces.
+ * WFA_HIP_MAILBOX=0: a launch per call (13 / 21 us).
  */
 int wfa_hip_align_pair(wfa_hip_aligner_t* aligner, const uint8_t* pattern, int32_t plen, const uint8_t* text, int32_t tlen,
                        int32_t* score, int32_t* status, uint8_t* cigar_ops, int64_t* cigar_begin, int32_t* cigar_len);
@@ -184,7 +187,8 @@ int wfa_hip_align_pair(wfa_hip_aligner_t* aligner, const uint8_t* pattern, int32
  * (len + 3) / 4 bytes starting at its BYTE offset p_off[i] / t_off[i]; p_len / t_len stay in bases.  The results are those
  * of wfa_hip_align_batch on the decoded ASCII sequences (that is what the tests pin it against: the reference's own entry
  * reads only (len + 7) / 8 bytes per sequence, wavefront_sequences.c:112, and aligns uninitialised buffer bytes behind them).
- * No host packing and a quarter of the bytes over PCIe.  A wildcard letter cannot be expressed: WFA_HIP_ENOTSUP.
+ * A quarter of the bytes are read on the host; large batches are re-based to whole words by the upload workers on their way into the
+ * pinned ring (round 6: the same bytes cross PCIe as for ASCII input).  A wildcard letter cannot be expressed: WFA_HIP_ENOTSUP.
  */
 int wfa_hip_align_batch_packed2bits(wfa_hip_aligner_t* aligner, int64_t n,
                                     const uint8_t* packed,
