@@ -148,6 +148,10 @@ def test_biwfa_short_divergent_reads_under_large_penalties(gpu, kw):
 @pytest.mark.parametrize("kw0", [dict(span="end-to-end"), dict(distance="affine2p"), dict(distance="levenshtein", span="end-to-end"), dict(match=-1, span="end-to-end")])
 @pytest.mark.parametrize("scope", ["full", "score"])
 def test_biwfa_step_limit_matches_oracle(gpu, kw0, scope):
+    # (the suite's time budget: with CIGARs gap-affine-2p only under -m gpu, 10 s a case; WFA_TEST_FULL=1 runs the four)
+    import os
+    if scope == "full" and kw0.get("distance") != "affine2p" and os.environ.get("WFA_TEST_FULL") != "1":
+        pytest.skip("sampled on the suite's time budget (WFA_TEST_FULL=1 runs every cell)")
     import validate_oracle as vo
     corpora = [datagen.generate(500, 150, 0.05, 21), datagen.generate(200, 150, 0.2, 22), datagen.generate(300, 60, 0.1, 23),
                datagen.generate(40, 1500, 0.08, 24), datagen.generate(3, 10000, 0.08, 25), vo.corpus_special(seed=6)]

@@ -15,7 +15,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), 
 def test_fuzz_slice(gpu, seed):
     # (the GPU suite runs on a budget — up to 14 rounds, none started after 14 s: on a fresh box the first
     # run-time shapes of a seed compile for seconds each; WFA_TEST_FULL=1 lifts the limit)
-    seconds = "0" if os.environ.get("WFA_TEST_FULL") == "1" else "14"
+    seconds = "0" if os.environ.get("WFA_TEST_FULL") == "1" else "10"
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz.py"), "14", str(seed), seconds], capture_output=True, text=True, timeout=1500)
     tail = "\n".join(out.stdout.splitlines()[-20:])
     assert out.returncode == 0 and "TOTAL BAD 0" in out.stdout, tail + out.stderr[-2000:]

@@ -627,7 +627,7 @@ LIN = [dict(distance="levenshtein"), dict(distance="levenshtein", span="end-to-e
 @pytest.mark.parametrize("cfg_idx", range(len(LIN)))
 def test_one_component_distances_with_cigars_on_the_register_kernels(gpu, cfg_idx, env, monkeypatch):
     # (the suite's time budget: the mapping switched off and the failing run-time compiler on two configurations each; WFA_TEST_FULL=1: all)
-    if env and os.environ.get("WFA_TEST_FULL") != "1" and cfg_idx not in ((0, 6) if "WFA_HIP_NO_LIN" in env else (2, 7)):
+    if os.environ.get("WFA_TEST_FULL") != "1" and cfg_idx not in ((0, 2, 3, 6) if not env else (0,) if "WFA_HIP_NO_LIN" in env else (2,)):
         pytest.skip("sampled on the suite's time budget (WFA_TEST_FULL=1 runs every cell)")
     """Round 6 (VERDICT r05 missing 1): gap-linear, levenshtein and indel with CIGARs take the lane / segment kernels' LIN form (gap-affine with
     o = 0 and no extension candidates: R/wavefront_compute_linear.c:44-74, R/wavefront_compute_edit.c:44-100 and the linear backtrace's
@@ -638,7 +638,7 @@ def test_one_component_distances_with_cigars_on_the_register_kernels(gpu, cfg_id
     for k_, v_ in env.items():
         monkeypatch.setenv(k_, v_)
     batches = [datagen.generate(3000, 150, 0.04, 8800 + cfg_idx), datagen.generate(600, 150, 0.15, 8900 + cfg_idx), vo.corpus_special(seed=123),
-               datagen.generate(120000 if not env else 20000, 100, 0.02, 9000 + cfg_idx)]
+               datagen.generate(80000 if not env else 20000, 100, 0.02, 9000 + cfg_idx)]
     for bi, batch in enumerate(batches):
         oc, nc = common.configs_pair(**dict(LIN[cfg_idx], scope="full"))
         if bi == 3:   # (the large batch: every 50th pair against the oracle, all of them for completion)

@@ -62,7 +62,7 @@ CONFIGS = [
 @pytest.mark.parametrize("scope", ["full", "score"])
 @pytest.mark.parametrize("cfg_idx", range(len(CONFIGS)))
 def test_slim_kernel_matches_oracle_and_band_kernel(gpu, cfg_idx, scope, monkeypatch):
-    if cfg_idx >= len(CONFIGS) - 2 and scope == "score" and __import__("os").environ.get("WFA_TEST_FULL") != "1":
+    if (cfg_idx == len(CONFIGS) - 1 or (cfg_idx == len(CONFIGS) - 2 and scope == "score")) and __import__("os").environ.get("WFA_TEST_FULL") != "1":
         pytest.skip("the run-time 2p shapes: score scope with WFA_TEST_FULL=1 (the suite's time budget)")
     two = CONFIGS[cfg_idx].get("distance") == "affine2p"   # (the oracle's 2p runs are what this test takes: fewer 10 kb pairs)
     batches = [ragged(31 + cfg_idx, 96, 1100, 4000, 0.08, indel_bias=6), datagen.generate(16 if two else 48, 10000, 0.08, 4100 + cfg_idx),
