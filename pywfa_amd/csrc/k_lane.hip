@@ -4,7 +4,7 @@
 
 namespace wfa {
 #define WFA_LANE_DEFINE(i, x, oe, e)                                                                                        \
-  int launch_lane_s##i(unsigned grid, size_t smem, hipStream_t stream, const FastArgs& a, int slot_words, int refill_min, bool full, bool heur) { \
+  int launch_lane_s##i(unsigned grid, size_t smem, hipStream_t stream, const FastArgs& a, int slot_words, int refill_min, bool full, int heur) { \
     return launch_lane_shape<x, oe, e>(grid, smem, stream, a, slot_words, refill_min, full, heur);                                               \
   }
 #if WFA_TU_INDEX == 0

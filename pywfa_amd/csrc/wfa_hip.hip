@@ -50,7 +50,7 @@ static thread_local std::string g_error;
 #define WFA_KNOBS(F)                                                                                              \
   F(ARENA_KB) F(BAND_DEBUG) F(BAND_SLIM) F(BAND_LDS_MAX) F(BAND_NO_WIN) F(BAND_SPLIT_MIN) F(NO_TINY_INLINE) F(BILEVEL) F(BILEVEL_WIDE_LEVELS) F(BILEVEL_PER_CU) F(BILEVEL_I32) F(BILEVEL_QCAP) F(BILEVEL_LEVELS) F(BILEVEL_LDS) F(BILEVEL_NO_1024) F(BILEVEL_HUGE_MIN) F(BILEVEL_LDS_W) F(BILEVEL_NO_SEQL) F(LANE_DYN) F(LANE_DYN_WAVES) F(BAND_LEFTOVER_WAVES_PER_CU) F(BAND_NCH) F(BAND_NO_LDS) F(BAND_NO_SPLIT) F(BAND_PB) F(PIPE_TAIL) F(LEN16) F(MAILBOX) F(MAILBOX_IDLE_US) F(TILE32)     \
   F(BAND_RECORDS) F(BAND_SPLIT_ROUNDS) F(BAND_WAVES_PER_CU) F(NO_BAND) F(NO_FAST) F(NO_SEGFULL) F(SEGFULL_PAIRS)     \
-  F(SEGFULL_STAGES) F(STAGE_TIMING) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
+  F(SEGFULL_STAGES) F(STAGE_TIMING) F(LANE_HEUR32) F(THREADS) F(TINY_BATCH) F(WAVES_PER_CU) F(FAST_WAVES_PER_CU) F(TIMING)          \
   F(LANE_FULL) F(LANE_FULL_SPLIT) F(LANE_HEUR) F(SEG_HEUR) F(LANE_LDS_PAD_KB) F(LANE_MIN_PAIRS) F(PIPE_CHUNK) F(PIPE_THREADS) F(PACK_THREADS) F(NO_TINY_BAND) F(NO_TINY_POLL) F(UP_STREAMS) F(NO_DUAL) F(NO_WIDE) F(WIDE_ADAPT) F(WIDE_GROWS) F(WIDE_LDS_KB) F(WIDE_THREADS) F(TILE) F(TILE_T) F(TILE_WT) F(TILE_THREADS) F(TILE_PER_CU) F(NO_PIPE) F(HOST_PACK) F(GENERAL_PB) F(LANE_WAVES_PER_CU) F(LANE_REFILL_MIN) F(LANE_DEBUG) F(NO_TINY) F(PILOT_PCT) F(WIDE_ADAPT_LDS)
 enum WfaKnob {
 #define WFA_KNOB_ENUM(n) K_##n,
@@ -1467,7 +1467,7 @@ static int pilot_lane_heur(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t st
   if (!lane_ok) forced = 0;                     // (X-drop: the segmented form only)
   if (wfa::seg_shape(b->dcfg, &X, &OE, &E) == WFA_SHAPE_RTC && !wfa::rtc_lane_shape_ok(X, OE, E)) forced = 0;   // (a run-time shape whose rings outgrow the lane kernel's registers)
   const int forced_seg = knob(al, K_SEG_HEUR, -1);    // (WFA_HIP_SEG_HEUR likewise)
-  if (forced >= 0) b->laneh_pick = forced ? 1 : 2;
+  if (forced >= 0) b->laneh_pick = forced == 2 ? 3 : forced ? 1 : 2;   // (2: the 32-diagonal form)
   if (forced_seg >= 0) b->segh_pick = (forced_seg && seg_ok) ? 1 : 2;
   else if (seg_ok && !free_begins) b->segh_pick = 1;  // (small batches: on, unless wavefront 0 already spans many diagonals)
   if ((forced >= 0 && (forced_seg >= 0 || !seg_ok)) || b->n_packed < 65536u) return WFA_HIP_OK;
@@ -1477,7 +1477,7 @@ static int pilot_lane_heur(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t st
   uint32_t* pcount = b->d_counters + 4;
   hipLaunchKernelGGL(wfa_pilot_sample_kernel, dim3((np + 255u) / 256u), dim3(256), 0, stream, b->d_list_packed, stride, np, psample);
   HIP_TRY(al, hipGetLastError());
-  HIP_TRY(al, hipMemsetAsync(pcount, 0, 2 * sizeof(uint32_t), stream));
+  HIP_TRY(al, hipMemsetAsync(pcount, 0, 3 * sizeof(uint32_t), stream));
   wfa::FastArgs fa;
   memset(&fa, 0, sizeof(fa));
   fa.words = b->d_words; fa.meta = b->d_meta; fa.worklist = psample; fa.nwork = np;
@@ -1489,16 +1489,27 @@ static int pilot_lane_heur(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t st
   fa.steps_between = b->dcfg.steps_between; fa.max_steps = b->dcfg.max_steps; fa.xdrop = b->dcfg.xdrop;
   if (forced < 0 &&
       wfa::launch_lane_args(wfa::seg_shape(b->dcfg, &X, &OE, &E), OE, E, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8),
-                            b->max_len, stream, fa, false, 0, 256, true, X) != 0) return pilot_launch_failed(al, b, rtc_failures);
+                            b->max_len, stream, fa, false, 0, 256, 1, X) != 0) return pilot_launch_failed(al, b, rtc_failures);
+  // (round 6) ... and through the 32-diagonal form of the same kernel (rings of 16 registers: shallow shapes only)
+  const bool lane32_ok = std::max(X, OE) <= 8 && E <= 3 && knob(al, K_LANE_HEUR32, 1) != 0;
+  if (forced < 0 && lane32_ok) {
+    fa.fb_count = pcount + 2;
+    if (wfa::launch_lane_args(wfa::seg_shape(b->dcfg, &X, &OE, &E), OE, E, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8),
+                              b->max_len, stream, fa, false, 0, 256, 2, X) != 0) return pilot_launch_failed(al, b, rtc_failures);
+  }
   if (forced_seg < 0 && seg_ok) {   // (the same sample through the 32-lane form; its list is not read, only its count)
     fa.fb_count = pcount + 1;
     if (wfa::launch_seg_heur(b->dcfg, al->cu_count, knob(al, K_FAST_WAVES_PER_CU, 256), stream, fa) != 0) return pilot_launch_failed(al, b, rtc_failures);
   }
-  uint32_t handed[2] = {0, 0};
-  HIP_TRY(al, hipMemcpyAsync(handed, pcount, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  uint32_t handed[3] = {0, 0, 0};
+  HIP_TRY(al, hipMemcpyAsync(handed, pcount, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   HIP_TRY(al, hipStreamSynchronize(stream));
-  HIP_TRY(al, hipMemsetAsync(pcount, 0, 2 * sizeof(uint32_t), stream));
-  if (forced < 0) b->laneh_pick = (handed[0] * 4u <= np) ? 1 : 2;                  // at most a quarter handed on
+  HIP_TRY(al, hipMemsetAsync(pcount, 0, 3 * sizeof(uint32_t), stream));
+  if (knob(al, K_STAGE_TIMING, 0)) fprintf(stderr, "[wfa_hip] pilot (general forms): 16 slots hand on %u, 32 slots %u, 32-lane segments %u of %u\n", handed[0], handed[2], handed[1], np);
+  // (round 6: measured per divergence and configuration, tools/probes/laneh_probe.py — wf-adaptive, free ends of 3 and 12 diagonals, a step
+  // limit; 2 M x 150 bp.  16 slots first while they hand on <= 1/4; beyond that 32 slots — 16 registers per component, the price of two
+  // 16-slot steps — unless they too hand on > 5 %: then the 32-lane segments start, whose lanes are diagonals and not pairs)
+  if (forced < 0) b->laneh_pick = (handed[0] * 4u <= np) ? 1 : (lane32_ok && handed[2] * 20u <= np) ? 3 : 2;
   // (X-drop keeps whole wavefronts: what outgrows the 32 diagonals are the expensive pairs, and the stage pays only below ~1/8 handed on —
   // 150 bp at 2 %, xdrop 100: 21 % handed on, 7.0 ms with the stage, 5.9 ms without)
   if (forced_seg < 0 && seg_ok) b->segh_pick = (handed[1] * (b->dcfg.heuristic == WFA_HEUR_XDROP ? 8u : 4u) <= np) ? 1 : 2;
@@ -1996,7 +2007,8 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
     const bool use_laneh = !tiny && !full && !use_fast && wfa::lane_heur_config(b->dcfg, b->ncomp) && wfa::seg_shape(b->dcfg, &lh_x, &lh_oe, &lh_e) >= 0 &&
                            (wfa::seg_shape(b->dcfg, &lh_x, &lh_oe, &lh_e) != WFA_SHAPE_RTC || wfa::rtc_lane_shape_ok(lh_x, lh_oe, lh_e)) &&
                            b->max_len <= WFA_FAST_MAX_LEN && knob(al, K_NO_FAST, 0) == 0 &&
-                           (b->laneh_pick == 1 || (b->laneh_pick == 0 && knob(al, K_LANE_HEUR, 0) != 0));   // (the pilot of batch_build, or WFA_HIP_LANE_HEUR=1)
+                           (b->laneh_pick == 1 || b->laneh_pick == 3 || (b->laneh_pick == 0 && knob(al, K_LANE_HEUR, 0) != 0));   // (the pilot of batch_build, or WFA_HIP_LANE_HEUR=1 / 2)
+    const int laneh_form = (b->laneh_pick == 3 || (b->laneh_pick == 0 && knob(al, K_LANE_HEUR, 0) == 2)) ? 2 : 1;   // (2: 32 diagonals per pair)
     // ... and then (or first, when the lane form's pilot said no) the same form of the 32-lane segments: two pairs per wave, a band twice
     // as wide (WFA_HIP_SEG_HEUR=0: off)
     const bool use_segh = !tiny && !full && !use_fast && wfa::seg_heur_config(b->dcfg, b->ncomp) && b->max_len <= WFA_FAST_MAX_LEN &&
@@ -2537,7 +2549,7 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
       // (slices of the list taken at run time, as the plain score-only form)
       const uint32_t laneh_dyn = (in_count == nullptr && in_n >= 65536u) ? (uint32_t)std::max(0, knob(al, K_LANE_DYN, 192)) : 0u;
       if (laneh_dyn) { fa.dyn_next = b->d_counters + 13; fa.dyn_chunk = laneh_dyn; }
-      if (wfa::launch_lane_args(shape, lh_oe, lh_e, al->cu_count, laneh_dyn ? knob(al, K_LANE_DYN_WAVES, 16) : knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, fa, false, 0, knob(al, K_LANE_MIN_PAIRS, 0), true, lh_x) != 0) {   // (pairs per wave by the size of the batch, as the plain form)
+      if (wfa::launch_lane_args(shape, lh_oe, lh_e, al->cu_count, laneh_dyn ? knob(al, K_LANE_DYN_WAVES, 16) : knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8), b->max_len, stream, fa, false, 0, knob(al, K_LANE_MIN_PAIRS, 0), laneh_form, lh_x) != 0) {   // (pairs per wave by the size of the batch, as the plain form)
         al->err = "lane kernel launch failed"; return WFA_HIP_EDEVICE;
       }
       if (first_stage) b->last_kernel_pairs = in_n;

@@ -120,12 +120,15 @@ struct LaneFull { static constexpr int NREC = 2 * (OE - E) + E * 17 + 1; };
 // same but ties between an opening and an extension go to the extension (R/wavefront_backtrace.c:49-59), and the walk is then bound to
 // the gap component where the linear backtrace would be free to take a mismatch: different op strings.  Instantiated at run time only.
 // LIN = 2: indel — the same without the mismatch candidate (R/wavefront_compute_edit.c:44-100 with the indel metric).
-template <int X, int OE, int E, bool FULL, bool HEUR = false, int LIN = 0>
+// NRP (round 6, HEUR only): packed registers per component — 8 (16 diagonals) or 16: a band of 32 diagonals for pairs whose whole
+// wavefront the 16 slots cannot hold (150 bp at 2 %: 45 % of the pairs pass score 20, where the hull reaches slots 0 / 15; 6 % pass 36).
+template <int X, int OE, int E, bool FULL, bool HEUR = false, int LIN = 0, int NRP = 8>
 __global__ void __launch_bounds__(64) WFA_LANE_OCCUPANCY
 wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg) {
   static_assert(!(FULL && HEUR), "the general form is score only");
+  static_assert(NRP == 8 || (HEUR && NRP == 16), "the wider band exists in the general form only");
   const int refill_min = refill_arg & 0xff;
-  constexpr int W = 16, H = 8, NR = 8;            // band of 16 diagonals = 8 packed registers
+  constexpr int NR = NRP, W = 2 * NR, H = NR;     // band of 16 diagonals = 8 packed registers (NRP = 16: 32 diagonals)
   constexpr int DM = (X > OE) ? X : OE;           // depth of the M ring
   constexpr int NEVER = 0x7fffffff;
   constexpr int NREC = LaneFull<OE, E>::NREC;     // FULL: steps a pair can take here (bounds the walk)
@@ -202,6 +205,20 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
   uint32_t myslot = 0;
   uint2* const wave_codes = FULL ? a.codes + (unsigned long long)blockIdx.x * (unsigned long long)a.codes_cap * 64ull : nullptr;
   bool codes_full = false;
+  // (round 6) what the wave hands on is collected in LDS and leaves 64 or more at a time: ONE atomic on the list's counter per flush.  An
+  // atomic per hand-over event serialises on that one address — the 16-diagonal general form hands on 11 % of 150 bp pairs at 1 %
+  // divergence and took 1.55 ms per 2 M pairs where the 32-diagonal form took 1.06 ms
+  __shared__ uint32_t rejq[128];
+  int nrej = 0;
+  auto rej_flush = [&]() {
+    if (nrej == 0) return;
+    uint32_t slot = 0;
+    if (lane == 0) slot = atomicAdd(a.fb_count, (uint32_t)nrej);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    if (lane < nrej) a.fb_list[slot + lane] = rejq[lane];
+    if (lane + 64 < nrej) a.fb_list[slot + 64 + lane] = rejq[64 + lane];
+    nrej = 0;
+  };
 
   while (true) {
     WFA_LANE_MARK("looptop_begin");   // (analysis builds: what precedes the first of these is the prologue)
@@ -310,6 +327,7 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
       }
       WFA_LANE_MARK("refill_end");
     } else if (idle == ~0ull && exhausted) {
+      rej_flush();
       break;                                 // nothing left
     }
 
@@ -464,14 +482,13 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
           a.status[mypid] = WFA_STATUS_MAX_STEPS_REACHED;
         }
         if (brej) {
-          uint32_t slot = 0;
-          if (lane == 0) slot = atomicAdd(a.fb_count, (uint32_t)__builtin_popcountll(brej));
-          slot = __builtin_amdgcn_readfirstlane(slot);
           if (__builtin_amdgcn_inverse_ballot_w64(brej)) {
-            a.fb_list[slot + __builtin_amdgcn_mbcnt_hi((uint32_t)(brej >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)brej, 0u))] = mypid;
+            rejq[nrej + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(brej >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)brej, 0u))] = mypid;
             a.status[mypid] = WFA_INTERNAL_FALLBACK;
             if (FULL) a.end_state[myslot] = make_int4(0, 0, 0, 0);
           }
+          nrej += __builtin_popcountll(brej);
+          if (nrej >= 64) rej_flush();
         }
         if (__builtin_amdgcn_inverse_ballot_w64(bd)) {
           // an idle lane computes nothing that lives: every new cell is clamped away
@@ -481,7 +498,7 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
         }
         idle |= bd;
         WFA_LANE_MARK("bd_end");
-        if (idle == ~0ull && next_i >= end && exhausted) break;
+        if (idle == ~0ull && next_i >= end && exhausted) { rej_flush(); break; }   // (a flush behind the loop costs 40 registers)
       }
     }
 
@@ -531,7 +548,7 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
           const bool cut = consider && (new_lo != lo || new_hi != hi);
           if (__any(cut)) {
             // the dropped slots read NULL in M, I and D from now on
-            const uint32_t keep = cut ? (((2u << new_hi) - 1u) & ~((1u << new_lo) - 1u)) : 0xffffu;
+            const uint32_t keep = cut ? (((2u << new_hi) - 1u) & ~((1u << new_lo) - 1u)) : 0xffffffffu;
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
               const uint32_t ka = (uint32_t)__builtin_amdgcn_sbfe((int)keep, 2 * r, 1) & 0xffffu;        // 0xffff if slot 2 r stays
@@ -620,15 +637,16 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
 #ifndef __HIPCC_RTC__   // ---- host side (launch code) ----
 // per-shape entry points (csrc/k_lane.hip compiled once per shape index of WFA_SEG_SHAPES)
 #define WFA_LANE_DECL(i, x, oe, e) \
-  int launch_lane_s##i(unsigned grid, size_t smem, hipStream_t stream, const FastArgs& a, int slot_words, int refill_min, bool full, bool heur);
+  int launch_lane_s##i(unsigned grid, size_t smem, hipStream_t stream, const FastArgs& a, int slot_words, int refill_min, bool full, int heur);
 // (the shape list is wfa_seg.hpp's; declared here without including it)
 WFA_LANE_DECL(0, 2, 4, 1) WFA_LANE_DECL(1, 2, 3, 1) WFA_LANE_DECL(2, 4, 7, 1) WFA_LANE_DECL(3, 3, 5, 1)
 WFA_LANE_DECL(4, 6, 8, 3) WFA_LANE_DECL(5, 5, 3, 3) WFA_LANE_DECL(6, 1, 2, 1)
 #undef WFA_LANE_DECL
 
 template <int X, int OE, int E>
-inline int launch_lane_shape(unsigned grid, size_t smem, hipStream_t stream, const FastArgs& a, int slot_words, int refill_min, bool full, bool heur) {
-  if (heur) hipLaunchKernelGGL((wfa_lane_kernel<X, OE, E, false, true>), dim3(grid), dim3(64), smem, stream, a, slot_words, refill_min);
+inline int launch_lane_shape(unsigned grid, size_t smem, hipStream_t stream, const FastArgs& a, int slot_words, int refill_min, bool full, int heur) {
+  if (heur == 2) hipLaunchKernelGGL((wfa_lane_kernel<X, OE, E, false, true, 0, 16>), dim3(grid), dim3(64), smem, stream, a, slot_words, refill_min);
+  else if (heur) hipLaunchKernelGGL((wfa_lane_kernel<X, OE, E, false, true>), dim3(grid), dim3(64), smem, stream, a, slot_words, refill_min);
   else if (full) hipLaunchKernelGGL((wfa_lane_kernel<X, OE, E, true>), dim3(grid), dim3(64), smem, stream, a, slot_words, refill_min);
   else hipLaunchKernelGGL((wfa_lane_kernel<X, OE, E, false>), dim3(grid), dim3(64), smem, stream, a, slot_words, refill_min);
   return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -670,7 +688,7 @@ inline void lane_full_geometry(uint32_t nwork, int cu_count, int per_cu, int min
 
 // full = the FULL form: a.hist = run-record slots (a.hist_stride ints each, slot = work item - a.work_begin), a.end_state per slot
 // (shape_idx WFA_SHAPE_RTC: no instantiation in the library — the kernel of (X, OE, E) is compiled at run time, csrc/wfa_rtc.cpp)
-inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full, int lds_pad_kb = 0, int min_pairs = 0, bool heur = false, int X = 0);
+inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full, int lds_pad_kb = 0, int min_pairs = 0, int heur = 0, int X = 0);   // heur: 0 no, 1 the general form (16 diagonals), 2 its 32-diagonal form
 
 inline int launch_lane(int shape_idx, int g, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, const uint32_t* words,
                        const WfaPairMeta* meta, const uint32_t* worklist, const uint32_t* nwork_dev, uint32_t nwork,
@@ -683,14 +701,14 @@ inline int launch_lane(int shape_idx, int g, int cu_count, int per_cu, int refil
   a.g = g;
   a.hist = debug_counters; a.hist_stride = 0; a.end_state = nullptr; a.work_begin = 0;
   a.ef = a.pbf = a.pef = a.tbf = a.tef = 0; a.heur = 0; a.min_wf_len = a.max_dist_thr = a.steps_between = 0; a.max_steps = INT_MAX;
-  return launch_lane_args(shape_idx, OE, E, cu_count, per_cu, refill_min, max_len, stream, a, false, lds_pad_kb, min_pairs, false, X);
+  return launch_lane_args(shape_idx, OE, E, cu_count, per_cu, refill_min, max_len, stream, a, false, lds_pad_kb, min_pairs, 0, X);
 }
 
-inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full, int lds_pad_kb, int min_pairs, bool heur, int X) {
+inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_cu, int refill_min, int max_len, hipStream_t stream, FastArgs a, bool full, int lds_pad_kb, int min_pairs, int heur, int X) {
   const uint32_t nwork = a.nwork;
   const uint32_t* nwork_dev = a.nwork_dev;
   const int slot_words = lane_slot_words(std::min(max_len, WFA_FAST_MAX_LEN));
-  const size_t smem = ((size_t)64 * slot_words + 8) * sizeof(uint32_t) + (size_t)lds_pad_kb * 1024;   // (lds_pad_kb: occupancy experiments)
+  const size_t smem = ((size_t)64 * slot_words + 8) * sizeof(uint32_t) + (size_t)lds_pad_kb * 1024;   // (lds_pad_kb: occupancy experiments)   // (lds_pad_kb: occupancy experiments)
   // every wave should see several hundred pairs (64 lanes x a few refills), and there should be several waves per SIMD
   long long grid = (long long)cu_count * per_cu;
   // a wave should see a few refills' worth of pairs (256) — when the batch is large enough to give every SIMD four such waves.  A smaller
@@ -714,7 +732,7 @@ inline int launch_lane_args(int shape_idx, int OE, int E, int cu_count, int per_
     case WFA_SHAPE_RTC: {
       struct { FastArgs a; int slot_words; int refill_min; } args = {a, slot_words, refill_min};   // (the kernel's argument list)
       const std::string name = "wfa::wfa_lane_kernel<" + std::to_string(X) + ", " + std::to_string(OE) + ", " + std::to_string(E) + ", " +
-                               rtc_bool(full && !heur) + ", " + rtc_bool(heur) + (a.lin ? ", " + std::to_string(a.lin) + ">" : std::string(">"));
+                               rtc_bool(full && !heur) + ", " + rtc_bool(heur != 0) + (heur == 2 ? std::string(", 0, 16>") : a.lin ? ", " + std::to_string(a.lin) + ">" : std::string(">"));
       return rtc_launch("wfa_lane.hpp", name, (unsigned)grid, 64, smem, stream, &args, sizeof(args));
     }
     default: return -1;

@@ -170,12 +170,13 @@ LANE_GENERAL = [dict(span="end-to-end", heuristic="adaptive"), dict(span="ends-f
                 dict(span="ends-free", text_begin_free=5, pattern_end_free=5, mismatch=3, gap_opening=3, gap_extension=1, heuristic="adaptive", min_wavefront_length=3)]
 
 
+@pytest.mark.parametrize("slots", [16, 32])
 @pytest.mark.parametrize("cfg_idx", range(len(LANE_GENERAL)))
-def test_lane_kernel_general_form(gpu, corpora, cfg_idx, monkeypatch):
+def test_lane_kernel_general_form(gpu, corpora, cfg_idx, slots, monkeypatch):
     """The general score-only form of the lane kernel (wfa_lane_kernel<.., HEUR>, round 3: wf-adaptive, free ends and the step limit
-    under the no-clipping rule) forced on (WFA_HIP_LANE_HEUR=1: small batches skip its pilot), over every corpus: what it keeps and
-    what it hands on to the banded stages must equal the oracle."""
-    monkeypatch.setenv("WFA_HIP_LANE_HEUR", "1")
+    under the no-clipping rule) forced on (WFA_HIP_LANE_HEUR=1: small batches skip its pilot; 2: its 32-diagonal form of round 6), over
+    every corpus: what it keeps and what it hands on to the banded stages must equal the oracle."""
+    monkeypatch.setenv("WFA_HIP_LANE_HEUR", "1" if slots == 16 else "2")
     for name in ("150bp_2pct", "150bp_15pct", "special"):
         batch = corpora[name]
         kw = common.clamp_free(dict(LANE_GENERAL[cfg_idx], scope="score"), batch)
@@ -185,7 +186,7 @@ def test_lane_kernel_general_form(gpu, corpora, cfg_idx, monkeypatch):
         common.assert_same(o, score, status, None, batch, f"lane general form {name} {kw}")
 
 
-@pytest.mark.parametrize("lane_first", [0, 1])
+@pytest.mark.parametrize("lane_first", [0, 1, 2])
 @pytest.mark.parametrize("cfg_idx", [i for i, c in enumerate(LANE_GENERAL) if "max_steps" not in c])
 def test_segmented_kernel_general_form(gpu, corpora, cfg_idx, lane_first, monkeypatch):
     """The same form of the 32-lane segments (wfa_seg_kernel<.., 32, .., HEUR>: two pairs per wave, a band of 32 diagonals) forced on
@@ -232,10 +233,11 @@ def test_segmented_kernel_general_form_xdrop_pilot(gpu, error):
     common.assert_same(o, score, status, None, batch, f"segment general form, X-drop, pilot {error}")
 
 
-@pytest.mark.parametrize("error", [0.005, 0.03])
+@pytest.mark.parametrize("error", [0.005, 0.02, 0.03])
 def test_lane_kernel_general_form_pilot(gpu, error):
-    """Batches of >= 64 k pairs let a pilot decide whether the general form goes first (few pairs outgrow its 16 slots at 0.5 %
-    divergence, about half at 3 %); either way the results are the oracle's."""
+    """Batches of >= 64 k pairs let a pilot decide which general form goes first (few pairs outgrow the lane kernel's 16 slots at 0.5 %
+    divergence; at 2 % two fifths do and 2 % its 32 slots: the 32-slot form; at 3 % a tenth outgrow those too: the 32-lane segments);
+    whichever, the results are the oracle's."""
     batch = datagen.generate(70000, 150, error, 4455)
     oc, nc = common.configs_pair(span="end-to-end", scope="score", heuristic="adaptive")
     o = loader.run(loader.reference() if loader.have_reference() else loader.oracle(), oc, batch, want_cigar=False)

@@ -19,7 +19,7 @@ import json, os, re, subprocess, sys, collections
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 CSRC = os.path.join(ROOT, "pywfa_amd", "csrc")
 ASM = "/tmp/k_lane_marks.s"
-KERNEL = "_ZN3wfa15wfa_lane_kernelILi2ELi4ELi1ELb0ELb0ELi0EEEvNS_8FastArgsEii"   # (round 6: the LIN parameter)
+KERNEL = "_ZN3wfa15wfa_lane_kernelILi2ELi4ELi1ELb0ELb0ELi0ELi8EEEvNS_8FastArgsEii"   # (round 6: the LIN and NRP parameters)
 FULL_RATE = ("v_add_u32", "v_add_co_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_and_or_b32", "v_or3_b32", "v_not_b32")
 
 
