@@ -119,6 +119,7 @@ struct FastArgs {
   uint32_t* dyn_next;
   uint32_t dyn_chunk;
   int lin;                // 1: the one-component form of the FULL kernels (wfa_lane.hpp: LIN) — host side: selects the run-time instantiation
+  int scope;              // heur = 2: max_score_scope (R/wavefront_components.c:81-124): more null steps than this end the alignment "unreachable"
 };
 
 // neighbour diagonals inside a segment of W lanes (wfa_seg.hpp): lanes at a segment border receive NULL

@@ -1486,7 +1486,7 @@ static int pilot_lane_heur(wfa_hip_aligner* al, wfa_hip_batch* b, hipStream_t st
   fa.ef = (b->dcfg.endsfree && (b->dcfg.pbf | b->dcfg.pef | b->dcfg.tbf | b->dcfg.tef)) ? 1 : 0;
   fa.pbf = b->dcfg.pbf; fa.pef = b->dcfg.pef; fa.tbf = b->dcfg.tbf; fa.tef = b->dcfg.tef;
   fa.heur = b->dcfg.heuristic; fa.min_wf_len = b->dcfg.min_wf_len; fa.max_dist_thr = b->dcfg.max_dist_thr;
-  fa.steps_between = b->dcfg.steps_between; fa.max_steps = b->dcfg.max_steps; fa.xdrop = b->dcfg.xdrop;
+  fa.steps_between = b->dcfg.steps_between; fa.max_steps = b->dcfg.max_steps; fa.xdrop = b->dcfg.xdrop; fa.scope = b->dcfg.scope;
   if (forced < 0 &&
       wfa::launch_lane_args(wfa::seg_shape(b->dcfg, &X, &OE, &E), OE, E, al->cu_count, knob(al, K_LANE_WAVES_PER_CU, 48), knob(al, K_LANE_REFILL_MIN, 8),
                             b->max_len, stream, fa, false, 0, 256, 1, X) != 0) return pilot_launch_failed(al, b, rtc_failures);
@@ -2565,7 +2565,7 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
       fa.ef = (b->dcfg.endsfree && (b->dcfg.pbf | b->dcfg.pef | b->dcfg.tbf | b->dcfg.tef)) ? 1 : 0;
       fa.pbf = b->dcfg.pbf; fa.pef = b->dcfg.pef; fa.tbf = b->dcfg.tbf; fa.tef = b->dcfg.tef;
       fa.heur = b->dcfg.heuristic; fa.min_wf_len = b->dcfg.min_wf_len; fa.max_dist_thr = b->dcfg.max_dist_thr;
-      fa.steps_between = b->dcfg.steps_between; fa.max_steps = b->dcfg.max_steps; fa.xdrop = b->dcfg.xdrop;
+      fa.steps_between = b->dcfg.steps_between; fa.max_steps = b->dcfg.max_steps; fa.xdrop = b->dcfg.xdrop; fa.scope = b->dcfg.scope;
       if (wfa::launch_seg_heur(b->dcfg, al->cu_count, knob(al, K_FAST_WAVES_PER_CU, 256), stream, fa) != 0) {
         al->err = "segmented kernel launch failed"; return WFA_HIP_EDEVICE;
       }

@@ -53,6 +53,7 @@
 namespace wfa {
 
 typedef short lane_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short lane_u2 __attribute__((ext_vector_type(2)));
 
 #define WFA_LANE_NULL16 (-16384)
 #define WFA_LANE_NULL2 0xC000C000u
@@ -505,15 +506,19 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
     // =================== wf-adaptive cut-off (R/wavefront_heuristic.c:257-293, dispatcher :509-567) ===================
     if constexpr (HEUR) {
       if (a.heur == 1) {
-        // live slots of M as a 16-bit mask per pair (bit j: slot j holds an offset)
+        // live slots of M as a bit mask per pair (bit j: slot j holds an offset).  Two instructions per register: the sign bits as 0 / 1
+        // halves (v_pk_lshrrev_b16), then a dot product with the two bit weights of the register accumulates them (v_dot2_u32_u16; eight
+        // registers = 16 bits per accumulator)
         auto mask16 = [&](const uint32_t (&x)[NR]) -> uint32_t {   // bit 2 r + q = sign bit of half q of x[r] is CLEAR
-          uint32_t m = 0;
+          uint32_t lo16 = 0, hi16 = 0;
 #pragma unroll
           for (int r = 0; r < NR; ++r) {
-            const uint32_t nx = ~x[r];
-            m |= (((nx >> 15) & 1u) | ((nx >> 30) & 2u)) << (2 * r);
+            const lane_u2 t = __builtin_bit_cast(lane_u2, x[r]) >> (unsigned short)15;
+            const uint32_t w = (1u << (2 * (r & 7))) | (1u << (2 * (r & 7) + 17));
+            if (r < 8) lo16 = __builtin_amdgcn_udot2(t, __builtin_bit_cast(lane_u2, w), lo16, false);
+            else hi16 = __builtin_amdgcn_udot2(t, __builtin_bit_cast(lane_u2, w), hi16, false);
           }
-          return m;
+          return ~(lo16 | (hi16 << 16)) & (NR == 16 ? 0xffffffffu : 0xffffu);
         };
         const uint32_t live = mask16(cur);
         if (live != 0u) --steps_wait;   // (the cut-off is looked at only when the wavefront exists)
@@ -547,13 +552,14 @@ wfa_lane_kernel(const FastArgs a, const int slot_words_seq, const int refill_arg
           if (consider) steps_wait = a.steps_between;
           const bool cut = consider && (new_lo != lo || new_hi != hi);
           if (__any(cut)) {
-            // the dropped slots read NULL in M, I and D from now on
-            const uint32_t keep = cut ? (((2u << new_hi) - 1u) & ~((1u << new_lo) - 1u)) : 0xffffffffu;
+            // the dropped slots read NULL in M, I and D from now on (slots below new_lo or above new_hi: the signs of slot - new_lo and
+            // new_hi - slot on packed halves; a pair without a cut keeps all)
+            const uint32_t lo2 = (uint32_t)(cut ? new_lo : 0) * 0x00010001u, hi2 = (uint32_t)(cut ? new_hi : W - 1) * 0x00010001u;
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-              const uint32_t ka = (uint32_t)__builtin_amdgcn_sbfe((int)keep, 2 * r, 1) & 0xffffu;        // 0xffff if slot 2 r stays
-              const uint32_t kb = (uint32_t)__builtin_amdgcn_sbfe((int)keep, 2 * r + 1, 1) << 16;       // 0xffff0000 if slot 2 r + 1 stays
-              const uint32_t km = ka | kb;
+              const uint32_t idx2 = (uint32_t)(2 * r) | ((uint32_t)(2 * r + 1) << 16);
+              const uint32_t out = pk_sub(idx2, lo2) | pk_sub(hi2, idx2);
+              const uint32_t km = ~__builtin_bit_cast(uint32_t, __builtin_bit_cast(lane_s2, out) >> (short)15);   // 0xffff per slot that stays
               cur[r] = (cur[r] & km) | (WFA_LANE_NULL2 & ~km);
               Ih[0][r] = (Ih[0][r] & km) | (WFA_LANE_NULL2 & ~km);
               Dh[0][r] = (Dh[0][r] & km) | (WFA_LANE_NULL2 & ~km);

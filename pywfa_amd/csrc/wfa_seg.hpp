@@ -32,6 +32,7 @@
 #pragma once
 #include "wfa_rtc_compat.hpp"
 #include "wfa_common.hpp"
+#include "wfa_hip.h"
 #ifndef __HIPCC_RTC__
 #include <string>
 #include "wfa_rtc.hpp"
@@ -197,6 +198,11 @@ wfa_seg_kernel(const FastArgs a) {
   // distance of an empty wavefront, steps until the cut-off is looked at again, "a cell of an outermost lane is alive"
   int hdl = 0, hjt = 0, hdinit = 0, steps_wait = 0;
   int max_sw = 0; bool have_max_sw = false;   // X-drop: the largest cell score seen at a cut-off so far (segment-uniform)
+  // X-drop (round 6): an alignment whose every cell was dropped ends "unreachable" once more than `scope` scores in a row had no input
+  // (R/wavefront_unialign.c:262-265, R/wavefront_extend.c:97-104; wfa_band.hpp has the same count): last score with a non-null input,
+  // and the score at which the count ran out (NEVER: it has not).  Before, such a pair sat in its segment until the cap on its steps
+  // (4 (plen + tlen) + 64) and was then aligned again by the banded stage: 3 % of 150 bp pairs at 2 % under X-drop(100)
+  int last_nonnull = 0, unreach_t = NEVER;
   bool edge = false;
   uint32_t want = (1u << NS) - 1u;  // segments waiting for a pair
   uint32_t busy = 0;                // segments aligning
@@ -266,6 +272,7 @@ wfa_seg_kernel(const FastArgs a) {
               if (!bad && a.ef && k >= -pbf_ && k <= tbf_) cur = max(k, 0);
               if (a.ef) target = bad ? NEVER : min(max(tl, pl + k - a.pef), max(pl + k, tl - a.tef));
               hdl = max(tl, pl + k); hjt = akk - (c - H); hdinit = max(pl, tl); steps_wait = a.steps_between; edge = false; have_max_sw = false;
+              last_nonnull = 0; unreach_t = NEVER;
             }
 #pragma unroll
             for (int d = 0; d < DM; ++d) Mh[d] = WFA_OFFSET_NULL;
@@ -338,10 +345,16 @@ wfa_seg_kernel(const FastArgs a) {
     }
     // ---------------- termination / hand-over ----------------
     {
-      const bool rej = gstep > deadline || (HEUR && edge);  // segment-uniform
+      const bool unr = HEUR && unreach_t != NEVER;          // segment-uniform: the null-step count ran out (no cell is alive)
+      const bool rej = (gstep > deadline || (HEUR && edge)) && !unr;  // segment-uniform
       const bool fin = (LAZY ? Mh[0] : cur) >= target;  // possible on the lane of the end diagonal only (HEUR, free ends: on any lane)
       unsigned long long bfin = __ballot(fin);
       const unsigned long long brej = __ballot(rej);
+      unsigned long long bunr = 0ull;
+      if constexpr (HEUR) {
+        bunr = __ballot(unr && l == 0);
+        if (unr && l == 0) { a.score[spair] = -unreach_t; a.status[spair] = WFA_STATUS_PARTIAL; }   // (R/wavefront_unialign.c:147-237: no end cell, the score of the last step)
+      }
       if (HEUR) {
         // one lane per segment reports (the score does not depend on which cell ended the alignment)
         unsigned long long one = 0ull;
@@ -349,9 +362,9 @@ wfa_seg_kernel(const FastArgs a) {
         for (int s = 0; s < NS; ++s) { const unsigned long long f = bfin & (FIELD << (s * W)); one |= f & (0ull - f); }
         bfin = one;
       }
-      const unsigned long long bd = bfin | brej;
+      const unsigned long long bd = bfin | brej | bunr;
       if (bd) {
-        const unsigned long long ba = bfin & ~brej;
+        const unsigned long long ba = bfin & ~brej & ~bunr;
         const bool acc = __builtin_amdgcn_inverse_ballot_w64(ba);
         if (ba) {
           const uint32_t na = (uint32_t)__builtin_popcountll(ba);
@@ -380,7 +393,7 @@ wfa_seg_kernel(const FastArgs a) {
             want |= 1u << s; busy &= ~(1u << s);
             if (LAZY) { mcur &= ~(FIELD << (s * W)); mold &= ~(FIELD << (s * W)); }
           }
-        if (((bd >> (seg * W)) & FIELD) != 0ull) { target = NEVER; deadline = NEVER; lim = WFA_OFFSET_NULL; cur = WFA_OFFSET_NULL; edge = false; }
+        if (((bd >> (seg * W)) & FIELD) != 0ull) { target = NEVER; deadline = NEVER; lim = WFA_OFFSET_NULL; cur = WFA_OFFSET_NULL; edge = false; unreach_t = NEVER; }
         if (!busy && next_i >= end) break;
       }
     }
@@ -441,6 +454,18 @@ wfa_seg_kernel(const FastArgs a) {
     {
       // I(k) = max(M_oe, I_e)(k-1) + 1 and D(k) = max(M_oe, D_e)(k+1): the max commutes with the lane shift
       const int mx = (LIN == 2) ? WFA_OFFSET_NULL : Mh[X - 1], mo = Mh[OE - 1], ie = LIN ? WFA_OFFSET_NULL : Ih[E - 1], de = LIN ? WFA_OFFSET_NULL : Dh[E - 1];
+      if constexpr (HEUR) {
+        if (a.heur == 2) {
+          // the null-step count of the score being made: null = no input of my segment's wavefront holds an offset
+          const bool nn = ((__ballot((mx & mo & ie & de) >= 0) >> (seg * W)) & FIELD) != 0ull;
+          const int snew = __mul24(gstep + 1 - s0, a.g);
+          if (deadline != NEVER && unreach_t == NEVER) {
+            const int t_un = last_nonnull + a.scope + 1;   // (the scores between two multiples of g are null steps too)
+            if (t_un < snew || (t_un == snew && !nn)) unreach_t = t_un;
+            if (nn) last_nonnull = snew;
+          }
+        }
+      }
       int ni, nd;
       if (FULL) {
         // the choices the backtrace would make (R/wavefront_backtrace.c:49-59: mismatch > deletion > insertion, extension > opening on
