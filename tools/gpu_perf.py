@@ -70,6 +70,11 @@ if "C4x" in which: run("C4 10kb affine2p endsfree EXACT full", 1024, 10000, 0.08
 if "C3xf" in which: run("10kb affine EXACT full", 1024, 10000, 0.08, 1003, dict(span="end-to-end", scope="full"), cpu_n=16, reps=1)
 if "C5" in which: run("C5 100kb xdrop", 2000, 100000, 0.08, 1005, dict(span="end-to-end", scope="full", heuristic="X-drop", xdrop=20), cpu_n=100)
 if "X150" in which: run("150bp X-drop(100) score", 2000000, 150, 0.02, 1002, dict(span="end-to-end", scope="score", heuristic="X-drop", xdrop=100), cpu_n=100000)
+if "X150l" in which: run("150bp X-drop(100) score, 0.5 %", 2000000, 150, 0.005, 1002, dict(span="end-to-end", scope="score", heuristic="X-drop", xdrop=100), cpu_n=100000)
+if "X20" in which: run("150bp X-drop(20) score", 2000000, 150, 0.02, 1002, dict(span="end-to-end", scope="score", heuristic="X-drop", xdrop=20), cpu_n=100000)
+if "X20l" in which: run("150bp X-drop(20) score, 0.5 %", 2000000, 150, 0.005, 1002, dict(span="end-to-end", scope="score", heuristic="X-drop", xdrop=20), cpu_n=100000)
+if "A150m" in which: run("150bp adaptive score, 1 %", 2000000, 150, 0.01, 1002, dict(span="end-to-end", scope="score", heuristic="adaptive"), cpu_n=100000)
+if "S150" in which: run("150bp step limit 30, score", 2000000, 150, 0.02, 1002, dict(span="end-to-end", scope="score", max_steps=30), cpu_n=100000)
 if "A150l" in which: run("150bp adaptive score, 0.5 %", 2000000, 150, 0.005, 1002, dict(span="end-to-end", scope="score", heuristic="adaptive"), cpu_n=100000)
 if "A150" in which: run("150bp adaptive score", 2000000, 150, 0.02, 1002, dict(span="end-to-end", scope="score", heuristic="adaptive"), cpu_n=100000)
 if "N150" in which: run("150bp no heuristic score", 2000000, 150, 0.02, 1002, dict(span="end-to-end", scope="score"), cpu_n=100000)
