@@ -176,6 +176,8 @@ def test_lane_kernel_general_form(gpu, corpora, cfg_idx, slots, monkeypatch):
     """The general score-only form of the lane kernel (wfa_lane_kernel<.., HEUR>, round 3: wf-adaptive, free ends and the step limit
     under the no-clipping rule) forced on (WFA_HIP_LANE_HEUR=1: small batches skip its pilot; 2: its 32-diagonal form of round 6), over
     every corpus: what it keeps and what it hands on to the banded stages must equal the oracle."""
+    if slots == 32 and cfg_idx % 2 == 1 and cfg_idx != 4 and os.environ.get("WFA_TEST_FULL") != "1":
+        pytest.skip("sampled on the suite's time budget (WFA_TEST_FULL=1 runs every cell)")   # (4: free begins of 20 diagonals fit the 32 slots only)
     monkeypatch.setenv("WFA_HIP_LANE_HEUR", "1" if slots == 16 else "2")
     for name in ("150bp_2pct", "150bp_15pct", "special"):
         batch = corpora[name]
@@ -191,6 +193,8 @@ def test_lane_kernel_general_form(gpu, corpora, cfg_idx, slots, monkeypatch):
 def test_segmented_kernel_general_form(gpu, corpora, cfg_idx, lane_first, monkeypatch):
     """The same form of the 32-lane segments (wfa_seg_kernel<.., 32, .., HEUR>: two pairs per wave, a band of 32 diagonals) forced on
     (WFA_HIP_SEG_HEUR=1), alone and behind the lane form: what it keeps and what it hands on must equal the oracle."""
+    if lane_first == 2 and cfg_idx % 2 == 0 and os.environ.get("WFA_TEST_FULL") != "1":
+        pytest.skip("sampled on the suite's time budget (WFA_TEST_FULL=1 runs every cell)")
     monkeypatch.setenv("WFA_HIP_SEG_HEUR", "1")
     monkeypatch.setenv("WFA_HIP_LANE_HEUR", str(lane_first))
     for name in ("150bp_2pct", "150bp_15pct", "special"):
@@ -222,12 +226,14 @@ def test_segmented_kernel_general_form_xdrop(gpu, corpora, cfg_idx, monkeypatch)
         common.assert_same(o, score, status, None, batch, f"segment general form, X-drop {name} {kw}")
 
 
+@pytest.mark.parametrize("xdrop", [100, 20])
 @pytest.mark.parametrize("error", [0.005, 0.02])
-def test_segmented_kernel_general_form_xdrop_pilot(gpu, error):
+def test_segmented_kernel_general_form_xdrop_pilot(gpu, error, xdrop):
     """A batch large enough for the pilot (>= 64 k pairs): X-drop(100) takes the segmented form at 0.5 % divergence (few pairs outgrow
-    its 32 diagonals) and the banded kernel alone at 2 % (a fifth would be handed on); either way the results are the real library's."""
+    its 32 diagonals) and the banded kernel alone at 2 % (a fifth would be handed on); X-drop(20) drops every cell of many alignments,
+    which then end "unreachable" inside the segmented form (round 6); either way the results are the real library's."""
     batch = datagen.generate(70000, 150, error, 4456)
-    oc, nc = common.configs_pair(span="end-to-end", scope="score", heuristic="X-drop", xdrop=100)
+    oc, nc = common.configs_pair(span="end-to-end", scope="score", heuristic="X-drop", xdrop=xdrop)
     o = loader.run(loader.reference() if loader.have_reference() else loader.oracle(), oc, batch, want_cigar=False)
     score, status, _ = common.gpu_run(nc, batch, False, resident=True)
     common.assert_same(o, score, status, None, batch, f"segment general form, X-drop, pilot {error}")
