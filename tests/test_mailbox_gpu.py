@@ -134,6 +134,8 @@ print("calls done", flush=True)
 def test_a_process_may_exit_with_an_instance_on_the_device(gpu, how):
     """The instance leaves by itself after its idle time; neither a normal interpreter exit (aligner never closed), nor os._exit, nor an
     exception hangs the process or the device: the child ends within seconds and the next child finds the device usable."""
+    if how in ("a.close(); sys.exit(0)", "raise SystemExit(3)") and os.environ.get("WFA_TEST_FULL") != "1":
+        pytest.skip("sampled on the suite's time budget: a child process each (WFA_TEST_FULL=1 runs the four)")
     env = dict(os.environ, WFA_HIP_MAILBOX_IDLE_US="200000")     # (an instance that would idle for 0.2 s: it is still there when the process ends)
     t0 = time.time()
     out = subprocess.run([sys.executable, "-c", EXIT_SCRIPT.format(root=ROOT, how=how)], capture_output=True, text=True, timeout=120, env=env)

@@ -193,7 +193,7 @@ def test_lane_kernel_general_form(gpu, corpora, cfg_idx, slots, monkeypatch):
 def test_segmented_kernel_general_form(gpu, corpora, cfg_idx, lane_first, monkeypatch):
     """The same form of the 32-lane segments (wfa_seg_kernel<.., 32, .., HEUR>: two pairs per wave, a band of 32 diagonals) forced on
     (WFA_HIP_SEG_HEUR=1), alone and behind the lane form: what it keeps and what it hands on must equal the oracle."""
-    if lane_first == 2 and cfg_idx % 2 == 0 and os.environ.get("WFA_TEST_FULL") != "1":
+    if lane_first == 2 and (cfg_idx % 2 == 0 or cfg_idx == 9) and os.environ.get("WFA_TEST_FULL") != "1":   # (9: a run-time shape: seconds of compiling)
         pytest.skip("sampled on the suite's time budget (WFA_TEST_FULL=1 runs every cell)")
     monkeypatch.setenv("WFA_HIP_SEG_HEUR", "1")
     monkeypatch.setenv("WFA_HIP_LANE_HEUR", str(lane_first))

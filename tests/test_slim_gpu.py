@@ -67,6 +67,7 @@ def test_slim_kernel_matches_oracle_and_band_kernel(gpu, cfg_idx, scope, monkeyp
     two = CONFIGS[cfg_idx].get("distance") == "affine2p"   # (the oracle's 2p runs are what this test takes: fewer 10 kb pairs)
     batches = [ragged(31 + cfg_idx, 96, 1100, 4000, 0.08, indel_bias=6), datagen.generate(16 if two else 48, 10000, 0.08, 4100 + cfg_idx),
                ragged(77 + cfg_idx, 64, 1200, 9000, 0.03), datagen.generate(200, 1500, 0.15, 4200 + cfg_idx)]
+    whole = __import__("os").environ.get("WFA_TEST_FULL") == "1"
     for bi, batch in enumerate(batches):
         kw = common.clamp_free(dict(CONFIGS[cfg_idx], scope=scope), batch)
         oc, nc = common.configs_pair(**kw)
@@ -75,6 +76,7 @@ def test_slim_kernel_matches_oracle_and_band_kernel(gpu, cfg_idx, scope, monkeyp
         monkeypatch.delenv("WFA_HIP_BAND_SLIM", raising=False)
         score, status, cigars = common.gpu_run(nc, batch, full, resident=(bi % 2 == 0))
         common.assert_same(o, score, status, cigars, batch, f"slim {kw} batch {bi}")
+        if not whole and (bi + cfg_idx) % 2 == 1: continue   # (the suite's time budget: the banded kernel beside it on every other batch)
         monkeypatch.setenv("WFA_HIP_BAND_SLIM", "0")
         score0, status0, cigars0 = common.gpu_run(nc, batch, full, resident=(bi % 2 == 0))
         assert np.array_equal(score, score0) and np.array_equal(status, status0) and cigars == cigars0

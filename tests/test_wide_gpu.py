@@ -60,7 +60,7 @@ def test_wide_kernel_matches_oracle(gpu, idx, tile, monkeypatch):
     if os.environ.get("WFA_TEST_FULL") != "1" and (idx // 2 + int(tile)) % 2 == 1:
         pytest.skip("sampled on the suite's time budget (WFA_TEST_FULL=1 runs every cell)")
     monkeypatch.setenv("WFA_HIP_TILE", tile)
-    batch = ragged_batch(180, 2500, 0.10, 9100 + idx)
+    batch = ragged_batch(180 if os.environ.get("WFA_TEST_FULL") == "1" else 110, 2500, 0.10, 9100 + idx)   # (the oracle's exact 2.5 kb runs are this test's time)
     kw = common.clamp_free(dict(CASES[idx]), batch)
     oc, nc = common.configs_pair(**kw)
     full = oc.scope == 1
@@ -84,7 +84,7 @@ def test_tile_kernel_geometries(gpu, idx, geo, monkeypatch):
         pytest.skip("sampled on the suite's time budget (WFA_TEST_FULL=1 runs every cell)")
     for k_, v_ in TILE_GEOMETRIES[geo].items():
         monkeypatch.setenv(k_, v_)
-    batch = ragged_batch(150, 2200, 0.10, 9600 + idx)
+    batch = ragged_batch(150 if os.environ.get("WFA_TEST_FULL") == "1" else 90, 2200, 0.10, 9600 + idx)   # (the oracle's exact 2 kb runs are this test's time)
     kw = common.clamp_free(dict(CASES[idx]), batch)
     oc, nc = common.configs_pair(**kw)
     full = oc.scope == 1
