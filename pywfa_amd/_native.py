@@ -229,6 +229,7 @@ class Aligner:
     def __init__(self, cfg, device=0):
         L = lib()
         self._pair_caller = None
+        self._pair_align = None
         self._h = L.wfa_hip_create(ctypes.byref(cfg), device)
         if not self._h:
             msg = L.wfa_hip_global_error().decode()
@@ -258,6 +259,8 @@ class Aligner:
                 rb.close()
             lib().wfa_hip_destroy(self._h)
             self._h = None
+            self._pair_caller = None
+            self._pair_align = None
 
     def __del__(self):
         try:
@@ -319,12 +322,16 @@ class Aligner:
         """wfa_hip_align_pair: one pair of ASCII ``bytes`` per call, without NumPy arrays on the way (pywfa's loop of
         ``wavefront_align(text)``).  Returns score, status, op bytes (or None).  Through the compiled host
         (pywfa_amd/host/_host.pyx: no ctypes marshalling) when it is built, through ctypes otherwise."""
-        host = compiled_host()
-        if host is not None:
-            pc = self._pair_caller
-            if pc is None:
-                pc = self._pair_caller = host.PairCaller(self._h)
-            rc, score, status, ops = pc.align(pattern, text, want_cigar)
+        pa = self._pair_align   # (the compiled host's bound method, looked up once per aligner: this is pywfa's one-pair-per-call loop)
+        if pa is None:
+            if not self._h:
+                raise NativeError("wfa_hip_align_pair: the aligner is closed")
+            host = compiled_host()
+            if host is not None:
+                self._pair_caller = host.PairCaller(self._h)
+                pa = self._pair_align = self._pair_caller.align
+        if pa is not None:
+            rc, score, status, ops = pa(pattern, text, want_cigar)
             if rc != OK:
                 self._raise(rc, "wfa_hip_align_pair")
             return score, status, ops

@@ -24,6 +24,9 @@ import numpy as np
 from . import _native
 from . import datagen
 
+_NO_OPS = np.zeros(0, np.uint8)   # (the op string of a call without a backtrace: one read-only array for every such call)
+_NO_OPS.flags.writeable = False
+
 __all__ = ["WavefrontAligner", "AlignmentResult", "BatchResults", "clip_cigartuples", "cigartuples_to_str",
            "elide_mismatches_from_cigar"]
 
@@ -387,7 +390,7 @@ class WavefrontAligner:
         # last single-pair result (the reference keeps it inside the C aligner object)
         self._status = -1
         self._score = -2147483648
-        self._ops = np.zeros(0, np.uint8)
+        self._ops = _NO_OPS
 
     # ------------------------------------------------------------------ helpers
     def _set_pattern(self, pattern):
@@ -420,7 +423,7 @@ class WavefrontAligner:
         score, status, ops = self._native.align_pair(self._bpattern, t, full)
         self._score = score
         self._status = status
-        self._ops = np.frombuffer(ops, np.uint8) if ops else np.zeros(0, np.uint8)
+        self._ops = np.frombuffer(ops, np.uint8) if ops else _NO_OPS
         self.alignment_score = self._score
         return self._score
 
