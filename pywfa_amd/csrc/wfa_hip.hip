@@ -2013,7 +2013,10 @@ static int batch_run_once(wfa_hip_batch_t* b, void* stream_) {
     // as wide (WFA_HIP_SEG_HEUR=0: off)
     const bool use_segh = !tiny && !full && !use_fast && wfa::seg_heur_config(b->dcfg, b->ncomp) && b->max_len <= WFA_FAST_MAX_LEN &&
                           knob(al, K_NO_FAST, 0) == 0 && !wfa::seg_supported(b->dcfg, b->ncomp, false) &&
-                          (b->segh_pick == 1 || (b->segh_pick == 0 && knob(al, K_SEG_HEUR, 0) != 0));   // (the pilot of batch_build, or WFA_HIP_SEG_HEUR=1)
+                          (b->segh_pick == 1 || (b->segh_pick == 0 && knob(al, K_SEG_HEUR, 0) != 0)) &&   // (the pilot of batch_build, or WFA_HIP_SEG_HEUR=1)
+                          // (behind the 32-slot lane form the segments would see the same 32 diagonals again: what it hands on — 2 % of 150 bp
+                          // pairs at 2 % — goes straight to the banded stages, 2.22 -> 2.02 ms per 2 M pairs; WFA_HIP_SEG_HEUR=1 keeps the stage)
+                          !(use_laneh && laneh_form == 2 && knob(al, K_SEG_HEUR, -1) < 0);
     if (!lin && !tiny && wfa::band_supported(b->dcfg, b->ncomp) && (b->ncomp != 5 || b->max_len < 32000) && knob(al, K_NO_BAND, 0) == 0) {
       if (b->ncomp == 5) {
         // gap-affine-2p wavefronts are wide (C4: 99 % need more than 108 diagonals, 2.6 % more than 172)
